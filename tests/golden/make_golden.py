@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+Usage (build container only; /root/reference does not exist on the GPU box):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+What runs from the reference (imported from /root/reference, never copied):
+  * CollocationRoots / Collocation with ``D_MATRIX_METHOD = "numerical"`` (mpopt.py:3706-4276):
+    roots, D (order 1 and 2, at nodes and at arbitrary taus), quadrature weights (incl.
+    sub-intervals), interpolation matrices and the four composite builders;
+  * ``OCP`` + ``mpopt.create_nlp()`` + ``initialize_solution()`` (mpopt.py:574-708) on the
+    problems of tests/problems.py.  CasADi is absent from the image, so the module
+    ``tests/golden/casadi_shim.py`` (sympy-backed) stands in for it: the reference's
+    transcription code builds f, g, x, p as sympy expressions, which this script evaluates and
+    differentiates (Jacobian of g, gradient of f, Hessian of sigma*f + lam^T g) with sympy.
+
+The output files hold DATA only (inputs and expected outputs).
+"""
+import os
+import sys
+import time
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import numpy as np
+import sympy as sp
+
+import casadi_shim
+
+sys.modules["casadi"] = casadi_shim
+sys.path.insert(0, "/root/reference")
+import mpopt.mpopt as ref  # noqa: E402  (the reference, unmodified)
+
+import problems  # noqa: E402
+
+ref.mpopt._MUTE_ = True
+SCHEMES = ["LGR", "LGL", "CGL"]
+DEGREES = [1, 2, 3, 4, 5, 6, 8, 10, 15, 20, 30]
+
+
+def full(m):
+    return np.array(m.full() if hasattr(m, "full") else m, dtype=float)
+
+
+def make_tables():
+    out = {}
+    ref.Collocation.D_MATRIX_METHOD = "numerical"
+    for tmin, tmax in [(-1, 1), (0, 1)]:
+        ref.CollocationRoots._TAU_MIN, ref.CollocationRoots._TAU_MAX = tmin, tmax
+        tag = f"t{tmin}_{tmax}".replace("-", "m")
+        for scheme in SCHEMES + ["LG"]:
+            for deg in DEGREES:
+                key = f"{tag}/{scheme}/{deg}"
+                if scheme == "LG":
+                    # p nodes instead of p+1: roots only; deg=1 raises in the reference
+                    if deg >= 2:
+                        out[key + "/roots"] = np.asarray(ref.CollocationRoots("LG")._taus_fn(deg), dtype=float)
+                    continue
+                col = ref.Collocation([deg], scheme)
+                roots = np.asarray(col.roots[deg], dtype=float)
+                out[key + "/roots"] = roots
+                out[key + "/D1"] = full(col.get_diff_matrix(deg))
+                out[key + "/D2"] = full(col.get_diff_matrix(deg, order=2))
+                out[key + "/w"] = full(col.get_quadrature_weights(deg)).ravel()
+                if deg <= 10:
+                    mids = (roots[:-1] + roots[1:]) / 2.0
+                    out[key + "/mids"] = mids
+                    out[key + "/C_mid"] = full(col.get_interpolation_matrix(mids, deg))
+                    out[key + "/D1_mid"] = full(col.get_diff_matrix(deg, taus=mids))
+                    out[key + "/D2_mid"] = full(col.get_diff_matrix(deg, taus=mids, order=2))
+                    ends = np.array([col.tau0, col.tau1], dtype=float)
+                    out[key + "/D1_ends"] = full(col.get_diff_matrix(deg, taus=ends))
+                    a, b = roots[0], roots[min(2, deg)]
+                    out[key + "/w_sub_ab"] = np.array([a, b])
+                    out[key + "/w_sub"] = full(col.get_quadrature_weights(deg, tau0=a, tau1=b)).ravel()
+        # composite builders
+        for scheme in SCHEMES:
+            for name, orders in [("20x3", [3] * 20), ("4x5", [5] * 4), ("3_10_3", [3, 10, 3]), ("2_4_3", [2, 4, 3])]:
+                col = ref.Collocation(orders, scheme)
+                key = f"{tag}/{scheme}/comp_{name}"
+                out[key + "/orders"] = np.array(orders)
+                out[key + "/compD"] = full(col.get_composite_differentiation_matrix())
+                out[key + "/compW"] = full(col.get_composite_quadrature_weights()).ravel()
+                taus_mid = [list((col._taus_fn(d)[:-1] + col._taus_fn(d)[1:]) / 2.0) for d in orders]
+                out[key + "/compI_mid"] = full(col.get_composite_interpolation_matrix(taus_mid, orders))
+                taus_end = [np.array([col.tau0, col.tau1]) for _ in orders]
+                out[key + "/compDat_ends"] = full(col.get_composite_interpolation_Dmatrix_at(taus_end, orders, order=1))
+    # the symbolic back-end through the shim (sympy AD, exact quadrature) for the 1e-5 cross-check
+    ref.CollocationRoots._TAU_MIN, ref.CollocationRoots._TAU_MAX = -1, 1
+    ref.Collocation.D_MATRIX_METHOD = "symbolic"
+    for scheme in SCHEMES:
+        for deg in [3, 5]:
+            col = ref.Collocation([deg], scheme)
+            out[f"symbolic/{scheme}/{deg}/compD"] = full(col.get_composite_differentiation_matrix())
+            out[f"symbolic/{scheme}/{deg}/compW"] = full(col.get_composite_quadrature_weights()).ravel()
+    ref.Collocation.D_MATRIX_METHOD = "numerical"
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), **out)
+    print(f"tables.npz: {len(out)} arrays")
+
+
+def flat_syms(m):
+    return list(m.a.reshape(-1, order="F"))
+
+
+def make_case(name, builder, n_segments, poly_orders, scheme):
+    t0 = time.time()
+    ref.CollocationRoots._TAU_MIN, ref.CollocationRoots._TAU_MAX = -1, 1
+    ref.Collocation.D_MATRIX_METHOD = "numerical"
+    ocp = builder(ref, casadi_shim)
+    mpo = ref.mpopt(ocp, n_segments, poly_orders, scheme)
+    nlp, bounds = mpo.create_nlp()
+    zs, ps = flat_syms(nlp["x"]), flat_syms(nlp["p"])
+    g_exprs = [sp.sympify(e) for e in flat_syms(nlp["g"])]
+    f_expr = sp.sympify(nlp["f"].scalar())
+    n_z, n_p, n_g = len(zs), len(ps), len(g_exprs)
+    z0 = np.asarray(mpo.initialize_solution(), dtype=float)
+    lbx, ubx = np.asarray(bounds["lbx"], float), np.asarray(bounds["ubx"], float)
+    lbg, ubg = np.asarray(bounds["lbg"], float), np.asarray(bounds["ubg"], float)
+    assert len(z0) == n_z == len(lbx) and n_g == len(lbg)
+
+    z, lam, sigma, rng = problems.sample_point(name, n_z, n_p, n_g, z0, lbx, ubx)
+    p = problems.sample_widths(rng, n_segments, ocp.n_phases)
+    p_equal = np.asarray(mpo.get_segment_width_parameters(None), dtype=float)
+    zpos = {s: i for i, s in enumerate(zs)}
+    args = zs + ps
+
+    def ev(exprs, zz, pp):
+        fn = sp.lambdify(args, exprs, "math", cse=True)
+        return np.array(fn(*list(zz), *list(pp)), dtype=float)
+
+    out = dict(z0=z0, lbx=lbx, ubx=ubx, lbg=lbg, ubg=ubg, z=z, p=p, p_equal=p_equal, lam=lam,
+               sigma=np.array(sigma), n_segments=np.array(n_segments),
+               poly_orders=np.array(mpo.poly_orders), n_phases=np.array(ocp.n_phases))
+    # f, g at the sample point with non-uniform widths and at Z0 with equal widths
+    out["g"] = ev(g_exprs, z, p)
+    out["f"] = ev([f_expr], z, p)[0]
+    out["g_z0_equal"] = ev(g_exprs, z0, p_equal)
+    out["f_z0_equal"] = ev([f_expr], z0, p_equal)[0]
+    # Jacobian of g (structural triplets)
+    jr, jc, je = [], [], []
+    for i, e in enumerate(g_exprs):
+        for s in sorted(e.free_symbols & set(zs), key=lambda q: zpos[q]):
+            d = sp.diff(e, s)
+            if d != 0:
+                jr.append(i), jc.append(zpos[s]), je.append(d)
+    out["jac_row"], out["jac_col"] = np.array(jr), np.array(jc)
+    out["jac_val"] = ev(je, z, p)
+    # gradient of f
+    gsyms = sorted(f_expr.free_symbols & set(zs), key=lambda q: zpos[q])
+    gexp = [sp.diff(f_expr, s) for s in gsyms]
+    grad = np.zeros(n_z)
+    grad[[zpos[s] for s in gsyms]] = ev(gexp, z, p)
+    out["grad_f"] = grad
+    # Hessian of sigma*f + lam^T g, upper triangle (CasADi's nlp_hess_l convention)
+    lag = sigma * f_expr + sum(float(l) * e for l, e in zip(lam, g_exprs))
+    hr, hc, he = [], [], []
+    lsyms = sorted(lag.free_symbols & set(zs), key=lambda q: zpos[q])
+    for s in lsyms:
+        d1 = sp.diff(lag, s)
+        for s2 in sorted(d1.free_symbols & set(zs), key=lambda q: zpos[q]):
+            if zpos[s2] < zpos[s]:
+                continue
+            d2 = sp.diff(d1, s2)
+            if d2 != 0:
+                hr.append(zpos[s]), hc.append(zpos[s2]), he.append(d2)
+        # constant second derivative w.r.t. itself (d1 linear in s) is caught above because
+        # s stays in d1.free_symbols only if non-linear; handle the purely quadratic case:
+        if s not in d1.free_symbols:
+            d2 = sp.diff(d1, s)
+            if d2 != 0:
+                hr.append(zpos[s]), hc.append(zpos[s]), he.append(d2)
+    out["hess_row"], out["hess_col"] = np.array(hr, dtype=np.int64), np.array(hc, dtype=np.int64)
+    out["hess_val"] = ev(he, z, p) if he else np.zeros(0)
+    np.savez_compressed(os.path.join(HERE, f"nlp_{name}.npz"), **out)
+    print(f"nlp_{name}.npz: n_z={n_z} n_g={n_g} nnz_j={len(jr)} nnz_h={len(hr)}  ({time.time()-t0:.1f}s)")
+
+
+def main():
+    only = sys.argv[1:]
+    if not only or "tables" in only:
+        make_tables()
+    for name, (builder, s, po, scheme) in problems.GOLDEN_CASES.items():
+        if only and name not in only:
+            continue
+        make_case(name, builder, s, po, scheme)
+
+
+if __name__ == "__main__":
+    main()

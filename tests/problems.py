@@ -1,0 +1,228 @@
+"""OCP input definitions shared by the golden-vector generator, the oracle tests and the
+GPU parity tests.
+
+Every builder takes the *module that provides ``OCP``* (``mp``) and a math namespace ``fn``
+(``sqrt/exp/sin/cos/log``), so the very same problem statement can be handed to
+
+* the reference (``/root/reference/mpopt/mpopt.py``, imported by ``tests/golden/make_golden.py``),
+* the product (``mpopt_amd``), and
+* the oracle (``oracle/``).
+
+The problem statements restate the reference's own inputs:
+moon lander  examples/singlephase/moon_lander.py:30-63 (tests/test_mpopt.py:114-144),
+Van der Pol  tests/test_mpopt.py:206-227, with parameter + path row examples/singlephase/dae_vdp.py:28-60,
+hypersensitive  examples/singlephase/hyper_sensitive.py:31-41,
+two-phase Schwartz  tests/test_mpopt.py:165-202 (examples/Multi-phase/tpschwartz.py:30-69),
+generic 2-phase fixture  tests/test_mpopt.py:89-110.
+``kitchen_sink`` is synthetic: it exercises every feature flag of the transcription at once.
+"""
+import numpy as np
+
+
+def moon_lander(mp, fn=None):
+    ocp = mp.OCP(n_states=2, n_controls=1)
+    ocp.dynamics[0] = lambda x, u, t: [x[1], u[0] - 1.5]
+    ocp.running_costs[0] = lambda x, u, t: u[0]
+    ocp.terminal_constraints[0] = lambda xf, tf, x0, t0: [xf[0], xf[1]]
+    ocp.tf0[0] = 4.0
+    ocp.x00[0] = [10.0, -2.0]
+    ocp.lbx[0] = [0.0, -20.0]
+    ocp.ubx[0] = [20.0, 20.0]
+    ocp.lbu[0] = 0
+    ocp.ubu[0] = 3
+    ocp.lbtf[0], ocp.ubtf[0] = 3, 5
+    ocp.validate()
+    return ocp
+
+
+def van_der_pol(mp, fn=None):
+    ocp = mp.OCP(n_states=2, n_controls=1)
+    ocp.dynamics[0] = lambda x, u, t: [(1 - x[1] * x[1]) * x[0] - x[1] + u[0], x[0]]
+    ocp.running_costs[0] = lambda x, u, t: x[0] * x[0] + x[1] * x[1] + u[0] * u[0]
+    ocp.x00[0] = [0, 1]
+    ocp.lbu[0] = -1.0
+    ocp.ubu[0] = 1.0
+    ocp.lbx[0][1] = -0.25
+    ocp.lbtf[0] = 10.0
+    ocp.ubtf[0] = 10.0
+    ocp.validate()
+    return ocp
+
+
+def dae_vdp(mp, fn=None):
+    ocp = mp.OCP(n_states=2, n_controls=1, n_params=1)
+    ocp.dynamics[0] = lambda x, u, t, a: [(1 - x[1] * x[1]) * x[0] - x[1] + u[0], x[0]]
+    ocp.running_costs[0] = lambda x, u, t, a: x[0] * x[0] + x[1] * x[1] + u[0] * u[0]
+    ocp.path_constraints[0] = lambda x, u, t, a: [a[0] - x[1]]
+    ocp.x00[0] = [0, 1]
+    ocp.lbu[0] = -1.0
+    ocp.ubu[0] = 1.0
+    ocp.lba[0] = 0.25
+    ocp.uba[0] = 0.5
+    ocp.lbx[0][1] = -0.25
+    ocp.lbtf[0] = 10.0
+    ocp.ubtf[0] = 10.0
+    ocp.validate()
+    return ocp
+
+
+def hyper_sensitive(mp, fn=None):
+    ocp = mp.OCP(n_states=1, n_controls=1, n_phases=1)
+    ocp.dynamics[0] = lambda x, u, t: [-x[0] * x[0] * x[0] + u[0]]
+    ocp.running_costs[0] = lambda x, u, t: 0.5 * (x[0] * x[0] + u[0] * u[0])
+    ocp.terminal_constraints[0] = lambda xf, tf, x0, t0: [xf[0] - 1.0]
+    ocp.x00[0] = 1
+    ocp.lbtf[0] = ocp.ubtf[0] = 1000.0
+    ocp.scale_t = 1 / 1000.0
+    ocp.validate()
+    return ocp
+
+
+def two_phase_schwartz(mp, fn=None):
+    ocp = mp.OCP(n_states=2, n_controls=1, n_phases=2)
+
+    def dynamics0(x, u, t):
+        return [x[1], u[0] - 0.1 * (1.0 + 2.0 * x[0] * x[0]) * x[1]]
+
+    ocp.dynamics = [dynamics0, dynamics0]
+
+    def path_constraints0(x, u, t):
+        return [1.0 - 9.0 * (x[0] - 1) * (x[0] - 1) - (x[1] - 0.4) * (x[1] - 0.4) / (0.3 * 0.3)]
+
+    ocp.path_constraints[0] = path_constraints0
+    ocp.terminal_costs[1] = lambda xf, tf, x0, t0: 5 * (xf[0] * xf[0] + xf[1] * xf[1])
+    ocp.x00[0] = [1, 1]
+    ocp.x00[1] = [1, 1]
+    ocp.xf0[0] = [1, 1]
+    ocp.xf0[1] = [0, 0]
+    ocp.lbx[0][1] = -0.8
+    ocp.lbu[0], ocp.ubu[0] = -1, 1
+    ocp.lbt0[0], ocp.ubt0[0] = 0, 0
+    ocp.lbtf[0], ocp.ubtf[0] = 1, 1
+    ocp.lbtf[1], ocp.ubtf[1] = 2.9, 2.9
+    ocp.validate()
+    return ocp
+
+
+def generic_two_phase(mp, fn=None):
+    """tests/test_mpopt.py:89-110 plus the optional row blocks switched on."""
+    ocp = mp.OCP(n_states=2, n_controls=2, n_phases=2)
+    dynamics = lambda x, u, t: [u[0], u[0]]
+    path_constraints = lambda x, u, t: [x[0] + 1, u[0]]
+    running_costs = lambda x, u, t: u[0]
+    terminal_constraints = lambda xf, tf, x0, t0: [-xf[0]]
+    terminal_costs = lambda xf, tf, x0, t0: tf
+    ocp.dynamics = [dynamics] * ocp.n_phases
+    ocp.path_constraints = [path_constraints] * ocp.n_phases
+    ocp.running_costs = [running_costs] * ocp.n_phases
+    ocp.terminal_constraints = [terminal_constraints] * ocp.n_phases
+    ocp.terminal_costs = [terminal_costs] * ocp.n_phases
+    for phase in range(ocp.n_phases):
+        ocp.lbu[phase], ocp.ubu[phase] = -1.0, 1.0
+        ocp.lbtf[phase], ocp.ubtf[phase] = 1.0, 1.0
+    ocp.diff_u[0] = 1
+    ocp.du_continuity[1] = 1
+    ocp.validate()
+    return ocp
+
+
+def kitchen_sink(mp, fn):
+    """Synthetic: 3 states, 2 controls, 2 parameters, 2 phases, explicit time dependence,
+    transcendental functions, non-unit scaling and every optional constraint block."""
+    ocp = mp.OCP(n_states=3, n_controls=2, n_phases=2, n_params=2)
+
+    def dyn0(x, u, t, a):
+        return [
+            x[1] * fn.cos(x[2]) + a[0] * u[0],
+            -x[0] * x[1] + u[1] * fn.exp(-0.1 * t) + a[1],
+            u[0] * x[2] / (1.0 + x[0] * x[0]) - 0.3 * t,
+        ]
+
+    def dyn1(x, u, t, a):
+        return [
+            x[1] + 0.5 * t * u[0],
+            fn.sin(x[0]) * u[1] - a[0] * x[1] * x[1],
+            fn.sqrt(1.0 + x[2] * x[2]) * a[1] - u[0] * u[1],
+        ]
+
+    ocp.dynamics = [dyn0, dyn1]
+    ocp.path_constraints[0] = lambda x, u, t, a: [x[0] * x[0] + u[0] * u[0] - 4.0 - a[0], x[1] * t - 3.0]
+    ocp.path_constraints[1] = lambda x, u, t, a: [u[1] * x[2] - 2.0 - 0.2 * t * a[1]]
+    ocp.running_costs[0] = lambda x, u, t, a: u[0] * u[0] + 0.5 * u[1] * u[1] + 0.1 * x[0] * t + a[0] * a[0]
+    ocp.running_costs[1] = lambda x, u, t, a: fn.exp(0.1 * x[1]) + u[0] * u[0] * (1.0 + a[1] * a[1])
+    ocp.terminal_costs[0] = lambda xf, tf, x0, t0, a: 0.3 * xf[0] * x0[1] + 0.2 * tf * a[0]
+    ocp.terminal_costs[1] = lambda xf, tf, x0, t0, a: xf[2] * xf[2] + (tf - t0) * (tf - t0) * 0.05 + a[1] * xf[0]
+    ocp.terminal_constraints[0] = lambda xf, tf, x0, t0, a: [xf[1] * tf - x0[0] * a[1]]
+    ocp.terminal_constraints[1] = lambda xf, tf, x0, t0, a: [xf[0] - 1.0 + 0.1 * t0, xf[1] * xf[2] - a[0]]
+    ocp.scale_x = np.array([0.5, 2.0, 1.25])
+    ocp.scale_u = np.array([4.0, 0.25])
+    ocp.scale_a = np.array([2.0, 0.5])
+    ocp.scale_t = 0.1
+    ocp.x00[0] = [1.0, -0.5, 0.2]
+    ocp.xf0[0] = [0.5, 0.5, 0.4]
+    ocp.x00[1] = [0.5, 0.5, 0.4]
+    ocp.xf0[1] = [1.0, 0.0, -0.3]
+    ocp.u00[0] = [0.1, -0.2]
+    ocp.uf0[0] = [0.3, 0.2]
+    ocp.u00[1] = [0.3, 0.2]
+    ocp.uf0[1] = [-0.1, 0.1]
+    ocp.a0[0] = [0.3, 0.7]
+    ocp.a0[1] = [0.6, -0.2]
+    ocp.t00[0], ocp.tf0[0] = 0.0, 2.0
+    ocp.t00[1], ocp.tf0[1] = 2.0, 5.0
+    ocp.lbx[0] = [-5.0, -6.0, -7.0]
+    ocp.ubx[0] = [5.0, 6.0, 7.0]
+    ocp.lbu[0] = [-2.0, -3.0]
+    ocp.ubu[0] = [2.0, 3.0]
+    ocp.lbu[1] = [-1.0, -np.inf]
+    ocp.ubu[1] = [np.inf, 1.5]
+    ocp.lba[0] = [-1.0, -1.0]
+    ocp.uba[0] = [1.0, 2.0]
+    ocp.lbtf[0], ocp.ubtf[0] = 1.0, 3.0
+    ocp.lbt0[1], ocp.ubt0[1] = 1.0, 3.0
+    ocp.lbtf[1], ocp.ubtf[1] = 4.0, 6.0
+    ocp.lbe[0] = [-0.1, 0.0, 0.0]
+    ocp.ube[0] = [0.1, 0.0, 0.2]
+    ocp.diff_u[0] = 1
+    ocp.diff_u[1] = 1
+    ocp.lbdu[1], ocp.ubdu[1] = -7, 9
+    ocp.du_continuity[0] = 1
+    ocp.du_continuity[1] = 1
+    ocp.midu[1] = 0
+    ocp.validate()
+    return ocp
+
+
+#: name -> (builder, n_segments, poly_orders, scheme).  These are the parity cases for which
+#: tests/golden/ holds vectors produced by the reference's own transcription code.
+GOLDEN_CASES = {
+    "moon_lander_20x3_LGR": (moon_lander, 20, 3, "LGR"),            # BASELINE.json configs[0]
+    "moon_lander_mixed_LGL": (moon_lander, 3, [2, 4, 3], "LGL"),
+    "van_der_pol_4x3_CGL": (van_der_pol, 4, 3, "CGL"),
+    "dae_vdp_mixed_CGL": (dae_vdp, 3, [3, 6, 3], "CGL"),
+    "hyper_sensitive_5x3_LGR": (hyper_sensitive, 5, 3, "LGR"),
+    "schwartz_4x3_LGL": (two_phase_schwartz, 4, 3, "LGL"),
+    "generic_two_phase_LGR": (generic_two_phase, 2, [2, 3], "LGR"),
+    "kitchen_sink_mixed_CGL": (kitchen_sink, 3, [2, 4, 3], "CGL"),
+    "kitchen_sink_1x5_LGR": (kitchen_sink, 1, [5], "LGR"),
+}
+
+
+def sample_point(name, n_z, n_p, n_g, z0, lbx, ubx):
+    """Deterministic evaluation point: Z0 + seeded perturbation clipped
+    to the bounds, non-uniform positive widths summing to one per phase, N(0,1) multipliers."""
+    seed = 20260928 + sum(ord(c) for c in name)
+    rng = np.random.default_rng(seed)
+    xi = rng.uniform(-1, 1, n_z)
+    xi2 = rng.uniform(-1, 1, n_z)
+    z = z0 + 0.05 * np.abs(z0) * xi + 0.01 * xi2
+    z = np.minimum(np.maximum(z, lbx), ubx)
+    lam = rng.standard_normal(n_g)
+    sigma = 0.75
+    return z, lam, sigma, rng
+
+
+def sample_widths(rng, n_segments, n_phases):
+    w = rng.uniform(0.5, 1.5, (n_phases, n_segments))
+    w = w / w.sum(axis=1, keepdims=True)
+    return w.reshape(-1)
