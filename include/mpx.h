@@ -1,0 +1,190 @@
+/* mpx.h -- C ABI of libmpx: MI355X-native pseudo-spectral collocation assembly.
+ *
+ * This is the drop-in boundary for ONE path of mpopt (reference: /root/reference/mpopt/mpopt.py):
+ * the NLP oracle functions that `ca.nlpsol("solver","ipopt",{"f","x","g","p"},opts)` derives
+ * from mpopt's transcription and that IPOPT calls every iteration
+ *   nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l      (mpopt.py:757, called at mpopt.py:804)
+ * plus the collocation tables they are built from
+ *   CollocationRoots (mpopt.py:4134-4276), Collocation (mpopt.py:3706-4131).
+ * The reference has no FFI seam of its own (it is pure Python over CasADi); the entry points
+ * below are what a ctypes binding replacing `ca.nlpsol`'s oracle evaluation binds to
+ * (see INTEGRATION.md for the reference-side stub).
+ *
+ * Conventions: plain C, caller owns every buffer, no pointer is retained after a call returns
+ * (device buffers belong to the context).  Every function returns 0 on success or a negative
+ * MPX_ERR_* code; the message is available from mpx_last_error().  Nothing throws or aborts
+ * across the ABI.  A context is used by one thread at a time.  All floating data is FP64, all
+ * index data is int32 (patterns) / int64 (sizes, strides).
+ *
+ * Layouts (identical to the reference):
+ *   z   per phase [vec(X) ; vec(U) ; t0 ; tf ; A], vec = column major (state-major):
+ *       z[a*N+i] = X[i,a]; phases concatenated                       (mpopt.py:537-543, 627)
+ *   p   segment widths, phase-major: p[ph*S + s]                      (mpopt.py:152, 631)
+ *   g   per phase [F ; C ; DU ; mU ; dU ; TC], then the three event blocks
+ *                                                                     (mpopt.py:458, 617-621)
+ *   jac_g   COO triplets in a fixed library-defined order (mpx_pattern_jac), structural
+ *           non-zeros only, values array matches that order; mpx_ccs_perm() gives the
+ *           permutation to CasADi's compressed-column order
+ *   hess_l  upper triangle (row <= col) of  sigma*f + lam_g^T g  in COO, like CasADi's
+ *           "triu:hess:gamma:x:x"
+ */
+#ifndef MPX_H
+#define MPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPX_VERSION 1
+
+/* error codes */
+#define MPX_OK 0
+#define MPX_ERR_INVALID (-1)     /* bad argument / malformed structure */
+#define MPX_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define MPX_ERR_NO_DEVICE (-3)   /* context was created without device code (structure only) */
+#define MPX_ERR_UNSUPPORTED (-4)
+#define MPX_ERR_ALLOC (-5)
+
+/* collocation schemes (mpopt.py:4166-4188) */
+#define MPX_SCHEME_LGR 0 /* {-1} U roots(P^(1,0)_{p-1}) U {+1}   mpopt.py:4208-4231 */
+#define MPX_SCHEME_LGL 1 /* {-1} U roots(P^(1,1)_{p-1}) U {+1}   mpopt.py:4234-4259 */
+#define MPX_SCHEME_CGL 2 /* cos(pi j/p) reversed                  mpopt.py:4262-4276 */
+#define MPX_SCHEME_LG 3  /* {-1} U leggauss(p-1): p nodes only; tables only, no NLP */
+#define MPX_SCHEME_EQUI 4 /* unknown scheme string -> linspace    mpopt.py:4182-4188 */
+
+/* what_mask bits for mpx_eval */
+#define MPX_F 1      /* nlp_f      */
+#define MPX_G 2      /* nlp_g      */
+#define MPX_GRAD 4   /* nlp_grad_f */
+#define MPX_JAC 8    /* nlp_jac_g  */
+#define MPX_HESS 16  /* nlp_hess_l */
+
+/* structure kinds (packed description produced by the host-side tracer) */
+#define MPX_COL_X 0
+#define MPX_COL_U 1
+#define MPX_COL_T0 2
+#define MPX_COL_TF 3
+#define MPX_COL_A 4
+#define MPX_ROW_F 0
+#define MPX_ROW_C 1
+#define MPX_TV_XF 0
+#define MPX_TV_TF 1
+#define MPX_TV_X0 2
+#define MPX_TV_T0 3
+#define MPX_TV_A 4
+
+/* ---------------------------------------------------------------------------------------------
+ * Collocation tables (host, no GPU needed).  Replace CollocationRoots._taus_fn and
+ * Collocation.get_diff_matrix / get_quadrature_weights / get_interpolation_matrix
+ * (mpopt.py:3815-3905, 4158-4276) with the D_MATRIX_METHOD="numerical" semantics.
+ * ------------------------------------------------------------------------------------------- */
+
+/* number of nodes of `scheme` at degree `deg` (deg+1, except LG: deg; deg==0: 1) */
+int mpx_colloc_n_nodes(int scheme, int deg);
+/* roots[n_nodes], ascending, mapped affinely to [tau_min, tau_max] (mpopt.py:4224) */
+int mpx_colloc_roots(int scheme, int deg, double tau_min, double tau_max, double* roots);
+/* D[i*n_nodes+j] = l_j^(order)(taus[i]) for the Lagrange basis on `nodes` (mpopt.py:3815-3849);
+ * taus==NULL evaluates at the nodes themselves.  order is 1 or 2. */
+int mpx_colloc_diff_matrix(const double* nodes, int n_nodes, const double* taus, int n_taus, int order, double* D);
+/* w[j] = integral_{a}^{b} l_j(tau) dtau (mpopt.py:3851-3882) */
+int mpx_colloc_quad_weights(const double* nodes, int n_nodes, double a, double b, double* w);
+/* C[i*n_nodes+j] = l_j(taus[i]) (mpopt.py:3884-3905) */
+int mpx_colloc_interp_matrix(const double* nodes, int n_nodes, const double* taus, int n_taus, double* C);
+
+/* ---------------------------------------------------------------------------------------------
+ * NLP context
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mpx_ctx mpx_ctx;
+
+typedef struct mpx_problem {
+  int32_t version;          /* MPX_VERSION */
+  int32_t n_phases, nx, nu, na;
+  int32_t n_segments;       /* per phase (all phases share one grid, mpopt.py:70-75) */
+  const int32_t* poly_orders; /* [n_segments] */
+  int32_t scheme;           /* MPX_SCHEME_* */
+  double tau0, tau1;        /* CollocationRoots._TAU_MIN/_TAU_MAX (mpopt.py:4144-4145) */
+  /* phase links (mpopt.py:3442): n_links pairs (i, j) */
+  int32_t n_links;
+  const int32_t* links;
+  /* packed structure, per phase in order:
+   *   nc, n_tc, diff_u, midu_rows, du_continuity,
+   *   NJV, NJV x (row_kind,row_comp,col_kind,col_comp),   variable Jacobian entries of a node
+   *   NHN, NHN x (kind1,comp1,kind2,comp2),               node Hessian entries (upper, node row)
+   *   NHC, NHC x (kind1,comp1,kind2,comp2),               (t0,tf,A) corner entries (reduced)
+   *   NMG, NMG x (tv_kind,comp),                          Mayer gradient entries
+   *   NTJ, NTJ x (tc_row,tv_kind,comp),                   terminal-constraint Jacobian entries
+   *   NTH, NTH x (tv_kind1,comp1,tv_kind2,comp2)          terminal Hessian entries            */
+  const int32_t* structure;
+  int64_t structure_len;
+  /* gfx950 code object holding the problem's kernels (hipcc --genco of the generated source);
+   * NULL creates a structure-only context: sizes/patterns/tables work, mpx_eval fails loudly. */
+  const void* code_object;
+  size_t code_object_size;
+  int32_t device;           /* HIP device ordinal */
+} mpx_problem;
+
+typedef struct mpx_sizes {
+  int64_t n_z, n_p, n_g, nnz_jac, nnz_hess;
+  int64_t n_nodes;          /* N = sum(poly_orders)+1 per phase */
+  int64_t n_tiles;          /* workgroup tiles per evaluation point */
+  /* algorithmic bytes per evaluation point */
+  int64_t bytes_fgj;        /* 8*(2 n_z + n_p + n_g + nnz_jac + 1) */
+  int64_t bytes_hess;       /* 8*(n_z + n_p + n_g + 1 + nnz_hess) */
+} mpx_sizes;
+
+int mpx_create(const mpx_problem* prob, mpx_ctx** out);
+int mpx_destroy(mpx_ctx* ctx);
+const char* mpx_last_error(const mpx_ctx* ctx); /* ctx==NULL: error of the last failed mpx_create */
+int mpx_get_sizes(const mpx_ctx* ctx, mpx_sizes* out);
+
+/* fixed COO patterns, 0-based (rows of g / indices of z) */
+int mpx_pattern_jac(const mpx_ctx* ctx, int32_t* row, int32_t* col);
+int mpx_pattern_hess(const mpx_ctx* ctx, int32_t* row, int32_t* col);
+/* perm[k] = position in the library's value order of the k-th entry in compressed-column order
+ * (sorted by column, then row), colind[n_cols+1]; which = MPX_JAC or MPX_HESS */
+int mpx_ccs_perm(const mpx_ctx* ctx, int which, int64_t* perm, int64_t* colind);
+
+/* composite tables of the context's grid (parity hooks for SURVEY a9-a11):
+ * compW[N] (mpopt.py:4041-4064), node_tau[N] reference-interval position of every node */
+int mpx_get_comp_weights(const mpx_ctx* ctx, double* compW);
+
+/* Use `stream` (a hipStream_t) for all subsequent work of this context; NULL = default stream. */
+int mpx_set_stream(mpx_ctx* ctx, void* stream);
+
+/* Evaluate `batch` points.  Host-pointer variant: copies in, runs, copies out, synchronous.
+ *   z        [batch][n_z]
+ *   p        [n_p] segment widths shared by the batch (p_per_point==0) or [batch][n_p]
+ *   lam_g    [batch][n_g], sigma [batch]   (only for MPX_HESS)
+ *   f [batch], g [batch][n_g], grad_f [batch][n_z], jac_val [batch][nnz_jac],
+ *   hess_val [batch][nnz_hess]; outputs not selected by what_mask may be NULL.            */
+int mpx_eval(mpx_ctx* ctx, int what_mask, int64_t batch, const double* z, const double* p, int p_per_point,
+             const double* lam_g, const double* sigma, double* f, double* g, double* grad_f, double* jac_val,
+             double* hess_val);
+/* Device-pointer variant: same arguments, all pointers are device pointers, asynchronous on the
+ * context's stream, nothing is copied.  This is the throughput path (inputs resident in HBM). */
+int mpx_eval_device(mpx_ctx* ctx, int what_mask, int64_t batch, const double* z, const double* p, int p_per_point,
+                    const double* lam_g, const double* sigma, double* f, double* g, double* grad_f,
+                    double* jac_val, double* hess_val);
+/* Block until the context's stream is idle. */
+int mpx_sync(mpx_ctx* ctx);
+
+/* Segment sharding (multi-GPU): restrict the node kernels of this context to the
+ * tiles [tile_begin, tile_end) and report the contiguous value ranges they own, so that ranks
+ * can all-gather disjoint slices.  Default: all tiles.  The boundary kernel (reductions,
+ * terminal and event rows) runs only when `run_boundary` is non-zero. */
+int mpx_set_tile_range(mpx_ctx* ctx, int64_t tile_begin, int64_t tile_end, int run_boundary);
+int mpx_get_tile_jac_range(const mpx_ctx* ctx, int64_t tile, int64_t* begin, int64_t* end);
+
+/* ---------------------------------------------------------------------------------------------
+ * Timing helper: HIP events on the context's stream (bench.py measures kernel time with these)
+ * ------------------------------------------------------------------------------------------- */
+int mpx_timer_start(mpx_ctx* ctx);
+int mpx_timer_stop(mpx_ctx* ctx, double* elapsed_ms); /* records stop, synchronises, returns ms */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPX_H */

@@ -1,0 +1,185 @@
+"""Build, load and bind libmpx (the C-ABI library of include/mpx.h) and JIT the per-problem kernels.
+
+There is deliberately no fallback: if the shared library is missing it is built with hipcc, and if
+that is impossible every entry point raises.  Nothing in the product path evaluates the NLP on the
+CPU.
+"""
+import ctypes
+import hashlib
+import os
+import shutil
+import subprocess
+import threading
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB_PATH = os.path.join(PKG, "libmpx.so")
+JIT_DIR = os.path.join(PKG, "_jit_cache")
+ARCH = "gfx950"
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+
+MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS = 1, 2, 4, 8, 16
+SCHEMES = {"LGR": 0, "LGL": 1, "CGL": 2, "LG": 3}
+SCHEME_EQUI = 4
+
+
+class MpxError(RuntimeError):
+    pass
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise MpxError("hipcc not found: libmpx and the collocation kernels cannot be built (no CPU fallback exists)")
+
+
+def _sources():
+    return [os.path.join(CSRC, f) for f in ("mpx_host.cpp", "mpx_colloc.cpp", "mpx_device.h")] + [os.path.join(INCLUDE, "mpx.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """hipcc -> mpopt_amd/libmpx.so (host runtime + generic kernels, gfx950)."""
+    if not force and not _stale(LIB_PATH, _sources()):
+        return LIB_PATH
+    cc = hipcc()
+    obj = os.path.join(PKG, "mpx_colloc.o")
+    hobj = os.path.join(PKG, "mpx_host.o")
+    cmds = [
+        ["g++", "-O2", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", os.path.join(CSRC, "mpx_colloc.cpp"), "-o", obj],
+        [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
+         os.path.join(CSRC, "mpx_host.cpp"), "-o", hobj],
+        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, obj, "-o", LIB_PATH + ".tmp"],
+    ]
+    for cmd in cmds:
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose:
+            print(" ".join(cmd), "\n", r.stdout, r.stderr)
+        if r.returncode:
+            raise MpxError("building libmpx failed: " + " ".join(cmd) + "\n" + r.stderr[:6000])
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+class mpx_problem(ctypes.Structure):
+    _fields_ = [
+        ("version", ctypes.c_int32), ("n_phases", ctypes.c_int32), ("nx", ctypes.c_int32), ("nu", ctypes.c_int32),
+        ("na", ctypes.c_int32), ("n_segments", ctypes.c_int32), ("poly_orders", c_int32_p), ("scheme", ctypes.c_int32),
+        ("tau0", ctypes.c_double), ("tau1", ctypes.c_double), ("n_links", ctypes.c_int32), ("links", c_int32_p),
+        ("structure", c_int32_p), ("structure_len", ctypes.c_int64), ("code_object", ctypes.c_void_p),
+        ("code_object_size", ctypes.c_size_t), ("device", ctypes.c_int32),
+    ]
+
+
+class mpx_sizes(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in
+                ("n_z", "n_p", "n_g", "nnz_jac", "nnz_hess", "n_nodes", "n_tiles", "bytes_fgj", "bytes_hess")]
+
+
+_lib = None
+_lock = threading.Lock()
+
+# every symbol include/mpx.h declares
+SYMBOLS = {
+    "mpx_colloc_n_nodes": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "mpx_colloc_roots": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, c_double_p]),
+    "mpx_colloc_diff_matrix": (ctypes.c_int, [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p]),
+    "mpx_colloc_quad_weights": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, c_double_p]),
+    "mpx_colloc_interp_matrix": (ctypes.c_int, [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p]),
+    "mpx_create": (ctypes.c_int, [ctypes.POINTER(mpx_problem), ctypes.POINTER(ctypes.c_void_p)]),
+    "mpx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "mpx_get_sizes": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(mpx_sizes)]),
+    "mpx_pattern_jac": (ctypes.c_int, [ctypes.c_void_p, c_int32_p, c_int32_p]),
+    "mpx_pattern_hess": (ctypes.c_int, [ctypes.c_void_p, c_int32_p, c_int32_p]),
+    "mpx_ccs_perm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_int64_p]),
+    "mpx_get_comp_weights": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+    "mpx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mpx_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7),
+    "mpx_eval_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7),
+    "mpx_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpx_set_tile_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
+    "mpx_get_tile_jac_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p, c_int64_p]),
+    "mpx_timer_start": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpx_timer_stop": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+}
+
+
+def lib():
+    """The loaded library (built on first use)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            try:  # share torch's HIP runtime when torch is around, so device pointers interoperate
+                import torch  # noqa: F401
+            except Exception:  # pragma: no cover
+                pass
+            path = build_library()
+            L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(L, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = L
+    return _lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().mpx_last_error(ctx)
+        raise MpxError(f"libmpx error {rc}: {msg.decode() if msg else ''}")
+
+
+def compile_kernels(source, verbose=False):
+    """hipcc --genco of the generated problem source (+ mpx_kernels.h) -> code object bytes.
+    Cached on disk under mpopt_amd/_jit_cache keyed by the full text of everything compiled."""
+    h = hashlib.sha256()
+    h.update(source.encode())
+    for dep in ("mpx_kernels.h", "mpx_device.h"):
+        with open(os.path.join(CSRC, dep), "rb") as f:
+            h.update(f.read())
+    key = h.hexdigest()[:24]
+    os.makedirs(JIT_DIR, exist_ok=True)
+    co = os.path.join(JIT_DIR, f"mpx_{key}.hsaco")
+    if not os.path.exists(co):
+        src = os.path.join(JIT_DIR, f"mpx_{key}.hip")
+        with open(src, "w") as f:
+            f.write(source)
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "--genco", "-I", CSRC, "-o", co + ".tmp", src]
+        extra = os.environ.get("MPX_HIPCC_FLAGS")
+        if extra:
+            cmd[1:1] = extra.split()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose:
+            print(" ".join(cmd), "\n", r.stdout, r.stderr)
+        if r.returncode:
+            raise MpxError("kernel compilation failed: " + " ".join(cmd) + "\n" + r.stderr[:8000])
+        os.replace(co + ".tmp", co)
+    with open(co, "rb") as f:
+        return f.read(), co
+
+
+def gpu_available():
+    try:
+        import torch
+
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return os.path.exists("/dev/kfd")

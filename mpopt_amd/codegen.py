@@ -1,0 +1,268 @@
+"""Per-problem code generation: OCP callables -> ``__device__`` node/terminal functions.
+
+For every phase the user's ``dynamics / path_constraints / running_costs`` are traced exactly
+as the reference evaluates them at a collocation node (mpopt.py:175-206):
+
+    x = X/scale_x, u = U/scale_u, a = A/scale_a, t0 = t0_var/scale_t, tf = tf_var/scale_t,
+    h = (tf - t0)/(tau1 - tau0) * w_s,  t = t_seg0 + h (tau_k - tau0),
+    f_i = h * scale_x * dyn(x,u,t,a),  c_i = path(x,u,t,a),  q_i = h * L(x,u,t,a)
+
+but in terms of the *NLP variables* (scaled X, U, t0_var, tf_var, A) plus three per-node
+constants (kap = w_s/(tau1-tau0), th = normalised node time, W = composite quadrature weight),
+so that symbolic differentiation yields directly the entries of jac_g / grad_f / hess_l that the
+reference obtains from CasADi's AD inside ``nlpsol`` (mpopt.py:757).  Terminal cost and terminal
+constraints (mpopt.py:277-298) are traced the same way in (xf, tf, x0, t0, a).
+
+Outputs: HIP source text (structs ``mpxgen::Phase<PH>``) and the structural description
+(which derivative entries exist) that the C library turns into the COO patterns.
+"""
+import hashlib
+
+import numpy as np
+
+from .expr import Tracer, Expr
+
+# column kinds of a node row / terminal variable kinds (must match mpx.h)
+COL_X, COL_U, COL_T0, COL_TF, COL_A = 0, 1, 2, 3, 4
+ROW_F, ROW_C = 0, 1
+TV_XF, TV_TF, TV_X0, TV_T0, TV_A = 0, 1, 2, 3, 4
+
+
+def _as_list(v):
+    if v is None:
+        return None
+    if isinstance(v, (list, tuple)):
+        return list(v)
+    if isinstance(v, np.ndarray):
+        return list(v.reshape(-1))
+    return [v]
+
+
+class PhaseProgram:
+    """Traced node + terminal program of one phase."""
+
+    def __init__(self, ocp, phase):
+        self.phase = phase
+        nx, nu, na = ocp.nx, ocp.nu, ocp.na
+        self.nx, self.nu, self.na = nx, nu, na
+        tr = self.tr = Tracer()
+        sx = [float(v) for v in np.asarray(ocp.scale_x, dtype=float).reshape(-1)]
+        su = [float(v) for v in np.asarray(ocp.scale_u, dtype=float).reshape(-1)]
+        sa = [float(v) for v in np.asarray(ocp.scale_a, dtype=float).reshape(-1)]
+        st = float(ocp.scale_t)
+        # ---- node program ------------------------------------------------------------
+        Xs = [tr.var(f"Xs[{a}]") for a in range(nx)]
+        Us = [tr.var(f"Us[{b}]") for b in range(nu)]
+        As = [tr.var(f"As[{c}]") for c in range(na)]
+        t0v, tfv = tr.var("t0v"), tr.var("tfv")
+        kap, th, W = tr.var("kap"), tr.var("th"), tr.var("W")
+        x = [Xs[a] * (1.0 / sx[a]) for a in range(nx)]
+        u = [Us[b] * (1.0 / su[b]) for b in range(nu)]
+        a_ = [As[c] * (1.0 / sa[c]) for c in range(na)]
+        t0, tf = t0v / st, tfv / st
+        dt = tf - t0
+        h = dt * kap
+        t = t0 + dt * th
+        dyn = _as_list(ocp.get_dynamics(phase)(x, u, t, a_))
+        if len(dyn) != nx:
+            raise ValueError(f"phase {phase}: dynamics returned {len(dyn)} values for {nx} states")
+        self.fx = [h * (sx[a] * tr.wrap(dyn[a])) for a in range(nx)]
+        if ocp.has_path_constraints(phase):
+            self.c = [tr.wrap(v) for v in _as_list(ocp.get_path_constraints(phase)(x, u, t, a_))]
+        else:
+            self.c = []
+        self.nc = len(self.c)
+        L = tr.wrap(ocp.get_running_costs(phase)(x, u, t, a_))
+        self.qW = W * (h * L)
+        self.node_vars = ([(COL_X, a, Xs[a]) for a in range(nx)] + [(COL_U, b, Us[b]) for b in range(nu)]
+                          + [(COL_T0, 0, t0v), (COL_TF, 0, tfv)] + [(COL_A, c, As[c]) for c in range(na)])
+        nv = self.node_vars
+        # first derivatives
+        self.dd = []            # d fx[a] / d Xs[a]  (merged with the D-block diagonal)
+        self.jv = []            # (row_kind,row_comp,col_kind,col_comp, expr) structural entries
+        rows = [(ROW_F, a, self.fx[a]) for a in range(nx)] + [(ROW_C, j, self.c[j]) for j in range(self.nc)]
+        dmemo = {id(v[2]): {} for v in nv}
+        for rk, rc, e in rows:
+            for ck, cc, v in nv:
+                d = tr.diff(e, v, dmemo[id(v)])
+                if rk == ROW_F and ck == COL_X and cc == rc:
+                    self.dd.append(d)
+                    continue
+                if not d.is_zero:
+                    # defect row = D.X - f  (mpopt.py:232): the entry is -df/dv
+                    self.jv.append((rk, rc, ck, cc, tr.neg(d) if rk == ROW_F else d))
+        self.gn = [tr.diff(self.qW, v, dmemo[id(v)]) for ck, cc, v in nv if ck in (COL_X, COL_U)]
+        self.gr = [self.qW] + [tr.diff(self.qW, v, dmemo[id(v)]) for ck, cc, v in nv if ck not in (COL_X, COL_U)]
+        # second derivatives of the node Lagrangian
+        sig = tr.var("sig")
+        lF = [tr.var(f"lF[{a}]") for a in range(nx)]
+        lC = [tr.var(f"lC[{j}]") for j in range(self.nc)]
+        lag = sig * self.qW
+        for a in range(nx):
+            lag = lag - lF[a] * self.fx[a]
+        for j in range(self.nc):
+            lag = lag + lC[j] * self.c[j]
+        self.hn, self.hc = [], []
+        for i, (k1, c1, v1) in enumerate(nv):
+            g1 = tr.diff(lag, v1, dmemo[id(v1)])
+            if g1.is_zero:
+                continue
+            for (k2, c2, v2) in nv[i:]:
+                d2 = tr.diff(g1, v2, dmemo[id(v2)])
+                if d2.is_zero:
+                    continue
+                if k1 in (COL_X, COL_U):
+                    self.hn.append((k1, c1, k2, c2, d2))
+                else:
+                    self.hc.append((k1, c1, k2, c2, d2))
+        # ---- terminal program --------------------------------------------------------
+        XF = [tr.var(f"XF[{a}]") for a in range(nx)]
+        X0 = [tr.var(f"X0[{a}]") for a in range(nx)]
+        xf = [XF[a] * (1.0 / sx[a]) for a in range(nx)]
+        x0 = [X0[a] * (1.0 / sx[a]) for a in range(nx)]
+        self.mayer = tr.wrap(ocp.get_terminal_costs(phase)(xf, tf, x0, t0, a_))
+        if ocp.has_terminal_constraints(phase):
+            self.tc = [tr.wrap(v) for v in _as_list(ocp.get_terminal_constraints(phase)(xf, tf, x0, t0, a_))]
+        else:
+            self.tc = []
+        self.ntc = len(self.tc)
+        self.term_vars = ([(TV_XF, a, XF[a]) for a in range(nx)] + [(TV_TF, 0, tfv)]
+                          + [(TV_X0, a, X0[a]) for a in range(nx)] + [(TV_T0, 0, t0v)]
+                          + [(TV_A, c, As[c]) for c in range(na)])
+        tv = self.term_vars
+        self.mg = [(k, c, tr.diff(self.mayer, v)) for k, c, v in tv]
+        self.mg = [m for m in self.mg if not m[2].is_zero]
+        self.tj = []
+        for j, e in enumerate(self.tc):
+            for k, c, v in tv:
+                d = tr.diff(e, v)
+                if not d.is_zero:
+                    self.tj.append((j, k, c, d))
+        lT = [tr.var(f"lT[{j}]") for j in range(self.ntc)]
+        lagT = sig * self.mayer
+        for j in range(self.ntc):
+            lagT = lagT + lT[j] * self.tc[j]
+        self.th = []
+        for i, (k1, c1, v1) in enumerate(tv):
+            g1 = tr.diff(lagT, v1)
+            if g1.is_zero:
+                continue
+            for (k2, c2, v2) in tv[i:]:
+                d2 = tr.diff(g1, v2)
+                if not d2.is_zero:
+                    self.th.append((k1, c1, k2, c2, d2))
+
+    # -- emission ----------------------------------------------------------------------
+    def _names(self):
+        n = {f"Xs[{a}]": f"Xs[{a}]" for a in range(self.nx)}
+        n.update({f"Us[{b}]": f"Us[{b}]" for b in range(self.nu)})
+        n.update({f"As[{c}]": f"As[{c}]" for c in range(self.na)})
+        n.update({f"XF[{a}]": f"XF[{a}]" for a in range(self.nx)})
+        n.update({f"X0[{a}]": f"X0[{a}]" for a in range(self.nx)})
+        n.update({f"lF[{a}]": f"lF[{a}]" for a in range(self.nx)})
+        n.update({f"lC[{j}]": f"lC[{j}]" for j in range(self.nc)})
+        n.update({f"lT[{j}]": f"lT[{j}]" for j in range(self.ntc)})
+        for s in ("t0v", "tfv", "kap", "th", "W", "sig"):
+            n[s] = s
+        return n
+
+    def source(self):
+        tr, names, ph = self.tr, self._names(), self.phase
+        NRED = 3 + self.na
+        out = [f"template <> struct Phase<{ph}> {{"]
+        out.append(f"  static constexpr int NX = {self.nx}, NU = {self.nu}, NA = {self.na}, NC = {self.nc}, NTC = {self.ntc};")
+        out.append(f"  static constexpr int NJV = {len(self.jv)}, NHN = {len(self.hn)}, NHC = {len(self.hc)};")
+        out.append(f"  static constexpr int NMG = {len(self.mg)}, NTJ = {len(self.tj)}, NTH = {len(self.th)}, NRED = {NRED};")
+        node_sig = ("const double* __restrict__ Xs, const double* __restrict__ Us, double t0v, double tfv, "
+                    "const double* __restrict__ As, double kap, double th, double W")
+        term_sig = ("const double* __restrict__ XF, double tfv, const double* __restrict__ X0, double t0v, "
+                    "const double* __restrict__ As")
+        # fg
+        out.append(f"  __device__ static __forceinline__ void fg({node_sig}, double* fx, double* c, double& qW) {{")
+        asg = [(f"fx[{a}]", e) for a, e in enumerate(self.fx)] + [(f"c[{j}]", e) for j, e in enumerate(self.c)] + [("qW", self.qW)]
+        out += tr.emit(asg, names, "    ")
+        out.append("  }")
+        # fgj
+        out.append(f"  __device__ static __forceinline__ void fgj({node_sig}, double* fx, double* c, double* dd, double* jv, double* gn, double* gr) {{")
+        asg = ([(f"fx[{a}]", e) for a, e in enumerate(self.fx)] + [(f"c[{j}]", e) for j, e in enumerate(self.c)]
+               + [(f"dd[{a}]", e) for a, e in enumerate(self.dd)] + [(f"jv[{k}]", s[4]) for k, s in enumerate(self.jv)]
+               + [(f"gn[{k}]", e) for k, e in enumerate(self.gn)] + [(f"gr[{k}]", e) for k, e in enumerate(self.gr)])
+        out += tr.emit(asg, names, "    ")
+        out.append("  }")
+        # hess
+        out.append(f"  __device__ static __forceinline__ void hess({node_sig}, double sig, const double* __restrict__ lF, const double* __restrict__ lC, double* hn, double* hc) {{")
+        asg = [(f"hn[{k}]", s[4]) for k, s in enumerate(self.hn)] + [(f"hc[{k}]", s[4]) for k, s in enumerate(self.hc)]
+        out += tr.emit(asg, names, "    ")
+        out.append("  }")
+        # terminal
+        out.append(f"  __device__ static __forceinline__ void term_fg({term_sig}, double& M, double* tc) {{")
+        out += tr.emit([("M", self.mayer)] + [(f"tc[{j}]", e) for j, e in enumerate(self.tc)], names, "    ")
+        out.append("  }")
+        out.append(f"  __device__ static __forceinline__ void term_fgj({term_sig}, double& M, double* tc, double* mg, double* tj) {{")
+        asg = ([("M", self.mayer)] + [(f"tc[{j}]", e) for j, e in enumerate(self.tc)]
+               + [(f"mg[{k}]", s[2]) for k, s in enumerate(self.mg)] + [(f"tj[{k}]", s[3]) for k, s in enumerate(self.tj)])
+        out += tr.emit(asg, names, "    ")
+        out.append("  }")
+        out.append(f"  __device__ static __forceinline__ void term_hess({term_sig}, double sig, const double* __restrict__ lT, double* th) {{")
+        out += tr.emit([(f"th[{k}]", s[4]) for k, s in enumerate(self.th)], names, "    ")
+        out.append("  }")
+        out.append("};")
+        return "\n".join(out)
+
+    def structure(self, flags):
+        """Packed int32 description of one phase (format documented in include/mpx.h)."""
+        s = [self.nc, self.ntc, int(flags["diff_u"]), int(flags["midu"]), int(flags["du_continuity"])]
+        s.append(len(self.jv))
+        for rk, rc, ck, cc, _ in self.jv:
+            s += [rk, rc, ck, cc]
+        s.append(len(self.hn))
+        for k1, c1, k2, c2, _ in self.hn:
+            s += [k1, c1, k2, c2]
+        s.append(len(self.hc))
+        for k1, c1, k2, c2, _ in self.hc:
+            s += [k1, c1, k2, c2]
+        s.append(len(self.mg))
+        for k, c, _ in self.mg:
+            s += [k, c]
+        s.append(len(self.tj))
+        for j, k, c, _ in self.tj:
+            s += [j, k, c]
+        s.append(len(self.th))
+        for k1, c1, k2, c2, _ in self.th:
+            s += [k1, c1, k2, c2]
+        return s
+
+
+class ProblemProgram:
+    """All phases of an OCP: generated source + structure + instantiation list."""
+
+    def __init__(self, ocp, degrees, midu_rows):
+        """``degrees``: distinct polynomial degrees on the grid; ``midu_rows[ph]``: whether the
+        mid-point control rows are emitted for that phase (mpopt.py:346, 363-365)."""
+        self.ocp = ocp
+        self.degrees = sorted(set(int(d) for d in degrees))
+        self.phases = [PhaseProgram(ocp, ph) for ph in range(ocp.n_phases)]
+        self.flags = [dict(diff_u=bool(ocp.diff_u[ph]), midu=bool(midu_rows[ph]),
+                           du_continuity=bool(ocp.du_continuity[ph])) for ph in range(ocp.n_phases)]
+
+    def structure(self):
+        s = []
+        for ph, prog in enumerate(self.phases):
+            s += prog.structure(self.flags[ph])
+        return np.asarray(s, dtype=np.int32)
+
+    def source(self):
+        nph = len(self.phases)
+        parts = ["// generated by mpopt_amd.codegen -- do not edit", "#include <hip/hip_runtime.h>",
+                 f"#define MPX_NPH {nph}", "namespace mpxgen {", "template <int PH> struct Phase;"]
+        parts += [p.source() for p in self.phases]
+        parts.append("}  // namespace mpxgen")
+        parts.append('#include "mpx_kernels.h"')
+        for ph in range(nph):
+            for d in self.degrees:
+                parts.append(f"MPX_INSTANTIATE_NODE({ph}, {d})")
+        parts.append("MPX_INSTANTIATE_BOUNDARY()")
+        return "\n".join(parts) + "\n"
+
+    def key(self, extra=""):
+        return hashlib.sha256((self.source() + extra).encode()).hexdigest()[:24]

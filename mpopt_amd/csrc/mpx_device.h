@@ -1,0 +1,91 @@
+// mpx_device.h -- argument blocks shared by the host runtime (mpx_host.cpp) and the kernels
+// (mpx_kernels.h, compiled per problem).  Plain-old-data only.
+#ifndef MPX_DEVICE_H
+#define MPX_DEVICE_H
+#include <stdint.h>
+
+#define MPX_TILE 256           // nodes (= lanes) per workgroup tile: 4 wavefronts of 64
+#define MPX_MAX_PHASES 8
+
+// kernel modes
+#define MPX_MODE_FG 0    // f, g
+#define MPX_MODE_FGJ 1   // f, g, grad_f, jac_g
+#define MPX_MODE_HESS 2  // hess_l
+
+// One workgroup's share of one (phase, degree) bucket: whole segments, <= MPX_TILE nodes.
+struct MpxTile {
+  int32_t m0;        // first bucket-local node
+  int32_t n;         // nodes in this tile
+  int32_t seg0;      // first segment of the tile
+  int32_t mu_skip;   // 1 when the tile starts with node 0 of the phase (it owns no mid-point row)
+  int32_t tile_id;   // slot in the partial-sum buffer, global over phases and buckets
+  int32_t pad;
+  int64_t jac_base;  // offset of the tile's block in the jac_g value array
+  int64_t hess_base; // offset of the tile's block in the hess_l value array
+};
+
+// Batched I/O views: pointer + per-evaluation-point stride (in doubles).
+struct MpxIO {
+  const double* z;      int64_t z_stride;
+  const double* w;      // segment widths   [n_wvec][n_phases*S]
+  const double* wcum;   // exclusive prefix [n_wvec][n_phases*S]
+  int64_t w_stride;     // 0: widths shared by the batch
+  const double* lam_g;  int64_t lam_stride;
+  const double* sigma;
+  double* f;
+  double* g;            int64_t g_stride;
+  double* grad;         int64_t grad_stride;
+  double* jac;          int64_t jac_stride;
+  double* hess;         int64_t hess_stride;
+  double* partial;      // [B][n_tiles_total][nred]
+  int32_t n_tiles_total, nred;
+  int32_t B, b_per_block;
+};
+
+// Node kernels: one launch per (phase, degree) bucket.
+struct MpxNodeArgs {
+  MpxIO io;
+  const MpxTile* tiles;    // tiles of this bucket (blockIdx.x indexes it, offset by tile_first)
+  const int32_t* node_i;   // bucket-local node -> node index in the phase
+  const int32_t* node_sk;  // bucket-local node -> (segment << 8) | point
+  const double* Dmat;      // (P+1)x(P+1) row-major first-derivative matrix of this degree
+  const double* Cmid;      // P x (P+1) interpolation to the mid-points between consecutive nodes
+  const double* tk;        // (tau_k - tau0)/(tau1 - tau0), k = 0..P
+  const double* Wnode;     // composite quadrature weight per node of this phase
+  double inv_dtau;         // 1/(tau1 - tau0)
+  int64_t z_off;           // offset of the phase's block in z / grad_f
+  int64_t g_off_F, g_off_C, g_off_DU, g_off_mU;  // row offsets of the phase's blocks in g
+  int32_t N, S, seg_off;   // nodes, segments per phase; phase*S
+  int32_t diff_u, midu;
+  int32_t tile_first, tile_count;  // tile sub-range to run (segment sharding)
+};
+
+// Linear rows handled by the boundary kernel (control-slope continuity dU, phase-link events):
+// g[row] = sum_e coef[e] * z[idx[e]], Jacobian values = coef.
+struct MpxPhaseInfo {
+  int64_t z_off;
+  int32_t N, tile_first, tile_count, pad;
+  int64_t g_off_TC;      // first terminal-constraint row
+  int64_t jac_TC;        // first terminal-constraint Jacobian value
+};
+
+struct MpxBoundArgs {
+  MpxIO io;
+  MpxPhaseInfo ph[MPX_MAX_PHASES];
+  // destinations (host built): grad index for every Mayer-gradient entry, hess index for every
+  // corner / terminal Hessian entry (bit 62 set: accumulate into an entry a node kernel wrote)
+  const int64_t* mg_dst;   // concatenated over phases
+  const int64_t* hc_dst;
+  const int64_t* th_dst;
+  int32_t mg_off[MPX_MAX_PHASES], hc_off[MPX_MAX_PHASES], th_off[MPX_MAX_PHASES];
+  // linear rows
+  const int64_t* lin_ptr;  // [n_lin+1]
+  const int64_t* lin_idx;  // z index
+  const double* lin_coef;
+  const int64_t* lin_row;  // g row of each linear row
+  int64_t lin_jac;         // first Jacobian value of the linear rows
+  int32_t n_lin, nx, nu, na;
+};
+
+#define MPX_ACCUM_BIT (1LL << 62)
+#endif

@@ -1,0 +1,897 @@
+// mpx_host.cpp -- libmpx host runtime: problem structure -> tiles, index maps and COO patterns;
+// device tables; kernel launches; the C ABI of include/mpx.h.
+//
+// Reference behaviour restated here (structure only -- all arithmetic is in mpx_kernels.h):
+//   decision vector layout          mpopt.py:537-543, 627   (state-major, phases concatenated)
+//   constraint row order            mpopt.py:458, 617-621   ([F;C;DU;mU;dU;TC] per phase, events)
+//   composite D / W / interpolation mpopt.py:4015-4131      (never formed densely: per-degree
+//                                                            tables + per-node (segment, point))
+//   node ownership                  mpopt.py:189-195, 208   (shared node belongs to the earlier
+//                                                            segment; later segments drop w_0)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "mpx.h"
+#include "mpx_device.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Entry4 {
+  int32_t a, b, c, d;
+};
+struct PhaseStruct {
+  int nc = 0, ntc = 0, diff_u = 0, midu = 0, du_cont = 0;
+  std::vector<Entry4> jv, hn, hc, th;
+  std::vector<std::pair<int32_t, int32_t>> mg;
+  struct TJ {
+    int32_t row, kind, comp;
+  };
+  std::vector<TJ> tj;
+  // layout
+  int64_t z_off = 0, g_off_F = 0, g_off_C = 0, g_off_DU = 0, g_off_mU = 0, g_off_dU = 0, g_off_TC = 0;
+  int64_t jac_TC = 0;
+  int tile_first = 0, tile_count = 0;
+};
+
+struct DegTable {
+  int deg = 0;
+  std::vector<double> roots, D, Cmid, w, tk;
+  double *d_D = nullptr, *d_Cmid = nullptr, *d_tk = nullptr;
+};
+
+struct Bucket {
+  int phase = 0, deg = 0, dt = 0;  // dt: index into degree tables
+  std::vector<int32_t> node_i, node_sk;
+  int tile_first = 0, tile_count = 0;  // global tile ids
+  int32_t *d_node_i = nullptr, *d_node_sk = nullptr;
+  hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
+};
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct mpx_ctx {
+  std::string err;
+  // problem
+  int n_phases = 0, nx = 0, nu = 0, na = 0, S = 0, scheme = 0, device = 0;
+  double tau0 = -1, tau1 = 1;
+  std::vector<int32_t> orders, seg_start, links;
+  std::vector<PhaseStruct> ph;
+  int64_t N = 0, n_zp = 0, n_z = 0, n_g = 0, n_p = 0, nnz_j = 0, nnz_h = 0;
+  std::vector<DegTable> degs;
+  std::vector<Bucket> buckets;
+  std::vector<MpxTile> tiles;  // global, phase-major, bucket-major
+  std::vector<double> compW;
+  std::vector<int32_t> jrow, jcol, hrow, hcol;
+  // linear rows
+  std::vector<int64_t> lin_ptr, lin_idx, lin_row;
+  std::vector<double> lin_coef;
+  int64_t lin_jac = 0;
+  std::vector<int64_t> mg_dst, hc_dst, th_dst;
+  std::vector<int32_t> mg_off, hc_off, th_off;
+  int nred = 1;
+  // device
+  bool has_device = false;
+  hipModule_t module = nullptr;
+  hipFunction_t fn_bound[3] = {nullptr, nullptr, nullptr};
+  hipStream_t stream = nullptr;
+  MpxTile* d_tiles = nullptr;
+  double* d_Wnode = nullptr;
+  int64_t *d_lin_ptr = nullptr, *d_lin_idx = nullptr, *d_lin_row = nullptr, *d_mg_dst = nullptr,
+          *d_hc_dst = nullptr, *d_th_dst = nullptr;
+  double* d_lin_coef = nullptr;
+  DevBuf<double> partial, wcum, st_z, st_p, st_lam, st_sig, st_f, st_g, st_grad, st_jac, st_hess;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int64_t tile_begin = 0, tile_end = 0;
+  int run_boundary = 1;
+};
+
+namespace {
+
+int fail(mpx_ctx* c, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(ctx, MPX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <class T>
+int upload(mpx_ctx* c, T** dst, const std::vector<T>& v) {
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  HIPCHK(c, hipMalloc((void**)dst, bytes));
+  if (!v.empty()) HIPCHK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return MPX_OK;
+}
+
+template <class T>
+int reserve(mpx_ctx* c, DevBuf<T>& b, size_t n) {
+  if (n <= b.cap) return MPX_OK;
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  HIPCHK(c, hipMalloc((void**)&b.p, n * sizeof(T)));
+  b.cap = n;
+  return MPX_OK;
+}
+
+// global z index of a node variable
+inline int64_t zcol(const mpx_ctx& c, const PhaseStruct& P, int kind, int comp, int64_t i) {
+  const int64_t N = c.N;
+  switch (kind) {
+    case MPX_COL_X: return P.z_off + (int64_t)comp * N + i;
+    case MPX_COL_U: return P.z_off + (int64_t)(c.nx + comp) * N + i;
+    case MPX_COL_T0: return P.z_off + (int64_t)(c.nx + c.nu) * N;
+    case MPX_COL_TF: return P.z_off + (int64_t)(c.nx + c.nu) * N + 1;
+    default: return P.z_off + (int64_t)(c.nx + c.nu) * N + 2 + comp;
+  }
+}
+inline int64_t zterm(const mpx_ctx& c, const PhaseStruct& P, int kind, int comp) {
+  switch (kind) {
+    case MPX_TV_XF: return zcol(c, P, MPX_COL_X, comp, c.N - 1);
+    case MPX_TV_X0: return zcol(c, P, MPX_COL_X, comp, 0);
+    case MPX_TV_TF: return zcol(c, P, MPX_COL_TF, 0, 0);
+    case MPX_TV_T0: return zcol(c, P, MPX_COL_T0, 0, 0);
+    default: return zcol(c, P, MPX_COL_A, comp, 0);
+  }
+}
+
+int parse_structure(mpx_ctx* c, const int32_t* s, int64_t len) {
+  int64_t q = 0;
+  auto need = [&](int64_t n) { return q + n <= len; };
+  for (int p = 0; p < c->n_phases; ++p) {
+    PhaseStruct& P = c->ph[p];
+    if (!need(6)) return fail(c, MPX_ERR_INVALID, "structure truncated (phase %d header)", p);
+    P.nc = s[q++];
+    P.ntc = s[q++];
+    P.diff_u = s[q++];
+    P.midu = s[q++];
+    P.du_cont = s[q++];
+    auto read4 = [&](std::vector<Entry4>& v) -> bool {
+      if (!need(1)) return false;
+      int n = s[q++];
+      if (n < 0 || !need(4LL * n)) return false;
+      v.resize(n);
+      for (int e = 0; e < n; ++e) {
+        v[e] = {s[q], s[q + 1], s[q + 2], s[q + 3]};
+        q += 4;
+      }
+      return true;
+    };
+    if (!read4(P.jv) || !read4(P.hn) || !read4(P.hc)) return fail(c, MPX_ERR_INVALID, "structure truncated (phase %d)", p);
+    if (!need(1)) return fail(c, MPX_ERR_INVALID, "structure truncated");
+    int n = s[q++];
+    if (n < 0 || !need(2LL * n)) return fail(c, MPX_ERR_INVALID, "structure truncated");
+    for (int e = 0; e < n; ++e, q += 2) P.mg.push_back({s[q], s[q + 1]});
+    if (!need(1)) return fail(c, MPX_ERR_INVALID, "structure truncated");
+    n = s[q++];
+    if (n < 0 || !need(3LL * n)) return fail(c, MPX_ERR_INVALID, "structure truncated");
+    for (int e = 0; e < n; ++e, q += 3) P.tj.push_back({s[q], s[q + 1], s[q + 2]});
+    if (!read4(P.th)) return fail(c, MPX_ERR_INVALID, "structure truncated (phase %d terminal)", p);
+    // validate kinds / components
+    for (auto& e : P.jv) {
+      if ((e.a != MPX_ROW_F && e.a != MPX_ROW_C) || e.b < 0 || e.b >= (e.a == MPX_ROW_F ? c->nx : P.nc) || e.c < 0 ||
+          e.c > MPX_COL_A)
+        return fail(c, MPX_ERR_INVALID, "bad Jacobian entry in phase %d", p);
+    }
+  }
+  if (q != len) return fail(c, MPX_ERR_INVALID, "structure has %lld trailing words", (long long)(len - q));
+  return MPX_OK;
+}
+
+int build_tables(mpx_ctx* c) {
+  std::vector<int> distinct(c->orders.begin(), c->orders.end());
+  std::sort(distinct.begin(), distinct.end());
+  distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+  for (int d : distinct) {
+    if (d < 1 || d > 255) return fail(c, MPX_ERR_UNSUPPORTED, "polynomial degree %d outside 1..255", d);
+    DegTable t;
+    t.deg = d;
+    int n = mpx_colloc_n_nodes(c->scheme, d);
+    if (n != d + 1) return fail(c, MPX_ERR_UNSUPPORTED, "scheme %d does not give degree+1 nodes (SURVEY a4)", c->scheme);
+    t.roots.resize(n);
+    mpx_colloc_roots(c->scheme, d, c->tau0, c->tau1, t.roots.data());
+    t.D.resize((size_t)n * n);
+    mpx_colloc_diff_matrix(t.roots.data(), n, nullptr, 0, 1, t.D.data());
+    t.w.resize(n);
+    mpx_colloc_quad_weights(t.roots.data(), n, c->tau0, c->tau1, t.w.data());
+    std::vector<double> mids(d);
+    for (int k = 0; k < d; ++k) mids[k] = (t.roots[k] + t.roots[k + 1]) / 2.0;  // mpopt.py:350-352
+    t.Cmid.resize((size_t)d * n);
+    mpx_colloc_interp_matrix(t.roots.data(), n, mids.data(), d, t.Cmid.data());
+    t.tk.resize(n);
+    for (int k = 0; k < n; ++k) t.tk[k] = (t.roots[k] - c->tau0) / (c->tau1 - c->tau0);
+    c->degs.push_back(std::move(t));
+  }
+  return MPX_OK;
+}
+
+int deg_index(const mpx_ctx* c, int d) {
+  for (size_t k = 0; k < c->degs.size(); ++k)
+    if (c->degs[k].deg == d) return (int)k;
+  return -1;
+}
+
+int build_layout(mpx_ctx* c) {
+  const int nx = c->nx, nu = c->nu, na = c->na, S = c->S;
+  c->seg_start.resize(S + 1);
+  c->seg_start[0] = 0;
+  for (int s = 0; s < S; ++s) c->seg_start[s + 1] = c->seg_start[s] + c->orders[s];
+  const int64_t N = c->N = c->seg_start[S] + 1;
+  c->n_zp = N * (nx + nu) + 2 + na;
+  c->n_z = c->n_zp * c->n_phases;
+  c->n_p = (int64_t)S * c->n_phases;
+  // composite quadrature weights (mpopt.py:4060-4062): w0 of segment 0, then w[1:] of every segment
+  c->compW.resize(N);
+  c->compW[0] = c->degs[deg_index(c, c->orders[0])].w[0];
+  for (int s = 0; s < S; ++s) {
+    const DegTable& t = c->degs[deg_index(c, c->orders[s])];
+    for (int k = 1; k <= c->orders[s]; ++k) c->compW[c->seg_start[s] + k] = t.w[k];
+  }
+  // g rows
+  int64_t g = 0;
+  for (int p = 0; p < c->n_phases; ++p) {
+    PhaseStruct& P = c->ph[p];
+    P.z_off = c->n_zp * p;
+    P.g_off_F = g;
+    g += (int64_t)nx * N;
+    P.g_off_C = g;
+    g += (int64_t)P.nc * N;
+    P.g_off_DU = g;
+    if (P.diff_u) g += (int64_t)nu * N;
+    P.g_off_mU = g;
+    if (P.midu) g += (int64_t)nu * (N - 1);
+    P.g_off_dU = g;
+    if (P.du_cont && S > 1) g += (int64_t)nu * (S - 1);
+    P.g_off_TC = g;
+    g += P.ntc;
+  }
+  const int64_t g_events = g;
+  const int nl = (int)c->links.size() / 2;
+  if (c->n_phases > 1) g += (int64_t)nl * (nx + nu + 1);
+  c->n_g = g;
+
+  // tiles: per phase, per degree bucket, whole segments, <= MPX_TILE nodes
+  c->tiles.clear();
+  for (int p = 0; p < c->n_phases; ++p) {
+    PhaseStruct& P = c->ph[p];
+    P.tile_first = (int)c->tiles.size();
+    for (size_t dt = 0; dt < c->degs.size(); ++dt) {
+      const int d = c->degs[dt].deg;
+      Bucket B;
+      B.phase = p;
+      B.deg = d;
+      B.dt = (int)dt;
+      B.tile_first = (int)c->tiles.size();
+      MpxTile cur{};
+      bool open = false;
+      const int max_segs = MPX_TILE / d;
+      int segs_in_tile = 0;
+      for (int s = 0; s < S; ++s) {
+        if (c->orders[s] != d) continue;
+        int add = d + (s == 0 ? 1 : 0);
+        if (open && (cur.n + add > MPX_TILE || segs_in_tile >= max_segs)) {
+          c->tiles.push_back(cur);
+          open = false;
+        }
+        if (!open) {
+          cur = MpxTile{};
+          cur.m0 = (int32_t)B.node_i.size();
+          cur.seg0 = s;
+          cur.mu_skip = (s == 0) ? 1 : 0;
+          cur.tile_id = (int32_t)c->tiles.size();
+          segs_in_tile = 0;
+          open = true;
+        }
+        if (s == 0) {
+          B.node_i.push_back(0);
+          B.node_sk.push_back(0);
+        }
+        for (int k = 1; k <= d; ++k) {
+          B.node_i.push_back(c->seg_start[s] + k);
+          B.node_sk.push_back((s << 8) | k);
+        }
+        cur.n += add;
+        ++segs_in_tile;
+      }
+      if (open) c->tiles.push_back(cur);
+      B.tile_count = (int)c->tiles.size() - B.tile_first;
+      if (B.tile_count > 0) c->buckets.push_back(std::move(B));
+    }
+    P.tile_count = (int)c->tiles.size() - P.tile_first;
+  }
+  c->tile_begin = 0;
+  c->tile_end = (int64_t)c->tiles.size();
+
+  // ---- Jacobian pattern -----------------------------------------------------------------
+  std::vector<int32_t>&jr = c->jrow, &jc = c->jcol;
+  int64_t jpos = 0;
+  for (auto& B : c->buckets) {
+    const PhaseStruct& P = c->ph[B.phase];
+    const int d = B.deg, P1 = d + 1;
+    for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
+      MpxTile& T = c->tiles[t];
+      T.jac_base = jpos;
+      const int64_t n = T.n, n2 = T.n - T.mu_skip;
+      int64_t slots = (int64_t)nx * P1 + (int64_t)P.jv.size() + (P.diff_u ? (int64_t)nu * P1 : 0);
+      int64_t size = slots * n + (P.midu ? (int64_t)nu * P1 * n2 : 0);
+      jr.resize(jpos + size);
+      jc.resize(jpos + size);
+      for (int64_t l = 0; l < n; ++l) {
+        const int64_t i = B.node_i[T.m0 + l];
+        const int sk = B.node_sk[T.m0 + l], s = sk >> 8, k = sk & 255;
+        const int64_t st = c->seg_start[s];
+        (void)k;
+        int64_t q = 0;
+        for (int a = 0; a < nx; ++a)
+          for (int j = 0; j < P1; ++j, ++q) {
+            jr[jpos + q * n + l] = (int32_t)(P.g_off_F + (int64_t)a * N + i);
+            jc[jpos + q * n + l] = (int32_t)zcol(*c, P, MPX_COL_X, a, st + j);
+          }
+        for (auto& e : P.jv) {
+          jr[jpos + q * n + l] = (int32_t)((e.a == MPX_ROW_F ? P.g_off_F : P.g_off_C) + (int64_t)e.b * N + i);
+          jc[jpos + q * n + l] = (int32_t)zcol(*c, P, e.c, e.d, i);
+          ++q;
+        }
+        if (P.diff_u)
+          for (int u = 0; u < nu; ++u)
+            for (int j = 0; j < P1; ++j, ++q) {
+              jr[jpos + q * n + l] = (int32_t)(P.g_off_DU + (int64_t)u * N + i);
+              jc[jpos + q * n + l] = (int32_t)zcol(*c, P, MPX_COL_U, u, st + j);
+            }
+        if (P.midu && l - T.mu_skip >= 0) {
+          const int64_t l2 = l - T.mu_skip;
+          const int64_t mb = jpos + q * n;
+          for (int u = 0; u < nu; ++u)
+            for (int j = 0; j < P1; ++j) {
+              jr[mb + (int64_t)(u * P1 + j) * n2 + l2] = (int32_t)(P.g_off_mU + (int64_t)u * (N - 1) + (i - 1));
+              jc[mb + (int64_t)(u * P1 + j) * n2 + l2] = (int32_t)zcol(*c, P, MPX_COL_U, u, st + j);
+            }
+        }
+      }
+      jpos += size;
+    }
+  }
+  for (int p = 0; p < c->n_phases; ++p) {  // terminal-constraint entries
+    PhaseStruct& P = c->ph[p];
+    P.jac_TC = jpos;
+    for (auto& e : P.tj) {
+      jr.push_back((int32_t)(P.g_off_TC + e.row));
+      jc.push_back((int32_t)zterm(*c, P, e.kind, e.comp));
+      ++jpos;
+    }
+  }
+  // linear rows: control-slope continuity (mpopt.py:398-411), then events (mpopt.py:484-519)
+  c->lin_ptr.assign(1, 0);
+  c->lin_jac = jpos;
+  for (int p = 0; p < c->n_phases; ++p) {
+    const PhaseStruct& P = c->ph[p];
+    if (!(P.du_cont && S > 1)) continue;
+    for (int u = 0; u < nu; ++u)
+      for (int s = 0; s + 1 < S; ++s) {
+        const DegTable& ta = c->degs[deg_index(c, c->orders[s])];
+        const DegTable& tb = c->degs[deg_index(c, c->orders[s + 1])];
+        const int pa = ta.deg, pb = tb.deg;
+        // end slope of segment s minus start slope of segment s+1; the shared node merges
+        for (int j = 0; j <= pa + pb; ++j) {
+          double coef = 0;
+          if (j <= pa) coef += ta.D[(size_t)pa * (pa + 1) + j];
+          if (j >= pa) coef -= tb.D[(size_t)0 * (pb + 1) + (j - pa)];
+          c->lin_idx.push_back(zcol(*c, P, MPX_COL_U, u, c->seg_start[s] + j));
+          c->lin_coef.push_back(coef);
+        }
+        c->lin_ptr.push_back((int64_t)c->lin_idx.size());
+        c->lin_row.push_back(P.g_off_dU + (int64_t)u * (S - 1) + s);
+      }
+  }
+  if (c->n_phases > 1) {
+    int64_t row = g_events;
+    for (int blk = 0; blk < 3; ++blk)
+      for (int l = 0; l < nl; ++l) {
+        const PhaseStruct& Pi = c->ph[c->links[2 * l]];
+        const PhaseStruct& Pj = c->ph[c->links[2 * l + 1]];
+        int cnt = blk == 0 ? nx : (blk == 1 ? nu : 1);
+        for (int a = 0; a < cnt; ++a) {
+          if (blk == 2) {  // t0_j - tf_i
+            c->lin_idx.push_back(zcol(*c, Pj, MPX_COL_T0, 0, 0));
+            c->lin_idx.push_back(zcol(*c, Pi, MPX_COL_TF, 0, 0));
+          } else {
+            int kind = blk == 0 ? MPX_COL_X : MPX_COL_U;
+            c->lin_idx.push_back(zcol(*c, Pj, kind, a, 0));
+            c->lin_idx.push_back(zcol(*c, Pi, kind, a, N - 1));
+          }
+          c->lin_coef.push_back(1.0);
+          c->lin_coef.push_back(-1.0);
+          c->lin_ptr.push_back((int64_t)c->lin_idx.size());
+          c->lin_row.push_back(row++);
+        }
+      }
+  }
+  for (size_t r = 0; r + 1 < c->lin_ptr.size(); ++r)
+    for (int64_t e = c->lin_ptr[r]; e < c->lin_ptr[r + 1]; ++e) {
+      jr.push_back((int32_t)c->lin_row[r]);
+      jc.push_back((int32_t)c->lin_idx[e]);
+      ++jpos;
+    }
+  c->nnz_j = jpos;
+
+  // ---- Hessian pattern (upper triangle) -----------------------------------------------------
+  std::vector<int32_t>&hr = c->hrow, &hc = c->hcol;
+  int64_t hpos = 0;
+  std::vector<std::map<std::pair<int64_t, int64_t>, int64_t>> edge(c->n_phases);
+  for (auto& B : c->buckets) {
+    const PhaseStruct& P = c->ph[B.phase];
+    for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
+      MpxTile& T = c->tiles[t];
+      T.hess_base = hpos;
+      const int64_t n = T.n;
+      const int64_t size = (int64_t)P.hn.size() * n;
+      hr.resize(hpos + size);
+      hc.resize(hpos + size);
+      for (int64_t l = 0; l < n; ++l) {
+        const int64_t i = B.node_i[T.m0 + l];
+        int64_t q = 0;
+        for (auto& e : P.hn) {
+          int64_t r = zcol(*c, P, e.a, e.b, i), cc = zcol(*c, P, e.c, e.d, i);
+          hr[hpos + q * n + l] = (int32_t)r;
+          hc[hpos + q * n + l] = (int32_t)cc;
+          if (i == 0 || i == N - 1) edge[B.phase][{r, cc}] = hpos + q * n + l;
+          ++q;
+        }
+      }
+      hpos += size;
+    }
+  }
+  c->mg_off.assign(MPX_MAX_PHASES, 0);
+  c->hc_off.assign(MPX_MAX_PHASES, 0);
+  c->th_off.assign(MPX_MAX_PHASES, 0);
+  int nred = 1;
+  for (int p = 0; p < c->n_phases; ++p) {
+    const PhaseStruct& P = c->ph[p];
+    nred = std::max(nred, std::max(3 + na, (int)P.hc.size()));
+    c->mg_off[p] = (int32_t)c->mg_dst.size();
+    for (auto& e : P.mg) c->mg_dst.push_back(zterm(*c, P, e.first, e.second));
+    c->hc_off[p] = (int32_t)c->hc_dst.size();
+    for (auto& e : P.hc) {
+      int64_t r = zcol(*c, P, e.a, e.b, 0), cc = zcol(*c, P, e.c, e.d, 0);
+      hr.push_back((int32_t)r);
+      hc.push_back((int32_t)cc);
+      edge[p][{r, cc}] = hpos;
+      c->hc_dst.push_back(hpos++);
+    }
+    c->th_off[p] = (int32_t)c->th_dst.size();
+    for (auto& e : P.th) {
+      int64_t r = zterm(*c, P, e.a, e.b), cc = zterm(*c, P, e.c, e.d);
+      if (r > cc) std::swap(r, cc);
+      auto it = edge[p].find({r, cc});
+      if (it != edge[p].end()) {
+        c->th_dst.push_back(it->second | MPX_ACCUM_BIT);
+      } else {
+        hr.push_back((int32_t)r);
+        hc.push_back((int32_t)cc);
+        edge[p][{r, cc}] = hpos;
+        c->th_dst.push_back(hpos++);
+      }
+    }
+  }
+  c->nred = nred;
+  c->nnz_h = hpos;
+  return MPX_OK;
+}
+
+int load_device(mpx_ctx* c, const mpx_problem* prob) {
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipModuleLoadData(&c->module, prob->code_object));
+  static const char* modes[3] = {"fg", "fgj", "hess"};
+  for (auto& B : c->buckets)
+    for (int m = 0; m < 3; ++m) {
+      char name[96];
+      snprintf(name, sizeof name, "mpx_node_%s_%d_%d", modes[m], B.phase, B.deg);
+      hipError_t e = hipModuleGetFunction(&B.fn[m], c->module, name);
+      if (e != hipSuccess) return fail(c, MPX_ERR_INVALID, "code object lacks kernel %s (%s)", name, hipGetErrorString(e));
+    }
+  for (int m = 0; m < 3; ++m) {
+    char name[64];
+    snprintf(name, sizeof name, "mpx_boundary_%s", modes[m]);
+    hipError_t e = hipModuleGetFunction(&c->fn_bound[m], c->module, name);
+    if (e != hipSuccess) return fail(c, MPX_ERR_INVALID, "code object lacks kernel %s", name);
+  }
+  int rc;
+  for (auto& t : c->degs) {
+    if ((rc = upload(c, &t.d_D, t.D))) return rc;
+    if ((rc = upload(c, &t.d_Cmid, t.Cmid))) return rc;
+    if ((rc = upload(c, &t.d_tk, t.tk))) return rc;
+  }
+  for (auto& B : c->buckets) {
+    if ((rc = upload(c, &B.d_node_i, B.node_i))) return rc;
+    if ((rc = upload(c, &B.d_node_sk, B.node_sk))) return rc;
+  }
+  if ((rc = upload(c, &c->d_tiles, c->tiles))) return rc;
+  if ((rc = upload(c, &c->d_Wnode, c->compW))) return rc;
+  if ((rc = upload(c, &c->d_lin_ptr, c->lin_ptr))) return rc;
+  if ((rc = upload(c, &c->d_lin_idx, c->lin_idx))) return rc;
+  if ((rc = upload(c, &c->d_lin_row, c->lin_row))) return rc;
+  if ((rc = upload(c, &c->d_lin_coef, c->lin_coef))) return rc;
+  if ((rc = upload(c, &c->d_mg_dst, c->mg_dst))) return rc;
+  if ((rc = upload(c, &c->d_hc_dst, c->hc_dst))) return rc;
+  if ((rc = upload(c, &c->d_th_dst, c->th_dst))) return rc;
+  HIPCHK(c, hipEventCreate(&c->ev0));
+  HIPCHK(c, hipEventCreate(&c->ev1));
+  c->has_device = true;
+  return MPX_OK;
+}
+
+// exclusive prefix sums of the segment widths, sequential per (width vector, phase) so that the
+// accumulation order matches the reference's running t_seg0 (mpopt.py:192)
+__global__ void mpx_prefix_kernel(const double* __restrict__ w, double* __restrict__ wcum, int S, int n_phases, int n_wvec) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_phases * n_wvec) return;
+  const double* a = w + (int64_t)t * S;
+  double* o = wcum + (int64_t)t * S;
+  double acc = 0;
+  for (int s = 0; s < S; ++s) {
+    o[s] = acc;
+    acc += a[s];
+  }
+}
+
+int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size_t size) {
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  HIPCHK(c, hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, c->stream, nullptr, cfg));
+  return MPX_OK;
+}
+
+int pick_bpb(const mpx_ctx* c, int64_t B) {
+  static const char* env = getenv("MPX_BPB");
+  if (env && atoi(env) > 0) return atoi(env);
+  int64_t work = B * (c->tile_end - c->tile_begin);
+  int64_t bpb = (work + 4095) / 4096;
+  return (int)std::min<int64_t>(std::max<int64_t>(bpb, 1), 64);
+}
+
+int run_mode(mpx_ctx* c, int mode, const MpxIO& io0) {
+  MpxIO io = io0;
+  io.b_per_block = pick_bpb(c, io.B);
+  const int gy = (io.B + io.b_per_block - 1) / io.b_per_block;
+  for (auto& B : c->buckets) {
+    int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);
+    if (hi <= lo) continue;
+    const PhaseStruct& P = c->ph[B.phase];
+    const DegTable& t = c->degs[B.dt];
+    MpxNodeArgs A{};
+    A.io = io;
+    A.tiles = c->d_tiles;
+    A.node_i = B.d_node_i;
+    A.node_sk = B.d_node_sk;
+    A.Dmat = t.d_D;
+    A.Cmid = t.d_Cmid;
+    A.tk = t.d_tk;
+    A.Wnode = c->d_Wnode;
+    A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
+    A.z_off = P.z_off;
+    A.g_off_F = P.g_off_F;
+    A.g_off_C = P.g_off_C;
+    A.g_off_DU = P.g_off_DU;
+    A.g_off_mU = P.g_off_mU;
+    A.N = (int32_t)c->N;
+    A.S = c->S;
+    A.seg_off = B.phase * c->S;
+    A.diff_u = P.diff_u;
+    A.midu = P.midu;
+    A.tile_first = (int32_t)lo;
+    A.tile_count = (int32_t)(hi - lo);
+    int rc = launch(c, B.fn[mode], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A);
+    if (rc) return rc;
+  }
+  if (!c->run_boundary) return MPX_OK;
+  MpxBoundArgs G{};
+  G.io = io;
+  for (int p = 0; p < c->n_phases; ++p) {
+    const PhaseStruct& P = c->ph[p];
+    G.ph[p].z_off = P.z_off;
+    G.ph[p].N = (int32_t)c->N;
+    G.ph[p].tile_first = P.tile_first;
+    G.ph[p].tile_count = P.tile_count;
+    G.ph[p].g_off_TC = P.g_off_TC;
+    G.ph[p].jac_TC = P.jac_TC;
+    G.mg_off[p] = c->mg_off[p];
+    G.hc_off[p] = c->hc_off[p];
+    G.th_off[p] = c->th_off[p];
+  }
+  G.mg_dst = c->d_mg_dst;
+  G.hc_dst = c->d_hc_dst;
+  G.th_dst = c->d_th_dst;
+  G.lin_ptr = c->d_lin_ptr;
+  G.lin_idx = c->d_lin_idx;
+  G.lin_coef = c->d_lin_coef;
+  G.lin_row = c->d_lin_row;
+  G.lin_jac = c->lin_jac;
+  G.n_lin = (int32_t)c->lin_row.size();
+  G.nx = c->nx;
+  G.nu = c->nu;
+  G.na = c->na;
+  return launch(c, c->fn_bound[mode], dim3((unsigned)io.B, 1, 1), dim3(256, 1, 1), &G, sizeof G);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* mpx_last_error(const mpx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int mpx_create(const mpx_problem* prob, mpx_ctx** out) {
+  if (!prob || !out) return fail(nullptr, MPX_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (prob->version != MPX_VERSION) return fail(nullptr, MPX_ERR_INVALID, "mpx_problem.version %d != %d", prob->version, MPX_VERSION);
+  if (prob->n_phases < 1 || prob->n_phases > MPX_MAX_PHASES) return fail(nullptr, MPX_ERR_UNSUPPORTED, "n_phases must be 1..%d", MPX_MAX_PHASES);
+  if (prob->nx < 1 || prob->nu < 0 || prob->na < 0 || prob->n_segments < 1 || !prob->poly_orders)
+    return fail(nullptr, MPX_ERR_INVALID, "bad dimensions");
+  if (prob->n_segments >= (1 << 23)) return fail(nullptr, MPX_ERR_UNSUPPORTED, "too many segments");
+  if (!(prob->tau1 > prob->tau0)) return fail(nullptr, MPX_ERR_INVALID, "tau1 must exceed tau0");
+  mpx_ctx* c = new (std::nothrow) mpx_ctx;
+  if (!c) return fail(nullptr, MPX_ERR_ALLOC, "out of memory");
+  c->n_phases = prob->n_phases;
+  c->nx = prob->nx;
+  c->nu = prob->nu;
+  c->na = prob->na;
+  c->S = prob->n_segments;
+  c->scheme = prob->scheme;
+  c->tau0 = prob->tau0;
+  c->tau1 = prob->tau1;
+  c->device = prob->device;
+  c->orders.assign(prob->poly_orders, prob->poly_orders + prob->n_segments);
+  if (prob->n_links > 0 && prob->links) c->links.assign(prob->links, prob->links + 2 * prob->n_links);
+  for (size_t l = 0; l < c->links.size(); ++l)
+    if (c->links[l] < 0 || c->links[l] >= c->n_phases) {
+      g_create_error = "phase link out of range";
+      delete c;
+      return MPX_ERR_INVALID;
+    }
+  c->ph.resize(c->n_phases);
+  int rc = parse_structure(c, prob->structure, prob->structure_len);
+  if (!rc) rc = build_tables(c);
+  if (!rc) rc = build_layout(c);
+  if (!rc && c->n_g >= (1LL << 31)) rc = fail(c, MPX_ERR_UNSUPPORTED, "problem too large for int32 patterns");
+  if (!rc && prob->code_object) rc = load_device(c, prob);
+  if (rc) {
+    g_create_error = c->err;
+    mpx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return MPX_OK;
+}
+
+extern "C" int mpx_destroy(mpx_ctx* c) {
+  if (!c) return MPX_OK;
+  if (c->has_device || c->module) {
+    (void)hipSetDevice(c->device);
+    auto fr = [](void* p) {
+      if (p) (void)hipFree(p);
+    };
+    for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk);
+    for (auto& B : c->buckets) fr(B.d_node_i), fr(B.d_node_sk);
+    fr(c->d_tiles), fr(c->d_Wnode), fr(c->d_lin_ptr), fr(c->d_lin_idx), fr(c->d_lin_row), fr(c->d_lin_coef);
+    fr(c->d_mg_dst), fr(c->d_hc_dst), fr(c->d_th_dst);
+    fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
+    fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->module) (void)hipModuleUnload(c->module);
+  }
+  delete c;
+  return MPX_OK;
+}
+
+extern "C" int mpx_get_sizes(const mpx_ctx* c, mpx_sizes* o) {
+  if (!c || !o) return MPX_ERR_INVALID;
+  o->n_z = c->n_z;
+  o->n_p = c->n_p;
+  o->n_g = c->n_g;
+  o->nnz_jac = c->nnz_j;
+  o->nnz_hess = c->nnz_h;
+  o->n_nodes = c->N;
+  o->n_tiles = (int64_t)c->tiles.size();
+  o->bytes_fgj = 8 * (2 * c->n_z + c->n_p + c->n_g + c->nnz_j + 1);
+  o->bytes_hess = 8 * (c->n_z + c->n_p + c->n_g + 1 + c->nnz_h);
+  return MPX_OK;
+}
+
+extern "C" int mpx_pattern_jac(const mpx_ctx* c, int32_t* row, int32_t* col) {
+  if (!c || !row || !col) return MPX_ERR_INVALID;
+  memcpy(row, c->jrow.data(), c->jrow.size() * sizeof(int32_t));
+  memcpy(col, c->jcol.data(), c->jcol.size() * sizeof(int32_t));
+  return MPX_OK;
+}
+
+extern "C" int mpx_pattern_hess(const mpx_ctx* c, int32_t* row, int32_t* col) {
+  if (!c || !row || !col) return MPX_ERR_INVALID;
+  memcpy(row, c->hrow.data(), c->hrow.size() * sizeof(int32_t));
+  memcpy(col, c->hcol.data(), c->hcol.size() * sizeof(int32_t));
+  return MPX_OK;
+}
+
+extern "C" int mpx_ccs_perm(const mpx_ctx* c, int which, int64_t* perm, int64_t* colind) {
+  if (!c || !perm || !colind || (which != MPX_JAC && which != MPX_HESS)) return MPX_ERR_INVALID;
+  const std::vector<int32_t>& r = which == MPX_JAC ? c->jrow : c->hrow;
+  const std::vector<int32_t>& cc = which == MPX_JAC ? c->jcol : c->hcol;
+  const int64_t nnz = (int64_t)r.size();
+  std::iota(perm, perm + nnz, (int64_t)0);
+  std::stable_sort(perm, perm + nnz, [&](int64_t a, int64_t b) { return cc[a] != cc[b] ? cc[a] < cc[b] : r[a] < r[b]; });
+  std::fill(colind, colind + c->n_z + 1, (int64_t)0);
+  for (int64_t k = 0; k < nnz; ++k) colind[cc[k] + 1]++;
+  for (int64_t j = 0; j < c->n_z; ++j) colind[j + 1] += colind[j];
+  return MPX_OK;
+}
+
+extern "C" int mpx_get_comp_weights(const mpx_ctx* c, double* w) {
+  if (!c || !w) return MPX_ERR_INVALID;
+  memcpy(w, c->compW.data(), c->compW.size() * sizeof(double));
+  return MPX_OK;
+}
+
+extern "C" int mpx_set_stream(mpx_ctx* c, void* stream) {
+  if (!c) return MPX_ERR_INVALID;
+  c->stream = (hipStream_t)stream;
+  return MPX_OK;
+}
+
+extern "C" int mpx_set_tile_range(mpx_ctx* c, int64_t b, int64_t e, int run_boundary) {
+  if (!c || b < 0 || e > (int64_t)c->tiles.size() || b > e) return fail(c, MPX_ERR_INVALID, "bad tile range");
+  c->tile_begin = b;
+  c->tile_end = e;
+  c->run_boundary = run_boundary;
+  return MPX_OK;
+}
+
+extern "C" int mpx_get_tile_jac_range(const mpx_ctx* c, int64_t t, int64_t* b, int64_t* e) {
+  if (!c || t < 0 || t >= (int64_t)c->tiles.size() || !b || !e) return MPX_ERR_INVALID;
+  *b = c->tiles[t].jac_base;
+  if (t + 1 < (int64_t)c->tiles.size())
+    *e = c->tiles[t + 1].jac_base;
+  else
+    *e = c->ph[0].jac_TC;
+  return MPX_OK;
+}
+
+extern "C" int mpx_sync(mpx_ctx* c) {
+  if (!c) return MPX_ERR_INVALID;
+  if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "context has no device code");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPX_OK;
+}
+
+extern "C" int mpx_timer_start(mpx_ctx* c) {
+  if (!c || !c->has_device) return MPX_ERR_NO_DEVICE;
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  return MPX_OK;
+}
+
+extern "C" int mpx_timer_stop(mpx_ctx* c, double* ms) {
+  if (!c || !c->has_device || !ms) return MPX_ERR_NO_DEVICE;
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  float f = 0;
+  HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
+  *ms = f;
+  return MPX_OK;
+}
+
+extern "C" int mpx_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point,
+                               const double* lam_g, const double* sigma, double* f, double* g, double* grad_f,
+                               double* jac_val, double* hess_val) {
+  if (!c) return MPX_ERR_INVALID;
+  if (!c->has_device)
+    return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
+  if (batch < 1 || batch > (1 << 30) || !z || !p) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
+  if ((mask & MPX_HESS) && (!lam_g || !sigma || !hess_val)) return fail(c, MPX_ERR_INVALID, "mpx_eval: HESS needs lam_g, sigma, hess_val");
+  if ((mask & MPX_F) && !f) return fail(c, MPX_ERR_INVALID, "mpx_eval: f is NULL");
+  if ((mask & MPX_G) && !g) return fail(c, MPX_ERR_INVALID, "mpx_eval: g is NULL");
+  if ((mask & MPX_GRAD) && !grad_f) return fail(c, MPX_ERR_INVALID, "mpx_eval: grad_f is NULL");
+  if ((mask & MPX_JAC) && !jac_val) return fail(c, MPX_ERR_INVALID, "mpx_eval: jac_val is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t n_w = p_per_point ? batch : 1;
+  int rc;
+  if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
+  if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
+  {
+    int threads = (int)(n_w * c->n_phases);
+    hipLaunchKernelGGL(mpx_prefix_kernel, dim3((threads + 63) / 64), dim3(64), 0, c->stream, p, c->wcum.p, c->S, c->n_phases, (int)n_w);
+    HIPCHK(c, hipGetLastError());
+  }
+  MpxIO io{};
+  io.z = z;
+  io.z_stride = c->n_z;
+  io.w = p;
+  io.wcum = c->wcum.p;
+  io.w_stride = p_per_point ? c->n_p : 0;
+  io.lam_g = lam_g;
+  io.lam_stride = c->n_g;
+  io.sigma = sigma;
+  io.f = (mask & MPX_F) ? f : nullptr;
+  io.g = (mask & MPX_G) ? g : nullptr;
+  io.g_stride = c->n_g;
+  io.grad = (mask & MPX_GRAD) ? grad_f : nullptr;
+  io.grad_stride = c->n_z;
+  io.jac = (mask & MPX_JAC) ? jac_val : nullptr;
+  io.jac_stride = c->nnz_j;
+  io.hess = hess_val;
+  io.hess_stride = c->nnz_h;
+  io.partial = c->partial.p;
+  io.n_tiles_total = (int32_t)c->tiles.size();
+  io.nred = c->nred;
+  io.B = (int32_t)batch;
+  if (mask & (MPX_GRAD | MPX_JAC)) {
+    if ((rc = run_mode(c, MPX_MODE_FGJ, io))) return rc;
+  } else if (mask & (MPX_F | MPX_G)) {
+    if ((rc = run_mode(c, MPX_MODE_FG, io))) return rc;
+  }
+  if (mask & MPX_HESS) {
+    if ((rc = run_mode(c, MPX_MODE_HESS, io))) return rc;
+  }
+  return MPX_OK;
+}
+
+extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point,
+                        const double* lam_g, const double* sigma, double* f, double* g, double* grad_f, double* jac_val,
+                        double* hess_val) {
+  if (!c) return MPX_ERR_INVALID;
+  if (!c->has_device)
+    return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
+  if (batch < 1 || !z || !p) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  const size_t B = (size_t)batch;
+  const size_t npv = (size_t)(p_per_point ? batch : 1) * c->n_p;
+  if ((rc = reserve(c, c->st_z, B * c->n_z)) || (rc = reserve(c, c->st_p, npv))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->st_z.p, z, B * c->n_z * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_p.p, p, npv * 8, hipMemcpyHostToDevice, c->stream));
+  if (mask & MPX_HESS) {
+    if (!lam_g || !sigma || !hess_val) return fail(c, MPX_ERR_INVALID, "mpx_eval: HESS needs lam_g, sigma, hess_val");
+    if ((rc = reserve(c, c->st_lam, B * c->n_g)) || (rc = reserve(c, c->st_sig, B)) || (rc = reserve(c, c->st_hess, B * std::max<int64_t>(c->nnz_h, 1))))
+      return rc;
+    HIPCHK(c, hipMemcpyAsync(c->st_lam.p, lam_g, B * c->n_g * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->st_sig.p, sigma, B * 8, hipMemcpyHostToDevice, c->stream));
+  }
+  if ((mask & MPX_F) && (rc = reserve(c, c->st_f, B))) return rc;
+  if ((mask & MPX_G) && (rc = reserve(c, c->st_g, B * c->n_g))) return rc;
+  if ((mask & MPX_GRAD) && (rc = reserve(c, c->st_grad, B * c->n_z))) return rc;
+  if ((mask & MPX_JAC) && (rc = reserve(c, c->st_jac, B * std::max<int64_t>(c->nnz_j, 1)))) return rc;
+  rc = mpx_eval_device(c, mask, batch, c->st_z.p, c->st_p.p, p_per_point, c->st_lam.p, c->st_sig.p, c->st_f.p, c->st_g.p,
+                       c->st_grad.p, c->st_jac.p, c->st_hess.p);
+  if (rc) return rc;
+  if (mask & MPX_F) HIPCHK(c, hipMemcpyAsync(f, c->st_f.p, B * 8, hipMemcpyDeviceToHost, c->stream));
+  if (mask & MPX_G) HIPCHK(c, hipMemcpyAsync(g, c->st_g.p, B * c->n_g * 8, hipMemcpyDeviceToHost, c->stream));
+  if (mask & MPX_GRAD) HIPCHK(c, hipMemcpyAsync(grad_f, c->st_grad.p, B * c->n_z * 8, hipMemcpyDeviceToHost, c->stream));
+  if (mask & MPX_JAC) HIPCHK(c, hipMemcpyAsync(jac_val, c->st_jac.p, B * c->nnz_j * 8, hipMemcpyDeviceToHost, c->stream));
+  if (mask & MPX_HESS) HIPCHK(c, hipMemcpyAsync(hess_val, c->st_hess.p, B * c->nnz_h * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPX_OK;
+}

@@ -1,0 +1,378 @@
+// mpx_kernels.h -- hand-written gfx950 (MI355X, CDNA4) kernels of the collocation hot path.
+//
+// Compiled once per problem together with the generated `mpxgen::Phase<PH>` structs
+// (mpopt_amd/codegen.py), which hold the traced dynamics / path / cost functions and their
+// symbolic first and second derivatives as straight-line code.
+//
+// What these kernels replace: CasADi's SX virtual machine evaluating nlp_f / nlp_g / nlp_grad_f /
+// nlp_jac_g / nlp_hess_l for mpopt's transcription (created at mpopt.py:757, called from IPOPT at
+// mpopt.py:804).  The mathematics per node follows mpopt.py:154-237, 330-377, 455 (see
+// codegen.py and DESIGN.md section 3).
+//
+// Mapping to the hardware:
+//   * one workgroup (4 wavefronts x 64 lanes) = one tile of whole collocation segments of one
+//     (phase, degree) bucket; lane <-> collocation node; the tile loops over a chunk of the
+//     batch so per-lane tables stay in registers;
+//   * the lane's row of the differentiation matrix D and of the mid-point interpolation matrix
+//     live in VGPRs for the whole batch loop; the segment's states/controls are staged through a
+//     double-buffered LDS tile so the D.X contraction reads neighbours from LDS, one barrier per
+//     evaluation point;
+//   * every global access is lane-contiguous: z is state-major so X[.,a] is a run over nodes; the
+//     Jacobian/Hessian value arrays are laid out tile-major / slot-major / lane-minor, i.e. each
+//     store instruction of a wavefront writes one contiguous run;
+//   * scalar sums (f, d/dt0, d/dtf, d/da, Hessian corner) are reduced in fixed order: DPP
+//     shuffle tree per wavefront -> LDS -> per-tile partial in HBM -> boundary kernel, so results
+//     do not depend on launch geometry or GPU count.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mpx_device.h"
+
+namespace mpxk {
+
+template <int N>
+struct Vec {
+  double v[N > 0 ? N : 1];
+  __device__ __forceinline__ double& operator[](int i) { return v[i]; }
+  __device__ __forceinline__ const double& operator[](int i) const { return v[i]; }
+  __device__ __forceinline__ operator double*() { return v; }
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;  // lane 0 holds the total; fixed tree => deterministic
+}
+
+template <int PH, int P, int MODE>
+__device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
+  using G = mpxgen::Phase<PH>;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
+  constexpr int P1 = P + 1;
+  constexpr int SEGS = MPX_TILE / P;
+  constexpr int SLOTS = (MODE == MPX_MODE_HESS) ? 1 : SEGS * P1;
+  constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : (MODE == MPX_MODE_FGJ ? G::NRED : G::NHC);
+  constexpr int NRED1 = NRED > 0 ? NRED : 1;
+  __shared__ double sXU[2][NX + NU][SLOTS];
+  __shared__ double sRed[2][MPX_TILE / 64][NRED1];
+
+  const MpxTile T = A.tiles[A.tile_first + blockIdx.x];
+  const int l = threadIdx.x;
+  const bool act = l < T.n;
+  const int m = T.m0 + (act ? l : 0);
+  const int i = A.node_i[m];
+  const int sk = A.node_sk[m];
+  const int s = sk >> 8, k = sk & 255;
+  // LDS slot of the lane's segment: tiles hold whole segments of one degree, P lanes each
+  const int base = ((k == 0) ? 0 : (l - T.mu_skip) / P) * P1;
+  const bool halo = act && (k == 1);
+  const int lane = l & 63, wave = l >> 6;
+  const int N = A.N;
+
+  // per-lane rows of D and of the mid-point interpolation matrix, resident for the batch loop
+  double Drow[P1], Crow[P1];
+#pragma unroll
+  for (int j = 0; j < P1; ++j) {
+    Drow[j] = A.Dmat[k * P1 + j];
+    Crow[j] = (k >= 1) ? A.Cmid[(k - 1) * P1 + j] : 0.0;
+  }
+  const double tkk = A.tk[k];
+  const double Wn = A.Wnode[i];
+
+  const MpxIO& io = A.io;
+  const int b0 = blockIdx.y * io.b_per_block;
+  const int b1 = (b0 + io.b_per_block < io.B) ? b0 + io.b_per_block : io.B;
+  const int64_t tslot = (int64_t)T.tile_id * io.nred;
+  int it = 0;
+  for (int b = b0; b < b1; ++b, ++it) {
+    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + A.z_off;
+    Vec<NX> Xs;
+    Vec<NU> Us;
+    Vec<NA> As;
+#pragma unroll
+    for (int a = 0; a < NX; ++a) Xs[a] = zb[(int64_t)a * N + i];
+#pragma unroll
+    for (int c = 0; c < NU; ++c) Us[c] = zb[(int64_t)(NX + c) * N + i];
+    const double* __restrict__ zt = zb + (int64_t)(NX + NU) * N;
+    const double t0v = zt[0], tfv = zt[1];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
+    const int64_t woff = (int64_t)b * io.w_stride + A.seg_off + s;
+    const double ws = io.w[woff], wc = io.wcum[woff];
+    const double kap = ws * A.inv_dtau;  // h = (tf - t0) * kap            (mpopt.py:184)
+    const double th = wc + ws * tkk;     // t = t0 + (tf - t0) * th        (mpopt.py:192, 198)
+    const int buf = it & 1;
+    if constexpr (MODE != MPX_MODE_HESS) {
+      if (act) {
+#pragma unroll
+        for (int a = 0; a < NX; ++a) sXU[buf][a][base + k] = Xs[a];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) sXU[buf][NX + c][base + k] = Us[c];
+        if (halo) {  // first node of the segment belongs to the previous segment (mpopt.py:190-195)
+#pragma unroll
+          for (int a = 0; a < NX + NU; ++a) sXU[buf][a][base] = zb[(int64_t)a * N + i - 1];
+        }
+      }
+    }
+    __syncthreads();
+    if (it > 0 && l < NRED) {  // publish the previous point's tile sums
+      double v = 0;
+#pragma unroll
+      for (int w = 0; w < MPX_TILE / 64; ++w) v += sRed[buf ^ 1][w][l];
+      io.partial[((int64_t)(b - 1) * io.n_tiles_total) * io.nred + tslot + l] = v;
+    }
+
+    Vec<NRED> red;
+    if constexpr (MODE == MPX_MODE_HESS) {
+      Vec<NX> lF;
+      Vec<NC> lC;
+      const double* __restrict__ lb = io.lam_g + (int64_t)b * io.lam_stride;
+#pragma unroll
+      for (int a = 0; a < NX; ++a) lF[a] = lb[A.g_off_F + (int64_t)a * N + i];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) lC[j] = lb[A.g_off_C + (int64_t)j * N + i];
+      Vec<G::NHN> hn;
+      G::hess(Xs, Us, t0v, tfv, As, kap, th, Wn, io.sigma[b], lF, lC, hn, red);
+      if (act) {
+        double* __restrict__ hb = io.hess + (int64_t)b * io.hess_stride + T.hess_base;
+#pragma unroll
+        for (int e = 0; e < G::NHN; ++e) hb[(int64_t)e * T.n + l] = hn[e];
+      }
+    } else {
+      Vec<NX> fx;
+      Vec<NC> cc;
+      Vec<NX> dd;
+      Vec<G::NJV> jv;
+      Vec<NX + NU> gn;
+      if constexpr (MODE == MPX_MODE_FGJ) {
+        G::fgj(Xs, Us, t0v, tfv, As, kap, th, Wn, fx, cc, dd, jv, gn, red);
+      } else {
+        G::fg(Xs, Us, t0v, tfv, As, kap, th, Wn, fx, cc, red[0]);
+      }
+      if (act) {
+        if (io.g) {
+          double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
+#pragma unroll
+          for (int a = 0; a < NX; ++a) {  // defect  F = D.X - h*Sx*dyn      (mpopt.py:227-232)
+            double acc = 0;
+#pragma unroll
+            for (int j = 0; j < P1; ++j) acc = fma(Drow[j], sXU[buf][a][base + j], acc);
+            gb[A.g_off_F + (int64_t)a * N + i] = acc - fx[a];
+          }
+#pragma unroll
+          for (int j = 0; j < NC; ++j) gb[A.g_off_C + (int64_t)j * N + i] = cc[j];  // mpopt.py:204, 255
+          if (A.diff_u) {  // DU = D.U                                        (mpopt.py:315-324)
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+              double acc = 0;
+#pragma unroll
+              for (int j = 0; j < P1; ++j) acc = fma(Drow[j], sXU[buf][NX + c][base + j], acc);
+              gb[A.g_off_DU + (int64_t)c * N + i] = acc;
+            }
+          }
+          if (A.midu && k >= 1) {  // control at the mid-points of the nodes   (mpopt.py:350-369)
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+              double acc = 0;
+#pragma unroll
+              for (int j = 0; j < P1; ++j) acc = fma(Crow[j], sXU[buf][NX + c][base + j], acc);
+              gb[A.g_off_mU + (int64_t)c * (N - 1) + (i - 1)] = acc;
+            }
+          }
+        }
+        if constexpr (MODE == MPX_MODE_FGJ) {
+          if (io.grad) {
+            double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
+#pragma unroll
+            for (int a = 0; a < NX + NU; ++a) qb[(int64_t)a * N + i] = gn[a];
+          }
+          if (io.jac) {
+            double* __restrict__ jb = io.jac + (int64_t)b * io.jac_stride + T.jac_base;
+            const int64_t n = T.n;
+            int64_t q = 0;
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+#pragma unroll
+              for (int j = 0; j < P1; ++j) jb[(q++) * n + l] = (j == k) ? Drow[j] - dd[a] : Drow[j];
+            }
+#pragma unroll
+            for (int e = 0; e < G::NJV; ++e) jb[(q++) * n + l] = jv[e];
+            if (A.diff_u) {
+#pragma unroll
+              for (int c = 0; c < NU; ++c) {
+#pragma unroll
+                for (int j = 0; j < P1; ++j) jb[(q++) * n + l] = Drow[j];
+              }
+            }
+            if (A.midu) {
+              const int64_t n2 = n - T.mu_skip;
+              const int l2 = l - T.mu_skip;
+              double* __restrict__ jm = jb + q * n;
+              if (l2 >= 0) {
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+#pragma unroll
+                  for (int j = 0; j < P1; ++j) jm[(int64_t)(c * P1 + j) * n2 + l2] = Crow[j];
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    // tile sums
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) {
+      double v = wave_sum(act ? red[r] : 0.0);
+      if (lane == 0) sRed[buf][wave][r] = v;
+    }
+  }
+  __syncthreads();
+  if (it > 0 && l < NRED) {
+    double v = 0;
+#pragma unroll
+    for (int w = 0; w < MPX_TILE / 64; ++w) v += sRed[(it - 1) & 1][w][l];
+    io.partial[((int64_t)(b1 - 1) * io.n_tiles_total) * io.nred + tslot + l] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Boundary kernel: one workgroup per evaluation point.  Finishes the fixed-order reductions,
+// evaluates Mayer cost and terminal constraints (mpopt.py:264-300), the linear rows that couple
+// segments or phases (control-slope continuity mpopt.py:379-413, events mpopt.py:464-521) and
+// scatters their derivative entries.
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXRED = 64;
+
+template <int PH, int MODE>
+__device__ __forceinline__ void boundary_phase(const MpxBoundArgs& A, int b, int l, double* red, double& facc) {
+  using G = mpxgen::Phase<PH>;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA;
+  constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : (MODE == MPX_MODE_FGJ ? G::NRED : G::NHC);
+  static_assert(NRED <= MAXRED, "too many reduced quantities");
+  const MpxIO& io = A.io;
+  const MpxPhaseInfo& P = A.ph[PH];
+  if (l < NRED) {
+    double s = 0;
+    const double* pp = io.partial + ((int64_t)b * io.n_tiles_total + P.tile_first) * io.nred + l;
+    for (int t = 0; t < P.tile_count; ++t) s += pp[(int64_t)t * io.nred];
+    red[l] = s;
+  }
+  __syncthreads();
+  if (l == 0) {
+    const int N = P.N;
+    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + P.z_off;
+    Vec<NX> XF, X0;
+    Vec<NA> As;
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+      XF[a] = zb[(int64_t)a * N + N - 1];
+      X0[a] = zb[(int64_t)a * N];
+    }
+    const double* zt = zb + (int64_t)(NX + NU) * N;
+    const double t0v = zt[0], tfv = zt[1];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
+    double M = 0;
+    Vec<G::NTC> tc;
+    if constexpr (MODE == MPX_MODE_FG) {
+      G::term_fg(XF, tfv, X0, t0v, As, M, tc);
+      facc += red[0] + M;
+      if (io.g)
+        for (int j = 0; j < G::NTC; ++j) io.g[(int64_t)b * io.g_stride + P.g_off_TC + j] = tc[j];
+    } else if constexpr (MODE == MPX_MODE_FGJ) {
+      Vec<G::NMG> mg;
+      Vec<G::NTJ> tj;
+      G::term_fgj(XF, tfv, X0, t0v, As, M, tc, mg, tj);
+      facc += red[0] + M;
+      if (io.g)
+        for (int j = 0; j < G::NTC; ++j) io.g[(int64_t)b * io.g_stride + P.g_off_TC + j] = tc[j];
+      if (io.grad) {
+        double* qb = io.grad + (int64_t)b * io.grad_stride;
+        double* qt = qb + P.z_off + (int64_t)(NX + NU) * N;
+        for (int r = 0; r < 2 + NA; ++r) qt[r] = red[1 + r];
+        for (int e = 0; e < G::NMG; ++e) qb[A.mg_dst[A.mg_off[PH] + e]] += mg[e];
+      }
+      if (io.jac) {
+        double* jb = io.jac + (int64_t)b * io.jac_stride + P.jac_TC;
+        for (int e = 0; e < G::NTJ; ++e) jb[e] = tj[e];
+      }
+    } else {
+      Vec<G::NTC> lT;
+      const double* lb = io.lam_g + (int64_t)b * io.lam_stride + P.g_off_TC;
+      for (int j = 0; j < G::NTC; ++j) lT[j] = lb[j];
+      Vec<G::NTH> th;
+      G::term_hess(XF, tfv, X0, t0v, As, io.sigma[b], lT, th);
+      double* hb = io.hess + (int64_t)b * io.hess_stride;
+      for (int e = 0; e < G::NHC; ++e) hb[A.hc_dst[A.hc_off[PH] + e]] = red[e];
+      for (int e = 0; e < G::NTH; ++e) {
+        const int64_t d = A.th_dst[A.th_off[PH] + e];
+        if (d & MPX_ACCUM_BIT)
+          hb[d & ~MPX_ACCUM_BIT] += th[e];
+        else
+          hb[d] = th[e];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <int PH, int MODE>
+struct PhaseLoop {
+  __device__ static __forceinline__ void run(const MpxBoundArgs& A, int b, int l, double* red, double& facc) {
+    PhaseLoop<PH - 1, MODE>::run(A, b, l, red, facc);
+    boundary_phase<PH, MODE>(A, b, l, red, facc);
+  }
+};
+template <int MODE>
+struct PhaseLoop<-1, MODE> {
+  __device__ static __forceinline__ void run(const MpxBoundArgs&, int, int, double*, double&) {}
+};
+
+template <int MODE>
+__device__ __forceinline__ void boundary_body(const MpxBoundArgs& A) {
+  __shared__ double red[MAXRED];
+  const int b = blockIdx.x, l = threadIdx.x;
+  const MpxIO& io = A.io;
+  double facc = 0;
+  PhaseLoop<MPX_NPH - 1, MODE>::run(A, b, l, red, facc);
+  if constexpr (MODE != MPX_MODE_HESS) {
+    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride;
+    for (int r = l; r < A.n_lin; r += blockDim.x) {
+      const int64_t e0 = A.lin_ptr[r], e1 = A.lin_ptr[r + 1];
+      double s = 0;
+      for (int64_t e = e0; e < e1; ++e) s = fma(A.lin_coef[e], zb[A.lin_idx[e]], s);
+      if (io.g) io.g[(int64_t)b * io.g_stride + A.lin_row[r]] = s;
+      if constexpr (MODE == MPX_MODE_FGJ) {
+        if (io.jac) {
+          double* jb = io.jac + (int64_t)b * io.jac_stride + A.lin_jac;
+          for (int64_t e = e0; e < e1; ++e) jb[e] = A.lin_coef[e];
+        }
+      }
+    }
+    if (l == 0 && io.f) io.f[b] = facc;
+  }
+}
+}  // namespace mpxk
+
+#define MPX_INSTANTIATE_NODE(PH, P)                                                                         \
+  extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_node_fg_##PH##_##P(const MpxNodeArgs A) {      \
+    mpxk::node_body<PH, P, MPX_MODE_FG>(A);                                                                 \
+  }                                                                                                         \
+  extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_node_fgj_##PH##_##P(const MpxNodeArgs A) {     \
+    mpxk::node_body<PH, P, MPX_MODE_FGJ>(A);                                                                \
+  }                                                                                                         \
+  extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_node_hess_##PH##_##P(const MpxNodeArgs A) {    \
+    mpxk::node_body<PH, P, MPX_MODE_HESS>(A);                                                               \
+  }
+
+#define MPX_INSTANTIATE_BOUNDARY()                                                                          \
+  extern "C" __global__ __launch_bounds__(256) void mpx_boundary_fg(const MpxBoundArgs A) {                 \
+    mpxk::boundary_body<MPX_MODE_FG>(A);                                                                    \
+  }                                                                                                         \
+  extern "C" __global__ __launch_bounds__(256) void mpx_boundary_fgj(const MpxBoundArgs A) {                \
+    mpxk::boundary_body<MPX_MODE_FGJ>(A);                                                                   \
+  }                                                                                                         \
+  extern "C" __global__ __launch_bounds__(256) void mpx_boundary_hess(const MpxBoundArgs A) {               \
+    mpxk::boundary_body<MPX_MODE_HESS>(A);                                                                  \
+  }

@@ -1,0 +1,599 @@
+"""Host-side mirror of the reference's public interface for the collocation hot path.
+
+Same names, argument meaning and defaults as ``/root/reference/mpopt/mpopt.py`` for
+
+    OCP                 (mpopt.py:3378-3703)   problem container -- pure data + arity adapters
+    CollocationRoots    (mpopt.py:4134-4276)   node sets
+    Collocation         (mpopt.py:3706-4131)   D / W / interpolation tables and composites
+    mpopt               (mpopt.py:31-855)      transcription OCP -> NLP and the solve entry
+    solve               (mpopt.py:4279-4308)
+
+but nothing here builds a CasADi graph: the tables come from libmpx (mpx_colloc_*), and the NLP
+functions f, g, grad_f, jac_g, hess_l are ``NlpFunctions`` (GPU kernels behind the C ABI).
+Post-solve analysis, plotting and the adaptive subclasses are out of scope.
+"""
+import copy
+import time
+
+import numpy as np
+
+from . import _lib
+from .nlp import NlpFunctions
+
+
+# ---------------------------------------------------------------------------------------------
+class OCP:
+    """Optimal control problem in Bolza form; attribute-for-attribute the reference's ``OCP``."""
+
+    LB_DYNAMICS = 0
+    UB_DYNAMICS = 0
+    LB_PATH_CONSTRAINTS = -np.inf
+    UB_PATH_CONSTRAINTS = 0
+    LB_TERMINAL_CONSTRAINTS = 0
+    UB_TERMINAL_CONSTRAINTS = 0
+
+    def __init__(self, n_states=1, n_controls=1, n_phases=1, n_params=0, **kwargs):
+        self.nx, self.nu, self.na, self.n_phases = n_states, n_controls, n_params, n_phases
+        P = n_phases
+        self.dynamics = [lambda x, u, t, a=None: [0] * self.nx] * P
+        self.path_constraints = [lambda x, u, t, a=None: None] * P
+        self.terminal_costs = [lambda xf, tf, x0, t0, a=None: 0] * P
+        self.running_costs = [lambda x, u, t, a=None: 0] * P
+        self.terminal_constraints = [lambda xf, tf, x0, t0, a=None: None] * P
+        self.phase_links = [(i, i + 1) for i in range(P - 1)]
+        # scaling
+        self.scale_x, self.scale_u, self.scale_a = np.ones(self.nx), np.ones(self.nu), np.ones(self.na)
+        self.scale_t = 1.0
+        # initial guess
+        self.x00, self.xf0 = np.zeros((P, self.nx)), np.zeros((P, self.nx))
+        self.u00, self.uf0 = np.zeros((P, self.nu)), np.zeros((P, self.nu))
+        self.t00, self.tf0 = np.zeros((P, 1)), np.ones((P, 1))
+        self.a0 = np.zeros((P, self.na))
+        # bounds
+        self.lbx, self.ubx = np.full((P, self.nx), -np.inf), np.full((P, self.nx), np.inf)
+        self.lbu, self.ubu = np.full((P, self.nu), -np.inf), np.full((P, self.nu), np.inf)
+        self.lba, self.uba = np.full((P, self.na), -np.inf), np.full((P, self.na), np.inf)
+        self.lbt0, self.ubt0 = np.zeros((P, 1)), np.full((P, 1), np.inf)
+        self.ubt0[0] = 0.0  # the first phase starts at t = 0
+        self.lbtf, self.ubtf = np.zeros((P, 1)), np.full((P, 1), np.inf)
+        self.lbe, self.ube = np.zeros((P - 1, self.nx)), np.zeros((P - 1, self.nx))
+        # optional row blocks
+        self.diff_u = np.zeros(P, dtype=int)
+        self.lbdu, self.ubdu = np.full(P, -15), np.full(P, 15)
+        self.midu = np.ones(P, dtype=int)
+        self.du_continuity = np.zeros(P, dtype=int)
+        # post-processing defaults (kept for interface compatibility)
+        self.n_figures = 1
+        self.phases_to_plot = [tuple(range(P))]
+        self.plot_type = 1
+        self.plot_interpolation_level = 3
+
+    # arity adapters: user functions omit `a` when the problem has no parameters
+    def _node_fn(self, table, phase):
+        fn = table[phase]
+        return (lambda x, u, t, a: fn(x, u, t)) if self.na == 0 else fn
+
+    def _term_fn(self, table, phase):
+        fn = table[phase]
+        return (lambda xf, tf, x0, t0, a: fn(xf, tf, x0, t0)) if self.na == 0 else fn
+
+    def get_dynamics(self, phase=0):
+        return self._node_fn(self.dynamics, phase)
+
+    def get_path_constraints(self, phase=0):
+        return self._node_fn(self.path_constraints, phase)
+
+    def get_running_costs(self, phase=0):
+        return self._node_fn(self.running_costs, phase)
+
+    def get_terminal_constraints(self, phase=0):
+        return self._term_fn(self.terminal_constraints, phase)
+
+    def get_terminal_costs(self, phase=0):
+        return self._term_fn(self.terminal_costs, phase)
+
+    def has_path_constraints(self, phase=0):
+        args = (self.x00[phase], self.u00[phase], self.t00[phase]) + ((self.a0[phase],) if self.na else ())
+        return self.path_constraints[phase](*args) is not None
+
+    def has_terminal_constraints(self, phase=0):
+        args = (self.xf0[phase], self.tf0[phase], self.x00[phase], self.t00[phase]) + ((self.a0[phase],) if self.na else ())
+        return self.terminal_constraints[phase](*args) is not None
+
+    def validate(self):
+        P = self.n_phases
+        assert P > 0
+        for name in ("dynamics", "running_costs", "terminal_costs", "path_constraints", "terminal_constraints"):
+            assert len(getattr(self, name)) == P, name
+        for ph in range(P):
+            x, u, t, a = self.x00[ph], self.u00[ph], self.t00[ph], self.a0[ph]
+            assert len(self.get_dynamics(ph)(x, u, t, a)) == self.nx
+            assert self.get_terminal_costs(ph)(x, t, x, t, a) is not None
+            assert self.get_running_costs(ph)(x, u, t, a) is not None
+            pc = self.get_path_constraints(ph)(x, u, t, a)
+            tc = self.get_terminal_constraints(ph)(x, t, x, t, a)
+            assert pc is None or len(pc) > 0
+            assert tc is None or len(tc) > 0
+        assert len(self.scale_x) == self.nx and len(self.scale_u) == self.nu and len(self.scale_a) == self.na
+        for name, n in (("x00", self.nx), ("xf0", self.nx), ("u00", self.nu), ("uf0", self.nu), ("a0", self.na),
+                        ("t00", 1), ("tf0", 1), ("lbx", self.nx), ("ubx", self.nx), ("lbu", self.nu), ("ubu", self.nu),
+                        ("lba", self.na), ("uba", self.na), ("lbt0", 1), ("ubt0", 1), ("lbtf", 1), ("ubtf", 1)):
+            assert np.shape(getattr(self, name)) == (P, n), name
+        assert np.shape(self.lbe)[0] == P - 1 and np.shape(self.ube)[0] == P - 1
+        if P > 1:
+            assert np.shape(self.lbe)[1] == self.nx and np.shape(self.ube)[1] == self.nx
+        for ph in range(P):
+            assert (np.asarray(self.lbx[ph]) <= np.asarray(self.ubx[ph])).all()
+            assert (np.asarray(self.lbu[ph]) <= np.asarray(self.ubu[ph])).all()
+            assert (np.asarray(self.lba[ph]) <= np.asarray(self.uba[ph])).all()
+            assert self.lbt0[ph] <= self.ubt0[ph] and self.lbtf[ph] <= self.ubtf[ph]
+            if ph < P - 1:
+                assert (np.asarray(self.lbe[ph]) <= np.asarray(self.ube[ph])).all()
+
+
+# ---------------------------------------------------------------------------------------------
+class _Mat(np.ndarray):
+    """ndarray with CasADi-DM's ``full()`` so callers written against the reference keep working."""
+
+    def full(self):
+        return np.asarray(self)
+
+
+def _mat(a):
+    return np.asarray(a, dtype=float).view(_Mat)
+
+
+class CollocationRoots:
+    """Node sets LG / LGR / LGL / CGL on [_TAU_MIN, _TAU_MAX] (mpopt.py:4134-4276) via libmpx."""
+
+    _TAU_MIN = -1
+    _TAU_MAX = 1
+
+    def __init__(self, scheme="LGR"):
+        self.scheme = scheme
+        self._taus_fn = self.get_collocation_points(scheme)
+
+    @classmethod
+    def get_collocation_points(cls, scheme):
+        return cls._make(_lib.SCHEMES.get(scheme, _lib.SCHEME_EQUI), cls._TAU_MIN, cls._TAU_MAX)
+
+    @staticmethod
+    def _make(scheme_id, tau_min, tau_max):
+        def taus(deg):
+            L = _lib.lib()
+            n = L.mpx_colloc_n_nodes(scheme_id, int(deg))
+            if n < 0:
+                raise ValueError(f"degree {deg} is invalid for this scheme")
+            out = np.empty(n)
+            _lib.check(L.mpx_colloc_roots(scheme_id, int(deg), float(tau_min), float(tau_max), _lib.dptr(out)))
+            return out
+
+        return taus
+
+    @staticmethod
+    def roots_legendre_gauss(tau_min=-1, tau_max=1):
+        return CollocationRoots._make(_lib.SCHEMES["LG"], tau_min, tau_max)
+
+    @staticmethod
+    def roots_legendre_gauss_radau(tau_min=-1, tau_max=1):
+        return CollocationRoots._make(_lib.SCHEMES["LGR"], tau_min, tau_max)
+
+    @staticmethod
+    def roots_legendre_gauss_lobatto(tau_min=-1, tau_max=1):
+        return CollocationRoots._make(_lib.SCHEMES["LGL"], tau_min, tau_max)
+
+    @staticmethod
+    def roots_chebyshev_gauss_lobatto(tau_min=-1, tau_max=1):
+        return CollocationRoots._make(_lib.SCHEMES["CGL"], tau_min, tau_max)
+
+
+class _Basis:
+    """Callable Lagrange basis polynomial l_j on a node set (what ``polys[key][j]`` is used for)."""
+
+    def __init__(self, nodes, j):
+        self.nodes, self.j = np.ascontiguousarray(nodes, dtype=float), j
+
+    def __call__(self, tau):
+        taus = np.ascontiguousarray(np.atleast_1d(tau), dtype=float)
+        C = np.empty((len(taus), len(self.nodes)))
+        _lib.check(_lib.lib().mpx_colloc_interp_matrix(_lib.dptr(self.nodes), len(self.nodes), _lib.dptr(taus), len(taus), _lib.dptr(C)))
+        return C[:, self.j] if np.ndim(tau) else float(C[0, self.j])
+
+
+class Collocation:
+    """Differentiation / quadrature / interpolation tables (mpopt.py:3706-4131).
+
+    ``D_MATRIX_METHOD`` is accepted for compatibility; both values select the same native
+    implementation (barycentric D, exact interpolatory quadrature), which agrees with the
+    reference's "numerical" back-end to rounding and is more accurate at high degree."""
+
+    D_MATRIX_METHOD = "symbolic"
+
+    def __init__(self, poly_orders=[], scheme="LGR", polynomial_type="lagrange"):
+        self.poly_orders = poly_orders
+        colloc_roots = CollocationRoots(scheme)
+        self._taus_fn = colloc_roots._taus_fn
+        self.tau0, self.tau1 = colloc_roots._TAU_MIN, colloc_roots._TAU_MAX
+        self.poly_fn = self.get_polynomial_function(polynomial_type)
+        self.roots, self.polys = {}, {}
+        self.unique_polys = set(self.poly_orders)
+        self.init_polynomials(self.unique_polys)
+        self.diff_matrix_fn = self.get_diff_matrix_fn(polynomial_type)
+        self.quad_matrix_fn = self.get_quadrature_weights_fn(polynomial_type)
+
+    @classmethod
+    def get_diff_matrix_fn(cls, polynomial_type="lagrange"):
+        return cls.get_diff_matrix
+
+    @classmethod
+    def get_quadrature_weights_fn(cls, polynomial_type="lagrange"):
+        return cls.get_quadrature_weights
+
+    @classmethod
+    def get_polynomial_function(cls, polynomial_type="lagrange"):
+        return cls.get_lagrange_polynomials if polynomial_type == "lagrange" else 0
+
+    @classmethod
+    def get_lagrange_polynomials(cls, roots):
+        return [_Basis(roots, j) for j in range(len(roots))]
+
+    def init_polynomials(self, poly_orders):
+        for degree in poly_orders:
+            self.roots[degree] = self._taus_fn(degree)
+            self.polys[degree] = self.poly_fn(self.roots[degree])
+
+    def init_polynomials_with_customized_roots(self, roots_dict=None):
+        for key in roots_dict:
+            self.roots[key] = np.asarray(roots_dict[key], dtype=float)
+            self.polys[key] = self.poly_fn(self.roots[key])
+
+    def _nodes(self, key):
+        if key not in self.roots or key not in self.polys:
+            self.init_polynomials([key])
+        return np.ascontiguousarray(self.roots[key], dtype=float)
+
+    def get_diff_matrix(self, key, taus=None, order=1):
+        x = self._nodes(key)
+        n = len(x)
+        if taus is None:
+            D = np.empty((n, n))
+            _lib.check(_lib.lib().mpx_colloc_diff_matrix(_lib.dptr(x), n, None, 0, int(order), _lib.dptr(D)))
+        else:
+            t = np.ascontiguousarray(taus, dtype=float)
+            D = np.empty((len(t), n))
+            if len(t):
+                _lib.check(_lib.lib().mpx_colloc_diff_matrix(_lib.dptr(x), n, _lib.dptr(t), len(t), int(order), _lib.dptr(D)))
+        return _mat(D)
+
+    def get_quadrature_weights(self, key, tau0=None, tau1=None):
+        x = self._nodes(key)
+        a = self.tau0 if tau0 is None else tau0
+        b = self.tau1 if tau1 is None else tau1
+        w = np.empty(len(x))
+        _lib.check(_lib.lib().mpx_colloc_quad_weights(_lib.dptr(x), len(x), float(a), float(b), _lib.dptr(w)))
+        return _mat(w.reshape(-1, 1))
+
+    def get_interpolation_matrix(self, taus, degree):
+        x = self._nodes(degree)
+        t = np.ascontiguousarray(taus, dtype=float)
+        C = np.empty((len(t), len(x)))
+        if len(t):
+            _lib.check(_lib.lib().mpx_colloc_interp_matrix(_lib.dptr(x), len(x), _lib.dptr(t), len(t), _lib.dptr(C)))
+        return _mat(C)
+
+    def get_diff_matrices(self, poly_orders=None, order=1):
+        keys = self.unique_polys if poly_orders is None else set(poly_orders)
+        return {d: self.diff_matrix_fn(self, d, order=order) for d in keys}
+
+    def get_interpolation_Dmatrices_at(self, taus, keys=None, order=1):
+        keys = self.poly_orders if keys is None else keys
+        return {i: self.diff_matrix_fn(self, key, taus=taus[i], order=order) for i, key in enumerate(keys)}
+
+    def get_quad_weight_matrices(self, keys=None, tau0=None, tau1=None):
+        keys = self.unique_polys if keys is None else set(keys)
+        a = self.tau0 if tau0 is None else tau0
+        b = self.tau1 if tau1 is None else tau1
+        return {k: self.quad_matrix_fn(self, k, tau0=a, tau1=b) for k in keys}
+
+    def get_interpolation_matrices(self, taus, poly_orders=None):
+        poly_orders = self.poly_orders if poly_orders is None else poly_orders
+        return {i: self.get_interpolation_matrix(taus[i], d) for i, d in enumerate(poly_orders)}
+
+    # composites: dense, as the reference returns them (mpopt.py:4015-4131).  The GPU path never
+    # forms them; they exist for callers and parity tests.
+    def get_composite_differentiation_matrix(self, poly_orders=None, order=1):
+        D = self.get_diff_matrices(poly_orders, order=order)
+        poly_orders = self.poly_orders if poly_orders is None else poly_orders
+        n = sum(poly_orders) + 1
+        out = np.zeros((n, n))
+        start = 0
+        for i, p in enumerate(poly_orders):
+            if i == 0:
+                out[0:p + 1, 0:p + 1] = D[p]
+            else:
+                out[start + 1:start + 1 + p, start:start + p + 1] = np.asarray(D[p])[1:, :]
+            start += p
+        return _mat(out)
+
+    def get_composite_quadrature_weights(self, poly_orders=None, tau0=None, tau1=None):
+        poly_orders = self.poly_orders if poly_orders is None else poly_orders
+        W = self.get_quad_weight_matrices(poly_orders, tau0=tau0, tau1=tau1)
+        parts = [np.asarray(W[poly_orders[0]]).ravel()[:1]] + [np.asarray(W[p]).ravel()[1:] for p in poly_orders]
+        return _mat(np.concatenate(parts).reshape(1, -1))
+
+    def _composite(self, blocks, taus, poly_orders):
+        n_nodes = sum(poly_orders) + 1
+        n_taus = [len(t) for t in taus]
+        out = np.zeros((sum(n_taus), n_nodes))
+        r = c = 0
+        for i, p in enumerate(poly_orders):
+            if n_taus[i]:
+                out[r:r + n_taus[i], c:c + p + 1] = blocks[i]
+            r += n_taus[i]
+            c += p
+        return out
+
+    def get_composite_interpolation_matrix(self, taus, poly_orders=None):
+        C = self.get_interpolation_matrices(taus, poly_orders)
+        poly_orders = self.poly_orders if poly_orders is None else poly_orders
+        return self._composite(C, taus, poly_orders)
+
+    def get_composite_interpolation_Dmatrix_at(self, taus, poly_orders=None, order=1):
+        D = self.get_interpolation_Dmatrices_at(taus, keys=poly_orders, order=order)
+        poly_orders = self.poly_orders if poly_orders is None else poly_orders
+        return self._composite(D, taus, poly_orders)
+
+
+# ---------------------------------------------------------------------------------------------
+class _NlpSymbol:
+    """Placeholder for the reference's SX entries of the nlp dict (f, x, g, p)."""
+
+    def __init__(self, name, size, oracle):
+        self.name, self.size, self.oracle = name, size, oracle
+
+    def size1(self):
+        return self.size
+
+    def __repr__(self):
+        return f"<{self.name}[{self.size}] of {self.oracle.__class__.__name__}>"
+
+
+class mpopt:
+    """Transcription of a multi-phase OCP to an NLP on a pseudo-spectral grid (mpopt.py:31-855)."""
+
+    _GRID_TYPE = "fixed"
+    _MAX_GRID_POINTS = 15
+    _MUTE_ = False
+
+    def __init__(self, problem, n_segments=1, poly_orders=[9], scheme="LGR", **kwargs):
+        self.n_segments = n_segments
+        self.poly_orders = [poly_orders] * n_segments if isinstance(poly_orders, (int, np.integer)) else list(poly_orders)
+        self._ocp = copy.deepcopy(problem)
+        self.colloc_scheme = scheme
+        self.reset_mpopt()
+
+    def reset_mpopt(self):
+        assert len(self.poly_orders) == self.n_segments
+        self._Npoints = sum(self.poly_orders) + 1
+        self._collocation_approximation_computed = False
+        self._variables_created = False
+        self._nlpsolver_initialized = False
+        self.grid_type = [self._GRID_TYPE] * self._ocp.n_phases
+        self.max_grid_points = [self._MAX_GRID_POINTS] * self._ocp.n_phases
+        self.oracle = None
+
+    def compute_numerical_approximation(self, scheme=None):
+        scheme = self.colloc_scheme if scheme is None else scheme
+        self.collocation = Collocation(self.poly_orders, scheme)
+        self._taus = self.collocation.roots
+        self.tau0, self.tau1 = self.collocation.tau0, self.collocation.tau1
+        self._collocation_approximation_computed = True
+
+    @property
+    def _compD(self):
+        return self.collocation.get_composite_differentiation_matrix()
+
+    @property
+    def _compW(self):
+        return self.collocation.get_composite_quadrature_weights()
+
+    def create_variables(self):
+        o = self._ocp
+        self._optimization_vars_per_phase = self._Npoints * (o.nx + o.nu) + o.n_phases * o.na + 2
+        self._variables_created = True
+
+    # ---- bounds -------------------------------------------------------------------------
+    def _midu_rows(self, phase):
+        o = self._ocp
+        return bool(o.midu[phase]) and bool((np.asarray(o.lbu[phase]) > -np.inf).any() or (np.asarray(o.ubu[phase]) < np.inf).any())
+
+    def get_nlp_variables(self, phase):
+        """(Z, Zmin, Zmax) of one phase; layout [vec(X); vec(U); t0; tf; A], state-major."""
+        o, N = self._ocp, self._Npoints
+        sx, su, sa, st = np.asarray(o.scale_x, float), np.asarray(o.scale_u, float), np.asarray(o.scale_a, float), o.scale_t
+        xmin = np.tile(np.asarray(o.lbx[phase], float) * sx, (N, 1))
+        xmax = np.tile(np.asarray(o.ubx[phase], float) * sx, (N, 1))
+        if phase == 0:  # initial state fixed through equal bounds
+            xmin[0] = xmax[0] = np.asarray(o.x00[0], float) * sx
+        zmin = np.concatenate([xmin.T.ravel(), np.repeat(np.asarray(o.lbu[phase], float) * su, N),
+                               np.asarray(o.lbt0[phase], float).ravel() * st, np.asarray(o.lbtf[phase], float).ravel() * st,
+                               np.asarray(o.lba[phase], float) * sa])
+        zmax = np.concatenate([xmax.T.ravel(), np.repeat(np.asarray(o.ubu[phase], float) * su, N),
+                               np.asarray(o.ubt0[phase], float).ravel() * st, np.asarray(o.ubtf[phase], float).ravel() * st,
+                               np.asarray(o.uba[phase], float) * sa])
+        n = len(zmin)
+        return (_NlpSymbol(f"z{phase}", n, self.oracle), zmin, zmax)
+
+    def _phase_row_bounds(self, phase):
+        o, N, S = self._ocp, self._Npoints, self.n_segments
+        prog = self.oracle.program.phases[phase]
+        lo, hi = [], []
+
+        def block(n, a, b):
+            lo.append(np.full(n, a, dtype=float)), hi.append(np.full(n, b, dtype=float))
+
+        block(o.nx * N, o.LB_DYNAMICS, o.UB_DYNAMICS)
+        block(prog.nc * N, o.LB_PATH_CONSTRAINTS, o.UB_PATH_CONSTRAINTS)
+        if o.diff_u[phase]:
+            block(o.nu * N, o.lbdu[phase], o.ubdu[phase])
+        if self._midu_rows(phase):
+            n_mid = N - 1
+            lo.append(np.repeat(np.asarray(o.lbu[phase], float) * np.asarray(o.scale_u, float), n_mid))
+            hi.append(np.repeat(np.asarray(o.ubu[phase], float) * np.asarray(o.scale_u, float), n_mid))
+        if o.du_continuity[phase] and S > 1:
+            block(o.nu * (S - 1), 0, 0)
+        block(prog.ntc, o.LB_TERMINAL_CONSTRAINTS, o.UB_TERMINAL_CONSTRAINTS)
+        return np.concatenate(lo), np.concatenate(hi)
+
+    def get_event_constraints(self):
+        o = self._ocp
+        if o.n_phases < 2:
+            return ([], [], [])
+        n = len(o.phase_links)
+        sx = np.asarray(o.scale_x, float)
+        emin = [np.concatenate([np.asarray(o.lbe[ph], float) * sx for ph in range(n)]), np.zeros(o.nu * n), np.zeros(n)]
+        emax = [np.concatenate([np.asarray(o.ube[ph], float) * sx for ph in range(n)]), np.zeros(o.nu * n), np.zeros(n)]
+        return ([_NlpSymbol(f"E{k}", len(emin[k]), self.oracle) for k in range(3)], emin, emax)
+
+    def create_nlp(self):
+        """Returns ``(nlp_prob, nlp_bounds)`` with the reference's keys.  ``f,x,g,p`` are handles on
+        the GPU oracle object (``nlp_prob["oracle"]``) instead of CasADi expressions."""
+        o = self._ocp
+        self.compute_numerical_approximation()
+        self.create_variables()
+        self.oracle = NlpFunctions(o, self.n_segments, self.poly_orders, self.colloc_scheme, tau0=self.tau0,
+                                   tau1=self.tau1, midu_rows=[self._midu_rows(ph) for ph in range(o.n_phases)])
+        zmin, zmax, gmin, gmax = [], [], [], []
+        for ph in range(o.n_phases):
+            _, a, b = self.get_nlp_variables(ph)
+            zmin.append(a), zmax.append(b)
+            a, b = self._phase_row_bounds(ph)
+            gmin.append(a), gmax.append(b)
+        if o.n_phases > 1:
+            _, emin, emax = self.get_event_constraints()
+            gmin.extend(emin), gmax.extend(emax)
+        self.Zmin, self.Zmax = np.concatenate(zmin), np.concatenate(zmax)
+        self.Gmin, self.Gmax = np.concatenate(gmin), np.concatenate(gmax)
+        assert len(self.Zmin) == self.oracle.n_z and len(self.Gmin) == self.oracle.n_g, "layout mismatch with libmpx"
+        orc = self.oracle
+        nlp_prob = {"f": _NlpSymbol("f", 1, orc), "x": _NlpSymbol("x", orc.n_z, orc), "g": _NlpSymbol("g", orc.n_g, orc),
+                    "p": _NlpSymbol("p", orc.n_p, orc), "oracle": orc}
+        nlp_bounds = {"lbg": self.Gmin, "ubg": self.Gmax, "lbx": self.Zmin, "ubx": self.Zmax}
+        return (nlp_prob, nlp_bounds)
+
+    # ---- initial guess ------------------------------------------------------------------
+    def init_solution_per_phase(self, phase):
+        o, N = self._ocp, self._Npoints
+        sx, su, sa, st = np.asarray(o.scale_x, float), np.asarray(o.scale_u, float), np.asarray(o.scale_a, float), o.scale_t
+        x00, xf0 = np.asarray(o.x00[phase], float) * sx, np.asarray(o.xf0[phase], float) * sx
+        u00, uf0 = np.asarray(o.u00[phase], float) * su, np.asarray(o.uf0[phase], float) * su
+        t00, tf0 = np.asarray(o.t00[phase], float) * st, np.asarray(o.tf0[phase], float) * st
+        a0 = np.asarray(o.a0[phase], float) * sa
+        ts = np.linspace(t00, tf0, N)  # linear in node index, (N,1)
+        X = np.array([x00 + (xf0 - x00) / (tf0 - t00) * (t - t00) for t in ts])
+        U = np.array([u00 + (uf0 - u00) / (tf0 - t00) * (t - t00) for t in ts])
+        return np.concatenate([X.T.ravel(), _ref_control_order(U), t00, tf0, a0])
+
+    def initialize_solution(self):
+        return np.concatenate([self.init_solution_per_phase(ph) for ph in range(self._ocp.n_phases)])
+
+    def get_segment_width_parameters(self, solution):
+        return [1.0 / self.n_segments] * (self.n_segments * self._ocp.n_phases)
+
+    # ---- solver -------------------------------------------------------------------------
+    def create_solver(self, solver="ipopt", options={}):
+        from .solver import NlpSolver
+
+        nlp_problem, self.nlp_bounds = self.create_nlp()
+        defaults = {"ipopt.max_iter": 2000, "ipopt.acceptable_tol": 1e-4, "ipopt.print_level": 0, "ipopt.sb": "yes",
+                    "print_time": 0} if solver == "ipopt" else {}
+        defaults.update(options)
+        self.nlp_solver = NlpSolver("solver", solver, nlp_problem, defaults)
+        self._nlpsolver_initialized = True
+
+    def solve(self, initial_solution=None, reinitialize_nlp=False, solver="ipopt", nlp_solver_options={},
+              mpopt_options={}, **kwargs):
+        start = time.monotonic()
+        if (not self._nlpsolver_initialized) or reinitialize_nlp:
+            self.create_solver(solver=solver, options=nlp_solver_options)
+        if "nlp_sw_params" in mpopt_options:
+            self._nlp_sw_params = mpopt_options["nlp_sw_params"]
+        else:
+            self._nlp_sw_params = self.get_segment_width_parameters(initial_solution)
+        inputs = self.get_solver_warm_start_input_parameters(initial_solution)
+        inputs["p"] = self._nlp_sw_params
+        t_ocp = time.monotonic()
+        solution = self.nlp_solver(**inputs, **self.nlp_bounds)
+        end = time.monotonic()
+        if not self._MUTE_:
+            print("\n *********** MPOPT Summary ********** \n")
+            print(" Optimal cost (J): ", solution["f"], "\n")
+            print(f" Solved in {round((end - start) * 1e3, 3)} ms")
+            print(f" \t OCP transcription time  : {round((t_ocp - start) * 1e3, 3)} ms")
+            print(f" \t NLP solution time       : {round((end - t_ocp) * 1e3, 3)} ms")
+        return solution
+
+    def get_solver_warm_start_input_parameters(self, solution=None):
+        target = {"x": "x0", "x0": "x0", "lam_x": "lam_x0", "lam_x0": "lam_x0", "lam_g": "lam_g0", "lam_g0": "lam_g0"}
+        inputs = {}
+        if solution is not None:
+            for key in solution:
+                if key in target:
+                    inputs[target[key]] = solution[key]
+        if "x0" not in inputs:
+            inputs["x0"] = self.initialize_solution()
+        return inputs
+
+    # ---- minimal result extraction (post-processing proper is out of scope) ----------------
+    def get_trajectories(self, solution, phase=0):
+        """Unscaled (x, u, t, t0, tf, a) of one phase from a solution vector."""
+        o, N = self._ocp, self._Npoints
+        n_zp = N * (o.nx + o.nu) + 2 + o.na
+        z = np.asarray(solution["x"], float).ravel()[phase * n_zp:(phase + 1) * n_zp]
+        X = z[:o.nx * N].reshape(o.nx, N).T / np.asarray(o.scale_x, float)
+        U = z[o.nx * N:(o.nx + o.nu) * N].reshape(o.nu, N).T / np.asarray(o.scale_u, float)
+        t0, tf = z[(o.nx + o.nu) * N] / o.scale_t, z[(o.nx + o.nu) * N + 1] / o.scale_t
+        a = z[(o.nx + o.nu) * N + 2:] / np.asarray(o.scale_a, float)
+        p = np.asarray(self._nlp_sw_params, float).reshape(o.n_phases, self.n_segments)[phase]
+        t = np.empty(N)
+        t_seg0, idx = t0, 0
+        for s, deg in enumerate(self.poly_orders):
+            h = (tf - t0) / (self.tau1 - self.tau0) * p[s]
+            taus = self._taus[deg]
+            for k in range(0 if s == 0 else 1, deg + 1):
+                t[idx] = t_seg0 + h * (taus[k] - self.tau0)
+                idx += 1
+            t_seg0 += h * (self.tau1 - self.tau0)
+        return X, U, t, t0, tf, a
+
+    def process_results(self, solution, plot=False, **kwargs):
+        return post_process(self, solution)
+
+
+def _ref_control_order(U):
+    """The reference flattens the control guess node-major (``np.concatenate`` of an (N, nu)
+    array, mpopt.py:678-689) although the decision vector is control-major -- identical for
+    nu == 1 and for constant guesses.  Reproduced as is: parity beats tidiness."""
+    return np.concatenate(U)
+
+
+class post_process:
+    """Minimal stand-in for the reference's post-processor: solution data per phase, no plots."""
+
+    def __init__(self, mpo, solution):
+        self.mpo, self.solution = mpo, solution
+
+    def get_data(self, phases=None, interpolate=False):
+        phases = range(self.mpo._ocp.n_phases) if phases is None else phases
+        xs, us, ts = [], [], []
+        for ph in phases:
+            X, U, t, *_ = self.mpo.get_trajectories(self.solution, ph)
+            xs.append(X), us.append(U), ts.append(t.reshape(-1, 1))
+        return np.concatenate(xs), np.concatenate(us), np.concatenate(ts), None
+
+
+def solve(ocp, n_segments=1, poly_orders=9, scheme="LGR", plot=True, solve_dict=dict(), residual_x=False, residual_dx=True):
+    mpo = mpopt(ocp, n_segments=n_segments, poly_orders=poly_orders, scheme=scheme)
+    solution = mpo.solve(**solve_dict)
+    post = mpo.process_results(solution, plot=False, residual_x=residual_x, residual_dx=residual_dx)
+    return (mpo, post)

@@ -1,0 +1,200 @@
+"""``NlpFunctions``: the five NLP oracle functions of a transcribed OCP, evaluated on the GPU.
+
+This object stands where ``ca.nlpsol`` keeps ``nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l``
+after differentiating mpopt's ``{"f","x","g","p"}`` dict (mpopt.py:757).  It owns one ``mpx_ctx``
+(include/mpx.h) and adds a batch dimension: every call evaluates ``B`` points in one launch.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MpxError, mpx_problem, mpx_sizes
+from .codegen import ProblemProgram
+
+
+def _ptr(x):
+    """void* of a numpy array, a torch tensor, an int device pointer or None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()  # torch tensor
+
+
+class NlpFunctions:
+    def __init__(self, ocp, n_segments, poly_orders, scheme="LGR", tau0=-1.0, tau1=1.0, midu_rows=None,
+                 device=0, with_device=None, verbose=False):
+        L = _lib.lib()
+        self.ocp = ocp
+        self.n_segments = int(n_segments)
+        self.poly_orders = np.ascontiguousarray(poly_orders, dtype=np.int32)
+        if len(self.poly_orders) != self.n_segments:
+            raise ValueError("poly_orders must have one entry per segment")
+        if scheme not in _lib.SCHEMES or scheme == "LG":
+            raise MpxError(f"scheme {scheme!r} is not usable for transcription (needs degree+1 nodes; LGR, LGL, CGL)")
+        self.scheme = scheme
+        if midu_rows is None:
+            midu_rows = [bool(ocp.midu[ph]) and bool((np.asarray(ocp.lbu[ph]) > -np.inf).any()
+                                                     or (np.asarray(ocp.ubu[ph]) < np.inf).any())
+                         for ph in range(ocp.n_phases)]
+        self.program = ProblemProgram(ocp, self.poly_orders, midu_rows)
+        self.structure = np.ascontiguousarray(self.program.structure(), dtype=np.int32)
+        self.source = self.program.source()
+        if with_device is None:
+            with_device = _lib.gpu_available()
+        self.code_object = None
+        if with_device:
+            self.code_object, self.code_object_path = _lib.compile_kernels(self.source, verbose=verbose)
+        links = np.ascontiguousarray(np.asarray(ocp.phase_links, dtype=np.int32).reshape(-1))
+        prob = mpx_problem()
+        prob.version = 1
+        prob.n_phases, prob.nx, prob.nu, prob.na = ocp.n_phases, ocp.nx, ocp.nu, ocp.na
+        prob.n_segments = self.n_segments
+        prob.poly_orders = self.poly_orders.ctypes.data_as(_lib.c_int32_p)
+        prob.scheme = _lib.SCHEMES[scheme]
+        prob.tau0, prob.tau1 = float(tau0), float(tau1)
+        prob.n_links = len(links) // 2
+        prob.links = links.ctypes.data_as(_lib.c_int32_p)
+        prob.structure = self.structure.ctypes.data_as(_lib.c_int32_p)
+        prob.structure_len = len(self.structure)
+        if self.code_object is not None:
+            self._co_buf = ctypes.create_string_buffer(self.code_object, len(self.code_object))
+            prob.code_object = ctypes.cast(self._co_buf, ctypes.c_void_p)
+            prob.code_object_size = len(self.code_object)
+        prob.device = int(device)
+        ctx = ctypes.c_void_p()
+        rc = L.mpx_create(ctypes.byref(prob), ctypes.byref(ctx))
+        if rc != 0:
+            raise MpxError(f"mpx_create failed ({rc}): {L.mpx_last_error(None).decode()}")
+        self._ctx = ctx
+        self._L = L
+        s = mpx_sizes()
+        _lib.check(L.mpx_get_sizes(ctx, ctypes.byref(s)), ctx)
+        self.sizes = s
+        self.n_z, self.n_p, self.n_g = s.n_z, s.n_p, s.n_g
+        self.nnz_jac, self.nnz_hess, self.n_nodes, self.n_tiles = s.nnz_jac, s.nnz_hess, s.n_nodes, s.n_tiles
+        self.bytes_fgj, self.bytes_hess = s.bytes_fgj, s.bytes_hess
+        self._jac_pat = self._hess_pat = None
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.mpx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- structure -------------------------------------------------------------------------
+    @property
+    def has_device(self):
+        return self.code_object is not None
+
+    def jac_pattern(self):
+        if self._jac_pat is None:
+            r, c = np.empty(self.nnz_jac, np.int32), np.empty(self.nnz_jac, np.int32)
+            _lib.check(self._L.mpx_pattern_jac(self._ctx, r.ctypes.data_as(_lib.c_int32_p), c.ctypes.data_as(_lib.c_int32_p)), self._ctx)
+            self._jac_pat = (r, c)
+        return self._jac_pat
+
+    def hess_pattern(self):
+        if self._hess_pat is None:
+            r, c = np.empty(self.nnz_hess, np.int32), np.empty(self.nnz_hess, np.int32)
+            _lib.check(self._L.mpx_pattern_hess(self._ctx, r.ctypes.data_as(_lib.c_int32_p), c.ctypes.data_as(_lib.c_int32_p)), self._ctx)
+            self._hess_pat = (r, c)
+        return self._hess_pat
+
+    def ccs_perm(self, which="jac"):
+        nnz = self.nnz_jac if which == "jac" else self.nnz_hess
+        perm, colind = np.empty(nnz, np.int64), np.empty(self.n_z + 1, np.int64)
+        _lib.check(self._L.mpx_ccs_perm(self._ctx, MPX_JAC if which == "jac" else MPX_HESS,
+                                        perm.ctypes.data_as(_lib.c_int64_p), colind.ctypes.data_as(_lib.c_int64_p)), self._ctx)
+        return perm, colind
+
+    def comp_weights(self):
+        w = np.empty(self.n_nodes)
+        _lib.check(self._L.mpx_get_comp_weights(self._ctx, _lib.dptr(w)), self._ctx)
+        return w
+
+    # -- evaluation ------------------------------------------------------------------------
+    def eval(self, what, z, p, lam_g=None, sigma=None):
+        """Host arrays in, dict of host arrays out.  ``z``: (B, n_z) or (n_z,); ``p``: (n_p,) shared
+        or (B, n_p).  ``what``: iterable of {"f","g","grad_f","jac_g","hess_l"}."""
+        mask = sum({"f": MPX_F, "g": MPX_G, "grad_f": MPX_GRAD, "jac_g": MPX_JAC, "hess_l": MPX_HESS}[w] for w in set(what))
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        single = z.ndim == 1
+        z = z.reshape(-1, self.n_z)
+        B = z.shape[0]
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        if p.size not in (self.n_p, B * self.n_p):
+            raise ValueError(f"p has {p.size} values, expected {self.n_p} or {B}x{self.n_p}")
+        per_point = int(p.size == B * self.n_p and B > 1)
+        out = {}
+        f = np.empty(B) if mask & MPX_F else None
+        g = np.empty((B, self.n_g)) if mask & MPX_G else None
+        gr = np.empty((B, self.n_z)) if mask & MPX_GRAD else None
+        jv = np.empty((B, self.nnz_jac)) if mask & MPX_JAC else None
+        hv = lam = sig = None
+        if mask & MPX_HESS:
+            lam = np.ascontiguousarray(np.broadcast_to(np.asarray(lam_g, dtype=np.float64).reshape(-1, self.n_g), (B, self.n_g)))
+            sig = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype=np.float64).reshape(-1), (B,)))
+            hv = np.empty((B, self.nnz_hess))
+        rc = self._L.mpx_eval(self._ctx, mask, B, _ptr(z), _ptr(p), per_point, _ptr(lam), _ptr(sig), _ptr(f), _ptr(g),
+                              _ptr(gr), _ptr(jv), _ptr(hv))
+        _lib.check(rc, self._ctx)
+        for k, v in (("f", f), ("g", g), ("grad_f", gr), ("jac_g", jv), ("hess_l", hv)):
+            if v is not None:
+                out[k] = v[0] if single else v
+        return out
+
+    def eval_device(self, mask, batch, z, p, p_per_point=0, lam_g=None, sigma=None, f=None, g=None, grad_f=None,
+                    jac_val=None, hess_val=None):
+        """Device pointers (torch tensors or ints) in and out, asynchronous on the context stream."""
+        rc = self._L.mpx_eval_device(self._ctx, int(mask), int(batch), _ptr(z), _ptr(p), int(p_per_point), _ptr(lam_g),
+                                     _ptr(sigma), _ptr(f), _ptr(g), _ptr(grad_f), _ptr(jac_val), _ptr(hess_val))
+        _lib.check(rc, self._ctx)
+
+    def set_stream(self, stream):
+        _lib.check(self._L.mpx_set_stream(self._ctx, ctypes.c_void_p(int(stream) if stream else None)), self._ctx)
+
+    def sync(self):
+        _lib.check(self._L.mpx_sync(self._ctx), self._ctx)
+
+    def timer_start(self):
+        _lib.check(self._L.mpx_timer_start(self._ctx), self._ctx)
+
+    def timer_stop(self):
+        ms = ctypes.c_double()
+        _lib.check(self._L.mpx_timer_stop(self._ctx, ctypes.byref(ms)), self._ctx)
+        return ms.value
+
+    def set_tile_range(self, begin, end, run_boundary=True):
+        _lib.check(self._L.mpx_set_tile_range(self._ctx, int(begin), int(end), int(bool(run_boundary))), self._ctx)
+
+    def tile_jac_range(self, tile):
+        b, e = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._L.mpx_get_tile_jac_range(self._ctx, int(tile), ctypes.byref(b), ctypes.byref(e)), self._ctx)
+        return b.value, e.value
+
+    # -- the five oracles with CasADi's names/signatures (single point, host arrays) --------
+    def nlp_f(self, x, p):
+        return self.eval(["f"], x, p)["f"]
+
+    def nlp_g(self, x, p):
+        return self.eval(["g"], x, p)["g"]
+
+    def nlp_grad_f(self, x, p):
+        r = self.eval(["f", "grad_f"], x, p)
+        return r["f"], r["grad_f"]
+
+    def nlp_jac_g(self, x, p):
+        r = self.eval(["g", "jac_g"], x, p)
+        return r["g"], r["jac_g"]
+
+    def nlp_hess_l(self, x, p, lam_f, lam_g):
+        return self.eval(["hess_l"], x, p, lam_g=lam_g, sigma=lam_f)["hess_l"]

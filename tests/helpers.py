@@ -1,0 +1,50 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, f"nlp_{name}.npz"))
+
+
+def build_case(name, with_device=None):
+    import mpopt_amd as M
+    from mpopt_amd import mp
+    import problems
+
+    builder, S, po, scheme = problems.GOLDEN_CASES[name]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    mpo.compute_numerical_approximation()
+    oracle = M.NlpFunctions(ocp, S, mpo.poly_orders, scheme, tau0=mpo.tau0, tau1=mpo.tau1, with_device=with_device)
+    return ocp, mpo, oracle
+
+
+def coo_to_dict(rows, cols, vals):
+    d = {}
+    for r, c, v in zip(rows.tolist(), cols.tolist(), np.asarray(vals).tolist()):
+        assert (r, c) not in d, f"duplicate entry {(r, c)}"
+        d[(r, c)] = v
+    return d
+
+
+def assert_coo_close(rows, cols, vals, rrows, rcols, rvals, rtol=1e-10, what=""):
+    """Compare triplets: every reference entry must be present and equal; extra entries of ours
+    must be explicit zeros (structural over-approximation, e.g. exact-zero D entries)."""
+    mine = coo_to_dict(rows, cols, vals)
+    ref = coo_to_dict(rrows, rcols, rvals)
+    scale = max(1.0, max((abs(v) for v in ref.values()), default=1.0))
+    for k, v in ref.items():
+        assert k in mine, f"{what}: entry {k} missing"
+        assert abs(mine[k] - v) <= rtol * max(scale, 1.0), f"{what}: entry {k}: {mine[k]} vs {v}"
+    for k, v in mine.items():
+        if k not in ref:
+            assert abs(v) <= 1e-13 * scale, f"{what}: extra entry {k} = {v} is not a structural zero"
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max()) if a.size else 0.0

@@ -1,0 +1,64 @@
+"""GPU parity against the golden vectors produced by the reference's own transcription code
+(tests/golden/make_golden.py).  Tolerance: 1e-10 relative for FP64 values (BASELINE.json
+north_star); index data (rows/cols) must match exactly."""
+import numpy as np
+import pytest
+
+import problems
+from helpers import assert_coo_close, build_case, load_golden, rel_err
+
+TOL = 1e-10
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(problems.GOLDEN_CASES))
+def test_golden_point(name):
+    G = load_golden(name)
+    ocp, mpo, o = build_case(name, with_device=True)
+    assert o.has_device
+    r = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], G["z"], G["p"], lam_g=G["lam"], sigma=float(G["sigma"]))
+    assert rel_err(r["f"], G["f"]) < TOL
+    assert rel_err(r["g"], G["g"]) < TOL
+    assert rel_err(r["grad_f"], G["grad_f"]) < TOL
+    jr, jc = o.jac_pattern()
+    assert_coo_close(jr, jc, r["jac_g"], G["jac_row"], G["jac_col"], G["jac_val"], TOL, "jac_g")
+    hr, hc = o.hess_pattern()
+    assert (hr <= hc).all()
+    assert_coo_close(hr, hc, r["hess_l"], G["hess_row"], G["hess_col"], G["hess_val"], TOL, "hess_l")
+
+
+@pytest.mark.parametrize("name", list(problems.GOLDEN_CASES))
+def test_golden_initial_guess_equal_widths(name):
+    G = load_golden(name)
+    ocp, mpo, o = build_case(name, with_device=True)
+    z0 = mpo.initialize_solution()
+    assert np.array_equal(z0, G["z0"])
+    p = np.asarray(mpo.get_segment_width_parameters(None))
+    r = o.eval(["f", "g"], z0, p)
+    assert rel_err(r["f"], G["f_z0_equal"]) < TOL
+    assert rel_err(r["g"], G["g_z0_equal"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL"])
+def test_batch_matches_single(name):
+    """A batch of B points equals B single evaluations bit for bit (fixed-order reductions)."""
+    G = load_golden(name)
+    ocp, mpo, o = build_case(name, with_device=True)
+    rng = np.random.default_rng(5)
+    B = 7
+    Z = G["z"][None, :] + 0.01 * rng.standard_normal((B, o.n_z))
+    lam = rng.standard_normal((B, o.n_g))
+    sig = rng.uniform(0.5, 1.5, B)
+    what = ["f", "g", "grad_f", "jac_g", "hess_l"]
+    rb = o.eval(what, Z, G["p"], lam_g=lam, sigma=sig)
+    for b in range(B):
+        r1 = o.eval(what, Z[b], G["p"], lam_g=lam[b], sigma=sig[b])
+        for k in what:
+            assert np.array_equal(rb[k][b], r1[k]), (k, b)
+    # per-point widths
+    P = np.stack([np.roll(G["p"].reshape(ocp.n_phases, -1), b, axis=1).ravel() for b in range(B)])
+    rp = o.eval(["f", "g", "jac_g"], Z, P)
+    for b in range(B):
+        r1 = o.eval(["f", "g", "jac_g"], Z[b], P[b])
+        for k in ("f", "g", "jac_g"):
+            assert np.array_equal(rp[k][b], r1[k]), (k, b)
