@@ -183,6 +183,12 @@ int mpx_get_tile_jac_range(const mpx_ctx* ctx, int64_t tile, int64_t* begin, int
  * ------------------------------------------------------------------------------------------- */
 int mpx_timer_start(mpx_ctx* ctx);
 int mpx_timer_stop(mpx_ctx* ctx, double* elapsed_ms); /* records stop, synchronises, returns ms */
+/* Per-kernel timing: while enabled, every mpx_eval_device brackets its node-kernel launches (the
+ * dominant kernels) with a pair of HIP events on the context's stream.  mpx_profile_read
+ * synchronises, returns the summed node-kernel time and the number of bracketed launches since
+ * the last read, and resets the counters. */
+int mpx_profile(mpx_ctx* ctx, int enable);
+int mpx_profile_read(mpx_ctx* ctx, double* node_ms_total, int64_t* n_node_launches);
 
 #ifdef __cplusplus
 }

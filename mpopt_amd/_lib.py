@@ -116,6 +116,8 @@ SYMBOLS = {
     "mpx_get_tile_jac_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p, c_int64_p]),
     "mpx_timer_start": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_timer_stop": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+    "mpx_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "mpx_profile_read": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_int64_p]),
 }
 
 

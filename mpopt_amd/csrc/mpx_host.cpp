@@ -100,6 +100,11 @@ struct mpx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t tile_begin = 0, tile_end = 0;
   int run_boundary = 1;
+  // per-kernel profiling
+  int profile = 0;
+  std::vector<hipEvent_t> prof_ev;  // pairs
+  size_t prof_used = 0;
+  int64_t prof_launches = 0;
 };
 
 namespace {
@@ -581,6 +586,20 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0) {
   MpxIO io = io0;
   io.b_per_block = pick_bpb(c, io.B);
   const int gy = (io.B + io.b_per_block - 1) / io.b_per_block;
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  if (c->profile) {
+    if (c->prof_used + 2 > c->prof_ev.size()) {
+      for (int k = 0; k < 2; ++k) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreate(&e));
+        c->prof_ev.push_back(e);
+      }
+    }
+    pe0 = c->prof_ev[c->prof_used];
+    pe1 = c->prof_ev[c->prof_used + 1];
+    c->prof_used += 2;
+    HIPCHK(c, hipEventRecord(pe0, c->stream));
+  }
   for (auto& B : c->buckets) {
     int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);
     if (hi <= lo) continue;
@@ -610,7 +629,9 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0) {
     A.tile_count = (int32_t)(hi - lo);
     int rc = launch(c, B.fn[mode], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A);
     if (rc) return rc;
+    if (c->profile) ++c->prof_launches;
   }
+  if (c->profile) HIPCHK(c, hipEventRecord(pe1, c->stream));
   if (!c->run_boundary) return MPX_OK;
   MpxBoundArgs G{};
   G.io = io;
@@ -704,6 +725,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->module) (void)hipModuleUnload(c->module);
   }
   delete c;
@@ -801,6 +823,28 @@ extern "C" int mpx_timer_stop(mpx_ctx* c, double* ms) {
   float f = 0;
   HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
   *ms = f;
+  return MPX_OK;
+}
+
+extern "C" int mpx_profile(mpx_ctx* c, int enable) {
+  if (!c || !c->has_device) return MPX_ERR_NO_DEVICE;
+  c->profile = enable;
+  return MPX_OK;
+}
+
+extern "C" int mpx_profile_read(mpx_ctx* c, double* ms, int64_t* n) {
+  if (!c || !c->has_device || !ms || !n) return MPX_ERR_NO_DEVICE;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double tot = 0;
+  for (size_t k = 0; k + 1 < c->prof_used; k += 2) {
+    float f = 0;
+    HIPCHK(c, hipEventElapsedTime(&f, c->prof_ev[k], c->prof_ev[k + 1]));
+    tot += f;
+  }
+  *ms = tot;
+  *n = c->prof_launches;
+  c->prof_used = 0;
+  c->prof_launches = 0;
   return MPX_OK;
 }
 

@@ -173,6 +173,15 @@ class NlpFunctions:
         _lib.check(self._L.mpx_timer_stop(self._ctx, ctypes.byref(ms)), self._ctx)
         return ms.value
 
+    def profile(self, enable=True):
+        _lib.check(self._L.mpx_profile(self._ctx, int(bool(enable))), self._ctx)
+
+    def profile_read(self):
+        """(summed node-kernel milliseconds, number of node-kernel launches) since the last read."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        _lib.check(self._L.mpx_profile_read(self._ctx, ctypes.byref(ms), ctypes.byref(n)), self._ctx)
+        return ms.value, n.value
+
     def set_tile_range(self, begin, end, run_boundary=True):
         _lib.check(self._L.mpx_set_tile_range(self._ctx, int(begin), int(end), int(bool(run_boundary))), self._ctx)
 

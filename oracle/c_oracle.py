@@ -1,0 +1,92 @@
+"""ctypes wrapper of oracle/mpopt_oracle.c (TEST INFRASTRUCTURE ONLY; see the header of the C file)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from . import mpopt_oracle as npo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "mpopt_oracle.c")
+LIB = os.path.join(HERE, "liborc.so")
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-o", LIB + ".tmp", SRC, "-lm"])
+        os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        L.orc_create.restype = ctypes.c_void_p
+        L.orc_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ip, ctypes.c_int, ip, dp,
+                                 ctypes.c_double, ctypes.c_double, dp, dp, dp, ctypes.c_double, ip]
+        L.orc_destroy.argtypes = [ctypes.c_void_p]
+        for n in ("orc_n_z", "orc_n_g", "orc_nnz"):
+            getattr(L, n).restype = ctypes.c_int64
+            getattr(L, n).argtypes = [ctypes.c_void_p]
+        L.orc_eval.restype = ctypes.c_int64
+        L.orc_eval.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 8
+        L.orc_eval_many.restype = None
+        L.orc_eval_many.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 6
+        _lib = L
+    return _lib
+
+
+class COracle:
+    """``names``: one C problem name per phase (see PROBLEMS[] in mpopt_oracle.c)."""
+
+    def __init__(self, names, n_segments, poly_orders, scheme="LGR", tau0=-1.0, tau1=1.0, scale_x=None, scale_u=None,
+                 scale_a=None, scale_t=1.0, midu=None):
+        L = lib()
+        orders = np.ascontiguousarray([poly_orders] * n_segments if np.isscalar(poly_orders) else poly_orders, dtype=np.intc)
+        degs = np.ascontiguousarray(sorted(set(int(d) for d in orders)), dtype=np.intc)
+        taus = np.ascontiguousarray(np.concatenate([npo.roots(scheme, int(d), tau0, tau1) for d in degs]), dtype=float)
+        arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+        sx = np.ascontiguousarray(scale_x if scale_x is not None else np.ones(8), dtype=float)
+        su = np.ascontiguousarray(scale_u if scale_u is not None else np.ones(8), dtype=float)
+        sa = np.ascontiguousarray(scale_a if scale_a is not None else np.ones(8), dtype=float)
+        midu = np.ascontiguousarray(midu if midu is not None else [1] * len(names), dtype=np.intc)
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        self._h = L.orc_create(len(names), arr, int(n_segments), orders.ctypes.data_as(ip), len(degs), degs.ctypes.data_as(ip),
+                               taus.ctypes.data_as(dp), float(tau0), float(tau1), sx.ctypes.data_as(dp), su.ctypes.data_as(dp),
+                               sa.ctypes.data_as(dp), float(scale_t), midu.ctypes.data_as(ip))
+        if not self._h:
+            raise ValueError(f"unknown C oracle problem in {names}")
+        self.n_z, self.n_g, self.nnz = L.orc_n_z(self._h), L.orc_n_g(self._h), L.orc_nnz(self._h)
+
+    def eval(self, z, p):
+        L = lib()
+        z, p = np.ascontiguousarray(z, float), np.ascontiguousarray(p, float)
+        f, g, grad = np.zeros(1), np.zeros(self.n_g), np.zeros(self.n_z)
+        rows, cols, vals = np.zeros(self.nnz, np.int32), np.zeros(self.nnz, np.int32), np.zeros(self.nnz)
+        n = L.orc_eval(self._h, z.ctypes.data, p.ctypes.data, f.ctypes.data, g.ctypes.data, grad.ctypes.data, rows.ctypes.data,
+                       cols.ctypes.data, vals.ctypes.data)
+        assert n == self.nnz, (n, self.nnz)
+        return dict(f=f[0], g=g, grad_f=grad, jac_row=rows, jac_col=cols, jac_val=vals)
+
+    def time_many(self, Z, p, reps):
+        """Wall seconds for ``reps`` passes of f+g+grad_f+jac_g over the points Z (values only)."""
+        import time
+
+        L = lib()
+        Z, p = np.ascontiguousarray(Z, float), np.ascontiguousarray(p, float)
+        B = Z.shape[0]
+        f, g, grad, vals = np.zeros(B), np.zeros(self.n_g), np.zeros(self.n_z), np.zeros(self.nnz)
+        L.orc_eval_many(self._h, B, 1, Z.ctypes.data, p.ctypes.data, f.ctypes.data, g.ctypes.data, grad.ctypes.data, vals.ctypes.data)
+        t = time.perf_counter()
+        L.orc_eval_many(self._h, B, int(reps), Z.ctypes.data, p.ctypes.data, f.ctypes.data, g.ctypes.data, grad.ctypes.data, vals.ctypes.data)
+        return time.perf_counter() - t
+
+    def __del__(self):
+        try:
+            lib().orc_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,530 @@
+/* CPU ORACLE (C) -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Scalar, single-threaded restatement of the reference's collocation hot path
+ * (/root/reference/mpopt/mpopt.py) for the benchmark OCPs of BASELINE.json:
+ *     f, g, grad_f, jac_g   = what CasADi's nlp_f / nlp_g / nlp_grad_f / nlp_jac_g compute for the
+ *                             NLP built by mpopt.create_nlp (mpopt.py:574-639, 757).
+ * Used (a) by tests/ as a second, independent checker of the HIP kernels and of the numpy oracle,
+ * (b) by bench.py as the `cpu_baseline` ("kind": "port") timed on the GPU box's host cores.
+ * Never linked into or called from the product (mpopt_amd/).
+ *
+ * Pinning: validated in tests/test_oracle.py against tests/golden/ (vectors produced by the
+ * reference's own code, see tests/golden/make_golden.py) through the numpy oracle and directly.
+ * CasADi itself is absent, so CasADi's evaluation order is unpinned (O(1e-16) differences).
+ *
+ * Arithmetic of the tables follows the reference's "numerical" back-end: Lagrange basis as
+ * monomial-coefficient products (np.poly1d, mpopt.py:4006-4011), D by polyder + Horner
+ * (mpopt.py:3842-3847), w by polyint (mpopt.py:3879-3880).  Node sets are an input (the caller
+ * passes scipy's, as the reference does at mpopt.py:4220, 4246).
+ *
+ * The OCP functions and their first derivatives are hand-written below (independent of the
+ * product's tracer); the chain rule through scaling, segment step h and node time t is done here
+ * in the unscaled formulation (mpopt.py:175-206).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXV 16 /* nx + nu + 1 + na */
+#define MAXP 64 /* max degree + 1 */
+
+typedef struct {
+  const char* name;
+  int nx, nu, na, nc, ntc;
+  /* dyn[nx], pc[nc], L ; derivatives w.r.t. v = (x[nx], u[nu], t, a[na]) row-major [.][nv] */
+  void (*node)(const double* x, const double* u, double t, const double* a, double* dyn, double* pc, double* L);
+  void (*node_d)(const double* x, const double* u, double t, const double* a, double* ddyn, double* dpc, double* dL);
+  /* structural masks (1 = entry exists), same shapes as the derivative arrays */
+  const unsigned char* m_dyn;
+  const unsigned char* m_pc;
+  /* terminal: w = (xf[nx], tf, x0[nx], t0, a[na]) */
+  void (*term)(const double* xf, double tf, const double* x0, double t0, const double* a, double* M, double* tc);
+  void (*term_d)(const double* xf, double tf, const double* x0, double t0, const double* a, double* dM, double* dtc);
+  const unsigned char* m_M;
+  const unsigned char* m_tc;
+} ocp_fns;
+
+/* ------------------------------------------------------------------ problems ---------------- */
+/* moon lander: examples/singlephase/moon_lander.py:30-63 */
+static void ml_node(const double* x, const double* u, double t, const double* a, double* d, double* pc, double* L) {
+  d[0] = x[1];
+  d[1] = u[0] - 1.5;
+  *L = u[0];
+}
+static void ml_node_d(const double* x, const double* u, double t, const double* a, double* dd, double* dpc, double* dL) {
+  /* nv = 4: x0 x1 u t */
+  memset(dd, 0, 8 * sizeof(double));
+  dd[0 * 4 + 1] = 1.0;
+  dd[1 * 4 + 2] = 1.0;
+  dL[0] = 0, dL[1] = 0, dL[2] = 1.0, dL[3] = 0;
+}
+static const unsigned char ml_mdyn[8] = {0, 1, 0, 0, 0, 0, 1, 0};
+static void ml_term(const double* xf, double tf, const double* x0, double t0, const double* a, double* M, double* tc) {
+  *M = 0;
+  tc[0] = xf[0];
+  tc[1] = xf[1];
+}
+static void ml_term_d(const double* xf, double tf, const double* x0, double t0, const double* a, double* dM, double* dtc) {
+  /* ntv = 6: xf0 xf1 tf x00 x01 t0 */
+  memset(dM, 0, 6 * sizeof(double));
+  memset(dtc, 0, 12 * sizeof(double));
+  dtc[0] = 1.0;
+  dtc[6 + 1] = 1.0;
+}
+static const unsigned char ml_mM[6] = {0, 0, 0, 0, 0, 0};
+static const unsigned char ml_mtc[12] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
+
+/* Van der Pol: tests/test_mpopt.py:206-227 */
+static void vdp_node(const double* x, const double* u, double t, const double* a, double* d, double* pc, double* L) {
+  d[0] = (1 - x[1] * x[1]) * x[0] - x[1] + u[0];
+  d[1] = x[0];
+  *L = x[0] * x[0] + x[1] * x[1] + u[0] * u[0];
+}
+static void vdp_node_d(const double* x, const double* u, double t, const double* a, double* dd, double* dpc, double* dL) {
+  memset(dd, 0, 8 * sizeof(double));
+  dd[0] = 1 - x[1] * x[1];
+  dd[1] = -2 * x[1] * x[0] - 1;
+  dd[2] = 1;
+  dd[4] = 1;
+  dL[0] = 2 * x[0], dL[1] = 2 * x[1], dL[2] = 2 * u[0], dL[3] = 0;
+}
+static const unsigned char vdp_mdyn[8] = {1, 1, 1, 0, 1, 0, 0, 0};
+static void none_term(const double* xf, double tf, const double* x0, double t0, const double* a, double* M, double* tc) { *M = 0; }
+static void none_term_d(const double* xf, double tf, const double* x0, double t0, const double* a, double* dM, double* dtc) {
+  memset(dM, 0, MAXV * 2 * sizeof(double));
+}
+static const unsigned char zeros_mask[4 * MAXV * MAXV] = {0};
+
+/* Van der Pol with parameter and path row: examples/singlephase/dae_vdp.py:28-60; nv = 5: x0 x1 u t a0 */
+static void dvdp_node(const double* x, const double* u, double t, const double* a, double* d, double* pc, double* L) {
+  vdp_node(x, u, t, a, d, pc, L);
+  pc[0] = a[0] - x[1];
+}
+static void dvdp_node_d(const double* x, const double* u, double t, const double* a, double* dd, double* dpc, double* dL) {
+  memset(dd, 0, 10 * sizeof(double));
+  dd[0] = 1 - x[1] * x[1];
+  dd[1] = -2 * x[1] * x[0] - 1;
+  dd[2] = 1;
+  dd[5] = 1;
+  memset(dpc, 0, 5 * sizeof(double));
+  dpc[1] = -1;
+  dpc[4] = 1;
+  dL[0] = 2 * x[0], dL[1] = 2 * x[1], dL[2] = 2 * u[0], dL[3] = 0, dL[4] = 0;
+}
+static const unsigned char dvdp_mdyn[10] = {1, 1, 1, 0, 0, 1, 0, 0, 0, 0};
+static const unsigned char dvdp_mpc[5] = {0, 1, 0, 0, 1};
+
+/* hypersensitive: examples/singlephase/hyper_sensitive.py:31-41; nv = 3: x u t */
+static void hs_node(const double* x, const double* u, double t, const double* a, double* d, double* pc, double* L) {
+  d[0] = -x[0] * x[0] * x[0] + u[0];
+  *L = 0.5 * (x[0] * x[0] + u[0] * u[0]);
+}
+static void hs_node_d(const double* x, const double* u, double t, const double* a, double* dd, double* dpc, double* dL) {
+  dd[0] = -3 * x[0] * x[0];
+  dd[1] = 1;
+  dd[2] = 0;
+  dL[0] = x[0], dL[1] = u[0], dL[2] = 0;
+}
+static const unsigned char hs_mdyn[3] = {1, 1, 0};
+static void hs_term(const double* xf, double tf, const double* x0, double t0, const double* a, double* M, double* tc) {
+  *M = 0;
+  tc[0] = xf[0] - 1.0;
+}
+static void hs_term_d(const double* xf, double tf, const double* x0, double t0, const double* a, double* dM, double* dtc) {
+  memset(dM, 0, 4 * sizeof(double));
+  memset(dtc, 0, 4 * sizeof(double));
+  dtc[0] = 1.0;
+}
+static const unsigned char hs_mtc[4] = {1, 0, 0, 0};
+
+/* two-phase Schwartz: tests/test_mpopt.py:165-202; nv = 4 */
+static void sw_node0(const double* x, const double* u, double t, const double* a, double* d, double* pc, double* L) {
+  d[0] = x[1];
+  d[1] = u[0] - 0.1 * (1.0 + 2.0 * x[0] * x[0]) * x[1];
+  pc[0] = 1.0 - 9.0 * (x[0] - 1) * (x[0] - 1) - (x[1] - 0.4) * (x[1] - 0.4) / (0.3 * 0.3);
+  *L = 0;
+}
+static void sw_node0_d(const double* x, const double* u, double t, const double* a, double* dd, double* dpc, double* dL) {
+  memset(dd, 0, 8 * sizeof(double));
+  dd[1] = 1;
+  dd[4] = -0.1 * 4.0 * x[0] * x[1];
+  dd[5] = -0.1 * (1.0 + 2.0 * x[0] * x[0]);
+  dd[6] = 1;
+  dpc[0] = -18.0 * (x[0] - 1);
+  dpc[1] = -2.0 * (x[1] - 0.4) / (0.3 * 0.3);
+  dpc[2] = 0, dpc[3] = 0;
+  memset(dL, 0, 4 * sizeof(double));
+}
+static void sw_node1(const double* x, const double* u, double t, const double* a, double* d, double* pc, double* L) {
+  d[0] = x[1];
+  d[1] = u[0] - 0.1 * (1.0 + 2.0 * x[0] * x[0]) * x[1];
+  *L = 0;
+}
+static void sw_node1_d(const double* x, const double* u, double t, const double* a, double* dd, double* dpc, double* dL) {
+  double dummy[4];
+  sw_node0_d(x, u, t, a, dd, dummy, dL);
+}
+static const unsigned char sw_mdyn[8] = {0, 1, 0, 0, 1, 1, 1, 0};
+static const unsigned char sw_mpc[4] = {1, 1, 0, 0};
+static void sw_term1(const double* xf, double tf, const double* x0, double t0, const double* a, double* M, double* tc) {
+  *M = 5 * (xf[0] * xf[0] + xf[1] * xf[1]);
+}
+static void sw_term1_d(const double* xf, double tf, const double* x0, double t0, const double* a, double* dM, double* dtc) {
+  memset(dM, 0, 6 * sizeof(double));
+  dM[0] = 10 * xf[0];
+  dM[1] = 10 * xf[1];
+}
+static const unsigned char sw_mM1[6] = {1, 1, 0, 0, 0, 0};
+
+static const ocp_fns PROBLEMS[] = {
+    {"moon_lander", 2, 1, 0, 0, 2, ml_node, ml_node_d, ml_mdyn, zeros_mask, ml_term, ml_term_d, ml_mM, ml_mtc},
+    {"van_der_pol", 2, 1, 0, 0, 0, vdp_node, vdp_node_d, vdp_mdyn, zeros_mask, none_term, none_term_d, zeros_mask, zeros_mask},
+    {"dae_vdp", 2, 1, 1, 1, 0, dvdp_node, dvdp_node_d, dvdp_mdyn, dvdp_mpc, none_term, none_term_d, zeros_mask, zeros_mask},
+    {"hyper_sensitive", 1, 1, 0, 0, 1, hs_node, hs_node_d, hs_mdyn, zeros_mask, hs_term, hs_term_d, zeros_mask, hs_mtc},
+    {"schwartz_phase0", 2, 1, 0, 1, 0, sw_node0, sw_node0_d, sw_mdyn, sw_mpc, none_term, none_term_d, zeros_mask, zeros_mask},
+    {"schwartz_phase1", 2, 1, 0, 0, 0, sw_node1, sw_node1_d, sw_mdyn, zeros_mask, sw_term1, sw_term1_d, sw_mM1, zeros_mask},
+};
+#define N_PROBLEMS ((int)(sizeof(PROBLEMS) / sizeof(PROBLEMS[0])))
+
+/* ------------------------------------------------------------------ tables ------------------ */
+/* monomial coefficients, highest power first (numpy poly1d convention) */
+static void lagrange_coeffs(const double* x, int n, int j, double* c /* n */) {
+  double tmp[MAXP];
+  int len = 1;
+  c[0] = 1.0;
+  for (int i = 0; i < n; ++i) {
+    if (i == j) continue;
+    double den = x[j] - x[i];
+    /* c <- c * [1, -x_i] / den          (mpopt.py:4010) */
+    tmp[0] = c[0];
+    for (int k = 1; k < len; ++k) tmp[k] = c[k] - x[i] * c[k - 1];
+    tmp[len] = -x[i] * c[len - 1];
+    ++len;
+    for (int k = 0; k < len; ++k) c[k] = tmp[k] / den;
+  }
+}
+static double polyval(const double* c, int len, double t) {
+  double v = 0;
+  for (int k = 0; k < len; ++k) v = v * t + c[k];
+  return v;
+}
+
+typedef struct {
+  int deg;
+  double tau[MAXP], D[MAXP * MAXP], w[MAXP], Cmid[MAXP * MAXP];
+} deg_table;
+
+static void build_table(deg_table* T, int deg, const double* taus, double tau0, double tau1) {
+  int n = deg + 1;
+  T->deg = deg;
+  memcpy(T->tau, taus, n * sizeof(double));
+  for (int j = 0; j < n; ++j) {
+    double c[MAXP], d[MAXP], I[MAXP + 1];
+    lagrange_coeffs(taus, n, j, c);
+    for (int k = 0; k < n - 1; ++k) d[k] = c[k] * (double)(n - 1 - k); /* np.polyder */
+    for (int i = 0; i < n; ++i) T->D[i * n + j] = n > 1 ? polyval(d, n - 1, taus[i]) : 0.0;
+    for (int k = 0; k < n; ++k) I[k] = c[k] / (double)(n - k); /* np.polyint */
+    I[n] = 0.0;
+    T->w[j] = polyval(I, n + 1, tau1) - polyval(I, n + 1, tau0);
+    for (int m = 0; m < deg; ++m) T->Cmid[m * n + j] = polyval(c, n, (taus[m] + taus[m + 1]) / 2.0); /* mpopt.py:350-352 */
+  }
+}
+
+/* ------------------------------------------------------------------ NLP --------------------- */
+typedef struct {
+  int n_ph, S, N, nx, nu, na;
+  int* orders;
+  int* start;
+  int* seg;
+  int* pt;
+  deg_table* tabs;
+  int n_tabs;
+  double tau0, tau1;
+  double *sx, *su, *sa, st;
+  const ocp_fns* fn[8];
+  int midu[8];
+  double* compW;
+  int64_t n_zp, n_z, n_g, nnz;
+  int64_t off_F[8], off_C[8], off_mU[8], off_TC[8], off_ev;
+} orc;
+
+static const deg_table* tab(const orc* o, int deg) {
+  for (int k = 0; k < o->n_tabs; ++k)
+    if (o->tabs[k].deg == deg) return &o->tabs[k];
+  return 0;
+}
+
+/* names: one per phase; degs/taus: distinct degrees and their node sets (concatenated) */
+orc* orc_create(int n_ph, const char** names, int S, const int* orders, int n_degs, const int* degs, const double* taus,
+                double tau0, double tau1, const double* sx, const double* su, const double* sa, double st, const int* midu) {
+  orc* o = (orc*)calloc(1, sizeof(orc));
+  o->n_ph = n_ph;
+  o->S = S;
+  for (int p = 0; p < n_ph; ++p) {
+    o->fn[p] = 0;
+    for (int k = 0; k < N_PROBLEMS; ++k)
+      if (!strcmp(PROBLEMS[k].name, names[p])) o->fn[p] = &PROBLEMS[k];
+    if (!o->fn[p]) {
+      free(o);
+      return 0;
+    }
+    o->midu[p] = midu[p];
+  }
+  o->nx = o->fn[0]->nx, o->nu = o->fn[0]->nu, o->na = o->fn[0]->na;
+  o->orders = (int*)malloc(S * sizeof(int));
+  o->start = (int*)malloc((S + 1) * sizeof(int));
+  memcpy(o->orders, orders, S * sizeof(int));
+  o->start[0] = 0;
+  for (int s = 0; s < S; ++s) o->start[s + 1] = o->start[s] + orders[s];
+  o->N = o->start[S] + 1;
+  o->tau0 = tau0, o->tau1 = tau1;
+  o->tabs = (deg_table*)calloc(n_degs, sizeof(deg_table));
+  o->n_tabs = n_degs;
+  const double* t = taus;
+  for (int k = 0; k < n_degs; ++k) {
+    build_table(&o->tabs[k], degs[k], t, tau0, tau1);
+    t += degs[k] + 1;
+  }
+  o->sx = (double*)malloc(o->nx * sizeof(double)), o->su = (double*)malloc((o->nu + 1) * sizeof(double));
+  o->sa = (double*)malloc((o->na + 1) * sizeof(double));
+  memcpy(o->sx, sx, o->nx * sizeof(double));
+  memcpy(o->su, su, o->nu * sizeof(double));
+  memcpy(o->sa, sa, o->na * sizeof(double));
+  o->st = st;
+  /* node -> (segment, point), mpopt.py:189-195, 208 */
+  o->seg = (int*)malloc(o->N * sizeof(int)), o->pt = (int*)malloc(o->N * sizeof(int));
+  for (int i = 0, s = 0, k = 0; i < o->N; ++i) {
+    if (k > orders[s]) s++, k = 1;
+    o->seg[i] = s, o->pt[i] = k++;
+  }
+  /* composite weights, mpopt.py:4060-4062 */
+  o->compW = (double*)malloc(o->N * sizeof(double));
+  o->compW[0] = tab(o, orders[0])->w[0];
+  for (int s = 0; s < S; ++s)
+    for (int k = 1; k <= orders[s]; ++k) o->compW[o->start[s] + k] = tab(o, orders[s])->w[k];
+  int N = o->N;
+  o->n_zp = (int64_t)N * (o->nx + o->nu) + 2 + o->na;
+  o->n_z = o->n_zp * n_ph;
+  int64_t r = 0, nnz = 0;
+  int nv = o->nx + o->nu + 1 + o->na, ntv = 2 * o->nx + 2 + o->na;
+  for (int p = 0; p < n_ph; ++p) {
+    const ocp_fns* f = o->fn[p];
+    o->off_F[p] = r, r += (int64_t)o->nx * N;
+    o->off_C[p] = r, r += (int64_t)f->nc * N;
+    o->off_mU[p] = r, r += o->midu[p] ? (int64_t)o->nu * (N - 1) : 0;
+    o->off_TC[p] = r, r += f->ntc;
+    for (int i = 0; i < N; ++i) {
+      int pdeg = orders[o->seg[i]];
+      for (int a = 0; a < o->nx; ++a) {
+        nnz += pdeg + 1;
+        for (int v = 0; v < nv; ++v) {
+          if (v == a) continue;
+          int m = f->m_dyn[a * nv + v];
+          if (v == o->nx + o->nu) nnz += 2; /* t0, tf always: h multiplies dyn */
+          else nnz += m;
+        }
+      }
+      for (int j = 0; j < f->nc; ++j)
+        for (int v = 0; v < nv; ++v) nnz += (v == o->nx + o->nu ? 2 : 1) * f->m_pc[j * nv + v];
+      if (o->midu[p] && i > 0) nnz += (int64_t)o->nu * (pdeg + 1);
+    }
+    for (int j = 0; j < f->ntc; ++j)
+      for (int v = 0; v < ntv; ++v) nnz += f->m_tc[j * ntv + v];
+  }
+  o->off_ev = r;
+  if (n_ph > 1) r += (int64_t)(n_ph - 1) * (o->nx + o->nu + 1), nnz += 2 * (int64_t)(n_ph - 1) * (o->nx + o->nu + 1);
+  o->n_g = r;
+  o->nnz = nnz;
+  return o;
+}
+
+void orc_destroy(orc* o) {
+  if (!o) return;
+  free(o->orders), free(o->start), free(o->seg), free(o->pt), free(o->tabs), free(o->sx), free(o->su), free(o->sa), free(o->compW);
+  free(o);
+}
+int64_t orc_n_z(const orc* o) { return o->n_z; }
+int64_t orc_n_g(const orc* o) { return o->n_g; }
+int64_t orc_nnz(const orc* o) { return o->nnz; }
+
+/* One evaluation of f, g, grad_f (dense) and jac_g (COO triplets, row-major emission order).
+ * rows/cols may be NULL (values only, the timed configuration).  Returns the number of triplets. */
+int64_t orc_eval(const orc* o, const double* z, const double* p, double* f_out, double* g, double* grad, int32_t* rows,
+                 int32_t* cols, double* vals) {
+  const int N = o->N, nx = o->nx, nu = o->nu, na = o->na, nv = nx + nu + 1 + na, ntv = 2 * nx + 2 + na;
+  int64_t q = 0;
+  double ftot = 0;
+  if (grad) memset(grad, 0, o->n_z * sizeof(double));
+#define EMIT(r, c, v)                 \
+  do {                                \
+    if (rows) rows[q] = (int32_t)(r); \
+    if (cols) cols[q] = (int32_t)(c); \
+    vals[q++] = (v);                  \
+  } while (0)
+  for (int ph = 0; ph < o->n_ph; ++ph) {
+    const ocp_fns* F = o->fn[ph];
+    const double* zp = z + ph * o->n_zp;
+    const double* X = zp;                      /* X[a*N+i] */
+    const double* U = zp + (int64_t)nx * N;    /* U[b*N+i] */
+    const int64_t zt = (int64_t)(nx + nu) * N; /* t0, tf, A */
+    const double t0 = zp[zt] / o->st, tf = zp[zt + 1] / o->st; /* mpopt.py:175-176 */
+    const int64_t zb = ph * o->n_zp;
+    double a[MAXV];
+    for (int c = 0; c < na; ++c) a[c] = zp[zt + 2 + c] / o->sa[c];
+    const double* w = p + ph * o->S;
+    const double dtau = o->tau1 - o->tau0;
+    double t_seg0 = t0, h = (tf - t0) / dtau * w[0]; /* mpopt.py:180-184 */
+    double dt0 = 0, dtf = 0, da[MAXV] = {0};
+    for (int i = 0, s = 0; i < N; ++i) {
+      if (o->seg[i] != s) { /* mpopt.py:190-195 */
+        s = o->seg[i];
+        t_seg0 += h * dtau;
+        h = (tf - t0) / dtau * w[s];
+      }
+      const int pdeg = o->orders[s], k = o->pt[i], st = o->start[s];
+      const deg_table* T = tab(o, pdeg);
+      const double tk = T->tau[k] - o->tau0;
+      const double t = t_seg0 + h * tk; /* mpopt.py:198 */
+      /* d t / d(t0,tf), d h / d(t0,tf) in the unscaled times */
+      const double theta = (t - t0) / (tf - t0);
+      const double kap = w[s] / dtau;
+      double x[MAXV], u[MAXV], dyn[MAXV], pc[MAXV], L, ddyn[MAXV * MAXV], dpc[MAXV * MAXV], dL[MAXV];
+      for (int c = 0; c < nx; ++c) x[c] = X[(int64_t)c * N + i] / o->sx[c]; /* mpopt.py:196 */
+      for (int c = 0; c < nu; ++c) u[c] = U[(int64_t)c * N + i] / o->su[c]; /* mpopt.py:197 */
+      F->node(x, u, t, a, dyn, pc, &L);
+      F->node_d(x, u, t, a, ddyn, dpc, dL);
+      for (int c = 0; c < nx; ++c) { /* defect rows, mpopt.py:201, 227-232 */
+        const int64_t row = o->off_F[ph] + (int64_t)c * N + i;
+        double acc = 0;
+        for (int j = 0; j <= pdeg; ++j) acc += T->D[k * (pdeg + 1) + j] * X[(int64_t)c * N + st + j];
+        const double fi = h * o->sx[c] * dyn[c];
+        g[row] = acc - fi;
+        for (int j = 0; j <= pdeg; ++j) {
+          double v = T->D[k * (pdeg + 1) + j];
+          if (j == k) v -= h * o->sx[c] * ddyn[c * nv + c] / o->sx[c];
+          EMIT(row, zb + (int64_t)c * N + st + j, v);
+        }
+        for (int v = 0; v < nv; ++v) {
+          if (v == c) continue;
+          const double d = ddyn[c * nv + v];
+          if (v < nx) {
+            if (F->m_dyn[c * nv + v]) EMIT(row, zb + (int64_t)v * N + i, -h * o->sx[c] * d / o->sx[v]);
+          } else if (v < nx + nu) {
+            if (F->m_dyn[c * nv + v]) EMIT(row, zb + (int64_t)v * N + i, -h * o->sx[c] * d / o->su[v - nx]);
+          } else if (v == nx + nu) {
+            /* f = kap (tf - t0) Sx dyn(.., t0 + (tf-t0) theta, ..) */
+            EMIT(row, zb + zt, -(-kap * o->sx[c] * dyn[c] + h * o->sx[c] * d * (1 - theta)) / o->st);
+            EMIT(row, zb + zt + 1, -(kap * o->sx[c] * dyn[c] + h * o->sx[c] * d * theta) / o->st);
+          } else if (F->m_dyn[c * nv + v]) {
+            EMIT(row, zb + zt + 2 + (v - nx - nu - 1), -h * o->sx[c] * d / o->sa[v - nx - nu - 1]);
+          }
+        }
+      }
+      for (int j = 0; j < F->nc; ++j) { /* path rows, mpopt.py:204, 255 */
+        const int64_t row = o->off_C[ph] + (int64_t)j * N + i;
+        g[row] = pc[j];
+        for (int v = 0; v < nv; ++v) {
+          if (!F->m_pc[j * nv + v]) continue;
+          const double d = dpc[j * nv + v];
+          if (v < nx) EMIT(row, zb + (int64_t)v * N + i, d / o->sx[v]);
+          else if (v < nx + nu) EMIT(row, zb + (int64_t)v * N + i, d / o->su[v - nx]);
+          else if (v == nx + nu) {
+            EMIT(row, zb + zt, d * (1 - theta) / o->st);
+            EMIT(row, zb + zt + 1, d * theta / o->st);
+          } else EMIT(row, zb + zt + 2 + (v - nx - nu - 1), d / o->sa[v - nx - nu - 1]);
+        }
+      }
+      /* running cost, mpopt.py:206, 455 */
+      const double W = o->compW[i];
+      ftot += W * h * L;
+      if (grad) {
+        for (int v = 0; v < nx; ++v) grad[zb + (int64_t)v * N + i] += W * h * dL[v] / o->sx[v];
+        for (int v = 0; v < nu; ++v) grad[zb + (int64_t)(nx + v) * N + i] += W * h * dL[nx + v] / o->su[v];
+        dt0 += W * (-kap * L + h * dL[nx + nu] * (1 - theta)) / o->st;
+        dtf += W * (kap * L + h * dL[nx + nu] * theta) / o->st;
+        for (int c = 0; c < na; ++c) da[c] += W * h * dL[nx + nu + 1 + c] / o->sa[c];
+      }
+    }
+    if (o->midu[ph]) { /* control at mid-points, mpopt.py:350-369 */
+      for (int b = 0; b < nu; ++b)
+        for (int s = 0; s < o->S; ++s) {
+          const int pdeg = o->orders[s], st = o->start[s];
+          const deg_table* T = tab(o, pdeg);
+          for (int m = 0; m < pdeg; ++m) {
+            const int64_t row = o->off_mU[ph] + (int64_t)b * (N - 1) + st + m;
+            double acc = 0;
+            for (int j = 0; j <= pdeg; ++j) {
+              acc += T->Cmid[m * (pdeg + 1) + j] * U[(int64_t)b * N + st + j];
+              EMIT(row, zb + (int64_t)(nx + b) * N + st + j, T->Cmid[m * (pdeg + 1) + j]);
+            }
+            g[row] = acc;
+          }
+        }
+    }
+    /* terminal cost and constraints, mpopt.py:277-298 */
+    double xf[MAXV], x0[MAXV], M, tc[MAXV], dM[2 * MAXV + 2], dtc[MAXV * (2 * MAXV + 2)];
+    for (int c = 0; c < nx; ++c) xf[c] = X[(int64_t)c * N + N - 1] / o->sx[c], x0[c] = X[(int64_t)c * N] / o->sx[c];
+    F->term(xf, tf, x0, t0, a, &M, tc);
+    F->term_d(xf, tf, x0, t0, a, dM, dtc);
+    ftot += M;
+    for (int j = 0; j < F->ntc; ++j) {
+      const int64_t row = o->off_TC[ph] + j;
+      g[row] = tc[j];
+      for (int v = 0; v < ntv; ++v) {
+        if (!F->m_tc[j * ntv + v]) continue;
+        const double d = dtc[j * ntv + v];
+        if (v < nx) EMIT(row, zb + (int64_t)v * N + N - 1, d / o->sx[v]);
+        else if (v == nx) EMIT(row, zb + zt + 1, d / o->st);
+        else if (v < 2 * nx + 1) EMIT(row, zb + (int64_t)(v - nx - 1) * N, d / o->sx[v - nx - 1]);
+        else if (v == 2 * nx + 1) EMIT(row, zb + zt, d / o->st);
+        else EMIT(row, zb + zt + 2 + (v - 2 * nx - 2), d / o->sa[v - 2 * nx - 2]);
+      }
+    }
+    if (grad) {
+      grad[zb + zt] += dt0, grad[zb + zt + 1] += dtf;
+      for (int c = 0; c < na; ++c) grad[zb + zt + 2 + c] += da[c];
+      for (int v = 0; v < ntv; ++v) {
+        if (!F->m_M[v]) continue;
+        const double d = dM[v];
+        if (v < nx) grad[zb + (int64_t)v * N + N - 1] += d / o->sx[v];
+        else if (v == nx) grad[zb + zt + 1] += d / o->st;
+        else if (v < 2 * nx + 1) grad[zb + (int64_t)(v - nx - 1) * N] += d / o->sx[v - nx - 1];
+        else if (v == 2 * nx + 1) grad[zb + zt] += d / o->st;
+        else grad[zb + zt + 2 + (v - 2 * nx - 2)] += d / o->sa[v - 2 * nx - 2];
+      }
+    }
+  }
+  if (o->n_ph > 1) { /* events with the default consecutive links, mpopt.py:484-519 */
+    int64_t row = o->off_ev;
+    const int64_t zt = (int64_t)(nx + nu) * N;
+    for (int blk = 0; blk < 3; ++blk)
+      for (int l = 0; l + 1 < o->n_ph; ++l) {
+        const int64_t zi = l * o->n_zp, zj = (l + 1) * o->n_zp;
+        int cnt = blk == 0 ? nx : (blk == 1 ? nu : 1);
+        for (int c = 0; c < cnt; ++c) {
+          int64_t cj, ci;
+          if (blk == 2) cj = zj + zt, ci = zi + zt + 1;
+          else {
+            int comp = blk == 0 ? c : nx + c;
+            cj = zj + (int64_t)comp * N, ci = zi + (int64_t)comp * N + N - 1;
+          }
+          g[row] = z[cj] - z[ci];
+          EMIT(row, cj, 1.0);
+          EMIT(row, ci, -1.0);
+          ++row;
+        }
+      }
+  }
+  *f_out = ftot;
+  return q;
+#undef EMIT
+}
+
+/* Timed loop for bench.py: `reps` evaluations of f+g+grad_f+jac_g (values only) on `n_points`
+ * different points; returns nothing, the caller clocks it. */
+void orc_eval_many(const orc* o, int64_t n_points, int reps, const double* Z, const double* p, double* f, double* g, double* grad,
+                   double* vals) {
+  for (int r = 0; r < reps; ++r)
+    for (int64_t b = 0; b < n_points; ++b) orc_eval(o, Z + b * o->n_z, p, f + b, g, grad, 0, 0, vals);
+}

@@ -1,0 +1,476 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A plain numpy / sympy restatement of the reference's algorithm for the collocation hot path
+(/root/reference/mpopt/mpopt.py).  It exists to CHECK the HIP kernels; it is never the thing
+that is shipped or measured as the product:  only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  ``mpopt_amd`` never does.
+
+Pinning:
+  * tables (roots, D, W, interpolation, composites): pinned against ``tests/golden/tables.npz``,
+    produced by importing the reference's CollocationRoots / Collocation ("numerical" back-end);
+  * z0, bounds, f, g, jac_g, grad_f, hess_l: pinned against ``tests/golden/nlp_*.npz``, produced by
+    running the reference's own ``mpopt.create_nlp()`` over a sympy-backed stand-in for CasADi
+    (tests/golden/casadi_shim.py) because CasADi itself (casadi==3.6.0, requirements.txt:4) is not
+    installable here.  CasADi's own floating-point evaluation order and AD are therefore NOT
+    pinned ("parity unpinned" for that last step); differences are O(1e-16) relative.
+
+Each function cites the reference lines it follows.  Derivatives take an independent route from
+the product (sympy differentiation of per-node expressions + numpy assembly, versus the
+product's own tracer + generated device code + C++ pattern builder).
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.special
+
+
+# ---------------------------------------------------------------------------------------------
+# CollocationRoots (mpopt.py:4134-4276)
+# ---------------------------------------------------------------------------------------------
+def roots(scheme, deg, tau_min=-1.0, tau_max=1.0):
+    def scale(r):  # mpopt.py:4203, 4224, 4250, 4274
+        return tau_min + (tau_max - tau_min) / 2 * (np.asarray(r, dtype=float) + 1)
+
+    if scheme == "LG":  # mpopt.py:4199-4203
+        return scale(np.append(-1, np.polynomial.legendre.leggauss(deg - 1)[0]))
+    if scheme in ("LGR", "LGL"):  # mpopt.py:4216-4229, 4242-4255
+        if deg > 1:
+            r = scipy.special.j_roots(deg - 1, 1.0, 0.0 if scheme == "LGR" else 1.0)[0]
+            return scale(np.append(np.append(-1, r), 1.0))
+        return np.array([tau_min, tau_max], dtype=float) if deg == 1 else np.array([0.0])
+    if scheme == "CGL":  # mpopt.py:4270-4274
+        return scale(np.array([np.cos(np.pi * j / deg) for j in range(deg + 1)])[::-1])
+    # unknown scheme -> equally spaced (mpopt.py:4182-4188); argument is the node count
+    return np.linspace(tau_min, tau_max, deg) if deg > 1 else np.array([tau_min, tau_max], dtype=float)
+
+
+# ---------------------------------------------------------------------------------------------
+# Collocation, D_MATRIX_METHOD == "numerical" (mpopt.py:3815-3905, 3987-4131)
+# ---------------------------------------------------------------------------------------------
+def lagrange_polys(nodes):  # mpopt.py:4006-4011
+    n = len(nodes)
+    polys = []
+    for j in range(n):
+        p = np.poly1d([1])
+        for i in range(n):
+            if i != j:
+                p *= np.poly1d([1, -nodes[i]]) / (nodes[j] - nodes[i])
+        polys.append(p)
+    return polys
+
+
+def diff_matrix(nodes, taus=None, order=1):  # mpopt.py:3815-3849
+    at = nodes if taus is None else taus
+    polys = lagrange_polys(nodes)
+    D = np.zeros((len(at), len(nodes)))
+    for j, p in enumerate(polys):
+        d = np.polyder(p) if order == 1 else np.polyder(np.polyder(p))
+        for i in range(len(at)):
+            D[i, j] = d(at[i])
+    return D
+
+
+def quad_weights(nodes, a, b):  # mpopt.py:3851-3882
+    w = np.zeros(len(nodes))
+    for i, p in enumerate(lagrange_polys(nodes)):
+        P = np.polyint(p)
+        w[i] = P(b) - P(a)
+    return w
+
+
+def interp_matrix(nodes, taus):  # mpopt.py:3884-3905
+    C = np.zeros((len(taus), len(nodes)))
+    for j, p in enumerate(lagrange_polys(nodes)):
+        for i in range(len(taus)):
+            C[i, j] = p(taus[i])
+    return C
+
+
+class Grid:
+    """Tables of one grid: what mpopt.compute_numerical_approximation caches (mpopt.py:95-103)."""
+
+    def __init__(self, poly_orders, scheme, tau0=-1.0, tau1=1.0):
+        self.orders = [int(p) for p in poly_orders]
+        self.scheme, self.tau0, self.tau1 = scheme, float(tau0), float(tau1)
+        self.S = len(self.orders)
+        self.N = sum(self.orders) + 1
+        self.taus = {d: roots(scheme, d, tau0, tau1) for d in set(self.orders)}
+        self.D = {d: diff_matrix(self.taus[d]) for d in self.taus}
+        self.w = {d: quad_weights(self.taus[d], tau0, tau1) for d in self.taus}
+        self.start = np.concatenate([[0], np.cumsum(self.orders)]).astype(int)
+
+    def comp_D(self):  # mpopt.py:4015-4039
+        out = np.zeros((self.N, self.N))
+        for i, p in enumerate(self.orders):
+            if i == 0:
+                out[0:p + 1, 0:p + 1] = self.D[p]
+            else:
+                st = self.start[i]
+                out[st + 1:st + 1 + p, st:st + 1 + p] = self.D[p][1:, :]
+        return out
+
+    def comp_W(self):  # mpopt.py:4041-4064 (w_0 of later segments is dropped)
+        return np.concatenate([self.w[self.orders[0]][:1]] + [self.w[p][1:] for p in self.orders])
+
+    def comp_interp(self, taus_list, deriv=0):  # mpopt.py:4066-4131
+        n_t = [len(t) for t in taus_list]
+        out = np.zeros((sum(n_t), self.N))
+        r = 0
+        for i, p in enumerate(self.orders):
+            if n_t[i]:
+                blk = interp_matrix(self.taus[p], taus_list[i]) if deriv == 0 else diff_matrix(self.taus[p], taus_list[i], deriv)
+                out[r:r + n_t[i], self.start[i]:self.start[i] + p + 1] = blk
+            r += n_t[i]
+        return out
+
+    def comp_I_mid(self):  # mpopt.py:350-359
+        return self.comp_interp([list((self.taus[p][:-1] + self.taus[p][1:]) / 2.0) for p in self.orders])
+
+    def node_seg_point(self):
+        """(segment, point) of every node following the loop at mpopt.py:189-195, 208."""
+        seg, pt = np.zeros(self.N, int), np.zeros(self.N, int)
+        s, k = 0, 0
+        for i in range(self.N):
+            if k > self.orders[s]:
+                s, k = s + 1, 1
+            seg[i], pt[i] = s, k
+            k += 1
+        return seg, pt
+
+
+# ---------------------------------------------------------------------------------------------
+# Transcription (mpopt.py:105-639)
+# ---------------------------------------------------------------------------------------------
+class OracleNLP:
+    """f, g and derivatives of the NLP that ``mpopt.create_nlp`` builds, evaluated on the CPU."""
+
+    def __init__(self, ocp, n_segments, poly_orders, scheme="LGR", tau0=-1.0, tau1=1.0, fn=None):
+        import sympy
+
+        self.sympy = sympy
+        self.ocp = o = ocp
+        orders = [poly_orders] * n_segments if isinstance(poly_orders, (int, np.integer)) else list(poly_orders)
+        assert len(orders) == n_segments
+        self.grid = G = Grid(orders, scheme, tau0, tau1)
+        self.S, self.N = G.S, G.N
+        self.nx, self.nu, self.na, self.n_ph = o.nx, o.nu, o.na, o.n_phases
+        self.sx, self.su, self.sa = (np.asarray(v, float) for v in (o.scale_x, o.scale_u, o.scale_a))
+        self.st = float(o.scale_t)
+        self.compD, self.compW = G.comp_D(), G.comp_W()
+        self.seg, self.pt = G.node_seg_point()
+        self.n_zp = self.N * (self.nx + self.nu) + 2 + self.na  # mpopt.py:537-543
+        self.n_z = self.n_zp * self.n_ph
+        self.n_p = self.S * self.n_ph
+        self.has_path = [o.has_path_constraints(ph) for ph in range(self.n_ph)]
+        self.has_tc = [o.has_terminal_constraints(ph) for ph in range(self.n_ph)]
+        self.midu = [bool(o.midu[ph]) and bool((np.asarray(o.lbu[ph]) > -np.inf).any() or (np.asarray(o.ubu[ph]) < np.inf).any())
+                     for ph in range(self.n_ph)]
+        self.I_mid = G.comp_I_mid()
+        if self.S > 1:  # mpopt.py:398-403
+            Dat = G.comp_interp([np.array([tau0, tau1])] * self.S, deriv=1)
+            self.D_cont = Dat[1:-1][::2] - Dat[2:-1][::2]
+        self._build_symbolic()
+        self.n_g = len(self.g(np.zeros(self.n_z) + 0.5, np.full(self.n_p, 1.0 / self.S)))
+
+    # -- helpers ---------------------------------------------------------------------------
+    def split(self, z, ph):
+        zp = np.asarray(z, float)[ph * self.n_zp:(ph + 1) * self.n_zp]
+        N, nx, nu = self.N, self.nx, self.nu
+        X = zp[:nx * N].reshape(nx, N).T
+        U = zp[nx * N:(nx + nu) * N].reshape(nu, N).T
+        return X, U, zp[(nx + nu) * N], zp[(nx + nu) * N + 1], zp[(nx + nu) * N + 2:]
+
+    def zidx(self, ph, kind, comp=0, node=0):
+        base, N, nx, nu = ph * self.n_zp, self.N, self.nx, self.nu
+        return {"X": base + comp * N + node, "U": base + (nx + comp) * N + node, "t0": base + (nx + nu) * N,
+                "tf": base + (nx + nu) * N + 1, "A": base + (nx + nu) * N + 2 + comp}[kind]
+
+    def node_times(self, t0, tf, w):
+        """h_seg and t of every node, accumulated like mpopt.py:180-198."""
+        G = self.grid
+        h_node, t_node = np.zeros(self.N), np.zeros(self.N)
+        t_seg0, s = t0, 0
+        h = (tf - t0) / (G.tau1 - G.tau0) * w[0]
+        for i in range(self.N):
+            if self.seg[i] != s:
+                s = self.seg[i]
+                t_seg0 = t_seg0 + h * (G.tau1 - G.tau0)
+                h = (tf - t0) / (G.tau1 - G.tau0) * w[s]
+            h_node[i] = h
+            t_node[i] = t_seg0 + h * (G.taus[G.orders[s]][self.pt[i]] - G.tau0)
+        return h_node, t_node
+
+    # -- values: a line-by-line restatement ------------------------------------------------------
+    def phase_parts(self, z, p, ph):
+        o, G = self.ocp, self.grid
+        X, U, t0v, tfv, A = self.split(z, ph)
+        t0, tf = t0v / self.st, tfv / self.st  # mpopt.py:175-176
+        a = A / self.sa  # mpopt.py:177
+        w = np.asarray(p, float)[ph * self.S:(ph + 1) * self.S]
+        h, t = self.node_times(t0, tf, w)
+        dyn, pc, rc = o.get_dynamics(ph), o.get_path_constraints(ph), o.get_running_costs(ph)
+        f = np.zeros((self.N, self.nx))
+        c = []
+        q = np.zeros(self.N)
+        for i in range(self.N):
+            x, u = X[i] / self.sx, U[i] / self.su  # mpopt.py:196-197
+            f[i] = h[i] * self.sx * np.array([float(v) for v in dyn(x, u, t[i], a)])  # mpopt.py:201
+            if self.has_path[ph]:
+                c.append([float(v) for v in pc(x, u, t[i], a)])  # mpopt.py:204
+            q[i] = h[i] * float(rc(x, u, t[i], a))  # mpopt.py:206
+        F = (self.compD @ X - f).T.ravel()  # mpopt.py:227-232, state-major
+        parts = [F]
+        if self.has_path[ph]:
+            parts.append(np.array(c).T.ravel())  # mpopt.py:255
+        if o.diff_u[ph]:
+            parts.append((self.compD @ U).T.ravel())  # mpopt.py:315-321
+        if self.midu[ph]:
+            parts.append((self.I_mid @ U).T.ravel())  # mpopt.py:357-366
+        if self.S > 1 and o.du_continuity[ph]:
+            parts.append((self.D_cont @ U).T.ravel())  # mpopt.py:394-408
+        x0, xf = X[0] / self.sx, X[-1] / self.sx  # mpopt.py:277-278
+        if self.has_tc[ph]:
+            parts.append(np.array([float(v) for v in o.get_terminal_constraints(ph)(xf, tf, x0, t0, a)]))  # 289
+        J = float(o.get_terminal_costs(ph)(xf, tf, x0, t0, a)) + float(self.compW @ q)  # mpopt.py:297-298, 455
+        return np.concatenate(parts), J
+
+    def events(self, z):  # mpopt.py:464-521
+        o = self.ocp
+        if self.n_ph < 2:
+            return np.zeros(0)
+        ex, eu, et = [], [], []
+        for (i, j) in o.phase_links:
+            Xi, Ui, _, tfi, _ = self.split(z, i)
+            Xj, Uj, t0j, _, _ = self.split(z, j)
+            ex.append(Xj[0] - Xi[-1]), eu.append(Uj[0] - Ui[-1]), et.append([t0j - tfi])
+        return np.concatenate([np.concatenate(ex), np.concatenate(eu), np.concatenate(et)])
+
+    def g(self, z, p):  # mpopt.py:612-624
+        return np.concatenate([self.phase_parts(z, p, ph)[0] for ph in range(self.n_ph)] + [self.events(z)])
+
+    def f(self, z, p):
+        return sum(self.phase_parts(z, p, ph)[1] for ph in range(self.n_ph))
+
+    # -- bounds and initial guess ---------------------------------------------------------------
+    def bounds(self):
+        """(lbx, ubx, lbg, ubg) following mpopt.py:546-570, 234-235, 257-258, 291-292, 323-324,
+        368-369, 410-411, 459-460, 491-519."""
+        o, N = self.ocp, self.N
+        zmin, zmax, gmin, gmax = [], [], [], []
+        for ph in range(self.n_ph):
+            xmin = [np.asarray(o.lbx[ph], float) * self.sx] * N
+            xmax = [np.asarray(o.ubx[ph], float) * self.sx] * N
+            if ph == 0:
+                xmin[0] = xmax[0] = np.asarray(o.x00[0], float) * self.sx
+            zmin.append(np.concatenate([np.concatenate(np.array(xmin).T), np.repeat(np.asarray(o.lbu[ph], float) * self.su, N),
+                                        np.asarray(o.lbt0[ph], float).ravel() * self.st, np.asarray(o.lbtf[ph], float).ravel() * self.st,
+                                        np.asarray(o.lba[ph], float) * self.sa]))
+            zmax.append(np.concatenate([np.concatenate(np.array(xmax).T), np.repeat(np.asarray(o.ubu[ph], float) * self.su, N),
+                                        np.asarray(o.ubt0[ph], float).ravel() * self.st, np.asarray(o.ubtf[ph], float).ravel() * self.st,
+                                        np.asarray(o.uba[ph], float) * self.sa]))
+            lo, hi = [np.zeros(self.nx * N)], [np.zeros(self.nx * N)]
+            if self.has_path[ph]:
+                nc = len(o.get_path_constraints(ph)(o.x00[ph], o.u00[ph], o.t00[ph], o.a0[ph]))
+                lo.append(np.full(nc * N, -np.inf)), hi.append(np.zeros(nc * N))
+            if o.diff_u[ph]:
+                lo.append(np.full(self.nu * N, float(o.lbdu[ph]))), hi.append(np.full(self.nu * N, float(o.ubdu[ph])))
+            if self.midu[ph]:
+                lo.append(np.repeat(np.asarray(o.lbu[ph], float) * self.su, N - 1))
+                hi.append(np.repeat(np.asarray(o.ubu[ph], float) * self.su, N - 1))
+            if self.S > 1 and o.du_continuity[ph]:
+                lo.append(np.zeros(self.nu * (self.S - 1))), hi.append(np.zeros(self.nu * (self.S - 1)))
+            if self.has_tc[ph]:
+                ntc = len(o.get_terminal_constraints(ph)(o.xf0[ph], o.tf0[ph], o.x00[ph], o.t00[ph], o.a0[ph]))
+                lo.append(np.zeros(ntc)), hi.append(np.zeros(ntc))
+            gmin.append(np.concatenate(lo)), gmax.append(np.concatenate(hi))
+        if self.n_ph > 1:
+            n = len(o.phase_links)
+            gmin += [np.concatenate([np.asarray(o.lbe[k], float) * self.sx for k in range(n)]), np.zeros(self.nu * n), np.zeros(n)]
+            gmax += [np.concatenate([np.asarray(o.ube[k], float) * self.sx for k in range(n)]), np.zeros(self.nu * n), np.zeros(n)]
+        return np.concatenate(zmin), np.concatenate(zmax), np.concatenate(gmin), np.concatenate(gmax)
+
+    def initial_guess(self):  # mpopt.py:641-708
+        o, N, out = self.ocp, self.N, []
+        for ph in range(self.n_ph):
+            x00, xf0 = np.asarray(o.x00[ph], float) * self.sx, np.asarray(o.xf0[ph], float) * self.sx
+            u00, uf0 = np.asarray(o.u00[ph], float) * self.su, np.asarray(o.uf0[ph], float) * self.su
+            t00, tf0 = np.asarray(o.t00[ph], float) * self.st, np.asarray(o.tf0[ph], float) * self.st
+            a0 = np.asarray(o.a0[ph], float) * self.sa
+            ts = np.linspace(t00, tf0, N)
+            zx = np.concatenate(np.array([x00 + (xf0 - x00) / (tf0 - t00) * (t - t00) for t in ts]).T)
+            zu = np.concatenate(np.array([u00 + (uf0 - u00) / (tf0 - t00) * (t - t00) for t in ts]))
+            out.append(np.concatenate([zx, zu, t00, tf0, a0]))
+        return np.concatenate(out)
+
+    # -- derivatives: sympy per node, numpy assembly ------------------------------------------------
+    def _build_symbolic(self):
+        """Per-phase symbolic node functions in the NLP variables.  Mirrors what CasADi's AD sees:
+        f_i = h_s*Sx*dyn(X_i/Sx, U_i/Su, t_i, A/Sa) with h_s, t_i functions of (t0, tf, w)."""
+        sy, o = self.sympy, self.ocp
+        nx, nu, na = self.nx, self.nu, self.na
+        self.sym = []
+        for ph in range(self.n_ph):
+            X = sy.symbols(f"X0:{nx}", real=True)
+            U = sy.symbols(f"U0:{nu}", real=True) if nu else ()
+            A = sy.symbols(f"A0:{na}", real=True) if na else ()
+            t0v, tfv, kap, th = sy.symbols("t0v tfv kap th", real=True)
+            x = [X[a] / sy.Float(self.sx[a]) for a in range(nx)]
+            u = [U[b] / sy.Float(self.su[b]) for b in range(nu)]
+            a_ = [A[c] / sy.Float(self.sa[c]) for c in range(na)]
+            t0, tf = t0v / sy.Float(self.st), tfv / sy.Float(self.st)
+            h = (tf - t0) * kap
+            t = t0 + (tf - t0) * th
+            dyn = [sy.sympify(v) for v in o.get_dynamics(ph)(x, u, t, a_)]
+            fx = [h * sy.Float(self.sx[a]) * dyn[a] for a in range(nx)]
+            c = [sy.sympify(v) for v in o.get_path_constraints(ph)(x, u, t, a_)] if self.has_path[ph] else []
+            q = h * sy.sympify(o.get_running_costs(ph)(x, u, t, a_))
+            v = list(X) + list(U) + [t0v, tfv] + list(A)
+            args = v + [kap, th]
+            XF = sy.symbols(f"XF0:{nx}", real=True)
+            XI = sy.symbols(f"XI0:{nx}", real=True)
+            xf = [XF[a] / sy.Float(self.sx[a]) for a in range(nx)]
+            x0 = [XI[a] / sy.Float(self.sx[a]) for a in range(nx)]
+            M = sy.sympify(o.get_terminal_costs(ph)(xf, tf, x0, t0, a_))
+            TC = [sy.sympify(e) for e in o.get_terminal_constraints(ph)(xf, tf, x0, t0, a_)] if self.has_tc[ph] else []
+            tvars = list(XF) + [tfv] + list(XI) + [t0v] + list(A)
+            L = lambda exprs, ar: sy.lambdify(ar, exprs, "numpy")
+            d = dict(nc=len(c), ntc=len(TC), v=v, tvars=tvars,
+                     vals=L(fx + c + [q], args),
+                     jac=L([[sy.diff(e, s) for s in v] for e in fx + c + [q]], args),
+                     hes=L([[[sy.diff(e, s1, s2) for s2 in v] for s1 in v] for e in fx + c + [q]], args),
+                     tvals=L([M] + TC, tvars),
+                     tjac=L([[sy.diff(e, s) for s in tvars] for e in [M] + TC], tvars),
+                     thes=L([[[sy.diff(e, s1, s2) for s2 in tvars] for s1 in tvars] for e in [M] + TC], tvars))
+            self.sym.append(d)
+
+    def _node_args(self, z, p, ph):
+        G = self.grid
+        X, U, t0v, tfv, A = self.split(z, ph)
+        w = np.asarray(p, float)[ph * self.S:(ph + 1) * self.S]
+        wcum = np.concatenate([[0.0], np.cumsum(w)[:-1]])
+        kap = w[self.seg] / (G.tau1 - G.tau0)
+        tk = np.array([(G.taus[G.orders[s]][k] - G.tau0) / (G.tau1 - G.tau0) for s, k in zip(self.seg, self.pt)])
+        th = wcum[self.seg] + w[self.seg] * tk
+        ones = np.ones(self.N)
+        return [X[:, a] for a in range(self.nx)] + [U[:, b] for b in range(self.nu)] + [t0v * ones, tfv * ones] + \
+               [A[c] * ones for c in range(self.na)] + [kap, th]
+
+    def _term_args(self, z, ph):
+        X, U, t0v, tfv, A = self.split(z, ph)
+        return list(X[-1]) + [tfv] + list(X[0]) + [t0v] + list(A)
+
+    def _vcols(self, ph, i):
+        return ([self.zidx(ph, "X", a, i) for a in range(self.nx)] + [self.zidx(ph, "U", b, i) for b in range(self.nu)]
+                + [self.zidx(ph, "t0"), self.zidx(ph, "tf")] + [self.zidx(ph, "A", c) for c in range(self.na)])
+
+    def _tcols(self, ph):
+        N = self.N
+        return ([self.zidx(ph, "X", a, N - 1) for a in range(self.nx)] + [self.zidx(ph, "tf")]
+                + [self.zidx(ph, "X", a, 0) for a in range(self.nx)] + [self.zidx(ph, "t0")] + [self.zidx(ph, "A", c) for c in range(self.na)])
+
+    def _bc(self, v):
+        return np.broadcast_to(np.asarray(v, float), (self.N,))
+
+    def row_offsets(self, ph_target=None):
+        """Row offset of every block, per phase: dict with F, C, DU, mU, dU, TC, and 'events'."""
+        o, N, r, out = self.ocp, self.N, 0, []
+        for ph in range(self.n_ph):
+            d = {"F": r}
+            r += self.nx * N
+            d["C"] = r
+            r += self.sym[ph]["nc"] * N
+            d["DU"] = r
+            r += self.nu * N if o.diff_u[ph] else 0
+            d["mU"] = r
+            r += self.nu * (N - 1) if self.midu[ph] else 0
+            d["dU"] = r
+            r += self.nu * (self.S - 1) if (self.S > 1 and o.du_continuity[ph]) else 0
+            d["TC"] = r
+            r += self.sym[ph]["ntc"]
+            out.append(d)
+        return out, r
+
+    def jac_g(self, z, p):
+        """Sparse (n_g x n_z) Jacobian of g; explicit zeros are not stored."""
+        o, N, nx, nu = self.ocp, self.N, self.nx, self.nu
+        offs, ev_row = self.row_offsets()
+        R, C, V = [], [], []
+
+        def add(r, c, v):
+            R.append(np.asarray(r).ravel()), C.append(np.asarray(c).ravel()), V.append(np.asarray(v, float).ravel())
+
+        nodes = np.arange(N)
+        for ph in range(self.n_ph):
+            d, off = self.sym[ph], offs[ph]
+            J = d["jac"](*self._node_args(z, p, ph))
+            Dr, Dc = np.nonzero(self.compD)
+            for a in range(nx):
+                add(off["F"] + a * N + Dr, self.zidx(ph, "X", a, 0) + Dc, self.compD[Dr, Dc])
+                for k, col in enumerate(zip(*[self._vcols(ph, i) for i in range(N)])):
+                    add(off["F"] + a * N + nodes, np.array(col), -self._bc(J[a][k]))
+            for j in range(d["nc"]):
+                for k, col in enumerate(zip(*[self._vcols(ph, i) for i in range(N)])):
+                    add(off["C"] + j * N + nodes, np.array(col), self._bc(J[nx + j][k]))
+            if o.diff_u[ph]:
+                for b in range(nu):
+                    add(off["DU"] + b * N + Dr, self.zidx(ph, "U", b, 0) + Dc, self.compD[Dr, Dc])
+            if self.midu[ph]:
+                Ir, Ic = np.nonzero(self.I_mid)
+                for b in range(nu):
+                    add(off["mU"] + b * (N - 1) + Ir, self.zidx(ph, "U", b, 0) + Ic, self.I_mid[Ir, Ic])
+            if self.S > 1 and o.du_continuity[ph]:
+                Cr, Cc = np.nonzero(self.D_cont)
+                for b in range(nu):
+                    add(off["dU"] + b * (self.S - 1) + Cr, self.zidx(ph, "U", b, 0) + Cc, self.D_cont[Cr, Cc])
+            if d["ntc"]:
+                TJ = d["tjac"](*self._term_args(z, ph))
+                for j in range(d["ntc"]):
+                    add(off["TC"] + j + np.zeros(len(TJ[1 + j]), int), np.array(self._tcols(ph)), np.array(TJ[1 + j], float))
+        if self.n_ph > 1:
+            r = ev_row
+            for kind, cnt in (("X", nx), ("U", nu)):
+                for (i, j) in o.phase_links:
+                    for a in range(cnt):
+                        add([r, r], [self.zidx(j, kind, a, 0), self.zidx(i, kind, a, N - 1)], [1.0, -1.0])
+                        r += 1
+            for (i, j) in o.phase_links:
+                add([r, r], [self.zidx(j, "t0"), self.zidx(i, "tf")], [1.0, -1.0])
+                r += 1
+        M = sp.coo_matrix((np.concatenate(V), (np.concatenate(R), np.concatenate(C))), shape=(self.n_g, self.n_z)).tocsr()
+        M.eliminate_zeros()
+        return M
+
+    def grad_f(self, z, p):
+        g = np.zeros(self.n_z)
+        for ph in range(self.n_ph):
+            d = self.sym[ph]
+            J = d["jac"](*self._node_args(z, p, ph))
+            dq = J[self.nx + d["nc"]]
+            for k, col in enumerate(zip(*[self._vcols(ph, i) for i in range(self.N)])):
+                np.add.at(g, np.array(col), self.compW * self._bc(dq[k]))
+            TJ = d["tjac"](*self._term_args(z, ph))
+            np.add.at(g, np.array(self._tcols(ph)), np.array(TJ[0], float))
+        return g
+
+    def hess_l(self, z, p, sigma, lam):
+        """Dense symmetric Hessian of sigma*f + lam^T g."""
+        N, nx = self.N, self.nx
+        offs, _ = self.row_offsets()
+        H = np.zeros((self.n_z, self.n_z))
+        lam = np.asarray(lam, float)
+        for ph in range(self.n_ph):
+            d, off = self.sym[ph], offs[ph]
+            Hs = d["hes"](*self._node_args(z, p, ph))
+            nv = len(d["v"])
+            cols = np.array([self._vcols(ph, i) for i in range(N)])  # N x nv
+            wts = [-lam[off["F"] + a * N:off["F"] + (a + 1) * N] for a in range(nx)] + \
+                  [lam[off["C"] + j * N:off["C"] + (j + 1) * N] for j in range(d["nc"])] + [sigma * self.compW]
+            for e, wt in enumerate(wts):
+                for k1 in range(nv):
+                    for k2 in range(nv):
+                        np.add.at(H, (cols[:, k1], cols[:, k2]), wt * self._bc(Hs[e][k1][k2]))
+            TH = d["thes"](*self._term_args(z, ph))
+            tc = np.array(self._tcols(ph))
+            twts = [sigma] + [lam[off["TC"] + j] for j in range(d["ntc"])]
+            for e, wt in enumerate(twts):
+                H[np.ix_(tc, tc)] += wt * np.array(TH[e], float)
+        return H

@@ -208,6 +208,15 @@ GOLDEN_CASES = {
 }
 
 
+#: (builder, n_segments, poly_orders, scheme) of the BASELINE.json configurations at full size
+BENCH_CASES = [
+    (moon_lander, 1000, 5, "LGR"),                                           # configs[1] (the metric's config)
+    (van_der_pol, 2000, [30 if s % 3 == 1 else 3 for s in range(2000)], "CGL"),  # configs[2]
+    (two_phase_schwartz, 500, 3, "LGL"),                                     # configs[3]
+    (hyper_sensitive, 4000, 3, "LGR"),                                       # configs[4]
+]
+
+
 def sample_point(name, n_z, n_p, n_g, z0, lbx, ubx):
     """Deterministic evaluation point: Z0 + seeded perturbation clipped
     to the bounds, non-uniform positive widths summing to one per phase, N(0,1) multipliers."""
