@@ -1,0 +1,135 @@
+"""Host logic without a GPU: C-ABI symbols, structure (sizes, COO patterns, z0, bounds) against the
+reference goldens, loud failure without device code, the tracer, and the OCP container."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mpopt_amd as M
+from mpopt_amd import mp, _lib
+from mpopt_amd.expr import Tracer
+import problems
+from helpers import build_case, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_symbol_of_the_header():
+    hdr = open(os.path.join(ROOT, "include", "mpx.h")).read()
+    declared = set(re.findall(r"\b(mpx_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"mpx_problem", "mpx_sizes", "mpx_ctx"}
+    L = ctypes.CDLL(_lib.build_library())
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libmpx.so does not export {name}"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+
+
+@pytest.mark.parametrize("name", list(problems.GOLDEN_CASES))
+def test_structure_matches_reference(name):
+    G = load_golden(name)
+    ocp, mpo, o = build_case(name, with_device=False)
+    assert (o.n_z, o.n_g, o.n_p) == (len(G["z0"]), len(G["lbg"]), len(G["p"]))
+    nlp, b = mpo.create_nlp()
+    for k in ("lbx", "ubx", "lbg", "ubg"):
+        assert np.array_equal(b[k], G[k]), k
+    assert set(nlp) >= {"f", "x", "g", "p"}
+    assert np.array_equal(mpo.initialize_solution(), G["z0"])
+    assert np.array_equal(np.asarray(mpo.get_segment_width_parameters(None)), G["p_equal"])
+    jr, jc = o.jac_pattern()
+    mine = set(zip(jr.tolist(), jc.tolist()))
+    ref = set(zip(G["jac_row"].tolist(), G["jac_col"].tolist()))
+    assert len(mine) == o.nnz_jac, "duplicate Jacobian entries"
+    assert ref <= mine
+    # anything extra must sit in a differentiation/interpolation block (an exactly-zero table entry
+    # that CasADi drops): same row has other entries in the same column block
+    assert len(mine - ref) <= 0.02 * len(ref) + 8
+    hr, hc = o.hess_pattern()
+    hm = set(zip(hr.tolist(), hc.tolist()))
+    assert len(hm) == o.nnz_hess and (hr <= hc).all()
+    assert hm == set(zip(G["hess_row"].tolist(), G["hess_col"].tolist()))
+    perm, colind = o.ccs_perm("jac")
+    assert sorted(perm.tolist()) == list(range(o.nnz_jac)) and colind[-1] == o.nnz_jac
+    cols, rows = jc[perm], jr[perm]
+    assert (np.diff(cols) >= 0).all() and all((np.diff(rows[colind[j]:colind[j + 1]]) > 0).all() for j in range(0, o.n_z, 7))
+    assert o.bytes_fgj == 8 * (2 * o.n_z + o.n_p + o.n_g + o.nnz_jac + 1)
+
+
+def test_sizes_of_baseline_configs():
+    """SURVEY.md section 8 size table (n_z, n_g) for BASELINE.json configs 1, 2, 4, 5."""
+    for builder, S, po, scheme, n_z, n_g in [
+        (problems.moon_lander, 20, 3, "LGR", 185, 184),
+        (problems.moon_lander, 1000, 5, "LGR", 15005, 15004),
+        (problems.two_phase_schwartz, 500, 3, "LGL", 2 * 4505, 6003 + 3002 + 4),
+        (problems.hyper_sensitive, 4000, 3, "LGR", 24004, 12002),
+    ]:
+        o = M.NlpFunctions(builder(mp, M.math), S, [po] * S, scheme, with_device=False)
+        assert (o.n_z, o.n_g) == (n_z, n_g)
+
+
+def test_no_cpu_fallback():
+    ocp, mpo, o = build_case("moon_lander_20x3_LGR", with_device=False)
+    assert not o.has_device
+    with pytest.raises(M.MpxError, match="no CPU fallback"):
+        o.eval(["f"], mpo.initialize_solution(), np.full(20, 1 / 20))
+
+
+def test_bad_inputs_are_reported_not_fatal():
+    ocp = problems.moon_lander(mp, M.math)
+    with pytest.raises(ValueError):
+        M.NlpFunctions(ocp, 3, [3, 3], "LGR", with_device=False)
+    with pytest.raises(M.MpxError):
+        M.NlpFunctions(ocp, 2, [3, 0], "LGR", with_device=False)
+    L = _lib.lib()
+    assert L.mpx_create(None, None) < 0 and b"null" in L.mpx_last_error(None)
+
+
+def test_tracer_derivatives_against_sympy():
+    import sympy as sp
+
+    tr = Tracer()
+    x, y, z = tr.var("x"), tr.var("y"), tr.var("z")
+    m = M.math
+    e = (x * y - m.sin(z * x)) / (1.0 + y * y) + m.exp(-0.3 * x) * m.sqrt(2.0 + z * z) + x ** 3 - (y ** 2.5) + m.tanh(x * z) + m.log(3.0 + y)
+    X, Y, Z = sp.symbols("x y z")
+    se = (X * Y - sp.sin(Z * X)) / (1.0 + Y * Y) + sp.exp(-0.3 * X) * sp.sqrt(2.0 + Z * Z) + X ** 3 - (Y ** 2.5) + sp.tanh(X * Z) + sp.log(3.0 + Y)
+    env = {"x": 0.7, "y": 1.3, "z": -0.4}
+    sub = {X: 0.7, Y: 1.3, Z: -0.4}
+    vs, svs = [x, y, z], [X, Y, Z]
+    assert tr.evaluate([e], env)[0] == pytest.approx(float(se.subs(sub)), rel=1e-14)
+    for v, sv in zip(vs, svs):
+        d = tr.diff(e, v)
+        assert tr.evaluate([d], env)[0] == pytest.approx(float(sp.diff(se, sv).subs(sub)), rel=1e-12)
+        for w, sw in zip(vs, svs):
+            d2 = tr.diff(d, w)
+            assert tr.evaluate([d2], env)[0] == pytest.approx(float(sp.diff(se, sv, sw).subs(sub)), rel=1e-11, abs=1e-13)
+    # structural zeros are exact
+    assert tr.diff(x * y, z).is_zero and tr.diff(tr.diff(x * y + z, x), x).is_zero
+    with pytest.raises(TypeError):
+        bool(x > 0) if hasattr(x, "__gt__") else bool(x)
+
+
+@pytest.mark.parametrize("nx,nu,nph,na", [(1, 1, 1, 0), (2, 1, 1, 0), (3, 2, 2, 0), (2, 2, 3, 2), (7, 3, 4, 1)])
+def test_ocp_defaults(nx, nu, nph, na):
+    """Mirror of the reference's OCP shape/default checks (tests/test_mpopt.py:28-85)."""
+    ocp = mp.OCP(n_states=nx, n_controls=nu, n_phases=nph, n_params=na)
+    ocp.validate()
+    assert (ocp.nx, ocp.nu, ocp.n_phases, ocp.na) == (nx, nu, nph, na)
+    assert ocp.x00.shape == (nph, nx) and ocp.u00.shape == (nph, nu) and ocp.a0.shape == (nph, na)
+    assert ocp.lbt0[0] == 0 and ocp.ubt0[0] == 0 and (ocp.tf0 == 1).all()
+    assert np.isinf(ocp.lbx).all() and np.isinf(ocp.ubu).all()
+    assert ocp.phase_links == [(i, i + 1) for i in range(nph - 1)]
+    assert (ocp.midu == 1).all() and (ocp.diff_u == 0).all() and (ocp.du_continuity == 0).all()
+    assert not ocp.has_path_constraints(0) and not ocp.has_terminal_constraints(0)
+    assert len(ocp.get_dynamics(0)(ocp.x00[0], ocp.u00[0], 0.0, ocp.a0[0])) == nx
+
+
+def test_generated_source_is_deterministic_and_cached():
+    ocp = problems.kitchen_sink(mp, M.math)
+    a = M.NlpFunctions(ocp, 3, [2, 4, 3], "CGL", with_device=False)
+    b = M.NlpFunctions(problems.kitchen_sink(mp, M.math), 3, [2, 4, 3], "CGL", with_device=False)
+    assert a.source == b.source and (a.structure == b.structure).all()
+    co1, path1 = _lib.compile_kernels(a.source)
+    co2, path2 = _lib.compile_kernels(b.source)
+    assert path1 == path2 and co1 == co2 and (co1[:4] == b"\x7fELF" or co1.startswith(b"__CLANG_OFFLOAD_BUNDLE__"))
