@@ -32,6 +32,8 @@ def lib():
         for n in ("orc_n_z", "orc_n_g", "orc_nnz"):
             getattr(L, n).restype = ctypes.c_int64
             getattr(L, n).argtypes = [ctypes.c_void_p]
+        L.orc_set_table.restype = ctypes.c_int
+        L.orc_set_table.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp, dp]
         L.orc_eval.restype = ctypes.c_int64
         L.orc_eval.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 8
         L.orc_eval_many.restype = None
@@ -61,6 +63,13 @@ class COracle:
         if not self._h:
             raise ValueError(f"unknown C oracle problem in {names}")
         self.n_z, self.n_g, self.nnz = L.orc_n_z(self._h), L.orc_n_g(self._h), L.orc_nnz(self._h)
+        for d in degs:
+            if d > 10:  # see "exact_tables" in mpopt_oracle.py
+                x = npo.roots(scheme, int(d), tau0, tau1)
+                D = np.ascontiguousarray(npo.exact_tables(x, x, 1))
+                w = np.ascontiguousarray(npo.exact_tables(x, None, "w", tau0, tau1))
+                Cm = np.ascontiguousarray(npo.exact_tables(x, (x[:-1] + x[1:]) / 2.0, 0))
+                assert L.orc_set_table(self._h, int(d), D.ctypes.data_as(dp), w.ctypes.data_as(dp), Cm.ctypes.data_as(dp)) == 0
 
     def eval(self, z, p):
         L = lib()

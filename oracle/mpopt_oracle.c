@@ -339,6 +339,23 @@ orc* orc_create(int n_ph, const char** names, int S, const int* orders, int n_de
   return o;
 }
 
+/* Replace the tables of one degree (used above degree 10, where monomial-coefficient arithmetic
+ * is no longer accurate: the caller passes 50-digit tables from oracle/mpopt_oracle.py). */
+int orc_set_table(orc* o, int deg, const double* D, const double* w, const double* Cmid) {
+  for (int k = 0; k < o->n_tabs; ++k)
+    if (o->tabs[k].deg == deg) {
+      int n = deg + 1;
+      memcpy(o->tabs[k].D, D, n * n * sizeof(double));
+      memcpy(o->tabs[k].w, w, n * sizeof(double));
+      memcpy(o->tabs[k].Cmid, Cmid, deg * n * sizeof(double));
+      o->compW[0] = tab(o, o->orders[0])->w[0];
+      for (int s = 0; s < o->S; ++s)
+        for (int q = 1; q <= o->orders[s]; ++q) o->compW[o->start[s] + q] = tab(o, o->orders[s])->w[q];
+      return 0;
+    }
+  return -1;
+}
+
 void orc_destroy(orc* o) {
   if (!o) return;
   free(o->orders), free(o->start), free(o->seg), free(o->pt), free(o->tabs), free(o->sx), free(o->su), free(o->sa), free(o->compW);

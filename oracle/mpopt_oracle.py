@@ -85,18 +85,89 @@ def interp_matrix(nodes, taus):  # mpopt.py:3884-3905
     return C
 
 
-class Grid:
-    """Tables of one grid: what mpopt.compute_numerical_approximation caches (mpopt.py:95-103)."""
+# ---------------------------------------------------------------------------------------------
+# The same definitions in 50-digit arithmetic.  The reference's "numerical" back-end above loses
+# digits as the degree grows (np.poly1d coefficient products: ~1e-9 at p=20, ~4e-4 at p=30, see
+# tests/test_tables.py and DESIGN.md), while its default "symbolic" back-end (CasADi AD of the
+# product form, mpopt.py:3832-3840) does not.  Above degree 10 the oracle therefore evaluates the
+# definitions l_j^(k)(tau_i), int l_j exactly (mpmath) instead of imitating the rounding failure.
+# ---------------------------------------------------------------------------------------------
+def _mp_basis_coeffs(nodes):
+    import mpmath as mpm
 
-    def __init__(self, poly_orders, scheme, tau0=-1.0, tau1=1.0):
+    mpm.mp.dps = 50
+    xs = [mpm.mpf(float(v)) for v in nodes]
+    out = []
+    for j in range(len(xs)):
+        c = [mpm.mpf(1)]  # highest power first
+        for i in range(len(xs)):
+            if i != j:
+                den = xs[j] - xs[i]
+                new = [mpm.mpf(0)] * (len(c) + 1)
+                for k, ck in enumerate(c):
+                    new[k] += ck / den
+                    new[k + 1] -= ck * xs[i] / den
+                c = new
+        out.append(c)
+    return out
+
+
+def _mp_polyval(c, t):
+    import mpmath as mpm
+
+    v = mpm.mpf(0)
+    for ck in c:
+        v = v * t + ck
+    return v
+
+
+def exact_tables(nodes, taus, order, a=None, b=None):
+    """order 0/1/2: matrix l_j^(order)(taus_i); order 'w': weights over [a, b]."""
+    import mpmath as mpm
+
+    C = _mp_basis_coeffs(nodes)
+    n = len(nodes)
+    if order == "w":
+        out = np.zeros(n)
+        for j, c in enumerate(C):
+            I = [ck / (n - k) for k, ck in enumerate(c)] + [mpm.mpf(0)]
+            out[j] = float(_mp_polyval(I, mpm.mpf(float(b))) - _mp_polyval(I, mpm.mpf(float(a))))
+        return out
+    out = np.zeros((len(taus), n))
+    for j, c in enumerate(C):
+        d = c
+        for _ in range(order):
+            m = len(d) - 1
+            d = [ck * (m - k) for k, ck in enumerate(d[:-1])] or [mpm.mpf(0)]
+        for i, t in enumerate(taus):
+            out[i, j] = float(_mp_polyval(d, mpm.mpf(float(t))))
+    return out
+
+
+class Grid:
+    """Tables of one grid: what mpopt.compute_numerical_approximation caches (mpopt.py:95-103).
+    ``method``: "numerical" = the reference's np.poly1d arithmetic (pinned by the goldens),
+    "exact" = 50-digit evaluation, "auto" = numerical up to degree 10, exact above."""
+
+    def __init__(self, poly_orders, scheme, tau0=-1.0, tau1=1.0, method="auto"):
         self.orders = [int(p) for p in poly_orders]
         self.scheme, self.tau0, self.tau1 = scheme, float(tau0), float(tau1)
         self.S = len(self.orders)
         self.N = sum(self.orders) + 1
         self.taus = {d: roots(scheme, d, tau0, tau1) for d in set(self.orders)}
-        self.D = {d: diff_matrix(self.taus[d]) for d in self.taus}
-        self.w = {d: quad_weights(self.taus[d], tau0, tau1) for d in self.taus}
+        self.exact = {d: (method == "exact" or (method == "auto" and d > 10)) for d in self.taus}
+        self.D = {d: self._diff(d, None, 1) for d in self.taus}
+        self.w = {d: (exact_tables(self.taus[d], None, "w", tau0, tau1) if self.exact[d] else quad_weights(self.taus[d], tau0, tau1))
+                  for d in self.taus}
         self.start = np.concatenate([[0], np.cumsum(self.orders)]).astype(int)
+
+    def _diff(self, d, taus, order):
+        if self.exact[d]:
+            return exact_tables(self.taus[d], self.taus[d] if taus is None else taus, order)
+        return diff_matrix(self.taus[d], taus, order)
+
+    def _interp(self, d, taus):
+        return exact_tables(self.taus[d], taus, 0) if self.exact[d] else interp_matrix(self.taus[d], taus)
 
     def comp_D(self):  # mpopt.py:4015-4039
         out = np.zeros((self.N, self.N))
@@ -117,7 +188,7 @@ class Grid:
         r = 0
         for i, p in enumerate(self.orders):
             if n_t[i]:
-                blk = interp_matrix(self.taus[p], taus_list[i]) if deriv == 0 else diff_matrix(self.taus[p], taus_list[i], deriv)
+                blk = self._interp(p, taus_list[i]) if deriv == 0 else self._diff(p, taus_list[i], deriv)
                 out[r:r + n_t[i], self.start[i]:self.start[i] + p + 1] = blk
             r += n_t[i]
         return out
@@ -143,14 +214,14 @@ class Grid:
 class OracleNLP:
     """f, g and derivatives of the NLP that ``mpopt.create_nlp`` builds, evaluated on the CPU."""
 
-    def __init__(self, ocp, n_segments, poly_orders, scheme="LGR", tau0=-1.0, tau1=1.0, fn=None):
+    def __init__(self, ocp, n_segments, poly_orders, scheme="LGR", tau0=-1.0, tau1=1.0, table_method="auto"):
         import sympy
 
         self.sympy = sympy
         self.ocp = o = ocp
         orders = [poly_orders] * n_segments if isinstance(poly_orders, (int, np.integer)) else list(poly_orders)
         assert len(orders) == n_segments
-        self.grid = G = Grid(orders, scheme, tau0, tau1)
+        self.grid = G = Grid(orders, scheme, tau0, tau1, table_method)
         self.S, self.N = G.S, G.N
         self.nx, self.nu, self.na, self.n_ph = o.nx, o.nu, o.na, o.n_phases
         self.sx, self.su, self.sa = (np.asarray(v, float) for v in (o.scale_x, o.scale_u, o.scale_a))

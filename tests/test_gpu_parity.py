@@ -1,0 +1,176 @@
+"""GPU parity tests proper (through the C ABI): HIP kernels vs the oracles on seeded inputs, at
+reduced sizes against the numpy/sympy oracle (all five outputs) and at BASELINE.json's full sizes
+against the C oracle (f, g, grad_f, jac_g) plus size-independent derivative properties.
+Tolerance: 1e-10 relative for FP64 values (north_star); indices exact."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import mpopt_amd as M
+from mpopt_amd import mp
+import problems
+from helpers import rel_err
+from oracle.mpopt_oracle import OracleNLP
+from oracle.c_oracle import COracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def mixed(S):
+    return [30 if s % 3 == 1 else 3 for s in range(S)]
+
+
+REDUCED = {
+    "moon_lander_60x5": (problems.moon_lander, 60, 5, "LGR"),          # 301 nodes: two tiles
+    "moon_lander_1x1": (problems.moon_lander, 1, 1, "LGL"),            # smallest possible grid
+    "moon_lander_51x5": (problems.moon_lander, 51, 5, "CGL"),          # 256 nodes: exactly one full tile
+    "vdp_mixed_3_30_3": (problems.van_der_pol, 12, mixed(12), "CGL"),  # config 3's degree pattern
+    "dae_vdp_9x7": (problems.dae_vdp, 9, 7, "LGL"),
+    "hyper_sensitive_90x3": (problems.hyper_sensitive, 90, 3, "LGR"),  # 271 nodes
+    "schwartz_30x3": (problems.two_phase_schwartz, 30, 3, "LGL"),
+    "kitchen_sink_40": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR"),
+    "generic_two_phase_70x4": (problems.generic_two_phase, 70, 4, "CGL"),
+}
+
+
+def random_point(o, mpo, bounds, seed, S, n_ph):
+    rng = np.random.default_rng(seed)
+    z0 = mpo.initialize_solution()
+    z = z0 + 0.05 * np.abs(z0) * rng.uniform(-1, 1, o.n_z) + 0.05 * rng.uniform(-1, 1, o.n_z)
+    w = rng.uniform(0.3, 1.7, (n_ph, S))
+    p = (w / w.sum(axis=1, keepdims=True)).ravel()
+    return z, p, rng.standard_normal(o.n_g), float(rng.uniform(0.2, 2.0))
+
+
+@pytest.mark.parametrize("name", list(REDUCED))
+def test_reduced_size_against_numpy_oracle(name):
+    builder, S, po, scheme = REDUCED[name]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    O = OracleNLP(ocp, S, po, scheme)
+    assert (o.n_z, o.n_g) == (O.n_z, O.n_g)
+    lbx, ubx, lbg, ubg = O.bounds()
+    assert np.array_equal(lbx, bounds["lbx"]) and np.array_equal(ubx, bounds["ubx"])
+    assert np.array_equal(lbg, bounds["lbg"]) and np.array_equal(ubg, bounds["ubg"])
+    assert np.array_equal(O.initial_guess(), mpo.initialize_solution())
+    z, p, lam, sig = random_point(o, mpo, bounds, 11, S, ocp.n_phases)
+    r = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], z, p, lam_g=lam, sigma=sig)
+    assert rel_err(r["f"], O.f(z, p)) < TOL
+    assert rel_err(r["g"], O.g(z, p)) < TOL
+    assert rel_err(r["grad_f"], O.grad_f(z, p)) < TOL
+    jr, jc = o.jac_pattern()
+    J = sp.coo_matrix((r["jac_g"], (jr, jc)), shape=(o.n_g, o.n_z)).toarray()
+    assert rel_err(J, O.jac_g(z, p).toarray()) < TOL
+    hr, hc = o.hess_pattern()
+    H = sp.coo_matrix((r["hess_l"], (hr, hc)), shape=(o.n_z, o.n_z)).toarray()
+    H = H + np.triu(H, 1).T
+    assert rel_err(H, O.hess_l(z, p, sig, lam)) < TOL
+
+
+FULL = {
+    "config2_moon_lander_1000x5_LGR": (problems.BENCH_CASES[0], ["moon_lander"], 1.0, [1]),
+    "config3_vdp_2000_mixed_CGL": (problems.BENCH_CASES[1], ["van_der_pol"], 1.0, [1]),
+    "config4_schwartz_2x500x3_LGL": (problems.BENCH_CASES[2], ["schwartz_phase0", "schwartz_phase1"], 1.0, [1, 0]),
+    "config5_hyper_sensitive_4000x3_LGR": (problems.BENCH_CASES[3], ["hyper_sensitive"], 1e-3, [0]),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_against_c_oracle_and_properties(name):
+    (builder, S, po, scheme), cnames, st, midu = FULL[name]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    C = COracle(cnames, S, po, scheme, scale_t=st, midu=midu)
+    assert (o.n_z, o.n_g) == (C.n_z, C.n_g)
+    z, p, lam, sig = random_point(o, mpo, bounds, 23, S, ocp.n_phases)
+    B = 3
+    Z = np.stack([z, mpo.initialize_solution(), z[::-1] * 0 + z * 1.01])
+    r = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], Z, p, lam_g=lam, sigma=sig)
+    jr, jc = o.jac_pattern()
+    hr, hc = o.hess_pattern()
+    assert (hr <= hc).all() and len(set(zip(hr.tolist(), hc.tolist()))) == o.nnz_hess
+    for b in range(B):
+        c = C.eval(Z[b], p)
+        assert rel_err(r["f"][b], c["f"]) < TOL
+        assert rel_err(r["g"][b], c["g"]) < TOL
+        assert rel_err(r["grad_f"][b], c["grad_f"]) < TOL
+        J = sp.coo_matrix((r["jac_g"][b], (jr, jc)), shape=(o.n_g, o.n_z)).tocsr()
+        Jc = sp.coo_matrix((c["jac_val"], (c["jac_row"], c["jac_col"])), shape=(o.n_g, o.n_z)).tocsr()
+        d = (J - Jc)
+        assert (abs(d).max() if d.nnz else 0.0) < TOL * max(1.0, abs(Jc).max())
+    # size-independent derivative properties (central differences of the GPU's own f, g)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(o.n_z)
+    eps = 1e-6
+    rp = o.eval(["f", "g", "grad_f", "jac_g"], np.stack([z + eps * v, z - eps * v]), p)
+    J = sp.coo_matrix((r["jac_g"][0], (jr, jc)), shape=(o.n_g, o.n_z)).tocsr()
+    dg = (rp["g"][0] - rp["g"][1]) / (2 * eps)
+    assert np.abs(J @ v - dg).max() < 1e-6 * max(1.0, np.abs(dg).max())
+    df = (rp["f"][0] - rp["f"][1]) / (2 * eps)
+    assert abs(r["grad_f"][0] @ v - df) < 1e-6 * max(1.0, abs(df))
+    H = sp.coo_matrix((r["hess_l"][0], (hr, hc)), shape=(o.n_z, o.n_z)).tocsr()
+    H = H + sp.triu(H, 1).T
+    Jp = sp.coo_matrix((rp["jac_g"][0], (jr, jc)), shape=(o.n_g, o.n_z)).tocsr()
+    Jm = sp.coo_matrix((rp["jac_g"][1], (jr, jc)), shape=(o.n_g, o.n_z)).tocsr()
+    dL = (sig * (rp["grad_f"][0] - rp["grad_f"][1]) + (Jp - Jm).T @ lam) / (2 * eps)
+    assert np.abs(H @ v - dL).max() < 2e-5 * max(1.0, np.abs(dL).max())
+
+
+def test_launch_geometry_does_not_change_results(monkeypatch):
+    """Fixed-order reductions: any batch split (b_per_block) gives bit-identical outputs."""
+    import subprocess, sys, os, json
+
+    code = (
+        "import sys,os,json,hashlib;sys.path.insert(0,os.getcwd());sys.path.insert(0,'tests');import numpy as np\n"
+        "import mpopt_amd as M;from mpopt_amd import mp;import problems\n"
+        "ocp=problems.kitchen_sink(mp,M.math);mpo=mp.mpopt(ocp,40,[2,5,3,4]*10,'LGR');nlp,b=mpo.create_nlp();o=nlp['oracle']\n"
+        "rng=np.random.default_rng(3);Z=mpo.initialize_solution()[None,:]+0.05*rng.standard_normal((37,o.n_z))\n"
+        "p=np.full(o.n_p,1/40);lam=rng.standard_normal((37,o.n_g));sig=rng.uniform(0.5,1.5,37)\n"
+        "r=o.eval(['f','g','grad_f','jac_g','hess_l'],Z,p,lam_g=lam,sigma=sig)\n"
+        "print(hashlib.sha256(b''.join(np.ascontiguousarray(r[k]).tobytes() for k in sorted(r))).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = set()
+    for bpb in ("1", "5", "64"):
+        env = dict(os.environ, MPX_BPB=bpb)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.add(out.stdout.strip().splitlines()[-1])
+    assert len(digests) == 1
+
+
+def test_device_pointer_api_matches_host_api():
+    import torch
+
+    ocp, S = problems.moon_lander(mp, M.math), 60
+    mpo = mp.mpopt(ocp, S, 5, "LGR")
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    rng = np.random.default_rng(1)
+    B = 9
+    Zh = mpo.initialize_solution()[None, :] + 0.03 * rng.standard_normal((B, o.n_z))
+    ph = np.full(o.n_p, 1 / S)
+    lamh, sigh = rng.standard_normal((B, o.n_g)), rng.uniform(0.5, 1.5, B)
+    ref = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], Zh, ph, lam_g=lamh, sigma=sigh)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.tensor(a, device=dev)
+    Z, p, lam, sig = t(Zh), t(ph), t(lamh), t(sigh)
+    f = torch.empty(B, dtype=torch.float64, device=dev)
+    g = torch.empty(B, o.n_g, dtype=torch.float64, device=dev)
+    gr = torch.empty(B, o.n_z, dtype=torch.float64, device=dev)
+    jv = torch.empty(B, o.nnz_jac, dtype=torch.float64, device=dev)
+    hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
+    o.set_stream(torch.cuda.current_stream().cuda_stream)
+    o.eval_device(31, B, Z, p, 0, lam, sig, f, g, gr, jv, hv)
+    o.sync()
+    for k, v in (("f", f), ("g", g), ("grad_f", gr), ("jac_g", jv), ("hess_l", hv)):
+        assert np.array_equal(v.cpu().numpy(), ref[k]), k
+    # partial masks leave unrequested outputs untouched
+    jv.fill_(7.0)
+    o.eval_device(1 | 2, B, Z, p, 0, None, None, f, g, None, None, None)
+    o.sync()
+    assert (jv == 7.0).all() and np.array_equal(g.cpu().numpy(), ref["g"])
