@@ -157,6 +157,7 @@ def compile_kernels(source, verbose=False):
     for dep in ("mpx_kernels.h", "mpx_device.h"):
         with open(os.path.join(CSRC, dep), "rb") as f:
             h.update(f.read())
+    h.update(os.environ.get("MPX_HIPCC_FLAGS", "").encode())
     key = h.hexdigest()[:24]
     os.makedirs(JIT_DIR, exist_ok=True)
     co = os.path.join(JIT_DIR, f"mpx_{key}.hsaco")

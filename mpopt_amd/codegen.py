@@ -166,13 +166,14 @@ class PhaseProgram:
             n[s] = s
         return n
 
-    def source(self):
+    def source(self, flags):
         tr, names, ph = self.tr, self._names(), self.phase
         NRED = 3 + self.na
         out = [f"template <> struct Phase<{ph}> {{"]
         out.append(f"  static constexpr int NX = {self.nx}, NU = {self.nu}, NA = {self.na}, NC = {self.nc}, NTC = {self.ntc};")
         out.append(f"  static constexpr int NJV = {len(self.jv)}, NHN = {len(self.hn)}, NHC = {len(self.hc)};")
         out.append(f"  static constexpr int NMG = {len(self.mg)}, NTJ = {len(self.tj)}, NTH = {len(self.th)}, NRED = {NRED};")
+        out.append(f"  static constexpr bool DIFF_U = {'true' if flags['diff_u'] else 'false'}, MIDU = {'true' if flags['midu'] else 'false'};")
         node_sig = ("const double* __restrict__ Xs, const double* __restrict__ Us, double t0v, double tfv, "
                     "const double* __restrict__ As, double kap, double th, double W")
         term_sig = ("const double* __restrict__ XF, double tfv, const double* __restrict__ X0, double t0v, "
@@ -255,7 +256,7 @@ class ProblemProgram:
         nph = len(self.phases)
         parts = ["// generated by mpopt_amd.codegen -- do not edit", "#include <hip/hip_runtime.h>",
                  f"#define MPX_NPH {nph}", "namespace mpxgen {", "template <int PH> struct Phase;"]
-        parts += [p.source() for p in self.phases]
+        parts += [p.source(self.flags[k]) for k, p in enumerate(self.phases)]
         parts.append("}  // namespace mpxgen")
         parts.append('#include "mpx_kernels.h"')
         for ph in range(nph):

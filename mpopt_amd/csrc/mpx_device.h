@@ -15,11 +15,12 @@
 // One workgroup's share of one (phase, degree) bucket: whole segments, <= MPX_TILE nodes.
 struct MpxTile {
   int32_t m0;        // first bucket-local node
-  int32_t n;         // nodes in this tile
-  int32_t seg0;      // first segment of the tile
-  int32_t mu_skip;   // 1 when the tile starts with node 0 of the phase (it owns no mid-point row)
+  int32_t n;         // lanes that load a node (stage it in LDS)
+  int32_t n_own;     // lanes that own outputs (== n, except the node-0 tile: 1)
+  int32_t node0;     // 1: this is the mini-tile of node 0 of the phase (lanes 1..P only feed LDS;
+                     //    node 0 has no mid-point row).  Regular tiles hold whole segments, points 1..P.
   int32_t tile_id;   // slot in the partial-sum buffer, global over phases and buckets
-  int32_t pad;
+  int32_t seg0;      // first segment of the tile
   int64_t jac_base;  // offset of the tile's block in the jac_g value array
   int64_t hess_base; // offset of the tile's block in the hess_l value array
 };

@@ -82,7 +82,7 @@ struct mpx_ctx {
   // linear rows
   std::vector<int64_t> lin_ptr, lin_idx, lin_row;
   std::vector<double> lin_coef;
-  int64_t lin_jac = 0;
+  int64_t lin_jac = 0, jac_tiles_end = 0;
   std::vector<int64_t> mg_dst, hc_dst, th_dst;
   std::vector<int32_t> mg_off, hc_off, th_off;
   int nred = 1;
@@ -167,6 +167,13 @@ inline int64_t zterm(const mpx_ctx& c, const PhaseStruct& P, int kind, int comp)
     case MPX_TV_T0: return zcol(c, P, MPX_COL_T0, 0, 0);
     default: return zcol(c, P, MPX_COL_A, comp, 0);
   }
+}
+
+// position of (slot q, lane l) inside a tile block of n lanes and ns slots: slot pairs interleaved
+// so that a lane's two values are adjacent (16-byte stores, see scatter_slots in mpx_kernels.h)
+inline int64_t slot_index(int64_t q, int64_t l, int64_t n, int64_t ns) {
+  if ((ns & 1) && q == ns - 1) return q * n + l;
+  return (q >> 1) * 2 * n + 2 * l + (q & 1);
 }
 
 int parse_structure(mpx_ctx* c, const int32_t* s, int64_t len) {
@@ -296,38 +303,44 @@ int build_layout(mpx_ctx* c) {
       B.deg = d;
       B.dt = (int)dt;
       B.tile_first = (int)c->tiles.size();
-      MpxTile cur{};
-      bool open = false;
-      const int max_segs = MPX_TILE / d;
-      int segs_in_tile = 0;
-      for (int s = 0; s < S; ++s) {
-        if (c->orders[s] != d) continue;
-        int add = d + (s == 0 ? 1 : 0);
-        if (open && (cur.n + add > MPX_TILE || segs_in_tile >= max_segs)) {
-          c->tiles.push_back(cur);
-          open = false;
-        }
-        if (!open) {
-          cur = MpxTile{};
-          cur.m0 = (int32_t)B.node_i.size();
-          cur.seg0 = s;
-          cur.mu_skip = (s == 0) ? 1 : 0;
-          cur.tile_id = (int32_t)c->tiles.size();
-          segs_in_tile = 0;
-          open = true;
-        }
-        if (s == 0) {
-          B.node_i.push_back(0);
-          B.node_sk.push_back(0);
-        }
+      // node list of the bucket: node 0 (if segment 0 has this degree), then points 1..d of every segment
+      std::vector<int> segs;
+      for (int s = 0; s < S; ++s)
+        if (c->orders[s] == d) segs.push_back(s);
+      if (segs.empty()) continue;
+      const bool has0 = segs[0] == 0;
+      if (has0) {
+        B.node_i.push_back(0);
+        B.node_sk.push_back(0);
+      }
+      for (int s : segs)
         for (int k = 1; k <= d; ++k) {
           B.node_i.push_back(c->seg_start[s] + k);
           B.node_sk.push_back((s << 8) | k);
         }
-        cur.n += add;
-        ++segs_in_tile;
+      if (has0) {  // mini-tile of node 0: lanes 0..d stage segment 0 in LDS, lane 0 owns the outputs
+        MpxTile t{};
+        t.m0 = 0;
+        t.n = d + 1;
+        t.n_own = 1;
+        t.node0 = 1;
+        t.seg0 = 0;
+        t.tile_id = (int32_t)c->tiles.size();
+        c->tiles.push_back(t);
       }
-      if (open) c->tiles.push_back(cur);
+      // regular tiles: whole segments, an even number of nodes so that 16-byte stores stay aligned
+      int per = MPX_TILE / d;
+      if ((d & 1) && (per & 1) && per > 1) --per;
+      for (size_t q = 0; q < segs.size(); q += per) {
+        const int cnt = (int)std::min<size_t>(per, segs.size() - q);
+        MpxTile t{};
+        t.m0 = (int32_t)((has0 ? 1 : 0) + q * d);
+        t.n = t.n_own = cnt * d;
+        t.node0 = 0;
+        t.seg0 = segs[q];
+        t.tile_id = (int32_t)c->tiles.size();
+        c->tiles.push_back(t);
+      }
       B.tile_count = (int)c->tiles.size() - B.tile_first;
       if (B.tile_count > 0) c->buckets.push_back(std::move(B));
     }
@@ -337,54 +350,56 @@ int build_layout(mpx_ctx* c) {
   c->tile_end = (int64_t)c->tiles.size();
 
   // ---- Jacobian pattern -----------------------------------------------------------------
+  // value blocks of the tiles: even-sized blocks first so that they all start 16-byte aligned
   std::vector<int32_t>&jr = c->jrow, &jc = c->jcol;
   int64_t jpos = 0;
+  auto tile_slots = [&](const MpxTile& T, const PhaseStruct& P, int d) {
+    int64_t sl = (int64_t)nx * (d + 1) + (int64_t)P.jv.size() + (P.diff_u ? (int64_t)nu * (d + 1) : 0);
+    if (P.midu && !T.node0) sl += (int64_t)nu * (d + 1);
+    return sl;
+  };
+  for (int pass = 0; pass < 2; ++pass)
+    for (auto& B : c->buckets)
+      for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
+        MpxTile& T = c->tiles[t];
+        const int64_t size = tile_slots(T, c->ph[B.phase], B.deg) * T.n_own;
+        if ((int)(size & 1) != pass) continue;
+        T.jac_base = jpos;
+        jpos += size;
+      }
+  jr.assign(jpos, 0);
+  jc.assign(jpos, 0);
   for (auto& B : c->buckets) {
     const PhaseStruct& P = c->ph[B.phase];
     const int d = B.deg, P1 = d + 1;
     for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
-      MpxTile& T = c->tiles[t];
-      T.jac_base = jpos;
-      const int64_t n = T.n, n2 = T.n - T.mu_skip;
-      int64_t slots = (int64_t)nx * P1 + (int64_t)P.jv.size() + (P.diff_u ? (int64_t)nu * P1 : 0);
-      int64_t size = slots * n + (P.midu ? (int64_t)nu * P1 * n2 : 0);
-      jr.resize(jpos + size);
-      jc.resize(jpos + size);
+      const MpxTile& T = c->tiles[t];
+      const int64_t n = T.n_own, base = T.jac_base;
       for (int64_t l = 0; l < n; ++l) {
         const int64_t i = B.node_i[T.m0 + l];
-        const int sk = B.node_sk[T.m0 + l], s = sk >> 8, k = sk & 255;
+        const int sk = B.node_sk[T.m0 + l], s = sk >> 8;
         const int64_t st = c->seg_start[s];
-        (void)k;
         int64_t q = 0;
-        for (int a = 0; a < nx; ++a)
-          for (int j = 0; j < P1; ++j, ++q) {
-            jr[jpos + q * n + l] = (int32_t)(P.g_off_F + (int64_t)a * N + i);
-            jc[jpos + q * n + l] = (int32_t)zcol(*c, P, MPX_COL_X, a, st + j);
-          }
-        for (auto& e : P.jv) {
-          jr[jpos + q * n + l] = (int32_t)((e.a == MPX_ROW_F ? P.g_off_F : P.g_off_C) + (int64_t)e.b * N + i);
-          jc[jpos + q * n + l] = (int32_t)zcol(*c, P, e.c, e.d, i);
+        const int64_t ns = tile_slots(T, P, d);
+        auto put = [&](int64_t row, int64_t col) {
+          const int64_t at = base + slot_index(q, l, n, ns);
+          jr[at] = (int32_t)row;
+          jc[at] = (int32_t)col;
           ++q;
-        }
+        };
+        for (int a = 0; a < nx; ++a)
+          for (int j = 0; j < P1; ++j) put(P.g_off_F + (int64_t)a * N + i, zcol(*c, P, MPX_COL_X, a, st + j));
+        for (auto& e : P.jv) put((e.a == MPX_ROW_F ? P.g_off_F : P.g_off_C) + (int64_t)e.b * N + i, zcol(*c, P, e.c, e.d, i));
         if (P.diff_u)
           for (int u = 0; u < nu; ++u)
-            for (int j = 0; j < P1; ++j, ++q) {
-              jr[jpos + q * n + l] = (int32_t)(P.g_off_DU + (int64_t)u * N + i);
-              jc[jpos + q * n + l] = (int32_t)zcol(*c, P, MPX_COL_U, u, st + j);
-            }
-        if (P.midu && l - T.mu_skip >= 0) {
-          const int64_t l2 = l - T.mu_skip;
-          const int64_t mb = jpos + q * n;
+            for (int j = 0; j < P1; ++j) put(P.g_off_DU + (int64_t)u * N + i, zcol(*c, P, MPX_COL_U, u, st + j));
+        if (P.midu && !T.node0)
           for (int u = 0; u < nu; ++u)
-            for (int j = 0; j < P1; ++j) {
-              jr[mb + (int64_t)(u * P1 + j) * n2 + l2] = (int32_t)(P.g_off_mU + (int64_t)u * (N - 1) + (i - 1));
-              jc[mb + (int64_t)(u * P1 + j) * n2 + l2] = (int32_t)zcol(*c, P, MPX_COL_U, u, st + j);
-            }
-        }
+            for (int j = 0; j < P1; ++j) put(P.g_off_mU + (int64_t)u * (N - 1) + (i - 1), zcol(*c, P, MPX_COL_U, u, st + j));
       }
-      jpos += size;
     }
   }
+  c->jac_tiles_end = jpos;
   for (int p = 0; p < c->n_phases; ++p) {  // terminal-constraint entries
     PhaseStruct& P = c->ph[p];
     P.jac_TC = jpos;
@@ -452,27 +467,35 @@ int build_layout(mpx_ctx* c) {
   std::vector<int32_t>&hr = c->hrow, &hc = c->hcol;
   int64_t hpos = 0;
   std::vector<std::map<std::pair<int64_t, int64_t>, int64_t>> edge(c->n_phases);
+  for (int pass = 0; pass < 2; ++pass)
+    for (auto& B : c->buckets)
+      for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
+        MpxTile& T = c->tiles[t];
+        const int64_t size = (int64_t)c->ph[B.phase].hn.size() * T.n_own;
+        if ((int)(size & 1) != pass) continue;
+        T.hess_base = hpos;
+        hpos += size;
+      }
+  hr.assign(hpos, 0);
+  hc.assign(hpos, 0);
   for (auto& B : c->buckets) {
     const PhaseStruct& P = c->ph[B.phase];
     for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
-      MpxTile& T = c->tiles[t];
-      T.hess_base = hpos;
-      const int64_t n = T.n;
-      const int64_t size = (int64_t)P.hn.size() * n;
-      hr.resize(hpos + size);
-      hc.resize(hpos + size);
+      const MpxTile& T = c->tiles[t];
+      const int64_t n = T.n_own, base = T.hess_base;
       for (int64_t l = 0; l < n; ++l) {
         const int64_t i = B.node_i[T.m0 + l];
         int64_t q = 0;
+        const int64_t ns = (int64_t)P.hn.size();
         for (auto& e : P.hn) {
           int64_t r = zcol(*c, P, e.a, e.b, i), cc = zcol(*c, P, e.c, e.d, i);
-          hr[hpos + q * n + l] = (int32_t)r;
-          hc[hpos + q * n + l] = (int32_t)cc;
-          if (i == 0 || i == N - 1) edge[B.phase][{r, cc}] = hpos + q * n + l;
+          const int64_t at = base + slot_index(q, l, n, ns);
+          hr[at] = (int32_t)r;
+          hc[at] = (int32_t)cc;
+          if (i == 0 || i == N - 1) edge[B.phase][{r, cc}] = at;
           ++q;
         }
       }
-      hpos += size;
     }
   }
   c->mg_off.assign(MPX_MAX_PHASES, 0);
@@ -554,17 +577,31 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   return MPX_OK;
 }
 
-// exclusive prefix sums of the segment widths, sequential per (width vector, phase) so that the
-// accumulation order matches the reference's running t_seg0 (mpopt.py:192)
-__global__ void mpx_prefix_kernel(const double* __restrict__ w, double* __restrict__ wcum, int S, int n_phases, int n_wvec) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_phases * n_wvec) return;
-  const double* a = w + (int64_t)t * S;
-  double* o = wcum + (int64_t)t * S;
-  double acc = 0;
-  for (int s = 0; s < S; ++s) {
-    o[s] = acc;
-    acc += a[s];
+// exclusive prefix sums of the segment widths (the reference's running t_seg0, mpopt.py:192):
+// one workgroup per (width vector, phase); each lane scans a contiguous chunk, the chunk totals are
+// scanned by shuffles within a wavefront and through LDS across the four wavefronts.
+__global__ __launch_bounds__(256) void mpx_prefix_kernel(const double* __restrict__ w, double* __restrict__ wcum, int S) {
+  __shared__ double wave_tot[4];
+  const double* a = w + (int64_t)blockIdx.x * S;
+  double* o = wcum + (int64_t)blockIdx.x * S;
+  const int l = threadIdx.x, chunk = (S + 255) / 256;
+  const int s0 = l * chunk, s1 = min(S, s0 + chunk);
+  double tot = 0;
+  for (int s = s0; s < s1; ++s) tot += a[s];
+  double inc = tot;  // inclusive scan of the lane totals within the wavefront
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    double v = __shfl_up(inc, d, 64);
+    if ((l & 63) >= d) inc += v;
+  }
+  if ((l & 63) == 63) wave_tot[l >> 6] = inc;
+  __syncthreads();  // (the shuffle below is executed by all lanes: no divergence before it)
+  double off = __shfl_up(inc, 1, 64);  // exclusive prefix of the lane inside its wavefront
+  if ((l & 63) == 0) off = 0;
+  for (int q = 0; q < (l >> 6); ++q) off += wave_tot[q];
+  for (int s = s0; s < s1; ++s) {
+    o[s] = off;
+    off += a[s];
   }
 }
 
@@ -577,9 +614,11 @@ int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size
 int pick_bpb(const mpx_ctx* c, int64_t B) {
   static const char* env = getenv("MPX_BPB");
   if (env && atoi(env) > 0) return atoi(env);
+  // measured on MI355X (moon lander 1000x5, B=4096): 8 points per workgroup is the sweet spot of the
+  // software-pipelined loop (3: -2.5 %, 21: -4 %, 64: -6 %); small batches get one point per workgroup
   int64_t work = B * (c->tile_end - c->tile_begin);
-  int64_t bpb = (work + 4095) / 4096;
-  return (int)std::min<int64_t>(std::max<int64_t>(bpb, 1), 64);
+  int64_t bpb = work / 8192;
+  return (int)std::min<int64_t>(std::max<int64_t>(bpb, 1), 8);
 }
 
 int run_mode(mpx_ctx* c, int mode, const MpxIO& io0) {
@@ -795,11 +834,13 @@ extern "C" int mpx_set_tile_range(mpx_ctx* c, int64_t b, int64_t e, int run_boun
 
 extern "C" int mpx_get_tile_jac_range(const mpx_ctx* c, int64_t t, int64_t* b, int64_t* e) {
   if (!c || t < 0 || t >= (int64_t)c->tiles.size() || !b || !e) return MPX_ERR_INVALID;
-  *b = c->tiles[t].jac_base;
-  if (t + 1 < (int64_t)c->tiles.size())
-    *e = c->tiles[t + 1].jac_base;
-  else
-    *e = c->ph[0].jac_TC;
+  // the block of a tile ends where the next block (in base order) starts
+  const int64_t base = c->tiles[t].jac_base;
+  int64_t end = c->jac_tiles_end;
+  for (auto& o : c->tiles)
+    if (o.jac_base > base && o.jac_base < end) end = o.jac_base;
+  *b = base;
+  *e = end;
   return MPX_OK;
 }
 
@@ -866,8 +907,7 @@ extern "C" int mpx_eval_device(mpx_ctx* c, int mask, int64_t batch, const double
   if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
   if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
   {
-    int threads = (int)(n_w * c->n_phases);
-    hipLaunchKernelGGL(mpx_prefix_kernel, dim3((threads + 63) / 64), dim3(64), 0, c->stream, p, c->wcum.p, c->S, c->n_phases, (int)n_w);
+    hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(256), 0, c->stream, p, c->wcum.p, c->S);
     HIPCHK(c, hipGetLastError());
   }
   MpxIO io{};

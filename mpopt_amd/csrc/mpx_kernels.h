@@ -44,6 +44,45 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // lane 0 holds the total; fixed tree => deterministic
 }
 
+typedef double mpx_d2 __attribute__((ext_vector_type(2)));
+
+// Scatter NS per-lane values into a tile block.  Layout of a block (n lanes, NS slots), chosen so
+// that one store instruction of a wavefront writes ONE contiguous run with 16 bytes per lane:
+//     slots are interleaved in pairs:  index(q, l) = (q/2)*2n + 2l + (q&1)      for q < NS - (NS&1)
+//     an unpaired last slot is plain:  index(NS-1, l) = (NS-1)*n + l
+// (the COO patterns reported by mpx_pattern_* follow the same formula, mpx_host.cpp).  Measured on
+// MI355X (tools/store_bw.hip): 16 B/lane contiguous stores stream at 5.2-5.5 TB/s, 8 B/lane at
+// 4.4-5.0 TB/s, nontemporal stores are slower than both.
+// Addressing: uniform base (SGPRs) + ONE running 32-bit byte offset per lane.  The offsets are loop
+// invariant across the batch loop; the empty asm stops the compiler from hoisting one 64-bit address
+// pair per slot out of it (that cost 90+ VGPRs and more than halved the occupancy).
+template <int NS, class F>
+__device__ __forceinline__ void scatter_slots(double* __restrict__ blk, int64_t n, int l, bool own, bool vec, F sv) {
+  if (!own) return;
+  char* __restrict__ base = reinterpret_cast<char*>(blk);
+  const uint32_t nb = (uint32_t)n * 8u;  // bytes per slot
+  uint32_t off = (uint32_t)l * 16u;
+#pragma unroll
+  for (int q = 0; q + 1 < NS; q += 2) {
+    asm volatile("" : "+v"(off));
+    if (vec) {
+      mpx_d2 w;
+      w.x = sv(q);
+      w.y = sv(q + 1);
+      *reinterpret_cast<mpx_d2*>(base + off) = w;
+    } else {  // block not 16-byte aligned (odd-sized blocks come last, mpx_host.cpp)
+      *reinterpret_cast<double*>(base + off) = sv(q);
+      *reinterpret_cast<double*>(base + off + 8u) = sv(q + 1);
+    }
+    off += 2u * nb;
+  }
+  if (NS & 1) {
+    uint32_t o1 = (uint32_t)(NS - 1) * nb + (uint32_t)l * 8u;
+    asm volatile("" : "+v"(o1));
+    *reinterpret_cast<double*>(base + o1) = sv(NS - 1);
+  }
+}
+
 template <int PH, int P, int MODE>
 __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   using G = mpxgen::Phase<PH>;
@@ -53,21 +92,32 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   constexpr int SLOTS = (MODE == MPX_MODE_HESS) ? 1 : SEGS * P1;
   constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : (MODE == MPX_MODE_FGJ ? G::NRED : G::NHC);
   constexpr int NRED1 = NRED > 0 ? NRED : 1;
+  // Jacobian slots of a node: D-blocks of the defect rows, variable entries, D-blocks of the
+  // control-slope rows, interpolation blocks of the mid-point rows
+  constexpr int NS_MAIN = NX * P1 + G::NJV + (G::DIFF_U ? NU * P1 : 0);
+  constexpr int NS_MID = G::MIDU ? NU * P1 : 0;
   __shared__ double sXU[2][NX + NU][SLOTS];
   __shared__ double sRed[2][MPX_TILE / 64][NRED1];
 
   const MpxTile T = A.tiles[A.tile_first + blockIdx.x];
   const int l = threadIdx.x;
-  const bool act = l < T.n;
+  const bool act = l < T.n;      // stages a node in LDS
+  const bool own = l < T.n_own;  // owns output rows / entries
   const int m = T.m0 + (act ? l : 0);
   const int i = A.node_i[m];
   const int sk = A.node_sk[m];
   const int s = sk >> 8, k = sk & 255;
   // LDS slot of the lane's segment: tiles hold whole segments of one degree, P lanes each
-  const int base = ((k == 0) ? 0 : (l - T.mu_skip) / P) * P1;
+  const int base = ((k == 0) ? 0 : (l - T.node0) / P) * P1;
   const bool halo = act && (k == 1);
   const int lane = l & 63, wave = l >> 6;
   const int N = A.N;
+  const int64_t n = T.n_own;
+#ifdef MPX_NO_VEC  // A/B switch for tools/ab.py: force 8-byte stores
+  const bool vec = false, vech = false;
+#else
+  const bool vec = (T.jac_base & 1) == 0, vech = (T.hess_base & 1) == 0;
+#endif
 
   // per-lane rows of D and of the mid-point interpolation matrix, resident for the batch loop
   double Drow[P1], Crow[P1];
@@ -83,24 +133,49 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   const int b0 = blockIdx.y * io.b_per_block;
   const int b1 = (b0 + io.b_per_block < io.B) ? b0 + io.b_per_block : io.B;
   const int64_t tslot = (int64_t)T.tile_id * io.nred;
-  int it = 0;
-  for (int b = b0; b < b1; ++b, ++it) {
-    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + A.z_off;
+
+  // One evaluation point's inputs of this lane.  The batch loop is software pipelined: the loads of
+  // point b+1 are issued BEFORE the stores of point b.  vmcnt retires in order, so a wait for loads
+  // that were issued after a burst of stores would drain the whole store queue every iteration
+  // (measured: the un-pipelined loop was 10 % slower and preferred tiny batch chunks).
+  struct In {
     Vec<NX> Xs;
     Vec<NU> Us;
+    Vec<NX + NU> Hl;  // first node of the segment (only lanes with k == 1 use it)
     Vec<NA> As;
+    double t0v, tfv, ws, wc;
+  };
+  auto load_point = [&](int b, In& q) {
+    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + A.z_off;
 #pragma unroll
-    for (int a = 0; a < NX; ++a) Xs[a] = zb[(int64_t)a * N + i];
+    for (int a = 0; a < NX; ++a) q.Xs[a] = (zb + (int64_t)a * N)[i];
 #pragma unroll
-    for (int c = 0; c < NU; ++c) Us[c] = zb[(int64_t)(NX + c) * N + i];
+    for (int c = 0; c < NU; ++c) q.Us[c] = (zb + (int64_t)(NX + c) * N)[i];
+    if constexpr (MODE != MPX_MODE_HESS) {
+      if (halo) {  // first node of the segment belongs to the previous segment (mpopt.py:190-195)
+#pragma unroll
+        for (int a = 0; a < NX + NU; ++a) q.Hl[a] = (zb + (int64_t)a * N)[i - 1];
+      }
+    }
     const double* __restrict__ zt = zb + (int64_t)(NX + NU) * N;
-    const double t0v = zt[0], tfv = zt[1];
+    q.t0v = zt[0];
+    q.tfv = zt[1];
 #pragma unroll
-    for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
+    for (int c = 0; c < NA; ++c) q.As[c] = zt[2 + c];
     const int64_t woff = (int64_t)b * io.w_stride + A.seg_off + s;
-    const double ws = io.w[woff], wc = io.wcum[woff];
-    const double kap = ws * A.inv_dtau;  // h = (tf - t0) * kap            (mpopt.py:184)
-    const double th = wc + ws * tkk;     // t = t0 + (tf - t0) * th        (mpopt.py:192, 198)
+    q.ws = io.w[woff];
+    q.wc = io.wcum[woff];
+  };
+  In cur, nxt;
+  if (b0 < b1) load_point(b0, cur);
+  int it = 0;
+  for (int b = b0; b < b1; ++b, ++it) {
+    Vec<NX>& Xs = cur.Xs;
+    Vec<NU>& Us = cur.Us;
+    Vec<NA>& As = cur.As;
+    const double t0v = cur.t0v, tfv = cur.tfv;
+    const double kap = cur.ws * A.inv_dtau;    // h = (tf - t0) * kap            (mpopt.py:184)
+    const double th = cur.wc + cur.ws * tkk;   // t = t0 + (tf - t0) * th        (mpopt.py:192, 198)
     const int buf = it & 1;
     if constexpr (MODE != MPX_MODE_HESS) {
       if (act) {
@@ -108,12 +183,13 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
         for (int a = 0; a < NX; ++a) sXU[buf][a][base + k] = Xs[a];
 #pragma unroll
         for (int c = 0; c < NU; ++c) sXU[buf][NX + c][base + k] = Us[c];
-        if (halo) {  // first node of the segment belongs to the previous segment (mpopt.py:190-195)
+        if (halo) {
 #pragma unroll
-          for (int a = 0; a < NX + NU; ++a) sXU[buf][a][base] = zb[(int64_t)a * N + i - 1];
+          for (int a = 0; a < NX + NU; ++a) sXU[buf][a][base] = cur.Hl[a];
         }
       }
     }
+    if (b + 1 < b1) load_point(b + 1, nxt);
     __syncthreads();
     if (it > 0 && l < NRED) {  // publish the previous point's tile sums
       double v = 0;
@@ -128,16 +204,12 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
       Vec<NC> lC;
       const double* __restrict__ lb = io.lam_g + (int64_t)b * io.lam_stride;
 #pragma unroll
-      for (int a = 0; a < NX; ++a) lF[a] = lb[A.g_off_F + (int64_t)a * N + i];
+      for (int a = 0; a < NX; ++a) lF[a] = (lb + (A.g_off_F + (int64_t)a * N))[i];
 #pragma unroll
-      for (int j = 0; j < NC; ++j) lC[j] = lb[A.g_off_C + (int64_t)j * N + i];
+      for (int j = 0; j < NC; ++j) lC[j] = (lb + (A.g_off_C + (int64_t)j * N))[i];
       Vec<G::NHN> hn;
       G::hess(Xs, Us, t0v, tfv, As, kap, th, Wn, io.sigma[b], lF, lC, hn, red);
-      if (act) {
-        double* __restrict__ hb = io.hess + (int64_t)b * io.hess_stride + T.hess_base;
-#pragma unroll
-        for (int e = 0; e < G::NHN; ++e) hb[(int64_t)e * T.n + l] = hn[e];
-      }
+      scatter_slots<G::NHN>(io.hess + (int64_t)b * io.hess_stride + T.hess_base, n, l, own, vech, [&](int q) { return hn[q]; });
     } else {
       Vec<NX> fx;
       Vec<NC> cc;
@@ -149,83 +221,83 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
       } else {
         G::fg(Xs, Us, t0v, tfv, As, kap, th, Wn, fx, cc, red[0]);
       }
-      if (act) {
-        if (io.g) {
-          double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
+      if (own && io.g) {
+        double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
 #pragma unroll
-          for (int a = 0; a < NX; ++a) {  // defect  F = D.X - h*Sx*dyn      (mpopt.py:227-232)
+        for (int a = 0; a < NX; ++a) {  // defect  F = D.X - h*Sx*dyn      (mpopt.py:227-232)
+          double acc = 0;
+#pragma unroll
+          for (int j = 0; j < P1; ++j) acc = fma(Drow[j], sXU[buf][a][base + j], acc);
+          (gb + (A.g_off_F + (int64_t)a * N))[i] = acc - fx[a];
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) (gb + (A.g_off_C + (int64_t)j * N))[i] = cc[j];  // mpopt.py:204, 255
+        if constexpr (G::DIFF_U) {  // DU = D.U                              (mpopt.py:315-324)
+#pragma unroll
+          for (int c = 0; c < NU; ++c) {
             double acc = 0;
 #pragma unroll
-            for (int j = 0; j < P1; ++j) acc = fma(Drow[j], sXU[buf][a][base + j], acc);
-            gb[A.g_off_F + (int64_t)a * N + i] = acc - fx[a];
+            for (int j = 0; j < P1; ++j) acc = fma(Drow[j], sXU[buf][NX + c][base + j], acc);
+            (gb + (A.g_off_DU + (int64_t)c * N))[i] = acc;
           }
-#pragma unroll
-          for (int j = 0; j < NC; ++j) gb[A.g_off_C + (int64_t)j * N + i] = cc[j];  // mpopt.py:204, 255
-          if (A.diff_u) {  // DU = D.U                                        (mpopt.py:315-324)
-#pragma unroll
-            for (int c = 0; c < NU; ++c) {
-              double acc = 0;
-#pragma unroll
-              for (int j = 0; j < P1; ++j) acc = fma(Drow[j], sXU[buf][NX + c][base + j], acc);
-              gb[A.g_off_DU + (int64_t)c * N + i] = acc;
-            }
-          }
-          if (A.midu && k >= 1) {  // control at the mid-points of the nodes   (mpopt.py:350-369)
+        }
+        if constexpr (G::MIDU) {  // control at the mid-points of the nodes  (mpopt.py:350-369)
+          if (k >= 1) {
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
               double acc = 0;
 #pragma unroll
               for (int j = 0; j < P1; ++j) acc = fma(Crow[j], sXU[buf][NX + c][base + j], acc);
-              gb[A.g_off_mU + (int64_t)c * (N - 1) + (i - 1)] = acc;
+              (gb + (A.g_off_mU + (int64_t)c * (N - 1)))[i - 1] = acc;
             }
           }
         }
-        if constexpr (MODE == MPX_MODE_FGJ) {
-          if (io.grad) {
-            double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
+      }
+      if constexpr (MODE == MPX_MODE_FGJ) {
+        if (own && io.grad) {
+          double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
 #pragma unroll
-            for (int a = 0; a < NX + NU; ++a) qb[(int64_t)a * N + i] = gn[a];
-          }
-          if (io.jac) {
-            double* __restrict__ jb = io.jac + (int64_t)b * io.jac_stride + T.jac_base;
-            const int64_t n = T.n;
-            int64_t q = 0;
-#pragma unroll
-            for (int a = 0; a < NX; ++a) {
-#pragma unroll
-              for (int j = 0; j < P1; ++j) jb[(q++) * n + l] = (j == k) ? Drow[j] - dd[a] : Drow[j];
+          for (int a = 0; a < NX + NU; ++a) (qb + (int64_t)a * N)[i] = gn[a];
+        }
+        if (io.jac) {
+          double* __restrict__ jb = io.jac + (int64_t)b * io.jac_stride + T.jac_base;
+          // slot q -> value, evaluated lazily (q is a compile-time constant after unrolling).  The
+          // table rows are loop invariant; the empty asm keeps the compiler from hoisting every
+          // lane-exchanged pair out of the batch loop (registers are worth more than ~100 VALU ops
+          // next to the stores).
+          auto opaque = [](double v) {
+            asm volatile("" : "+v"(v));
+            return v;
+          };
+          auto sv = [&](int q) -> double {
+            if (q < NX * P1) {
+              const int a = q / P1, j = q % P1;
+              const double d = opaque(Drow[j]);
+              return (j == k) ? d - dd[a] : d;
             }
-#pragma unroll
-            for (int e = 0; e < G::NJV; ++e) jb[(q++) * n + l] = jv[e];
-            if (A.diff_u) {
-#pragma unroll
-              for (int c = 0; c < NU; ++c) {
-#pragma unroll
-                for (int j = 0; j < P1; ++j) jb[(q++) * n + l] = Drow[j];
-              }
+            q -= NX * P1;
+            if (q < G::NJV) return jv[q];
+            q -= G::NJV;
+            if (G::DIFF_U) {
+              if (q < NU * P1) return opaque(Drow[q % P1]);
+              q -= NU * P1;
             }
-            if (A.midu) {
-              const int64_t n2 = n - T.mu_skip;
-              const int l2 = l - T.mu_skip;
-              double* __restrict__ jm = jb + q * n;
-              if (l2 >= 0) {
-#pragma unroll
-                for (int c = 0; c < NU; ++c) {
-#pragma unroll
-                  for (int j = 0; j < P1; ++j) jm[(int64_t)(c * P1 + j) * n2 + l2] = Crow[j];
-                }
-              }
-            }
-          }
+            return opaque(Crow[q % P1]);
+          };
+          if (T.node0)  // node 0 owns no mid-point row: its block ends after the main slots
+            scatter_slots<NS_MAIN>(jb, n, l, own, false, sv);
+          else
+            scatter_slots<NS_MAIN + NS_MID>(jb, n, l, own, vec, sv);
         }
       }
     }
     // tile sums
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
-      double v = wave_sum(act ? red[r] : 0.0);
+      double v = wave_sum(own ? red[r] : 0.0);
       if (lane == 0) sRed[buf][wave][r] = v;
     }
+    cur = nxt;
   }
   __syncthreads();
   if (it > 0 && l < NRED) {
@@ -355,14 +427,17 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A) {
 }
 }  // namespace mpxk
 
+#ifndef MPX_MIN_WAVES
+#define MPX_MIN_WAVES 1
+#endif
 #define MPX_INSTANTIATE_NODE(PH, P)                                                                         \
-  extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_node_fg_##PH##_##P(const MpxNodeArgs A) {      \
+  extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_fg_##PH##_##P(const MpxNodeArgs A) {      \
     mpxk::node_body<PH, P, MPX_MODE_FG>(A);                                                                 \
   }                                                                                                         \
-  extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_node_fgj_##PH##_##P(const MpxNodeArgs A) {     \
+  extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_fgj_##PH##_##P(const MpxNodeArgs A) {     \
     mpxk::node_body<PH, P, MPX_MODE_FGJ>(A);                                                                \
   }                                                                                                         \
-  extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_node_hess_##PH##_##P(const MpxNodeArgs A) {    \
+  extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_hess_##PH##_##P(const MpxNodeArgs A) {    \
     mpxk::node_body<PH, P, MPX_MODE_HESS>(A);                                                               \
   }
 
