@@ -65,7 +65,8 @@ class NlpSolver:
         res = minimize(fun, x0, jac=grad, hess=hess_obj, method="trust-constr",
                        bounds=Bounds(lbx, ubx, keep_feasible=False),
                        constraints=[NonlinearConstraint(con, lbg, ubg, jac=jac, hess=hess_con)] if m else [],
-                       options={"maxiter": max_iter, "gtol": tol, "xtol": 1e-12, "verbose": 0, "sparse_jacobian": True})
+                       options={"maxiter": max_iter, "gtol": tol, "xtol": 1e-14, "barrier_tol": min(tol, 1e-10), "verbose": 0,
+                                "sparse_jacobian": True})
         self.stats = {"iter_count": res.nit, "success": bool(res.success), "return_status": res.message,
                       "n_eval": cnt, "t_oracle_s": t_eval[0]}
         lam_g = np.asarray(res.v[0]) if m and len(res.v) else np.zeros(m)

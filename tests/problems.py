@@ -104,6 +104,18 @@ def two_phase_schwartz(mp, fn=None):
     return ocp
 
 
+def analytic_solution(mp, fn=None):
+    """Chachuat Ex. 3.10 (reference tests/test_mpopt.py:1090-1112): x(t) = -2t^2 + 6t + 1, u(t) = 2(t - 1)."""
+    ocp = mp.OCP(n_states=1, n_controls=1)
+    ocp.dynamics[0] = lambda x, u, t: [2 * (1 - u[0])]
+    ocp.running_costs[0] = lambda x, u, t: 0.5 * u[0] * u[0] - x[0]
+    ocp.x00[0] = [1.0]
+    ocp.lbtf[0] = 1.0
+    ocp.ubtf[0] = 1.0
+    ocp.validate()
+    return ocp
+
+
 def generic_two_phase(mp, fn=None):
     """tests/test_mpopt.py:89-110 plus the optional row blocks switched on."""
     ocp = mp.OCP(n_states=2, n_controls=2, n_phases=2)
