@@ -55,15 +55,12 @@ def main():
                          "runs ~18%% slower for the first few hundred milliseconds")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from mpopt_amd import distributed as mpd
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    rank, world, local_rank = mpd.init_from_env("nccl")  # nccl == RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -121,10 +118,7 @@ def main():
     elapsed = time.perf_counter() - t0
     node_ms, n_launch = o.profile_read()
     o.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = mpd.max_over_ranks(elapsed, device=dev)
 
     # sanity: the timed outputs are real (finite, and f matches a host recomputation of one point)
     assert torch.isfinite(jv[0]).all() and torch.isfinite(g[-1]).all()

@@ -61,6 +61,8 @@ extern "C" {
 #define MPX_GRAD 4   /* nlp_grad_f */
 #define MPX_JAC 8    /* nlp_jac_g  */
 #define MPX_HESS 16  /* nlp_hess_l */
+#define MPX_BOUNDARY_ONLY 32 /* skip the node kernels: finish reductions / terminal / linking rows only
+                                (second half of a segment-sharded evaluation, see mpx_set_tile_range) */
 
 /* structure kinds (packed description produced by the host-side tracer) */
 #define MPX_COL_X 0
@@ -177,6 +179,12 @@ int mpx_sync(mpx_ctx* ctx);
  * terminal and event rows) runs only when `run_boundary` is non-zero. */
 int mpx_set_tile_range(mpx_ctx* ctx, int64_t tile_begin, int64_t tile_end, int run_boundary);
 int mpx_get_tile_jac_range(const mpx_ctx* ctx, int64_t tile, int64_t* begin, int64_t* end);
+/* Relative cost of every tile (its Jacobian block size), for balancing tile ranges over ranks. */
+int mpx_get_tile_weights(const mpx_ctx* ctx, int64_t* weights);
+/* Device buffer holding the per-tile partial sums of the last mpx_eval_device call
+ * ([batch][n_tiles][width] doubles; entries of tiles outside the tile range are untouched).  Ranks
+ * sum this buffer (and their disjoint output slices) before the MPX_BOUNDARY_ONLY pass. */
+int mpx_get_partials(mpx_ctx* ctx, int64_t batch, double** device_ptr, int64_t* count);
 
 /* ---------------------------------------------------------------------------------------------
  * Timing helper: HIP events on the context's stream (bench.py measures kernel time with these)

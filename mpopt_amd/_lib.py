@@ -25,7 +25,7 @@ c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)
 
-MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS = 1, 2, 4, 8, 16
+MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MPX_BOUNDARY_ONLY = 1, 2, 4, 8, 16, 32
 SCHEMES = {"LGR": 0, "LGL": 1, "CGL": 2, "LG": 3}
 SCHEME_EQUI = 4
 
@@ -114,6 +114,8 @@ SYMBOLS = {
     "mpx_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_set_tile_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "mpx_get_tile_jac_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p, c_int64_p]),
+    "mpx_get_tile_weights": (ctypes.c_int, [ctypes.c_void_p, c_int64_p]),
+    "mpx_get_partials": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), c_int64_p]),
     "mpx_timer_start": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_timer_stop": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "mpx_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

@@ -621,7 +621,7 @@ int pick_bpb(const mpx_ctx* c, int64_t B) {
   return (int)std::min<int64_t>(std::max<int64_t>(bpb, 1), 8);
 }
 
-int run_mode(mpx_ctx* c, int mode, const MpxIO& io0) {
+int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
   MpxIO io = io0;
   io.b_per_block = pick_bpb(c, io.B);
   const int gy = (io.B + io.b_per_block - 1) / io.b_per_block;
@@ -641,7 +641,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0) {
   }
   for (auto& B : c->buckets) {
     int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);
-    if (hi <= lo) continue;
+    if (hi <= lo || !nodes) continue;
     const PhaseStruct& P = c->ph[B.phase];
     const DegTable& t = c->degs[B.dt];
     MpxNodeArgs A{};
@@ -844,6 +844,27 @@ extern "C" int mpx_get_tile_jac_range(const mpx_ctx* c, int64_t t, int64_t* b, i
   return MPX_OK;
 }
 
+extern "C" int mpx_get_tile_weights(const mpx_ctx* c, int64_t* w) {
+  if (!c || !w) return MPX_ERR_INVALID;
+  for (size_t t = 0; t < c->tiles.size(); ++t) {
+    int64_t b, e;
+    mpx_get_tile_jac_range(c, (int64_t)t, &b, &e);
+    w[t] = e - b;
+  }
+  return MPX_OK;
+}
+
+extern "C" int mpx_get_partials(mpx_ctx* c, int64_t batch, double** ptr, int64_t* count) {
+  if (!c || !ptr || !count || batch < 1) return MPX_ERR_INVALID;
+  if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "context has no device code");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred));
+  if (rc) return rc;
+  *ptr = c->partial.p;
+  *count = batch * (int64_t)c->tiles.size() * c->nred;
+  return MPX_OK;
+}
+
 extern "C" int mpx_sync(mpx_ctx* c) {
   if (!c) return MPX_ERR_INVALID;
   if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "context has no device code");
@@ -932,13 +953,15 @@ extern "C" int mpx_eval_device(mpx_ctx* c, int mask, int64_t batch, const double
   io.n_tiles_total = (int32_t)c->tiles.size();
   io.nred = c->nred;
   io.B = (int32_t)batch;
+  const bool nodes = !(mask & MPX_BOUNDARY_ONLY);
+  if (!nodes && !c->run_boundary) return fail(c, MPX_ERR_INVALID, "MPX_BOUNDARY_ONLY with the boundary pass disabled");
   if (mask & (MPX_GRAD | MPX_JAC)) {
-    if ((rc = run_mode(c, MPX_MODE_FGJ, io))) return rc;
+    if ((rc = run_mode(c, MPX_MODE_FGJ, io, nodes))) return rc;
   } else if (mask & (MPX_F | MPX_G)) {
-    if ((rc = run_mode(c, MPX_MODE_FG, io))) return rc;
+    if ((rc = run_mode(c, MPX_MODE_FG, io, nodes))) return rc;
   }
   if (mask & MPX_HESS) {
-    if ((rc = run_mode(c, MPX_MODE_HESS, io))) return rc;
+    if ((rc = run_mode(c, MPX_MODE_HESS, io, nodes))) return rc;
   }
   return MPX_OK;
 }

@@ -185,6 +185,17 @@ class NlpFunctions:
     def set_tile_range(self, begin, end, run_boundary=True):
         _lib.check(self._L.mpx_set_tile_range(self._ctx, int(begin), int(end), int(bool(run_boundary))), self._ctx)
 
+    def tile_weights(self):
+        w = np.empty(self.n_tiles, np.int64)
+        _lib.check(self._L.mpx_get_tile_weights(self._ctx, w.ctypes.data_as(_lib.c_int64_p)), self._ctx)
+        return w
+
+    def partials(self, batch):
+        """(device pointer, element count) of the per-tile partial-sum buffer for ``batch`` points."""
+        ptr, cnt = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(self._L.mpx_get_partials(self._ctx, int(batch), ctypes.byref(ptr), ctypes.byref(cnt)), self._ctx)
+        return ptr.value, cnt.value
+
     def tile_jac_range(self, tile):
         b, e = ctypes.c_int64(), ctypes.c_int64()
         _lib.check(self._L.mpx_get_tile_jac_range(self._ctx, int(tile), ctypes.byref(b), ctypes.byref(e)), self._ctx)

@@ -174,3 +174,54 @@ def test_device_pointer_api_matches_host_api():
     o.eval_device(1 | 2, B, Z, p, 0, None, None, f, g, None, None, None)
     o.sync()
     assert (jv == 7.0).all() and np.array_equal(g.cpu().numpy(), ref["g"])
+
+
+@pytest.mark.parametrize("case,world", [("kitchen_sink_40", 3), ("vdp_mixed_3_30_3", 2), ("moon_lander_60x5", 4)])
+def test_segment_sharding_is_bit_identical(case, world):
+    """ranks run disjoint tile ranges, outputs and tile partial sums are summed
+    (x + 0 exact), the boundary pass finishes.  Emulated with `world` virtual ranks on one GPU."""
+    import torch
+    from mpopt_amd import distributed as D
+    from mpopt_amd._lib import MPX_BOUNDARY_ONLY
+
+    builder, S, po, scheme = REDUCED[case]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2)
+    B = 5
+    Zh = mpo.initialize_solution()[None, :] + 0.05 * rng.standard_normal((B, o.n_z))
+    ph = np.full(o.n_p, 1.0 / S)
+    lamh, sigh = rng.standard_normal((B, o.n_g)), rng.uniform(0.5, 1.5, B)
+    ref = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], Zh, ph, lam_g=lamh, sigma=sigh)
+    t = lambda a: torch.tensor(a, device=dev)
+    Z, p, lam, sig = t(Zh), t(ph), t(lamh), t(sigh)
+    ranges = D.partition_tiles(o.tile_weights(), world)
+    assert sum(e - b for b, e in ranges) == o.n_tiles
+    shapes = {"g": (B, o.n_g), "grad_f": (B, o.n_z), "jac_g": (B, o.nnz_jac), "hess_l": (B, o.nnz_hess)}
+    total = {k: torch.zeros(s, dtype=torch.float64, device=dev) for k, s in shapes.items()}
+    ptr, cnt = o.partials(B)
+    part = D._wrap_device_buffer(ptr, cnt, dev)
+    part_total = torch.zeros(cnt, dtype=torch.float64, device=dev)
+    f = torch.empty(B, dtype=torch.float64, device=dev)
+    # the tile partial-sum buffer is shared by the fgj and the hess pass: shard them one after the other
+    for mask in (15, 16):
+        part_total.zero_()
+        for r in range(world):  # what each rank would do before the all-reduce
+            mine = {k: torch.zeros(s, dtype=torch.float64, device=dev) for k, s in shapes.items()}
+            part.zero_()
+            o.set_tile_range(*ranges[r], run_boundary=False)
+            o.eval_device(mask, B, Z, p, 0, lam, sig, f, mine["g"], mine["grad_f"], mine["jac_g"], mine["hess_l"])
+            o.sync()
+            for k in (("g", "grad_f", "jac_g") if mask == 15 else ("hess_l",)):
+                total[k] += mine[k]
+            part_total += part
+        part.copy_(part_total)  # = all-reduce(SUM)
+        o.set_tile_range(0, o.n_tiles, run_boundary=True)
+        o.eval_device(mask | MPX_BOUNDARY_ONLY, B, Z, p, 0, lam, sig, f, total["g"], total["grad_f"], total["jac_g"], total["hess_l"])
+        o.sync()
+    assert np.array_equal(f.cpu().numpy(), ref["f"])
+    for k in total:
+        assert np.array_equal(total[k].cpu().numpy(), ref[k]), k
