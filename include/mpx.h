@@ -187,6 +187,14 @@ int mpx_get_tile_weights(const mpx_ctx* ctx, int64_t* weights);
 int mpx_get_partials(mpx_ctx* ctx, int64_t batch, double** device_ptr, int64_t* count);
 
 /* ---------------------------------------------------------------------------------------------
+ * CasADi-external-compatible surface (mpx_casadi.cpp): the symbols nlp_f, nlp_g, nlp_grad_f,
+ * nlp_jac_g, nlp_hess_l (+ _n_in/_n_out/_name_in/_name_out/_sparsity_in/_sparsity_out/_work/
+ * _incref/_decref) follow the calling convention of CasADi-generated C code and act on the context
+ * selected here (process-wide; NULL clears it).  The context must outlive its selection.
+ * ------------------------------------------------------------------------------------------- */
+int mpx_set_current(mpx_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------------
  * Timing helper: HIP events on the context's stream (bench.py measures kernel time with these)
  * ------------------------------------------------------------------------------------------- */
 int mpx_timer_start(mpx_ctx* ctx);

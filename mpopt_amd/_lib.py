@@ -42,7 +42,7 @@ def hipcc():
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("mpx_host.cpp", "mpx_colloc.cpp", "mpx_device.h")] + [os.path.join(INCLUDE, "mpx.h")]
+    return [os.path.join(CSRC, f) for f in ("mpx_host.cpp", "mpx_colloc.cpp", "mpx_casadi.cpp", "mpx_device.h")] + [os.path.join(INCLUDE, "mpx.h")]
 
 
 def _stale(target, deps):
@@ -59,11 +59,13 @@ def build_library(force=False, verbose=False):
     cc = hipcc()
     obj = os.path.join(PKG, "mpx_colloc.o")
     hobj = os.path.join(PKG, "mpx_host.o")
+    cobj = os.path.join(PKG, "mpx_casadi.o")
     cmds = [
         ["g++", "-O2", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", os.path.join(CSRC, "mpx_colloc.cpp"), "-o", obj],
+        ["g++", "-O2", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", os.path.join(CSRC, "mpx_casadi.cpp"), "-o", cobj],
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
          os.path.join(CSRC, "mpx_host.cpp"), "-o", hobj],
-        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, obj, "-o", LIB_PATH + ".tmp"],
+        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, obj, cobj, "-o", LIB_PATH + ".tmp"],
     ]
     for cmd in cmds:
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -116,6 +118,7 @@ SYMBOLS = {
     "mpx_get_tile_jac_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p, c_int64_p]),
     "mpx_get_tile_weights": (ctypes.c_int, [ctypes.c_void_p, c_int64_p]),
     "mpx_get_partials": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), c_int64_p]),
+    "mpx_set_current": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_timer_start": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_timer_stop": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "mpx_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

@@ -1,0 +1,168 @@
+// mpx_casadi.cpp -- the five NLP oracles with the calling convention of CasADi-generated C code, so
+// that `ca.nlpsol("solver", "ipopt", "libmpx.so", opts)` can load this library in place of the SX
+// graph that mpopt hands to nlpsol (mpopt.py:757).  SURVEY.md section 8(b), second surface.
+//
+// Convention (CasADi's public generated-code interface; casadi_int = long long, casadi_real = double):
+//   int NAME(const double** arg, double** res, long long* iw, double* w, int mem);   0 = ok
+//   NAME_n_in / _n_out / _name_in / _name_out / _sparsity_in / _sparsity_out / _work / _incref / _decref
+//   sparsity = {nrow, ncol, colind[ncol+1], row[nnz]} (compressed column)
+//   NULL arg[i] means zeros, NULL res[i] means "not requested".
+// These entry points carry no user pointer, so they act on the process-wide *current* context chosen
+// with mpx_set_current().  Values leave in compressed-column order (mpx_ccs_perm); hess_l is the upper
+// triangle, as CasADi's "triu:hess:gamma:x:x".
+//
+// CasADi is not installable in the build image: the metadata and the numerical results are tested
+// through ctypes (tests/test_host.py, tests/test_gpu_golden.py), the hand-off to nlpsol itself is not.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mpx.h"
+
+namespace {
+typedef long long cint;
+struct Current {
+  mpx_ctx* ctx = nullptr;
+  mpx_sizes sz{};
+  std::vector<cint> sp_x, sp_p, sp_g, sp_one, sp_jac, sp_hess;
+  std::vector<int64_t> perm_j, perm_h;
+  std::vector<double> zx, zp, zl, buf_j, buf_h, buf_g, buf_grad;
+} C;
+
+std::vector<cint> dense_col(cint n) {
+  std::vector<cint> s = {n, 1, 0, n};
+  for (cint i = 0; i < n; ++i) s.push_back(i);
+  return s;
+}
+std::vector<cint> ccs(cint nrow, cint ncol, const std::vector<int64_t>& colind, const std::vector<int32_t>& row, const std::vector<int64_t>& perm) {
+  std::vector<cint> s = {nrow, ncol};
+  for (auto v : colind) s.push_back(v);
+  for (auto k : perm) s.push_back(row[k]);
+  return s;
+}
+const double* in(const double** arg, int i, std::vector<double>& zeros) { return arg && arg[i] ? arg[i] : zeros.data(); }
+}  // namespace
+
+extern "C" int mpx_set_current(mpx_ctx* ctx) {
+  if (!ctx) {
+    C = Current{};
+    return MPX_OK;
+  }
+  Current n;
+  n.ctx = ctx;
+  int rc = mpx_get_sizes(ctx, &n.sz);
+  if (rc) return rc;
+  const mpx_sizes& z = n.sz;
+  std::vector<int32_t> r(z.nnz_jac), c(z.nnz_jac), hr(z.nnz_hess), hc(z.nnz_hess);
+  std::vector<int64_t> colind(z.n_z + 1);
+  n.perm_j.resize(z.nnz_jac);
+  n.perm_h.resize(z.nnz_hess);
+  mpx_pattern_jac(ctx, r.data(), c.data());
+  mpx_ccs_perm(ctx, MPX_JAC, n.perm_j.data(), colind.data());
+  n.sp_jac = ccs(z.n_g, z.n_z, colind, r, n.perm_j);
+  mpx_pattern_hess(ctx, hr.data(), hc.data());
+  mpx_ccs_perm(ctx, MPX_HESS, n.perm_h.data(), colind.data());
+  n.sp_hess = ccs(z.n_z, z.n_z, colind, hr, n.perm_h);
+  n.sp_x = dense_col(z.n_z);
+  n.sp_p = dense_col(z.n_p);
+  n.sp_g = dense_col(z.n_g);
+  n.sp_one = dense_col(1);
+  n.zx.assign(z.n_z, 0.0);
+  n.zp.assign(z.n_p, 0.0);
+  n.zl.assign(z.n_g, 0.0);
+  n.buf_j.resize(z.nnz_jac);
+  n.buf_h.resize(z.nnz_hess);
+  n.buf_g.resize(z.n_g);
+  n.buf_grad.resize(z.n_z);
+  C = std::move(n);
+  return MPX_OK;
+}
+
+#define MPX_COMMON(NAME, NIN, NOUT)                                                     \
+  extern "C" long long NAME##_n_in(void) { return NIN; }                                \
+  extern "C" long long NAME##_n_out(void) { return NOUT; }                              \
+  extern "C" void NAME##_incref(void) {}                                                \
+  extern "C" void NAME##_decref(void) {}                                                \
+  extern "C" int NAME##_work(long long* a, long long* r, long long* iw, long long* w) { \
+    if (a) *a = NIN;                                                                    \
+    if (r) *r = NOUT;                                                                   \
+    if (iw) *iw = 0;                                                                    \
+    if (w) *w = 0;                                                                      \
+    return 0;                                                                           \
+  }
+
+// ---- nlp_f : (x, p) -> (f) ---------------------------------------------------------------------
+MPX_COMMON(nlp_f, 2, 1)
+extern "C" const char* nlp_f_name_in(long long i) { return i == 0 ? "x" : (i == 1 ? "p" : 0); }
+extern "C" const char* nlp_f_name_out(long long i) { return i == 0 ? "f" : 0; }
+extern "C" const long long* nlp_f_sparsity_in(long long i) { return i == 0 ? C.sp_x.data() : (i == 1 ? C.sp_p.data() : 0); }
+extern "C" const long long* nlp_f_sparsity_out(long long i) { return i == 0 ? C.sp_one.data() : 0; }
+extern "C" int nlp_f(const double** arg, double** res, long long*, double*, int) {
+  if (!C.ctx) return 1;
+  double f;
+  if (mpx_eval(C.ctx, MPX_F, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, &f, 0, 0, 0, 0)) return 1;
+  if (res && res[0]) res[0][0] = f;
+  return 0;
+}
+
+// ---- nlp_g : (x, p) -> (g) ---------------------------------------------------------------------
+MPX_COMMON(nlp_g, 2, 1)
+extern "C" const char* nlp_g_name_in(long long i) { return nlp_f_name_in(i); }
+extern "C" const char* nlp_g_name_out(long long i) { return i == 0 ? "g" : 0; }
+extern "C" const long long* nlp_g_sparsity_in(long long i) { return nlp_f_sparsity_in(i); }
+extern "C" const long long* nlp_g_sparsity_out(long long i) { return i == 0 ? C.sp_g.data() : 0; }
+extern "C" int nlp_g(const double** arg, double** res, long long*, double*, int) {
+  if (!C.ctx) return 1;
+  double* g = res && res[0] ? res[0] : C.buf_g.data();
+  return mpx_eval(C.ctx, MPX_G, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, 0, g, 0, 0, 0) ? 1 : 0;
+}
+
+// ---- nlp_grad_f : (x, p) -> (f, grad_f_x) ------------------------------------------------------
+MPX_COMMON(nlp_grad_f, 2, 2)
+extern "C" const char* nlp_grad_f_name_in(long long i) { return nlp_f_name_in(i); }
+extern "C" const char* nlp_grad_f_name_out(long long i) { return i == 0 ? "f" : (i == 1 ? "grad_f_x" : 0); }
+extern "C" const long long* nlp_grad_f_sparsity_in(long long i) { return nlp_f_sparsity_in(i); }
+extern "C" const long long* nlp_grad_f_sparsity_out(long long i) { return i == 0 ? C.sp_one.data() : (i == 1 ? C.sp_x.data() : 0); }
+extern "C" int nlp_grad_f(const double** arg, double** res, long long*, double*, int) {
+  if (!C.ctx) return 1;
+  double f;
+  double* gr = res && res[1] ? res[1] : C.buf_grad.data();
+  if (mpx_eval(C.ctx, MPX_F | MPX_GRAD, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, &f, 0, gr, 0, 0)) return 1;
+  if (res && res[0]) res[0][0] = f;
+  return 0;
+}
+
+// ---- nlp_jac_g : (x, p) -> (g, jac_g_x) --------------------------------------------------------
+MPX_COMMON(nlp_jac_g, 2, 2)
+extern "C" const char* nlp_jac_g_name_in(long long i) { return nlp_f_name_in(i); }
+extern "C" const char* nlp_jac_g_name_out(long long i) { return i == 0 ? "g" : (i == 1 ? "jac_g_x" : 0); }
+extern "C" const long long* nlp_jac_g_sparsity_in(long long i) { return nlp_f_sparsity_in(i); }
+extern "C" const long long* nlp_jac_g_sparsity_out(long long i) { return i == 0 ? C.sp_g.data() : (i == 1 ? C.sp_jac.data() : 0); }
+extern "C" int nlp_jac_g(const double** arg, double** res, long long*, double*, int) {
+  if (!C.ctx) return 1;
+  double* g = res && res[0] ? res[0] : C.buf_g.data();
+  if (mpx_eval(C.ctx, MPX_G | MPX_JAC, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, 0, g, 0, C.buf_j.data(), 0)) return 1;
+  if (res && res[1])
+    for (size_t k = 0; k < C.perm_j.size(); ++k) res[1][k] = C.buf_j[C.perm_j[k]];
+  return 0;
+}
+
+// ---- nlp_hess_l : (x, p, lam_f, lam_g) -> (hess_gamma_x_x, upper triangle) -----------------------
+MPX_COMMON(nlp_hess_l, 4, 1)
+extern "C" const char* nlp_hess_l_name_in(long long i) {
+  static const char* n[] = {"x", "p", "lam_f", "lam_g"};
+  return i >= 0 && i < 4 ? n[i] : 0;
+}
+extern "C" const char* nlp_hess_l_name_out(long long i) { return i == 0 ? "hess_gamma_x_x" : 0; }
+extern "C" const long long* nlp_hess_l_sparsity_in(long long i) {
+  return i == 0 ? C.sp_x.data() : (i == 1 ? C.sp_p.data() : (i == 2 ? C.sp_one.data() : (i == 3 ? C.sp_g.data() : 0)));
+}
+extern "C" const long long* nlp_hess_l_sparsity_out(long long i) { return i == 0 ? C.sp_hess.data() : 0; }
+extern "C" int nlp_hess_l(const double** arg, double** res, long long*, double*, int) {
+  if (!C.ctx) return 1;
+  const double sigma = arg && arg[2] ? arg[2][0] : 0.0;
+  if (mpx_eval(C.ctx, MPX_HESS, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, in(arg, 3, C.zl), &sigma, 0, 0, 0, 0, C.buf_h.data())) return 1;
+  if (res && res[0])
+    for (size_t k = 0; k < C.perm_h.size(); ++k) res[0][k] = C.buf_h[C.perm_h[k]];
+  return 0;
+}

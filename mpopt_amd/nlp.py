@@ -79,7 +79,16 @@ class NlpFunctions:
         self.bytes_fgj, self.bytes_hess = s.bytes_fgj, s.bytes_hess
         self._jac_pat = self._hess_pat = None
 
+    def make_current(self):
+        """Select this context for the CasADi-external entry points (nlp_f ... nlp_hess_l in libmpx.so):
+        ``ca.nlpsol("solver", "ipopt", mpopt_amd._lib.LIB_PATH, opts)`` then evaluates on the GPU."""
+        _lib.check(self._L.mpx_set_current(self._ctx), self._ctx)
+        NlpFunctions._current = self
+
     def close(self):
+        if getattr(NlpFunctions, "_current", None) is self:
+            self._L.mpx_set_current(None)
+            NlpFunctions._current = None
         if getattr(self, "_ctx", None):
             self._L.mpx_destroy(self._ctx)
             self._ctx = None

@@ -62,3 +62,60 @@ def test_batch_matches_single(name):
         r1 = o.eval(["f", "g", "jac_g"], Z[b], P[b])
         for k in ("f", "g", "jac_g"):
             assert np.array_equal(rp[k][b], r1[k]), (k, b)
+
+
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL"])
+def test_casadi_external_entry_points(name):
+    """nlp_f / nlp_g / nlp_grad_f / nlp_jac_g / nlp_hess_l with CasADi's generated-code calling
+    convention (mpx_casadi.cpp), values in compressed-column order, against the reference goldens."""
+    import ctypes
+    from mpopt_amd import _lib
+
+    G = load_golden(name)
+    ocp, mpo, o = build_case(name, with_device=True)
+    o.make_current()
+    L = _lib.lib()
+    LL = ctypes.POINTER(ctypes.c_longlong)
+
+    def call(fn, ins, outs):
+        arg = (ctypes.c_void_p * len(ins))(*[a.ctypes.data if a is not None else None for a in ins])
+        res = (ctypes.c_void_p * len(outs))(*[a.ctypes.data if a is not None else None for a in outs])
+        assert getattr(L, fn)(arg, res, None, None, 0) == 0
+
+    def ccs_dense(fn, idx, vals):
+        f = getattr(L, fn + "_sparsity_out")
+        f.restype, f.argtypes = LL, [ctypes.c_longlong]
+        sp = f(idx)
+        nrow, ncol = sp[0], sp[1]
+        M_ = np.zeros((nrow, ncol))
+        k = 0
+        for j in range(ncol):
+            for q in range(sp[2 + j], sp[2 + j + 1]):
+                M_[sp[2 + ncol + 1 + q], j] = vals[k]
+                k += 1
+        return M_
+
+    z, p, lam, sig = G["z"].copy(), G["p"].copy(), G["lam"].copy(), np.array([float(G["sigma"])])
+    f, g, gr = np.zeros(1), np.zeros(o.n_g), np.zeros(o.n_z)
+    jv, hv = np.zeros(o.nnz_jac), np.zeros(o.nnz_hess)
+    call("nlp_f", [z, p], [f])
+    assert rel_err(f[0], G["f"]) < TOL
+    call("nlp_g", [z, p], [g])
+    assert rel_err(g, G["g"]) < TOL
+    f[:] = 0
+    call("nlp_grad_f", [z, p], [f, gr])
+    assert rel_err(f[0], G["f"]) < TOL and rel_err(gr, G["grad_f"]) < TOL
+    g[:] = 0
+    call("nlp_jac_g", [z, p], [g, jv])
+    Jr = np.zeros((o.n_g, o.n_z))
+    Jr[G["jac_row"], G["jac_col"]] = G["jac_val"]
+    assert rel_err(g, G["g"]) < TOL and rel_err(ccs_dense("nlp_jac_g", 1, jv), Jr) < TOL
+    call("nlp_hess_l", [z, p, sig, lam], [hv])
+    Hr = np.zeros((o.n_z, o.n_z))
+    Hr[G["hess_row"], G["hess_col"]] = G["hess_val"]
+    assert rel_err(ccs_dense("nlp_hess_l", 0, hv), Hr) < TOL
+    # NULL argument = zeros, NULL result = not requested (CasADi convention)
+    call("nlp_jac_g", [z, p], [None, jv])
+    call("nlp_hess_l", [z, p, None, None], [hv])
+    assert np.abs(hv).max() == 0.0
+    o.close()

@@ -133,3 +133,58 @@ def test_generated_source_is_deterministic_and_cached():
     co1, path1 = _lib.compile_kernels(a.source)
     co2, path2 = _lib.compile_kernels(b.source)
     assert path1 == path2 and co1 == co2 and (co1[:4] == b"\x7fELF" or co1.startswith(b"__CLANG_OFFLOAD_BUNDLE__"))
+
+
+CASADI_FUNCS = {"nlp_f": (2, 1), "nlp_g": (2, 1), "nlp_grad_f": (2, 2), "nlp_jac_g": (2, 2), "nlp_hess_l": (4, 1)}
+
+
+def _sparsity(ptr):
+    nrow, ncol = ptr[0], ptr[1]
+    colind = [ptr[2 + j] for j in range(ncol + 1)]
+    rows = [ptr[2 + ncol + 1 + k] for k in range(colind[-1])]
+    return nrow, ncol, colind, rows
+
+
+def test_casadi_external_surface_metadata():
+    """The five oracles with CasADi's generated-code convention: counts, names, CCS
+    sparsities consistent with the COO patterns; evaluation without device code fails with rc != 0."""
+    ocp, mpo, o = build_case("kitchen_sink_mixed_CGL", with_device=False)
+    L = ctypes.CDLL(_lib.build_library())
+    o.make_current()
+    LL = ctypes.POINTER(ctypes.c_longlong)
+    for name, (nin, nout) in CASADI_FUNCS.items():
+        for suffix in ("", "_n_in", "_n_out", "_name_in", "_name_out", "_sparsity_in", "_sparsity_out", "_work", "_incref", "_decref"):
+            assert hasattr(L, name + suffix), name + suffix
+        getattr(L, name + "_n_in").restype = ctypes.c_longlong
+        getattr(L, name + "_n_out").restype = ctypes.c_longlong
+        assert getattr(L, name + "_n_in")() == nin and getattr(L, name + "_n_out")() == nout
+        getattr(L, name + "_name_in").restype = ctypes.c_char_p
+        getattr(L, name + "_name_in").argtypes = [ctypes.c_longlong]
+        assert getattr(L, name + "_name_in")(0) == b"x" and getattr(L, name + "_name_in")(1) == b"p"
+        getattr(L, name + "_sparsity_in").restype = LL
+        getattr(L, name + "_sparsity_in").argtypes = [ctypes.c_longlong]
+        assert _sparsity(getattr(L, name + "_sparsity_in")(0))[:2] == (o.n_z, 1)
+        assert _sparsity(getattr(L, name + "_sparsity_in")(1))[:2] == (o.n_p, 1)
+    L.nlp_hess_l_name_in.restype = ctypes.c_char_p
+    assert L.nlp_hess_l_name_in(ctypes.c_longlong(2)) == b"lam_f" and L.nlp_hess_l_name_in(ctypes.c_longlong(3)) == b"lam_g"
+    for fn, idx, pat, shape in (("nlp_jac_g", 1, o.jac_pattern(), (o.n_g, o.n_z)), ("nlp_hess_l", 0, o.hess_pattern(), (o.n_z, o.n_z))):
+        f = getattr(L, fn + "_sparsity_out")
+        f.restype, f.argtypes = LL, [ctypes.c_longlong]
+        nrow, ncol, colind, rows = _sparsity(f(idx))
+        assert (nrow, ncol) == shape and colind[-1] == len(pat[0])
+        got = set()
+        for j in range(ncol):
+            seg = rows[colind[j]:colind[j + 1]]
+            assert seg == sorted(seg) and len(set(seg)) == len(seg)
+            got |= {(r, j) for r in seg}
+        assert got == set(zip(pat[0].tolist(), pat[1].tolist()))
+        if fn == "nlp_hess_l":
+            assert all(r <= c for r, c in got)  # upper triangle, like triu:hess:gamma:x:x
+    # no device code: the CasADi entry points report failure (non-zero), they do not compute on the CPU
+    x, p = np.zeros(o.n_z), np.full(o.n_p, 0.5)
+    arg = (ctypes.c_void_p * 2)(x.ctypes.data, p.ctypes.data)
+    fval = np.zeros(1)
+    res = (ctypes.c_void_p * 1)(fval.ctypes.data)
+    assert L.nlp_f(arg, res, None, None, 0) != 0
+    o.close()
+    assert L.nlp_f(arg, res, None, None, 0) != 0  # no current context any more
