@@ -187,6 +187,27 @@ int mpx_get_tile_weights(const mpx_ctx* ctx, int64_t* weights);
 int mpx_get_partials(mpx_ctx* ctx, int64_t batch, double** device_ptr, int64_t* count);
 
 /* ---------------------------------------------------------------------------------------------
+ * Off-node evaluation ("next" row): what mpopt.interpolate_single_phase and
+ * mpopt.get_dynamics_residuals_single_phase compute after a solve (mpopt.py:1428-1543), batched.
+ * A plan fixes the target points of one phase: points of segment s are
+ * taus[seg_ptr[s] .. seg_ptr[s+1]) on the reference interval [tau0, tau1]; segments may be empty.
+ * Outputs, all optional, row-major per evaluation point:
+ *   ti [n_pts]       unscaled time                         (get_interpolated_time_grid, 1545-1573)
+ *   xi [n_pts][nx], ui [n_pts][nu]    C.X, C.U  (scaled variables)        (1523-1532)
+ *   dxi, dui         D_at.X, D_at.U
+ *   dyn [n_pts][nx]  h_s * scale_x * dynamics(xi/scale_x, ui/scale_u, ti, a/scale_a)   (1466-1480)
+ *   resid            dxi - dyn                                                          (1481)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mpx_resid_plan mpx_resid_plan;
+int mpx_resid_plan_create(mpx_ctx* ctx, int phase, const int64_t* seg_ptr, const double* taus, mpx_resid_plan** out);
+int mpx_resid_plan_destroy(mpx_resid_plan* plan);
+int mpx_resid_eval(mpx_ctx* ctx, mpx_resid_plan* plan, int64_t batch, const double* z, const double* p, int p_per_point,
+                   double* ti, double* xi, double* ui, double* dxi, double* dui, double* dyn, double* resid);
+int mpx_resid_eval_device(mpx_ctx* ctx, mpx_resid_plan* plan, int64_t batch, const double* z, const double* p,
+                          int p_per_point, double* ti, double* xi, double* ui, double* dxi, double* dui, double* dyn,
+                          double* resid);
+
+/* ---------------------------------------------------------------------------------------------
  * CasADi-external-compatible surface (mpx_casadi.cpp): the symbols nlp_f, nlp_g, nlp_grad_f,
  * nlp_jac_g, nlp_hess_l (+ _n_in/_n_out/_name_in/_name_out/_sparsity_in/_sparsity_out/_work/
  * _incref/_decref) follow the calling convention of CasADi-generated C code and act on the context

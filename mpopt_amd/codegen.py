@@ -66,6 +66,7 @@ class PhaseProgram:
         dyn = _as_list(ocp.get_dynamics(phase)(x, u, t, a_))
         if len(dyn) != nx:
             raise ValueError(f"phase {phase}: dynamics returned {len(dyn)} values for {nx} states")
+        self.t_node = t
         self.fx = [h * (sx[a] * tr.wrap(dyn[a])) for a in range(nx)]
         if ocp.has_path_constraints(phase):
             self.c = [tr.wrap(v) for v in _as_list(ocp.get_path_constraints(phase)(x, u, t, a_))]
@@ -178,6 +179,12 @@ class PhaseProgram:
                     "const double* __restrict__ As, double kap, double th, double W")
         term_sig = ("const double* __restrict__ XF, double tfv, const double* __restrict__ X0, double t0v, "
                     "const double* __restrict__ As")
+        # unscaled time of a point with normalised position th in the phase (mpopt.py:198, 1564-1571)
+        out.append("  __device__ static __forceinline__ double node_time(double t0v, double tfv, double th) {")
+        out.append("    double t;")
+        out += tr.emit([("t", self.t_node)], names, "    ")
+        out.append("    return t;")
+        out.append("  }")
         # fg
         out.append(f"  __device__ static __forceinline__ void fg({node_sig}, double* fx, double* c, double& qW) {{")
         asg = [(f"fx[{a}]", e) for a, e in enumerate(self.fx)] + [(f"c[{j}]", e) for j, e in enumerate(self.c)] + [("qW", self.qW)]

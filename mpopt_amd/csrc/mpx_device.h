@@ -88,5 +88,28 @@ struct MpxBoundArgs {
   int32_t n_lin, nx, nu, na;
 };
 
+// Off-node evaluation (interpolated trajectories and dynamics residuals, mpopt.py:1428-1543):
+// one launch per degree bucket of a residual plan; lane <-> target point.
+struct MpxResidArgs {
+  const double* z;      int64_t z_stride;
+  const double* w;      const double* wcum; int64_t w_stride;
+  const int32_t* pt_id;   // [n] row of the point in the outputs
+  const int32_t* pt_seg;  // [n] segment of the point
+  const double* pt_tn;    // [n] (tau - tau0)/(tau1 - tau0)
+  const double* Cmat;     // [P+1][n] interpolation row of every point (transposed: lane-contiguous)
+  const double* Dmat;     // [P+1][n] first-derivative row of every point
+  const int32_t* seg_start;  // [S+1] first node of every segment
+  double* ti;           // [B][n_pts]
+  double* xi;           // [B][n_pts][nx]
+  double* ui;           // [B][n_pts][nu]
+  double* dxi;          // [B][n_pts][nx]
+  double* dui;          // [B][n_pts][nu]
+  double* dyn;          // [B][n_pts][nx]   h_s * Sx * dyn(...)
+  double* resid;        // [B][n_pts][nx]   dxi - dyn
+  double inv_dtau;
+  int64_t z_off;
+  int32_t n, n_pts, N, seg_off, B, b_per_block;
+};
+
 #define MPX_ACCUM_BIT (1LL << 62)
 #endif

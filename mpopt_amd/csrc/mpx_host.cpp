@@ -93,6 +93,7 @@ struct mpx_ctx {
   hipStream_t stream = nullptr;
   MpxTile* d_tiles = nullptr;
   double* d_Wnode = nullptr;
+  int32_t* d_seg_start = nullptr;
   int64_t *d_lin_ptr = nullptr, *d_lin_idx = nullptr, *d_lin_row = nullptr, *d_mg_dst = nullptr,
           *d_hc_dst = nullptr, *d_th_dst = nullptr;
   double* d_lin_coef = nullptr;
@@ -564,6 +565,7 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   }
   if ((rc = upload(c, &c->d_tiles, c->tiles))) return rc;
   if ((rc = upload(c, &c->d_Wnode, c->compW))) return rc;
+  if ((rc = upload(c, &c->d_seg_start, c->seg_start))) return rc;
   if ((rc = upload(c, &c->d_lin_ptr, c->lin_ptr))) return rc;
   if ((rc = upload(c, &c->d_lin_idx, c->lin_idx))) return rc;
   if ((rc = upload(c, &c->d_lin_row, c->lin_row))) return rc;
@@ -758,7 +760,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     };
     for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk);
     for (auto& B : c->buckets) fr(B.d_node_i), fr(B.d_node_sk);
-    fr(c->d_tiles), fr(c->d_Wnode), fr(c->d_lin_ptr), fr(c->d_lin_idx), fr(c->d_lin_row), fr(c->d_lin_coef);
+    fr(c->d_tiles), fr(c->d_Wnode), fr(c->d_seg_start), fr(c->d_lin_ptr), fr(c->d_lin_idx), fr(c->d_lin_row), fr(c->d_lin_coef);
     fr(c->d_mg_dst), fr(c->d_hc_dst), fr(c->d_th_dst);
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
@@ -907,6 +909,181 @@ extern "C" int mpx_profile_read(mpx_ctx* c, double* ms, int64_t* n) {
   *n = c->prof_launches;
   c->prof_used = 0;
   c->prof_launches = 0;
+  return MPX_OK;
+}
+
+// ---- off-node evaluation ---------------------------------------------------------------------
+struct ResidBucket {
+  int deg = 0, n = 0;
+  std::vector<int32_t> pt_id, pt_seg;
+  std::vector<double> pt_tn, Cmat, Dmat;  // Cmat/Dmat: [deg+1][n]
+  int32_t *d_id = nullptr, *d_seg = nullptr;
+  double *d_tn = nullptr, *d_C = nullptr, *d_D = nullptr;
+  hipFunction_t fn = nullptr;
+};
+struct mpx_resid_plan {
+  mpx_ctx* ctx = nullptr;
+  int phase = 0;
+  int64_t n_pts = 0;
+  std::vector<ResidBucket> buckets;
+  DevBuf<double> st[7];
+};
+
+extern "C" int mpx_resid_plan_destroy(mpx_resid_plan* P) {
+  if (!P) return MPX_OK;
+  if (P->ctx && P->ctx->has_device) {
+    (void)hipSetDevice(P->ctx->device);
+    for (auto& B : P->buckets) {
+      if (B.d_id) (void)hipFree(B.d_id);
+      if (B.d_seg) (void)hipFree(B.d_seg);
+      if (B.d_tn) (void)hipFree(B.d_tn);
+      if (B.d_C) (void)hipFree(B.d_C);
+      if (B.d_D) (void)hipFree(B.d_D);
+    }
+    for (auto& b : P->st)
+      if (b.p) (void)hipFree(b.p);
+  }
+  delete P;
+  return MPX_OK;
+}
+
+extern "C" int mpx_resid_plan_create(mpx_ctx* c, int phase, const int64_t* seg_ptr, const double* taus, mpx_resid_plan** out) {
+  if (!c || !seg_ptr || !out) return MPX_ERR_INVALID;
+  if (phase < 0 || phase >= c->n_phases) return fail(c, MPX_ERR_INVALID, "residual plan: phase out of range");
+  if (seg_ptr[0] != 0) return fail(c, MPX_ERR_INVALID, "residual plan: seg_ptr[0] must be 0");
+  for (int s = 0; s < c->S; ++s)
+    if (seg_ptr[s + 1] < seg_ptr[s]) return fail(c, MPX_ERR_INVALID, "residual plan: seg_ptr must be non-decreasing");
+  if (seg_ptr[c->S] > 0 && !taus) return MPX_ERR_INVALID;
+  mpx_resid_plan* P = new (std::nothrow) mpx_resid_plan;
+  if (!P) return MPX_ERR_ALLOC;
+  P->ctx = c;
+  P->phase = phase;
+  P->n_pts = seg_ptr[c->S];
+  for (auto& t : c->degs) {
+    ResidBucket B;
+    B.deg = t.deg;
+    const int n1 = t.deg + 1;
+    std::vector<double> Crows, Drows;  // [n][n1] then transposed
+    for (int s = 0; s < c->S; ++s) {
+      if (c->orders[s] != t.deg) continue;
+      const int64_t a = seg_ptr[s], b = seg_ptr[s + 1];
+      if (b == a) continue;
+      std::vector<double> Cm((size_t)(b - a) * n1), Dm((size_t)(b - a) * n1);
+      mpx_colloc_interp_matrix(t.roots.data(), n1, taus + a, (int)(b - a), Cm.data());
+      mpx_colloc_diff_matrix(t.roots.data(), n1, taus + a, (int)(b - a), 1, Dm.data());
+      for (int64_t q = a; q < b; ++q) {
+        B.pt_id.push_back((int32_t)q);
+        B.pt_seg.push_back(s);
+        B.pt_tn.push_back((taus[q] - c->tau0) / (c->tau1 - c->tau0));
+      }
+      Crows.insert(Crows.end(), Cm.begin(), Cm.end());
+      Drows.insert(Drows.end(), Dm.begin(), Dm.end());
+    }
+    B.n = (int)B.pt_id.size();
+    if (!B.n) continue;
+    B.Cmat.resize((size_t)n1 * B.n);
+    B.Dmat.resize((size_t)n1 * B.n);
+    for (int m = 0; m < B.n; ++m)
+      for (int j = 0; j < n1; ++j) {
+        B.Cmat[(size_t)j * B.n + m] = Crows[(size_t)m * n1 + j];
+        B.Dmat[(size_t)j * B.n + m] = Drows[(size_t)m * n1 + j];
+      }
+    P->buckets.push_back(std::move(B));
+  }
+  if (c->has_device) {
+    int rc = MPX_OK;
+    if (hipSetDevice(c->device) != hipSuccess) rc = MPX_ERR_HIP;
+    for (auto& B : P->buckets) {
+      if (rc) break;
+      char name[96];
+      snprintf(name, sizeof name, "mpx_resid_%d_%d", phase, B.deg);
+      if (hipModuleGetFunction(&B.fn, c->module, name) != hipSuccess) {
+        rc = fail(c, MPX_ERR_INVALID, "code object lacks kernel %s", name);
+        break;
+      }
+      if ((rc = upload(c, &B.d_id, B.pt_id)) || (rc = upload(c, &B.d_seg, B.pt_seg)) || (rc = upload(c, &B.d_tn, B.pt_tn)) ||
+          (rc = upload(c, &B.d_C, B.Cmat)) || (rc = upload(c, &B.d_D, B.Dmat)))
+        break;
+    }
+    if (rc) {
+      mpx_resid_plan_destroy(P);
+      return rc;
+    }
+  }
+  *out = P;
+  return MPX_OK;
+}
+
+extern "C" int mpx_resid_eval_device(mpx_ctx* c, mpx_resid_plan* P, int64_t batch, const double* z, const double* p,
+                                     int p_per_point, double* ti, double* xi, double* ui, double* dxi, double* dui,
+                                     double* dyn, double* resid) {
+  if (!c || !P || P->ctx != c) return MPX_ERR_INVALID;
+  if (!c->has_device)
+    return fail(c, MPX_ERR_NO_DEVICE, "mpx_resid_eval: context was created without a gfx950 code object; there is no CPU fallback");
+  if (batch < 1 || !z || !p) return fail(c, MPX_ERR_INVALID, "mpx_resid_eval: batch/z/p invalid");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t n_w = p_per_point ? batch : 1;
+  int rc;
+  if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
+  hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(256), 0, c->stream, p, c->wcum.p, c->S);
+  HIPCHK(c, hipGetLastError());
+  const PhaseStruct& Ph = c->ph[P->phase];
+  for (auto& B : P->buckets) {
+    MpxResidArgs A{};
+    A.z = z;
+    A.z_stride = c->n_z;
+    A.w = p;
+    A.wcum = c->wcum.p;
+    A.w_stride = p_per_point ? c->n_p : 0;
+    A.pt_id = B.d_id;
+    A.pt_seg = B.d_seg;
+    A.pt_tn = B.d_tn;
+    A.Cmat = B.d_C;
+    A.Dmat = B.d_D;
+    A.seg_start = c->d_seg_start;
+    A.ti = ti, A.xi = xi, A.ui = ui, A.dxi = dxi, A.dui = dui, A.dyn = dyn, A.resid = resid;
+    A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
+    A.z_off = Ph.z_off;
+    A.n = B.n;
+    A.n_pts = (int32_t)P->n_pts;
+    A.N = (int32_t)c->N;
+    A.seg_off = P->phase * c->S;
+    A.B = (int32_t)batch;
+    const int gx = (B.n + MPX_TILE - 1) / MPX_TILE;
+    A.b_per_block = (int)std::min<int64_t>(std::max<int64_t>(batch * gx / 2048, 1), 16);
+    const int gy = (int)((batch + A.b_per_block - 1) / A.b_per_block);
+    if ((rc = launch(c, B.fn, dim3(gx, gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A))) return rc;
+  }
+  return MPX_OK;
+}
+
+extern "C" int mpx_resid_eval(mpx_ctx* c, mpx_resid_plan* P, int64_t batch, const double* z, const double* p, int p_per_point,
+                              double* ti, double* xi, double* ui, double* dxi, double* dui, double* dyn, double* resid) {
+  if (!c || !P || P->ctx != c) return MPX_ERR_INVALID;
+  if (!c->has_device)
+    return fail(c, MPX_ERR_NO_DEVICE, "mpx_resid_eval: context was created without a gfx950 code object; there is no CPU fallback");
+  if (batch < 1 || !z || !p) return fail(c, MPX_ERR_INVALID, "mpx_resid_eval: batch/z/p invalid");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  const size_t Bz = (size_t)batch, npv = (size_t)(p_per_point ? batch : 1) * c->n_p, np_ = (size_t)std::max<int64_t>(P->n_pts, 1);
+  if ((rc = reserve(c, c->st_z, Bz * c->n_z)) || (rc = reserve(c, c->st_p, npv))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->st_z.p, z, Bz * c->n_z * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_p.p, p, npv * 8, hipMemcpyHostToDevice, c->stream));
+  double* host[7] = {ti, xi, ui, dxi, dui, dyn, resid};
+  const size_t width[7] = {1, (size_t)c->nx, (size_t)c->nu, (size_t)c->nx, (size_t)c->nu, (size_t)c->nx, (size_t)c->nx};
+  double* dev[7];
+  for (int k = 0; k < 7; ++k) {
+    dev[k] = nullptr;
+    if (host[k] && width[k]) {
+      if ((rc = reserve(c, P->st[k], Bz * np_ * width[k]))) return rc;
+      dev[k] = P->st[k].p;
+    }
+  }
+  if ((rc = mpx_resid_eval_device(c, P, batch, c->st_z.p, c->st_p.p, p_per_point, dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dev[6])))
+    return rc;
+  for (int k = 0; k < 7; ++k)
+    if (dev[k] && P->n_pts) HIPCHK(c, hipMemcpyAsync(host[k], dev[k], Bz * P->n_pts * width[k] * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return MPX_OK;
 }
 

@@ -309,6 +309,86 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Off-node evaluation: interpolated states/controls, their polynomial derivatives and the dynamics
+// residual  DXi - h_s*Sx*dyn(Xi/Sx, Ui/Su, ti, a)  at arbitrary points of every segment
+// (mpopt.interpolate_single_phase / get_dynamics_residuals_single_phase, mpopt.py:1428-1543).
+// lane <-> target point; the point's interpolation and derivative rows stay in VGPRs over the batch.
+// ---------------------------------------------------------------------------------------------
+template <int PH, int P>
+__device__ __forceinline__ void resid_body(const MpxResidArgs& A) {
+  using G = mpxgen::Phase<PH>;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC, P1 = P + 1;
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= A.n) return;
+  const int row = A.pt_id[m], s = A.pt_seg[m];
+  const int st = A.seg_start[s];
+  const double tn = A.pt_tn[m];
+  double Crow[P1], Drow[P1];
+#pragma unroll
+  for (int j = 0; j < P1; ++j) {
+    Crow[j] = A.Cmat[(int64_t)j * A.n + m];
+    Drow[j] = A.Dmat[(int64_t)j * A.n + m];
+  }
+  const int N = A.N;
+  const int b0 = blockIdx.y * A.b_per_block;
+  const int b1 = (b0 + A.b_per_block < A.B) ? b0 + A.b_per_block : A.B;
+  for (int b = b0; b < b1; ++b) {
+    const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride + A.z_off;
+    Vec<NX> Xi, DXi, fx;
+    Vec<NU> Ui, DUi;
+    Vec<NA> As;
+    Vec<NC> cc;
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+      double v = 0, d = 0;
+#pragma unroll
+      for (int j = 0; j < P1; ++j) {
+        const double x = (zb + (int64_t)a * N)[st + j];
+        v = fma(Crow[j], x, v);
+        d = fma(Drow[j], x, d);
+      }
+      Xi[a] = v;
+      DXi[a] = d;
+    }
+#pragma unroll
+    for (int c = 0; c < NU; ++c) {
+      double v = 0, d = 0;
+#pragma unroll
+      for (int j = 0; j < P1; ++j) {
+        const double x = (zb + (int64_t)(NX + c) * N)[st + j];
+        v = fma(Crow[j], x, v);
+        d = fma(Drow[j], x, d);
+      }
+      Ui[c] = v;
+      DUi[c] = d;
+    }
+    const double* __restrict__ zt = zb + (int64_t)(NX + NU) * N;
+    const double t0v = zt[0], tfv = zt[1];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
+    const int64_t woff = (int64_t)b * A.w_stride + A.seg_off + s;
+    const double ws = A.w[woff], wc = A.wcum[woff];
+    const double kap = ws * A.inv_dtau, th = wc + ws * tn;
+    double qW;
+    G::fg(Xi, Ui, t0v, tfv, As, kap, th, 0.0, fx, cc, qW);
+    const int64_t o = (int64_t)b * A.n_pts + row;
+    if (A.ti) A.ti[o] = G::node_time(t0v, tfv, th);
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+      if (A.xi) A.xi[o * NX + a] = Xi[a];
+      if (A.dxi) A.dxi[o * NX + a] = DXi[a];
+      if (A.dyn) A.dyn[o * NX + a] = fx[a];
+      if (A.resid) A.resid[o * NX + a] = DXi[a] - fx[a];
+    }
+#pragma unroll
+    for (int c = 0; c < NU; ++c) {
+      if (A.ui) A.ui[o * NU + c] = Ui[c];
+      if (A.dui) A.dui[o * NU + c] = DUi[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Boundary kernel: one workgroup per evaluation point.  Finishes the fixed-order reductions,
 // evaluates Mayer cost and terminal constraints (mpopt.py:264-300), the linear rows that couple
 // segments or phases (control-slope continuity mpopt.py:379-413, events mpopt.py:464-521) and
@@ -439,6 +519,9 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A) {
   }                                                                                                         \
   extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_hess_##PH##_##P(const MpxNodeArgs A) {    \
     mpxk::node_body<PH, P, MPX_MODE_HESS>(A);                                                               \
+  }                                                                                                         \
+  extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_resid_##PH##_##P(const MpxResidArgs A) {       \
+    mpxk::resid_body<PH, P>(A);                                                                             \
   }
 
 #define MPX_INSTANTIATE_BOUNDARY()                                                                          \

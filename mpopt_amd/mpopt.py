@@ -566,6 +566,94 @@ class mpopt:
             t_seg0 += h * (self.tau1 - self.tau0)
         return X, U, t, t0, tf, a
 
+    # ---- post-solve: off-node interpolation and dynamics residuals (mpopt.py:1152-1236, 1360-1573) --
+    def get_residual_grid_taus(self, phase=0, grid_type=None):
+        """Non-collocation target points per segment: "fixed" (equally spaced over the phase),
+        "mid-points" (between consecutive nodes), "spectral" (interior nodes of degree _MAX_GRID_POINTS+2)."""
+        grid_type = self.grid_type[phase] if grid_type is None else grid_type
+        if grid_type == "fixed":
+            n_nodes = max(sum(self.poly_orders) + 2, self._MAX_GRID_POINTS + 2)
+            target = np.linspace(self.tau0, self.tau1, n_nodes)
+            S = self.n_segments
+            taus = self.compute_interpolation_taus_corresponding_to_original_grid(
+                target, self._nlp_sw_params[S * phase:S * (phase + 1)], tau0=self.tau0, tau1=self.tau1)
+            taus[0] = taus[0][:-1]
+            return taus
+        if grid_type == "mid-points":
+            return [(self.collocation._taus_fn(d)[:-1] + self.collocation._taus_fn(d)[1:]) / 2.0 for d in self.poly_orders]
+        if grid_type == "spectral":
+            return [np.array(self.collocation._taus_fn(self._MAX_GRID_POINTS + 2)[1:-1]) for _ in self.poly_orders]
+        return None
+
+    @staticmethod
+    def compute_interpolation_taus_corresponding_to_original_grid(nodes_req, seg_widths, tau0=0, tau1=1):
+        cum = np.append(0, np.cumsum(seg_widths))
+        assert abs(cum[-1] - 1) < 1e-6
+        scaled = (np.asarray(nodes_req, float) - tau0) / (tau1 - tau0)
+        out = []
+        for i, w in enumerate(seg_widths):
+            t = scaled[scaled > cum[i]]  # the start node is excluded, the end node included
+            t = t[t <= cum[i + 1]]
+            out.append(tau0 + (tau1 - tau0) * ((t - cum[i]) / w))
+        return out
+
+    @staticmethod
+    def get_interpolated_time_grid(t_orig, taus, poly_orders, tau0, tau1):
+        t_orig = np.asarray(t_orig, float).ravel()
+        t_seg = [t_orig[0]] + [t_orig[sum(poly_orders[:i + 1])] for i in range(len(poly_orders))]
+        return np.concatenate([t_seg[i] + (t_seg[i + 1] - t_seg[i]) * ((np.asarray(taus[i], float) - tau0) / (tau1 - tau0))
+                               for i in range(len(t_seg) - 1)]).reshape(-1, 1)
+
+    def _residual_plan(self, phase, target_nodes):
+        if self.oracle is None:
+            self.create_nlp()
+        key = (phase, tuple(np.asarray(t, float).tobytes() for t in target_nodes))
+        cache = self.__dict__.setdefault("_resid_plans", {})
+        if key not in cache:
+            cache.clear()
+            cache[key] = self.oracle.residual_plan(phase, target_nodes)
+        return cache[key]
+
+    def interpolate_single_phase(self, solution, phase=0, target_nodes=None, grid_type=None, options={}):
+        """(Xi, Ui, ti, a, DXi, DUi, target_nodes, t0, tf) like the reference (mpopt.py:1489-1543); the
+        products C.X, D_at.X are evaluated by the GPU kernel mpx_resid_*."""
+        if target_nodes is None:
+            target_nodes = self.get_residual_grid_taus(phase=phase, grid_type=grid_type)
+        plan = self._residual_plan(phase, target_nodes)
+        r = plan.eval(np.asarray(solution["x"], float).ravel(), np.asarray(self._nlp_sw_params, float))
+        o, N = self._ocp, self._Npoints
+        n_zp = N * (o.nx + o.nu) + 2 + o.na
+        zp = np.asarray(solution["x"], float).ravel()[phase * n_zp:(phase + 1) * n_zp]
+        a = zp[(o.nx + o.nu) * N + 2:]
+        t0 = np.array([zp[(o.nx + o.nu) * N] / o.scale_t])
+        tf = np.array([zp[(o.nx + o.nu) * N + 1] / o.scale_t])
+        nu_empty = np.zeros((plan.n_pts, 0))
+        return (_mat(r["xi"]), _mat(r.get("ui", nu_empty)), _mat(r["ti"].reshape(-1, 1)), _mat(a.reshape(-1, 1)),
+                _mat(r["dxi"]), _mat(r.get("dui", nu_empty)), target_nodes, t0, tf)
+
+    def get_dynamics_residuals_single_phase(self, solution, phase=0, target_nodes=None):
+        """(ti_phase, residual_phase, dyn_phase): per-segment lists, ``None``/[] for empty segments
+        (mpopt.py:1428-1487)."""
+        if target_nodes is None:
+            target_nodes = self.get_residual_grid_taus(phase=phase)
+        plan = self._residual_plan(phase, target_nodes)
+        r = plan.eval(np.asarray(solution["x"], float).ravel(), np.asarray(self._nlp_sw_params, float), what=("ti", "dyn", "resid"))
+        ti = [t if t is not None else [] for t in plan.split(r["ti"])]
+        return ti, plan.split(r["resid"]), plan.split(r["dyn"])
+
+    def get_dynamics_residuals(self, solution, nodes=None, grid_type=None, residual_type=None, plot=False, fig=None, axs=None):
+        ti, residuals = [None] * self._ocp.n_phases, [None] * self._ocp.n_phases
+        for phase in range(self._ocp.n_phases):
+            target = nodes[phase] if nodes is not None else self.get_residual_grid_taus(phase, grid_type=grid_type)
+            ti[phase], residuals[phase], dyn = self.get_dynamics_residuals_single_phase(solution, phase, target_nodes=target)
+            if residual_type == "relative":  # scaled by the largest |h*Sx*dyn| of the phase (mpopt.py:1403-1418)
+                mx = np.zeros(self._ocp.nx)
+                for seg in dyn:
+                    if seg is not None:
+                        mx = np.maximum(mx, np.abs(seg).max(axis=0))
+                residuals[phase] = [None if r is None else r / mx for r in residuals[phase]]
+        return ti, residuals
+
     def process_results(self, solution, plot=False, **kwargs):
         return post_process(self, solution)
 

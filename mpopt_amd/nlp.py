@@ -24,6 +24,73 @@ def _ptr(x):
     return x.data_ptr()  # torch tensor
 
 
+class ResidualPlan:
+    """Target points of one phase for the off-node evaluation (include/mpx.h, mpx_resid_*): what
+    ``mpopt.interpolate_single_phase`` / ``get_dynamics_residuals_single_phase`` compute in the reference
+    (mpopt.py:1428-1543), on the GPU and batched."""
+
+    FIELDS = ("ti", "xi", "ui", "dxi", "dui", "dyn", "resid")
+
+    def __init__(self, oracle, phase, taus_per_segment):
+        self.oracle, self.phase = oracle, int(phase)
+        taus = [np.ascontiguousarray(np.asarray(t, dtype=np.float64).ravel()) for t in taus_per_segment]
+        if len(taus) != oracle.n_segments:
+            raise ValueError("one array of target points per segment is required")
+        self.seg_ptr = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(t) for t in taus])]), dtype=np.int64)
+        self.taus = np.ascontiguousarray(np.concatenate(taus) if len(taus) else np.zeros(0), dtype=np.float64)
+        if self.taus.size == 0:
+            self.taus = np.zeros(1)
+        self.n_pts = int(self.seg_ptr[-1])
+        h = ctypes.c_void_p()
+        _lib.check(oracle._L.mpx_resid_plan_create(oracle._ctx, self.phase, self.seg_ptr.ctypes.data_as(_lib.c_int64_p),
+                                                   _lib.dptr(self.taus), ctypes.byref(h)), oracle._ctx)
+        self._h = h
+        o = oracle.ocp
+        self.widths = {"ti": 0, "xi": o.nx, "ui": o.nu, "dxi": o.nx, "dui": o.nu, "dyn": o.nx, "resid": o.nx}
+
+    def eval(self, z, p, what=FIELDS):
+        """Host arrays; z (n_z,) or (B, n_z).  Returns dict name -> array (B?, n_pts[, width])."""
+        orc = self.oracle
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        single = z.ndim == 1
+        z = z.reshape(-1, orc.n_z)
+        B = z.shape[0]
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        per_point = int(p.size == B * orc.n_p and B > 1)
+        out, ptrs = {}, []
+        for name in self.FIELDS:
+            if name in what and (self.widths[name] or name == "ti"):
+                shape = (B, self.n_pts) if name == "ti" else (B, self.n_pts, self.widths[name])
+                out[name] = np.zeros(shape)
+                ptrs.append(out[name].ctypes.data if out[name].size else None)
+            else:
+                ptrs.append(None)
+        _lib.check(orc._L.mpx_resid_eval(orc._ctx, self._h, B, z.ctypes.data, p.ctypes.data, per_point, *ptrs), orc._ctx)
+        return {k: (v[0] if single else v) for k, v in out.items()}
+
+    def eval_device(self, batch, z, p, p_per_point=0, **outs):
+        orc = self.oracle
+        ptrs = [_ptr(outs.get(name)) for name in self.FIELDS]
+        _lib.check(orc._L.mpx_resid_eval_device(orc._ctx, self._h, int(batch), _ptr(z), _ptr(p), int(p_per_point), *ptrs), orc._ctx)
+
+    def split(self, arr):
+        """Per-segment list (``None`` for empty segments), like the reference's return values."""
+        return [arr[self.seg_ptr[s]:self.seg_ptr[s + 1]] if self.seg_ptr[s + 1] > self.seg_ptr[s] else None
+                for s in range(len(self.seg_ptr) - 1)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.oracle._L.mpx_resid_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if getattr(self.oracle, "_ctx", None):
+                self.close()
+        except Exception:
+            pass
+
+
 class NlpFunctions:
     def __init__(self, ocp, n_segments, poly_orders, scheme="LGR", tau0=-1.0, tau1=1.0, midu_rows=None,
                  device=0, with_device=None, verbose=False):
@@ -129,6 +196,9 @@ class NlpFunctions:
         w = np.empty(self.n_nodes)
         _lib.check(self._L.mpx_get_comp_weights(self._ctx, _lib.dptr(w)), self._ctx)
         return w
+
+    def residual_plan(self, phase, taus_per_segment):
+        return ResidualPlan(self, phase, taus_per_segment)
 
     # -- evaluation ------------------------------------------------------------------------
     def eval(self, what, z, p, lam_g=None, sigma=None):

@@ -321,6 +321,34 @@ class OracleNLP:
     def f(self, z, p):
         return sum(self.phase_parts(z, p, ph)[1] for ph in range(self.n_ph))
 
+    # -- post-solve: off-node interpolation and dynamics residuals -----------------------------------
+    def residuals(self, z, p, phase, taus_per_segment):
+        """Restatement of mpopt.interpolate_single_phase + get_dynamics_residuals_single_phase
+        (mpopt.py:1428-1573).  Returns dict ti, xi, ui, dxi, dui, dyn, resid (points concatenated over
+        segments in order)."""
+        o, G = self.ocp, self.grid
+        X, U, t0v, tfv, A = self.split(z, phase)
+        t0, tf = t0v / self.st, tfv / self.st  # init_trajectories: t0, tf unscaled (mpopt.py:872)
+        w = np.asarray(p, float)[phase * self.S:(phase + 1) * self.S]
+        _, t_node = self.node_times(t0, tf, w)  # time_grid of the transcription (mpopt.py:209, 873)
+        taus = [np.asarray(t, float) for t in taus_per_segment]
+        CI = G.comp_interp(taus, 0)  # mpopt.py:1516-1521
+        CD = G.comp_interp(taus, 1)
+        Xi, Ui, DXi, DUi = CI @ X, CI @ U, CD @ X, CD @ U  # mpopt.py:1523-1526
+        # get_interpolated_time_grid (mpopt.py:1545-1573)
+        t_seg = [t_node[0]] + [t_node[sum(G.orders[:i + 1])] for i in range(self.S)]
+        ti = np.concatenate([t_seg[i] + (t_seg[i + 1] - t_seg[i]) * ((taus[i] - G.tau0) / (G.tau1 - G.tau0)) for i in range(self.S)])
+        dyn = o.get_dynamics(phase)
+        F = np.zeros((len(ti), self.nx))
+        idx = 0
+        for s in range(self.S):  # mpopt.py:1451-1480
+            h_seg = (tf - t0) / (G.tau1 - G.tau0) * w[s]
+            for _ in range(len(taus[s])):
+                f = dyn(Xi[idx] / self.sx, Ui[idx] / self.su, ti[idx], A / self.sa)
+                F[idx] = h_seg * (np.array([float(v) for v in f]) * self.sx)
+                idx += 1
+        return dict(ti=ti, xi=Xi, ui=Ui, dxi=DXi, dui=DUi, dyn=F, resid=DXi - F)
+
     # -- bounds and initial guess ---------------------------------------------------------------
     def bounds(self):
         """(lbx, ubx, lbg, ubg) following mpopt.py:546-570, 234-235, 257-258, 291-292, 323-324,

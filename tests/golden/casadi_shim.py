@@ -43,6 +43,8 @@ class M:
         elif _is_scalar(data):
             data = np.array([[_clean(data)]], dtype=object)
         else:
+            if isinstance(data, (list, tuple)):  # e.g. ca.DM([expr, expr, ...]) with 1x1 entries
+                data = [e.scalar() if isinstance(e, M) and e.a.size == 1 else _clean(e) for e in data]
             data = np.array(data, dtype=object)
             if data.ndim == 0:
                 data = data.reshape(1, 1)
@@ -63,6 +65,9 @@ class M:
 
     def numel(self):
         return self.a.size
+
+    def size(self):
+        return self.a.shape
 
     def is_empty(self):
         return self.a.size == 0

@@ -179,6 +179,60 @@ def make_case(name, builder, n_segments, poly_orders, scheme):
     print(f"nlp_{name}.npz: n_z={n_z} n_g={n_g} nnz_j={len(jr)} nnz_h={len(hr)}  ({time.time()-t0:.1f}s)")
 
 
+RESIDUAL_CASES = ["moon_lander_20x3_LGR", "hyper_sensitive_5x3_LGR", "kitchen_sink_mixed_CGL", "dae_vdp_mixed_CGL", "schwartz_4x3_LGL"]
+
+
+def make_residuals(name, builder, n_segments, poly_orders, scheme):
+    """Post-solve row: the reference's interpolate_single_phase and
+    get_dynamics_residuals_single_phase (mpopt.py:1428-1543) at the golden sample point, for the
+    three built-in residual grids and one custom grid."""
+    t0 = time.time()
+    ref.CollocationRoots._TAU_MIN, ref.CollocationRoots._TAU_MAX = -1, 1
+    ref.Collocation.D_MATRIX_METHOD = "numerical"
+    G = np.load(os.path.join(HERE, f"nlp_{name}.npz"))
+    ocp = builder(ref, casadi_shim)
+    mpo = ref.mpopt(ocp, n_segments, poly_orders, scheme)
+    mpo.create_nlp()
+    mpo._nlp_sw_params = list(G["p"])
+    sol = {"x": G["z"]}
+    rng = np.random.default_rng(7)
+    out = {}
+    for ph in range(ocp.n_phases):
+        grids = {}
+        for gt in ("fixed", "mid-points", "spectral"):
+            try:
+                grids[gt] = mpo.get_residual_grid_taus(ph, grid_type=gt)
+            except ValueError:
+                # mpopt.py:1188 wraps a ragged list in np.array(): an object array under the pinned
+                # numpy 1.22, an error under numpy >= 1.24 (mixed degrees).  Same content as a list:
+                assert gt == "mid-points"
+                grids[gt] = [(mpo.collocation._taus_fn(d)[:-1] + mpo.collocation._taus_fn(d)[1:]) / 2.0 for d in mpo.poly_orders]
+        custom = []
+        for s, d in enumerate(mpo.poly_orders):  # ragged: some segments empty, node values included
+            k = [0, 3, 1, 5][s % 4]
+            pts = np.sort(rng.uniform(-1, 1, k))
+            if s % 3 == 0 and k:
+                pts[-1] = 1.0
+            custom.append(pts)
+        grids["custom"] = custom
+        for gt, nodes in grids.items():
+            nodes = [np.asarray(t, dtype=float) for t in nodes]
+            Xi, Ui, ti, a, DXi, DUi, tg, t0_, tf_ = mpo.interpolate_single_phase(sol, phase=ph, target_nodes=nodes)
+            tis, res, dyn = mpo.get_dynamics_residuals_single_phase(sol, ph, target_nodes=nodes)
+            key = f"ph{ph}/{gt}"
+            out[key + "/seg_ptr"] = np.concatenate([[0], np.cumsum([len(t) for t in nodes])])
+            out[key + "/taus"] = np.concatenate(nodes) if sum(len(t) for t in nodes) else np.zeros(0)
+            out[key + "/xi"], out[key + "/ui"] = full(Xi), full(Ui)
+            out[key + "/dxi"], out[key + "/dui"] = full(DXi), full(DUi)
+            out[key + "/ti"] = full(ti).ravel()
+            out[key + "/t0tf"] = np.array([t0_[0], tf_[0]])
+            out[key + "/resid"] = np.concatenate([np.asarray(r, float) for r in res if r is not None]) if any(r is not None for r in res) else np.zeros((0, ocp.nx))
+            out[key + "/dyn"] = np.concatenate([np.asarray(r, float) for r in dyn if r is not None]) if any(r is not None for r in dyn) else np.zeros((0, ocp.nx))
+            out[key + "/ti_seg"] = np.concatenate([np.asarray(t, float).ravel() for t in tis]) if len(tis) else np.zeros(0)
+    np.savez_compressed(os.path.join(HERE, f"resid_{name}.npz"), **out)
+    print(f"resid_{name}.npz: {len(out)} arrays ({time.time()-t0:.1f}s)")
+
+
 def main():
     only = sys.argv[1:]
     if not only or "tables" in only:
@@ -186,7 +240,13 @@ def main():
     for name, (builder, s, po, scheme) in problems.GOLDEN_CASES.items():
         if only and name not in only:
             continue
+        if only == ["residuals"]:
+            continue
         make_case(name, builder, s, po, scheme)
+    for name in RESIDUAL_CASES:
+        if only and ("resid_" + name) not in only and "residuals" not in only:
+            continue
+        make_residuals(name, *problems.GOLDEN_CASES[name])
 
 
 if __name__ == "__main__":
