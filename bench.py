@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="evaluation points per GPU per step")
     ap.add_argument("--segments", type=int, default=1000)
     ap.add_argument("--degree", type=int, default=5)
+    ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config2-hess"],
+                    help="default: the metric's configuration (BASELINE configs[1], f+g+grad_f+jac_g).  The others are "
+                         "secondary reports (configs[4]: nlp_hess_l on hypersensitive 4000x3; configs[2]: mixed-degree grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
@@ -70,8 +73,17 @@ def main():
     import problems
 
     S, P, B, K, W = args.segments, args.degree, args.batch, args.steps, args.warmup
-    ocp = problems.moon_lander(mp, M.math)
-    mpo = mp.mpopt(ocp, S, P, "LGR")
+    hess_mode = args.workload.endswith("hess")
+    scheme, builder, label = "LGR", problems.moon_lander, f"moon-lander OCP, n_segments={S}, poly_orders={P}, LGR (BASELINE configs[1])"
+    if args.workload == "config5-hess":
+        builder, S, P, scheme = problems.BENCH_CASES[3]
+        label = "hypersensitive OCP, n_segments=4000, poly_orders=3, LGR (BASELINE configs[4])"
+    elif args.workload == "config3-fgj":
+        builder, S, P, scheme = problems.BENCH_CASES[1]
+        B = min(B, 512)
+        label = "Van der Pol OCP, n_segments=2000, poly_orders=[3,30,3]*, CGL (BASELINE configs[2])"
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, P, scheme)
     if rank == 0 or world == 1:
         nlp, bounds = mpo.create_nlp()  # rank 0 compiles (or finds the cached code object) first
     if world > 1:
@@ -81,7 +93,7 @@ def main():
     o = nlp["oracle"]
     if local_rank != 0:  # contexts are created on device 0 by default; re-create on this rank's GPU
         o.close()
-        o = M.NlpFunctions(ocp, S, mpo.poly_orders, "LGR", device=local_rank)
+        o = M.NlpFunctions(ocp, S, mpo.poly_orders, scheme, device=local_rank)
     o.set_stream(torch.cuda.current_stream().cuda_stream)
 
     Zh = make_points(o, mpo, bounds, B, 20260928 + rank)
@@ -92,9 +104,20 @@ def main():
     gr = torch.empty(B, o.n_z, dtype=torch.float64, device=dev)
     jv = torch.empty(B, o.nnz_jac, dtype=torch.float64, device=dev)
     mask = MPX_F | MPX_G | MPX_GRAD | MPX_JAC
+    if hess_mode:
+        from mpopt_amd._lib import MPX_HESS
+
+        mask = MPX_HESS
+        lam = torch.tensor(np.random.default_rng(20260928 + rank).standard_normal((B, o.n_g)), device=dev)
+        sig = torch.ones(B, dtype=torch.float64, device=dev)
+        hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
+        jv = hv
 
     def step():
-        o.eval_device(mask, B, Z, p, 0, None, None, f, g, gr, jv, None)
+        if hess_mode:
+            o.eval_device(mask, B, Z, p, 0, lam, sig, None, None, None, None, hv)
+        else:
+            o.eval_device(mask, B, Z, p, 0, None, None, f, g, gr, jv, None)
 
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < args.ramp_seconds:  # untimed; see --ramp-seconds
@@ -121,13 +144,15 @@ def main():
     elapsed = mpd.max_over_ranks(elapsed, device=dev)
 
     # sanity: the timed outputs are real (finite, and f matches a host recomputation of one point)
-    assert torch.isfinite(jv[0]).all() and torch.isfinite(g[-1]).all()
+    assert torch.isfinite(jv[0]).all() and (hess_mode or torch.isfinite(g[-1]).all())
 
     if rank == 0:
-        kernel_s = node_ms / 1e3 / max(n_launch, 1)
-        achieved = B * o.bytes_fgj / kernel_s / 1e9
+        n_buckets = len(set(int(d) for d in mpo.poly_orders))
+        kernel_s = node_ms / 1e3 / max(n_launch // n_buckets, 1)  # all node-kernel launches of one step
+        bytes_eval = o.bytes_hess if hess_mode else o.bytes_fgj
+        achieved = B * bytes_eval / kernel_s / 1e9
         out = {
-            "metric": "NLP grad_f+jac_g evals/sec, 1000-seg LGR",
+            "metric": "NLP grad_f+jac_g evals/sec, 1000-seg LGR" if args.workload == "config2-fgj" else f"NLP evals/sec ({args.workload})",
             "value": world * B * K / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
@@ -139,24 +164,24 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"moon-lander OCP, n_segments={S}, poly_orders={P}, LGR (BASELINE configs[1]); "
-                                   f"f+g+grad_f+jac_g, {B} evaluation points per GPU per step, inputs resident in HBM",
+            "config": {"workload": f"{label}; {'nlp_hess_l' if hess_mode else 'f+g+grad_f+jac_g'}, "
+                                   f"{B} evaluation points per GPU per step, inputs resident in HBM",
                        "n_z": o.n_z, "n_g": o.n_g, "nnz_jac": o.nnz_jac, "batch_per_gpu": B,
                        "parallelism": f"independent evaluation points x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": f"mpx_node_fgj_0_{P}", "kernel_us": kernel_s * 1e6,
-                         "bytes_per_eval": o.bytes_fgj, "evals_per_launch": B,
-                         "algorithmic_bytes_per_launch": B * o.bytes_fgj},
+                         "kernel": f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*", "kernel_us": kernel_s * 1e6,
+                         "bytes_per_eval": bytes_eval, "evals_per_launch": B,
+                         "algorithmic_bytes_per_launch": B * bytes_eval},
         }
         # HBM traffic of the dominant kernel from the committed PMC passes (same workload only)
         tf = os.path.join(ROOT, "profiles", "r1_tuned", "traffic.json")
         if os.path.exists(tf):
             tr = json.load(open(tf))
-            if tr["workload"] == {"segments": S, "degree": P, "batch": B}:
+            if args.workload == "config2-fgj" and tr["workload"] == {"segments": S, "degree": P, "batch": B}:
                 out["roofline"]["traffic"] = tr["bytes_per_launch"]
                 out["roofline"]["traffic_source"] = "profiles/r1_tuned/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "config2-fgj":
             from oracle.c_oracle import COracle
 
             C = COracle(["moon_lander"], S, P, "LGR")
