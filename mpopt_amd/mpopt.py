@@ -658,6 +658,216 @@ class mpopt:
         return post_process(self, solution)
 
 
+class mpopt_h_adaptive(mpopt):
+    """Iterative refinement of the segment widths with a fixed number of segments
+    (mpopt.py:2273-2874).  The NLP structure never changes -- only the parameter vector ``p`` -- so one
+    libmpx context (tables, patterns, code object) serves the whole loop; the dynamics residuals that
+    drive the refinement come from the GPU kernel ``mpx_resid_*``.  The refinement rules themselves are
+    O(n_segments) host arithmetic."""
+
+    _SEG_WIDTH_MIN = 1e-5
+    _SEG_WIDTH_MAX = 1
+    _TOL_SEG_WIDTH_CHANGE = 0.05
+    _TOL_RESIDUAL = 1e-2
+    _DEFAULT_METHOD = "residual"
+    _DEFAULT_SUB_METHOD = "equal_area"
+    _THRESHOLD_SLOPE = 1e-1
+
+    def __init__(self, problem, n_segments=1, poly_orders=[9], scheme="LGR", **kwargs):
+        super().__init__(problem=problem, n_segments=n_segments, poly_orders=poly_orders, scheme=scheme)
+        P = self._ocp.n_phases
+        self.lbh, self.ubh = [self._SEG_WIDTH_MIN] * P, [self._SEG_WIDTH_MAX] * P
+        self.tol_residual = [self._TOL_RESIDUAL] * P
+        self.fig = self.axs = None
+        self.plot_residual_evolution = False
+
+    def _say(self, *a):
+        if not self._MUTE_:
+            print(*a)
+
+    def solve(self, initial_solution=None, reinitialize_nlp=False, solver="ipopt", nlp_solver_options={}, mpopt_options={},
+              max_iter=10, **kwargs):
+        start = time.monotonic()
+        if (not self._nlpsolver_initialized) or reinitialize_nlp:
+            nlp_solver_options.setdefault("ipopt.print_level", 0)
+            self.create_solver(solver=solver, options=nlp_solver_options)
+        if mpopt_options == {}:
+            mpopt_options = {"method": self._DEFAULT_METHOD, "sub_method": self._DEFAULT_SUB_METHOD}
+        self.iter_count, self.iter_info = 0, dict()
+        sw_old = []
+        new_sw, max_error = self.get_segment_width_parameters(initial_solution, options=mpopt_options)
+        solution = initial_solution
+        if max_error is not None and max_error < min(self.tol_residual):
+            self.iter_info[self.iter_count] = max_error
+            self._say(f"Solved to acceptable tolerance {min(self.tol_residual)}", max_error)
+        else:
+            for it in range(max_iter):
+                self._nlp_sw_params = new_sw
+                if self.iter_count > 0:
+                    self.iter_info[self.iter_count] = max_error
+                    if self.iter_count > 4:  # stagnation of the max error over the last four iterations
+                        mean_error = np.mean(list(self.iter_info.values())[-4:])
+                        if abs(max_error - mean_error) < 0.05 * abs(max_error):
+                            self._say("Stopping the iterations: Change in max error is < 5%")
+                            self._nlp_sw_params = sw_old
+                            break
+                if it > 0:
+                    cur, old = np.asarray(self._nlp_sw_params, float), np.asarray(sw_old, float)
+                    if (np.abs(cur - old) / cur <= self._TOL_SEG_WIDTH_CHANGE).all():
+                        self._say("Stopping the iterations: Change in width less than 5%", max_error)
+                        self._nlp_sw_params = sw_old
+                        break
+                inputs = self.get_solver_warm_start_input_parameters(initial_solution)
+                inputs["p"] = self._nlp_sw_params
+                solution = self.nlp_solver(**inputs, **self.nlp_bounds)
+                initial_solution = solution
+                sw_old = copy.deepcopy(self._nlp_sw_params)
+                new_sw, max_error = self.get_segment_width_parameters(initial_solution, options=mpopt_options)
+                self.iter_count += 1
+                if max_error is not None and max_error < min(self.tol_residual):
+                    self.iter_info[self.iter_count] = max_error
+                    self._say(f"Solved to acceptable tolerance {min(self.tol_residual)}", max_error)
+                    break
+                if it == max_iter - 1:
+                    self.iter_info[self.iter_count] = max_error
+                    self._say("Stopping the iterations: Iteration limit exceeded")
+        self._say(f"H-Adaptive Iter., max_residual : {self.iter_count}, {max_error}")
+        self._say(" Optimal cost (J): ", solution["f"], f"\n Solved in {round((time.monotonic() - start) * 1e3, 3)} ms\n")
+        return solution
+
+    def get_segment_width_parameters(self, solution, options={"method": "residual", "sub_method": "merge_split"}):
+        S, P = self.n_segments, self._ocp.n_phases
+        default = [1 / S] * (S * P)
+        if S == 1 or solution is None:
+            return default, None
+        if not hasattr(self, "_nlp_sw_params"):
+            self._nlp_sw_params = default
+        method = options.get("method")
+        if method == "control_slope":
+            return self.compute_seg_width_based_on_input_slope(solution)
+        if method == "residual":
+            return self.compute_seg_width_based_on_residuals(solution, method=options.get("sub_method", "equal_area"))
+        return default, None
+
+    def _phase_max_residual(self, residuals_phase):
+        return max([np.abs(np.asarray(r)).max() if r is not None else 0 for r in residuals_phase])
+
+    def compute_seg_width_based_on_residuals(self, solution, method="merge_split"):
+        S = self.n_segments
+        ti, residuals = self.get_dynamics_residuals(solution)
+        widths, max_error = [], 0
+        for ph in range(self._ocp.n_phases):
+            mx = self._phase_max_residual(residuals[ph])
+            max_error = max(max_error, mx)
+            old = self._nlp_sw_params[S * ph:S * (ph + 1)]
+            if mx < self.tol_residual[ph]:
+                widths.append(old)
+                continue
+            new = self.refine_segment_widths_based_on_residuals(residuals[ph], old, ERR_TOL=self.tol_residual[ph], method=method)
+            if method == "equal_area":  # damped update
+                new = 0.4 * np.array(new) + 0.6 * np.array(old)
+            widths.append(new)
+        return np.concatenate(widths), max_error
+
+    def refine_segment_widths_based_on_residuals(self, residuals, segment_widths, ERR_TOL=1e-3, method="merge_split"):
+        if method == "merge_split":
+            mx = [np.abs(np.asarray(r)).max() if r is not None else 0 for r in residuals]
+            return self.merge_split_segments_based_on_residuals(mx, segment_widths, ERR_TOL=ERR_TOL)
+        if method == "equal_area":
+            r1d = np.concatenate([np.linalg.norm(np.asarray(r), 2, axis=1) if r is not None else [0] for r in residuals])
+            return self.get_roots_wrt_equal_area(r1d, self.n_segments)
+        return segment_widths
+
+    @staticmethod
+    def get_roots_wrt_equal_area(residuals, n_segments):
+        """Segment boundaries that split the area under the residual curve (trapezoids over an equally
+        spaced abscissa) into n_segments equal parts."""
+        r = np.asarray(residuals, float)
+        cum = np.append(0, np.cumsum(0.5 * (r[:-1] + r[1:])))
+        cum = cum / cum[-1]
+        target = (np.arange(n_segments) + 1) / n_segments
+        j = np.array([(cum >= t).argmax() for t in target])
+        pos = (j - 1 + (target - cum[j - 1]) / (cum[j] - cum[j - 1])) / (len(r) - 1)
+        return list(np.diff(np.append(0, pos)))
+
+    @staticmethod
+    def merge_split_segments_based_on_residuals(max_residuals, segment_widths, ERR_TOL=1e-3):
+        """Consecutive segments below the tolerance are merged into one; the segments freed that way are
+        spent on splitting every run above the tolerance evenly."""
+        ok = np.asarray(max_residuals) < ERR_TOL
+        ns = len(segment_widths)
+        starts = np.flatnonzero(np.append(True, ok[1:] != ok[:-1]))  # runs of equal flag
+        ends = np.append(starts[1:], ns)
+        bad_runs = [k for k, s0 in enumerate(starts) if not ok[s0]]
+        if len(starts) == ns or not bad_runs:
+            return segment_widths
+        w = np.asarray(segment_widths, float)
+        run_w = [w[a:b].sum() for a, b in zip(starts, ends)]
+        n_free = ns - len(starts)
+        per_bad = [1 + n_free // len(bad_runs)] * len(bad_runs)
+        per_bad[-1] += n_free % len(bad_runs)
+        out, b = [], 0
+        for k, s0 in enumerate(starts):
+            if ok[s0]:
+                out.append(run_w[k])
+            else:
+                out += [run_w[k] / per_bad[b]] * per_bad[b]
+                b += 1
+        return np.array(out)
+
+    def _node_plan_nodes(self):
+        """Target points = the collocation nodes themselves (node 0 once), so that the kernel's dui
+        equals compD.U of the reference (mpopt.py:2770)."""
+        return [self.collocation._taus_fn(d) if s == 0 else self.collocation._taus_fn(d)[1:] for s, d in enumerate(self.poly_orders)]
+
+    def compute_seg_width_based_on_input_slope(self, solution):
+        S = self.n_segments
+        ti, residuals = self.get_dynamics_residuals(solution)
+        widths, max_error = [], 0.0
+        for ph in range(self._ocp.n_phases):
+            mx = self._phase_max_residual(residuals[ph])
+            max_error = max(max_error, mx)
+            old = self._nlp_sw_params[S * ph:S * (ph + 1)]
+            if mx < self.tol_residual[ph]:
+                widths.append(old)
+                continue
+            plan = self._residual_plan(ph, self._node_plan_nodes())
+            r = plan.eval(np.asarray(solution["x"], float).ravel(), np.asarray(self._nlp_sw_params, float), what=("ti", "dui"))
+            _, _, _, t0, tf, _ = self.get_trajectories(solution, ph)
+            times = self.compute_time_at_max_values(None, r["ti"], np.abs(r["dui"]), threshold=self._THRESHOLD_SLOPE)
+            if len(times) == 0:
+                widths.append(old)
+                continue
+            new = np.clip(self.compute_segment_widths_at_times(times, S, t0, tf), self.lbh[ph], self.ubh[ph])
+            widths.append(new / new.sum())
+        return np.concatenate(widths), max_error
+
+    @staticmethod
+    def compute_time_at_max_values(t_grid, t_orig, du_orig, threshold=0):
+        """Interior node times whose control-slope 2-norm reaches the threshold, ordered by that norm
+        (ascending, stable) -- the reference's ordering, kept as is."""
+        t, nrm = np.asarray(t_orig, float).ravel()[1:-1], np.linalg.norm(np.asarray(du_orig, float), 2, axis=1)[1:-1]
+        keep = nrm >= threshold
+        t, nrm = t[keep], nrm[keep]
+        return t[np.argsort(nrm, kind="stable")] if len(t) else np.array([])
+
+    @staticmethod
+    def compute_segment_widths_at_times(times, n_segments, t0, tf):
+        times = np.asarray(times, float)
+        n_avail = len(times)
+        if n_avail > n_segments - 2:
+            cut = np.sort(times[:n_segments])
+            w = np.concatenate([[cut[0] - t0], np.diff(cut[:n_segments - 1]), [tf - cut[n_segments - 2]]])
+        else:
+            cut = np.sort(times)
+            sw0, sw_end = cut[0] - t0, tf - cut[-1]
+            n_req = n_segments - (n_avail - 1)
+            n_start = 1 if n_req == 2 else 1 + int(sw0 / (sw0 + sw_end) * (n_req - 1))
+            n_end = n_req - n_start
+            w = np.concatenate([[sw0 / n_start] * n_start, np.diff(cut), [sw_end / n_end] * n_end])
+        return np.asarray(w, float) / (tf - t0)
+
+
 def _ref_control_order(U):
     """The reference flattens the control guess node-major (``np.concatenate`` of an (N, nu)
     array, mpopt.py:678-689) although the decision vector is control-major -- identical for

@@ -233,6 +233,54 @@ def make_residuals(name, builder, n_segments, poly_orders, scheme):
     print(f"resid_{name}.npz: {len(out)} arrays ({time.time()-t0:.1f}s)")
 
 
+def make_hadaptive():
+    """h-adaptive refinement: the reference's static helpers on seeded inputs and its
+    width-update rules (mpopt.py:2524-2874) at the golden sample points."""
+    out = {}
+    H = ref.mpopt_h_adaptive
+    rng = np.random.default_rng(11)
+    for k in range(6):
+        n_seg = int(rng.integers(2, 9))
+        res = np.abs(rng.standard_normal(int(rng.integers(n_seg + 3, 60)))) + 1e-3
+        out[f"equal_area/{k}/residuals"], out[f"equal_area/{k}/n"] = res, np.array(n_seg)
+        out[f"equal_area/{k}/widths"] = np.asarray(H.get_roots_wrt_equal_area(res, n_seg), float)
+        mx = np.abs(rng.standard_normal(n_seg)) * 10.0 ** rng.integers(-4, 1, n_seg)
+        w = rng.uniform(0.2, 1.0, n_seg)
+        w /= w.sum()
+        tol = float(10.0 ** rng.integers(-3, 0))
+        out[f"merge_split/{k}/max_res"], out[f"merge_split/{k}/w"], out[f"merge_split/{k}/tol"] = mx, w, np.array(tol)
+        out[f"merge_split/{k}/widths"] = np.asarray(H.merge_split_segments_based_on_residuals(list(mx), list(w), ERR_TOL=tol), float)
+        t_orig = np.sort(rng.uniform(0, 5, 25))
+        du = np.abs(rng.standard_normal((25, int(rng.integers(1, 3)))))
+        thr = float(rng.uniform(0.2, 1.2))
+        times = H.compute_time_at_max_values(None, t_orig, du, threshold=thr)
+        out[f"max_values/{k}/t"], out[f"max_values/{k}/du"], out[f"max_values/{k}/thr"] = t_orig, du, np.array(thr)
+        out[f"max_values/{k}/times"] = np.asarray(times, float)
+        for n_seg2 in (3, 6, 40):
+            tt = np.array(times, float).copy()
+            if len(tt) == 0:
+                continue
+            out[f"widths_at_times/{k}/{n_seg2}"] = np.asarray(H.compute_segment_widths_at_times(tt, n_seg2, 0.0, 5.0), float)
+    for name in ["hyper_sensitive_5x3_LGR", "moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL", "schwartz_4x3_LGL"]:
+        builder, S, po, scheme = problems.GOLDEN_CASES[name]
+        G = np.load(os.path.join(HERE, f"nlp_{name}.npz"))
+        for method, sub in (("residual", "equal_area"), ("residual", "merge_split"), ("control_slope", None)):
+            ref.CollocationRoots._TAU_MIN, ref.CollocationRoots._TAU_MAX = -1, 1
+            ref.Collocation.D_MATRIX_METHOD = "numerical"
+            mpo = ref.mpopt_h_adaptive(builder(ref, casadi_shim), S, po, scheme)
+            mpo.create_nlp()
+            mpo._nlp_sw_params = list(G["p"])
+            mpo.tol_residual = [1e-3] * mpo._ocp.n_phases
+            opts = {"method": method}
+            if sub:
+                opts["sub_method"] = sub
+            w, err = mpo.get_segment_width_parameters({"x": G["z"]}, options=opts)
+            out[f"update/{name}/{method}/{sub}/widths"] = np.asarray(w, float)
+            out[f"update/{name}/{method}/{sub}/max_error"] = np.array(float(err))
+    np.savez_compressed(os.path.join(HERE, "hadaptive.npz"), **out)
+    print(f"hadaptive.npz: {len(out)} arrays")
+
+
 def main():
     only = sys.argv[1:]
     if not only or "tables" in only:
@@ -240,9 +288,11 @@ def main():
     for name, (builder, s, po, scheme) in problems.GOLDEN_CASES.items():
         if only and name not in only:
             continue
-        if only == ["residuals"]:
+        if only in (["residuals"], ["hadaptive"]):
             continue
         make_case(name, builder, s, po, scheme)
+    if not only or "hadaptive" in only:
+        make_hadaptive()
     for name in RESIDUAL_CASES:
         if only and ("resid_" + name) not in only and "residuals" not in only:
             continue
