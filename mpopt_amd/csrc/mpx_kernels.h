@@ -28,6 +28,10 @@
 
 #include "mpx_device.h"
 
+#ifndef MPX_TABLES_IN_LDS_ABOVE
+#define MPX_TABLES_IN_LDS_ABOVE 12  // degrees above this keep the D / mid-point tables in LDS
+#endif
+
 namespace mpxk {
 
 template <int N>
@@ -56,7 +60,7 @@ typedef double mpx_d2 __attribute__((ext_vector_type(2)));
 // Addressing: uniform base (SGPRs) + ONE running 32-bit byte offset per lane.  The offsets are loop
 // invariant across the batch loop; the empty asm stops the compiler from hoisting one 64-bit address
 // pair per slot out of it (that cost 90+ VGPRs and more than halved the occupancy).
-template <int NS, class F>
+template <int NS, int FENCE = 0, class F>
 __device__ __forceinline__ void scatter_slots(double* __restrict__ blk, int64_t n, int l, bool own, bool vec, F sv) {
   if (!own) return;
   char* __restrict__ base = reinterpret_cast<char*>(blk);
@@ -75,6 +79,9 @@ __device__ __forceinline__ void scatter_slots(double* __restrict__ blk, int64_t 
       *reinterpret_cast<double*>(base + off + 8u) = sv(q + 1);
     }
     off += 2u * nb;
+    // FENCE > 0 (tables in LDS): keep the compiler from hoisting every table read of the block above
+    // the first store -- that alone held ~60 VGPRs live at degree 30
+    if (FENCE > 0 && (q / 2) % FENCE == FENCE - 1) __builtin_amdgcn_sched_barrier(0);
   }
   if (NS & 1) {
     uint32_t o1 = (uint32_t)(NS - 1) * nb + (uint32_t)l * 8u;
@@ -119,13 +126,36 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   const bool vec = (T.jac_base & 1) == 0, vech = (T.hess_base & 1) == 0;
 #endif
 
-  // per-lane rows of D and of the mid-point interpolation matrix, resident for the batch loop
-  double Drow[P1], Crow[P1];
+  // The lane's row of D and of the mid-point interpolation matrix, resident for the batch loop:
+  // in VGPRs for low degrees; for high degrees (2*(P+1) doubles per lane would cost > 100 VGPRs and
+  // halve the occupancy) the two tables are staged once per workgroup in LDS and read per use.  Rows of
+  // different points are 2*(P+1) dwords apart: for odd P+1 the b64 reads of a wavefront hit distinct
+  // banks, equal points broadcast.
+  constexpr bool TAB_LDS = (P > MPX_TABLES_IN_LDS_ABOVE);
+  constexpr int NREG = TAB_LDS ? 1 : P1;
+  __shared__ double sD[TAB_LDS ? P1 * P1 : 1];
+  __shared__ double sC[TAB_LDS ? P * P1 : 1];
+  double Drow_[NREG], Crow_[NREG];
+  const int drow = k * P1, crow = (k >= 1 ? k - 1 : 0) * P1;
+  if constexpr (TAB_LDS) {
+    for (int e = l; e < P1 * P1; e += MPX_TILE) sD[e] = A.Dmat[e];
+    for (int e = l; e < P * P1; e += MPX_TILE) sC[e] = A.Cmid[e];
+    __syncthreads();
+  } else {
 #pragma unroll
-  for (int j = 0; j < P1; ++j) {
-    Drow[j] = A.Dmat[k * P1 + j];
-    Crow[j] = (k >= 1) ? A.Cmid[(k - 1) * P1 + j] : 0.0;
+    for (int j = 0; j < P1; ++j) {
+      Drow_[j] = A.Dmat[drow + j];
+      Crow_[j] = (k >= 1) ? A.Cmid[crow + j] : 0.0;
+    }
   }
+  auto Drow = [&](int j) -> double {
+    if constexpr (TAB_LDS) return sD[drow + j];
+    else return Drow_[j];
+  };
+  auto Crow = [&](int j) -> double {
+    if constexpr (TAB_LDS) return sC[crow + j];
+    else return Crow_[j];
+  };
   const double tkk = A.tk[k];
   const double Wn = A.Wnode[i];
 
@@ -190,7 +220,9 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
       }
     }
     if (b + 1 < b1) load_point(b + 1, nxt);
+#ifndef MPX_ABL_NO_BARRIER
     __syncthreads();
+#endif
     if (it > 0 && l < NRED) {  // publish the previous point's tile sums
       double v = 0;
 #pragma unroll
@@ -221,13 +253,17 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
       } else {
         G::fg(Xs, Us, t0v, tfv, As, kap, th, Wn, fx, cc, red[0]);
       }
+#ifdef MPX_ABL_NO_G
+      if (false) {
+#else
       if (own && io.g) {
+#endif
         double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
 #pragma unroll
         for (int a = 0; a < NX; ++a) {  // defect  F = D.X - h*Sx*dyn      (mpopt.py:227-232)
           double acc = 0;
 #pragma unroll
-          for (int j = 0; j < P1; ++j) acc = fma(Drow[j], sXU[buf][a][base + j], acc);
+          for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][a][base + j], acc);
           (gb + (A.g_off_F + (int64_t)a * N))[i] = acc - fx[a];
         }
 #pragma unroll
@@ -237,7 +273,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
           for (int c = 0; c < NU; ++c) {
             double acc = 0;
 #pragma unroll
-            for (int j = 0; j < P1; ++j) acc = fma(Drow[j], sXU[buf][NX + c][base + j], acc);
+            for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][NX + c][base + j], acc);
             (gb + (A.g_off_DU + (int64_t)c * N))[i] = acc;
           }
         }
@@ -247,19 +283,27 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
             for (int c = 0; c < NU; ++c) {
               double acc = 0;
 #pragma unroll
-              for (int j = 0; j < P1; ++j) acc = fma(Crow[j], sXU[buf][NX + c][base + j], acc);
+              for (int j = 0; j < P1; ++j) acc = fma(Crow(j), sXU[buf][NX + c][base + j], acc);
               (gb + (A.g_off_mU + (int64_t)c * (N - 1)))[i - 1] = acc;
             }
           }
         }
       }
       if constexpr (MODE == MPX_MODE_FGJ) {
+#ifdef MPX_ABL_NO_G
+        if (false) {
+#else
         if (own && io.grad) {
+#endif
           double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
 #pragma unroll
           for (int a = 0; a < NX + NU; ++a) (qb + (int64_t)a * N)[i] = gn[a];
         }
+#ifdef MPX_ABL_NO_JAC
+        if (false) {
+#else
         if (io.jac) {
+#endif
           double* __restrict__ jb = io.jac + (int64_t)b * io.jac_stride + T.jac_base;
           // slot q -> value, evaluated lazily (q is a compile-time constant after unrolling).  The
           // table rows are loop invariant; the empty asm keeps the compiler from hoisting every
@@ -272,31 +316,33 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
           auto sv = [&](int q) -> double {
             if (q < NX * P1) {
               const int a = q / P1, j = q % P1;
-              const double d = opaque(Drow[j]);
+              const double d = opaque(Drow(j));
               return (j == k) ? d - dd[a] : d;
             }
             q -= NX * P1;
             if (q < G::NJV) return jv[q];
             q -= G::NJV;
             if (G::DIFF_U) {
-              if (q < NU * P1) return opaque(Drow[q % P1]);
+              if (q < NU * P1) return opaque(Drow(q % P1));
               q -= NU * P1;
             }
-            return opaque(Crow[q % P1]);
+            return opaque(Crow(q % P1));
           };
           if (T.node0)  // node 0 owns no mid-point row: its block ends after the main slots
-            scatter_slots<NS_MAIN>(jb, n, l, own, false, sv);
+            scatter_slots<NS_MAIN, TAB_LDS ? 4 : 0>(jb, n, l, own, false, sv);
           else
-            scatter_slots<NS_MAIN + NS_MID>(jb, n, l, own, vec, sv);
+            scatter_slots<NS_MAIN + NS_MID, TAB_LDS ? 4 : 0>(jb, n, l, own, vec, sv);
         }
       }
     }
     // tile sums
+#ifndef MPX_ABL_NO_RED
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
       double v = wave_sum(own ? red[r] : 0.0);
       if (lane == 0) sRed[buf][wave][r] = v;
     }
+#endif
     cur = nxt;
   }
   __syncthreads();

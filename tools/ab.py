@@ -14,8 +14,12 @@ dev = torch.device("cuda:0")
 objs = []
 for v in variants:
     os.environ["MPX_HIPCC_FLAGS"] = v
-    ocp = problems.moon_lander(mp, M.math)
-    mpo = mp.mpopt(ocp, S, P, "LGR")
+    if "CASE" in os.environ:
+        builder, S, P, scheme = problems.BENCH_CASES[int(os.environ["CASE"])]
+    else:
+        builder, scheme = problems.moon_lander, "LGR"
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, P, scheme)
     nlp, _ = mpo.create_nlp()
     objs.append(nlp["oracle"])
 o = objs[0]
