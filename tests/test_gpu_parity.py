@@ -225,3 +225,27 @@ def test_segment_sharding_is_bit_identical(case, world):
     assert np.array_equal(f.cpu().numpy(), ref["f"])
     for k in total:
         assert np.array_equal(total[k].cpu().numpy(), ref[k]), k
+
+
+def test_edge_cases_default_ocp_and_extreme_grids():
+    """Reference defaults (mpopt.py:3426-3439): zero dynamics, no path/terminal rows, zero costs -> every
+    variable Jacobian/Hessian list is empty; plus degree-1 and a high-degree single segment."""
+    for nx, nu, S, po, scheme in [(1, 1, 3, 2, "LGR"), (3, 2, 1, [1], "LGL"), (2, 1, 2, [1, 1], "CGL"), (1, 1, 1, [60], "LGL")]:
+        ocp = mp.OCP(n_states=nx, n_controls=nu)
+        ocp.validate()
+        mpo = mp.mpopt(ocp, S, po, scheme)
+        nlp, bounds = mpo.create_nlp()
+        o = nlp["oracle"]
+        O = OracleNLP(ocp, S, po, scheme)
+        assert (o.n_z, o.n_g) == (O.n_z, O.n_g)
+        rng = np.random.default_rng(9)
+        z = rng.standard_normal(o.n_z)
+        w = rng.uniform(0.5, 1.5, S)
+        p = w / w.sum()
+        lam = rng.standard_normal(o.n_g)
+        r = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], z, p, lam_g=lam, sigma=1.3)
+        assert r["f"] == 0.0 and np.abs(r["grad_f"]).max() == 0.0 and o.nnz_hess == 0
+        assert rel_err(r["g"], O.g(z, p)) < TOL
+        jr, jc = o.jac_pattern()
+        J = sp.coo_matrix((r["jac_g"], (jr, jc)), shape=(o.n_g, o.n_z)).toarray()
+        assert rel_err(J, O.jac_g(z, p).toarray()) < TOL
