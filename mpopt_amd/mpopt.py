@@ -654,6 +654,54 @@ class mpopt:
                 residuals[phase] = [None if r is None else r / mx for r in residuals[phase]]
         return ti, residuals
 
+    # ---- post-solve: states re-integrated from the dynamics (mpopt.py:989-1150) -------------------
+    def compute_states_from_solution_dynamics(self, solution, phase=0, nodes=None):
+        """(xint_phase, u_phase, ti_phase, residual_phase) per segment: the states obtained by
+        integrating h_s*Sx*dyn over [tau0, tau_i] with the interpolatory quadrature on the target points
+        themselves, and the difference to the interpolated states.  Interpolation and dynamics come from
+        the GPU kernel (xi, ui, ti, dyn); the remaining per-segment n_s x n_s quadrature product is host
+        arithmetic."""
+        target = self.get_residual_grid_taus(phase=phase, grid_type=self.grid_type[phase]) if nodes is None else nodes
+        plan = self._residual_plan(phase, target)
+        z = np.asarray(solution["x"], float).ravel()
+        r = plan.eval(z, np.asarray(self._nlp_sw_params, float), what=("ti", "xi", "ui", "dyn"))
+        o, N = self._ocp, self._Npoints
+        X = z[phase * (N * (o.nx + o.nu) + 2 + o.na):][:o.nx * N].reshape(o.nx, N).T  # scaled states at the nodes
+        starts = np.concatenate([[0], np.cumsum(self.poly_orders)])
+        S = self.n_segments
+        xint, res, uph, tph = [None] * S, [None] * S, [None] * S, [None] * S
+        L = _lib.lib()
+        for s in range(S):
+            a, b = plan.seg_ptr[s], plan.seg_ptr[s + 1]
+            if a == b:
+                continue
+            taus = np.ascontiguousarray(target[s], dtype=float)
+            n = len(taus)
+            Q = np.empty((n, n))  # Q[i, j] = int_{tau0}^{tau_i} l_j, Lagrange basis on the target points
+            w = np.empty(n)
+            for i in range(n):
+                _lib.check(L.mpx_colloc_quad_weights(_lib.dptr(taus), n, float(self.tau0), float(taus[i]), _lib.dptr(w)))
+                Q[i] = w
+            xint[s] = X[starts[s]][None, :] + Q @ r["dyn"][a:b]
+            res[s] = list(r["xi"][a:b] - xint[s])
+            uph[s] = (r["ui"][a:b] if o.nu else np.zeros((n, 0))).reshape(n, 1, o.nu)
+            tph[s] = r["ti"][a:b]
+        return xint, uph, tph, res
+
+    def get_states_residuals(self, solution, phases=None, nodes=None, residual_type=None, plot=False, fig=None, axs=None):
+        P = self._ocp.n_phases
+        x_int, u_int, residuals, ti = [None] * P, [None] * P, [None] * P, [None] * P
+        for phase in (range(P) if phases is None else phases):
+            target = self.get_residual_grid_taus(phase, grid_type=self.grid_type[phase]) if nodes is None else nodes[phase]
+            x_int[phase], u_int[phase], ti[phase], residuals[phase] = self.compute_states_from_solution_dynamics(solution, phase, nodes=target)
+            if residual_type == "relative":
+                mx = np.zeros(self._ocp.nx)
+                for seg in x_int[phase]:
+                    if seg is not None:
+                        mx = np.maximum(mx, np.abs(np.asarray(seg)).max(axis=0))
+                residuals[phase] = [None if r_ is None else np.asarray(r_) / mx for r_ in residuals[phase]]
+        return x_int, u_int, ti, residuals
+
     def process_results(self, solution, plot=False, **kwargs):
         return post_process(self, solution)
 

@@ -347,7 +347,20 @@ class OracleNLP:
                 f = dyn(Xi[idx] / self.sx, Ui[idx] / self.su, ti[idx], A / self.sa)
                 F[idx] = h_seg * (np.array([float(v) for v in f]) * self.sx)
                 idx += 1
-        return dict(ti=ti, xi=Xi, ui=Ui, dxi=DXi, dui=DUi, dyn=F, resid=DXi - F)
+        # states re-integrated from the dynamics (compute_states_from_solution_dynamics, mpopt.py:1030-1066):
+        # quadrature weights over [tau0, tau_i] of the Lagrange basis on the target points of the segment
+        xint = np.zeros_like(Xi)
+        idx = 0
+        for s in range(self.S):
+            n = len(taus[s])
+            if n == 0:
+                continue
+            xstart = X[G.start[s]]
+            for i in range(n):
+                q = exact_tables(taus[s], None, "w", G.tau0, taus[s][i]) if n > 11 else quad_weights(taus[s], G.tau0, taus[s][i])
+                xint[idx + i] = xstart + q @ F[idx:idx + n]
+            idx += n
+        return dict(ti=ti, xi=Xi, ui=Ui, dxi=DXi, dui=DUi, dyn=F, resid=DXi - F, xint=xint, xres=Xi - xint)
 
     # -- bounds and initial guess ---------------------------------------------------------------
     def bounds(self):

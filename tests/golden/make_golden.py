@@ -229,6 +229,11 @@ def make_residuals(name, builder, n_segments, poly_orders, scheme):
             out[key + "/resid"] = np.concatenate([np.asarray(r, float) for r in res if r is not None]) if any(r is not None for r in res) else np.zeros((0, ocp.nx))
             out[key + "/dyn"] = np.concatenate([np.asarray(r, float) for r in dyn if r is not None]) if any(r is not None for r in dyn) else np.zeros((0, ocp.nx))
             out[key + "/ti_seg"] = np.concatenate([np.asarray(t, float).ravel() for t in tis]) if len(tis) else np.zeros(0)
+            # state-integral residuals (mpopt.py:989-1076)
+            xint, uph, tph, rph = mpo.compute_states_from_solution_dynamics(sol, ph, nodes=nodes)
+            cat = lambda L, w: np.concatenate([np.asarray(v, float).reshape(-1, w) for v in L if v is not None]) if any(v is not None for v in L) else np.zeros((0, w))
+            out[key + "/xint"] = cat(xint, ocp.nx)
+            out[key + "/xres"] = cat(rph, ocp.nx)
     np.savez_compressed(os.path.join(HERE, f"resid_{name}.npz"), **out)
     print(f"resid_{name}.npz: {len(out)} arrays ({time.time()-t0:.1f}s)")
 

@@ -33,10 +33,13 @@ def test_oracle_residuals_match_reference(name):
     for ph in range(ocp.n_phases):
         for gt in GRIDS:
             r = O.residuals(G["z"], G["p"], ph, _grid(R, ph, gt))
-            for k in FIELDS:
+            for k in FIELDS + ["xint", "xres"]:
                 ref = R[f"ph{ph}/{gt}/{k}"]
                 assert r[k].shape == ref.shape or r[k].size == ref.size == 0, (k, r[k].shape, ref.shape)
-                assert rel_err(r[k].ravel(), ref.ravel()) < 1e-12, (ph, gt, k)
+                # the quadrature on ~17 equally spaced points (spectral/fixed grids) is ill-conditioned in
+                # the reference's monomial arithmetic: compare those to 1e-7, everything else to 1e-12
+                tol = 1e-7 if k in ("xint", "xres") else 1e-12
+                assert rel_err(r[k].ravel(), ref.ravel()) < tol, (ph, gt, k)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -83,6 +86,13 @@ def test_gpu_residuals_match_reference(name):
             Xi, Ui, ti, a, DXi, DUi, tg, t0, tf = mpo.interpolate_single_phase(sol, phase=ph, target_nodes=nodes)
             assert rel_err(Xi.full(), R[f"ph{ph}/{gt}/xi"]) < TOL and rel_err(DXi.full(), R[f"ph{ph}/{gt}/dxi"]) < TOL
             assert rel_err(np.array([t0[0], tf[0]]), R[f"ph{ph}/{gt}/t0tf"]) < 1e-14
+            # state-integral residuals (rank 4)
+            xint, uph, tph, xres = mpo.compute_states_from_solution_dynamics(sol, ph, nodes=nodes)
+            if R[f"ph{ph}/{gt}/xint"].size:
+                cx = np.concatenate([v for v in xint if v is not None])
+                cr = np.concatenate([np.asarray(v) for v in xres if v is not None])
+                assert rel_err(cx, R[f"ph{ph}/{gt}/xint"]) < 1e-7, (ph, gt)
+                assert np.abs(cr - R[f"ph{ph}/{gt}/xres"]).max() < 1e-7 * max(1.0, np.abs(R[f"ph{ph}/{gt}/xint"]).max()), (ph, gt)
             tis, res, dyn = mpo.get_dynamics_residuals_single_phase(sol, ph, target_nodes=nodes)
             assert len(res) == mpo.n_segments and all((r_ is None) == (len(n_) == 0) for r_, n_ in zip(res, nodes))
             cat = np.concatenate([r_ for r_ in res if r_ is not None]) if any(r_ is not None for r_ in res) else np.zeros((0, ocp.nx))
