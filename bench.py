@@ -61,10 +61,17 @@ def main():
     from mpopt_amd import distributed as mpd
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    rank, world, local_rank = mpd.init_from_env("nccl")  # nccl == RCCL on ROCm
+    # nccl == RCCL on ROCm.  MPX_DIST_BACKEND=gloo lets several ranks share one GPU (smoke test of the
+    # multi-rank code path on a 1-GPU box); the device is then local_rank modulo the visible GPUs.
+    backend = os.environ.get("MPX_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl":
+        assert int(os.environ.get("LOCAL_RANK", "0")) < n_dev, "one process per GPU: LOCAL_RANK exceeds the visible GPUs"
+    rank, world, local_rank = mpd.init_from_env(backend)
     if world > 1:
         import torch.distributed as dist
-    dev = torch.device("cuda", local_rank)
+    dev_id = local_rank % n_dev
+    dev = torch.device("cuda", dev_id)
     torch.cuda.set_device(dev)
 
     import mpopt_amd as M
@@ -83,7 +90,7 @@ def main():
         B = min(B, 512)
         label = "Van der Pol OCP, n_segments=2000, poly_orders=[3,30,3]*, CGL (BASELINE configs[2])"
     ocp = builder(mp, M.math)
-    mpo = mp.mpopt(ocp, S, P, scheme)
+    mpo = mp.mpopt(ocp, S, P, scheme, device=dev_id)
     if rank == 0 or world == 1:
         nlp, bounds = mpo.create_nlp()  # rank 0 compiles (or finds the cached code object) first
     if world > 1:
@@ -91,9 +98,6 @@ def main():
         if rank != 0:
             nlp, bounds = mpo.create_nlp()
     o = nlp["oracle"]
-    if local_rank != 0:  # contexts are created on device 0 by default; re-create on this rank's GPU
-        o.close()
-        o = M.NlpFunctions(ocp, S, mpo.poly_orders, scheme, device=local_rank)
     o.set_stream(torch.cuda.current_stream().cuda_stream)
 
     Zh = make_points(o, mpo, bounds, B, 20260928 + rank)
@@ -141,7 +145,7 @@ def main():
     elapsed = time.perf_counter() - t0
     node_ms, n_launch = o.profile_read()
     o.profile(False)
-    elapsed = mpd.max_over_ranks(elapsed, device=dev)
+    elapsed = mpd.max_over_ranks(elapsed, device=dev if backend == "nccl" else None)
 
     # sanity: the timed outputs are real (finite, and f matches a host recomputation of one point)
     assert torch.isfinite(jv[0]).all() and (hess_mode or torch.isfinite(g[-1]).all())

@@ -364,9 +364,11 @@ class mpopt:
     _GRID_TYPE = "fixed"
     _MAX_GRID_POINTS = 15
     _MUTE_ = False
+    _DEVICE = 0  # HIP device ordinal of the libmpx context (one process per GPU: set to LOCAL_RANK)
 
     def __init__(self, problem, n_segments=1, poly_orders=[9], scheme="LGR", **kwargs):
         self.n_segments = n_segments
+        self.device = kwargs.get("device", self._DEVICE)
         self.poly_orders = [poly_orders] * n_segments if isinstance(poly_orders, (int, np.integer)) else list(poly_orders)
         self._ocp = copy.deepcopy(problem)
         self.colloc_scheme = scheme
@@ -462,7 +464,8 @@ class mpopt:
         self.compute_numerical_approximation()
         self.create_variables()
         self.oracle = NlpFunctions(o, self.n_segments, self.poly_orders, self.colloc_scheme, tau0=self.tau0,
-                                   tau1=self.tau1, midu_rows=[self._midu_rows(ph) for ph in range(o.n_phases)])
+                                   tau1=self.tau1, midu_rows=[self._midu_rows(ph) for ph in range(o.n_phases)],
+                                   device=self.device)
         zmin, zmax, gmin, gmax = [], [], [], []
         for ph in range(o.n_phases):
             _, a, b = self.get_nlp_variables(ph)
