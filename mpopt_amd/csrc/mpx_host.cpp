@@ -101,6 +101,10 @@ struct mpx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t tile_begin = 0, tile_end = 0;
   int run_boundary = 1;
+  // host path: widths of the previous mpx_eval (IPOPT never changes p between oracle calls, so the
+  // upload and the prefix-sum launch are skipped while p is unchanged)
+  std::vector<double> last_p;
+  bool wcum_valid = false;
   // per-kernel profiling
   int profile = 0;
   std::vector<hipEvent_t> prof_ev;  // pairs
@@ -1025,6 +1029,7 @@ extern "C" int mpx_resid_eval_device(mpx_ctx* c, mpx_resid_plan* P, int64_t batc
   const int64_t n_w = p_per_point ? batch : 1;
   int rc;
   if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
+  c->wcum_valid = false;
   hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(256), 0, c->stream, p, c->wcum.p, c->S);
   HIPCHK(c, hipGetLastError());
   const PhaseStruct& Ph = c->ph[P->phase];
@@ -1087,9 +1092,18 @@ extern "C" int mpx_resid_eval(mpx_ctx* c, mpx_resid_plan* P, int64_t batch, cons
   return MPX_OK;
 }
 
+static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                     const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix);
+
 extern "C" int mpx_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point,
                                const double* lam_g, const double* sigma, double* f, double* g, double* grad_f,
                                double* jac_val, double* hess_val) {
+  if (c) c->wcum_valid = false;  // caller-owned device widths: cannot be compared cheaply
+  return eval_core(c, mask, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val, false);
+}
+
+static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                     const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix) {
   if (!c) return MPX_ERR_INVALID;
   if (!c->has_device)
     return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
@@ -1104,7 +1118,7 @@ extern "C" int mpx_eval_device(mpx_ctx* c, int mask, int64_t batch, const double
   int rc;
   if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
   if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
-  {
+  if (!skip_prefix) {
     hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(256), 0, c->stream, p, c->wcum.p, c->S);
     HIPCHK(c, hipGetLastError());
   }
@@ -1154,9 +1168,15 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   int rc;
   const size_t B = (size_t)batch;
   const size_t npv = (size_t)(p_per_point ? batch : 1) * c->n_p;
-  if ((rc = reserve(c, c->st_z, B * c->n_z)) || (rc = reserve(c, c->st_p, npv))) return rc;
+  const size_t cap_p = c->st_p.cap, cap_w = c->wcum.cap;
+  if ((rc = reserve(c, c->st_z, B * c->n_z)) || (rc = reserve(c, c->st_p, npv)) || (rc = reserve(c, c->wcum, npv))) return rc;
+  const bool same_p = c->wcum_valid && cap_p == c->st_p.cap && cap_w == c->wcum.cap && c->last_p.size() == npv &&
+                      memcmp(c->last_p.data(), p, npv * 8) == 0;
   HIPCHK(c, hipMemcpyAsync(c->st_z.p, z, B * c->n_z * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->st_p.p, p, npv * 8, hipMemcpyHostToDevice, c->stream));
+  if (!same_p) {
+    HIPCHK(c, hipMemcpyAsync(c->st_p.p, p, npv * 8, hipMemcpyHostToDevice, c->stream));
+    c->last_p.assign(p, p + npv);
+  }
   if (mask & MPX_HESS) {
     if (!lam_g || !sigma || !hess_val) return fail(c, MPX_ERR_INVALID, "mpx_eval: HESS needs lam_g, sigma, hess_val");
     if ((rc = reserve(c, c->st_lam, B * c->n_g)) || (rc = reserve(c, c->st_sig, B)) || (rc = reserve(c, c->st_hess, B * std::max<int64_t>(c->nnz_h, 1))))
@@ -1168,9 +1188,13 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   if ((mask & MPX_G) && (rc = reserve(c, c->st_g, B * c->n_g))) return rc;
   if ((mask & MPX_GRAD) && (rc = reserve(c, c->st_grad, B * c->n_z))) return rc;
   if ((mask & MPX_JAC) && (rc = reserve(c, c->st_jac, B * std::max<int64_t>(c->nnz_j, 1)))) return rc;
-  rc = mpx_eval_device(c, mask, batch, c->st_z.p, c->st_p.p, p_per_point, c->st_lam.p, c->st_sig.p, c->st_f.p, c->st_g.p,
-                       c->st_grad.p, c->st_jac.p, c->st_hess.p);
-  if (rc) return rc;
+  rc = eval_core(c, mask, batch, c->st_z.p, c->st_p.p, p_per_point, c->st_lam.p, c->st_sig.p, c->st_f.p, c->st_g.p, c->st_grad.p,
+                 c->st_jac.p, c->st_hess.p, same_p);
+  if (rc) {
+    c->wcum_valid = false;
+    return rc;
+  }
+  c->wcum_valid = true;
   if (mask & MPX_F) HIPCHK(c, hipMemcpyAsync(f, c->st_f.p, B * 8, hipMemcpyDeviceToHost, c->stream));
   if (mask & MPX_G) HIPCHK(c, hipMemcpyAsync(g, c->st_g.p, B * c->n_g * 8, hipMemcpyDeviceToHost, c->stream));
   if (mask & MPX_GRAD) HIPCHK(c, hipMemcpyAsync(grad_f, c->st_grad.p, B * c->n_z * 8, hipMemcpyDeviceToHost, c->stream));

@@ -119,3 +119,30 @@ def test_casadi_external_entry_points(name):
     call("nlp_hess_l", [z, p, None, None], [hv])
     assert np.abs(hv).max() == 0.0
     o.close()
+
+
+def test_width_cache_on_host_path():
+    """mpx_eval skips the width upload + prefix kernel while p is unchanged (IPOPT's call pattern); a
+    changed p, a changed batch size, interleaved residual/device calls must all invalidate correctly."""
+    name = "kitchen_sink_mixed_CGL"
+    G = load_golden(name)
+    ocp, mpo, o = build_case(name, with_device=True)
+    ocp2, mpo2, fresh = build_case(name, with_device=True)
+    z, p1 = G["z"], G["p"]
+    p2 = np.asarray(mpo.get_segment_width_parameters(None))
+    what = ["f", "g", "jac_g"]
+
+    def same(a, b):
+        return all(np.array_equal(a[k], b[k]) for k in what)
+
+    seq = [p1, p1, p2, p2, p1, p1]
+    for k, p in enumerate(seq):
+        r = o.eval(what, z, p)
+        ref = fresh.eval(what, z * 1.0, p.copy())  # `fresh` alternates p every other call as well
+        assert same(r, ref), k
+        if k == 2:  # a residual evaluation in between recomputes the prefix sums with other widths
+            plan = o.residual_plan(0, mpo.__class__.get_residual_grid_taus.__get__(mpo)(0, "mid-points") if hasattr(mpo, "collocation") else None)
+            plan.eval(z, p1)
+    rb = o.eval(what, np.stack([z, z]), p1)  # batch size change
+    assert np.array_equal(rb["g"][0], o.eval(what, z, p1)["g"])
+    assert rel_err(o.eval(what, z, p1)["g"], G["g"]) < TOL
