@@ -132,11 +132,33 @@ class OCP:
 
 
 # ---------------------------------------------------------------------------------------------
+class _Size(int):
+    """ndarray.size stays an int, but is also callable like CasADi's ``DM.size()`` -> (rows, cols)."""
+
+    def __new__(cls, n, shape):
+        obj = int.__new__(cls, n)
+        obj._shape = tuple(shape)
+        return obj
+
+    def __call__(self):
+        return self._shape
+
+
 class _Mat(np.ndarray):
-    """ndarray with CasADi-DM's ``full()`` so callers written against the reference keep working."""
+    """ndarray with CasADi-DM's ``full()`` / ``size()`` so callers written against the reference keep working."""
 
     def full(self):
         return np.asarray(self)
+
+    @property
+    def size(self):
+        return _Size(int(np.prod(self.shape)), self.shape if self.ndim == 2 else (int(np.prod(self.shape)), 1))
+
+    def size1(self):
+        return self.shape[0]
+
+    def size2(self):
+        return self.shape[1] if self.ndim > 1 else 1
 
 
 def _mat(a):
@@ -354,6 +376,10 @@ class _NlpSymbol:
     def size1(self):
         return self.size
 
+    @property
+    def shape(self):
+        return (self.size, 1)
+
     def __repr__(self):
         return f"<{self.name}[{self.size}] of {self.oracle.__class__.__name__}>"
 
@@ -400,9 +426,34 @@ class mpopt:
         return self.collocation.get_composite_quadrature_weights()
 
     def create_variables(self):
-        o = self._ocp
-        self._optimization_vars_per_phase = self._Npoints * (o.nx + o.nu) + o.n_phases * o.na + 2
+        """The reference creates CasADi symbols here (mpopt.py:105-152); the handles below only keep the
+        attribute names alive.  ``_optimization_vars_per_phase`` reproduces the reference's formula
+        (``n_phases * na``, mpopt.py:130-134) although the vector holds ``na`` parameters per phase."""
+        o, N = self._ocp, self._Npoints
+        self._optimization_vars_per_phase = N * (o.nx + o.nu) + o.n_phases * o.na + 2
+        self.X = [_NlpSymbol(f"X{ph}", N * o.nx, None) for ph in range(o.n_phases)]
+        self.U = [_NlpSymbol(f"U{ph}", N * o.nu, None) for ph in range(o.n_phases)]
+        self.A = _NlpSymbol("A", o.na * o.n_phases, None)
+        self.t0, self.tf = _NlpSymbol("t0", o.n_phases, None), _NlpSymbol("tf", o.n_phases, None)
+        self.seg_widths = _NlpSymbol("h_seg", self.n_segments * o.n_phases, None)
         self._variables_created = True
+
+    def validate(self):
+        """Consistency checks of the reference's ``mpopt.validate`` (mpopt.py:983-987): grid definition."""
+        assert len(self.poly_orders) == self.n_segments and self.n_segments > 0
+        assert all(int(p) == p and p >= 1 for p in self.poly_orders)
+        assert self._Npoints == sum(self.poly_orders) + 1
+        self._ocp.validate()
+
+    def discretize_phase(self, phase):
+        """(G, Gmin, Gmax, J) of one phase: handles with ``.shape`` for G and J, bound arrays as in the
+        reference (mpopt.py:415-462)."""
+        if self.oracle is None:
+            self.create_nlp()
+        lo, hi = self._phase_row_bounds(phase)
+        J = _NlpSymbol(f"J{phase}", 1, self.oracle)
+        J.__class__ = type("_Scalar", (_NlpSymbol,), {"shape": property(lambda self_: (1, 1))})
+        return (_NlpSymbol(f"G{phase}", len(lo), self.oracle), lo, hi, J)
 
     # ---- bounds -------------------------------------------------------------------------
     def _midu_rows(self, phase):
@@ -932,12 +983,23 @@ class post_process:
     def __init__(self, mpo, solution):
         self.mpo, self.solution = mpo, solution
 
+    _INTERPOLATION_NODES_PER_SEG = 50
+
     def get_data(self, phases=None, interpolate=False):
-        phases = range(self.mpo._ocp.n_phases) if phases is None else phases
+        """(x, u, t, a) unscaled, phases stacked; ``interpolate=True`` evaluates the collocation polynomials
+        at ``_INTERPOLATION_NODES_PER_SEG`` equally spaced points of every segment (GPU kernel mpx_resid_*)."""
+        mpo, o = self.mpo, self.mpo._ocp
+        phases = range(o.n_phases) if phases is None else phases
         xs, us, ts = [], [], []
         for ph in phases:
-            X, U, t, *_ = self.mpo.get_trajectories(self.solution, ph)
-            xs.append(X), us.append(U), ts.append(t.reshape(-1, 1))
+            if not interpolate:
+                X, U, t, *_ = mpo.get_trajectories(self.solution, ph)
+            else:
+                n = self._INTERPOLATION_NODES_PER_SEG
+                taus = [np.linspace(mpo.tau0, mpo.tau1, n + 1)[(0 if s == 0 else 1):] for s in range(mpo.n_segments)]
+                Xi, Ui, ti, *_ = mpo.interpolate_single_phase(self.solution, phase=ph, target_nodes=taus)
+                X, U, t = Xi.full() / np.asarray(o.scale_x, float), Ui.full() / np.asarray(o.scale_u, float), ti.full().ravel()
+            xs.append(X), us.append(U), ts.append(np.asarray(t).reshape(-1, 1))
         return np.concatenate(xs), np.concatenate(us), np.concatenate(ts), None
 
 

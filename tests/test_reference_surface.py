@@ -1,0 +1,120 @@
+"""The reference's own tests (tests/test_mpopt.py) for the classes on the path, run against
+``mpopt_amd.mp``: same calls, same assertions.  Line numbers refer to /root/reference/tests/test_mpopt.py."""
+import numpy as np
+import pytest
+
+import mpopt_amd as M
+from mpopt_amd import mp
+import problems
+
+FIXTURES = {
+    "test_ocp": (problems.generic_two_phase, 2, [2, 3]),          # 231-233
+    "moon_lander": (problems.moon_lander, 3, 4),
+    "van_der_pol": (problems.van_der_pol, 2, [3, 4]),
+    "hyper_sensitive": (problems.hyper_sensitive, 4, 3),
+    "two_phase_schwartz": (problems.two_phase_schwartz, 3, 3),
+}
+
+
+@pytest.fixture(params=list(FIXTURES))
+def test_mpo(request):
+    builder, S, po = FIXTURES[request.param]
+    mp.mpopt._MUTE_ = True
+    mpo = mp.mpopt(builder(mp, M.math), S, po)
+    mpo.validate()
+    return mpo
+
+
+def test_mpopt_collocation_basis(test_mpo):  # 333-346
+    test_mpo.compute_numerical_approximation()
+    poly_orders, Npoints = test_mpo.poly_orders, test_mpo._Npoints
+    assert len(test_mpo._taus) == len(set(poly_orders))
+    assert test_mpo._compW.shape == (1, Npoints)
+    for p in poly_orders:
+        assert len(test_mpo._taus[p]) == p + 1
+    assert test_mpo._compD.shape == (Npoints, Npoints)
+    assert test_mpo._collocation_approximation_computed
+
+
+def test_mpopt_casadi_variables(test_mpo):  # 349-356
+    test_mpo.create_variables()
+    for name in ("X", "U", "t0", "tf", "seg_widths"):
+        assert getattr(test_mpo, name) is not None
+
+
+def test_mpopt_ocp_discretization(test_mpo):  # 359-364
+    for phase in range(test_mpo._ocp.n_phases):
+        G, Gmin, Gmax, J = test_mpo.discretize_phase(phase)
+        assert G.shape[0] == Gmin.shape[0] == Gmax.shape[0]
+        assert J.shape == (1, 1)
+
+
+def test_mpopt_event_constraints(test_mpo):  # 367-373
+    E, Emin, Emax = test_mpo.get_event_constraints()
+    if test_mpo._ocp.n_phases == 1:
+        assert E == Emin == Emax == []
+    assert len(E) == len(Emin) == len(Emax)
+
+
+def test_mpopt_nlp_vars_init(test_mpo):  # 376-385
+    test_mpo.create_variables()
+    for phase in range(test_mpo._ocp.n_phases):
+        Z, Zmin, Zmax = test_mpo.get_nlp_variables(phase)
+        assert Z.shape[0] == Zmin.shape[0] == Zmax.shape[0] == test_mpo._optimization_vars_per_phase
+
+
+def test_mpopt_nlp_init(test_mpo):  # 388-400
+    nlp_prob, nlp_bounds = test_mpo.create_nlp()
+    assert nlp_prob["x"].shape[0] == nlp_bounds["lbx"].shape[0] == nlp_bounds["ubx"].shape[0]
+    assert nlp_prob["g"].shape[0] == nlp_bounds["lbg"].shape[0] == nlp_bounds["ubg"].shape[0]
+    assert nlp_prob["f"].shape[0] == 1
+
+
+def test_mpopt_init_solution(test_mpo):  # 403-407
+    test_mpo.create_variables()
+    Z0 = test_mpo.initialize_solution()
+    assert Z0.shape[0] == test_mpo._optimization_vars_per_phase * test_mpo._ocp.n_phases
+
+
+def test_mpopt_get_residual_grid_taus(test_mpo):  # 637-660 (without the solve: widths are the defaults)
+    test_mpo.compute_numerical_approximation()
+    test_mpo._nlp_sw_params = test_mpo.get_segment_width_parameters(None)
+    for gt in ("fixed", "mid-points", "spectral"):
+        taus = test_mpo.get_residual_grid_taus(grid_type=gt)
+        taus_1D = np.concatenate(taus)
+        # (1e-12 slack: with widths 1/3 the reference's own formula yields 1.0000000000000004, golden-verified)
+        assert taus_1D.min() >= test_mpo.tau0 - 1e-12 and taus_1D.max() <= test_mpo.tau1 + 1e-12
+        assert len(taus) == test_mpo.n_segments
+    assert test_mpo.get_residual_grid_taus(grid_type="do-not-know-any") is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["moon_lander", "van_der_pol", "two_phase_schwartz"])
+def test_solve_and_postprocess(name):
+    """416-428, 554-602, 678-727: solve, result keys, data shapes, interpolate_single_phase sizes."""
+    builder, S, po = FIXTURES[name]
+    mp.mpopt._MUTE_ = True
+    mpo = mp.mpopt(builder(mp, M.math), S, po)
+    if name == "moon_lander":  # 417-419
+        mpo._ocp.diff_u[0], mpo._ocp.midu[0], mpo._ocp.du_continuity[0] = 1, 0, 1
+    sol = mpo.solve()
+    for key in ["x", "f"]:
+        assert key in sol
+    for key in ["lbx", "lbg", "ubx", "ubg"]:  # 410-413
+        assert key in mpo.nlp_bounds
+    post = mpo.process_results(sol, plot=False)
+    x, u, t, _ = post.get_data()
+    xi, ui, ti, _ = post.get_data(interpolate=True)
+    assert x.shape[0] == u.shape[0] == t.shape[0]
+    assert xi.shape[0] == ui.shape[0] == ti.shape[0]
+    Xi, Ui, ti, a, DXi, DUi, target_nodes, t0, tf = mpo.interpolate_single_phase(sol, phase=0)
+    assert Xi.size() == DXi.size() and Ui.size() == DUi.size()
+    assert a.size() == (mpo._ocp.na, 1)
+    assert ti.size() == (sum(len(n) for n in target_nodes), 1)
+    ends = np.array([[mpo.tau0, mpo.tau1] for _ in range(mpo.n_segments)])
+    Xi, Ui, ti, a, DXi, DUi, target_nodes, t0, tf = mpo.interpolate_single_phase(sol, phase=0, target_nodes=ends)
+    assert Xi.size() == DXi.size() and ti.size() == (2 * mpo.n_segments, 1)
+    # 730-744: dynamics residuals at a solution are small on this coarse grid
+    ti_r, residuals = mpo.get_dynamics_residuals(sol, grid_type="spectral")
+    mx = max(np.abs(r).max() for r in residuals[0] if r is not None)
+    assert np.isfinite(mx) and mx < 4
