@@ -198,6 +198,14 @@ def main():
             r = C.eval(Zh[0], ph)  # the CPU port and the GPU agree on the benchmarked point
             assert abs(r["f"] - float(f[0].item())) < 1e-9 * max(1.0, abs(r["f"]))
             assert np.abs(r["g"] - g[0].cpu().numpy()).max() < 1e-9
+            # the same port on every host core (OpenMP over evaluation points), bounded to a few seconds
+            na = min(B, 2048)
+            C.time_many_all_cores(Zh[:na], ph, 1)  # thread start-up, page touching
+            ta, nthr = C.time_many_all_cores(Zh[:na], ph, 3)
+            ra = max(1, int(5.0 / max(ta / 3, 1e-6)))
+            ta, nthr = C.time_many_all_cores(Zh[:na], ph, ra)
+            out["cpu_baseline_all_cores"] = {"value": na * ra / ta, "unit": "evals/s", "cores": nthr, "kind": "port",
+                                             "sample": f"{na} evaluation points x {ra} passes, OpenMP over points, {ta:.1f} s"}
             out["cpu_baseline"] = {"value": ns * reps / tt, "unit": "evals/s", "cores": 1, "kind": "port",
                                    "sample": f"{ns} of the same evaluation points x {reps} passes, oracle/mpopt_oracle.c "
                                              f"(gcc -O2, scalar, values only), {tt:.1f} s",

@@ -15,7 +15,7 @@ _lib = None
 
 def build(force=False):
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-o", LIB + ".tmp", SRC, "-lm"])
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fopenmp", "-fPIC", "-shared", "-o", LIB + ".tmp", SRC, "-lm"])
         os.replace(LIB + ".tmp", LIB)
     return LIB
 
@@ -36,6 +36,8 @@ def lib():
         L.orc_set_table.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp, dp]
         L.orc_eval.restype = ctypes.c_int64
         L.orc_eval.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 8
+        L.orc_eval_many_omp.restype = ctypes.c_int
+        L.orc_eval_many_omp.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_eval_many.restype = None
         L.orc_eval_many.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 6
         _lib = L
@@ -93,6 +95,18 @@ class COracle:
         t = time.perf_counter()
         L.orc_eval_many(self._h, B, int(reps), Z.ctypes.data, p.ctypes.data, f.ctypes.data, g.ctypes.data, grad.ctypes.data, vals.ctypes.data)
         return time.perf_counter() - t
+
+    def time_many_all_cores(self, Z, p, reps):
+        """(wall seconds, threads) for ``reps`` passes over Z with OpenMP over the points."""
+        import time
+
+        L = lib()
+        Z, p = np.ascontiguousarray(Z, float), np.ascontiguousarray(p, float)
+        f = np.zeros(Z.shape[0])
+        L.orc_eval_many_omp(self._h, Z.shape[0], 1, Z.ctypes.data, p.ctypes.data, f.ctypes.data)
+        t = time.perf_counter()
+        n = L.orc_eval_many_omp(self._h, Z.shape[0], int(reps), Z.ctypes.data, p.ctypes.data, f.ctypes.data)
+        return time.perf_counter() - t, n
 
     def __del__(self):
         try:

@@ -538,6 +538,39 @@ int64_t orc_eval(const orc* o, const double* z, const double* p, double* f_out, 
 #undef EMIT
 }
 
+/* All-host-cores variant of the timed loop: OpenMP over evaluation points, private output buffers per
+ * thread (values are discarded; the single-core loop above is the like-for-like stand-in for CasADi's
+ * serial SX interpreter, this one is the "whole CPU" number).  Returns the thread count used. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int orc_eval_many_omp(const orc* o, int64_t n_points, int reps, const double* Z, const double* p, double* f) {
+  int nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel
+  {
+#pragma omp single
+    nthreads = omp_get_num_threads();
+    double* g = (double*)malloc(o->n_g * sizeof(double));
+    double* grad = (double*)malloc(o->n_z * sizeof(double));
+    double* vals = (double*)malloc(o->nnz * sizeof(double));
+    for (int r = 0; r < reps; ++r) {
+#pragma omp for schedule(static)
+      for (int64_t b = 0; b < n_points; ++b) orc_eval(o, Z + b * o->n_z, p, f + b, g, grad, 0, 0, vals);
+    }
+    free(g), free(grad), free(vals);
+  }
+#else
+  double* g = (double*)malloc(o->n_g * sizeof(double));
+  double* grad = (double*)malloc(o->n_z * sizeof(double));
+  double* vals = (double*)malloc(o->nnz * sizeof(double));
+  for (int r = 0; r < reps; ++r)
+    for (int64_t b = 0; b < n_points; ++b) orc_eval(o, Z + b * o->n_z, p, f + b, g, grad, 0, 0, vals);
+  free(g), free(grad), free(vals);
+#endif
+  return nthreads;
+}
+
 /* Timed loop for bench.py: `reps` evaluations of f+g+grad_f+jac_g (values only) on `n_points`
  * different points; returns nothing, the caller clocks it. */
 void orc_eval_many(const orc* o, int64_t n_points, int reps, const double* Z, const double* p, double* f, double* g, double* grad,
