@@ -56,8 +56,7 @@ struct MpxNodeArgs {
   double inv_dtau;         // 1/(tau1 - tau0)
   int64_t z_off;           // offset of the phase's block in z / grad_f
   int64_t g_off_F, g_off_C, g_off_DU, g_off_mU;  // row offsets of the phase's blocks in g
-  int32_t N, S, seg_off;   // nodes, segments per phase; phase*S
-  int32_t diff_u, midu;
+  int32_t N, seg_off;      // nodes per phase; phase * n_segments (offset into the width vectors)
   int32_t tile_first, tile_count;  // tile sub-range to run (segment sharding)
 };
 
@@ -85,7 +84,7 @@ struct MpxBoundArgs {
   const double* lin_coef;
   const int64_t* lin_row;  // g row of each linear row
   int64_t lin_jac;         // first Jacobian value of the linear rows
-  int32_t n_lin, nx, nu, na;
+  int32_t n_lin;
 };
 
 // Off-node evaluation (interpolated trajectories and dynamics residuals, mpopt.py:1428-1543):

@@ -666,10 +666,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
     A.g_off_DU = P.g_off_DU;
     A.g_off_mU = P.g_off_mU;
     A.N = (int32_t)c->N;
-    A.S = c->S;
     A.seg_off = B.phase * c->S;
-    A.diff_u = P.diff_u;
-    A.midu = P.midu;
     A.tile_first = (int32_t)lo;
     A.tile_count = (int32_t)(hi - lo);
     int rc = launch(c, B.fn[mode], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A);
@@ -701,9 +698,6 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
   G.lin_row = c->d_lin_row;
   G.lin_jac = c->lin_jac;
   G.n_lin = (int32_t)c->lin_row.size();
-  G.nx = c->nx;
-  G.nu = c->nu;
-  G.na = c->na;
   return launch(c, c->fn_bound[mode], dim3((unsigned)io.B, 1, 1), dim3(256, 1, 1), &G, sizeof G);
 }
 

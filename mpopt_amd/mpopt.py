@@ -370,15 +370,16 @@ class Collocation:
 class _NlpSymbol:
     """Placeholder for the reference's SX entries of the nlp dict (f, x, g, p)."""
 
-    def __init__(self, name, size, oracle):
+    def __init__(self, name, size, oracle, shape=None):
         self.name, self.size, self.oracle = name, size, oracle
+        self._shape = (size, 1) if shape is None else shape
 
     def size1(self):
         return self.size
 
     @property
     def shape(self):
-        return (self.size, 1)
+        return self._shape
 
     def __repr__(self):
         return f"<{self.name}[{self.size}] of {self.oracle.__class__.__name__}>"
@@ -451,9 +452,7 @@ class mpopt:
         if self.oracle is None:
             self.create_nlp()
         lo, hi = self._phase_row_bounds(phase)
-        J = _NlpSymbol(f"J{phase}", 1, self.oracle)
-        J.__class__ = type("_Scalar", (_NlpSymbol,), {"shape": property(lambda self_: (1, 1))})
-        return (_NlpSymbol(f"G{phase}", len(lo), self.oracle), lo, hi, J)
+        return (_NlpSymbol(f"G{phase}", len(lo), self.oracle), lo, hi, _NlpSymbol(f"J{phase}", 1, self.oracle, shape=(1, 1)))
 
     # ---- bounds -------------------------------------------------------------------------
     def _midu_rows(self, phase):
