@@ -61,6 +61,11 @@ extern "C" {
 #define MPX_GRAD 4   /* nlp_grad_f */
 #define MPX_JAC 8    /* nlp_jac_g  */
 #define MPX_HESS 16  /* nlp_hess_l */
+#define MPX_JAC_VARIABLE_ONLY 64 /* opt-in, with MPX_JAC: rewrite only the jac_g entries that depend on (z, p).
+                                   The differentiation / interpolation blocks are constants of the grid; a caller
+                                   that keeps its jac_val buffers resident (a device-side consumer) pays for them
+                                   once: the buffers must hold the values of an earlier full MPX_JAC evaluation of
+                                   the same context and batch slots.  Never the default. */
 #define MPX_BOUNDARY_ONLY 32 /* skip the node kernels: finish reductions / terminal / linking rows only
                                 (second half of a segment-sharded evaluation, see mpx_set_tile_range) */
 

@@ -25,7 +25,7 @@ c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)
 
-MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MPX_BOUNDARY_ONLY = 1, 2, 4, 8, 16, 32
+MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MPX_BOUNDARY_ONLY, MPX_JAC_VARIABLE_ONLY = 1, 2, 4, 8, 16, 32, 64
 SCHEMES = {"LGR": 0, "LGL": 1, "CGL": 2, "LG": 3}
 SCHEME_EQUI = 4
 

@@ -175,6 +175,9 @@ class PhaseProgram:
         out.append(f"  static constexpr int NJV = {len(self.jv)}, NHN = {len(self.hn)}, NHC = {len(self.hc)};")
         out.append(f"  static constexpr int NMG = {len(self.mg)}, NTJ = {len(self.tj)}, NTH = {len(self.th)}, NRED = {NRED};")
         out.append(f"  static constexpr bool DIFF_U = {'true' if flags['diff_u'] else 'false'}, MIDU = {'true' if flags['midu'] else 'false'};")
+        # D-block of state a holds a variable entry (its diagonal, merged with -d fx_a/d X_a) or is constant
+        ddnz = ", ".join("true" if not e.is_zero else "false" for e in self.dd)
+        out.append(f"  static constexpr bool DD_VARIABLE[{max(self.nx, 1)}] = {{{ddnz}}};")
         node_sig = ("const double* __restrict__ Xs, const double* __restrict__ Us, double t0v, double tfv, "
                     "const double* __restrict__ As, double kap, double th, double W")
         term_sig = ("const double* __restrict__ XF, double tfv, const double* __restrict__ X0, double t0v, "

@@ -41,6 +41,7 @@ struct MpxIO {
   double* partial;      // [B][n_tiles_total][nred]
   int32_t n_tiles_total, nred;
   int32_t B, b_per_block;
+  int32_t jac_variable_only, pad_;
 };
 
 // Node kernels: one launch per (phase, degree) bucket.

@@ -1131,6 +1131,7 @@ static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const
   io.grad = (mask & MPX_GRAD) ? grad_f : nullptr;
   io.grad_stride = c->n_z;
   io.jac = (mask & MPX_JAC) ? jac_val : nullptr;
+  io.jac_variable_only = (mask & MPX_JAC_VARIABLE_ONLY) ? 1 : 0;
   io.jac_stride = c->nnz_j;
   io.hess = hess_val;
   io.hess_stride = c->nnz_h;

@@ -60,14 +60,24 @@ typedef double mpx_d2 __attribute__((ext_vector_type(2)));
 // Addressing: uniform base (SGPRs) + ONE running 32-bit byte offset per lane.  The offsets are loop
 // invariant across the batch loop; the empty asm stops the compiler from hoisting one 64-bit address
 // pair per slot out of it (that cost 90+ VGPRs and more than halved the occupancy).
-template <int NS, int FENCE = 0, class F>
-__device__ __forceinline__ void scatter_slots(double* __restrict__ blk, int64_t n, int l, bool own, bool vec, F sv) {
+struct AllSlots {
+  __device__ __forceinline__ bool operator()(int) const { return true; }
+};
+
+// `keep(q)`: false for slots whose value is a constant of the grid and may be skipped (opt-in
+// MPX_JAC_VARIABLE_ONLY); evaluated at compile time after unrolling, a pair is written if either slot is kept.
+template <int NS, int FENCE = 0, class F, class K = AllSlots>
+__device__ __forceinline__ void scatter_slots(double* __restrict__ blk, int64_t n, int l, bool own, bool vec, F sv, K keep = K()) {
   if (!own) return;
   char* __restrict__ base = reinterpret_cast<char*>(blk);
   const uint32_t nb = (uint32_t)n * 8u;  // bytes per slot
   uint32_t off = (uint32_t)l * 16u;
 #pragma unroll
   for (int q = 0; q + 1 < NS; q += 2) {
+    if (!(keep(q) || keep(q + 1))) {
+      off += 2u * nb;
+      continue;
+    }
     asm volatile("" : "+v"(off));
     if (vec) {
       mpx_d2 w;
@@ -83,7 +93,7 @@ __device__ __forceinline__ void scatter_slots(double* __restrict__ blk, int64_t 
     // the first store -- that alone held ~60 VGPRs live at degree 30
     if (FENCE > 0 && (q / 2) % FENCE == FENCE - 1) __builtin_amdgcn_sched_barrier(0);
   }
-  if (NS & 1) {
+  if ((NS & 1) && keep(NS - 1)) {
     uint32_t o1 = (uint32_t)(NS - 1) * nb + (uint32_t)l * 8u;
     asm volatile("" : "+v"(o1));
     *reinterpret_cast<double*>(base + o1) = sv(NS - 1);
@@ -328,10 +338,20 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
             }
             return opaque(Crow(q % P1));
           };
-          if (T.node0)  // node 0 owns no mid-point row: its block ends after the main slots
+          auto variable = [](int q) -> bool {  // slot depends on (z, p)?
+            if (q < NX * P1) return G::DD_VARIABLE[q / P1];
+            return q < NX * P1 + G::NJV;
+          };
+          if (io.jac_variable_only) {
+            if (T.node0)
+              scatter_slots<NS_MAIN, 0>(jb, n, l, own, false, sv, variable);
+            else
+              scatter_slots<NS_MAIN + NS_MID, 0>(jb, n, l, own, vec, sv, variable);
+          } else if (T.node0) {  // node 0 owns no mid-point row: its block ends after the main slots
             scatter_slots<NS_MAIN, TAB_LDS ? 4 : 0>(jb, n, l, own, false, sv);
-          else
+          } else {
             scatter_slots<NS_MAIN + NS_MID, TAB_LDS ? 4 : 0>(jb, n, l, own, vec, sv);
+          }
         }
       }
     }
@@ -542,7 +562,7 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A) {
       for (int64_t e = e0; e < e1; ++e) s = fma(A.lin_coef[e], zb[A.lin_idx[e]], s);
       if (io.g) io.g[(int64_t)b * io.g_stride + A.lin_row[r]] = s;
       if constexpr (MODE == MPX_MODE_FGJ) {
-        if (io.jac) {
+        if (io.jac && !io.jac_variable_only) {
           double* jb = io.jac + (int64_t)b * io.jac_stride + A.lin_jac;
           for (int64_t e = e0; e < e1; ++e) jb[e] = A.lin_coef[e];
         }
