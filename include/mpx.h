@@ -178,6 +178,12 @@ int mpx_eval_device(mpx_ctx* ctx, int what_mask, int64_t batch, const double* z,
 /* Block until the context's stream is idle. */
 int mpx_sync(mpx_ctx* ctx);
 
+/* Page-locked host memory for the buffers handed to mpx_eval / mpx_resid_eval: with pageable memory
+ * every transfer is staged by the runtime (~2x the latency of a single evaluation); buffers from
+ * mpx_host_alloc are DMA targets.  Free with mpx_host_free before mpx_destroy. */
+int mpx_host_alloc(mpx_ctx* ctx, size_t bytes, void** ptr);
+int mpx_host_free(mpx_ctx* ctx, void* ptr);
+
 /* Segment sharding (multi-GPU): restrict the node kernels of this context to the
  * tiles [tile_begin, tile_end) and report the contiguous value ranges they own, so that ranks
  * can all-gather disjoint slices.  Default: all tiles.  The boundary kernel (reductions,

@@ -114,6 +114,8 @@ SYMBOLS = {
     "mpx_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mpx_eval_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mpx_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpx_host_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "mpx_host_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mpx_set_tile_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "mpx_get_tile_jac_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p, c_int64_p]),
     "mpx_get_tile_weights": (ctypes.c_int, [ctypes.c_void_p, c_int64_p]),

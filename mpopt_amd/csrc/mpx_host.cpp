@@ -872,6 +872,20 @@ extern "C" int mpx_sync(mpx_ctx* c) {
   return MPX_OK;
 }
 
+extern "C" int mpx_host_alloc(mpx_ctx* c, size_t bytes, void** ptr) {
+  if (!c || !ptr) return MPX_ERR_INVALID;
+  if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "context has no device code");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault));
+  return MPX_OK;
+}
+
+extern "C" int mpx_host_free(mpx_ctx* c, void* ptr) {
+  if (!c) return MPX_ERR_INVALID;
+  if (ptr) HIPCHK(c, hipHostFree(ptr));
+  return MPX_OK;
+}
+
 extern "C" int mpx_timer_start(mpx_ctx* c) {
   if (!c || !c->has_device) return MPX_ERR_NO_DEVICE;
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));

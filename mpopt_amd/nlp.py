@@ -145,6 +145,23 @@ class NlpFunctions:
         self.nnz_jac, self.nnz_hess, self.n_nodes, self.n_tiles = s.nnz_jac, s.nnz_hess, s.n_nodes, s.n_tiles
         self.bytes_fgj, self.bytes_hess = s.bytes_fgj, s.bytes_hess
         self._jac_pat = self._hess_pat = None
+        self._pinned = {}
+
+    def pinned_empty(self, shape):
+        """float64 numpy array over page-locked host memory owned by this context (mpx_host_alloc)."""
+        n = int(np.prod(shape))
+        ptr = ctypes.c_void_p()
+        _lib.check(self._L.mpx_host_alloc(self._ctx, max(n, 1) * 8, ctypes.byref(ptr)), self._ctx)
+        buf = (ctypes.c_double * max(n, 1)).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape)
+        self._pinned.setdefault("_owned", []).append(ptr)
+        return arr
+
+    def _pinned_buf(self, key, shape):
+        cur = self._pinned.get(key)
+        if cur is None or cur.shape != tuple(shape):
+            cur = self._pinned[key] = self.pinned_empty(tuple(shape))
+        return cur
 
     def make_current(self):
         """Select this context for the CasADi-external entry points (nlp_f ... nlp_hess_l in libmpx.so):
@@ -157,6 +174,9 @@ class NlpFunctions:
             self._L.mpx_set_current(None)
             NlpFunctions._current = None
         if getattr(self, "_ctx", None):
+            for ptr in self._pinned.pop("_owned", []):
+                self._L.mpx_host_free(self._ctx, ptr)
+            self._pinned = {}
             self._L.mpx_destroy(self._ctx)
             self._ctx = None
 
@@ -201,9 +221,12 @@ class NlpFunctions:
         return ResidualPlan(self, phase, taus_per_segment)
 
     # -- evaluation ------------------------------------------------------------------------
-    def eval(self, what, z, p, lam_g=None, sigma=None):
+    def eval(self, what, z, p, lam_g=None, sigma=None, pinned=False):
         """Host arrays in, dict of host arrays out.  ``z``: (B, n_z) or (n_z,); ``p``: (n_p,) shared
-        or (B, n_p).  ``what``: iterable of {"f","g","grad_f","jac_g","hess_l"}."""
+        or (B, n_p).  ``what``: iterable of {"f","g","grad_f","jac_g","hess_l"}.
+        ``pinned=True``: inputs are staged through, and outputs are *views of*, page-locked buffers owned
+        by this object (true DMA transfers, about half the latency of a single evaluation); the returned
+        arrays are overwritten by the next ``eval(..., pinned=True)`` of the same shape."""
         mask = sum({"f": MPX_F, "g": MPX_G, "grad_f": MPX_GRAD, "jac_g": MPX_JAC, "hess_l": MPX_HESS}[w] for w in set(what))
         z = np.ascontiguousarray(z, dtype=np.float64)
         single = z.ndim == 1
@@ -214,15 +237,24 @@ class NlpFunctions:
             raise ValueError(f"p has {p.size} values, expected {self.n_p} or {B}x{self.n_p}")
         per_point = int(p.size == B * self.n_p and B > 1)
         out = {}
-        f = np.empty(B) if mask & MPX_F else None
-        g = np.empty((B, self.n_g)) if mask & MPX_G else None
-        gr = np.empty((B, self.n_z)) if mask & MPX_GRAD else None
-        jv = np.empty((B, self.nnz_jac)) if mask & MPX_JAC else None
+        new = (lambda key, shape: self._pinned_buf(key, shape)) if pinned else (lambda key, shape: np.empty(shape))
+        f = new("f", (B,)) if mask & MPX_F else None
+        g = new("g", (B, self.n_g)) if mask & MPX_G else None
+        gr = new("grad", (B, self.n_z)) if mask & MPX_GRAD else None
+        jv = new("jac", (B, self.nnz_jac)) if mask & MPX_JAC else None
         hv = lam = sig = None
         if mask & MPX_HESS:
             lam = np.ascontiguousarray(np.broadcast_to(np.asarray(lam_g, dtype=np.float64).reshape(-1, self.n_g), (B, self.n_g)))
             sig = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype=np.float64).reshape(-1), (B,)))
-            hv = np.empty((B, self.nnz_hess))
+            hv = new("hess", (B, self.nnz_hess))
+        if pinned:
+            zin = self._pinned_buf("z", z.shape)
+            zin[...] = z
+            z = zin
+            if lam is not None:
+                lin = self._pinned_buf("lam", lam.shape)
+                lin[...] = lam
+                lam = lin
         rc = self._L.mpx_eval(self._ctx, mask, B, _ptr(z), _ptr(p), per_point, _ptr(lam), _ptr(sig), _ptr(f), _ptr(g),
                               _ptr(gr), _ptr(jv), _ptr(hv))
         _lib.check(rc, self._ctx)

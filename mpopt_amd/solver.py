@@ -50,14 +50,14 @@ class NlpSolver:
             return timed(["g"], x, p)["g"]
 
         def jac(x):
-            return sp.csr_matrix((timed(["jac_g"], x, p)["jac_g"], (jr, jc)), shape=(m, n))
+            return sp.csr_matrix((timed(["jac_g"], x, p, pinned=True)["jac_g"], (jr, jc)), shape=(m, n))
 
         def hess_con(x, v):
-            h = timed(["hess_l"], x, p, lam_g=v, sigma=0.0)["hess_l"]
+            h = timed(["hess_l"], x, p, lam_g=v, sigma=0.0, pinned=True)["hess_l"]
             return _sym(h, hr, hc, n)
 
         def hess_obj(x):
-            h = timed(["hess_l"], x, p, lam_g=np.zeros(m), sigma=1.0)["hess_l"]
+            h = timed(["hess_l"], x, p, lam_g=np.zeros(m), sigma=1.0, pinned=True)["hess_l"]
             return _sym(h, hr, hc, n)
 
         max_iter = int(self.options.get("ipopt.max_iter", 2000))

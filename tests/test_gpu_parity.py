@@ -286,3 +286,29 @@ def test_jac_variable_only_mode(case):
     o.sync()
     frac_written = float((~torch.isnan(jn)).double().mean())
     assert 0.0 < frac_written < 0.9
+
+
+@pytest.mark.gpu
+def test_pinned_host_buffers_match_pageable():
+    """mpx_host_alloc staging (eval(..., pinned=True)) returns the same bits as pageable buffers and
+    reuses its buffers between calls."""
+    import mpopt_amd as M
+    from mpopt_amd import mp
+
+    ocp = problems.kitchen_sink(mp, M.math)
+    mpo = mp.mpopt(ocp, 6, 4, "LGR")
+    nlp, _ = mpo.create_nlp()
+    o = nlp["oracle"]
+    rng = np.random.default_rng(5)
+    z = rng.normal(size=(3, o.n_z))
+    p = np.full(o.n_p, 1.0 / 6)
+    lam = rng.normal(size=(3, o.n_g))
+    what = ["f", "g", "grad_f", "jac_g", "hess_l"]
+    a = o.eval(what, z, p, lam_g=lam, sigma=np.array([1.0, 0.5, 2.0]))
+    b = o.eval(what, z, p, lam_g=lam, sigma=np.array([1.0, 0.5, 2.0]), pinned=True)
+    for k in what:
+        assert np.array_equal(a[k], b[k]), k
+    keep = {k: b[k].copy() for k in what}
+    c = o.eval(what, 2 * z, p, lam_g=lam, sigma=np.array([1.0, 0.5, 2.0]), pinned=True)
+    assert c["jac_g"].ctypes.data == b["jac_g"].ctypes.data          # same page-locked buffer, overwritten
+    assert not np.array_equal(c["g"], keep["g"])
