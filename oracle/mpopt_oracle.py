@@ -228,7 +228,7 @@ class OracleNLP:
         self.st = float(o.scale_t)
         self.compD, self.compW = G.comp_D(), G.comp_W()
         self.seg, self.pt = G.node_seg_point()
-        self.n_zp = self.N * (self.nx + self.nu) + 2 + self.na  # mpopt.py:537-543
+        self.n_zp = self.N * (self.nx + self.nu) + 2 + self.na + self._extra_vars_per_phase()  # mpopt.py:537-543
         self.n_z = self.n_zp * self.n_ph
         self.n_p = self.S * self.n_ph
         self.has_path = [o.has_path_constraints(ph) for ph in range(self.n_ph)]
@@ -243,12 +243,15 @@ class OracleNLP:
         self.n_g = len(self.g(np.zeros(self.n_z) + 0.5, np.full(self.n_p, 1.0 / self.S)))
 
     # -- helpers ---------------------------------------------------------------------------
+    def _extra_vars_per_phase(self):
+        return 0
+
     def split(self, z, ph):
         zp = np.asarray(z, float)[ph * self.n_zp:(ph + 1) * self.n_zp]
         N, nx, nu = self.N, self.nx, self.nu
         X = zp[:nx * N].reshape(nx, N).T
         U = zp[nx * N:(nx + nu) * N].reshape(nu, N).T
-        return X, U, zp[(nx + nu) * N], zp[(nx + nu) * N + 1], zp[(nx + nu) * N + 2:]
+        return X, U, zp[(nx + nu) * N], zp[(nx + nu) * N + 1], zp[(nx + nu) * N + 2:(nx + nu) * N + 2 + self.na]
 
     def zidx(self, ph, kind, comp=0, node=0):
         base, N, nx, nu = ph * self.n_zp, self.N, self.nx, self.nu
@@ -586,3 +589,233 @@ class OracleNLP:
             for e, wt in enumerate(twts):
                 H[np.ix_(tc, tc)] += wt * np.array(TH[e], float)
         return H
+
+
+# ---------------------------------------------------------------------------------------------
+# mpopt_adaptive (mpopt.py:2877-3375): segment widths are decision variables, no NLP parameters
+# ---------------------------------------------------------------------------------------------
+class OracleAdaptiveNLP(OracleNLP):
+    """f, g and derivatives of the NLP that ``mpopt_adaptive.create_nlp`` builds (``p`` dropped,
+    mpopt.py:3190-3192).  Values are a line-by-line restatement that runs on floats *or* on sympy
+    symbols; derivatives are sympy differentiation of the whole-NLP expressions (what CasADi's AD does
+    to the reference's SX graph) -- an independent route from the product's per-point AD + sparse
+    assembly.  Meant for the small grids the adaptive variant is used with."""
+
+    SEG_WIDTH_MIN, SEG_WIDTH_MAX, TOL_RESIDUAL = 1e-4, 1.0, 1e-3  # mpopt.py:2896-2898
+
+    def __init__(self, ocp, n_segments, poly_orders, scheme="LGR", tau0=-1.0, tau1=1.0, table_method="auto"):
+        self._lam_cache = {}
+        super().__init__(ocp, n_segments, poly_orders, scheme, tau0, tau1, table_method)
+        self.n_p = 0
+
+    def _extra_vars_per_phase(self):
+        return self.S  # mpopt.py:2947
+
+    def _build_symbolic(self):  # derivatives are taken on the whole NLP (see _symbolic)
+        G = self.grid
+        self.taus_mid = [(G.taus[d][:-1] + G.taus[d][1:]) / 2.0 for d in G.orders]  # mpopt.py:3043-3048
+        self.I_mid_all = G.comp_interp(self.taus_mid, 0)  # mpopt.py:3057-3059
+        self.D_mid_all = G.comp_interp(self.taus_mid, 1)  # mpopt.py:3060-3062
+        self.u_bounded = [bool((np.asarray(self.ocp.lbu[ph]) > -np.inf).any() or (np.asarray(self.ocp.ubu[ph]) < np.inf).any())
+                          for ph in range(self.n_ph)]
+        self.x_bounded = [bool((np.asarray(self.ocp.lbx[ph]) > -np.inf).any() or (np.asarray(self.ocp.ubx[ph]) < np.inf).any())
+                          for ph in range(self.n_ph)]
+
+    # -- values (generic in the number type) ----------------------------------------------------------
+    def _phase_generic(self, zp, ph):
+        o, G, N, nx, nu, na, S = self.ocp, self.grid, self.N, self.nx, self.nu, self.na, self.S
+        zp = np.asarray(zp, dtype=object)
+        X = zp[:nx * N].reshape(nx, N).T
+        U = zp[nx * N:(nx + nu) * N].reshape(nu, N).T
+        k = (nx + nu) * N
+        t0v, tfv, A, W = zp[k], zp[k + 1], zp[k + 2:k + 2 + na], zp[k + 2 + na:k + 2 + na + S]
+        t0, tf = t0v / self.st, tfv / self.st  # mpopt.py:175-176
+        a = [A[c] / self.sa[c] for c in range(na)]
+        dyn, pc, rc = o.get_dynamics(ph), o.get_path_constraints(ph), o.get_running_costs(ph)
+        dtau = G.tau1 - G.tau0
+        # node loop, mpopt.py:180-206
+        f, c, q, tgrid = [], [], [], []
+        t_seg0, s, h = t0, 0, (tf - t0) / dtau * W[0]
+        for i in range(N):
+            if self.seg[i] != s:
+                s = self.seg[i]
+                t_seg0 = t_seg0 + h * dtau
+                h = (tf - t0) / dtau * W[s]
+            t = t_seg0 + h * (G.taus[G.orders[s]][self.pt[i]] - G.tau0)
+            tgrid.append(t)
+            x = [X[i, b] / self.sx[b] for b in range(nx)]
+            u = [U[i, b] / self.su[b] for b in range(nu)]
+            d = list(dyn(x, u, t, a))
+            f.append([h * (self.sx[b] * d[b]) for b in range(nx)])
+            if self.has_path[ph]:
+                c.append(list(pc(x, u, t, a)))
+            q.append(h * rc(x, u, t, a))
+        f = np.array(f, dtype=object).reshape(N, nx)
+        D = self.compD.astype(object)
+        parts = [(D.dot(X) - f).T.ravel()]  # F, mpopt.py:227-232
+        if self.has_path[ph]:
+            parts.append(np.array(c, dtype=object).reshape(N, -1).T.ravel())
+        if o.diff_u[ph]:
+            parts.append(D.dot(U).T.ravel())  # mpopt.py:315-321
+        x0 = [X[0, b] / self.sx[b] for b in range(nx)]
+        xf = [X[N - 1, b] / self.sx[b] for b in range(nx)]
+        if self.has_tc[ph]:
+            parts.append(np.array(list(o.get_terminal_constraints(ph)(xf, tf, x0, t0, a)), dtype=object))
+        J = o.get_terminal_costs(ph)(xf, tf, x0, t0, a)
+        for i in range(N):
+            if self.compW[i] != 0.0:
+                J = J + self.compW[i] * q[i]
+        # --- widths block, mpopt.py:3034-3136
+        sw = [np.array([sum(W[1:], W[0]) - 1.0], dtype=object)]
+        Im, Dm = self.I_mid_all.astype(object), self.D_mid_all.astype(object)
+        xi, ui, dxi = Im.dot(X), Im.dot(U), Dm.dot(X)
+        ti = [(tgrid[i] + tgrid[i + 1]) / 2.0 for i in range(N - 1)]
+        if self.u_bounded[ph]:
+            sw.append(ui.T.ravel())
+        if self.x_bounded[ph]:
+            sw.append(xi.T.ravel())
+        idx = 0
+        for s in range(S):
+            h_seg = (tfv - t0v) / self.st / dtau * W[s]
+            n_mid = len(self.taus_mid[s])
+            if n_mid == 0:
+                continue
+            blk = []
+            for m in range(n_mid):
+                x = [xi[idx, b] / self.sx[b] for b in range(nx)]
+                u = [ui[idx, b] / self.su[b] for b in range(nu)]
+                d = list(dyn(x, u, ti[idx], a))
+                blk.append([W[s] * (dxi[idx, b] - h_seg * (self.sx[b] * d[b])) for b in range(nx)])
+                idx += 1
+            sw.append(np.array(blk, dtype=object).reshape(n_mid, nx).T.ravel())
+        parts.append(np.concatenate(sw))
+        return np.concatenate(parts), J
+
+    def _nlp_generic(self, z):
+        z = np.asarray(z, dtype=object)
+        gs, f = [], 0
+        for ph in range(self.n_ph):
+            gp, J = self._phase_generic(z[ph * self.n_zp:(ph + 1) * self.n_zp], ph)
+            gs.append(gp)
+            f = f + J
+        if self.n_ph > 1:  # events, mpopt.py:464-521
+            N, ex, eu, et = self.N, [], [], []
+            for (i, j) in self.ocp.phase_links:
+                for a in range(self.nx):
+                    ex.append(z[self.zidx(j, "X", a, 0)] - z[self.zidx(i, "X", a, N - 1)])
+                for b in range(self.nu):
+                    eu.append(z[self.zidx(j, "U", b, 0)] - z[self.zidx(i, "U", b, N - 1)])
+                et.append(z[self.zidx(j, "t0")] - z[self.zidx(i, "tf")])
+            gs.append(np.array(ex + eu + et, dtype=object))
+        return np.concatenate(gs), f
+
+    def g(self, z, p=None):
+        return np.array([float(v) for v in self._nlp_generic([float(v) for v in z])[0]])
+
+    def f(self, z, p=None):
+        return float(self._nlp_generic([float(v) for v in z])[1])
+
+    # -- bounds and initial guess (mpopt.py:2927-3032, 3034-3136, 3138-3174) ----------------------------
+    def bounds(self):
+        o, N = self.ocp, self.N
+        zmin, zmax, gmin, gmax = [], [], [], []
+        base_nzp = N * (self.nx + self.nu) + 2 + self.na
+        blx, bux, _, _ = OracleNLP.bounds(self._as_base_for_bounds())  # per-phase variable bounds of the base class
+        for ph in range(self.n_ph):
+            zmin += [blx[ph * base_nzp:(ph + 1) * base_nzp], np.full(self.S, self.SEG_WIDTH_MIN)]
+            zmax += [bux[ph * base_nzp:(ph + 1) * base_nzp], np.full(self.S, self.SEG_WIDTH_MAX)]
+            lo, hi = [np.zeros(self.nx * N)], [np.zeros(self.nx * N)]
+            if self.has_path[ph]:
+                nc = len(o.get_path_constraints(ph)(o.x00[ph], o.u00[ph], o.t00[ph], o.a0[ph]))
+                lo.append(np.full(nc * N, -np.inf)), hi.append(np.zeros(nc * N))
+            if o.diff_u[ph]:
+                lo.append(np.full(self.nu * N, float(o.lbdu[ph]))), hi.append(np.full(self.nu * N, float(o.ubdu[ph])))
+            if self.has_tc[ph]:
+                ntc = len(o.get_terminal_constraints(ph)(o.xf0[ph], o.tf0[ph], o.x00[ph], o.t00[ph], o.a0[ph]))
+                lo.append(np.zeros(ntc)), hi.append(np.zeros(ntc))
+            lo.append(np.zeros(1)), hi.append(np.zeros(1))  # sum of widths = 1
+            n_mid = N - 1
+            if self.u_bounded[ph]:
+                lo.append(np.repeat(np.asarray(o.lbu[ph], float) * self.su, n_mid))
+                hi.append(np.repeat(np.asarray(o.ubu[ph], float) * self.su, n_mid))
+            if self.x_bounded[ph]:
+                lo.append(np.repeat(np.asarray(o.lbx[ph], float) * self.sx, n_mid))
+                hi.append(np.repeat(np.asarray(o.ubx[ph], float) * self.sx, n_mid))
+            lo.append(np.full(self.nx * n_mid, -self.TOL_RESIDUAL)), hi.append(np.full(self.nx * n_mid, self.TOL_RESIDUAL))
+            gmin.append(np.concatenate(lo)), gmax.append(np.concatenate(hi))
+        if self.n_ph > 1:
+            n = len(o.phase_links)
+            gmin += [np.concatenate([np.asarray(o.lbe[k], float) * self.sx for k in range(n)]), np.zeros(self.nu * n), np.zeros(n)]
+            gmax += [np.concatenate([np.asarray(o.ube[k], float) * self.sx for k in range(n)]), np.zeros(self.nu * n), np.zeros(n)]
+        return np.concatenate(zmin), np.concatenate(zmax), np.concatenate(gmin), np.concatenate(gmax)
+
+    def _as_base_for_bounds(self):
+        """A shallow stand-in exposing only what OracleNLP.bounds reads for the per-phase *variable* bounds."""
+        class _B:
+            pass
+
+        b = _B()
+        for k in ("ocp", "N", "n_ph", "nx", "nu", "sx", "su", "sa", "st", "has_path", "has_tc", "S"):
+            setattr(b, k, getattr(self, k))
+        b.midu = [False] * self.n_ph
+        return b
+
+    def initial_guess(self):  # mpopt.py:2981-3032
+        base = OracleNLP.initial_guess(self)
+        n0 = self.N * (self.nx + self.nu) + 2 + self.na
+        return np.concatenate([np.concatenate([base[ph * n0:(ph + 1) * n0], np.full(self.S, 1.0 / self.S)]) for ph in range(self.n_ph)])
+
+    # -- derivatives: sympy on the whole NLP ----------------------------------------------------------
+    def _symbolic(self):
+        if "syms" not in self._lam_cache:
+            sy = self.sympy
+            zs = list(sy.symbols(f"z0:{self.n_z}", real=True))
+            g, f = self._nlp_generic(zs)
+            self._lam_cache.update(syms=zs, g=[sy.sympify(e) for e in g], f=sy.sympify(f), pos={s: i for i, s in enumerate(zs)})
+        return self._lam_cache
+
+    def jac_g(self, z, p=None):
+        sy, C = self.sympy, self._symbolic()
+        if "jac" not in C:
+            R, Cc, E = [], [], []
+            for i, e in enumerate(C["g"]):
+                for s in e.free_symbols:
+                    d = sy.diff(e, s)
+                    if d != 0:
+                        R.append(i), Cc.append(C["pos"][s]), E.append(d)
+            C["jac"] = (np.array(R), np.array(Cc), sy.lambdify(C["syms"], E, "math", cse=True))
+        R, Cc, fn = C["jac"]
+        M = sp.coo_matrix((np.array(fn(*[float(v) for v in z]), float), (R, Cc)), shape=(self.n_g, self.n_z)).tocsr()
+        M.eliminate_zeros()
+        return M
+
+    def grad_f(self, z, p=None):
+        sy, C = self.sympy, self._symbolic()
+        if "grad" not in C:
+            C["grad"] = sy.lambdify(C["syms"], [sy.diff(C["f"], s) for s in C["syms"]], "math", cse=True)
+        return np.array(C["grad"](*[float(v) for v in z]), float)
+
+    def hess_l(self, z, p, sigma, lam):
+        """Dense symmetric Hessian of sigma*f + lam^T g (lam, sigma enter as symbols: one lambdify)."""
+        sy, C = self.sympy, self._symbolic()
+        if "hess" not in C:
+            ls = list(sy.symbols(f"lam0:{self.n_g}", real=True))
+            sg = sy.Symbol("sigma_f", real=True)
+            lag = sg * C["f"] + sum(l * e for l, e in zip(ls, C["g"]))
+            R, Cc, E = [], [], []
+            for s in C["syms"]:
+                d1 = sy.diff(lag, s)
+                if d1 == 0:
+                    continue
+                for s2 in C["syms"][C["pos"][s]:]:
+                    if s2 is not s and s2 not in d1.free_symbols:
+                        continue
+                    d2 = sy.diff(d1, s2)
+                    if d2 != 0:
+                        R.append(C["pos"][s]), Cc.append(C["pos"][s2]), E.append(d2)
+            C["hess"] = (np.array(R, int), np.array(Cc, int), sy.lambdify(C["syms"] + ls + [sg], E, "math", cse=True))
+        R, Cc, fn = C["hess"]
+        H = np.zeros((self.n_z, self.n_z))
+        if len(R):
+            H[R, Cc] = np.array(fn(*[float(v) for v in z], *[float(v) for v in lam], float(sigma)), float)
+        return H + np.triu(H, 1).T

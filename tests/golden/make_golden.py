@@ -106,14 +106,16 @@ def flat_syms(m):
     return list(m.a.reshape(-1, order="F"))
 
 
-def make_case(name, builder, n_segments, poly_orders, scheme):
+def make_case(name, builder, n_segments, poly_orders, scheme, adaptive=False):
+    """``adaptive``: the reference's ``mpopt_adaptive`` (mpopt.py:2877-3375): the segment widths are part of
+    ``x`` and the NLP has no parameters (create_solver pops ``p``, mpopt.py:3190-3192)."""
     t0 = time.time()
     ref.CollocationRoots._TAU_MIN, ref.CollocationRoots._TAU_MAX = -1, 1
     ref.Collocation.D_MATRIX_METHOD = "numerical"
     ocp = builder(ref, casadi_shim)
-    mpo = ref.mpopt(ocp, n_segments, poly_orders, scheme)
+    mpo = (ref.mpopt_adaptive if adaptive else ref.mpopt)(ocp, n_segments, poly_orders, scheme)
     nlp, bounds = mpo.create_nlp()
-    zs, ps = flat_syms(nlp["x"]), flat_syms(nlp["p"])
+    zs, ps = flat_syms(nlp["x"]), ([] if adaptive else flat_syms(nlp["p"]))
     g_exprs = [sp.sympify(e) for e in flat_syms(nlp["g"])]
     f_expr = sp.sympify(nlp["f"].scalar())
     n_z, n_p, n_g = len(zs), len(ps), len(g_exprs)
@@ -123,8 +125,8 @@ def make_case(name, builder, n_segments, poly_orders, scheme):
     assert len(z0) == n_z == len(lbx) and n_g == len(lbg)
 
     z, lam, sigma, rng = problems.sample_point(name, n_z, n_p, n_g, z0, lbx, ubx)
-    p = problems.sample_widths(rng, n_segments, ocp.n_phases)
-    p_equal = np.asarray(mpo.get_segment_width_parameters(None), dtype=float)
+    p = np.zeros(0) if adaptive else problems.sample_widths(rng, n_segments, ocp.n_phases)
+    p_equal = np.zeros(0) if adaptive else np.asarray(mpo.get_segment_width_parameters(None), dtype=float)
     zpos = {s: i for i, s in enumerate(zs)}
     args = zs + ps
 
@@ -293,9 +295,13 @@ def main():
     for name, (builder, s, po, scheme) in problems.GOLDEN_CASES.items():
         if only and name not in only:
             continue
-        if only in (["residuals"], ["hadaptive"]):
+        if only in (["residuals"], ["hadaptive"], ["adaptive"]):
             continue
         make_case(name, builder, s, po, scheme)
+    for name, (builder, s, po, scheme) in problems.ADAPTIVE_CASES.items():
+        if only and name not in only and "adaptive" not in only:
+            continue
+        make_case(name, builder, s, po, scheme, adaptive=True)
     if not only or "hadaptive" in only:
         make_hadaptive()
     for name in RESIDUAL_CASES:

@@ -220,6 +220,16 @@ GOLDEN_CASES = {
 }
 
 
+#: mpopt_adaptive (segment widths as decision variables)
+ADAPTIVE_CASES = {
+    "adaptive_moon_lander_3x2_LGR": (moon_lander, 3, [2, 2, 2], "LGR"),      # the reference's docstring example
+    "adaptive_van_der_pol_mixed_CGL": (van_der_pol, 3, [2, 4, 3], "CGL"),
+    "adaptive_hyper_sensitive_4x3_LGL": (hyper_sensitive, 4, 3, "LGL"),
+    "adaptive_generic_two_phase_LGR": (generic_two_phase, 2, [2, 3], "LGR"),
+    "adaptive_kitchen_sink_mixed_LGR": (kitchen_sink, 2, [3, 2], "LGR"),      # time-dependent, 2 phases, parameters
+}
+
+
 #: (builder, n_segments, poly_orders, scheme) of the BASELINE.json configurations at full size
 BENCH_CASES = [
     (moon_lander, 1000, 5, "LGR"),                                           # configs[1] (the metric's config)

@@ -78,3 +78,32 @@ def test_published_optimum_is_consistent_with_oracle_constraints():
     N = O.N
     z[2 * N:3 * N] = 3.0  # full thrust for tf0 = 4: cost 3*4
     assert O.f(z, np.full(20, 1 / 20)) == pytest.approx(12.0, rel=1e-12)
+
+
+@pytest.mark.parametrize("name", list(problems.ADAPTIVE_CASES))
+def test_adaptive_oracle_matches_reference(name):
+    """mpopt_adaptive: oracle restatement vs. what the reference's own
+    mpopt_adaptive.create_nlp produced through the sympy stand-in for CasADi."""
+    from oracle.mpopt_oracle import OracleAdaptiveNLP
+
+    builder, S, po, scheme = problems.ADAPTIVE_CASES[name]
+    G = load_golden(name)
+    O = OracleAdaptiveNLP(builder(mp, M.math), S, po, scheme)
+    z, lam, sig = G["z"], G["lam"], float(G["sigma"])
+    assert O.n_z == len(z) and O.n_g == len(G["g"]) and O.n_p == 0
+    lbx, ubx, lbg, ubg = O.bounds()
+    for a, b in ((lbx, "lbx"), (ubx, "ubx"), (lbg, "lbg"), (ubg, "ubg")):
+        assert np.array_equal(a, G[b]), b
+    assert np.array_equal(O.initial_guess(), G["z0"])
+    assert rel_err(O.f(z), G["f"]) < TOL and rel_err(O.g(z), G["g"]) < TOL
+    assert rel_err(O.g(G["z0"]), G["g_z0_equal"]) < TOL and rel_err(O.f(G["z0"]), G["f_z0_equal"]) < TOL
+    assert rel_err(O.grad_f(z), G["grad_f"]) < TOL
+    J = O.jac_g(z).toarray()
+    Jr = np.zeros_like(J)
+    Jr[G["jac_row"], G["jac_col"]] = G["jac_val"]
+    assert rel_err(J, Jr) < TOL
+    if O.n_z <= 40:  # whole-NLP sympy Hessians of the larger cases take too long for the CPU tier
+        H = O.hess_l(z, None, sig, lam)
+        Hr = np.zeros_like(H)
+        Hr[G["hess_row"], G["hess_col"]] = G["hess_val"]
+        assert rel_err(H, Hr + np.triu(Hr, 1).T) < TOL
