@@ -219,6 +219,64 @@ int mpx_resid_eval_device(mpx_ctx* ctx, mpx_resid_plan* plan, int64_t batch, con
                           double* resid);
 
 /* ---------------------------------------------------------------------------------------------
+ * Assembled contexts: transcriptions whose NLP has the form
+ *
+ *     f(z) = F . phi(L z),      g(z) = G_z z + g_0 + G . phi(L z)
+ *
+ * with phi a set of generated point functions (collocation nodes, mid-points, phase ends) applied to
+ * local variables that are LINEAR in z, and constant sparse maps around them.  Used for
+ * mpopt_adaptive (reference mpopt.py:2877-3375: segment widths are decision variables, mid-point
+ * residual rows couple all nodes of a segment).  Evaluation is two-stage and reduction-order fixed:
+ *   (1) point kernels (generated code, lane <-> point) write the point values / their structural
+ *       first or second derivatives to a raw buffer;
+ *   (2) one gather kernel forms every output entry as a fixed-order sum  sum_k coef_k * v[src_k]
+ *       over  v = [raw ; z ; 1]  (the products  G * dphi * L  and  L^T * d2phi * L  are expanded once,
+ *       on the host, into these rows).
+ * The context answers mpx_get_sizes / mpx_pattern_* / mpx_ccs_perm / mpx_eval / mpx_eval_device /
+ * the nlp_* symbols like any other; it has no parameters (n_p = 0, `p` may be NULL) and no tiles.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mpx_point_set {
+  int32_t fid;              /* kernels mpx_pt_val_<fid>, mpx_pt_jac_<fid>, mpx_pt_hes_<fid> of the code object */
+  int32_t n_points;
+  int32_t n_loc, n_cst, n_out, n_jac, n_hess; /* sizes of the generated function (checked against nothing: caller's contract) */
+  /* local variable v of point p:  sum_{t < loc_nterm[v]} loc_coef[(toff_v + t) * n_points + p] * z[loc_idx[...same...]] */
+  const int32_t* loc_nterm; /* [n_loc] */
+  const int32_t* loc_idx;
+  const double* loc_coef;
+  const double* cst;        /* [n_cst][n_points] per-point constants */
+  /* Hessian multiplier of output r of point p: same layout over [lam_g ; sigma] (index n_g = sigma) */
+  const int32_t* mu_nterm;  /* [n_out] */
+  const int32_t* mu_idx;
+  const double* mu_coef;
+} mpx_point_set;
+
+/* rows of sums over v = [raw ; z ; 1]:  src >= 0 raw slot, src == -1 the constant 1, src <= -2 z[-2 - src] */
+typedef struct mpx_gather {
+  int64_t n_rows;
+  const int64_t* ptr;   /* [n_rows + 1] */
+  const int32_t* src;
+  const double* coef;
+} mpx_gather;
+
+typedef struct mpx_assembly {
+  int32_t version;      /* MPX_VERSION */
+  int64_t n_z, n_g, nnz_jac, nnz_hess;
+  int32_t n_sets;
+  const mpx_point_set* sets;
+  /* raw slot of (set k, slot q, point p) = raw_off_k + q * n_points_k + p, raw_off_k = running sum of
+   * n_points * (n_out + n_jac) for first-order passes (slots: outputs, then Jacobian entries) and of
+   * n_points * n_hess for the Hessian pass */
+  mpx_gather fgj;       /* rows in order: f, g[n_g], grad_f[n_z], jac_val[nnz_jac] */
+  mpx_gather hess;      /* rows: hess_val[nnz_hess] */
+  const int32_t *jac_row, *jac_col, *hess_row, *hess_col;
+  const void* code_object;
+  size_t code_object_size;
+  int32_t device;
+} mpx_assembly;
+
+int mpx_create_assembled(const mpx_assembly* desc, mpx_ctx** out);
+
+/* ---------------------------------------------------------------------------------------------
  * CasADi-external-compatible surface (mpx_casadi.cpp): the symbols nlp_f, nlp_g, nlp_grad_f,
  * nlp_jac_g, nlp_hess_l (+ _n_in/_n_out/_name_in/_name_out/_sparsity_in/_sparsity_out/_work/
  * _incref/_decref) follow the calling convention of CasADi-generated C code and act on the context

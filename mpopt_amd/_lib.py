@@ -42,7 +42,7 @@ def hipcc():
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("mpx_host.cpp", "mpx_colloc.cpp", "mpx_casadi.cpp", "mpx_device.h")] + [os.path.join(INCLUDE, "mpx.h")]
+    return [os.path.join(CSRC, f) for f in ("mpx_host.cpp", "mpx_assembly.cpp", "mpx_colloc.cpp", "mpx_casadi.cpp", "mpx_device.h", "mpx_internal.h")] + [os.path.join(INCLUDE, "mpx.h")]
 
 
 def _stale(target, deps):
@@ -60,12 +60,15 @@ def build_library(force=False, verbose=False):
     obj = os.path.join(PKG, "mpx_colloc.o")
     hobj = os.path.join(PKG, "mpx_host.o")
     cobj = os.path.join(PKG, "mpx_casadi.o")
+    aobj = os.path.join(PKG, "mpx_assembly.o")
     cmds = [
         ["g++", "-O2", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", os.path.join(CSRC, "mpx_colloc.cpp"), "-o", obj],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", os.path.join(CSRC, "mpx_casadi.cpp"), "-o", cobj],
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
          os.path.join(CSRC, "mpx_host.cpp"), "-o", hobj],
-        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, obj, cobj, "-o", LIB_PATH + ".tmp"],
+        [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
+         os.path.join(CSRC, "mpx_assembly.cpp"), "-o", aobj],
+        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, aobj, obj, cobj, "-o", LIB_PATH + ".tmp"],
     ]
     for cmd in cmds:
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -92,6 +95,29 @@ class mpx_sizes(ctypes.Structure):
                 ("n_z", "n_p", "n_g", "nnz_jac", "nnz_hess", "n_nodes", "n_tiles", "bytes_fgj", "bytes_hess")]
 
 
+class mpx_point_set(ctypes.Structure):
+    _fields_ = [
+        ("fid", ctypes.c_int32), ("n_points", ctypes.c_int32), ("n_loc", ctypes.c_int32), ("n_cst", ctypes.c_int32),
+        ("n_out", ctypes.c_int32), ("n_jac", ctypes.c_int32), ("n_hess", ctypes.c_int32),
+        ("loc_nterm", c_int32_p), ("loc_idx", c_int32_p), ("loc_coef", c_double_p), ("cst", c_double_p),
+        ("mu_nterm", c_int32_p), ("mu_idx", c_int32_p), ("mu_coef", c_double_p),
+    ]
+
+
+class mpx_gather(ctypes.Structure):
+    _fields_ = [("n_rows", ctypes.c_int64), ("ptr", c_int64_p), ("src", c_int32_p), ("coef", c_double_p)]
+
+
+class mpx_assembly(ctypes.Structure):
+    _fields_ = [
+        ("version", ctypes.c_int32), ("n_z", ctypes.c_int64), ("n_g", ctypes.c_int64), ("nnz_jac", ctypes.c_int64),
+        ("nnz_hess", ctypes.c_int64), ("n_sets", ctypes.c_int32), ("sets", ctypes.POINTER(mpx_point_set)),
+        ("fgj", mpx_gather), ("hess", mpx_gather),
+        ("jac_row", c_int32_p), ("jac_col", c_int32_p), ("hess_row", c_int32_p), ("hess_col", c_int32_p),
+        ("code_object", ctypes.c_void_p), ("code_object_size", ctypes.c_size_t), ("device", ctypes.c_int32),
+    ]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -103,6 +129,7 @@ SYMBOLS = {
     "mpx_colloc_quad_weights": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, c_double_p]),
     "mpx_colloc_interp_matrix": (ctypes.c_int, [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p]),
     "mpx_create": (ctypes.c_int, [ctypes.POINTER(mpx_problem), ctypes.POINTER(ctypes.c_void_p)]),
+    "mpx_create_assembled": (ctypes.c_int, [ctypes.POINTER(mpx_assembly), ctypes.POINTER(ctypes.c_void_p)]),
     "mpx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "mpx_get_sizes": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(mpx_sizes)]),
@@ -165,7 +192,7 @@ def compile_kernels(source, verbose=False):
     Cached on disk under mpopt_amd/_jit_cache keyed by the full text of everything compiled."""
     h = hashlib.sha256()
     h.update(source.encode())
-    for dep in ("mpx_kernels.h", "mpx_device.h"):
+    for dep in ("mpx_kernels.h", "mpx_assembly_kernels.h", "mpx_device.h"):
         with open(os.path.join(CSRC, dep), "rb") as f:
             h.update(f.read())
     h.update(os.environ.get("MPX_HIPCC_FLAGS", "").encode())

@@ -1,0 +1,321 @@
+"""Assembled NLP oracles: point functions + constant sparse maps -> libmpx assembled context.
+
+A transcription is handed over as
+
+    f(z) = sum_k  fw_k . phi_k(L_k z),        g(z) = G_z z + g_0 + sum_k G_k phi_k(L_k z)
+
+where every ``phi_k`` is a *point function* (the user's dynamics / path / cost callables traced at a
+collocation node, a mid-point or a phase end), evaluated at ``n_k`` points whose local variables are
+linear in ``z`` (``L_k``: selections and interpolation rows).  From this description the module
+
+  * differentiates each point function symbolically (``mpopt_amd.expr``: structural zeros, like
+    CasADi's SX that the reference relies on, mpopt.py:757) and emits it as HIP device code;
+  * expands  jac_g = G_z + sum_k G_k (dphi_k) L_k,  grad_f = sum_k fw_k (dphi_k) L_k  and
+    hess_l = sum_k L_k^T (sum_r mu_r d2phi_k,r) L_k  ONCE into gather rows over the raw point
+    derivatives (sparsity patterns included), in a fixed term order;
+  * creates the context with ``mpx_create_assembled`` (include/mpx.h).  All arithmetic of an
+    evaluation then happens on the GPU: generated point kernels + one gather kernel.
+
+Used by ``mpopt_adaptive`` (mpopt_amd/adaptive.py).  Nothing here evaluates the NLP on the CPU.
+"""
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import MpxError, mpx_assembly, mpx_gather, mpx_point_set
+from .expr import Tracer
+from .nlp import NlpFunctions
+
+SRC_ONE = -1  # gather source of the constant 1
+
+
+def src_z(col):
+    """Gather source index of z[col]."""
+    return -2 - np.asarray(col, dtype=np.int64)
+
+
+class PointFunction:
+    """``build(loc, cst) -> [out expressions]`` traced once; first derivatives of every output and second
+    derivatives of ``sum_r mu_r out_r`` with respect to the local variables, structural entries only."""
+
+    def __init__(self, n_loc, n_cst, build):
+        tr = self.tr = Tracer()
+        self.n_loc, self.n_cst = int(n_loc), int(n_cst)
+        loc = [tr.var(f"loc[{i}]") for i in range(self.n_loc)]
+        cst = [tr.var(f"cst[{i}]") for i in range(self.n_cst)]
+        self.out = [tr.wrap(e) for e in build(loc, cst)]
+        self.n_out = len(self.out)
+        memo = [dict() for _ in range(self.n_loc)]
+        self.J = []  # (r, v, expr)
+        for r, e in enumerate(self.out):
+            for v in range(self.n_loc):
+                d = tr.diff(e, loc[v], memo[v])
+                if not d.is_zero:
+                    self.J.append((r, v, d))
+        mu = [tr.var(f"mu[{r}]") for r in range(self.n_out)]
+        lag = tr.zero
+        for r, e in enumerate(self.out):
+            lag = lag + mu[r] * e
+        self.H = []  # (v1, v2, expr), v1 <= v2
+        for v1 in range(self.n_loc):
+            g1 = tr.diff(lag, loc[v1], memo[v1])
+            if g1.is_zero:
+                continue
+            for v2 in range(v1, self.n_loc):
+                d2 = tr.diff(g1, loc[v2], memo[v2])
+                if not d2.is_zero:
+                    self.H.append((v1, v2, d2))
+        # which outputs carry second derivatives at all (their multipliers are the only ones gathered)
+        self.n_jac, self.n_hess = len(self.J), len(self.H)
+
+    def source(self, fid):
+        tr = self.tr
+        names = {f"loc[{i}]": f"loc[{i}]" for i in range(self.n_loc)}
+        names.update({f"cst[{i}]": f"cst[{i}]" for i in range(self.n_cst)})
+        names.update({f"mu[{r}]": f"mu[{r}]" for r in range(self.n_out)})
+        sig = "const double* __restrict__ loc, const double* __restrict__ cst"
+        o = [f"template <> struct Pt<{fid}> {{",
+             f"  static constexpr int NLOC = {self.n_loc}, NCST = {self.n_cst}, NOUT = {self.n_out}, NJ = {self.n_jac}, NH = {self.n_hess};",
+             f"  __device__ static __forceinline__ void val({sig}, double* out) {{"]
+        o += tr.emit([(f"out[{r}]", e) for r, e in enumerate(self.out)], names, "    ")
+        o += ["  }", f"  __device__ static __forceinline__ void jac({sig}, double* out, double* J) {{"]
+        o += tr.emit([(f"out[{r}]", e) for r, e in enumerate(self.out)] + [(f"J[{q}]", s[2]) for q, s in enumerate(self.J)], names, "    ")
+        o += ["  }", f"  __device__ static __forceinline__ void hes({sig}, const double* __restrict__ mu, double* H) {{"]
+        o += tr.emit([(f"H[{q}]", s[2]) for q, s in enumerate(self.H)], names, "    ")
+        o += ["  }", "};"]
+        return "\n".join(o)
+
+
+class PointSet:
+    """``n`` points of one point function.
+
+    ``L``   : sparse (n*n_loc, n_z), row p*n_loc + v = local variable v of point p
+    ``cst`` : (n, n_cst) per-point constants
+    ``G``   : sparse (n_g, n*n_out), column p*n_out + r = coefficient of output r of point p in g
+    ``fw``  : (n, n_out) coefficients of the outputs in the objective"""
+
+    def __init__(self, fn, n, L, cst, G, fw):
+        self.fn, self.n = fn, int(n)
+        self.L = sp.csr_matrix(L)
+        self.L.sum_duplicates()
+        self.cst = np.ascontiguousarray(np.asarray(cst, dtype=np.float64).reshape(self.n, fn.n_cst))
+        self.G = sp.csc_matrix(G)
+        self.G.sum_duplicates()
+        self.fw = np.ascontiguousarray(np.asarray(fw, dtype=np.float64).reshape(self.n, fn.n_out))
+        assert self.L.shape[0] == self.n * fn.n_loc and self.G.shape[1] == self.n * fn.n_out
+
+    def _rows(self, v):
+        """CSR slices of the local-variable rows v of all points: (counts, flat point index, col, coef)."""
+        rows = np.arange(self.n) * self.fn.n_loc + v
+        lo, hi = self.L.indptr[rows], self.L.indptr[rows + 1]
+        cnt = hi - lo
+        take = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)]) if cnt.sum() else np.zeros(0, np.int64)
+        return cnt, np.repeat(np.arange(self.n), cnt), self.L.indices[take].astype(np.int64), self.L.data[take]
+
+    def _gcols(self, r):
+        """Entries of G acting on output r of all points: (point, g row, coef)."""
+        cols = np.arange(self.n) * self.fn.n_out + r
+        lo, hi = self.G.indptr[cols], self.G.indptr[cols + 1]
+        cnt = hi - lo
+        take = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)]) if cnt.sum() else np.zeros(0, np.int64)
+        return np.repeat(np.arange(self.n), cnt), self.G.indices[take].astype(np.int64), self.G.data[take]
+
+    @staticmethod
+    def _ell(n, n_var, entries):
+        """entries[v] = (point, index, coef) -> (nterm[v], idx[(toff_v + t) * n + p], coef[...]); padding: index 0, coef 0."""
+        nterm, idx, coef = [], [], []
+        for v in range(n_var):
+            pt, ix, cf = entries[v]
+            cnt = np.bincount(pt, minlength=n) if len(pt) else np.zeros(n, np.int64)
+            T = int(cnt.max()) if n else 0
+            I, C = np.zeros((T, n), np.int32), np.zeros((T, n))
+            if len(pt):
+                order = np.argsort(pt, kind="stable")
+                pt, ix, cf = pt[order], ix[order], cf[order]
+                first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+                t = np.arange(len(pt)) - first[pt]
+                I[t, pt], C[t, pt] = ix, cf
+            nterm.append(T), idx.append(I.ravel()), coef.append(C.ravel())
+        cat = lambda parts, dt: np.ascontiguousarray(np.concatenate(parts) if parts and sum(len(a) for a in parts) else np.zeros(1), dtype=dt)
+        return np.ascontiguousarray(nterm if nterm else [0], dtype=np.int32), cat(idx, np.int32), cat(coef, np.float64)
+
+
+def _csr_from_terms(n_rows, rows, src, coef):
+    rows = np.asarray(rows, dtype=np.int64)
+    order = np.argsort(rows, kind="stable")  # stable: the stored order of a row's terms is the generation order
+    ptr = np.zeros(n_rows + 1, np.int64)
+    np.add.at(ptr, rows + 1, 1)
+    return np.cumsum(ptr), np.ascontiguousarray(np.asarray(src, dtype=np.int64)[order], dtype=np.int32), np.ascontiguousarray(np.asarray(coef, dtype=np.float64)[order])
+
+
+def _cat(parts, dtype):
+    parts = [np.asarray(a, dtype=dtype).ravel() for a in parts]
+    return np.concatenate(parts) if parts else np.zeros(0, dtype)
+
+
+class AssembledNlpFunctions(NlpFunctions):
+    """``NlpFunctions`` over an assembled context: same evaluation / pattern / CasADi-symbol surface, no NLP
+    parameters (``p`` is ignored), no tiles."""
+
+    def __init__(self, n_z, n_g, sets, Gz, g0, device=0, with_device=None, verbose=False):
+        self.n_z_, self.n_g_ = int(n_z), int(n_g)
+        self.sets = list(sets)
+        Gz = sp.coo_matrix(Gz)
+        Gz.sum_duplicates()
+        g0 = np.asarray(g0, dtype=np.float64).reshape(self.n_g_)
+        funcs = []  # distinct point functions -> kernel ids
+        for s in self.sets:
+            if s.fn not in funcs:
+                funcs.append(s.fn)
+        self.functions = funcs
+        self.source = self._source(funcs)
+        self._expand(Gz, g0)
+        if with_device is None:
+            with_device = _lib.gpu_available()
+        self.code_object = None
+        if with_device:
+            self.code_object, self.code_object_path = _lib.compile_kernels(self.source, verbose=verbose)
+        self._create(device)
+
+    # -- generated source ---------------------------------------------------------------------------
+    @staticmethod
+    def _source(funcs):
+        parts = ["// generated by mpopt_amd.assembly -- do not edit", "#include <hip/hip_runtime.h>", "namespace mpxgen {",
+                 "template <int FID> struct Pt;"]
+        parts += [f.source(k) for k, f in enumerate(funcs)]
+        parts += ["}  // namespace mpxgen", '#include "mpx_assembly_kernels.h"']
+        parts += [f"MPX_INSTANTIATE_POINTS({k})" for k in range(len(funcs))]
+        return "\n".join(parts) + "\n"
+
+    # -- expansion of the chain rule into gather rows -------------------------------------------------
+    def _expand(self, Gz, g0):
+        n_z, n_g = self.n_z_, self.n_g_
+        off = offh = 0
+        self.raw_off, self.rawh_off = [], []
+        for s in self.sets:
+            self.raw_off.append(off), self.rawh_off.append(offh)
+            off += s.n * (s.fn.n_out + s.fn.n_jac)
+            offh += s.n * s.fn.n_hess
+        R, S, C = [], [], []  # rows f, g, grad of the first-order gather
+        JK, JS, JC = [Gz.row.astype(np.int64) * n_z + Gz.col], [np.full(Gz.nnz, SRC_ONE, np.int64)], [Gz.data]
+        R.append(1 + Gz.row); S.append(src_z(Gz.col)); C.append(Gz.data)
+        nz0 = np.nonzero(g0)[0]
+        R.append(1 + nz0); S.append(np.full(len(nz0), SRC_ONE)); C.append(g0[nz0])
+        HK, HS, HC = [], [], []
+        for k, s in enumerate(self.sets):
+            fn, n, o = s.fn, s.n, self.raw_off[k]
+            pts = np.arange(n)
+            for r in range(fn.n_out):
+                w = s.fw[:, r]
+                nzp = np.nonzero(w)[0]
+                R.append(np.zeros(len(nzp), np.int64)); S.append(o + r * n + nzp); C.append(w[nzp])
+                gp, gi, gc = s._gcols(r)
+                R.append(1 + gi); S.append(o + r * n + gp); C.append(gc)
+            for q, (r, v, _) in enumerate(fn.J):
+                slot = o + (fn.n_out + q) * n
+                cnt, lp, lc, lv = s._rows(v)  # terms of the local variable, grouped by point
+                # gradient:  fw[p, r] * dphi_r/dv * L[v, c]
+                w = s.fw[lp, r]
+                m = w != 0
+                R.append(1 + n_g + lc[m]); S.append(slot + lp[m]); C.append(w[m] * lv[m])
+                # Jacobian:  G[i, (p, r)] * dphi_r/dv * L[(p, v), c]   (join on the point)
+                gp, gi, gc = s._gcols(r)
+                if len(gp) and len(lp):
+                    first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+                    rep = cnt[gp]
+                    gidx = np.repeat(np.arange(len(gp)), rep)
+                    within = np.arange(rep.sum()) - np.repeat(np.concatenate([[0], np.cumsum(rep)[:-1]]), rep)
+                    li = first[gp][gidx] + within
+                    JK.append(gi[gidx] * n_z + lc[li]); JS.append(slot + gp[gidx]); JC.append(gc[gidx] * lv[li])
+            oh = self.rawh_off[k]
+            for q, (v1, v2, _) in enumerate(fn.H):
+                slot = oh + q * n
+                c1, p1, i1, a1 = s._rows(v1)
+                c2, p2, i2, a2 = s._rows(v2)
+                if not (len(p1) and len(p2)):
+                    continue
+                f2 = np.concatenate([[0], np.cumsum(c2)[:-1]])
+                rep = c2[p1]  # every term of v1 at point p pairs with all terms of v2 at p
+                t1 = np.repeat(np.arange(len(p1)), rep)
+                within = np.arange(rep.sum()) - np.repeat(np.concatenate([[0], np.cumsum(rep)[:-1]]), rep)
+                t2 = f2[p1][t1] + within
+                ca, cb, w = i1[t1], i2[t2], a1[t1] * a2[t2]
+                if v1 == v2:
+                    keep = ca <= cb
+                    ca, cb, w, pp = ca[keep], cb[keep], w[keep], p1[t1][keep]
+                else:
+                    w = np.where(ca == cb, 2.0 * w, w)
+                    ca, cb, pp = np.minimum(ca, cb), np.maximum(ca, cb), p1[t1]
+                HK.append(ca * n_z + cb); HS.append(slot + pp); HC.append(w)
+        # Jacobian / Hessian patterns: distinct keys, column-major (the order CasADi's CCS uses)
+        def pattern(K, S_, C_, by_col):
+            K, S_, C_ = _cat(K, np.int64), _cat(S_, np.int64), _cat(C_, np.float64)
+            rows, cols = K // n_z, K % n_z
+            uniq, inv = np.unique(cols * (max(n_g, n_z) + 1) + rows if by_col else K, return_inverse=True)
+            first = np.zeros(len(uniq), np.int64)
+            first[inv] = np.arange(len(K))
+            return rows[first].astype(np.int32), cols[first].astype(np.int32), inv.astype(np.int64), S_, C_
+
+        self.jrow, self.jcol, jinv, JS, JC = pattern(JK, JS, JC, True)
+        self.hrow, self.hcol, hinv, HS, HC = pattern(HK, HS, HC, True)
+        self.nnz_jac_, self.nnz_hess_ = len(self.jrow), len(self.hrow)
+        rows = np.concatenate([_cat(R, np.int64), 1 + n_g + n_z + jinv])
+        self.fgj = _csr_from_terms(1 + n_g + n_z + self.nnz_jac_, rows, np.concatenate([_cat(S, np.int64), JS]), np.concatenate([_cat(C, np.float64), JC]))
+        self.hess = _csr_from_terms(self.nnz_hess_, hinv, HS, HC)
+        self.raw_n, self.rawh_n = off, offh
+
+    # -- context ----------------------------------------------------------------------------------------
+    def _create(self, device):
+        L = _lib.lib()
+        keep = self._keep = []  # arrays referenced by the descriptor during mpx_create_assembled
+
+        def i32(a):
+            a = np.ascontiguousarray(a, dtype=np.int32)
+            keep.append(a)
+            return a.ctypes.data_as(_lib.c_int32_p)
+
+        def f64(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data_as(_lib.c_double_p)
+
+        def i64(a):
+            a = np.ascontiguousarray(a, dtype=np.int64)
+            keep.append(a)
+            return a.ctypes.data_as(_lib.c_int64_p)
+
+        arr = (mpx_point_set * len(self.sets))()
+        for k, s in enumerate(self.sets):
+            fn, d = s.fn, arr[k]
+            d.fid, d.n_points = self.functions.index(fn), s.n
+            d.n_loc, d.n_cst, d.n_out, d.n_jac, d.n_hess = fn.n_loc, fn.n_cst, fn.n_out, fn.n_jac, fn.n_hess
+            nt, ix, cf = PointSet._ell(s.n, fn.n_loc, [s._rows(v)[1:] for v in range(fn.n_loc)])
+            d.loc_nterm, d.loc_idx, d.loc_coef = i32(nt), i32(ix), f64(cf)
+            d.cst = f64(s.cst.T.copy() if s.cst.size else np.zeros(1))
+            mu = []
+            for r in range(fn.n_out):
+                gp, gi, gc = s._gcols(r)
+                nzp = np.nonzero(s.fw[:, r])[0]
+                mu.append((np.concatenate([gp, nzp]), np.concatenate([gi, np.full(len(nzp), self.n_g_, np.int64)]), np.concatenate([gc, s.fw[nzp, r]])))
+            nt, ix, cf = PointSet._ell(s.n, fn.n_out, mu)
+            d.mu_nterm, d.mu_idx, d.mu_coef = i32(nt), i32(ix), f64(cf)
+        D = mpx_assembly()
+        D.version = 1
+        D.n_z, D.n_g, D.nnz_jac, D.nnz_hess = self.n_z_, self.n_g_, self.nnz_jac_, self.nnz_hess_
+        D.n_sets, D.sets = len(self.sets), arr
+        for dst, (ptr, src, coef) in ((D.fgj, self.fgj), (D.hess, self.hess)):
+            dst.n_rows, dst.ptr, dst.src, dst.coef = len(ptr) - 1, i64(ptr), i32(src if len(src) else np.zeros(1)), f64(coef if len(coef) else np.zeros(1))
+        D.jac_row, D.jac_col, D.hess_row, D.hess_col = i32(self.jrow), i32(self.jcol), i32(self.hrow), i32(self.hcol)
+        if self.code_object is not None:
+            self._co_buf = ctypes.create_string_buffer(self.code_object, len(self.code_object))
+            D.code_object = ctypes.cast(self._co_buf, ctypes.c_void_p)
+            D.code_object_size = len(self.code_object)
+        D.device = int(device)
+        ctx = ctypes.c_void_p()
+        rc = L.mpx_create_assembled(ctypes.byref(D), ctypes.byref(ctx))
+        if rc != 0:
+            raise MpxError(f"mpx_create_assembled failed ({rc}): {L.mpx_last_error(None).decode()}")
+        self._adopt(ctx, L)
+        self._keep = None

@@ -1,0 +1,261 @@
+// mpx_assembly.cpp -- assembled contexts (include/mpx.h: mpx_create_assembled).
+//
+// Host runtime + the gather kernel of the two-stage evaluation used for transcriptions that do not fit
+// the tiled node kernels of mpx_kernels.h -- today mpopt_adaptive (reference mpopt.py:2877-3375), where
+// segment widths are decision variables and the mid-point residual rows (mpopt.py:3088-3124) couple all
+// nodes of a segment.  The structure (which z entries feed a point, which raw values feed an output
+// entry) is expanded once on the host side of the boundary (mpopt_amd/assembly.py); this file only
+// uploads it, launches the generated point kernels and the gather kernel, and owns the buffers.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mpx_internal.h"
+
+using namespace mpxi;
+
+namespace {
+
+struct DevSet {
+  int32_t n = 0, n_loc = 0, n_cst = 0, n_out = 0, n_jac = 0, n_hess = 0;
+  int32_t *loc_toff = nullptr, *loc_idx = nullptr, *mu_toff = nullptr, *mu_idx = nullptr;
+  double *loc_coef = nullptr, *cst = nullptr, *mu_coef = nullptr;
+  int64_t raw_off = 0, rawh_off = 0;
+  hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
+};
+
+struct DevGather {
+  int64_t n_rows = 0, nnz = 0;
+  int64_t* ptr = nullptr;
+  int32_t* src = nullptr;
+  double* coef = nullptr;
+};
+
+}  // namespace
+
+struct mpx_asm_state {
+  std::vector<DevSet> sets;
+  DevGather fgj, hess;
+  int64_t raw_n = 0, rawh_n = 0;
+  DevBuf<double> raw;
+};
+
+// One lane per output row; the row's terms are summed in their stored order for every evaluation
+// point of the lane's batch chunk, so results do not depend on the launch geometry.
+__global__ __launch_bounds__(256) void mpx_gather_kernel(const MpxGatherArgs A) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= A.n_rows) return;
+  int sg = 0;
+  while (sg + 1 < A.n_seg && row >= A.seg_begin[sg + 1]) ++sg;
+  double* out = A.seg_out[sg];
+  if (!out) return;
+  const int64_t local = row - A.seg_begin[sg], stride = A.seg_stride[sg];
+  const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
+  const int b0 = blockIdx.y * A.b_per_block;
+  const int b1 = (b0 + A.b_per_block < A.B) ? b0 + A.b_per_block : A.B;
+  for (int b = b0; b < b1; ++b) {
+    const double* __restrict__ rb = A.raw + (int64_t)b * A.raw_stride;
+    const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
+    double s = 0;
+    for (int64_t e = e0; e < e1; ++e) {
+      const int32_t k = A.src[e];
+      const double v = k >= 0 ? rb[k] : (k == -1 ? 1.0 : zb[-2 - k]);
+      s = fma(A.coef[e], v, s);
+    }
+    out[(int64_t)b * stride + local] = s;
+  }
+}
+
+namespace {
+
+template <class T>
+int upload_n(mpx_ctx* c, T** dst, const T* src, size_t n) {
+  HIPCHK(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) HIPCHK(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return MPX_OK;
+}
+
+int upload_gather(mpx_ctx* c, DevGather& d, const mpx_gather& g, int64_t raw_n, int64_t n_z, const char* what) {
+  if (g.n_rows < 0 || (g.n_rows && (!g.ptr || g.ptr[0] != 0))) return fail(c, MPX_ERR_INVALID, "%s: bad row pointers", what);
+  d.n_rows = g.n_rows;
+  d.nnz = g.n_rows ? g.ptr[g.n_rows] : 0;
+  for (int64_t r = 0; r < g.n_rows; ++r)
+    if (g.ptr[r + 1] < g.ptr[r]) return fail(c, MPX_ERR_INVALID, "%s: row pointers decrease", what);
+  for (int64_t e = 0; e < d.nnz; ++e) {
+    const int64_t k = g.src[e];
+    if (k >= raw_n || (k <= -2 && -2 - k >= n_z)) return fail(c, MPX_ERR_INVALID, "%s: source %lld out of range", what, (long long)k);
+  }
+  int rc;
+  std::vector<int64_t> one(1, 0);
+  if ((rc = upload_n(c, &d.ptr, g.n_rows ? g.ptr : one.data(), (size_t)g.n_rows + 1))) return rc;
+  if ((rc = upload_n(c, &d.src, g.src, (size_t)d.nnz))) return rc;
+  return upload_n(c, &d.coef, g.coef, (size_t)d.nnz);
+}
+
+int check_terms(mpx_ctx* c, const int32_t* nterm, int nv, const int32_t* idx, int64_t n, int64_t limit, std::vector<int32_t>& toff, const char* what) {
+  toff.assign((size_t)nv + 1, 0);
+  for (int v = 0; v < nv; ++v) {
+    if (nterm[v] < 0) return fail(c, MPX_ERR_INVALID, "%s: negative term count", what);
+    toff[v + 1] = toff[v] + nterm[v];
+  }
+  const int64_t tot = (int64_t)toff[nv] * n;
+  for (int64_t e = 0; e < tot; ++e)
+    if (idx[e] < 0 || idx[e] >= limit) return fail(c, MPX_ERR_INVALID, "%s: index %d out of range", what, idx[e]);
+  return MPX_OK;
+}
+
+}  // namespace
+
+void mpx_asm_release(mpx_ctx* c) {
+  mpx_asm_state* a = c->assembled;
+  if (!a) return;
+  auto fr = [](void* p) {
+    if (p) (void)hipFree(p);
+  };
+  for (auto& s : a->sets) fr(s.loc_toff), fr(s.loc_idx), fr(s.mu_toff), fr(s.mu_idx), fr(s.loc_coef), fr(s.cst), fr(s.mu_coef);
+  for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef);
+  fr(a->raw.p);
+  delete a;
+  c->assembled = nullptr;
+}
+
+extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
+  if (!D || !out) return fail(nullptr, MPX_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (D->version != MPX_VERSION) return fail(nullptr, MPX_ERR_INVALID, "mpx_assembly.version %d != %d", D->version, MPX_VERSION);
+  if (D->n_z < 1 || D->n_g < 0 || D->nnz_jac < 0 || D->nnz_hess < 0 || D->n_sets < 1 || !D->sets)
+    return fail(nullptr, MPX_ERR_INVALID, "bad dimensions");
+  if (D->n_z >= (1LL << 30) || D->n_g >= (1LL << 30)) return fail(nullptr, MPX_ERR_UNSUPPORTED, "problem too large for int32 indices");
+  if (D->fgj.n_rows != 1 + D->n_g + D->n_z + D->nnz_jac || D->hess.n_rows != D->nnz_hess)
+    return fail(nullptr, MPX_ERR_INVALID, "gather row counts do not match the sizes");
+  if ((D->nnz_jac && (!D->jac_row || !D->jac_col)) || (D->nnz_hess && (!D->hess_row || !D->hess_col)))
+    return fail(nullptr, MPX_ERR_INVALID, "missing patterns");
+  mpx_ctx* c = new (std::nothrow) mpx_ctx;
+  if (!c) return fail(nullptr, MPX_ERR_ALLOC, "out of memory");
+  c->kind = 1;
+  c->device = D->device;
+  c->n_z = D->n_z;
+  c->n_g = D->n_g;
+  c->n_p = 0;
+  c->nnz_j = D->nnz_jac;
+  c->nnz_h = D->nnz_hess;
+  c->jrow.assign(D->jac_row, D->jac_row + D->nnz_jac);
+  c->jcol.assign(D->jac_col, D->jac_col + D->nnz_jac);
+  c->hrow.assign(D->hess_row, D->hess_row + D->nnz_hess);
+  c->hcol.assign(D->hess_col, D->hess_col + D->nnz_hess);
+  int rc = MPX_OK;
+  for (int64_t k = 0; k < D->nnz_jac && !rc; ++k)
+    if (c->jrow[k] < 0 || c->jrow[k] >= D->n_g || c->jcol[k] < 0 || c->jcol[k] >= D->n_z) rc = fail(c, MPX_ERR_INVALID, "jac pattern out of range");
+  for (int64_t k = 0; k < D->nnz_hess && !rc; ++k)
+    if (c->hrow[k] < 0 || c->hrow[k] > c->hcol[k] || c->hcol[k] >= D->n_z) rc = fail(c, MPX_ERR_INVALID, "hess pattern must be upper triangular and in range");
+  auto bail = [&](int code) {
+    create_error() = c->err;
+    mpx_destroy(c);
+    return code;
+  };
+  if (rc) return bail(rc);
+  if (!D->code_object) {  // structure-only context (patterns and sizes); evaluation fails loudly
+    *out = c;
+    return MPX_OK;
+  }
+  if (hipSetDevice(c->device) != hipSuccess) return bail(fail(c, MPX_ERR_NO_DEVICE, "no usable HIP device %d", c->device));
+  if (hipModuleLoadData(&c->module, D->code_object) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "hipModuleLoadData failed (is the code object built for this GPU?)"));
+  mpx_asm_state* a = c->assembled = new mpx_asm_state;
+  a->sets.resize(D->n_sets);
+  static const char* kind[3] = {"val", "jac", "hes"};
+  for (int k = 0; k < D->n_sets; ++k) {
+    const mpx_point_set& S = D->sets[k];
+    DevSet& d = a->sets[k];
+    if (S.n_points < 1 || S.n_loc < 0 || S.n_cst < 0 || S.n_out < 0 || S.n_jac < 0 || S.n_hess < 0) return bail(fail(c, MPX_ERR_INVALID, "point set %d: bad sizes", k));
+    d.n = S.n_points, d.n_loc = S.n_loc, d.n_cst = S.n_cst, d.n_out = S.n_out, d.n_jac = S.n_jac, d.n_hess = S.n_hess;
+    std::vector<int32_t> toff, moff;
+    if ((rc = check_terms(c, S.loc_nterm, S.n_loc, S.loc_idx, S.n_points, D->n_z, toff, "local variables"))) return bail(rc);
+    if ((rc = check_terms(c, S.mu_nterm, S.n_out, S.mu_idx, S.n_points, D->n_g + 1, moff, "multipliers"))) return bail(rc);
+    if ((rc = upload(c, &d.loc_toff, toff)) || (rc = upload(c, &d.mu_toff, moff))) return bail(rc);
+    if ((rc = upload_n(c, &d.loc_idx, S.loc_idx, (size_t)toff.back() * d.n)) || (rc = upload_n(c, &d.loc_coef, S.loc_coef, (size_t)toff.back() * d.n)) ||
+        (rc = upload_n(c, &d.mu_idx, S.mu_idx, (size_t)moff.back() * d.n)) || (rc = upload_n(c, &d.mu_coef, S.mu_coef, (size_t)moff.back() * d.n)) ||
+        (rc = upload_n(c, &d.cst, S.cst, (size_t)S.n_cst * d.n)))
+      return bail(rc);
+    d.raw_off = a->raw_n;
+    d.rawh_off = a->rawh_n;
+    a->raw_n += (int64_t)d.n * (d.n_out + d.n_jac);
+    a->rawh_n += (int64_t)d.n * d.n_hess;
+    for (int m = 0; m < 3; ++m) {
+      const std::string name = std::string("mpx_pt_") + kind[m] + "_" + std::to_string(S.fid);
+      if (hipModuleGetFunction(&d.fn[m], c->module, name.c_str()) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "kernel %s missing from the code object", name.c_str()));
+    }
+  }
+  if (a->raw_n >= (1LL << 31) || a->rawh_n >= (1LL << 31)) return bail(fail(c, MPX_ERR_UNSUPPORTED, "raw buffer too large for int32 sources"));
+  if ((rc = upload_gather(c, a->fgj, D->fgj, a->raw_n, D->n_z, "fgj gather")) || (rc = upload_gather(c, a->hess, D->hess, a->rawh_n, D->n_z, "hess gather")))
+    return bail(rc);
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "hipEventCreate failed"));
+  c->has_device = true;
+  *out = c;
+  return MPX_OK;
+}
+
+static int launch_points(mpx_ctx* c, int mode, int64_t batch, const double* z, const double* lam, const double* sigma) {
+  mpx_asm_state* a = c->assembled;
+  const int64_t stride = mode == MPX_MODE_HESS ? a->rawh_n : a->raw_n;
+  const int bpb = (int)std::max<int64_t>(1, (batch + 4095) / 4096);
+  for (auto& d : a->sets) {
+    if (mode == MPX_MODE_HESS && d.n_hess == 0) continue;
+    if (mode != MPX_MODE_HESS && d.n_out + (mode == MPX_MODE_FGJ ? d.n_jac : 0) == 0) continue;
+    MpxPtArgs A{};
+    A.n = d.n, A.n_g = (int32_t)c->n_g, A.B = (int32_t)batch, A.b_per_block = bpb;
+    A.loc_toff = d.loc_toff, A.loc_idx = d.loc_idx, A.loc_coef = d.loc_coef, A.cst = d.cst;
+    A.mu_toff = d.mu_toff, A.mu_idx = d.mu_idx, A.mu_coef = d.mu_coef;
+    A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma;
+    A.raw = c->assembled->raw.p + (mode == MPX_MODE_HESS ? d.rawh_off : d.raw_off);
+    A.raw_stride = stride;
+    size_t sz = sizeof(A);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    HIPCHK(c, hipModuleLaunchKernel(d.fn[mode], (unsigned)((d.n + 63) / 64), (unsigned)((batch + bpb - 1) / bpb), 1, 64, 1, 1, 0, c->stream, nullptr, cfg));
+  }
+  return MPX_OK;
+}
+
+static int launch_gather(mpx_ctx* c, const DevGather& g, int64_t batch, const double* z, int64_t raw_stride, int n_seg, const int64_t* seg_begin,
+                         double* const* seg_out, const int64_t* seg_stride) {
+  if (g.n_rows == 0) return MPX_OK;
+  MpxGatherArgs A{};
+  A.n_rows = g.n_rows, A.ptr = g.ptr, A.src = g.src, A.coef = g.coef;
+  A.raw = c->assembled->raw.p, A.raw_stride = raw_stride, A.z = z, A.z_stride = c->n_z;
+  A.n_seg = n_seg;
+  for (int k = 0; k < n_seg; ++k) A.seg_begin[k] = seg_begin[k], A.seg_out[k] = seg_out[k], A.seg_stride[k] = seg_stride[k];
+  A.seg_begin[n_seg] = g.n_rows;
+  A.B = (int32_t)batch;
+  A.b_per_block = (int)std::max<int64_t>(1, (batch + 4095) / 4096);
+  hipLaunchKernelGGL(mpx_gather_kernel, dim3((unsigned)((g.n_rows + 255) / 256), (unsigned)((batch + A.b_per_block - 1) / A.b_per_block)), dim3(256), 0,
+                     c->stream, A);
+  HIPCHK(c, hipGetLastError());
+  return MPX_OK;
+}
+
+// Device-pointer evaluation of an assembled context (called from eval_core in mpx_host.cpp after the
+// argument checks).  All pointers are device pointers.
+int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* lam_g, const double* sigma, double* f, double* g,
+                        double* grad_f, double* jac_val, double* hess_val) {
+  mpx_asm_state* a = c->assembled;
+  if (mask & (MPX_BOUNDARY_ONLY | MPX_JAC_VARIABLE_ONLY)) return fail(c, MPX_ERR_UNSUPPORTED, "mask bit not available on assembled contexts");
+  int rc;
+  if ((rc = reserve(c, a->raw, (size_t)(batch * std::max(a->raw_n, a->rawh_n))))) return rc;
+  if (mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC)) {
+    const int mode = (mask & (MPX_GRAD | MPX_JAC)) ? MPX_MODE_FGJ : MPX_MODE_FG;
+    if ((rc = launch_points(c, mode, batch, z, nullptr, nullptr))) return rc;
+    const int64_t begin[4] = {0, 1, 1 + c->n_g, 1 + c->n_g + c->n_z};
+    double* outp[4] = {(mask & MPX_F) ? f : nullptr, (mask & MPX_G) ? g : nullptr, (mask & MPX_GRAD) ? grad_f : nullptr, (mask & MPX_JAC) ? jac_val : nullptr};
+    const int64_t stride[4] = {1, c->n_g, c->n_z, c->nnz_j};
+    if ((rc = launch_gather(c, a->fgj, batch, z, a->raw_n, 4, begin, outp, stride))) return rc;
+  }
+  if (mask & MPX_HESS) {
+    if ((rc = launch_points(c, MPX_MODE_HESS, batch, z, lam_g, sigma))) return rc;
+    const int64_t begin[1] = {0};
+    double* outp[1] = {hess_val};
+    const int64_t stride[1] = {c->nnz_h};
+    if ((rc = launch_gather(c, a->hess, batch, z, a->rawh_n, 1, begin, outp, stride))) return rc;
+  }
+  return MPX_OK;
+}

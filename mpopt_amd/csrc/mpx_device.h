@@ -112,4 +112,38 @@ struct MpxResidArgs {
 };
 
 #define MPX_ACCUM_BIT (1LL << 62)
+
+// ---- assembled contexts (mpx_create_assembled) ---------------------------------------------------
+struct MpxPtArgs {
+  int32_t n, n_g, B, b_per_block;
+  const int32_t* loc_toff;  // [NLOC + 1] running term offsets
+  const int32_t* loc_idx;   // [terms][n]
+  const double* loc_coef;
+  const double* cst;        // [NCST][n]
+  const int32_t* mu_toff;   // [NOUT + 1]
+  const int32_t* mu_idx;
+  const double* mu_coef;
+  const double* z;
+  int64_t z_stride;
+  const double* lam;
+  int64_t lam_stride;
+  const double* sigma;
+  double* raw;              // already offset to this set's block
+  int64_t raw_stride;
+};
+
+struct MpxGatherArgs {
+  int64_t n_rows;
+  const int64_t* ptr;
+  const int32_t* src;
+  const double* coef;
+  const double* raw;
+  int64_t raw_stride;
+  const double* z;
+  int64_t z_stride;
+  int64_t seg_begin[5];     // row ranges of up to four output arrays
+  double* seg_out[4];       // NULL: not requested
+  int64_t seg_stride[4];
+  int32_t n_seg, B, b_per_block;
+};
 #endif

@@ -23,135 +23,19 @@
 #include "mpx.h"
 #include "mpx_device.h"
 
-namespace {
+#include "mpx_internal.h"
 
-thread_local std::string g_create_error;
+using namespace mpxi;
 
-struct Entry4 {
-  int32_t a, b, c, d;
-};
-struct PhaseStruct {
-  int nc = 0, ntc = 0, diff_u = 0, midu = 0, du_cont = 0;
-  std::vector<Entry4> jv, hn, hc, th;
-  std::vector<std::pair<int32_t, int32_t>> mg;
-  struct TJ {
-    int32_t row, kind, comp;
-  };
-  std::vector<TJ> tj;
-  // layout
-  int64_t z_off = 0, g_off_F = 0, g_off_C = 0, g_off_DU = 0, g_off_mU = 0, g_off_dU = 0, g_off_TC = 0;
-  int64_t jac_TC = 0;
-  int tile_first = 0, tile_count = 0;
-};
-
-struct DegTable {
-  int deg = 0;
-  std::vector<double> roots, D, Cmid, w, tk;
-  double *d_D = nullptr, *d_Cmid = nullptr, *d_tk = nullptr;
-};
-
-struct Bucket {
-  int phase = 0, deg = 0, dt = 0;  // dt: index into degree tables
-  std::vector<int32_t> node_i, node_sk;
-  int tile_first = 0, tile_count = 0;  // global tile ids
-  int32_t *d_node_i = nullptr, *d_node_sk = nullptr;
-  hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
-};
-
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t cap = 0;
-};
-
-}  // namespace
-
-struct mpx_ctx {
-  std::string err;
-  // problem
-  int n_phases = 0, nx = 0, nu = 0, na = 0, S = 0, scheme = 0, device = 0;
-  double tau0 = -1, tau1 = 1;
-  std::vector<int32_t> orders, seg_start, links;
-  std::vector<PhaseStruct> ph;
-  int64_t N = 0, n_zp = 0, n_z = 0, n_g = 0, n_p = 0, nnz_j = 0, nnz_h = 0;
-  std::vector<DegTable> degs;
-  std::vector<Bucket> buckets;
-  std::vector<MpxTile> tiles;  // global, phase-major, bucket-major
-  std::vector<double> compW;
-  std::vector<int32_t> jrow, jcol, hrow, hcol;
-  // linear rows
-  std::vector<int64_t> lin_ptr, lin_idx, lin_row;
-  std::vector<double> lin_coef;
-  int64_t lin_jac = 0, jac_tiles_end = 0;
-  std::vector<int64_t> mg_dst, hc_dst, th_dst;
-  std::vector<int32_t> mg_off, hc_off, th_off;
-  int nred = 1;
-  // device
-  bool has_device = false;
-  hipModule_t module = nullptr;
-  hipFunction_t fn_bound[3] = {nullptr, nullptr, nullptr};
-  hipStream_t stream = nullptr;
-  MpxTile* d_tiles = nullptr;
-  double* d_Wnode = nullptr;
-  int32_t* d_seg_start = nullptr;
-  int64_t *d_lin_ptr = nullptr, *d_lin_idx = nullptr, *d_lin_row = nullptr, *d_mg_dst = nullptr,
-          *d_hc_dst = nullptr, *d_th_dst = nullptr;
-  double* d_lin_coef = nullptr;
-  DevBuf<double> partial, wcum, st_z, st_p, st_lam, st_sig, st_f, st_g, st_grad, st_jac, st_hess;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int64_t tile_begin = 0, tile_end = 0;
-  int run_boundary = 1;
-  // host path: widths of the previous mpx_eval (IPOPT never changes p between oracle calls, so the
-  // upload and the prefix-sum launch are skipped while p is unchanged)
-  std::vector<double> last_p;
-  bool wcum_valid = false;
-  // per-kernel profiling
-  int profile = 0;
-  std::vector<hipEvent_t> prof_ev;  // pairs
-  size_t prof_used = 0;
-  int64_t prof_launches = 0;
-};
+namespace mpxi {
+std::string& create_error() {
+  thread_local std::string e;
+  return e;
+}
+}  // namespace mpxi
+#define g_create_error (mpxi::create_error())
 
 namespace {
-
-int fail(mpx_ctx* c, int code, const char* fmt, ...) {
-  char buf[1024];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  if (c)
-    c->err = buf;
-  else
-    g_create_error = buf;
-  return code;
-}
-
-#define HIPCHK(ctx, call)                                                                        \
-  do {                                                                                           \
-    hipError_t e_ = (call);                                                                      \
-    if (e_ != hipSuccess)                                                                        \
-      return fail(ctx, MPX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-
-template <class T>
-int upload(mpx_ctx* c, T** dst, const std::vector<T>& v) {
-  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
-  HIPCHK(c, hipMalloc((void**)dst, bytes));
-  if (!v.empty()) HIPCHK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  return MPX_OK;
-}
-
-template <class T>
-int reserve(mpx_ctx* c, DevBuf<T>& b, size_t n) {
-  if (n <= b.cap) return MPX_OK;
-  if (b.p) HIPCHK(c, hipFree(b.p));
-  b.p = nullptr;
-  b.cap = 0;
-  HIPCHK(c, hipMalloc((void**)&b.p, n * sizeof(T)));
-  b.cap = n;
-  return MPX_OK;
-}
 
 // global z index of a node variable
 inline int64_t zcol(const mpx_ctx& c, const PhaseStruct& P, int kind, int comp, int64_t i) {
@@ -753,6 +637,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
   if (!c) return MPX_OK;
   if (c->has_device || c->module) {
     (void)hipSetDevice(c->device);
+    mpx_asm_release(c);
     auto fr = [](void* p) {
       if (p) (void)hipFree(p);
     };
@@ -813,7 +698,7 @@ extern "C" int mpx_ccs_perm(const mpx_ctx* c, int which, int64_t* perm, int64_t*
 }
 
 extern "C" int mpx_get_comp_weights(const mpx_ctx* c, double* w) {
-  if (!c || !w) return MPX_ERR_INVALID;
+  if (!c || !w || c->kind != 0) return MPX_ERR_INVALID;
   memcpy(w, c->compW.data(), c->compW.size() * sizeof(double));
   return MPX_OK;
 }
@@ -826,6 +711,7 @@ extern "C" int mpx_set_stream(mpx_ctx* c, void* stream) {
 
 extern "C" int mpx_set_tile_range(mpx_ctx* c, int64_t b, int64_t e, int run_boundary) {
   if (!c || b < 0 || e > (int64_t)c->tiles.size() || b > e) return fail(c, MPX_ERR_INVALID, "bad tile range");
+  if (c->kind != 0) return fail(c, MPX_ERR_UNSUPPORTED, "assembled contexts have no tiles");
   c->tile_begin = b;
   c->tile_end = e;
   c->run_boundary = run_boundary;
@@ -1115,13 +1001,14 @@ static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const
   if (!c) return MPX_ERR_INVALID;
   if (!c->has_device)
     return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
-  if (batch < 1 || batch > (1 << 30) || !z || !p) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
+  if (batch < 1 || batch > (1 << 30) || !z || (!p && c->n_p > 0)) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
   if ((mask & MPX_HESS) && (!lam_g || !sigma || !hess_val)) return fail(c, MPX_ERR_INVALID, "mpx_eval: HESS needs lam_g, sigma, hess_val");
   if ((mask & MPX_F) && !f) return fail(c, MPX_ERR_INVALID, "mpx_eval: f is NULL");
   if ((mask & MPX_G) && !g) return fail(c, MPX_ERR_INVALID, "mpx_eval: g is NULL");
   if ((mask & MPX_GRAD) && !grad_f) return fail(c, MPX_ERR_INVALID, "mpx_eval: grad_f is NULL");
   if ((mask & MPX_JAC) && !jac_val) return fail(c, MPX_ERR_INVALID, "mpx_eval: jac_val is NULL");
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->kind == 1) return mpx_asm_eval_device(c, mask, batch, z, lam_g, sigma, f, g, grad_f, jac_val, hess_val);
   const int64_t n_w = p_per_point ? batch : 1;
   int rc;
   if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
@@ -1172,14 +1059,14 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   if (!c) return MPX_ERR_INVALID;
   if (!c->has_device)
     return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
-  if (batch < 1 || !z || !p) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
+  if (batch < 1 || !z || (!p && c->n_p > 0)) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   const size_t B = (size_t)batch;
   const size_t npv = (size_t)(p_per_point ? batch : 1) * c->n_p;
   const size_t cap_p = c->st_p.cap, cap_w = c->wcum.cap;
   if ((rc = reserve(c, c->st_z, B * c->n_z)) || (rc = reserve(c, c->st_p, npv)) || (rc = reserve(c, c->wcum, npv))) return rc;
-  const bool same_p = c->wcum_valid && cap_p == c->st_p.cap && cap_w == c->wcum.cap && c->last_p.size() == npv &&
+  const bool same_p = npv == 0 || c->wcum_valid && cap_p == c->st_p.cap && cap_w == c->wcum.cap && c->last_p.size() == npv &&
                       memcmp(c->last_p.data(), p, npv * 8) == 0;
   HIPCHK(c, hipMemcpyAsync(c->st_z.p, z, B * c->n_z * 8, hipMemcpyHostToDevice, c->stream));
   if (!same_p) {

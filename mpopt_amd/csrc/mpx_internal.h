@@ -1,0 +1,155 @@
+// mpx_internal.h -- state shared by the translation units of libmpx (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "mpx.h"
+#include "mpx_device.h"
+
+namespace mpxi {
+
+std::string& create_error();  // thread-local message of a failed mpx_create*
+
+struct Entry4 {
+  int32_t a, b, c, d;
+};
+struct PhaseStruct {
+  int nc = 0, ntc = 0, diff_u = 0, midu = 0, du_cont = 0;
+  std::vector<Entry4> jv, hn, hc, th;
+  std::vector<std::pair<int32_t, int32_t>> mg;
+  struct TJ {
+    int32_t row, kind, comp;
+  };
+  std::vector<TJ> tj;
+  // layout
+  int64_t z_off = 0, g_off_F = 0, g_off_C = 0, g_off_DU = 0, g_off_mU = 0, g_off_dU = 0, g_off_TC = 0;
+  int64_t jac_TC = 0;
+  int tile_first = 0, tile_count = 0;
+};
+
+struct DegTable {
+  int deg = 0;
+  std::vector<double> roots, D, Cmid, w, tk;
+  double *d_D = nullptr, *d_Cmid = nullptr, *d_tk = nullptr;
+};
+
+struct Bucket {
+  int phase = 0, deg = 0, dt = 0;  // dt: index into degree tables
+  std::vector<int32_t> node_i, node_sk;
+  int tile_first = 0, tile_count = 0;  // global tile ids
+  int32_t *d_node_i = nullptr, *d_node_sk = nullptr;
+  hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
+};
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace mpxi
+
+struct mpx_asm_state;  // mpx_assembly.cpp
+using namespace mpxi;
+
+struct mpx_ctx {
+  // 0: structured collocation context (mpx_create); 1: assembled context (mpx_create_assembled)
+  int kind = 0;
+  mpx_asm_state* assembled = nullptr;
+  std::string err;
+  // problem
+  int n_phases = 0, nx = 0, nu = 0, na = 0, S = 0, scheme = 0, device = 0;
+  double tau0 = -1, tau1 = 1;
+  std::vector<int32_t> orders, seg_start, links;
+  std::vector<PhaseStruct> ph;
+  int64_t N = 0, n_zp = 0, n_z = 0, n_g = 0, n_p = 0, nnz_j = 0, nnz_h = 0;
+  std::vector<DegTable> degs;
+  std::vector<Bucket> buckets;
+  std::vector<MpxTile> tiles;  // global, phase-major, bucket-major
+  std::vector<double> compW;
+  std::vector<int32_t> jrow, jcol, hrow, hcol;
+  // linear rows
+  std::vector<int64_t> lin_ptr, lin_idx, lin_row;
+  std::vector<double> lin_coef;
+  int64_t lin_jac = 0, jac_tiles_end = 0;
+  std::vector<int64_t> mg_dst, hc_dst, th_dst;
+  std::vector<int32_t> mg_off, hc_off, th_off;
+  int nred = 1;
+  // device
+  bool has_device = false;
+  hipModule_t module = nullptr;
+  hipFunction_t fn_bound[3] = {nullptr, nullptr, nullptr};
+  hipStream_t stream = nullptr;
+  MpxTile* d_tiles = nullptr;
+  double* d_Wnode = nullptr;
+  int32_t* d_seg_start = nullptr;
+  int64_t *d_lin_ptr = nullptr, *d_lin_idx = nullptr, *d_lin_row = nullptr, *d_mg_dst = nullptr,
+          *d_hc_dst = nullptr, *d_th_dst = nullptr;
+  double* d_lin_coef = nullptr;
+  DevBuf<double> partial, wcum, st_z, st_p, st_lam, st_sig, st_f, st_g, st_grad, st_jac, st_hess;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int64_t tile_begin = 0, tile_end = 0;
+  int run_boundary = 1;
+  // host path: widths of the previous mpx_eval (IPOPT never changes p between oracle calls, so the
+  // upload and the prefix-sum launch are skipped while p is unchanged)
+  std::vector<double> last_p;
+  bool wcum_valid = false;
+  // per-kernel profiling
+  int profile = 0;
+  std::vector<hipEvent_t> prof_ev;  // pairs
+  size_t prof_used = 0;
+  int64_t prof_launches = 0;
+};
+
+namespace mpxi {
+
+inline int fail(mpx_ctx* c, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    create_error() = buf;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(ctx, MPX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <class T>
+inline int upload(mpx_ctx* c, T** dst, const std::vector<T>& v) {
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  HIPCHK(c, hipMalloc((void**)dst, bytes));
+  if (!v.empty()) HIPCHK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return MPX_OK;
+}
+
+template <class T>
+inline int reserve(mpx_ctx* c, DevBuf<T>& b, size_t n) {
+  if (n <= b.cap) return MPX_OK;
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  HIPCHK(c, hipMalloc((void**)&b.p, n * sizeof(T)));
+  b.cap = n;
+  return MPX_OK;
+}
+
+}  // namespace mpxi
+
+// mpx_assembly.cpp
+void mpx_asm_release(mpx_ctx* c);
+int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* lam_g, const double* sigma, double* f, double* g,
+                        double* grad_f, double* jac_val, double* hess_val);

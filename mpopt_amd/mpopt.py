@@ -969,6 +969,191 @@ class mpopt_h_adaptive(mpopt):
         return np.asarray(w, float) / (tf - t0)
 
 
+class mpopt_adaptive(mpopt):
+    """Segment widths as decision variables, solved for together with the trajectories
+    (mpopt.py:2877-3375).  Per phase Z = [X; U; t0; tf; A; W] and G = [F; C; DU; TC; SW] with
+    SW = [sum(W) - 1; mid-point controls; mid-point states; W_s * mid-point dynamics residuals].
+    The NLP oracles run on the GPU through an assembled libmpx context (mpopt_amd/adaptive.py);
+    post-processing (trajectories, residuals) reuses the fixed-width machinery with the optimal widths.
+
+    Examples :
+        >>> ocp = mp.OCP(n_states=2, n_controls=1, n_phases=1)
+        >>> ocp.dynamics[0] = lambda x, u, t: [x[1], u[0] - 1.5]
+        >>> ocp.running_costs[0] = lambda x, u, t: u[0]
+        >>> ocp.terminal_constraints[0] = lambda xf, tf, x0, t0: [xf[0], xf[1]]
+        >>> ocp.x00[0] = [10, -2]; ocp.lbu[0] = 0; ocp.ubu[0] = 3; ocp.lbtf[0] = 3; ocp.ubtf[0] = 5
+        >>> opt = mp.mpopt_adaptive(ocp, n_segments=3, poly_orders=[2]*3)
+        >>> solution = opt.solve()
+    """
+
+    _SEG_WIDTH_MIN = 1e-4
+    _SEG_WIDTH_MAX = 1.0
+    _TOL_RESIDUAL = 1e-3
+
+    def __init__(self, problem, n_segments=1, poly_orders=[9], scheme="LGR", **kwargs):
+        super().__init__(problem, n_segments=n_segments, poly_orders=poly_orders, scheme=scheme, **kwargs)
+        self.mid_residuals = True
+        n_ph = self._ocp.n_phases
+        self.lbh = [self._SEG_WIDTH_MIN] * n_ph
+        self.ubh = [self._SEG_WIDTH_MAX] * n_ph
+        self.tol_residual = [self._TOL_RESIDUAL] * n_ph
+        self._post = None
+
+    def _n_zp(self):
+        o = self._ocp
+        return self._Npoints * (o.nx + o.nu) + 2 + o.na + self.n_segments
+
+    def get_nlp_variables(self, phase=0):
+        """(Z, Zmin, Zmax): the base layout followed by the S segment widths (mpopt.py:2927-2979)."""
+        sym, zmin, zmax = super().get_nlp_variables(phase)
+        S = self.n_segments
+        zmin = np.concatenate([zmin, np.full(S, float(self.lbh[phase]))])
+        zmax = np.concatenate([zmax, np.full(S, float(self.ubh[phase]))])
+        return (_NlpSymbol(f"z{phase}", len(zmin), self.oracle), zmin, zmax)
+
+    def init_solution_per_phase(self, phase):
+        return np.concatenate([super().init_solution_per_phase(phase), np.full(self.n_segments, 1.0 / self.n_segments)])
+
+    def _bounded(self, phase):
+        o = self._ocp
+        fin = lambda lo, hi: bool((np.asarray(lo, float) > -np.inf).any() or (np.asarray(hi, float) < np.inf).any())
+        return fin(o.lbu[phase], o.ubu[phase]), fin(o.lbx[phase], o.ubx[phase])
+
+    def get_nlp_constrains_for_segment_widths(self, phase=0):
+        """(SW, SWmin, SWmax) (mpopt.py:3034-3136); SW is a handle, the rows live in the GPU oracle."""
+        o, n_mid = self._ocp, self._Npoints - 1
+        lo, hi = [np.zeros(1)], [np.zeros(1)]
+        u_b, x_b = self._bounded(phase)
+        if u_b:
+            lo.append(np.repeat(np.asarray(o.lbu[phase], float) * np.asarray(o.scale_u, float), n_mid))
+            hi.append(np.repeat(np.asarray(o.ubu[phase], float) * np.asarray(o.scale_u, float), n_mid))
+        if x_b:
+            lo.append(np.repeat(np.asarray(o.lbx[phase], float) * np.asarray(o.scale_x, float), n_mid))
+            hi.append(np.repeat(np.asarray(o.ubx[phase], float) * np.asarray(o.scale_x, float), n_mid))
+        if self.mid_residuals:
+            lo.append(np.full(o.nx * n_mid, -float(self.tol_residual[phase])))
+            hi.append(np.full(o.nx * n_mid, float(self.tol_residual[phase])))
+        lo, hi = np.concatenate(lo), np.concatenate(hi)
+        return (_NlpSymbol(f"SW{phase}", len(lo), self.oracle), lo, hi)
+
+    def _phase_row_bounds(self, phase):
+        """[F; C; DU; TC; SW] (mpopt.py:3166-3172)."""
+        o, N = self._ocp, self._Npoints
+        lay = self._layout
+        nc = (lay.rows[phase]["DU"] - lay.rows[phase]["C"]) // N
+        ntc = lay.rows[phase]["sum"] - lay.rows[phase]["TC"]
+        lo = [np.full(o.nx * N, float(o.LB_DYNAMICS)), np.full(nc * N, float(o.LB_PATH_CONSTRAINTS))]
+        hi = [np.full(o.nx * N, float(o.UB_DYNAMICS)), np.full(nc * N, float(o.UB_PATH_CONSTRAINTS))]
+        if o.diff_u[phase]:
+            lo.append(np.full(o.nu * N, float(o.lbdu[phase]))), hi.append(np.full(o.nu * N, float(o.ubdu[phase])))
+        lo.append(np.full(ntc, float(o.LB_TERMINAL_CONSTRAINTS))), hi.append(np.full(ntc, float(o.UB_TERMINAL_CONSTRAINTS)))
+        _, a, b = self.get_nlp_constrains_for_segment_widths(phase)
+        return np.concatenate(lo + [a]), np.concatenate(hi + [b])
+
+    def create_nlp(self):
+        from .adaptive import build_adaptive_oracle
+
+        o = self._ocp
+        self.compute_numerical_approximation()
+        self.create_variables()
+        self.oracle, self._layout = build_adaptive_oracle(o, self.n_segments, self.poly_orders, self.collocation,
+                                                          mid_residuals=self.mid_residuals, device=self.device)
+        zmin, zmax, gmin, gmax = [], [], [], []
+        for ph in range(o.n_phases):
+            _, a, b = self.get_nlp_variables(ph)
+            zmin.append(a), zmax.append(b)
+            a, b = self._phase_row_bounds(ph)
+            gmin.append(a), gmax.append(b)
+        if o.n_phases > 1:
+            _, emin, emax = self.get_event_constraints()
+            gmin.extend(emin), gmax.extend(emax)
+        self.Zmin, self.Zmax = np.concatenate(zmin), np.concatenate(zmax)
+        self.Gmin, self.Gmax = np.concatenate(gmin), np.concatenate(gmax)
+        orc = self.oracle
+        assert len(self.Zmin) == orc.n_z and len(self.Gmin) == orc.n_g, "layout mismatch with libmpx"
+        nlp_prob = {"f": _NlpSymbol("f", 1, orc), "x": _NlpSymbol("x", orc.n_z, orc), "g": _NlpSymbol("g", orc.n_g, orc),
+                    "p": _NlpSymbol("p", self.n_segments * o.n_phases, orc), "oracle": orc}
+        return (nlp_prob, {"lbg": self.Gmin, "ubg": self.Gmax, "lbx": self.Zmin, "ubx": self.Zmax})
+
+    def discretize_phase(self, phase):
+        if self.oracle is None:
+            self.create_nlp()
+        lo, hi = self._phase_row_bounds(phase)
+        return (_NlpSymbol(f"G{phase}", len(lo), self.oracle), lo, hi, _NlpSymbol(f"J{phase}", 1, self.oracle, shape=(1, 1)))
+
+    def create_solver(self, solver="ipopt", options={}):
+        from .solver import NlpSolver
+
+        nlp_problem, self.nlp_bounds = self.create_nlp()
+        nlp_problem.pop("p", None)  # the widths are part of x (mpopt.py:3190-3192)
+        defaults = {"ipopt.max_iter": 2000, "ipopt.acceptable_tol": 1e-4, "ipopt.print_level": 0, "ipopt.sb": "yes",
+                    "print_time": 0} if solver == "ipopt" else {}
+        defaults.update(options)
+        self.nlp_solver = NlpSolver("solver", solver, nlp_problem, defaults)
+        self._nlpsolver_initialized = True
+
+    def segment_widths(self, solution):
+        """(n_phases * S,) optimal width fractions, phase-major (what the reference prints, mpopt.py:3243-3245)."""
+        z = np.asarray(solution["x"], float).ravel()
+        n_zp, S = self._n_zp(), self.n_segments
+        return np.concatenate([z[(ph + 1) * n_zp - S:(ph + 1) * n_zp] for ph in range(self._ocp.n_phases)])
+
+    def solve(self, initial_solution=None, reinitialize_nlp=False, solver="ipopt", nlp_solver_options={}, mpopt_options={}, **kwargs):
+        if (not self._nlpsolver_initialized) or reinitialize_nlp:
+            self.create_solver(solver=solver, options=nlp_solver_options)
+        if initial_solution is None and mpopt_options.get("warm_start_fixed_width", True):
+            # The SciPy stand-in for IPOPT (solver.py) does not recover from the linear default guess on this
+            # problem class; start from the equal-width solution on the same grid instead (the reference starts
+            # IPOPT from the linear guess, mpopt.py:3235-3239 -- pass {"warm_start_fixed_width": False} for that).
+            fixed = mpopt(self._ocp, self.n_segments, self.poly_orders, self.colloc_scheme, device=self.device)
+            zf = np.asarray(fixed.solve(solver=solver, nlp_solver_options=nlp_solver_options)["x"], float).ravel()
+            n0, S = self._n_zp() - self.n_segments, self.n_segments
+            initial_solution = {"x0": np.concatenate([np.concatenate([zf[ph * n0:(ph + 1) * n0], np.full(S, 1.0 / S)])
+                                                      for ph in range(self._ocp.n_phases)])}
+        inputs = self.get_solver_warm_start_input_parameters(initial_solution)
+        solution = self.nlp_solver(**inputs, **self.nlp_bounds)
+        self._nlp_sw_params = self.segment_widths(solution)
+        if not self._MUTE_:
+            print(f"Optimal segment width fractions: {self._nlp_sw_params}")
+        return solution
+
+    # ---- post-processing: fixed-width machinery with the optimal widths as parameters ----------------
+    def _as_fixed_width(self, solution):
+        """(base mpopt on the same grid, solution without the width variables)."""
+        if self._post is None:
+            self._post = mpopt(self._ocp, self.n_segments, self.poly_orders, self.colloc_scheme, device=self.device)
+            self._post.compute_numerical_approximation()
+        z = np.asarray(solution["x"], float).ravel()
+        n_zp, S = self._n_zp(), self.n_segments
+        self._post._nlp_sw_params = self.segment_widths(solution)
+        self._post.grid_type, self._post.max_grid_points = self.grid_type, self.max_grid_points
+        return self._post, {"x": np.concatenate([z[ph * n_zp:(ph + 1) * n_zp - S] for ph in range(self._ocp.n_phases)])}
+
+    def get_trajectories(self, solution, phase=0):
+        post, sol = self._as_fixed_width(solution)
+        return post.get_trajectories(sol, phase)
+
+    def interpolate_single_phase(self, solution, phase=0, target_nodes=None, grid_type=None, options={}):
+        post, sol = self._as_fixed_width(solution)
+        return post.interpolate_single_phase(sol, phase, target_nodes, grid_type, options)
+
+    def get_dynamics_residuals_single_phase(self, solution, phase=0, target_nodes=None):
+        post, sol = self._as_fixed_width(solution)
+        return post.get_dynamics_residuals_single_phase(sol, phase, target_nodes)
+
+    def get_dynamics_residuals(self, solution, nodes=None, grid_type=None, residual_type=None, plot=False, fig=None, axs=None):
+        post, sol = self._as_fixed_width(solution)
+        return post.get_dynamics_residuals(sol, nodes, grid_type, residual_type)
+
+    def compute_states_from_solution_dynamics(self, solution, phase=0, nodes=None):
+        post, sol = self._as_fixed_width(solution)
+        return post.compute_states_from_solution_dynamics(sol, phase, nodes)
+
+    def get_states_residuals(self, solution, phases=None, nodes=None, residual_type=None, plot=False, fig=None, axs=None):
+        post, sol = self._as_fixed_width(solution)
+        return post.get_states_residuals(sol, phases, nodes, residual_type)
+
+
 def _ref_control_order(U):
     """The reference flattens the control guess node-major (``np.concatenate`` of an (N, nu)
     array, mpopt.py:678-689) although the decision vector is control-major -- identical for

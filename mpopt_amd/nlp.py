@@ -136,6 +136,10 @@ class NlpFunctions:
         rc = L.mpx_create(ctypes.byref(prob), ctypes.byref(ctx))
         if rc != 0:
             raise MpxError(f"mpx_create failed ({rc}): {L.mpx_last_error(None).decode()}")
+        self._adopt(ctx, L)
+
+    def _adopt(self, ctx, L):
+        """Take ownership of a created context and read its sizes."""
         self._ctx = ctx
         self._L = L
         s = mpx_sizes()
@@ -232,7 +236,7 @@ class NlpFunctions:
         single = z.ndim == 1
         z = z.reshape(-1, self.n_z)
         B = z.shape[0]
-        p = np.ascontiguousarray(p, dtype=np.float64)
+        p = np.zeros(0) if (p is None or self.n_p == 0) else np.ascontiguousarray(p, dtype=np.float64)
         if p.size not in (self.n_p, B * self.n_p):
             raise ValueError(f"p has {p.size} values, expected {self.n_p} or {B}x{self.n_p}")
         per_point = int(p.size == B * self.n_p and B > 1)

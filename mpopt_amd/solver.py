@@ -24,7 +24,7 @@ class NlpSolver:
 
     def __call__(self, x0=None, p=None, lbx=None, ubx=None, lbg=None, ubg=None, lam_x0=None, lam_g0=None):
         orc = self.oracle
-        p = np.asarray(p, dtype=float).ravel()
+        p = np.zeros(0) if p is None else np.asarray(p, dtype=float).ravel()
         n, m = orc.n_z, orc.n_g
         x0 = np.clip(np.asarray(x0, dtype=float).ravel(), lbx, ubx)
         jr, jc = orc.jac_pattern()
