@@ -236,7 +236,7 @@ int mpx_resid_eval_device(mpx_ctx* ctx, mpx_resid_plan* plan, int64_t batch, con
  * the nlp_* symbols like any other; it has no parameters (n_p = 0, `p` may be NULL) and no tiles.
  * ------------------------------------------------------------------------------------------- */
 typedef struct mpx_point_set {
-  int32_t fid;              /* kernels mpx_pt_val_<fid>, mpx_pt_jac_<fid>, mpx_pt_hes_<fid> of the code object */
+  int32_t fid;              /* generated function mpxgen::Pt<fid> of the code object (kernels mpx_pts_val / _jac / _hes) */
   int32_t n_points;
   int32_t n_loc, n_cst, n_out, n_jac, n_hess; /* sizes of the generated function (checked against nothing: caller's contract) */
   /* local variable v of point p:  sum_{t < loc_nterm[v]} loc_coef[(toff_v + t) * n_points + p] * z[loc_idx[...same...]] */

@@ -186,7 +186,7 @@ class AssembledNlpFunctions(NlpFunctions):
                  "template <int FID> struct Pt;"]
         parts += [f.source(k) for k, f in enumerate(funcs)]
         parts += ["}  // namespace mpxgen", '#include "mpx_assembly_kernels.h"']
-        parts += [f"MPX_INSTANTIATE_POINTS({k})" for k in range(len(funcs))]
+        parts.append(f"MPX_INSTANTIATE_POINTS({len(funcs)})")
         return "\n".join(parts) + "\n"
 
     # -- expansion of the chain rule into gather rows -------------------------------------------------

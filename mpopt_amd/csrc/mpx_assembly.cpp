@@ -22,13 +22,11 @@ struct DevSet {
   int32_t n = 0, n_loc = 0, n_cst = 0, n_out = 0, n_jac = 0, n_hess = 0;
   int32_t *loc_toff = nullptr, *loc_idx = nullptr, *mu_toff = nullptr, *mu_idx = nullptr;
   double *loc_coef = nullptr, *cst = nullptr, *mu_coef = nullptr;
-  int64_t raw_off = 0, rawh_off = 0;
-  hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
 };
 
 struct DevGather {
-  int64_t n_rows = 0, nnz = 0;
-  int64_t* ptr = nullptr;
+  int64_t n_rows = 0, nnz = 0, n_long = 0;
+  int64_t *ptr = nullptr, *long_rows = nullptr;
   int32_t* src = nullptr;
   double* coef = nullptr;
 };
@@ -37,33 +35,77 @@ struct DevGather {
 
 struct mpx_asm_state {
   std::vector<DevSet> sets;
+  MpxPtSet* d_sets = nullptr;  // device copy of the per-set argument blocks
+  int n_blocks = 0;            // 64-lane blocks of the fused point launch
+  hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
   DevGather fgj, hess;
   int64_t raw_n = 0, rawh_n = 0;
   DevBuf<double> raw;
 };
 
-// One lane per output row; the row's terms are summed in their stored order for every evaluation
-// point of the lane's batch chunk, so results do not depend on the launch geometry.
-__global__ __launch_bounds__(256) void mpx_gather_kernel(const MpxGatherArgs A) {
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= A.n_rows) return;
+// Rows with at most MPX_GATHER_LONG terms: one lane per row, terms summed in their stored order (the
+// first two terms of a row stay in registers over the batch chunk -- most rows are copies or two-term
+// sums).  Longer rows (the objective, gradients and Hessian corners of global variables): one wavefront
+// per row, lane j sums terms j, j+64, ... in order, then a fixed shuffle tree.  Either way the result of a
+// row does not depend on the launch geometry.
+__device__ __forceinline__ double gather_value(int32_t k, const double* __restrict__ rb, const double* __restrict__ zb) {
+  return k >= 0 ? rb[k] : (k == -1 ? 1.0 : zb[-2 - k]);
+}
+
+__device__ __forceinline__ double* gather_out(const MpxGatherArgs& A, int64_t row, int64_t& local, int64_t& stride) {
   int sg = 0;
   while (sg + 1 < A.n_seg && row >= A.seg_begin[sg + 1]) ++sg;
-  double* out = A.seg_out[sg];
-  if (!out) return;
-  const int64_t local = row - A.seg_begin[sg], stride = A.seg_stride[sg];
-  const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
+  local = row - A.seg_begin[sg];
+  stride = A.seg_stride[sg];
+  return A.seg_out[sg];
+}
+
+__global__ __launch_bounds__(256) void mpx_gather_kernel(const MpxGatherArgs A) {
   const int b0 = blockIdx.y * A.b_per_block;
   const int b1 = (b0 + A.b_per_block < A.B) ? b0 + A.b_per_block : A.B;
+  // Workgroups go to the 8 XCDs round-robin by linear id.  With gridDim.x a multiple of 8 every XCD would
+  // own the same row blocks for ALL evaluation points -- measured 5.3x slower on MI355X (12.4 -> 2.3 M
+  // evals/s with one empty block appended to a 31-block grid) -- so the row block rotates with the point.
+  const int bx = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
+  if (bx >= A.n_short_blocks) {  // one wavefront per long row
+    const int64_t w = (int64_t)(bx - A.n_short_blocks) * 4 + (threadIdx.x >> 6);
+    if (w >= A.n_long) return;
+    const int64_t row = A.long_rows[w];
+    int64_t local, stride;
+    double* out = gather_out(A, row, local, stride);
+    if (!out) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
+    for (int b = b0; b < b1; ++b) {
+      const double* __restrict__ rb = A.raw + (int64_t)b * A.raw_stride;
+      const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
+      double s = 0;
+      for (int64_t e = e0 + lane; e < e1; e += 64) s = fma(A.coef[e], gather_value(A.src[e], rb, zb), s);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+      if (lane == 0) out[(int64_t)b * stride + local] = s;
+    }
+    return;
+  }
+  const int64_t row = (int64_t)bx * blockDim.x + threadIdx.x;
+  if (row >= A.n_rows) return;
+  const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
+  const int nt = (int)(e1 - e0);
+  if (nt > MPX_GATHER_LONG) return;
+  int64_t local, stride;
+  double* out = gather_out(A, row, local, stride);
+  if (!out) return;
+  int32_t k0 = -1, k1 = -1;
+  double c0 = 0, c1 = 0;
+  if (nt >= 1) k0 = A.src[e0], c0 = A.coef[e0];
+  if (nt >= 2) k1 = A.src[e0 + 1], c1 = A.coef[e0 + 1];
   for (int b = b0; b < b1; ++b) {
     const double* __restrict__ rb = A.raw + (int64_t)b * A.raw_stride;
     const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
     double s = 0;
-    for (int64_t e = e0; e < e1; ++e) {
-      const int32_t k = A.src[e];
-      const double v = k >= 0 ? rb[k] : (k == -1 ? 1.0 : zb[-2 - k]);
-      s = fma(A.coef[e], v, s);
-    }
+    if (nt >= 1) s = fma(c0, gather_value(k0, rb, zb), s);
+    if (nt >= 2) s = fma(c1, gather_value(k1, rb, zb), s);
+    for (int64_t e = e0 + 2; e < e1; ++e) s = fma(A.coef[e], gather_value(A.src[e], rb, zb), s);
     out[(int64_t)b * stride + local] = s;
   }
 }
@@ -91,6 +133,11 @@ int upload_gather(mpx_ctx* c, DevGather& d, const mpx_gather& g, int64_t raw_n, 
   std::vector<int64_t> one(1, 0);
   if ((rc = upload_n(c, &d.ptr, g.n_rows ? g.ptr : one.data(), (size_t)g.n_rows + 1))) return rc;
   if ((rc = upload_n(c, &d.src, g.src, (size_t)d.nnz))) return rc;
+  std::vector<int64_t> lr;
+  for (int64_t r = 0; r < g.n_rows; ++r)
+    if (g.ptr[r + 1] - g.ptr[r] > MPX_GATHER_LONG) lr.push_back(r);
+  d.n_long = (int64_t)lr.size();
+  if ((rc = upload(c, &d.long_rows, lr))) return rc;
   return upload_n(c, &d.coef, g.coef, (size_t)d.nnz);
 }
 
@@ -115,8 +162,8 @@ void mpx_asm_release(mpx_ctx* c) {
     if (p) (void)hipFree(p);
   };
   for (auto& s : a->sets) fr(s.loc_toff), fr(s.loc_idx), fr(s.mu_toff), fr(s.mu_idx), fr(s.loc_coef), fr(s.cst), fr(s.mu_coef);
-  for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef);
-  fr(a->raw.p);
+  for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef), fr(g->long_rows);
+  fr(a->raw.p), fr(a->d_sets);
   delete a;
   c->assembled = nullptr;
 }
@@ -164,11 +211,11 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
   if (hipModuleLoadData(&c->module, D->code_object) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "hipModuleLoadData failed (is the code object built for this GPU?)"));
   mpx_asm_state* a = c->assembled = new mpx_asm_state;
   a->sets.resize(D->n_sets);
-  static const char* kind[3] = {"val", "jac", "hes"};
+  std::vector<MpxPtSet> hs(D->n_sets);
   for (int k = 0; k < D->n_sets; ++k) {
     const mpx_point_set& S = D->sets[k];
     DevSet& d = a->sets[k];
-    if (S.n_points < 1 || S.n_loc < 0 || S.n_cst < 0 || S.n_out < 0 || S.n_jac < 0 || S.n_hess < 0) return bail(fail(c, MPX_ERR_INVALID, "point set %d: bad sizes", k));
+    if (S.n_points < 1 || S.n_loc < 0 || S.n_cst < 0 || S.n_out < 0 || S.n_jac < 0 || S.n_hess < 0 || S.fid < 0) return bail(fail(c, MPX_ERR_INVALID, "point set %d: bad sizes", k));
     d.n = S.n_points, d.n_loc = S.n_loc, d.n_cst = S.n_cst, d.n_out = S.n_out, d.n_jac = S.n_jac, d.n_hess = S.n_hess;
     std::vector<int32_t> toff, moff;
     if ((rc = check_terms(c, S.loc_nterm, S.n_loc, S.loc_idx, S.n_points, D->n_z, toff, "local variables"))) return bail(rc);
@@ -178,15 +225,19 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
         (rc = upload_n(c, &d.mu_idx, S.mu_idx, (size_t)moff.back() * d.n)) || (rc = upload_n(c, &d.mu_coef, S.mu_coef, (size_t)moff.back() * d.n)) ||
         (rc = upload_n(c, &d.cst, S.cst, (size_t)S.n_cst * d.n)))
       return bail(rc);
-    d.raw_off = a->raw_n;
-    d.rawh_off = a->rawh_n;
+    MpxPtSet& h = hs[k];
+    h.n = d.n, h.fid = S.fid, h.block_first = a->n_blocks, h.n_slots_fgj = d.n_out + d.n_jac, h.n_hess = d.n_hess;
+    h.loc_toff = d.loc_toff, h.loc_idx = d.loc_idx, h.loc_coef = d.loc_coef, h.cst = d.cst;
+    h.mu_toff = d.mu_toff, h.mu_idx = d.mu_idx, h.mu_coef = d.mu_coef;
+    h.raw_off = a->raw_n, h.rawh_off = a->rawh_n;
+    a->n_blocks += (d.n + 63) / 64;
     a->raw_n += (int64_t)d.n * (d.n_out + d.n_jac);
     a->rawh_n += (int64_t)d.n * d.n_hess;
-    for (int m = 0; m < 3; ++m) {
-      const std::string name = std::string("mpx_pt_") + kind[m] + "_" + std::to_string(S.fid);
-      if (hipModuleGetFunction(&d.fn[m], c->module, name.c_str()) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "kernel %s missing from the code object", name.c_str()));
-    }
   }
+  if ((rc = upload(c, &a->d_sets, hs))) return bail(rc);
+  static const char* kname[3] = {"mpx_pts_val", "mpx_pts_jac", "mpx_pts_hes"};
+  for (int m = 0; m < 3; ++m)
+    if (hipModuleGetFunction(&a->fn[m], c->module, kname[m]) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "kernel %s missing from the code object", kname[m]));
   if (a->raw_n >= (1LL << 31) || a->rawh_n >= (1LL << 31)) return bail(fail(c, MPX_ERR_UNSUPPORTED, "raw buffer too large for int32 sources"));
   if ((rc = upload_gather(c, a->fgj, D->fgj, a->raw_n, D->n_z, "fgj gather")) || (rc = upload_gather(c, a->hess, D->hess, a->rawh_n, D->n_z, "hess gather")))
     return bail(rc);
@@ -196,24 +247,23 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
   return MPX_OK;
 }
 
+// Batch elements per workgroup.  Measured on MI355X (tools/adaptive_bench.py + rocprofv3): these kernels are
+// latency-bound per lane and a batch loop only serialises the loads of a lane (4 points per workgroup: 1.8x
+// slower than 1, 64: 2.5x), so every workgroup takes ONE evaluation point; chunk only past the grid limit.
+static int pick_chunk(int64_t batch, int64_t) { return (int)((batch + 65534) / 65535); }
+
 static int launch_points(mpx_ctx* c, int mode, int64_t batch, const double* z, const double* lam, const double* sigma) {
   mpx_asm_state* a = c->assembled;
-  const int64_t stride = mode == MPX_MODE_HESS ? a->rawh_n : a->raw_n;
-  const int bpb = (int)std::max<int64_t>(1, (batch + 4095) / 4096);
-  for (auto& d : a->sets) {
-    if (mode == MPX_MODE_HESS && d.n_hess == 0) continue;
-    if (mode != MPX_MODE_HESS && d.n_out + (mode == MPX_MODE_FGJ ? d.n_jac : 0) == 0) continue;
-    MpxPtArgs A{};
-    A.n = d.n, A.n_g = (int32_t)c->n_g, A.B = (int32_t)batch, A.b_per_block = bpb;
-    A.loc_toff = d.loc_toff, A.loc_idx = d.loc_idx, A.loc_coef = d.loc_coef, A.cst = d.cst;
-    A.mu_toff = d.mu_toff, A.mu_idx = d.mu_idx, A.mu_coef = d.mu_coef;
-    A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma;
-    A.raw = c->assembled->raw.p + (mode == MPX_MODE_HESS ? d.rawh_off : d.raw_off);
-    A.raw_stride = stride;
-    size_t sz = sizeof(A);
-    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    HIPCHK(c, hipModuleLaunchKernel(d.fn[mode], (unsigned)((d.n + 63) / 64), (unsigned)((batch + bpb - 1) / bpb), 1, 64, 1, 1, 0, c->stream, nullptr, cfg));
-  }
+  if ((mode == MPX_MODE_HESS ? a->rawh_n : a->raw_n) == 0) return MPX_OK;
+  MpxPtCall A{};
+  A.sets = a->d_sets, A.n_sets = (int32_t)a->sets.size(), A.n_g = (int32_t)c->n_g, A.B = (int32_t)batch;
+  A.b_per_block = pick_chunk(batch, a->n_blocks);
+  A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma;
+  A.raw = a->raw.p;
+  A.raw_stride = mode == MPX_MODE_HESS ? a->rawh_n : a->raw_n;
+  size_t sz = sizeof(A);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIPCHK(c, hipModuleLaunchKernel(a->fn[mode], (unsigned)a->n_blocks, (unsigned)((batch + A.b_per_block - 1) / A.b_per_block), 1, 64, 1, 1, 0, c->stream, nullptr, cfg));
   return MPX_OK;
 }
 
@@ -227,9 +277,11 @@ static int launch_gather(mpx_ctx* c, const DevGather& g, int64_t batch, const do
   for (int k = 0; k < n_seg; ++k) A.seg_begin[k] = seg_begin[k], A.seg_out[k] = seg_out[k], A.seg_stride[k] = seg_stride[k];
   A.seg_begin[n_seg] = g.n_rows;
   A.B = (int32_t)batch;
-  A.b_per_block = (int)std::max<int64_t>(1, (batch + 4095) / 4096);
-  hipLaunchKernelGGL(mpx_gather_kernel, dim3((unsigned)((g.n_rows + 255) / 256), (unsigned)((batch + A.b_per_block - 1) / A.b_per_block)), dim3(256), 0,
-                     c->stream, A);
+  A.long_rows = g.long_rows, A.n_long = g.n_long;
+  A.n_short_blocks = (int32_t)((g.n_rows + 255) / 256);
+  const unsigned gx = (unsigned)(A.n_short_blocks + (g.n_long + 3) / 4);
+  A.b_per_block = pick_chunk(batch, gx);
+  hipLaunchKernelGGL(mpx_gather_kernel, dim3(gx, (unsigned)((batch + A.b_per_block - 1) / A.b_per_block)), dim3(256), 0, c->stream, A);
   HIPCHK(c, hipGetLastError());
   return MPX_OK;
 }

@@ -4,10 +4,12 @@
 // straight-line code of a point function phi(loc; cst) -> out, its structural Jacobian entries and the
 // structural entries of the Hessian of sum_r mu_r * out_r.
 //
-// lane <-> point.  A lane gathers its local variables as short fixed-order sums over z (node values: one
-// term; interpolated mid-point values: degree+1 terms), evaluates the generated code and writes every
-// result to raw[slot][point], i.e. one contiguous run per slot and wavefront.  No reductions happen here:
-// all sums over points are rows of the gather pass (mpx_assembly.cpp), whose order is fixed.
+// One launch covers every point set of the context (64-lane blocks, a block belongs to one set and
+// dispatches on its function id); lane <-> point.  A lane gathers its local variables as short
+// fixed-order sums over z (node values: one term; interpolated mid-point values: degree+1 terms; the
+// running width sum: one term per earlier segment), evaluates the generated code and writes every result
+// to raw[slot][point], i.e. one contiguous run per slot and wavefront.  No reductions happen here: all
+// sums over points are rows of the gather pass (mpx_assembly.cpp), whose order is fixed.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,27 +18,29 @@
 namespace mpxk {
 
 template <int FID, int MODE>
-__device__ __forceinline__ void point_body(const MpxPtArgs& A) {
+__device__ __forceinline__ void point_body(const MpxPtSet& S, const MpxPtCall& A, int blk) {
   using F = mpxgen::Pt<FID>;
   constexpr int NLOC = F::NLOC, NCST = F::NCST, NOUT = F::NOUT, NJ = F::NJ, NH = F::NH;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= A.n) return;
-  const int64_t n = A.n;
+  if constexpr (MODE == MPX_MODE_HESS && NH == 0) return;
+  const int p = blk * 64 + threadIdx.x;
+  if (p >= S.n) return;
+  const int64_t n = S.n;
   double cst[NCST > 0 ? NCST : 1];
 #pragma unroll
-  for (int k = 0; k < NCST; ++k) cst[k] = A.cst[(int64_t)k * n + p];
+  for (int k = 0; k < NCST; ++k) cst[k] = S.cst[(int64_t)k * n + p];
   const int b0 = blockIdx.y * A.b_per_block;
   const int b1 = (b0 + A.b_per_block < A.B) ? b0 + A.b_per_block : A.B;
+  double* __restrict__ raw0 = A.raw + (MODE == MPX_MODE_HESS ? S.rawh_off : S.raw_off);
   for (int b = b0; b < b1; ++b) {
     const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
     double loc[NLOC > 0 ? NLOC : 1];
 #pragma unroll
     for (int v = 0; v < NLOC; ++v) {
       double acc = 0;
-      for (int t = A.loc_toff[v]; t < A.loc_toff[v + 1]; ++t) acc = fma(A.loc_coef[(int64_t)t * n + p], zb[A.loc_idx[(int64_t)t * n + p]], acc);
+      for (int t = S.loc_toff[v]; t < S.loc_toff[v + 1]; ++t) acc = fma(S.loc_coef[(int64_t)t * n + p], zb[S.loc_idx[(int64_t)t * n + p]], acc);
       loc[v] = acc;
     }
-    double* __restrict__ rb = A.raw + (int64_t)b * A.raw_stride;
+    double* __restrict__ rb = raw0 + (int64_t)b * A.raw_stride;
     if constexpr (MODE == MPX_MODE_HESS) {
       double mu[NOUT > 0 ? NOUT : 1];
       const double* __restrict__ lb = A.lam + (int64_t)b * A.lam_stride;
@@ -44,9 +48,9 @@ __device__ __forceinline__ void point_body(const MpxPtArgs& A) {
 #pragma unroll
       for (int r = 0; r < NOUT; ++r) {
         double acc = 0;
-        for (int t = A.mu_toff[r]; t < A.mu_toff[r + 1]; ++t) {
-          const int ix = A.mu_idx[(int64_t)t * n + p];
-          acc = fma(A.mu_coef[(int64_t)t * n + p], ix == A.n_g ? sg : lb[ix], acc);
+        for (int t = S.mu_toff[r]; t < S.mu_toff[r + 1]; ++t) {
+          const int ix = S.mu_idx[(int64_t)t * n + p];
+          acc = fma(S.mu_coef[(int64_t)t * n + p], ix == A.n_g ? sg : lb[ix], acc);
         }
         mu[r] = acc;
       }
@@ -70,15 +74,40 @@ __device__ __forceinline__ void point_body(const MpxPtArgs& A) {
   }
 }
 
+template <int MODE, int FID>
+struct PtDispatch {
+  __device__ static __forceinline__ void run(const MpxPtSet& S, const MpxPtCall& A, int blk) {
+    if (S.fid == FID)
+      point_body<FID, MODE>(S, A, blk);
+    else
+      PtDispatch<MODE, FID - 1>::run(S, A, blk);
+  }
+};
+template <int MODE>
+struct PtDispatch<MODE, -1> {
+  __device__ static __forceinline__ void run(const MpxPtSet&, const MpxPtCall&, int) {}
+};
+
+template <int MODE, int NF>
+__device__ __forceinline__ void points_body(const MpxPtCall& A) {
+  // rotate the block index with the evaluation point so that a multiple-of-8 block count does not pin every
+  // block to one XCD (see mpx_gather_kernel)
+  const int bx = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
+  int k = 0;
+  while (k + 1 < A.n_sets && bx >= A.sets[k + 1].block_first) ++k;
+  const MpxPtSet S = A.sets[k];
+  PtDispatch<MODE, NF - 1>::run(S, A, bx - S.block_first);
+}
+
 }  // namespace mpxk
 
-#define MPX_INSTANTIATE_POINTS(FID)                                                                      \
-  extern "C" __global__ __launch_bounds__(64) void mpx_pt_val_##FID(const MpxPtArgs A) {                 \
-    mpxk::point_body<FID, MPX_MODE_FG>(A);                                                               \
+#define MPX_INSTANTIATE_POINTS(NF)                                                                       \
+  extern "C" __global__ __launch_bounds__(64) void mpx_pts_val(const MpxPtCall A) {                      \
+    mpxk::points_body<MPX_MODE_FG, NF>(A);                                                               \
   }                                                                                                      \
-  extern "C" __global__ __launch_bounds__(64) void mpx_pt_jac_##FID(const MpxPtArgs A) {                 \
-    mpxk::point_body<FID, MPX_MODE_FGJ>(A);                                                              \
+  extern "C" __global__ __launch_bounds__(64) void mpx_pts_jac(const MpxPtCall A) {                      \
+    mpxk::points_body<MPX_MODE_FGJ, NF>(A);                                                              \
   }                                                                                                      \
-  extern "C" __global__ __launch_bounds__(64) void mpx_pt_hes_##FID(const MpxPtArgs A) {                 \
-    mpxk::point_body<FID, MPX_MODE_HESS>(A);                                                             \
+  extern "C" __global__ __launch_bounds__(64) void mpx_pts_hes(const MpxPtCall A) {                      \
+    mpxk::points_body<MPX_MODE_HESS, NF>(A);                                                             \
   }

@@ -114,8 +114,9 @@ struct MpxResidArgs {
 #define MPX_ACCUM_BIT (1LL << 62)
 
 // ---- assembled contexts (mpx_create_assembled) ---------------------------------------------------
-struct MpxPtArgs {
-  int32_t n, n_g, B, b_per_block;
+// One point set (device-resident array, fixed for the life of the context).
+struct MpxPtSet {
+  int32_t n, fid, block_first, n_slots_fgj, n_hess;  // block_first: first 64-lane block of this set in the fused launch
   const int32_t* loc_toff;  // [NLOC + 1] running term offsets
   const int32_t* loc_idx;   // [terms][n]
   const double* loc_coef;
@@ -123,20 +124,32 @@ struct MpxPtArgs {
   const int32_t* mu_toff;   // [NOUT + 1]
   const int32_t* mu_idx;
   const double* mu_coef;
+  int64_t raw_off, rawh_off;
+};
+
+// Per-call arguments of the fused point kernels (all sets of the context in one launch).
+struct MpxPtCall {
+  const MpxPtSet* sets;
+  int32_t n_sets, n_g, B, b_per_block;
   const double* z;
   int64_t z_stride;
   const double* lam;
   int64_t lam_stride;
   const double* sigma;
-  double* raw;              // already offset to this set's block
+  double* raw;
   int64_t raw_stride;
 };
+
+#define MPX_GATHER_LONG 24  // rows with more terms are summed by a whole wavefront
 
 struct MpxGatherArgs {
   int64_t n_rows;
   const int64_t* ptr;
   const int32_t* src;
   const double* coef;
+  const int64_t* long_rows;  // rows with more than MPX_GATHER_LONG terms
+  int64_t n_long;
+  int32_t n_short_blocks;    // blocks [0, n_short_blocks): one lane per row; the rest: one wavefront per long row
   const double* raw;
   int64_t raw_stride;
   const double* z;

@@ -116,6 +116,8 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   __shared__ double sXU[2][NX + NU][SLOTS];
   __shared__ double sRed[2][MPX_TILE / 64][NRED1];
 
+  // (rotating the tile index with blockIdx.y -- the cure for the XCD aliasing of the gather kernel in
+  // mpx_assembly.cpp -- was measured here for 16/24/32 tiles and makes no difference: 4.4-4.6 TB/s either way)
   const MpxTile T = A.tiles[A.tile_first + blockIdx.x];
   const int l = threadIdx.x;
   const bool act = l < T.n;      // stages a node in LDS

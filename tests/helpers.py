@@ -15,6 +15,11 @@ def build_case(name, with_device=None):
     from mpopt_amd import mp
     import problems
 
+    if name in problems.ADAPTIVE_CASES:  # widths as variables: assembled context (mpopt_amd/adaptive.py)
+        builder, S, po, scheme = problems.ADAPTIVE_CASES[name]
+        ocp = builder(mp, M.math)
+        mpo = mp.mpopt_adaptive(ocp, S, po, scheme)
+        return ocp, mpo, mpo.create_nlp()[0]["oracle"]
     builder, S, po, scheme = problems.GOLDEN_CASES[name]
     ocp = builder(mp, M.math)
     mpo = mp.mpopt(ocp, S, po, scheme)

@@ -64,7 +64,7 @@ def test_batch_matches_single(name):
             assert np.array_equal(rp[k][b], r1[k]), (k, b)
 
 
-@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL"])
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL", "adaptive_kitchen_sink_mixed_LGR"])
 def test_casadi_external_entry_points(name):
     """nlp_f / nlp_g / nlp_grad_f / nlp_jac_g / nlp_hess_l with CasADi's generated-code calling
     convention (mpx_casadi.cpp), values in compressed-column order, against the reference goldens."""
