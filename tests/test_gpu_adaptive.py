@@ -96,3 +96,60 @@ def test_adaptive_solve_docstring_example():
     assert X.shape == (7, 2) and abs(X[-1]).max() < 1e-6 and np.all(np.diff(t) > 0)
     ti, res = opt.get_dynamics_residuals(sol, grid_type="mid-points")
     assert len(res[0]) == 3
+
+
+def test_moon_lander_mpopt_adaptive_solve():
+    """/root/reference/tests/test_mpopt.py:257-264, 473-483: same calls, same assertions."""
+    mp.mpopt._MUTE_ = True
+    mpo = mp.mpopt_adaptive(problems.moon_lander(mp, M.math), 3, 3)
+    mpo.lbh[0] = 1e-6
+    mpo.mid_residuals = True
+    mpo.validate()
+    mpo.mid_residuals = False
+    sol = mpo.solve()
+    for key in ["x", "f"]:
+        assert key in sol
+    assert mpo.oracle.n_g == len(mpo.Gmin) and mpo.Zmin[-1] == 1e-6
+    post = mpo.process_results(sol, plot=False)
+    x, u, t, _ = post.get_data()
+    xi, ui, ti, _ = post.get_data(interpolate=True)
+    assert x.shape[0] == u.shape[0] == t.shape[0]
+    assert xi.shape[0] == ui.shape[0] == ti.shape[0]
+    assert 8.24 < float(sol["f"]) < 8.6  # no mid-point residual rows: nothing pulls the switch onto a segment boundary
+
+
+def test_hyper_sensitive_mpopt_adaptive_oracles_at_degree_15():
+    """The reference's second adaptive fixture (tests/test_mpopt.py:275-282: 5 segments of degree 15).  The outer
+    solve is the stand-in's business; what is on the path is that the assembled oracles exist at that size and
+    are consistent: gradient and Jacobian against central differences of f and g, Hessian against differences
+    of the Lagrangian gradient."""
+    mp.mpopt._MUTE_ = True
+    mpo = mp.mpopt_adaptive(problems.hyper_sensitive(mp, M.math), 5, 15)
+    mpo.lbh[0] = 1e-6
+    mpo.validate()
+    nlp, _ = mpo.create_nlp()
+    o = nlp["oracle"]
+    rng = np.random.default_rng(1)
+    z = mpo.initialize_solution() + 0.05 * rng.uniform(-1, 1, o.n_z)
+    lam, sig = rng.standard_normal(o.n_g), 0.7
+    r = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], z, None, lam_g=lam, sigma=sig)
+    jr, jc = o.jac_pattern()
+    hr, hc = o.hess_pattern()
+    J = np.zeros((o.n_g, o.n_z))
+    J[jr, jc] = r["jac_g"]
+    H = np.zeros((o.n_z, o.n_z))
+    H[hr, hc] = r["hess_l"]
+    H = H + np.triu(H, 1).T
+    cols = rng.choice(o.n_z, 12, replace=False)
+    eps = 1e-6
+    Zp = np.stack([z + eps * np.eye(o.n_z)[c] for c in cols] + [z - eps * np.eye(o.n_z)[c] for c in cols])
+    q = o.eval(["f", "g", "grad_f", "jac_g"], Zp, None)
+    k = len(cols)
+    assert np.abs((q["f"][:k] - q["f"][k:]) / (2 * eps) - r["grad_f"][cols]).max() < 1e-6
+    assert np.abs((q["g"][:k] - q["g"][k:]).T / (2 * eps) - J[:, cols]).max() < 1e-5
+    gl = np.zeros((2 * k, o.n_z))
+    for b in range(2 * k):  # gradient of the Lagrangian at the shifted points
+        Jb = np.zeros((o.n_g, o.n_z))
+        Jb[jr, jc] = q["jac_g"][b]
+        gl[b] = sig * q["grad_f"][b] + lam @ Jb
+    assert np.abs((gl[:k] - gl[k:]).T / (2 * eps) - H[:, cols]).max() < 1e-4
