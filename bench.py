@@ -52,6 +52,9 @@ def main():
                     help="default: the metric's configuration (BASELINE configs[1], f+g+grad_f+jac_g).  The others are "
                          "secondary reports (configs[4]: nlp_hess_l on hypersensitive 4000x3; configs[2]: mixed-degree grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary MPX_JAC_VARIABLE_ONLY measurement (it launches the same kernel with less work, "
+                         "which would mix into a rocprofv3 per-kernel average)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed clock ramp before the warm-up steps: a fresh box starts in a low-power state and "
@@ -150,7 +153,7 @@ def main():
     # secondary, opt-in mode (NOT the metric): only the (z,p)-dependent Jacobian entries are rewritten into
     # the resident buffers, which hold the grid constants from the full evaluations above
     extra = {}
-    if not hess_mode:
+    if not hess_mode and not args.no_extras:
         from mpopt_amd._lib import MPX_JAC_VARIABLE_ONLY
 
         torch.cuda.synchronize()

@@ -504,10 +504,11 @@ int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size
 int pick_bpb(const mpx_ctx* c, int64_t B) {
   static const char* env = getenv("MPX_BPB");
   if (env && atoi(env) > 0) return atoi(env);
-  // measured on MI355X (moon lander 1000x5, B=4096): 8 points per workgroup is the sweet spot of the
-  // software-pipelined loop (3: -2.5 %, 21: -4 %, 64: -6 %); small batches get one point per workgroup
+  // measured on MI355X (moon lander 1000x5, B=4096, XCD-blocked mapping): 4-8 points per workgroup is the
+  // sweet spot of the software-pipelined loop (2: -8 %, 16: -5 %, 64: -10 %); small batches get one point
+  // per workgroup
   int64_t work = B * (c->tile_end - c->tile_begin);
-  int64_t bpb = work / 8192;
+  int64_t bpb = work / 16384;
   return (int)std::min<int64_t>(std::max<int64_t>(bpb, 1), 8);
 }
 
