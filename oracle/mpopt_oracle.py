@@ -603,8 +603,9 @@ class OracleAdaptiveNLP(OracleNLP):
 
     SEG_WIDTH_MIN, SEG_WIDTH_MAX, TOL_RESIDUAL = 1e-4, 1.0, 1e-3  # mpopt.py:2896-2898
 
-    def __init__(self, ocp, n_segments, poly_orders, scheme="LGR", tau0=-1.0, tau1=1.0, table_method="auto"):
+    def __init__(self, ocp, n_segments, poly_orders, scheme="LGR", tau0=-1.0, tau1=1.0, table_method="auto", mid_residuals=True):
         self._lam_cache = {}
+        self.mid_residuals = bool(mid_residuals)  # mpopt.py:2920, 3087
         super().__init__(ocp, n_segments, poly_orders, scheme, tau0, tau1, table_method)
         self.n_p = 0
 
@@ -675,7 +676,7 @@ class OracleAdaptiveNLP(OracleNLP):
         if self.x_bounded[ph]:
             sw.append(xi.T.ravel())
         idx = 0
-        for s in range(S):
+        for s in range(S if self.mid_residuals else 0):
             h_seg = (tfv - t0v) / self.st / dtau * W[s]
             n_mid = len(self.taus_mid[s])
             if n_mid == 0:
@@ -741,7 +742,8 @@ class OracleAdaptiveNLP(OracleNLP):
             if self.x_bounded[ph]:
                 lo.append(np.repeat(np.asarray(o.lbx[ph], float) * self.sx, n_mid))
                 hi.append(np.repeat(np.asarray(o.ubx[ph], float) * self.sx, n_mid))
-            lo.append(np.full(self.nx * n_mid, -self.TOL_RESIDUAL)), hi.append(np.full(self.nx * n_mid, self.TOL_RESIDUAL))
+            if self.mid_residuals:
+                lo.append(np.full(self.nx * n_mid, -self.TOL_RESIDUAL)), hi.append(np.full(self.nx * n_mid, self.TOL_RESIDUAL))
             gmin.append(np.concatenate(lo)), gmax.append(np.concatenate(hi))
         if self.n_ph > 1:
             n = len(o.phase_links)

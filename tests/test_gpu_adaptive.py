@@ -153,3 +153,35 @@ def test_hyper_sensitive_mpopt_adaptive_oracles_at_degree_15():
         Jb[jr, jc] = q["jac_g"][b]
         gl[b] = sig * q["grad_f"][b] + lam @ Jb
     assert np.abs((gl[:k] - gl[k:]).T / (2 * eps) - H[:, cols]).max() < 1e-4
+
+
+@pytest.mark.parametrize("builder,S,po,scheme,mid", [
+    (problems.moon_lander, 1, [1], "LGR", True),            # one segment of degree 1: no earlier widths, one mid-point
+    (problems.van_der_pol, 2, [1, 3], "LGL", True),         # ragged degrees incl. 1, path constraints
+    (problems.hyper_sensitive, 3, [2, 2, 2], "CGL", False),  # without the mid-point residual rows (mpopt.py:3087)
+    (problems.kitchen_sink, 1, [2], "LGR", True),           # 2 phases x 1 segment, time-dependent, parameters, events
+])
+def test_adaptive_edge_grids_match_oracle(builder, S, po, scheme, mid):
+    from oracle.mpopt_oracle import OracleAdaptiveNLP
+
+    O = OracleAdaptiveNLP(builder(mp, M.math), S, po, scheme, mid_residuals=mid)
+    mpo = mp.mpopt_adaptive(builder(mp, M.math), S, po, scheme)
+    mpo.mid_residuals = mid
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    assert (o.n_z, o.n_g) == (O.n_z, O.n_g)
+    lbx, ubx, lbg, ubg = O.bounds()
+    assert np.array_equal(bounds["lbx"], lbx) and np.array_equal(bounds["ubx"], ubx)
+    assert np.array_equal(bounds["lbg"], lbg) and np.array_equal(bounds["ubg"], ubg)
+    assert np.array_equal(mpo.initialize_solution(), O.initial_guess())
+    rng = np.random.default_rng(11)
+    z = O.initial_guess() * (1 + 0.1 * rng.uniform(-1, 1, o.n_z)) + 0.05 * rng.uniform(-1, 1, o.n_z)
+    lam, sig = rng.standard_normal(o.n_g), 1.3
+    r = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], z, None, lam_g=lam, sigma=sig)
+    assert rel_err(r["f"], O.f(z)) < TOL and rel_err(r["g"], O.g(z)) < TOL and rel_err(r["grad_f"], O.grad_f(z)) < TOL
+    J = np.zeros((o.n_g, o.n_z))
+    J[o.jac_pattern()] = r["jac_g"]
+    assert rel_err(J, O.jac_g(z).toarray()) < TOL
+    H = np.zeros((o.n_z, o.n_z))
+    H[o.hess_pattern()] = r["hess_l"]
+    assert rel_err(H + np.triu(H, 1).T, O.hess_l(z, None, sig, lam)) < TOL
