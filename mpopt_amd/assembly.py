@@ -249,14 +249,21 @@ class AssembledNlpFunctions(NlpFunctions):
                     w = np.where(ca == cb, 2.0 * w, w)
                     ca, cb, pp = np.minimum(ca, cb), np.maximum(ca, cb), p1[t1]
                 HK.append(ca * n_z + cb); HS.append(slot + pp); HC.append(w)
-        # Jacobian / Hessian patterns: distinct keys, column-major (the order CasADi's CCS uses)
+        # Jacobian / Hessian patterns: distinct (row, col) keys.  Entry ORDER is ours to choose (mpx_ccs_perm maps it to
+        # CasADi's compressed-column order): entries are sorted by the raw slot their first term reads -- set-major,
+        # slot-major, point-minor, exactly the layout the point kernels write -- so consecutive lanes of the gather kernel
+        # read consecutive raw values and write consecutive outputs; constants (no raw source) come first.
         def pattern(K, S_, C_, by_col):
             K, S_, C_ = _cat(K, np.int64), _cat(S_, np.int64), _cat(C_, np.float64)
             rows, cols = K // n_z, K % n_z
-            uniq, inv = np.unique(cols * (max(n_g, n_z) + 1) + rows if by_col else K, return_inverse=True)
-            first = np.zeros(len(uniq), np.int64)
-            first[inv] = np.arange(len(K))
-            return rows[first].astype(np.int32), cols[first].astype(np.int32), inv.astype(np.int64), S_, C_
+            colmajor = cols * (max(n_g, n_z) + 1) + rows
+            uniq, first, inv = np.unique(colmajor, return_index=True, return_inverse=True)
+            src0 = np.full(len(uniq), np.iinfo(np.int64).max)
+            np.minimum.at(src0, inv, np.where(S_ >= 0, S_, -1))  # smallest source of the entry (-1: has a constant / z term)
+            order = np.lexsort((uniq, src0))                      # by source, ties in column-major order
+            rank = np.empty(len(uniq), np.int64)
+            rank[order] = np.arange(len(uniq))
+            return rows[first][order].astype(np.int32), cols[first][order].astype(np.int32), rank[inv], S_, C_
 
         self.jrow, self.jcol, jinv, JS, JC = pattern(JK, JS, JC, True)
         self.hrow, self.hcol, hinv, HS, HC = pattern(HK, HS, HC, True)

@@ -16,6 +16,10 @@
 
 using namespace mpxi;
 
+#ifndef MPX_GATHER_UNROLL
+#define MPX_GATHER_UNROLL 4
+#endif
+
 namespace {
 
 struct DevSet {
@@ -99,7 +103,35 @@ __global__ __launch_bounds__(256) void mpx_gather_kernel(const MpxGatherArgs A) 
   double c0 = 0, c1 = 0;
   if (nt >= 1) k0 = A.src[e0], c0 = A.coef[e0];
   if (nt >= 2) k1 = A.src[e0 + 1], c1 = A.coef[e0 + 1];
-  for (int b = b0; b < b1; ++b) {
+  int b = b0;
+  // The kernel is latency-bound (pointer -> source -> value -> store is a chain of dependent round trips and
+  // only 2048 workgroups are resident), so a lane takes MPX_GATHER_UNROLL evaluation points at a time with their
+  // loads in flight together.  Per point the terms are added in the same order as in the remainder loop below:
+  // results are identical.
+  for (; b + MPX_GATHER_UNROLL <= b1; b += MPX_GATHER_UNROLL) {
+    const double* __restrict__ rb = A.raw + (int64_t)b * A.raw_stride;
+    const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
+    double s[MPX_GATHER_UNROLL];
+#pragma unroll
+    for (int u = 0; u < MPX_GATHER_UNROLL; ++u) s[u] = 0;
+    if (nt >= 1) {
+#pragma unroll
+      for (int u = 0; u < MPX_GATHER_UNROLL; ++u) s[u] = fma(c0, gather_value(k0, rb + u * A.raw_stride, zb + u * A.z_stride), s[u]);
+    }
+    if (nt >= 2) {
+#pragma unroll
+      for (int u = 0; u < MPX_GATHER_UNROLL; ++u) s[u] = fma(c1, gather_value(k1, rb + u * A.raw_stride, zb + u * A.z_stride), s[u]);
+    }
+    for (int64_t e = e0 + 2; e < e1; ++e) {
+      const int32_t k = A.src[e];
+      const double cf = A.coef[e];
+#pragma unroll
+      for (int u = 0; u < MPX_GATHER_UNROLL; ++u) s[u] = fma(cf, gather_value(k, rb + u * A.raw_stride, zb + u * A.z_stride), s[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < MPX_GATHER_UNROLL; ++u) out[(int64_t)(b + u) * stride + local] = s[u];
+  }
+  for (; b < b1; ++b) {
     const double* __restrict__ rb = A.raw + (int64_t)b * A.raw_stride;
     const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
     double s = 0;
@@ -281,6 +313,7 @@ static int launch_gather(mpx_ctx* c, const DevGather& g, int64_t batch, const do
   A.n_short_blocks = (int32_t)((g.n_rows + 255) / 256);
   const unsigned gx = (unsigned)(A.n_short_blocks + (g.n_long + 3) / 4);
   A.b_per_block = pick_chunk(batch, gx);
+  if (batch * gx >= 16384) A.b_per_block = std::max(A.b_per_block, MPX_GATHER_UNROLL);  // several points in flight per lane (see kernel)
   hipLaunchKernelGGL(mpx_gather_kernel, dim3(gx, (unsigned)((batch + A.b_per_block - 1) / A.b_per_block)), dim3(256), 0, c->stream, A);
   HIPCHK(c, hipGetLastError());
   return MPX_OK;
