@@ -118,14 +118,15 @@ def test_moon_lander_mpopt_adaptive_solve():
     assert 8.24 < float(sol["f"]) < 8.6  # no mid-point residual rows: nothing pulls the switch onto a segment boundary
 
 
-def test_hyper_sensitive_mpopt_adaptive_oracles_at_degree_15():
-    """The reference's second adaptive fixture (tests/test_mpopt.py:275-282: 5 segments of degree 15).  The outer
-    solve is the stand-in's business; what is on the path is that the assembled oracles exist at that size and
-    are consistent: gradient and Jacobian against central differences of f and g, Hessian against differences
-    of the Lagrangian gradient."""
+@pytest.mark.parametrize("builder,S,P", [(problems.hyper_sensitive, 5, 15), (problems.kitchen_sink, 20, 3)])
+def test_adaptive_oracles_are_consistent_at_larger_grids(builder, S, P):
+    """The reference's second adaptive fixture (tests/test_mpopt.py:275-282: 5 segments of degree 15) and a
+    20-segment, 2-phase, time-dependent grid (every row couples to all earlier widths).  The outer solve is the
+    stand-in's business; what is on the path is that the assembled oracles are consistent at that size: gradient
+    and Jacobian against central differences of f and g, Hessian against differences of the Lagrangian gradient."""
     mp.mpopt._MUTE_ = True
-    mpo = mp.mpopt_adaptive(problems.hyper_sensitive(mp, M.math), 5, 15)
-    mpo.lbh[0] = 1e-6
+    mpo = mp.mpopt_adaptive(builder(mp, M.math), S, P)
+    mpo.lbh = [1e-6] * mpo._ocp.n_phases
     mpo.validate()
     nlp, _ = mpo.create_nlp()
     o = nlp["oracle"]
@@ -140,19 +141,21 @@ def test_hyper_sensitive_mpopt_adaptive_oracles_at_degree_15():
     H = np.zeros((o.n_z, o.n_z))
     H[hr, hc] = r["hess_l"]
     H = H + np.triu(H, 1).T
-    cols = rng.choice(o.n_z, 12, replace=False)
+    n_zp = o.n_z // mpo._ocp.n_phases
+    cols = np.concatenate([rng.choice(o.n_z, 10, replace=False), [n_zp - 1, n_zp - S, n_zp - S - 1]])  # + widths and a parameter / tf
     eps = 1e-6
     Zp = np.stack([z + eps * np.eye(o.n_z)[c] for c in cols] + [z - eps * np.eye(o.n_z)[c] for c in cols])
     q = o.eval(["f", "g", "grad_f", "jac_g"], Zp, None)
     k = len(cols)
-    assert np.abs((q["f"][:k] - q["f"][k:]) / (2 * eps) - r["grad_f"][cols]).max() < 1e-6
-    assert np.abs((q["g"][:k] - q["g"][k:]).T / (2 * eps) - J[:, cols]).max() < 1e-5
+    scale = max(1.0, np.abs(J).max())
+    assert np.abs((q["f"][:k] - q["f"][k:]) / (2 * eps) - r["grad_f"][cols]).max() < 1e-6 * max(1.0, np.abs(r["grad_f"]).max())
+    assert np.abs((q["g"][:k] - q["g"][k:]).T / (2 * eps) - J[:, cols]).max() < 1e-6 * scale
     gl = np.zeros((2 * k, o.n_z))
     for b in range(2 * k):  # gradient of the Lagrangian at the shifted points
         Jb = np.zeros((o.n_g, o.n_z))
         Jb[jr, jc] = q["jac_g"][b]
         gl[b] = sig * q["grad_f"][b] + lam @ Jb
-    assert np.abs((gl[:k] - gl[k:]).T / (2 * eps) - H[:, cols]).max() < 1e-4
+    assert np.abs((gl[:k] - gl[k:]).T / (2 * eps) - H[:, cols]).max() < 1e-5 * max(1.0, np.abs(H).max())
 
 
 @pytest.mark.parametrize("builder,S,po,scheme,mid", [
