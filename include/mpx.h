@@ -66,6 +66,11 @@ extern "C" {
                                    that keeps its jac_val buffers resident (a device-side consumer) pays for them
                                    once: the buffers must hold the values of an earlier full MPX_JAC evaluation of
                                    the same context and batch slots.  Never the default. */
+#define MPX_CCS_ORDER 128 /* jac_val / hess_val leave in compressed-column order (the order mpx_ccs_perm describes,
+                             CasADi's convention) instead of the native order of mpx_pattern_*: a device-side
+                             permutation pass after the evaluation (~3 us), so that the nlp_jac_g / nlp_hess_l
+                             entry points need no host-side reordering.  Not combinable with
+                             MPX_JAC_VARIABLE_ONLY / MPX_BOUNDARY_ONLY. */
 #define MPX_BOUNDARY_ONLY 32 /* skip the node kernels: finish reductions / terminal / linking rows only
                                 (second half of a segment-sharded evaluation, see mpx_set_tile_range) */
 
@@ -183,6 +188,10 @@ int mpx_sync(mpx_ctx* ctx);
  * mpx_host_alloc are DMA targets.  Free with mpx_host_free before mpx_destroy. */
 int mpx_host_alloc(mpx_ctx* ctx, size_t bytes, void** ptr);
 int mpx_host_free(mpx_ctx* ctx, void* ptr);
+/* Page-lock caller-owned memory in place (for buffers the caller cannot allocate through mpx_host_alloc, e.g. a
+ * solver's work vectors).  Unregister before the memory is freed. */
+int mpx_host_register(mpx_ctx* ctx, void* ptr, size_t bytes);
+int mpx_host_unregister(mpx_ctx* ctx, void* ptr);
 
 /* Segment sharding (multi-GPU): restrict the node kernels of this context to the
  * tiles [tile_begin, tile_end) and report the contiguous value ranges they own, so that ranks
@@ -283,6 +292,10 @@ int mpx_create_assembled(const mpx_assembly* desc, mpx_ctx** out);
  * selected here (process-wide; NULL clears it).  The context must outlive its selection.
  * ------------------------------------------------------------------------------------------- */
 int mpx_set_current(mpx_ctx* ctx);
+/* Opt-in: page-lock the argument / result arrays handed to nlp_* the first time each pointer is seen (CasADi passes
+ * the same work-vector slices on every call), so that every transfer is a direct DMA.  The registrations are
+ * released by mpx_set_current (any argument) and by mpx_current_pin_buffers(0); the arrays must outlive that. */
+int mpx_current_pin_buffers(int enable);
 
 /* ---------------------------------------------------------------------------------------------
  * Timing helper: HIP events on the context's stream (bench.py measures kernel time with these)

@@ -25,7 +25,7 @@ c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)
 
-MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MPX_BOUNDARY_ONLY, MPX_JAC_VARIABLE_ONLY = 1, 2, 4, 8, 16, 32, 64
+MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MPX_BOUNDARY_ONLY, MPX_JAC_VARIABLE_ONLY, MPX_CCS_ORDER = 1, 2, 4, 8, 16, 32, 64, 128
 SCHEMES = {"LGR": 0, "LGL": 1, "CGL": 2, "LG": 3}
 SCHEME_EQUI = 4
 
@@ -143,6 +143,9 @@ SYMBOLS = {
     "mpx_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_host_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
     "mpx_host_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mpx_host_register": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "mpx_host_unregister": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mpx_current_pin_buffers": (ctypes.c_int, [ctypes.c_int]),
     "mpx_set_tile_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "mpx_get_tile_jac_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p, c_int64_p]),
     "mpx_get_tile_weights": (ctypes.c_int, [ctypes.c_void_p, c_int64_p]),

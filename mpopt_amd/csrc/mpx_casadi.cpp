@@ -27,7 +27,25 @@ struct Current {
   std::vector<cint> sp_x, sp_p, sp_g, sp_one, sp_jac, sp_hess;
   std::vector<int64_t> perm_j, perm_h;
   std::vector<double> zx, zp, zl, buf_j, buf_h, buf_g, buf_grad;
+  bool pin = false;
+  std::vector<std::pair<const void*, size_t>> pinned;  // caller arrays registered so far (mpx_current_pin_buffers)
 } C;
+
+void release_pins() {
+  for (auto& e : C.pinned)
+    if (e.second) mpx_host_unregister(C.ctx, const_cast<void*>(e.first));
+  C.pinned.clear();
+}
+
+// Register a caller array once; a failed registration (e.g. memory that is already page-locked) is remembered
+// with size 0 so that it is not retried on every call.
+void pin(const void* p, size_t n_doubles) {
+  if (!C.pin || !p || !n_doubles) return;
+  for (auto& e : C.pinned)
+    if (e.first == p) return;
+  const bool ok = mpx_host_register(C.ctx, const_cast<void*>(p), n_doubles * sizeof(double)) == MPX_OK;
+  C.pinned.emplace_back(p, ok ? n_doubles : 0);
+}
 
 std::vector<cint> dense_col(cint n) {
   std::vector<cint> s = {n, 1, 0, n};
@@ -43,7 +61,19 @@ std::vector<cint> ccs(cint nrow, cint ncol, const std::vector<int64_t>& colind, 
 const double* in(const double** arg, int i, std::vector<double>& zeros) { return arg && arg[i] ? arg[i] : zeros.data(); }
 }  // namespace
 
+extern "C" int mpx_current_pin_buffers(int enable) {
+  if (!C.ctx) return MPX_ERR_INVALID;
+  if (!enable) release_pins();
+  C.pin = enable != 0;
+  return MPX_OK;
+}
+
 extern "C" int mpx_set_current(mpx_ctx* ctx) {
+  if (C.ctx) {  // drop the registrations made for the previous selection (failed ones are skipped by the size)
+    for (auto& e : C.pinned)
+      if (e.second) mpx_host_unregister(C.ctx, const_cast<void*>(e.first));
+    C.pinned.clear();
+  }
   if (!ctx) {
     C = Current{};
     return MPX_OK;
@@ -114,6 +144,7 @@ extern "C" const long long* nlp_g_sparsity_out(long long i) { return i == 0 ? C.
 extern "C" int nlp_g(const double** arg, double** res, long long*, double*, int) {
   if (!C.ctx) return 1;
   double* g = res && res[0] ? res[0] : C.buf_g.data();
+  if (C.pin) pin(arg ? arg[0] : 0, C.sz.n_z), pin(res ? res[0] : 0, C.sz.n_g);
   return mpx_eval(C.ctx, MPX_G, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, 0, g, 0, 0, 0) ? 1 : 0;
 }
 
@@ -127,6 +158,7 @@ extern "C" int nlp_grad_f(const double** arg, double** res, long long*, double*,
   if (!C.ctx) return 1;
   double f;
   double* gr = res && res[1] ? res[1] : C.buf_grad.data();
+  if (C.pin) pin(arg ? arg[0] : 0, C.sz.n_z), pin(res ? res[1] : 0, C.sz.n_z);
   if (mpx_eval(C.ctx, MPX_F | MPX_GRAD, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, &f, 0, gr, 0, 0)) return 1;
   if (res && res[0]) res[0][0] = f;
   return 0;
@@ -141,10 +173,9 @@ extern "C" const long long* nlp_jac_g_sparsity_out(long long i) { return i == 0 
 extern "C" int nlp_jac_g(const double** arg, double** res, long long*, double*, int) {
   if (!C.ctx) return 1;
   double* g = res && res[0] ? res[0] : C.buf_g.data();
-  if (mpx_eval(C.ctx, MPX_G | MPX_JAC, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, 0, g, 0, C.buf_j.data(), 0)) return 1;
-  if (res && res[1])
-    for (size_t k = 0; k < C.perm_j.size(); ++k) res[1][k] = C.buf_j[C.perm_j[k]];
-  return 0;
+  double* jv = res && res[1] ? res[1] : C.buf_j.data();  // compressed-column order straight from the device
+  if (C.pin) pin(arg ? arg[0] : 0, C.sz.n_z), pin(res ? res[0] : 0, C.sz.n_g), pin(res ? res[1] : 0, C.sz.nnz_jac);
+  return mpx_eval(C.ctx, MPX_G | MPX_JAC | MPX_CCS_ORDER, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, 0, g, 0, jv, 0) ? 1 : 0;
 }
 
 // ---- nlp_hess_l : (x, p, lam_f, lam_g) -> (hess_gamma_x_x, upper triangle) -----------------------
@@ -161,8 +192,7 @@ extern "C" const long long* nlp_hess_l_sparsity_out(long long i) { return i == 0
 extern "C" int nlp_hess_l(const double** arg, double** res, long long*, double*, int) {
   if (!C.ctx) return 1;
   const double sigma = arg && arg[2] ? arg[2][0] : 0.0;
-  if (mpx_eval(C.ctx, MPX_HESS, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, in(arg, 3, C.zl), &sigma, 0, 0, 0, 0, C.buf_h.data())) return 1;
-  if (res && res[0])
-    for (size_t k = 0; k < C.perm_h.size(); ++k) res[0][k] = C.buf_h[C.perm_h[k]];
-  return 0;
+  double* hv = res && res[0] ? res[0] : C.buf_h.data();
+  if (C.pin) pin(arg ? arg[0] : 0, C.sz.n_z), pin(arg ? arg[3] : 0, C.sz.n_g), pin(res ? res[0] : 0, C.sz.nnz_hess);
+  return mpx_eval(C.ctx, MPX_HESS | MPX_CCS_ORDER, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, in(arg, 3, C.zl), &sigma, 0, 0, 0, 0, hv) ? 1 : 0;
 }

@@ -648,6 +648,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->d_mg_dst), fr(c->d_hc_dst), fr(c->d_th_dst);
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
+    fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
@@ -770,6 +771,20 @@ extern "C" int mpx_host_alloc(mpx_ctx* c, size_t bytes, void** ptr) {
 extern "C" int mpx_host_free(mpx_ctx* c, void* ptr) {
   if (!c) return MPX_ERR_INVALID;
   if (ptr) HIPCHK(c, hipHostFree(ptr));
+  return MPX_OK;
+}
+
+extern "C" int mpx_host_register(mpx_ctx* c, void* ptr, size_t bytes) {
+  if (!c || !ptr || !bytes) return MPX_ERR_INVALID;
+  if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "context has no device code");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return MPX_OK;
+}
+
+extern "C" int mpx_host_unregister(mpx_ctx* c, void* ptr) {
+  if (!c || !ptr) return MPX_ERR_INVALID;
+  HIPCHK(c, hipHostUnregister(ptr));
   return MPX_OK;
 }
 
@@ -997,8 +1012,53 @@ extern "C" int mpx_eval_device(mpx_ctx* c, int mask, int64_t batch, const double
   return eval_core(c, mask, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val, false);
 }
 
+// out[b][k] = in[b][perm[k]]
+__global__ __launch_bounds__(256) void mpx_permute_kernel(const double* __restrict__ in, double* __restrict__ out, const int64_t* __restrict__ perm,
+                                                          int64_t n) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[(int64_t)blockIdx.y * n + k] = in[(int64_t)blockIdx.y * n + perm[k]];
+}
+
+static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                       const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix);
+
+static int upload_ccs_perm(mpx_ctx* c, int which, int64_t** dst) {
+  if (*dst) return MPX_OK;
+  const int64_t nnz = which == MPX_JAC ? c->nnz_j : c->nnz_h;
+  std::vector<int64_t> perm((size_t)std::max<int64_t>(nnz, 1)), colind((size_t)c->n_z + 1);
+  int rc = mpx_ccs_perm(c, which, perm.data(), colind.data());
+  if (rc) return rc;
+  perm.resize((size_t)nnz);
+  return upload(c, dst, perm);
+}
+
 static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
                      const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix) {
+  if (!c || !(mask & MPX_CCS_ORDER)) return eval_native(c, mask, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val, skip_prefix);
+  if (mask & (MPX_JAC_VARIABLE_ONLY | MPX_BOUNDARY_ONLY)) return fail(c, MPX_ERR_INVALID, "MPX_CCS_ORDER cannot be combined with MPX_JAC_VARIABLE_ONLY / MPX_BOUNDARY_ONLY");
+  if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
+  if (batch < 1 || batch > 65535) return fail(c, MPX_ERR_INVALID, "MPX_CCS_ORDER: batch must be 1..65535");
+  if (((mask & MPX_JAC) && !jac_val) || ((mask & MPX_HESS) && !hess_val)) return fail(c, MPX_ERR_INVALID, "mpx_eval: output array is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  double *tj = jac_val, *th = hess_val;
+  if ((mask & MPX_JAC) && c->nnz_j) {
+    if ((rc = upload_ccs_perm(c, MPX_JAC, &c->d_perm_j)) || (rc = reserve(c, c->ccs_j, (size_t)(batch * c->nnz_j)))) return rc;
+    tj = c->ccs_j.p;
+  }
+  if ((mask & MPX_HESS) && c->nnz_h) {
+    if ((rc = upload_ccs_perm(c, MPX_HESS, &c->d_perm_h)) || (rc = reserve(c, c->ccs_h, (size_t)(batch * c->nnz_h)))) return rc;
+    th = c->ccs_h.p;
+  }
+  if ((rc = eval_native(c, mask & ~MPX_CCS_ORDER, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, tj, th, skip_prefix))) return rc;
+  if (tj != jac_val) hipLaunchKernelGGL(mpx_permute_kernel, dim3((unsigned)((c->nnz_j + 255) / 256), (unsigned)batch), dim3(256), 0, c->stream, tj, jac_val, c->d_perm_j, c->nnz_j);
+  if (th != hess_val) hipLaunchKernelGGL(mpx_permute_kernel, dim3((unsigned)((c->nnz_h + 255) / 256), (unsigned)batch), dim3(256), 0, c->stream, th, hess_val, c->d_perm_h, c->nnz_h);
+  HIPCHK(c, hipGetLastError());
+  return MPX_OK;
+}
+
+static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                       const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix) {
   if (!c) return MPX_ERR_INVALID;
   if (!c->has_device)
     return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");

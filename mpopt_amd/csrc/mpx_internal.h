@@ -92,6 +92,9 @@ struct mpx_ctx {
           *d_hc_dst = nullptr, *d_th_dst = nullptr;
   double* d_lin_coef = nullptr;
   DevBuf<double> partial, wcum, st_z, st_p, st_lam, st_sig, st_f, st_g, st_grad, st_jac, st_hess;
+  // MPX_CCS_ORDER: scratch in native order + device copies of the permutations (built on first use)
+  DevBuf<double> ccs_j, ccs_h;
+  int64_t *d_perm_j = nullptr, *d_perm_h = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t tile_begin = 0, tile_end = 0;
   int run_boundary = 1;

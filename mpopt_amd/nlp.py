@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MpxError, mpx_problem, mpx_sizes
+from ._lib import MPX_CCS_ORDER, MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MpxError, mpx_problem, mpx_sizes
 from .codegen import ProblemProgram
 
 
@@ -225,13 +225,15 @@ class NlpFunctions:
         return ResidualPlan(self, phase, taus_per_segment)
 
     # -- evaluation ------------------------------------------------------------------------
-    def eval(self, what, z, p, lam_g=None, sigma=None, pinned=False):
+    def eval(self, what, z, p, lam_g=None, sigma=None, pinned=False, ccs_order=False):
         """Host arrays in, dict of host arrays out.  ``z``: (B, n_z) or (n_z,); ``p``: (n_p,) shared
         or (B, n_p).  ``what``: iterable of {"f","g","grad_f","jac_g","hess_l"}.
         ``pinned=True``: inputs are staged through, and outputs are *views of*, page-locked buffers owned
         by this object (true DMA transfers, about half the latency of a single evaluation); the returned
-        arrays are overwritten by the next ``eval(..., pinned=True)`` of the same shape."""
-        mask = sum({"f": MPX_F, "g": MPX_G, "grad_f": MPX_GRAD, "jac_g": MPX_JAC, "hess_l": MPX_HESS}[w] for w in set(what))
+        arrays are overwritten by the next ``eval(..., pinned=True)`` of the same shape.
+        ``ccs_order=True``: ``jac_g`` / ``hess_l`` values leave in compressed-column order (``ccs_perm``), permuted
+        on the device (MPX_CCS_ORDER)."""
+        mask = (MPX_CCS_ORDER if ccs_order else 0) + sum({"f": MPX_F, "g": MPX_G, "grad_f": MPX_GRAD, "jac_g": MPX_JAC, "hess_l": MPX_HESS}[w] for w in set(what))
         z = np.ascontiguousarray(z, dtype=np.float64)
         single = z.ndim == 1
         z = z.reshape(-1, self.n_z)

@@ -114,6 +114,14 @@ def test_casadi_external_entry_points(name):
     Hr = np.zeros((o.n_z, o.n_z))
     Hr[G["hess_row"], G["hess_col"]] = G["hess_val"]
     assert rel_err(ccs_dense("nlp_hess_l", 0, hv), Hr) < TOL
+    # opt-in: page-lock the caller's arrays on first sight (CasADi's work vectors persist over a solve): same values
+    assert L.mpx_current_pin_buffers(1) == 0
+    jv2, hv2, g2 = np.zeros(o.nnz_jac), np.zeros(o.nnz_hess), np.zeros(o.n_g)
+    for _ in range(2):
+        call("nlp_jac_g", [z, p], [g2, jv2])
+        call("nlp_hess_l", [z, p, sig, lam], [hv2])
+    assert np.array_equal(jv2, jv) and np.array_equal(hv2, hv) and np.array_equal(g2, g)
+    assert L.mpx_current_pin_buffers(0) == 0
     # NULL argument = zeros, NULL result = not requested (CasADi convention)
     call("nlp_jac_g", [z, p], [None, jv])
     call("nlp_hess_l", [z, p, None, None], [hv])

@@ -312,3 +312,29 @@ def test_pinned_host_buffers_match_pageable():
     c = o.eval(what, 2 * z, p, lam_g=lam, sigma=np.array([1.0, 0.5, 2.0]), pinned=True)
     assert c["jac_g"].ctypes.data == b["jac_g"].ctypes.data          # same page-locked buffer, overwritten
     assert not np.array_equal(c["g"], keep["g"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kitchen_sink_mixed_CGL", "adaptive_generic_two_phase_LGR"])
+def test_ccs_order_is_the_device_side_permutation(name):
+    """MPX_CCS_ORDER: jac_g / hess_l values in compressed-column order equal the native values gathered with
+    mpx_ccs_perm, bit for bit, for tiled and assembled contexts and for batches."""
+    from helpers import build_case, load_golden
+
+    G = load_golden(name)
+    ocp, mpo, o = build_case(name, with_device=True)
+    rng = np.random.default_rng(2)
+    Z = G["z"][None, :] * (1 + 0.01 * rng.uniform(-1, 1, (3, o.n_z)))
+    lam = rng.standard_normal((3, o.n_g))
+    sig = np.array([1.0, 0.3, 2.0])
+    a = o.eval(["g", "jac_g", "hess_l"], Z, G["p"], lam_g=lam, sigma=sig)
+    b = o.eval(["g", "jac_g", "hess_l"], Z, G["p"], lam_g=lam, sigma=sig, ccs_order=True)
+    pj, colj = o.ccs_perm("jac")
+    ph, colh = o.ccs_perm("hess")
+    assert np.array_equal(a["g"], b["g"])
+    assert np.array_equal(a["jac_g"][:, pj], b["jac_g"]) and np.array_equal(a["hess_l"][:, ph], b["hess_l"])
+    jr, jc = o.jac_pattern()
+    assert (np.diff(jc[pj]) >= 0).all() and colj[-1] == o.nnz_jac
+    one = o.eval(["jac_g"], Z[1], G["p"], ccs_order=True)
+    assert np.array_equal(one["jac_g"], b["jac_g"][1])
+    o.close()
