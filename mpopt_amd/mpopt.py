@@ -755,8 +755,49 @@ class mpopt:
                 residuals[phase] = [None if r_ is None else np.asarray(r_) / mx for r_ in residuals[phase]]
         return x_int, u_int, ti, residuals
 
-    def process_results(self, solution, plot=False, **kwargs):
-        return post_process(self, solution)
+    def init_trajectories(self, phase=0):
+        """Callable ``(z, seg_widths) -> (x, u, t, t0, tf, a)`` of one phase: scaled x, u, a, unscaled t, t0, tf
+        (the CasADi Function of mpopt.py:857-882)."""
+        o = self._ocp
+        sx, su, sa = np.asarray(o.scale_x, float), np.asarray(o.scale_u, float), np.asarray(o.scale_a, float)
+
+        def trajectories(z, seg_widths):
+            keep = getattr(self, "_nlp_sw_params", None)
+            self._nlp_sw_params = np.asarray(seg_widths, float).ravel()
+            try:
+                X, U, t, t0, tf, a = self.get_trajectories({"x": z}, phase)
+            finally:
+                if keep is not None:
+                    self._nlp_sw_params = keep
+            return (_mat(X * sx), _mat(U * su), _mat(t.reshape(-1, 1)), t0, tf, _mat((a * sa).reshape(-1, 1)))
+
+        return trajectories
+
+    def process_results(self, solution, plot=False, scaling=False, residual_x=False, residual_dx=True):
+        """``post_process`` object with the solution, the per-phase trajectory extractors and, like the reference
+        (mpopt.py:884-981), the residuals it was asked for in ``options["residuals"]``.  ``plot`` is ignored."""
+        o = self._ocp
+        trajectories = [self.init_trajectories(phase) for phase in range(o.n_phases)]
+        resid_value = {}
+        if residual_x:
+            x_int, u_int, ti, res_x = self.get_states_residuals(solution)
+            resid_value["t_x"] = [ti, res_x]
+        if residual_dx:
+            tdx, res_dx = self.get_dynamics_residuals(solution)
+            resid_value["t_dx"] = [tdx, res_dx]
+        else:  # the reference drops the state residuals too in this case (mpopt.py:921-925)
+            resid_value = None
+
+        def interpolate(phase, taus):
+            Xi, Ui, *_ = self.interpolate_single_phase(solution, phase=phase, target_nodes=taus)
+            return Xi.full(), Ui.full()
+
+        options = {"nx": o.nx, "nu": o.nu, "na": o.na, "nPh": o.n_phases, "ns": self.n_segments, "poly_orders": self.poly_orders,
+                   "N": self._Npoints, "phases_to_plot": o.phases_to_plot, "scale_x": o.scale_x, "scale_u": o.scale_u,
+                   "scale_a": o.scale_a, "scale_t": o.scale_t, "scaling": scaling, "colloc_scheme": self.colloc_scheme,
+                   "tau0": self.tau0, "tau1": self.tau1, "interpolation_depth": 3, "seg_widths": self._nlp_sw_params,
+                   "residuals": resid_value, "interpolate": interpolate}
+        return post_process(solution, trajectories, options)
 
 
 class mpopt_h_adaptive(mpopt):
@@ -1162,29 +1203,103 @@ def _ref_control_order(U):
 
 
 class post_process:
-    """Minimal stand-in for the reference's post-processor: solution data per phase, no plots."""
+    """Solution data of the optimizer for further processing (mpopt.py:1576-1858, data methods).  Plotting
+    (plot_phases, plot_x, ...; mpopt.py:1860-2270) is outside this build: those names raise.
 
-    def __init__(self, mpo, solution):
-        self.mpo, self.solution = mpo, solution
+        >>> post = post_process(solution, trajectories, options)      # what mpopt.process_results builds
+
+    ``trajectories[phase](z, seg_widths) -> (x, u, t, t0, tf, a)`` (scaled x, u, a; unscaled t), as returned by
+    ``mpopt.init_trajectories``.  ``options["interpolate"]``, when present, is a callable
+    ``(phase, taus) -> (Xi, Ui)`` evaluating the collocation polynomials on the GPU (kernel mpx_resid_*); without it
+    the composite interpolation matrix is applied on the host like the reference does (mpopt.py:1804-1812)."""
 
     _INTERPOLATION_NODES_PER_SEG = 50
 
-    def get_data(self, phases=None, interpolate=False):
-        """(x, u, t, a) unscaled, phases stacked; ``interpolate=True`` evaluates the collocation polynomials
-        at ``_INTERPOLATION_NODES_PER_SEG`` equally spaced points of every segment (GPU kernel mpx_resid_*)."""
-        mpo, o = self.mpo, self.mpo._ocp
-        phases = range(o.n_phases) if phases is None else phases
-        xs, us, ts = [], [], []
-        for ph in phases:
-            if not interpolate:
-                X, U, t, *_ = mpo.get_trajectories(self.solution, ph)
+    def __init__(self, solution={}, trajectories=None, options={}):
+        self.solution, self.trajectories, self.options = solution, trajectories, options
+        self.phases = self.options["phases_to_plot"][0] if "phases_to_plot" in self.options else [0]
+        self.nx, self.nu, self.na = self.options.get("nx", 1), self.options.get("nu", 1), self.options.get("na", 0)
+        self.scaling = self.options.get("scaling", False)
+        self.tau0 = self.options.get("tau0", CollocationRoots._TAU_MIN)
+        self.tau1 = self.options.get("tau1", CollocationRoots._TAU_MAX)
+        self.residuals = options.get("residuals")
+
+    def get_trajectories(self, phase=0):
+        """(x, u, t, a) of one phase; unscaled unless ``options["scaling"]`` (mpopt.py:1633-1661)."""
+        x, u, t, t0, tf, a = self.trajectories[phase](self.solution["x"], self.options["seg_widths"])
+        x, u, t, a = (np.asarray(v.full() if hasattr(v, "full") else v, float) for v in (x, u, t, a))
+        if not self.scaling:
+            # a (na x 1) divided by the 1-D scale vector broadcasts to na x na -- the reference does exactly this
+            # (mpopt.py:1655-1659); reproduced so that callers indexing its result keep working
+            return (x / self.options.get("scale_x", 1.0), u / self.options.get("scale_u", 1.0), t, a / self.options.get("scale_a", 1.0))
+        return (x, u, t, a)
+
+    def get_original_data(self, phases=[]):
+        if not phases:
+            phases = self.phases
+        x, u, t, a = self.get_trajectories(phases[0])
+        for phase in phases[1:]:
+            xp, up, tp, ap = self.get_trajectories(phase)
+            x, u, t, a = np.vstack((x, xp)), np.vstack((u, up)), np.vstack((t, tp)), np.vstack((a, ap))
+        return (x, u, t, a)
+
+    def get_interpolation_taus(self, n=75, taus_orig=None, method="uniform"):
+        if method == "uniform" or taus_orig is None:
+            return np.linspace(self.tau0, self.tau1, n)
+        return self.get_non_uniform_interpolation_grid(taus_orig, n)
+
+    @staticmethod
+    def get_non_uniform_interpolation_grid(taus_orig, n=75):
+        """Insert mid-points until there are ``n`` points, at most 6 times (mpopt.py:1712-1738)."""
+        taus = np.asarray(taus_orig, float)
+        count = 0
+        while len(taus) < n:
+            out = np.empty(2 * len(taus) - 1)
+            out[0::2], out[1::2] = taus, (taus[:-1] + taus[1:]) / 2.0
+            taus = out
+            count += 1
+            if count > 5:
+                break
+        return taus
+
+    @staticmethod
+    def get_interpolated_time_grid(t_orig, taus, poly_orders, tau0, tau1):
+        return mpopt.get_interpolated_time_grid(t_orig, taus, poly_orders, tau0, tau1).ravel()
+
+    def get_interpolated_data(self, phases, taus=[]):
+        """(x, u, t, a) on a refined grid: by default ``_INTERPOLATION_NODES_PER_SEG`` equally spaced points per
+        segment (mpopt.py:1773-1831)."""
+        poly_orders = list(self.options["poly_orders"])
+        if len(taus) == 0:
+            taus = [self.get_interpolation_taus(n=self._INTERPOLATION_NODES_PER_SEG)[1:] for _ in poly_orders]
+            taus[0] = np.append(self.tau0, taus[0])
+        gpu = self.options.get("interpolate")
+        compI = None
+        xs, us, ts, as_ = [], [], [], []
+        for phase in phases:
+            x_orig, u_orig, t_orig, a = self.get_original_data([phase])
+            if gpu is not None:
+                scale_x = 1.0 if self.scaling else self.options.get("scale_x", 1.0)
+                scale_u = 1.0 if self.scaling else self.options.get("scale_u", 1.0)
+                Xi, Ui = gpu(phase, taus)
+                x, u = Xi / scale_x, Ui / scale_u
             else:
-                n = self._INTERPOLATION_NODES_PER_SEG
-                taus = [np.linspace(mpo.tau0, mpo.tau1, n + 1)[(0 if s == 0 else 1):] for s in range(mpo.n_segments)]
-                Xi, Ui, ti, *_ = mpo.interpolate_single_phase(self.solution, phase=ph, target_nodes=taus)
-                X, U, t = Xi.full() / np.asarray(o.scale_x, float), Ui.full() / np.asarray(o.scale_u, float), ti.full().ravel()
-            xs.append(X), us.append(U), ts.append(np.asarray(t).reshape(-1, 1))
-        return np.concatenate(xs), np.concatenate(us), np.concatenate(ts), None
+                if compI is None:
+                    compI = Collocation(poly_orders, self.options.get("colloc_scheme", "LGR")).get_composite_interpolation_matrix(taus, poly_orders)
+                x, u = np.dot(compI, x_orig), np.dot(compI, u_orig)
+            xs.append(x), us.append(u), as_.append(a)
+            ts.append(self.get_interpolated_time_grid(t_orig, taus, poly_orders, self.tau0, self.tau1))
+        return (np.vstack(xs), np.vstack(us), np.hstack(ts), np.hstack(as_) if len(phases) > 1 else as_[0])
+
+    def get_data(self, phases=[], interpolate=False):
+        if not phases:
+            phases = self.phases
+        return self.get_interpolated_data(phases) if interpolate else self.get_original_data(phases)
+
+    def __getattr__(self, name):
+        if name.startswith("plot_") or name == "sort_residual_data":
+            raise NotImplementedError(f"post_process.{name}: plotting is outside the scope of mpopt_amd (DESIGN.md section 1)")
+        raise AttributeError(name)
 
 
 def solve(ocp, n_segments=1, poly_orders=9, scheme="LGR", plot=True, solve_dict=dict(), residual_x=False, residual_dx=True):

@@ -240,6 +240,29 @@ def make_residuals(name, builder, n_segments, poly_orders, scheme):
     print(f"resid_{name}.npz: {len(out)} arrays ({time.time()-t0:.1f}s)")
 
 
+POST_CASES = ["moon_lander_20x3_LGR", "schwartz_4x3_LGL", "kitchen_sink_mixed_CGL"]
+
+
+def make_post(name, builder, n_segments, poly_orders, scheme):
+    """post_process data methods (mpopt.py:1633-1858): the reference's
+    process_results(...).get_data() and get_data(interpolate=True) at the golden sample point."""
+    ref.CollocationRoots._TAU_MIN, ref.CollocationRoots._TAU_MAX = -1, 1
+    ref.Collocation.D_MATRIX_METHOD = "numerical"
+    G = np.load(os.path.join(HERE, f"nlp_{name}.npz"))
+    mpo = ref.mpopt(builder(ref, casadi_shim), n_segments, poly_orders, scheme)
+    mpo.create_nlp()
+    mpo._nlp_sw_params = list(G["p"])
+    post = mpo.process_results({"x": G["z"]}, plot=False, residual_dx=False)
+    out = {}
+    for tag, interp in (("orig", False), ("interp", True)):
+        x, u, t, a = post.get_data(interpolate=interp)
+        out[tag + "/x"], out[tag + "/u"], out[tag + "/t"] = np.asarray(x, float), np.asarray(u, float), np.asarray(t, float)
+        out[tag + "/a"] = np.asarray(a, float)
+    out["grid/non_uniform"] = ref.post_process.get_non_uniform_interpolation_grid(np.array([-1.0, -0.2, 0.5, 1.0]), 20)
+    np.savez_compressed(os.path.join(HERE, f"post_{name}.npz"), **out)
+    print(f"post_{name}.npz: " + ", ".join(f"{k}{v.shape}" for k, v in out.items()))
+
+
 def make_hadaptive():
     """h-adaptive refinement: the reference's static helpers on seeded inputs and its
     width-update rules (mpopt.py:2524-2874) at the golden sample points."""
@@ -295,15 +318,22 @@ def main():
     for name, (builder, s, po, scheme) in problems.GOLDEN_CASES.items():
         if only and name not in only:
             continue
-        if only in (["residuals"], ["hadaptive"], ["adaptive"]):
+        if only in (["residuals"], ["hadaptive"], ["adaptive"], ["post"]):
             continue
         make_case(name, builder, s, po, scheme)
     for name, (builder, s, po, scheme) in problems.ADAPTIVE_CASES.items():
-        if only and name not in only and "adaptive" not in only:
+        if only == ["post"] or (only and name not in only and "adaptive" not in only):
             continue
         make_case(name, builder, s, po, scheme, adaptive=True)
     if not only or "hadaptive" in only:
         make_hadaptive()
+    if only == ["post"]:
+        for name in POST_CASES:
+            make_post(name, *problems.GOLDEN_CASES[name])
+        return
+    if not only:
+        for name in POST_CASES:
+            make_post(name, *problems.GOLDEN_CASES[name])
     for name in RESIDUAL_CASES:
         if only and ("resid_" + name) not in only and "residuals" not in only:
             continue

@@ -154,3 +154,25 @@ def test_width_cache_on_host_path():
     rb = o.eval(what, np.stack([z, z]), p1)  # batch size change
     assert np.array_equal(rb["g"][0], o.eval(what, z, p1)["g"])
     assert rel_err(o.eval(what, z, p1)["g"], G["g"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "schwartz_4x3_LGL", "kitchen_sink_mixed_CGL"])
+def test_process_results_interpolated_data_on_gpu(name):
+    """mpopt.process_results(...).get_data(interpolate=True): the refined-grid states/controls come from the GPU
+    interpolation kernel (mpx_resid_*) and equal what the reference's post_process returned (mpopt.py:1773-1831)."""
+    import os
+    from helpers import GOLDEN
+
+    G, P = load_golden(name), np.load(os.path.join(GOLDEN, f"post_{name}.npz"))
+    ocp, mpo, o = build_case(name, with_device=True)
+    mpo.create_nlp()
+    mpo._nlp_sw_params = G["p"]
+    post = mpo.process_results({"x": G["z"]}, plot=False, residual_x=True, residual_dx=True)
+    assert set(post.residuals) == {"t_x", "t_dx"} and len(post.residuals["t_dx"][1]) == ocp.n_phases
+    x, u, t, a = post.get_data()
+    xi, ui, ti, ai = post.get_data(interpolate=True)
+    assert xi.shape == P["interp/x"].shape and ui.shape == P["interp/u"].shape and ti.shape == P["interp/t"].shape
+    assert rel_err(x, P["orig/x"]) < 1e-12 and rel_err(t, P["orig/t"]) < 1e-12
+    assert rel_err(xi, P["interp/x"]) < TOL and rel_err(ui, P["interp/u"]) < TOL and rel_err(ti, P["interp/t"]) < TOL
+    assert mpo.process_results({"x": G["z"]}, residual_dx=False).residuals is None
+    o.close()

@@ -118,3 +118,34 @@ def test_solve_and_postprocess(name):
     ti_r, residuals = mpo.get_dynamics_residuals(sol, grid_type="spectral")
     mx = max(np.abs(r).max() for r in residuals[0] if r is not None)
     assert np.isfinite(mx) and mx < 4
+
+
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "schwartz_4x3_LGL", "kitchen_sink_mixed_CGL"])
+def test_post_process_original_data_matches_reference(name):
+    """post_process.get_data() (mpopt.py:1633-1690, 1833-1858) at the golden sample point against what the
+    reference's own process_results(...).get_data() returned (tests/golden/make_golden.py post)."""
+    import os
+    from helpers import GOLDEN, load_golden
+
+    builder, S, po, scheme = problems.GOLDEN_CASES[name]
+    G, P = load_golden(name), np.load(os.path.join(GOLDEN, f"post_{name}.npz"))
+    mp.mpopt._MUTE_ = True
+    mpo = mp.mpopt(builder(mp, M.math), S, po, scheme)
+    mpo.compute_numerical_approximation()
+    mpo._nlp_sw_params = G["p"]
+    post = mp.post_process({"x": G["z"]}, [mpo.init_trajectories(ph) for ph in range(mpo._ocp.n_phases)],
+                           {"phases_to_plot": mpo._ocp.phases_to_plot, "seg_widths": G["p"], "scale_x": mpo._ocp.scale_x,
+                            "scale_u": mpo._ocp.scale_u, "scale_a": mpo._ocp.scale_a, "poly_orders": mpo.poly_orders,
+                            "colloc_scheme": scheme, "tau0": mpo.tau0, "tau1": mpo.tau1})
+    x, u, t, a = post.get_data()
+    assert x.shape == P["orig/x"].shape and a.shape == P["orig/a"].shape
+    for got, key in ((x, "orig/x"), (u, "orig/u"), (t, "orig/t"), (a, "orig/a")):
+        assert got.size == 0 or np.abs(got - P[key]).max() <= 1e-12 * max(1.0, np.abs(P[key]).max()), key
+    # host interpolation path (no GPU callable in the options): composite interpolation matrix, like the reference
+    xi, ui, ti, ai = post.get_data(interpolate=True)
+    assert xi.shape == P["interp/x"].shape and ti.shape == P["interp/t"].shape and ai.shape == P["interp/a"].shape
+    for got, key in ((xi, "interp/x"), (ui, "interp/u"), (ti, "interp/t")):
+        assert np.abs(got - P[key]).max() <= 1e-10 * max(1.0, np.abs(P[key]).max()), key
+    assert np.array_equal(mp.post_process.get_non_uniform_interpolation_grid(np.array([-1.0, -0.2, 0.5, 1.0]), 20), P["grid/non_uniform"])
+    with pytest.raises(NotImplementedError):
+        post.plot_phases([0])
