@@ -220,6 +220,11 @@ int mpx_get_partials(mpx_ctx* ctx, int64_t batch, double** device_ptr, int64_t* 
  * ------------------------------------------------------------------------------------------- */
 typedef struct mpx_resid_plan mpx_resid_plan;
 int mpx_resid_plan_create(mpx_ctx* ctx, int phase, const int64_t* seg_ptr, const double* taus, mpx_resid_plan** out);
+/* Same, with the derivative order of the D_at rows: 1 (as above) or 2, in which case dxi / dui hold the SECOND
+ * derivatives of the interpolating polynomials (mpopt.get_state_second_derivative_single_phase, mpopt.py:1285-1358)
+ * and dyn / resid are not meaningful. */
+int mpx_resid_plan_create_order(mpx_ctx* ctx, int phase, const int64_t* seg_ptr, const double* taus, int deriv_order,
+                                mpx_resid_plan** out);
 int mpx_resid_plan_destroy(mpx_resid_plan* plan);
 int mpx_resid_eval(mpx_ctx* ctx, mpx_resid_plan* plan, int64_t batch, const double* z, const double* p, int p_per_point,
                    double* ti, double* xi, double* ui, double* dxi, double* dui, double* dyn, double* resid);

@@ -152,6 +152,7 @@ SYMBOLS = {
     "mpx_get_partials": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), c_int64_p]),
     "mpx_set_current": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_resid_plan_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_double_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "mpx_resid_plan_create_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_double_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "mpx_resid_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_resid_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mpx_resid_eval_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7),

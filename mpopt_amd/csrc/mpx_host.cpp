@@ -862,7 +862,13 @@ extern "C" int mpx_resid_plan_destroy(mpx_resid_plan* P) {
 }
 
 extern "C" int mpx_resid_plan_create(mpx_ctx* c, int phase, const int64_t* seg_ptr, const double* taus, mpx_resid_plan** out) {
+  return mpx_resid_plan_create_order(c, phase, seg_ptr, taus, 1, out);
+}
+
+extern "C" int mpx_resid_plan_create_order(mpx_ctx* c, int phase, const int64_t* seg_ptr, const double* taus, int deriv_order,
+                                           mpx_resid_plan** out) {
   if (!c || !seg_ptr || !out) return MPX_ERR_INVALID;
+  if (deriv_order != 1 && deriv_order != 2) return fail(c, MPX_ERR_INVALID, "residual plan: derivative order must be 1 or 2");
   if (phase < 0 || phase >= c->n_phases) return fail(c, MPX_ERR_INVALID, "residual plan: phase out of range");
   if (seg_ptr[0] != 0) return fail(c, MPX_ERR_INVALID, "residual plan: seg_ptr[0] must be 0");
   for (int s = 0; s < c->S; ++s)
@@ -884,7 +890,7 @@ extern "C" int mpx_resid_plan_create(mpx_ctx* c, int phase, const int64_t* seg_p
       if (b == a) continue;
       std::vector<double> Cm((size_t)(b - a) * n1), Dm((size_t)(b - a) * n1);
       mpx_colloc_interp_matrix(t.roots.data(), n1, taus + a, (int)(b - a), Cm.data());
-      mpx_colloc_diff_matrix(t.roots.data(), n1, taus + a, (int)(b - a), 1, Dm.data());
+      mpx_colloc_diff_matrix(t.roots.data(), n1, taus + a, (int)(b - a), deriv_order, Dm.data());
       for (int64_t q = a; q < b; ++q) {
         B.pt_id.push_back((int32_t)q);
         B.pt_seg.push_back(s);

@@ -497,6 +497,63 @@ class mpopt:
         block(prog.ntc, o.LB_TERMINAL_CONSTRAINTS, o.UB_TERMINAL_CONSTRAINTS)
         return np.concatenate(lo), np.concatenate(hi)
 
+    # ---- the reference's per-block builders (mpopt.py:144-413): same names, argument lists and bound vectors; the
+    # first element of every tuple is a handle with .shape where the reference returns CasADi expressions (the
+    # rows themselves are evaluated by the GPU oracle, never formed symbolically)
+    def init_segment_width(self):
+        self.seg_widths = _NlpSymbol("h_seg", self.n_segments * self._ocp.n_phases, None)
+
+    def _block(self, name, lo, hi):
+        lo, hi = np.asarray(lo, float).ravel(), np.asarray(hi, float).ravel()
+        return (_NlpSymbol(name, len(lo), self.oracle) if len(lo) else [], lo if len(lo) else [], hi if len(hi) else [])
+
+    def _n_path(self, phase):
+        o = self._ocp
+        if not o.has_path_constraints(phase):
+            return 0
+        return len(np.atleast_1d(o.get_path_constraints(phase)(o.x00[phase], o.u00[phase], o.t00[phase], o.a0[phase])))
+
+    def get_discretized_dynamics_constraints_and_cost_matrices(self, phase=0):
+        """(f, c, q): handles for the N node values of h*Sx*dyn, the path constraints and h*L (mpopt.py:154-212)."""
+        N, o = self._Npoints, self._ocp
+        return (_NlpSymbol(f"f{phase}", N * o.nx, self.oracle, shape=(N, o.nx)),
+                _NlpSymbol(f"c{phase}", N * self._n_path(phase), self.oracle, shape=(N, self._n_path(phase))),
+                _NlpSymbol(f"q{phase}", N, self.oracle, shape=(N, 1)))
+
+    def get_nlp_constraints_for_dynamics(self, f=[], phase=0):  # mpopt.py:214-237
+        o, n = self._ocp, self._ocp.nx * self._Npoints
+        return self._block(f"F{phase}", np.full(n, o.LB_DYNAMICS), np.full(n, o.UB_DYNAMICS))
+
+    def get_nlp_constraints_for_path_contraints(self, c=[], phase=0):  # mpopt.py:239-262
+        o, n = self._ocp, self._n_path(phase) * self._Npoints
+        return self._block(f"C{phase}", np.full(n, o.LB_PATH_CONSTRAINTS), np.full(n, o.UB_PATH_CONSTRAINTS))
+
+    def get_nlp_constraints_for_terminal_contraints(self, phase=0):  # mpopt.py:264-300: (TC, TCmin, TCmax, J)
+        o = self._ocp
+        n = len(np.atleast_1d(o.get_terminal_constraints(phase)(o.xf0[phase], o.tf0[phase], o.x00[phase], o.t00[phase], o.a0[phase]))) \
+            if o.has_terminal_constraints(phase) else 0
+        return self._block(f"TC{phase}", np.full(n, o.LB_TERMINAL_CONSTRAINTS), np.full(n, o.UB_TERMINAL_CONSTRAINTS)) + \
+            (_NlpSymbol(f"mayer{phase}", 1, self.oracle, shape=(1, 1)),)
+
+    def get_nlp_constraints_for_control_input_slope(self, phase=0):  # mpopt.py:302-328
+        o = self._ocp
+        n = o.nu * self._Npoints if o.diff_u[phase] else 0
+        return self._block(f"DU{phase}", np.full(n, float(o.lbdu[phase])), np.full(n, float(o.ubdu[phase])))
+
+    def get_nlp_constrains_for_control_input_at_mid_colloc_points(self, phase=0):  # mpopt.py:330-377
+        o, n_mid = self._ocp, self._Npoints - 1
+        if not self._midu_rows(phase):
+            return ([], [], [])
+        su = np.asarray(o.scale_u, float)
+        return self._block(f"mU{phase}", np.repeat(np.asarray(o.lbu[phase], float) * su, n_mid), np.repeat(np.asarray(o.ubu[phase], float) * su, n_mid))
+
+    def get_nlp_constrains_for_control_slope_continuity_across_segments(self, phase=0):  # mpopt.py:379-413
+        o = self._ocp
+        if self.n_segments == 1 or not o.du_continuity[phase]:
+            return ([], [], [])
+        n = o.nu * (self.n_segments - 1)
+        return self._block(f"dU{phase}", np.zeros(n), np.zeros(n))
+
     def get_event_constraints(self):
         o = self._ocp
         if o.n_phases < 2:
@@ -657,15 +714,46 @@ class mpopt:
         return np.concatenate([t_seg[i] + (t_seg[i + 1] - t_seg[i]) * ((np.asarray(taus[i], float) - tau0) / (tau1 - tau0))
                                for i in range(len(t_seg) - 1)]).reshape(-1, 1)
 
-    def _residual_plan(self, phase, target_nodes):
+    def _residual_plan(self, phase, target_nodes, deriv_order=1):
         if self.oracle is None:
             self.create_nlp()
-        key = (phase, tuple(np.asarray(t, float).tobytes() for t in target_nodes))
+        key = (phase, deriv_order, tuple(np.asarray(t, float).tobytes() for t in target_nodes))
         cache = self.__dict__.setdefault("_resid_plans", {})
         if key not in cache:
             cache.clear()
-            cache[key] = self.oracle.residual_plan(phase, target_nodes)
+            cache[key] = self.oracle.residual_plan(phase, target_nodes, deriv_order)
         return cache[key]
+
+    # ---- post-solve: second derivatives of the interpolating polynomials (mpopt.py:1238-1358) -----------
+    def get_state_second_derivative_single_phase(self, solution, phase=0, nodes=None, grid_type=None, residual_type=None):
+        """(ti_phase, ddx_phase, ddu_phase): per segment, arrays of shape (n_taus, nx, 1) / (n_taus, nu, 1) with
+        D2_at . X and D2_at . U (scaled variables), ``None`` for segments without target points.  The products
+        are evaluated by the GPU kernel mpx_resid_* with second-derivative rows."""
+        target = self.get_residual_grid_taus(phase=phase, grid_type=self.grid_type[phase]) if nodes is None else nodes
+        plan = self._residual_plan(phase, target, deriv_order=2)
+        r = plan.eval(np.asarray(solution["x"], float).ravel(), np.asarray(self._nlp_sw_params, float), what=("ti", "dxi", "dui"))
+        o, S = self._ocp, self.n_segments
+        ddx = r["dxi"]
+        ddu = r["dui"] if o.nu else np.zeros((plan.n_pts, 0))
+        ti_phase, ddx_phase, ddu_phase = [None] * S, [None] * S, [None] * S
+        for s in range(S):
+            a, b = plan.seg_ptr[s], plan.seg_ptr[s + 1]
+            if a == b:
+                continue
+            ddx_phase[s], ddu_phase[s] = ddx[a:b, :, None].copy(), ddu[a:b, :, None].copy()
+            if residual_type == "relative":
+                ddx_phase[s] = ddx_phase[s] / ddx_phase[s].max()
+                ddu_phase[s] = ddu_phase[s] / ddu_phase[s].max()
+            ti_phase[s] = r["ti"][a:b].copy()
+        return ti_phase, ddx_phase, ddu_phase
+
+    def get_state_second_derivative(self, solution, grid_type="spectral", nodes=None, plot=False, fig=None, axs=None):
+        P = self._ocp.n_phases
+        ti, DDx, DDu = [None] * P, [None] * P, [None] * P
+        for phase in range(P):
+            target = self.get_residual_grid_taus(phase, grid_type=grid_type) if nodes is None else nodes[phase]
+            ti[phase], DDx[phase], DDu[phase] = self.get_state_second_derivative_single_phase(solution, phase, nodes=target)
+        return ti, DDx, DDu
 
     def interpolate_single_phase(self, solution, phase=0, target_nodes=None, grid_type=None, options={}):
         """(Xi, Ui, ti, a, DXi, DUi, target_nodes, t0, tf) like the reference (mpopt.py:1489-1543); the

@@ -31,8 +31,10 @@ class ResidualPlan:
 
     FIELDS = ("ti", "xi", "ui", "dxi", "dui", "dyn", "resid")
 
-    def __init__(self, oracle, phase, taus_per_segment):
-        self.oracle, self.phase = oracle, int(phase)
+    def __init__(self, oracle, phase, taus_per_segment, deriv_order=1):
+        """``deriv_order=2``: ``dxi`` / ``dui`` are the second derivatives of the interpolating polynomials
+        (mpopt.py:1316-1321); ``dyn`` / ``resid`` are then meaningless."""
+        self.oracle, self.phase, self.deriv_order = oracle, int(phase), int(deriv_order)
         taus = [np.ascontiguousarray(np.asarray(t, dtype=np.float64).ravel()) for t in taus_per_segment]
         if len(taus) != oracle.n_segments:
             raise ValueError("one array of target points per segment is required")
@@ -42,8 +44,8 @@ class ResidualPlan:
             self.taus = np.zeros(1)
         self.n_pts = int(self.seg_ptr[-1])
         h = ctypes.c_void_p()
-        _lib.check(oracle._L.mpx_resid_plan_create(oracle._ctx, self.phase, self.seg_ptr.ctypes.data_as(_lib.c_int64_p),
-                                                   _lib.dptr(self.taus), ctypes.byref(h)), oracle._ctx)
+        _lib.check(oracle._L.mpx_resid_plan_create_order(oracle._ctx, self.phase, self.seg_ptr.ctypes.data_as(_lib.c_int64_p),
+                                                         _lib.dptr(self.taus), self.deriv_order, ctypes.byref(h)), oracle._ctx)
         self._h = h
         o = oracle.ocp
         self.widths = {"ti": 0, "xi": o.nx, "ui": o.nu, "dxi": o.nx, "dui": o.nu, "dyn": o.nx, "resid": o.nx}
@@ -221,8 +223,8 @@ class NlpFunctions:
         _lib.check(self._L.mpx_get_comp_weights(self._ctx, _lib.dptr(w)), self._ctx)
         return w
 
-    def residual_plan(self, phase, taus_per_segment):
-        return ResidualPlan(self, phase, taus_per_segment)
+    def residual_plan(self, phase, taus_per_segment, deriv_order=1):
+        return ResidualPlan(self, phase, taus_per_segment, deriv_order)
 
     # -- evaluation ------------------------------------------------------------------------
     def eval(self, what, z, p, lam_g=None, sigma=None, pinned=False, ccs_order=False):

@@ -263,6 +263,33 @@ def make_post(name, builder, n_segments, poly_orders, scheme):
     print(f"post_{name}.npz: " + ", ".join(f"{k}{v.shape}" for k, v in out.items()))
 
 
+def make_second_derivative(name, builder, n_segments, poly_orders, scheme):
+    """mpopt.get_state_second_derivative (mpopt.py:1238-1358) at the golden sample point, spectral grid + ragged custom grid."""
+    ref.CollocationRoots._TAU_MIN, ref.CollocationRoots._TAU_MAX = -1, 1
+    ref.Collocation.D_MATRIX_METHOD = "numerical"
+    G = np.load(os.path.join(HERE, f"nlp_{name}.npz"))
+    mpo = ref.mpopt(builder(ref, casadi_shim), n_segments, poly_orders, scheme)
+    mpo.create_nlp()
+    mpo._nlp_sw_params = list(G["p"])
+    sol = {"x": G["z"]}
+    rng = np.random.default_rng(13)
+    out = {}
+    for ph in range(mpo._ocp.n_phases):
+        grids = {"spectral": mpo.get_residual_grid_taus(ph, grid_type="spectral"),
+                 "custom": [np.sort(rng.uniform(-1, 1, [0, 3, 1, 4][s % 4])) for s in range(n_segments)]}
+        for gt, nodes in grids.items():
+            nodes = [np.asarray(t, float) for t in nodes]
+            ti, ddx, ddu = mpo.get_state_second_derivative_single_phase(sol, ph, nodes=nodes)
+            key = f"ph{ph}/{gt}"
+            out[key + "/seg_ptr"] = np.concatenate([[0], np.cumsum([len(t) for t in nodes])])
+            out[key + "/taus"] = np.concatenate(nodes)
+            out[key + "/ddx"] = np.concatenate([np.asarray(v, float) for v in ddx if v is not None])
+            out[key + "/ddu"] = np.concatenate([np.asarray(v, float) for v in ddu if v is not None])
+            out[key + "/ti"] = np.concatenate([np.asarray(v, float).ravel() for v in ti if v is not None])
+    np.savez_compressed(os.path.join(HERE, f"ddx_{name}.npz"), **out)
+    print(f"ddx_{name}.npz: {len(out)} arrays")
+
+
 def make_hadaptive():
     """h-adaptive refinement: the reference's static helpers on seeded inputs and its
     width-update rules (mpopt.py:2524-2874) at the golden sample points."""
@@ -318,15 +345,20 @@ def main():
     for name, (builder, s, po, scheme) in problems.GOLDEN_CASES.items():
         if only and name not in only:
             continue
-        if only in (["residuals"], ["hadaptive"], ["adaptive"], ["post"]):
+        if only in (["residuals"], ["hadaptive"], ["adaptive"], ["post"], ["ddx"]):
             continue
         make_case(name, builder, s, po, scheme)
     for name, (builder, s, po, scheme) in problems.ADAPTIVE_CASES.items():
-        if only == ["post"] or (only and name not in only and "adaptive" not in only):
+        if only in (["post"], ["ddx"]) or (only and name not in only and "adaptive" not in only):
             continue
         make_case(name, builder, s, po, scheme, adaptive=True)
     if not only or "hadaptive" in only:
         make_hadaptive()
+    if only == ["ddx"] or not only:
+        for name in RESIDUAL_CASES[:4]:
+            make_second_derivative(name, *problems.GOLDEN_CASES[name])
+        if only:
+            return
     if only == ["post"]:
         for name in POST_CASES:
             make_post(name, *problems.GOLDEN_CASES[name])

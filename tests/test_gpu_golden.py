@@ -176,3 +176,31 @@ def test_process_results_interpolated_data_on_gpu(name):
     assert rel_err(xi, P["interp/x"]) < TOL and rel_err(ui, P["interp/u"]) < TOL and rel_err(ti, P["interp/t"]) < TOL
     assert mpo.process_results({"x": G["z"]}, residual_dx=False).residuals is None
     o.close()
+
+
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "hyper_sensitive_5x3_LGR", "kitchen_sink_mixed_CGL", "dae_vdp_mixed_CGL"])
+def test_state_second_derivative_matches_reference(name):
+    """mpopt.get_state_second_derivative[_single_phase] (mpopt.py:1238-1358): D2_at.X, D2_at.U on the spectral grid
+    and on a ragged custom grid (empty segments), GPU kernel with second-derivative rows vs the reference's output."""
+    import os
+    from helpers import GOLDEN
+
+    G, D = load_golden(name), np.load(os.path.join(GOLDEN, f"ddx_{name}.npz"))
+    ocp, mpo, o = build_case(name, with_device=True)
+    mpo.create_nlp()
+    mpo._nlp_sw_params = G["p"]
+    sol = {"x": G["z"]}
+    for ph in range(ocp.n_phases):
+        for gt in ("spectral", "custom"):
+            key = f"ph{ph}/{gt}"
+            ptr = D[key + "/seg_ptr"]
+            nodes = [D[key + "/taus"][ptr[s]:ptr[s + 1]] for s in range(len(ptr) - 1)]
+            ti, ddx, ddu = mpo.get_state_second_derivative_single_phase(sol, ph, nodes=nodes)
+            assert [v is None for v in ddx] == [len(t) == 0 for t in nodes]
+            cat = lambda L: np.concatenate([v for v in L if v is not None])
+            assert cat(ddx).shape == D[key + "/ddx"].shape and cat(ddu).shape == D[key + "/ddu"].shape
+            assert rel_err(cat(ddx), D[key + "/ddx"]) < 1e-9 and rel_err(cat(ddu), D[key + "/ddu"]) < 1e-9
+            assert rel_err(cat(ti), D[key + "/ti"]) < TOL
+    ti, DDx, DDu = mpo.get_state_second_derivative(sol)  # default spectral grid, all phases
+    assert len(DDx) == ocp.n_phases and rel_err(np.concatenate([v for v in DDx[0] if v is not None]), D["ph0/spectral/ddx"]) < 1e-9
+    o.close()

@@ -149,3 +149,26 @@ def test_post_process_original_data_matches_reference(name):
     assert np.array_equal(mp.post_process.get_non_uniform_interpolation_grid(np.array([-1.0, -0.2, 0.5, 1.0]), 20), P["grid/non_uniform"])
     with pytest.raises(NotImplementedError):
         post.plot_phases([0])
+
+
+def test_mpopt_block_builders_agree_with_phase_bounds(test_mpo):
+    """The reference's per-block builders (mpopt.py:214-413): concatenated in the reference's row order
+    [F; C; DU; mU; dU; TC] (mpopt.py:458) they reproduce the bounds of discretize_phase."""
+    test_mpo.create_nlp()
+    test_mpo.init_segment_width()
+    for phase in range(test_mpo._ocp.n_phases):
+        f, c, q = test_mpo.get_discretized_dynamics_constraints_and_cost_matrices(phase)
+        assert f.shape == (test_mpo._Npoints, test_mpo._ocp.nx) and q.shape == (test_mpo._Npoints, 1)
+        F = test_mpo.get_nlp_constraints_for_dynamics(f, phase)
+        C = test_mpo.get_nlp_constraints_for_path_contraints(c, phase)
+        TC = test_mpo.get_nlp_constraints_for_terminal_contraints(phase)
+        assert len(TC) == 4 and TC[3].shape == (1, 1)
+        blocks = [F, C, test_mpo.get_nlp_constraints_for_control_input_slope(phase),
+                  test_mpo.get_nlp_constrains_for_control_input_at_mid_colloc_points(phase),
+                  test_mpo.get_nlp_constrains_for_control_slope_continuity_across_segments(phase), TC[:3]]
+        lo = np.concatenate([np.asarray(b[1], float) for b in blocks])
+        hi = np.concatenate([np.asarray(b[2], float) for b in blocks])
+        G, Gmin, Gmax, J = test_mpo.discretize_phase(phase)
+        assert np.array_equal(lo, Gmin) and np.array_equal(hi, Gmax)
+        for b in blocks:
+            assert (b[0] == [] and len(b[1]) == 0) or b[0].shape[0] == len(b[1])
