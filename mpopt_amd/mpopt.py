@@ -885,7 +885,11 @@ class mpopt:
                    "scale_a": o.scale_a, "scale_t": o.scale_t, "scaling": scaling, "colloc_scheme": self.colloc_scheme,
                    "tau0": self.tau0, "tau1": self.tau1, "interpolation_depth": 3, "seg_widths": self._nlp_sw_params,
                    "residuals": resid_value, "interpolate": interpolate}
-        return post_process(solution, trajectories, options)
+        post = post_process(solution, trajectories, options)
+        if plot:
+            for phases in o.phases_to_plot:
+                post.plot_phases(phases, residuals=residual_x or residual_dx)
+        return post
 
 
 class mpopt_h_adaptive(mpopt):
@@ -1231,9 +1235,9 @@ class mpopt_adaptive(mpopt):
         if (not self._nlpsolver_initialized) or reinitialize_nlp:
             self.create_solver(solver=solver, options=nlp_solver_options)
         if initial_solution is None and mpopt_options.get("warm_start_fixed_width", True):
-            # The SciPy stand-in for IPOPT (solver.py) does not recover from the linear default guess on this
-            # problem class; start from the equal-width solution on the same grid instead (the reference starts
-            # IPOPT from the linear guess, mpopt.py:3235-3239 -- pass {"warm_start_fixed_width": False} for that).
+            # The stand-ins for IPOPT (solver.py) are not reliable from the linear default guess on this problem
+            # class (no proper restoration phase); start from the equal-width solution on the same grid instead (the
+            # reference starts IPOPT from the linear guess, mpopt.py:3235-3239 -- {"warm_start_fixed_width": False}).
             fixed = mpopt(self._ocp, self.n_segments, self.poly_orders, self.colloc_scheme, device=self.device)
             zf = np.asarray(fixed.solve(solver=solver, nlp_solver_options=nlp_solver_options)["x"], float).ravel()
             n0, S = self._n_zp() - self.n_segments, self.n_segments
@@ -1291,8 +1295,7 @@ def _ref_control_order(U):
 
 
 class post_process:
-    """Solution data of the optimizer for further processing (mpopt.py:1576-1858, data methods).  Plotting
-    (plot_phases, plot_x, ...; mpopt.py:1860-2270) is outside this build: those names raise.
+    """Solution data of the optimizer for further processing and plots (mpopt.py:1576-2270).
 
         >>> post = post_process(solution, trajectories, options)      # what mpopt.process_results builds
 
@@ -1384,14 +1387,120 @@ class post_process:
             phases = self.phases
         return self.get_interpolated_data(phases) if interpolate else self.get_original_data(phases)
 
-    def __getattr__(self, name):
-        if name.startswith("plot_") or name == "sort_residual_data":
-            raise NotImplementedError(f"post_process.{name}: plotting is outside the scope of mpopt_amd (DESIGN.md section 1)")
-        raise AttributeError(name)
+    # ---- plots (mpopt.py:1858-2270): thin matplotlib front-ends over the data methods above -----------------
+    @staticmethod
+    def _plt():
+        import matplotlib
+
+        if not matplotlib.get_backend():  # pragma: no cover
+            matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+
+        return plt
+
+    @staticmethod
+    def plot_curve(ax, x, t, name=None, ylabel="", tics=["-"] * 15, legend_index=None):
+        """Columns of ``x`` against ``t`` on one axis; legend ``name i`` (or ``name legend_index[i]``)."""
+        x = np.asarray(x, float).reshape(len(np.asarray(t).ravel()), -1)
+        for i in range(x.shape[1]):
+            label = None if name is None else f"{name} {legend_index[i] if legend_index is not None else i}"
+            ax.plot(np.asarray(t).ravel(), x[:, i], tics[i % len(tics)], label=label)
+        if name is not None:
+            ax.legend()
+        ax.set(ylabel=ylabel)
+        ax.grid(True)
+
+    def plot_all(self, x, u, t, tics=None, fig=None, axs=None, legend=True, name=""):
+        """States on the first axis, controls on the second."""
+        plt = self._plt()
+        tics = ["-"] * 15 if tics is None else tics
+        if fig is None and axs is None:
+            fig, axs = plt.subplots(2, 1, sharex=True)
+        self.plot_curve(axs[0], x, t, name=(name + "state") if legend else None, ylabel="State variables", tics=tics)
+        self.plot_curve(axs[1], u, t, name=(name + "control") if legend else None, ylabel="Control variables", tics=tics)
+        axs[1].set(xlabel="Time, s")
+        return fig, axs
+
+    def plot_phases(self, phases=None, interpolate=True, residuals=True, fig=None, axs=None, tics=["-"] * 15, name=""):
+        """States and controls of the given phases (refined grid by default, nodes as markers); a third axis with
+        the dynamics residuals when they were computed by ``process_results``."""
+        plt = self._plt()
+        if phases is None:
+            phases = self.options["phases_to_plot"][0] if "phases_to_plot" in self.options else self.phases
+        phases = list(phases)
+        with_res = bool(residuals) and self.residuals is not None and "t_dx" in self.residuals
+        if fig is None and axs is None:
+            fig, axs = plt.subplots(3 if with_res else 2, 1, sharex=True)
+        x, u, t, _ = self.get_original_data(phases)
+        if interpolate:
+            xi, ui, ti, _ = self.get_interpolated_data(phases)
+            self.plot_all(xi, ui, ti, tics=tics, fig=fig, axs=axs, name=name)
+            self.plot_all(x, u, t, tics=["."] * 15, fig=fig, axs=axs, legend=False)
+        else:
+            self.plot_all(x, u, t, tics=tics, fig=fig, axs=axs, name=name)
+        if with_res:
+            tr, rr = self.residuals["t_dx"]
+            self.plot_residuals(tr, rr, phases=phases, fig=fig, axs=axs[2])
+        return fig, axs
+
+    def plot_phase(self, phase=0, interpolate=True, fig=None, axs=None):
+        return self.plot_phases([phase], interpolate, fig=fig, axs=axs)
+
+    def plot_single_variable(self, var_data, t, dims, name=None, ylabel=None, axis=1, fig=None, axs=None, tics=["-"] * 15):
+        """One subplot per entry of ``dims`` (an entry may be a list of columns sharing a subplot), stacked along ``axis``."""
+        plt = self._plt()
+        groups = [list(np.atleast_1d(d)) for d in dims]
+        if fig is None and axs is None:
+            fig, axs = plt.subplots(*( (len(groups), 1) if axis == 1 else (1, len(groups)) ), squeeze=False)
+        flat = np.asarray(axs).ravel()
+        var_data = np.asarray(var_data, float)
+        for ax, cols in zip(flat, groups):
+            self.plot_curve(ax, var_data[:, cols], t, name=name, ylabel=ylabel or "", tics=tics, legend_index=cols)
+        flat[-1].set(xlabel="Time, s")
+        return fig, axs
+
+    def _plot_var(self, which, dims, phases, axis, interpolate, fig, axs, tics, name, ylabel):
+        phases = list(self.phases if phases is None else phases)
+        x, u, t, _ = self.get_data(phases, interpolate=interpolate)
+        data = x if which == "x" else u
+        dims = list(range(data.shape[1])) if dims is None else dims
+        return self.plot_single_variable(data, t, dims, name=name, ylabel=ylabel, axis=axis, fig=fig, axs=axs,
+                                         tics=["-"] * 15 if tics is None else tics)
+
+    def plot_x(self, dims=None, phases=None, axis=1, interpolate=True, fig=None, axs=None, tics=["-"] * 15):
+        return self._plot_var("x", dims, phases, axis, interpolate, fig, axs, tics, "state", "State variables")
+
+    def plot_u(self, dims=None, phases=None, axis=1, interpolate=True, fig=None, axs=None, tics=None, name="control", ylabel="Control variables"):
+        return self._plot_var("u", dims, phases, axis, interpolate, fig, axs, tics, name, ylabel)
+
+    @staticmethod
+    def sort_residual_data(time, residuals, phases=[0]):
+        """(r, t): 2-norm over the states of every residual point, phases concatenated (mpopt.py:2210-2229)."""
+        rs, ts = [], []
+        for phase in phases:
+            for seg_t, seg_r in zip(time[phase], residuals[phase]):
+                if seg_r is None or len(np.atleast_1d(seg_t)) == 0:
+                    continue
+                rs.append(np.linalg.norm(np.asarray(seg_r, float).reshape(len(np.asarray(seg_t).ravel()), -1), 2, axis=1))
+                ts.append(np.asarray(seg_t, float).ravel())
+        r = np.concatenate(rs) if rs else np.zeros(0)
+        t = np.concatenate(ts) if ts else np.zeros(0)
+        return (r.reshape(-1, 1), t)
+
+    @classmethod
+    def plot_residuals(cls, time, residuals, phases=[0], name=None, fig=None, axs=None, tics=["."] * 15):
+        plt = cls._plt()
+        if fig is None and axs is None:
+            fig, axs = plt.subplots(1, 1)
+        r, t = cls.sort_residual_data(time, residuals, phases=phases)
+        cls.plot_curve(axs, r, t, name, ylabel="residuals", tics=tics, legend_index=[""] * 15)
+        cls.plot_curve(axs, r, t, ylabel="residuals", tics=["-"] * 15, legend_index=[""] * 15)
+        axs.set(xlabel="Time, s")
+        return fig, axs
 
 
 def solve(ocp, n_segments=1, poly_orders=9, scheme="LGR", plot=True, solve_dict=dict(), residual_x=False, residual_dx=True):
     mpo = mpopt(ocp, n_segments=n_segments, poly_orders=poly_orders, scheme=scheme)
     solution = mpo.solve(**solve_dict)
-    post = mpo.process_results(solution, plot=False, residual_x=residual_x, residual_dx=residual_dx)
+    post = mpo.process_results(solution, plot=plot, residual_x=residual_x, residual_dx=residual_dx)
     return (mpo, post)

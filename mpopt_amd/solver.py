@@ -4,9 +4,11 @@ returned by ``ca.nlpsol`` (mpopt.py:757, 804).
 The outer NLP iteration (IPOPT + MUMPS inside CasADi in the reference) is OUT OF SCOPE of this
 build (only the oracle functions are the hot path).  So that ``mp.solve``
 still runs end to end -- and so that the published optimum of the reference can anchor the whole
-pipeline -- the GPU oracles are driven here by SciPy's interior-point ``trust-constr`` method.
-It is a stand-in driver, not a product claim: every f/g/grad/jac/hess value it consumes comes from
-the HIP kernels through the C ABI.
+pipeline -- the GPU oracles are driven here by stand-ins: a compact primal-dual barrier method in
+IPOPT's formulation (mpopt_amd/ipm.py; default) with SciPy's ``trust-constr`` as the fallback when it
+does not converge (``options["standin"]``: "auto" | "ipm" | "trust-constr").  They are stand-in
+drivers, not a product claim: every f/g/grad/jac/hess value they consume comes from the HIP kernels
+through the C ABI.
 """
 import time
 
@@ -25,6 +27,49 @@ class NlpSolver:
     def __call__(self, x0=None, p=None, lbx=None, ubx=None, lbg=None, ubg=None, lam_x0=None, lam_g0=None):
         orc = self.oracle
         p = np.zeros(0) if p is None else np.asarray(p, dtype=float).ravel()
+        standin = self.options.get("standin", "auto")
+        if standin == "trust-constr":
+            return self._trust_constr(x0, p, lbx, ubx, lbg, ubg)
+        sol = self._interior_point(x0, p, lbx, ubx, lbg, ubg, lam_g0)
+        if standin == "ipm" or self.stats["success"]:
+            return sol
+        # "auto": the barrier method did not converge (it has no proper restoration phase) -- let SciPy's trust-region
+        # interior point continue from where it stopped and keep the better of the two end points
+        first, viol = dict(self.stats), self._violation(sol, lbx, ubx, lbg, ubg)
+        start = sol["x"] if np.isfinite(sol["x"]).all() and viol < 1e-2 else x0
+        sol2 = self._trust_constr(start, p, lbx, ubx, lbg, ubg)
+        viol2 = self._violation(sol2, lbx, ubx, lbg, ubg)
+        self.stats["first_attempt"] = first
+        if self.stats["success"] or viol2 < viol or (viol2 <= 10 * max(viol, 1e-8) and sol2["f"] < sol["f"]):
+            return sol2
+        self.stats = dict(first, second_attempt=self.stats)
+        return sol
+
+    @staticmethod
+    def _violation(sol, lbx, ubx, lbg, ubg):
+        x, g = np.asarray(sol["x"], float).ravel(), np.asarray(sol["g"], float).ravel()
+        v = [np.maximum(np.asarray(lbx, float) - x, 0).max(initial=0.0), np.maximum(x - np.asarray(ubx, float), 0).max(initial=0.0)]
+        if g.size:
+            v += [np.maximum(np.asarray(lbg, float) - g, 0).max(initial=0.0), np.maximum(g - np.asarray(ubg, float), 0).max(initial=0.0)]
+        return float(max(v))
+
+    def _interior_point(self, x0, p, lbx, ubx, lbg, ubg, lam_g0):
+        """Barrier method of mpopt_amd/ipm.py (the default stand-in: same problem formulation and options as IPOPT)."""
+        from .ipm import InteriorPoint
+
+        t0 = time.perf_counter()
+        ip = InteriorPoint(self.oracle, p, lbx, ubx, lbg, ubg, tol=float(self.options.get("ipopt.tol", 1e-8)),
+                           max_iter=int(self.options.get("ipopt.max_iter", 2000)),
+                           acceptable_tol=float(self.options.get("ipopt.acceptable_tol", 1e-4)),
+                           print_level=int(self.options.get("ipopt.print_level", 0)))
+        res = ip.solve(np.asarray(x0, dtype=float).ravel(), lam_g0)
+        self.stats = {"iter_count": res["iter_count"], "success": res["success"], "return_status": res["status"], "n_eval": ip.n_eval,
+                      "t_wall_s": time.perf_counter() - t0}
+        return {"x": res["x"], "f": res["f"], "g": res["g"], "lam_x": res["lam_x"], "lam_g": res["lam_g"], "lam_p": np.zeros_like(p)}
+
+    def _trust_constr(self, x0, p, lbx, ubx, lbg, ubg):
+        """SciPy's interior-point trust-region method (options={"standin": "trust-constr"})."""
+        orc = self.oracle
         n, m = orc.n_z, orc.n_g
         x0 = np.clip(np.asarray(x0, dtype=float).ravel(), lbx, ubx)
         jr, jc = orc.jac_pattern()

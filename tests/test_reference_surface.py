@@ -147,8 +147,16 @@ def test_post_process_original_data_matches_reference(name):
     for got, key in ((xi, "interp/x"), (ui, "interp/u"), (ti, "interp/t")):
         assert np.abs(got - P[key]).max() <= 1e-10 * max(1.0, np.abs(P[key]).max()), key
     assert np.array_equal(mp.post_process.get_non_uniform_interpolation_grid(np.array([-1.0, -0.2, 0.5, 1.0]), 20), P["grid/non_uniform"])
-    with pytest.raises(NotImplementedError):
-        post.plot_phases([0])
+    import matplotlib
+    matplotlib.use("Agg")
+    fig, axs = post.plot_phases()
+    assert len(axs) == 2 and len(axs[0].lines) >= x.shape[1]
+    fig, axs = post.plot_x()
+    fig, axs = post.plot_u()
+    fig, axs = post.plot_phases(interpolate=False)
+    fig, ax = mp.post_process.plot_residuals([[np.array([0.0, 1.0]), None]], [[np.array([[1.0, 2.0], [0.5, 0.1]]), None]])
+    assert len(ax.lines) == 2
+    matplotlib.pyplot.close("all")
 
 
 def test_mpopt_block_builders_agree_with_phase_bounds(test_mpo):
