@@ -223,9 +223,16 @@ class InteriorPoint:
                 return (th_t <= (1 - 1e-5) * th0 or phi_t <= phi0 - 1e-5 * th0), False
 
             a, accepted, ftype, soc_done = a_max, False, False, False
+            spec = None  # backtracking candidates evaluated ahead, as one batched oracle call
             for ls in range(30):
                 yt = y + a * dy
-                rt = self._ev(["f", "g"], yt[:n])
+                if ls >= 1 and (ls - 1) % 8 == 0:
+                    # the first trial failed: the next eight step lengths cost one launch instead of eight (a batch of
+                    # evaluation points is the GPU oracle's native mode; IPOPT's sequential line search cannot use it)
+                    cand = np.stack([(y + a * 0.5 ** k * dy)[:n] for k in range(8)])
+                    rb = self._ev(["f", "g"], cand)
+                    spec = [{"f": rb["f"][k], "g": rb["g"][k]} for k in range(8)]
+                rt = self._ev(["f", "g"], yt[:n]) if ls == 0 else spec[(ls - 1) % 8]
                 ct = self._c(rt["g"], yt[n:])
                 tht = float(np.abs(ct).sum())
                 accepted, ftype = acceptable(tht, self._phi(float(rt["f"]), yt, mu) if np.isfinite(rt["f"]) else np.inf, a)
