@@ -11,8 +11,6 @@ import shutil
 import subprocess
 import threading
 
-import numpy as np
-
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")

@@ -24,7 +24,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from ._lib import MpxError, mpx_assembly, mpx_gather, mpx_point_set
+from ._lib import MpxError, mpx_assembly, mpx_point_set
 from .expr import Tracer
 from .nlp import NlpFunctions
 
@@ -67,7 +67,6 @@ class PointFunction:
                 d2 = tr.diff(g1, loc[v2], memo[v2])
                 if not d2.is_zero:
                     self.H.append((v1, v2, d2))
-        # which outputs carry second derivatives at all (their multipliers are the only ones gathered)
         self.n_jac, self.n_hess = len(self.J), len(self.H)
 
     def source(self, fid):

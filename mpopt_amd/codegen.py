@@ -20,7 +20,7 @@ import hashlib
 
 import numpy as np
 
-from .expr import Tracer, Expr
+from .expr import Tracer
 
 # column kinds of a node row / terminal variable kinds (must match mpx.h)
 COL_X, COL_U, COL_T0, COL_TF, COL_A = 0, 1, 2, 3, 4
