@@ -23,6 +23,7 @@ struct MpxTile {
   int32_t seg0;      // first segment of the tile
   int64_t jac_base;  // offset of the tile's block in the jac_g value array
   int64_t hess_base; // offset of the tile's block in the hess_l value array
+  int64_t g_base;    // offset of the tile's block in the packed g / grad_f staging buffer (mixed-degree phases)
 };
 
 // Batched I/O views: pointer + per-evaluation-point stride (in doubles).
@@ -42,6 +43,11 @@ struct MpxIO {
   int32_t n_tiles_total, nred;
   int32_t B, b_per_block;
   int32_t jac_variable_only, pad_;
+  // Mixed-degree phases: the nodes of one (phase, degree) bucket are NOT contiguous in the node index, so direct
+  // stores to g / grad_f are short runs with gaps that another kernel fills later (partial cache lines: measured
+  // 4x the cost per byte on config 3).  Non-NULL: node kernels write [tile][slot][lane] here (coalesced) and
+  // mpx_unpack_kernel moves the values to their rows with fully coalesced stores.
+  double* gtmp;         int64_t gtmp_stride;
 };
 
 // Node kernels: one launch per (phase, degree) bucket.

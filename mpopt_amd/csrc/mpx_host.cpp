@@ -238,6 +238,41 @@ int build_layout(mpx_ctx* c) {
   c->tile_begin = 0;
   c->tile_end = (int64_t)c->tiles.size();
 
+  // ---- packed g / grad_f staging for mixed-degree phases (see MpxIO::gtmp) -------------------------------
+  {
+    std::vector<int> per_phase(c->n_phases, 0);
+    for (auto& B : c->buckets) per_phase[B.phase]++;
+    c->g_packed = false;
+    for (int v : per_phase) c->g_packed = c->g_packed || v > 1;
+    if (c->g_packed) {
+      c->gmap.assign((size_t)c->n_g, -1);
+      c->qmap.assign((size_t)c->n_z, -1);
+      int64_t pos = 0;
+      for (auto& B : c->buckets) {
+        const PhaseStruct& P = c->ph[B.phase];
+        const int sC = nx, sDU = nx + P.nc, sMU = sDU + (P.diff_u ? nu : 0), sQ = sMU + (P.midu ? nu : 0), nsg = sQ + nx + nu;
+        for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
+          MpxTile& T = c->tiles[t];
+          T.g_base = pos;
+          const int64_t n = T.n_own;
+          for (int64_t l = 0; l < n; ++l) {
+            const int64_t i = B.node_i[T.m0 + l];
+            const int k = B.node_sk[T.m0 + l] & 255;
+            for (int a = 0; a < nx; ++a) c->gmap[P.g_off_F + (int64_t)a * N + i] = pos + a * n + l;
+            for (int j = 0; j < P.nc; ++j) c->gmap[P.g_off_C + (int64_t)j * N + i] = pos + (sC + j) * n + l;
+            if (P.diff_u)
+              for (int q = 0; q < nu; ++q) c->gmap[P.g_off_DU + (int64_t)q * N + i] = pos + (sDU + q) * n + l;
+            if (P.midu && k >= 1)
+              for (int q = 0; q < nu; ++q) c->gmap[P.g_off_mU + (int64_t)q * (N - 1) + (i - 1)] = pos + (sMU + q) * n + l;
+            for (int a = 0; a < nx + nu; ++a) c->qmap[P.z_off + (int64_t)a * N + i] = pos + (sQ + a) * n + l;
+          }
+          pos += (int64_t)nsg * n;
+        }
+      }
+      c->gtmp_n = pos;
+    }
+  }
+
   // ---- Jacobian pattern -----------------------------------------------------------------
   // value blocks of the tiles: even-sized blocks first so that they all start 16-byte aligned
   std::vector<int32_t>&jr = c->jrow, &jc = c->jcol;
@@ -461,6 +496,7 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   if ((rc = upload(c, &c->d_mg_dst, c->mg_dst))) return rc;
   if ((rc = upload(c, &c->d_hc_dst, c->hc_dst))) return rc;
   if ((rc = upload(c, &c->d_th_dst, c->th_dst))) return rc;
+  if (c->g_packed && ((rc = upload(c, &c->d_gmap, c->gmap)) || (rc = upload(c, &c->d_qmap, c->qmap)))) return rc;
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   c->has_device = true;
@@ -501,6 +537,25 @@ int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size
   return MPX_OK;
 }
 
+// Move the packed g / grad_f values of the node kernels to their rows: lane <-> output entry, so the stores are
+// fully coalesced; entries written by the boundary kernel (map < 0) are left alone.
+__global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restrict__ tmp, int64_t tmp_stride, double* __restrict__ g, int64_t g_stride,
+                                                         const int64_t* __restrict__ gmap, int64_t n_g, double* __restrict__ grad,
+                                                         int64_t grad_stride, const int64_t* __restrict__ qmap, int64_t n_z) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const double* __restrict__ tb = tmp + (int64_t)blockIdx.y * tmp_stride;
+  if (r < n_g) {
+    const int64_t m = gmap[r];
+    if (g && m >= 0) g[(int64_t)blockIdx.y * g_stride + r] = tb[m];
+    return;
+  }
+  r -= n_g;
+  if (r < n_z && grad) {
+    const int64_t m = qmap[r];
+    if (m >= 0) grad[(int64_t)blockIdx.y * grad_stride + r] = tb[m];
+  }
+}
+
 int pick_bpb(const mpx_ctx* c, int64_t B) {
   static const char* env = getenv("MPX_BPB");
   if (env && atoi(env) > 0) return atoi(env);
@@ -515,6 +570,16 @@ int pick_bpb(const mpx_ctx* c, int64_t B) {
 int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
   MpxIO io = io0;
   io.b_per_block = pick_bpb(c, io.B);
+  // mixed-degree phases: stage g / grad_f in tile order (only for full evaluations: with a restricted tile range the
+  // direct stores keep every rank's slice disjoint for the all-reduce)
+  const bool packed = c->g_packed && nodes && mode != MPX_MODE_HESS && (io.g || io.grad) && c->tile_begin == 0 &&
+                      c->tile_end == (int64_t)c->tiles.size() && io.B <= 65535 && !getenv("MPX_NO_PACKED_G");
+  if (packed) {
+    int rc = reserve(c, c->gtmp, (size_t)(io.B * c->gtmp_n));
+    if (rc) return rc;
+    io.gtmp = c->gtmp.p;
+    io.gtmp_stride = c->gtmp_n;
+  }
   const int gy = (io.B + io.b_per_block - 1) / io.b_per_block;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   if (c->profile) {
@@ -557,6 +622,12 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
     int rc = launch(c, B.fn[mode], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A);
     if (rc) return rc;
     if (c->profile) ++c->prof_launches;
+  }
+  if (packed) {
+    const int64_t rows = c->n_g + c->n_z;
+    hipLaunchKernelGGL(mpx_unpack_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)io.B), dim3(256), 0, c->stream, c->gtmp.p, c->gtmp_n, io.g,
+                       io.g_stride, c->d_gmap, c->n_g, io.grad, io.grad_stride, c->d_qmap, c->n_z);
+    HIPCHK(c, hipGetLastError());
   }
   if (c->profile) HIPCHK(c, hipEventRecord(pe1, c->stream));
   if (!c->run_boundary) return MPX_OK;
@@ -649,6 +720,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
     fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
+    fr(c->d_gmap), fr(c->d_qmap), fr(c->gtmp.p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);

@@ -92,6 +92,12 @@ struct mpx_ctx {
           *d_hc_dst = nullptr, *d_th_dst = nullptr;
   double* d_lin_coef = nullptr;
   DevBuf<double> partial, wcum, st_z, st_p, st_lam, st_sig, st_f, st_g, st_grad, st_jac, st_hess;
+  // mixed-degree phases: packed staging of g / grad_f (MpxIO::gtmp) and the maps of mpx_unpack_kernel
+  bool g_packed = false;
+  int64_t gtmp_n = 0;
+  std::vector<int64_t> gmap, qmap;  // row of g / entry of grad_f -> index in the staging block, -1: written elsewhere
+  int64_t *d_gmap = nullptr, *d_qmap = nullptr;
+  DevBuf<double> gtmp;
   // MPX_CCS_ORDER: scratch in native order + device copies of the permutations (built on first use)
   DevBuf<double> ccs_j, ccs_h;
   int64_t *d_perm_j = nullptr, *d_perm_h = nullptr;

@@ -282,22 +282,25 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
       if (own && io.g) {
 #endif
         double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
+        // destination of a g value: its row, or (mixed-degree phases) slot `sl` of the tile's packed block
+        double* __restrict__ gp = io.gtmp ? io.gtmp + (int64_t)b * io.gtmp_stride + T.g_base + l : nullptr;
+        auto gdst = [&](int sl, double* row) -> double* { return gp ? gp + (int64_t)sl * n : row; };
 #pragma unroll
         for (int a = 0; a < NX; ++a) {  // defect  F = D.X - h*Sx*dyn      (mpopt.py:227-232)
           double acc = 0;
 #pragma unroll
           for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][a][base + j], acc);
-          (gb + (A.g_off_F + (int64_t)a * N))[i] = acc - fx[a];
+          *gdst(a, gb + (A.g_off_F + (int64_t)a * N) + i) = acc - fx[a];
         }
 #pragma unroll
-        for (int j = 0; j < NC; ++j) (gb + (A.g_off_C + (int64_t)j * N))[i] = cc[j];  // mpopt.py:204, 255
+        for (int j = 0; j < NC; ++j) *gdst(NX + j, gb + (A.g_off_C + (int64_t)j * N) + i) = cc[j];  // mpopt.py:204, 255
         if constexpr (G::DIFF_U) {  // DU = D.U                              (mpopt.py:315-324)
 #pragma unroll
           for (int c = 0; c < NU; ++c) {
             double acc = 0;
 #pragma unroll
             for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][NX + c][base + j], acc);
-            (gb + (A.g_off_DU + (int64_t)c * N))[i] = acc;
+            *gdst(NX + NC + c, gb + (A.g_off_DU + (int64_t)c * N) + i) = acc;
           }
         }
         if constexpr (G::MIDU) {  // control at the mid-points of the nodes  (mpopt.py:350-369)
@@ -307,7 +310,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
               double acc = 0;
 #pragma unroll
               for (int j = 0; j < P1; ++j) acc = fma(Crow(j), sXU[buf][NX + c][base + j], acc);
-              (gb + (A.g_off_mU + (int64_t)c * (N - 1)))[i - 1] = acc;
+              *gdst(NX + NC + (G::DIFF_U ? NU : 0) + c, gb + (A.g_off_mU + (int64_t)c * (N - 1)) + (i - 1)) = acc;
             }
           }
         }
@@ -319,8 +322,10 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
         if (own && io.grad) {
 #endif
           double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
+          constexpr int SQ = NX + NC + (G::DIFF_U ? NU : 0) + (G::MIDU ? NU : 0);  // first grad_f slot of the packed block
+          double* __restrict__ qp = io.gtmp ? io.gtmp + (int64_t)b * io.gtmp_stride + T.g_base + l : nullptr;
 #pragma unroll
-          for (int a = 0; a < NX + NU; ++a) (qb + (int64_t)a * N)[i] = gn[a];
+          for (int a = 0; a < NX + NU; ++a) *(qp ? qp + (int64_t)(SQ + a) * n : qb + (int64_t)a * N + i) = gn[a];
         }
 #ifdef MPX_ABL_NO_JAC
         if (false) {
