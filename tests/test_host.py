@@ -214,3 +214,20 @@ def test_assembled_context_structure_without_gpu():
         with pytest.raises(M.MpxError):
             orc.eval(["f"], G["z"], None)
         orc.close()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: importing every module of the product must not pull it in, and no product
+    source file may mention the package in an import."""
+    import subprocess
+    import sys
+
+    code = ("import sys; import mpopt_amd, mpopt_amd.adaptive, mpopt_amd.assembly, mpopt_amd.solver, mpopt_amd.ipm, "
+            "mpopt_amd.distributed, mpopt_amd.codegen, mpopt_amd.nlp; "
+            "bad = [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]; assert not bad, bad")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mpopt_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), fn
