@@ -588,6 +588,7 @@ class mpopt:
         orc = self.oracle
         nlp_prob = {"f": _NlpSymbol("f", 1, orc), "x": _NlpSymbol("x", orc.n_z, orc), "g": _NlpSymbol("g", orc.n_g, orc),
                     "p": _NlpSymbol("p", orc.n_p, orc), "oracle": orc}
+        self.Z, self.G, self.J = nlp_prob["x"], nlp_prob["g"], nlp_prob["f"]  # mpopt.py:595-627 (handles with .shape)
         nlp_bounds = {"lbg": self.Gmin, "ubg": self.Gmax, "lbx": self.Zmin, "ubx": self.Zmax}
         return (nlp_prob, nlp_bounds)
 
@@ -1206,6 +1207,7 @@ class mpopt_adaptive(mpopt):
         assert len(self.Zmin) == orc.n_z and len(self.Gmin) == orc.n_g, "layout mismatch with libmpx"
         nlp_prob = {"f": _NlpSymbol("f", 1, orc), "x": _NlpSymbol("x", orc.n_z, orc), "g": _NlpSymbol("g", orc.n_g, orc),
                     "p": _NlpSymbol("p", self.n_segments * o.n_phases, orc), "oracle": orc}
+        self.Z, self.G, self.J = nlp_prob["x"], nlp_prob["g"], nlp_prob["f"]
         return (nlp_prob, {"lbg": self.Gmin, "ubg": self.Gmax, "lbx": self.Zmin, "ubx": self.Zmax})
 
     def discretize_phase(self, phase):
@@ -1504,3 +1506,10 @@ def solve(ocp, n_segments=1, poly_orders=9, scheme="LGR", plot=True, solve_dict=
     solution = mpo.solve(**solve_dict)
     post = mpo.process_results(solution, plot=plot, residual_x=residual_x, residual_dx=residual_dx)
     return (mpo, post)
+
+
+def __getattr__(name):
+    """``mp.plt`` like the reference module (mpopt.py:25), imported on first use."""
+    if name == "plt":
+        return post_process._plt()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -180,3 +180,21 @@ def test_mpopt_block_builders_agree_with_phase_bounds(test_mpo):
         assert np.array_equal(lo, Gmin) and np.array_equal(hi, Gmax)
         for b in blocks:
             assert (b[0] == [] and len(b[1]) == 0) or b[0].shape[0] == len(b[1])
+
+
+def test_module_surface_used_by_the_reference_examples():
+    """Names the reference's examples/ scripts touch on ``mp`` and on the optimizer objects."""
+    import matplotlib
+    matplotlib.use("Agg")
+    assert mp.plt.__name__ == "matplotlib.pyplot"
+    for name in ("OCP", "mpopt", "mpopt_h_adaptive", "mpopt_adaptive", "post_process", "solve", "Collocation", "CollocationRoots"):
+        assert hasattr(mp, name), name
+    mpo = mp.mpopt(problems.moon_lander(mp, M.math), 3, 3)
+    nlp, bounds = mpo.create_nlp()
+    assert mpo.Z.shape[0] == len(bounds["lbx"]) and mpo.G.shape[0] == len(bounds["lbg"])
+    h = mp.mpopt_h_adaptive(problems.moon_lander(mp, M.math), 3, 3)
+    for name in ("tol_residual", "plot_residual_evolution", "_THRESHOLD_SLOPE", "_SEG_WIDTH_MIN"):
+        assert hasattr(h, name), name
+    a = mp.mpopt_adaptive(problems.moon_lander(mp, M.math), 3, 3)
+    for name in ("tol_residual", "mid_residuals", "lbh", "ubh"):
+        assert hasattr(a, name), name
