@@ -163,6 +163,30 @@ def main():
         torch.cuda.synchronize()
         extra["jac_variable_only_evals_per_s"] = world * B * K / (time.perf_counter() - t1)
 
+    # Also NOT the metric: the same kernel on freshly allocated output buffers.  Where the arrays land in physical
+    # memory moves the node kernel by +-15 % within one process (not the box, not the TLB, pure-store
+    # bandwidth per allocation is flat); `value` above is whatever the first allocation gave, this records the spread.
+    if not hess_mode and not args.no_extras and world == 1:
+        sweep, hold = [], []
+        for k in range(4):
+            f2, g2 = torch.empty_like(f), torch.empty_like(g)
+            gr2, jv2 = torch.empty_like(gr), torch.empty_like(jv)
+            for _ in range(3):
+                o.eval_device(mask, B, Z, p, 0, None, None, f2, g2, gr2, jv2, None)
+            torch.cuda.synchronize()
+            o.profile(True)
+            for _ in range(10):
+                o.eval_device(mask, B, Z, p, 0, None, None, f2, g2, gr2, jv2, None)
+            ms, nl = o.profile_read()
+            o.profile(False)
+            sweep.append(ms / max(nl, 1) * 1e3)
+            if k % 2 == 0:
+                hold.append((f2, g2, gr2, jv2))  # keeping some alive moves the next allocation elsewhere
+            del f2, g2, gr2, jv2
+            torch.cuda.empty_cache()
+        del hold
+        extra["placement_sweep_node_kernel_us"] = [round(v, 1) for v in sweep]
+
     # sanity: the timed outputs are real (finite, and f matches a host recomputation of one point)
     assert torch.isfinite(jv[0]).all() and (hess_mode or torch.isfinite(g[-1]).all())
 
