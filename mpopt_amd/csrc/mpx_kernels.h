@@ -119,7 +119,8 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   // Workgroup -> (tile, batch chunk).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin;
   // here every XCD (id = linear id mod 8) walks a CONTIGUOUS range of (chunk, tile) items, so each XCD's L2
   // streams one contiguous eighth of the output arrays.  Measured on MI355X (config 2, B=4096): +3.4 % over the
-  // natural mapping at equal chunk size; chunk-fastest order: -6 %; rotating tiles with the chunk: +-0.
+  // natural mapping at equal chunk size; chunk-fastest order: -6 %; rotating tiles with the chunk: +-0; starting
+  // every XCD at a different phase of its range: +-0.
   // (MPX_MAP_NATURAL restores blockIdx.x = tile, blockIdx.y = chunk for A/B runs.)
 #if defined(MPX_MAP_NATURAL)
   const unsigned bx_ = blockIdx.x, by_ = blockIdx.y;
