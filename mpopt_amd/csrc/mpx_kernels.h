@@ -200,7 +200,11 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
     double t0v, tfv, ws, wc;
   };
   auto load_point = [&](int b, In& q) {
+#ifdef MPX_ABL_SAME_Z  // ablation: every evaluation point reads the first point's z (no HBM reads to speak of)
+    const double* __restrict__ zb = io.z + A.z_off;
+#else
     const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + A.z_off;
+#endif
 #pragma unroll
     for (int a = 0; a < NX; ++a) q.Xs[a] = (zb + (int64_t)a * N)[i];
 #pragma unroll
