@@ -205,6 +205,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
 #else
     const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + A.z_off;
 #endif
+    // (a streaming hint on these loads, __builtin_nontemporal_load, measured 7 % slower)
 #pragma unroll
     for (int a = 0; a < NX; ++a) q.Xs[a] = (zb + (int64_t)a * N)[i];
 #pragma unroll
