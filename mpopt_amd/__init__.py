@@ -11,6 +11,6 @@
 """
 from . import mpopt as mp  # noqa: F401
 from .expr import math_ns as math  # noqa: F401
-from .mpopt import OCP, Collocation, CollocationRoots, mpopt, mpopt_adaptive, mpopt_h_adaptive, solve  # noqa: F401
+from .mpopt import OCP, Collocation, CollocationRoots, mpopt, mpopt_adaptive, mpopt_h_adaptive, mpopt_ph_adaptive, solve  # noqa: F401
 from .nlp import NlpFunctions  # noqa: F401
 from ._lib import MpxError  # noqa: F401

@@ -410,6 +410,7 @@ class mpopt:
         self.grid_type = [self._GRID_TYPE] * self._ocp.n_phases
         self.max_grid_points = [self._MAX_GRID_POINTS] * self._ocp.n_phases
         self.oracle = None
+        self.__dict__.pop("_resid_plans", None)  # residual plans belong to the previous context
 
     def compute_numerical_approximation(self, scheme=None):
         scheme = self.colloc_scheme if scheme is None else scheme
@@ -1287,6 +1288,91 @@ class mpopt_adaptive(mpopt):
     def get_states_residuals(self, solution, phases=None, nodes=None, residual_type=None, plot=False, fig=None, axs=None):
         post, sol = self._as_fixed_width(solution)
         return post.get_states_residuals(sol, phases, nodes, residual_type)
+
+
+class mpopt_ph_adaptive(mpopt):
+    """Iterative refinement of polynomial degrees and segment widths (mpopt.py:4316-4596; the scheme of Patterson, Hager
+    & Rao, doi:10.1016/j.jfranklin.2015.05.028).  Constructor, attributes and ``get_abs_max_residual`` follow the
+    reference; ``solve_ph`` implements the loop the reference sketches (there it stops at an undefined name,
+    mpopt.py:4443): solve, measure the relative state residuals per segment, raise the degree by 3 where they exceed
+    ``max_residual``, re-solve, and split segments whose second derivative grew (non-smooth) instead of raising their
+    degree further.  Every re-solve builds a new transcription (new degrees = new kernels, compiled once and cached)."""
+
+    _SEG_WIDTH_MIN = 1e-5
+    _SEG_WIDTH_MAX = 1
+    _TOL_SEG_WIDTH_CHANGE = 0.05
+    _TOL_RESIDUAL = 1e-2
+
+    def __init__(self, problem, n_segments=1, poly_orders=[9], scheme="LGR", grid_type="spectral", max_residual=1e-4,
+                 poly_order_min=3, poly_order_max=16, seg_min=1, seg_max=20, n_grid_points=20, non_smooth_threshold=1.05):
+        super().__init__(problem=problem, n_segments=n_segments, poly_orders=poly_orders, scheme=scheme)
+        self.poly_order_min = min(poly_order_min, min(self.poly_orders))
+        self.poly_order_max = max(poly_order_max, max(self.poly_orders))
+        self.min_segments, self.max_segments = min(seg_min, n_segments), max(seg_max, n_segments)
+        self._MAX_GRID_POINTS, self._TOL_RESIDUAL, self._GRID_TYPE = n_grid_points, max_residual, grid_type
+        self.max_residual, self.n_grid_points, self.non_smooth_threshold = max_residual, n_grid_points, non_smooth_threshold
+        n_ph = self._ocp.n_phases
+        self.lbh, self.ubh = [self._SEG_WIDTH_MIN] * n_ph, [self._SEG_WIDTH_MAX] * n_ph
+        self.tol_residual = [self._TOL_RESIDUAL] * n_ph
+        self.fig, self.axs, self.plot_residual_evolution = None, None, False
+        self.reset_mpopt()
+
+    @staticmethod
+    def get_abs_max_residual(residual):
+        """Per phase, per segment: [index of the largest |residual| per state, that largest value] (mpopt.py:4400-4420)."""
+        out = [None] * len(residual)
+        for i_phase, r_phase in enumerate(residual):
+            out[i_phase] = [[np.abs(np.array(r_seg)).argmax(axis=0), np.abs(np.array(r_seg)).max(axis=0)] for r_seg in r_phase]
+        return out
+
+    def _regrid(self, poly_orders, widths):
+        self.poly_orders = [int(p) for p in poly_orders]
+        self.n_segments = len(self.poly_orders)
+        self._nlp_sw_params = np.asarray(widths, float)
+        self.reset_mpopt()
+
+    def _segment_residuals(self, solution):
+        _, _, _, res = self.get_states_residuals(solution, residual_type="relative")
+        mx = self.get_abs_max_residual([[r for r in ph if r is not None] for ph in res])
+        return [np.array([np.max(seg[1]) for seg in ph]) for ph in mx]
+
+    def solve_ph(self, max_iter=1, solve_dict={}):
+        if self._ocp.n_phases != 1:
+            raise NotImplementedError("solve_ph: the refinement loop is defined for single-phase problems (one grid per phase)")
+        clip = lambda orders: [min(max(self.poly_order_min, int(p)), self.poly_order_max) for p in orders]
+        widths = np.full(self.n_segments, 1.0 / self.n_segments)
+        solution = None
+        for _ in range(max_iter):
+            opts = dict(solve_dict, mpopt_options=dict(solve_dict.get("mpopt_options", {}), nlp_sw_params=widths))
+            solution = self.solve(reinitialize_nlp=True, **opts)
+            seg_res = self._segment_residuals(solution)[0]
+            bad = seg_res > self.max_residual
+            if not bad.any():
+                return solution
+            taus = [self.collocation._taus_fn(clip([p + 3])[0]) for p in self.poly_orders]
+            _, ddx, _ = self.get_state_second_derivative(solution, nodes=[taus])
+            coarse_orders, coarse_dd = list(self.poly_orders), [np.abs(v).max() if v is not None else 0.0 for v in ddx[0]]
+            # finer polynomial where the residual is too large, same segments
+            self._regrid(clip([p + 3 * int(b) for p, b in zip(coarse_orders, bad)]), widths)
+            opts = dict(solve_dict, mpopt_options=dict(solve_dict.get("mpopt_options", {}), nlp_sw_params=widths))
+            solution = self.solve(reinitialize_nlp=True, **opts)
+            seg_res = self._segment_residuals(solution)[0]
+            bad = seg_res > self.max_residual
+            if not bad.any():
+                return solution
+            _, ddx_new, _ = self.get_state_second_derivative(solution, nodes=[taus])
+            orders, new_w = [], []
+            for s, (p, w) in enumerate(zip(self.poly_orders, widths)):
+                grew = ddx_new[0][s] is not None and coarse_dd[s] > 0 and np.abs(ddx_new[0][s]).max() / coarse_dd[s] > self.non_smooth_threshold
+                if bad[s] and grew and len(orders) + (self.n_segments - s) < self.max_segments:
+                    orders += [coarse_orders[s]] * 2  # non-smooth: split, keep the degree
+                    new_w += [w / 2] * 2
+                else:
+                    orders.append(p)
+                    new_w.append(w)
+            widths = np.asarray(new_w)
+            self._regrid(clip(orders), widths)
+        return solution
 
 
 def _ref_control_order(U):

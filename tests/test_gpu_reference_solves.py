@@ -123,3 +123,15 @@ def test_moon_lander_h_adaptive_solve(grid_type):  # 249-255, 431-470
         mpo.grid_type[0] = grid_type
     sol = mpo.solve(max_iter=3) if grid_type is None else mpo.solve(max_iter=2, mpopt_options={"method": "residual", "sub_method": "equal_area"})
     check_solution_and_post(mpo, sol)
+
+
+def test_ph_adaptive_refinement_loop():
+    """mpopt_ph_adaptive.solve_ph (the loop the reference sketches at mpopt.py:4422-4596): degrees go up where the
+    relative state residual exceeds the tolerance, the grid stays consistent and the cost approaches the optimum."""
+    mp.mpopt._MUTE_ = True
+    opt = mp.mpopt_ph_adaptive(problems.moon_lander(mp, M.math), n_segments=3, poly_orders=[2] * 3, max_residual=1e-3)
+    sol = opt.solve_ph(max_iter=3)
+    assert len(opt.poly_orders) == opt.n_segments == len(opt._nlp_sw_params) and abs(sum(opt._nlp_sw_params) - 1) < 1e-12
+    assert max(opt.poly_orders) > 2 and opt.n_segments <= opt.max_segments
+    assert abs(float(sol["f"]) - 8.2462) < 0.05
+    check_solution_and_post(opt, sol)

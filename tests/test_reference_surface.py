@@ -198,3 +198,14 @@ def test_module_surface_used_by_the_reference_examples():
     a = mp.mpopt_adaptive(problems.moon_lander(mp, M.math), 3, 3)
     for name in ("tol_residual", "mid_residuals", "lbh", "ubh"):
         assert hasattr(a, name), name
+
+
+def test_ph_adaptive_surface_and_max_residual():
+    """mpopt_ph_adaptive (mpopt.py:4316-4420): constructor attributes and get_abs_max_residual."""
+    mpo = mp.mpopt_ph_adaptive(problems.moon_lander(mp, M.math), n_segments=3, poly_orders=[2] * 3)
+    assert (mpo.poly_order_min, mpo.poly_order_max, mpo.min_segments, mpo.max_segments) == (2, 16, 1, 20)
+    assert mpo.max_residual == 1e-4 and mpo.grid_type == ["spectral"] and mpo.max_grid_points == [20]
+    assert mpo.lbh == [1e-5] and mpo.ubh == [1] and mpo.tol_residual == [1e-4]
+    res = [[np.array([[1.0, -3.0], [-2.0, 0.5]]), np.array([[0.1, 0.2]])]]
+    out = mp.mpopt_ph_adaptive.get_abs_max_residual(res)
+    assert np.array_equal(out[0][0][0], [1, 0]) and np.array_equal(out[0][0][1], [2.0, 3.0]) and np.array_equal(out[0][1][1], [0.1, 0.2])
