@@ -205,7 +205,6 @@ class AssembledNlpFunctions(NlpFunctions):
         HK, HS, HC = [], [], []
         for k, s in enumerate(self.sets):
             fn, n, o = s.fn, s.n, self.raw_off[k]
-            pts = np.arange(n)
             for r in range(fn.n_out):
                 w = s.fw[:, r]
                 nzp = np.nonzero(w)[0]
@@ -252,7 +251,7 @@ class AssembledNlpFunctions(NlpFunctions):
         # CasADi's compressed-column order): entries are sorted by the raw slot their first term reads -- set-major,
         # slot-major, point-minor, exactly the layout the point kernels write -- so consecutive lanes of the gather kernel
         # read consecutive raw values and write consecutive outputs; constants (no raw source) come first.
-        def pattern(K, S_, C_, by_col):
+        def pattern(K, S_, C_):
             K, S_, C_ = _cat(K, np.int64), _cat(S_, np.int64), _cat(C_, np.float64)
             rows, cols = K // n_z, K % n_z
             colmajor = cols * (max(n_g, n_z) + 1) + rows
@@ -264,8 +263,8 @@ class AssembledNlpFunctions(NlpFunctions):
             rank[order] = np.arange(len(uniq))
             return rows[first][order].astype(np.int32), cols[first][order].astype(np.int32), rank[inv], S_, C_
 
-        self.jrow, self.jcol, jinv, JS, JC = pattern(JK, JS, JC, True)
-        self.hrow, self.hcol, hinv, HS, HC = pattern(HK, HS, HC, True)
+        self.jrow, self.jcol, jinv, JS, JC = pattern(JK, JS, JC)
+        self.hrow, self.hcol, hinv, HS, HC = pattern(HK, HS, HC)
         self.nnz_jac_, self.nnz_hess_ = len(self.jrow), len(self.hrow)
         rows = np.concatenate([_cat(R, np.int64), 1 + n_g + n_z + jinv])
         self.fgj = _csr_from_terms(1 + n_g + n_z + self.nnz_jac_, rows, np.concatenate([_cat(S, np.int64), JS]), np.concatenate([_cat(C, np.float64), JC]))
