@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="evaluation points per GPU per step")
     ap.add_argument("--segments", type=int, default=1000)
     ap.add_argument("--degree", type=int, default=5)
-    ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config2-hess"],
+    ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config2-hess", "adaptive-fgj"],
                     help="default: the metric's configuration (BASELINE configs[1], f+g+grad_f+jac_g).  The others are "
                          "secondary reports (configs[4]: nlp_hess_l on hypersensitive 4000x3; configs[2]: mixed-degree grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,8 +92,12 @@ def main():
         builder, S, P, scheme = problems.BENCH_CASES[1]
         B = min(B, 512)
         label = "Van der Pol OCP, n_segments=2000, poly_orders=[3,30,3]*, CGL (BASELINE configs[2])"
+    adaptive = args.workload == "adaptive-fgj"
+    if adaptive:  # widths as decision variables, assembled context (point kernels + gather)
+        S, P = 20, 5
+        label = "moon-lander OCP, mpopt_adaptive (segment widths as variables), n_segments=20, poly_orders=5, LGR"
     ocp = builder(mp, M.math)
-    mpo = mp.mpopt(ocp, S, P, scheme, device=dev_id)
+    mpo = (mp.mpopt_adaptive if adaptive else mp.mpopt)(ocp, S, P, scheme, device=dev_id)
     if rank == 0 or world == 1:
         nlp, bounds = mpo.create_nlp()  # rank 0 compiles (or finds the cached code object) first
     if world > 1:
@@ -105,7 +109,7 @@ def main():
 
     Zh = make_points(o, mpo, bounds, B, 20260928 + rank)
     Z = torch.tensor(Zh, device=dev)
-    p = torch.tensor(np.full(o.n_p, 1.0 / S), device=dev)
+    p = torch.tensor(np.full(max(o.n_p, 1), 1.0 / S), device=dev)
     f = torch.empty(B, dtype=torch.float64, device=dev)
     g = torch.empty(B, o.n_g, dtype=torch.float64, device=dev)
     gr = torch.empty(B, o.n_z, dtype=torch.float64, device=dev)
@@ -153,7 +157,7 @@ def main():
     # secondary, opt-in mode (NOT the metric): only the (z,p)-dependent Jacobian entries are rewritten into
     # the resident buffers, which hold the grid constants from the full evaluations above
     extra = {}
-    if not hess_mode and not args.no_extras:
+    if not hess_mode and not args.no_extras and not adaptive:
         from mpopt_amd._lib import MPX_JAC_VARIABLE_ONLY
 
         torch.cuda.synchronize()
@@ -166,7 +170,7 @@ def main():
     # Also NOT the metric: the same kernel on freshly allocated output buffers.  Where the arrays land in physical
     # memory moves the node kernel by +-15 % within one process (not the box, not the TLB, pure-store
     # bandwidth per allocation is flat); `value` above is whatever the first allocation gave, this records the spread.
-    if not hess_mode and not args.no_extras and world == 1:
+    if not hess_mode and not args.no_extras and world == 1 and not adaptive:
         sweep, hold = [], []
         for k in range(4):
             f2, g2 = torch.empty_like(f), torch.empty_like(g)
@@ -191,7 +195,7 @@ def main():
     assert torch.isfinite(jv[0]).all() and (hess_mode or torch.isfinite(g[-1]).all())
 
     if rank == 0:
-        n_buckets = len(set(int(d) for d in mpo.poly_orders))
+        n_buckets = 1 if adaptive else len(set(int(d) for d in mpo.poly_orders))
         kernel_s = node_ms / 1e3 / max(n_launch // n_buckets, 1)  # all node-kernel launches of one step
         bytes_eval = o.bytes_hess if hess_mode else o.bytes_fgj
         achieved = B * bytes_eval / kernel_s / 1e9
@@ -214,7 +218,8 @@ def main():
                        "parallelism": f"independent evaluation points x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*", "kernel_us": kernel_s * 1e6,
+                         "kernel": "mpx_pts_jac + mpx_gather_kernel" if adaptive else f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*",
+                         "kernel_us": kernel_s * 1e6,
                          "bytes_per_eval": bytes_eval, "evals_per_launch": B,
                          "algorithmic_bytes_per_launch": B * bytes_eval},
         }

@@ -329,18 +329,26 @@ int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   if ((rc = reserve(c, a->raw, (size_t)(batch * std::max(a->raw_n, a->rawh_n))))) return rc;
   if (mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC)) {
     const int mode = (mask & (MPX_GRAD | MPX_JAC)) ? MPX_MODE_FGJ : MPX_MODE_FG;
+    hipEvent_t pe = nullptr;  // mpx_profile: one bracket per pass (point kernels + gather), counted as one launch
+    if ((rc = prof_begin(c, &pe))) return rc;
     if ((rc = launch_points(c, mode, batch, z, nullptr, nullptr))) return rc;
     const int64_t begin[4] = {0, 1, 1 + c->n_g, 1 + c->n_g + c->n_z};
     double* outp[4] = {(mask & MPX_F) ? f : nullptr, (mask & MPX_G) ? g : nullptr, (mask & MPX_GRAD) ? grad_f : nullptr, (mask & MPX_JAC) ? jac_val : nullptr};
     const int64_t stride[4] = {1, c->n_g, c->n_z, c->nnz_j};
     if ((rc = launch_gather(c, a->fgj, batch, z, a->raw_n, 4, begin, outp, stride))) return rc;
+    if ((rc = prof_end(c, pe))) return rc;
+    if (c->profile) ++c->prof_launches;
   }
   if (mask & MPX_HESS) {
+    hipEvent_t pe = nullptr;
+    if ((rc = prof_begin(c, &pe))) return rc;
     if ((rc = launch_points(c, MPX_MODE_HESS, batch, z, lam_g, sigma))) return rc;
     const int64_t begin[1] = {0};
     double* outp[1] = {hess_val};
     const int64_t stride[1] = {c->nnz_h};
     if ((rc = launch_gather(c, a->hess, batch, z, a->rawh_n, 1, begin, outp, stride))) return rc;
+    if ((rc = prof_end(c, pe))) return rc;
+    if (c->profile) ++c->prof_launches;
   }
   return MPX_OK;
 }

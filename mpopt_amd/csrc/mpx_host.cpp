@@ -581,19 +581,10 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
     io.gtmp_stride = c->gtmp_n;
   }
   const int gy = (io.B + io.b_per_block - 1) / io.b_per_block;
-  hipEvent_t pe0 = nullptr, pe1 = nullptr;
-  if (c->profile) {
-    if (c->prof_used + 2 > c->prof_ev.size()) {
-      for (int k = 0; k < 2; ++k) {
-        hipEvent_t e;
-        HIPCHK(c, hipEventCreate(&e));
-        c->prof_ev.push_back(e);
-      }
-    }
-    pe0 = c->prof_ev[c->prof_used];
-    pe1 = c->prof_ev[c->prof_used + 1];
-    c->prof_used += 2;
-    HIPCHK(c, hipEventRecord(pe0, c->stream));
+  hipEvent_t pe1 = nullptr;
+  {
+    int rc = prof_begin(c, &pe1);
+    if (rc) return rc;
   }
   for (auto& B : c->buckets) {
     int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);
@@ -629,7 +620,10 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
                        io.g_stride, c->d_gmap, c->n_g, io.grad, io.grad_stride, c->d_qmap, c->n_z);
     HIPCHK(c, hipGetLastError());
   }
-  if (c->profile) HIPCHK(c, hipEventRecord(pe1, c->stream));
+  {
+    int rc = prof_end(c, pe1);
+    if (rc) return rc;
+  }
   if (!c->run_boundary) return MPX_OK;
   MpxBoundArgs G{};
   G.io = io;

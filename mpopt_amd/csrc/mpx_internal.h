@@ -158,6 +158,30 @@ inline int reserve(mpx_ctx* c, DevBuf<T>& b, size_t n) {
 
 }  // namespace mpxi
 
+namespace mpxi {
+// Per-kernel profiling (mpx_profile): a pair of events on the context stream around the dominant launches of one pass.
+inline int prof_begin(mpx_ctx* c, hipEvent_t* end_event) {
+  *end_event = nullptr;
+  if (!c->profile) return MPX_OK;
+  if (c->prof_used + 2 > c->prof_ev.size()) {
+    for (int k = 0; k < 2; ++k) {
+      hipEvent_t e;
+      HIPCHK(c, hipEventCreate(&e));
+      c->prof_ev.push_back(e);
+    }
+  }
+  hipEvent_t begin = c->prof_ev[c->prof_used];
+  *end_event = c->prof_ev[c->prof_used + 1];
+  c->prof_used += 2;
+  HIPCHK(c, hipEventRecord(begin, c->stream));
+  return MPX_OK;
+}
+inline int prof_end(mpx_ctx* c, hipEvent_t end_event) {
+  if (end_event) HIPCHK(c, hipEventRecord(end_event, c->stream));
+  return MPX_OK;
+}
+}  // namespace mpxi
+
 // mpx_assembly.cpp
 void mpx_asm_release(mpx_ctx* c);
 int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* lam_g, const double* sigma, double* f, double* g,
