@@ -338,3 +338,39 @@ def test_ccs_order_is_the_device_side_permutation(name):
     one = o.eval(["jac_g"], Z[1], G["p"], ccs_order=True)
     assert np.array_equal(one["jac_g"], b["jac_g"][1])
     o.close()
+
+
+@pytest.mark.gpu
+def test_contexts_do_not_leak_device_memory():
+    """Create / evaluate / destroy tiled and assembled contexts repeatedly (host and device entry points, growing
+    batches, residual plans, page-locked buffers): device memory returns to where it started."""
+    import torch
+    import mpopt_amd as M
+    from mpopt_amd import mp
+
+    def cycle(k):
+        mpo = mp.mpopt(problems.kitchen_sink(mp, M.math), 3, [2, 4, 3], "CGL")
+        nlp, _ = mpo.create_nlp()
+        o = nlp["oracle"]
+        rng = np.random.default_rng(k)
+        B = 1 + 7 * k
+        z = rng.normal(size=(B, o.n_z))
+        p = np.full(o.n_p, 1.0 / 3)
+        o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], z, p, lam_g=rng.normal(size=(B, o.n_g)), sigma=np.ones(B), pinned=(k % 2 == 0), ccs_order=(k % 3 == 0))
+        plan = o.residual_plan(0, [np.linspace(-1, 1, 4)] * 3)
+        plan.eval(z[0], p)
+        plan.close()
+        o.close()
+        a = mp.mpopt_adaptive(problems.van_der_pol(mp, M.math), 3, [2, 4, 3], "CGL")
+        oa = a.create_nlp()[0]["oracle"]
+        oa.eval(["f", "g", "grad_f", "jac_g", "hess_l"], rng.normal(size=(B, oa.n_z)), None, lam_g=rng.normal(size=(B, oa.n_g)), sigma=np.ones(B))
+        oa.close()
+
+    cycle(0)  # first use loads libraries / code objects
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(1, 9):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 8 create/destroy cycles"
