@@ -12,6 +12,7 @@ Nothing here runs on the hot path: tracing happens once per problem, like ``nlps
 construction in the reference ("costly operation", mpopt.py:756).
 """
 import math
+import operator
 import numbers
 
 import numpy as np
@@ -50,7 +51,11 @@ _UNARY_PY = {
     "abs": abs,
     "sign": lambda v: (v > 0) - (v < 0),
 }
-_BINARY_C = {"add": "{0} + {1}", "sub": "{0} - {1}", "mul": "{0} * {1}", "div": "{0} / {1}", "pow": "pow({0}, {1})"}
+_BINARY_C = {"add": "{0} + {1}", "sub": "{0} - {1}", "mul": "{0} * {1}", "div": "{0} / {1}", "pow": "pow({0}, {1})",
+             "atan2": "atan2({0}, {1})", "fmax": "fmax({0}, {1})", "fmin": "fmin({0}, {1})",
+             "ge": "(({0}) >= ({1}) ? 1.0 : 0.0)"}  # ge: indicator used by the derivatives of fmax / fmin
+_BINARY_PY = {"add": lambda x, y: x + y, "sub": lambda x, y: x - y, "mul": lambda x, y: x * y, "div": lambda x, y: x / y,
+              "pow": lambda x, y: x ** y, "atan2": math.atan2, "fmax": max, "fmin": min, "ge": lambda x, y: 1.0 if x >= y else 0.0}
 
 
 class Tracer:
@@ -185,6 +190,12 @@ class Tracer:
             return self.const(a.val ** b.val)
         return self._mk("pow", (a, b))
 
+    def binary(self, op, a, b):
+        """atan2 / fmax / fmin / ge (the arithmetic operators have their own simplifying constructors)."""
+        if a.is_const and b.is_const:
+            return self.const(_BINARY_PY[op](a.val, b.val))
+        return self._mk(op, (a, b))
+
     def unary(self, op, a):
         if op == "neg":
             return self.neg(a)
@@ -250,6 +261,14 @@ class Tracer:
             if not da[1].is_zero:
                 t = self.add(t, self.mul(self.mul(n, self.unary("log", a[0])), da[1]))
             return t
+        if op == "atan2":  # atan2(y, x): (x y' - y x') / (x^2 + y^2)
+            den = self.add(self.mul(a[0], a[0]), self.mul(a[1], a[1]))
+            return self.div(self.sub(self.mul(a[1], da[0]), self.mul(a[0], da[1])), den)
+        if op in ("fmax", "fmin"):  # derivative of the active argument (ties: the first one)
+            first = self.binary("ge", a[0], a[1]) if op == "fmax" else self.binary("ge", a[1], a[0])
+            return self.add(self.mul(first, da[0]), self.mul(self.sub(self.one, first), da[1]))
+        if op == "ge":
+            return self.zero
         u, du = a[0], da[0]
         if op == "sqrt":
             return self.div(du, self.mul(self.const(2.0), n))
@@ -312,10 +331,7 @@ class Tracer:
             elif n.op in _UNARY_PY:
                 vals[n.id] = _UNARY_PY[n.op](vals[n.args[0].id])
             else:
-                x, y = vals[n.args[0].id], vals[n.args[1].id]
-                vals[n.id] = {"add": x + y, "sub": x - y, "mul": x * y,
-                              "div": x / y if n.op == "div" else 0.0,
-                              "pow": x ** y if n.op == "pow" else 0.0}[n.op]
+                vals[n.id] = _BINARY_PY[n.op](vals[n.args[0].id], vals[n.args[1].id])
         return [vals[o.id] for o in outputs]
 
     def emit(self, assignments, var_names, indent="  "):
@@ -367,7 +383,34 @@ def _cfloat(v):
 
 class Expr:
     __slots__ = ("tr", "op", "args", "val", "id")
-    __array_ufunc__ = None
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        """numpy functions on traced values (the reference's examples write np.sqrt / np.cos / np.sin / np.dot on
+        CasADi symbols): element-wise ufuncs map to tracer operations; arrays broadcast to object arrays."""
+        if method != "__call__" or kwargs.get("out") is not None:
+            return NotImplemented
+        if any(isinstance(a, np.ndarray) and a.ndim > 0 for a in inputs):
+            boxed = []  # plain object arrays, so that the element-wise helper is not dispatched back to this method
+            for a in inputs:
+                if isinstance(a, Expr):
+                    cell = np.empty((), dtype=object)
+                    cell[()] = a
+                    a = cell
+                boxed.append(a)
+            return np.frompyfunc(lambda *xs: ufunc(*xs), len(inputs), 1)(*boxed)
+        args = [a.item() if isinstance(a, np.ndarray) else a for a in inputs]
+        tr = self.tr
+        if ufunc in _UFUNC_UNARY:
+            return tr.unary(_UFUNC_UNARY[ufunc], tr.wrap(args[0]))
+        if ufunc in _UFUNC_OPERATOR:
+            return _UFUNC_OPERATOR[ufunc](*[a if isinstance(a, Expr) else float(a) for a in args])
+        if ufunc in _UFUNC_BINARY:
+            return tr.binary(_UFUNC_BINARY[ufunc], tr.wrap(args[0]), tr.wrap(args[1]))
+        if ufunc is np.square:
+            return args[0] * args[0]
+        if ufunc is np.reciprocal:
+            return 1.0 / args[0]
+        return NotImplemented
 
     def __init__(self, tr, op, args, val, id_):
         self.tr, self.op, self.args, self.val, self.id = tr, op, args, val, id_
@@ -384,33 +427,53 @@ class Expr:
         return any(n.op == "var" and n.val in names for n in Tracer.toposort([self]))
 
     def __add__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.add(self, self.tr.wrap(o))
 
     def __radd__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.add(self.tr.wrap(o), self)
 
     def __sub__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.sub(self, self.tr.wrap(o))
 
     def __rsub__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.sub(self.tr.wrap(o), self)
 
     def __mul__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.mul(self, self.tr.wrap(o))
 
     def __rmul__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.mul(self.tr.wrap(o), self)
 
     def __truediv__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.div(self, self.tr.wrap(o))
 
     def __rtruediv__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.div(self.tr.wrap(o), self)
 
     def __pow__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.pow(self, self.tr.wrap(o))
 
     def __rpow__(self, o):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            return NotImplemented  # numpy broadcasts (through __array_ufunc__)
         return self.tr.pow(self.tr.wrap(o), self)
 
     def __neg__(self):
@@ -422,6 +485,18 @@ class Expr:
     def __abs__(self):
         return self.tr.unary("abs", self)
 
+    # numpy's object-dtype loops (np.sin(array_of_exprs), ...) call a method named like the ufunc
+    def _u(op):  # noqa: N805
+        return lambda self: self.tr.unary(op, self)
+
+    sin, cos, tan, exp, log, sqrt = _u("sin"), _u("cos"), _u("tan"), _u("exp"), _u("log"), _u("sqrt")
+    arcsin, arccos, arctan, sinh, cosh, tanh = _u("asin"), _u("acos"), _u("atan"), _u("sinh"), _u("cosh"), _u("tanh")
+    fabs, absolute, sign = _u("abs"), _u("abs"), _u("sign")
+    del _u
+
+    def arctan2(self, o):
+        return self.tr.binary("atan2", self, self.tr.wrap(o))
+
     def __bool__(self):
         raise TypeError("traced expressions have no truth value (data-dependent branches are not supported)")
 
@@ -431,6 +506,14 @@ class Expr:
         if self.op == "var":
             return str(self.val)
         return f"{self.op}({', '.join(map(repr, self.args))})"
+
+
+_UFUNC_UNARY = {np.sin: "sin", np.cos: "cos", np.tan: "tan", np.exp: "exp", np.log: "log", np.sqrt: "sqrt", np.arcsin: "asin",
+                np.arccos: "acos", np.arctan: "atan", np.sinh: "sinh", np.cosh: "cosh", np.tanh: "tanh", np.absolute: "abs",
+                np.fabs: "abs", np.sign: "sign", np.negative: "neg"}
+_UFUNC_OPERATOR = {np.add: operator.add, np.subtract: operator.sub, np.multiply: operator.mul, np.true_divide: operator.truediv,
+                   np.power: operator.pow}
+_UFUNC_BINARY = {np.arctan2: "atan2", np.maximum: "fmax", np.minimum: "fmin", np.fmax: "fmax", np.fmin: "fmin"}
 
 
 def _math_fn(op, npfn):
@@ -468,8 +551,59 @@ class _Math:
     cosh = staticmethod(_math_fn("cosh", np.cosh))
     tanh = staticmethod(_math_fn("tanh", np.tanh))
     fabs = staticmethod(_math_fn("abs", np.abs))
+    sign = staticmethod(_math_fn("sign", np.sign))
     pi = math.pi
     inf = math.inf
+
+    # two-argument functions and the CasADi spellings the reference's examples use on symbols
+    @staticmethod
+    def _binary(op, npfn, spname):
+        def f(a, b):
+            for x in (a, b):
+                if isinstance(x, Expr):
+                    return x.tr.binary(op, x.tr.wrap(a), x.tr.wrap(b))
+            try:
+                import sympy as sp
+
+                if isinstance(a, sp.Expr) or isinstance(b, sp.Expr):
+                    return getattr(sp, spname)(a, b)
+            except ImportError:  # pragma: no cover
+                pass
+            return npfn(a, b)
+
+        return f
+
+    @staticmethod
+    def vertcat(*xs):
+        """ca.vertcat of scalars / lists -> a flat Python list (what the OCP callables return)."""
+        out = []
+        for x in xs:
+            out += list(x) if isinstance(x, (list, tuple, np.ndarray)) else [x]
+        return out
+
+    @staticmethod
+    def sumsqr(xs):
+        xs = _Math.vertcat(xs)
+        r = xs[0] * xs[0]
+        for v in xs[1:]:
+            r = r + v * v
+        return r
+
+    @staticmethod
+    def dot(a, b):
+        a, b = _Math.vertcat(a), _Math.vertcat(b)
+        r = a[0] * b[0]
+        for x, y in zip(a[1:], b[1:]):
+            r = r + x * y
+        return r
+
+
+_Math.atan2 = staticmethod(_Math._binary("atan2", np.arctan2, "atan2"))
+_Math.fmax = staticmethod(_Math._binary("fmax", np.maximum, "Max"))
+_Math.fmin = staticmethod(_Math._binary("fmin", np.minimum, "Min"))
+_Math.norm_2 = staticmethod(lambda xs: _Math.sqrt(_Math.sumsqr(xs)))
+_Math.arcsin, _Math.arccos, _Math.arctan, _Math.arctan2 = _Math.asin, _Math.acos, _Math.atan, _Math.atan2
+_Math.power = staticmethod(lambda a, b: a ** b)
 
 
 math_ns = _Math()

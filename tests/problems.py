@@ -257,3 +257,43 @@ def sample_widths(rng, n_segments, n_phases):
     w = rng.uniform(0.5, 1.5, (n_phases, n_segments))
     w = w / w.sum(axis=1, keepdims=True)
     return w.reshape(-1)
+
+
+def ascent_numpy_style(mp, fn=None, use_numpy=True):
+    """Point mass in a central gravity field with exponential-atmosphere drag, written the way the reference's
+    launch-vehicle examples are (examples/Multi-phase/multistage_launch_vehicle.py): numpy functions applied to the
+    symbols (np.sqrt, np.dot, np.exp, np.cos, np.sin, arrays of symbols).  ``use_numpy=False`` writes the same model with the
+    ``fn`` namespace, for comparison."""
+    ocp = mp.OCP(n_states=7, n_controls=3, n_phases=1)
+    mu, Re, h0, cd_a, thrust, isp_g0 = 1.0, 1.0, 0.05, 0.3, 0.6, 2.5
+    sqrt, exp, cos, sin = (np.sqrt, np.exp, np.cos, np.sin) if use_numpy else (fn.sqrt, fn.exp, fn.cos, fn.sin)
+
+    def dynamics(x, u, t):
+        r, v, m = x[0:3], x[3:6], x[6]
+        if use_numpy:
+            r, v, uu = np.array(r), np.array(v), np.array(u)
+            rn = sqrt(np.dot(r, r))
+            vn = sqrt(np.dot(v, v) + 1e-6)
+            drag = -0.5 * cd_a * exp(-(rn - Re) / h0) * vn * v
+            acc = -mu / (rn * rn * rn) * r + (thrust * uu + drag) / m
+            acc = list(acc)
+        else:
+            rn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2])
+            vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + 1e-6)
+            k = -0.5 * cd_a * exp(-(rn - Re) / h0) * vn
+            acc = [-mu / (rn * rn * rn) * r[i] + (thrust * u[i] + k * v[i]) / m for i in range(3)]
+        return [v[0], v[1], v[2], acc[0], acc[1], acc[2], -thrust / isp_g0 * (1.0 + 0.1 * cos(t) * sin(t))]
+
+    ocp.dynamics[0] = dynamics
+    ocp.path_constraints[0] = lambda x, u, t: [u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - 1.0]
+    ocp.running_costs[0] = lambda x, u, t: 0.01 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2])
+    ocp.terminal_costs[0] = lambda xf, tf, x0, t0: -xf[6]
+    ocp.terminal_constraints[0] = (lambda xf, tf, x0, t0: [sqrt(xf[0] * xf[0] + xf[1] * xf[1] + xf[2] * xf[2]) - 1.2])
+    ocp.x00[0] = [1.0, 0.0, 0.0, 0.0, 0.3, 0.1, 1.0]
+    ocp.xf0[0] = [0.9, 0.7, 0.2, -0.3, 0.6, 0.1, 0.6]
+    ocp.u00[0], ocp.uf0[0] = [0.2, 0.9, 0.1], [0.0, 1.0, 0.0]
+    ocp.lbu[0], ocp.ubu[0] = [-1, -1, -1], [1, 1, 1]
+    ocp.lbx[0][6] = 0.1
+    ocp.lbtf[0], ocp.ubtf[0] = 0.5, 2.0
+    ocp.tf0[0] = 1.0
+    return ocp

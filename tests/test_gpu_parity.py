@@ -374,3 +374,45 @@ def test_contexts_do_not_leak_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 8 create/destroy cycles"
+
+
+@pytest.mark.gpu
+def test_numpy_style_problem_on_gpu():
+    """An OCP written with numpy functions on the symbols (the style of the reference's launch-vehicle examples):
+    same values as the explicit spelling, derivatives consistent with central differences."""
+    import mpopt_amd as M
+    from mpopt_amd import mp
+
+    res = []
+    for use_numpy in (True, False):
+        mpo = mp.mpopt(problems.ascent_numpy_style(mp, M.math, use_numpy=use_numpy), 4, 4, "LGR")
+        nlp, bounds = mpo.create_nlp()
+        o = nlp["oracle"]
+        rng = np.random.default_rng(4)
+        z = mpo.initialize_solution() * (1 + 0.02 * rng.uniform(-1, 1, o.n_z))
+        p = np.full(o.n_p, 0.25)
+        lam, sig = rng.standard_normal(o.n_g), 0.9
+        res.append((o, z, p, lam, sig, o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], z, p, lam_g=lam, sigma=sig)))
+    (o, z, p, lam, sig, a), b = res[0], res[1][5]
+    for k in a:
+        assert rel_err(a[k], b[k]) < 1e-13, k
+    jr, jc = o.jac_pattern()
+    hr, hc = o.hess_pattern()
+    J = np.zeros((o.n_g, o.n_z))
+    J[jr, jc] = a["jac_g"]
+    H = np.zeros((o.n_z, o.n_z))
+    H[hr, hc] = a["hess_l"]
+    H = H + np.triu(H, 1).T
+    cols = np.random.default_rng(5).choice(o.n_z, 12, replace=False)
+    eps = 1e-6
+    Zp = np.stack([z + eps * np.eye(o.n_z)[c] for c in cols] + [z - eps * np.eye(o.n_z)[c] for c in cols])
+    q = o.eval(["f", "g", "grad_f", "jac_g"], Zp, p)
+    k = len(cols)
+    assert np.abs((q["f"][:k] - q["f"][k:]) / (2 * eps) - a["grad_f"][cols]).max() < 1e-7
+    assert np.abs((q["g"][:k] - q["g"][k:]).T / (2 * eps) - J[:, cols]).max() < 1e-6 * max(1.0, np.abs(J).max())
+    gl = np.zeros((2 * k, o.n_z))
+    for i in range(2 * k):
+        Jb = np.zeros((o.n_g, o.n_z))
+        Jb[jr, jc] = q["jac_g"][i]
+        gl[i] = sig * q["grad_f"][i] + lam @ Jb
+    assert np.abs((gl[:k] - gl[k:]).T / (2 * eps) - H[:, cols]).max() < 1e-5 * max(1.0, np.abs(H).max())

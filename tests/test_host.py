@@ -231,3 +231,24 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), fn
+
+
+def test_numpy_functions_on_traced_symbols():
+    """The reference's examples apply numpy functions to CasADi symbols (np.sqrt / np.cos / np.sin / np.dot, 190 uses
+    under examples/): the tracer accepts the same statements and produces the SAME program as the explicit spelling."""
+    from mpopt_amd.codegen import ProblemProgram
+
+    a = ProblemProgram(problems.ascent_numpy_style(mp, M.math, use_numpy=True), [4], [True])
+    b = ProblemProgram(problems.ascent_numpy_style(mp, M.math, use_numpy=False), [4], [True])
+    assert np.array_equal(a.structure(), b.structure())
+    tr = Tracer()
+    x, y = tr.var("x"), tr.var("y")
+    env = {"x": 0.3, "y": 0.7}
+    import math
+    for e, want in ((np.arctan2(y, x), math.atan2(0.7, 0.3)), (np.maximum(x * x, y), 0.7), (np.minimum(x, y) * 2, 0.6),
+                    (np.dot(np.array([x, y]), [2.0, 3.0]), 2.7), ((np.array([[1.0, 2.0], [3.0, 4.0]]) @ np.array([x, y]))[1], 3.7),
+                    (np.sin(np.array([x, y]))[1], math.sin(0.7)), ((x - np.array([1.0, 2.0]))[1], -1.7), (M.math.norm_2([x, y]), math.sqrt(0.58)),
+                    (M.math.vertcat(x, [y, 1.0])[1], 0.7), (np.power(x, 3), 0.027), (np.abs(-x), 0.3)):
+        assert abs(tr.evaluate([tr.wrap(e)], env)[0] - want) < 1e-14
+    d = tr.diff(np.arctan2(y, x), x)
+    assert abs(tr.evaluate([d], env)[0] + 0.7 / 0.58) < 1e-14
