@@ -23,6 +23,7 @@ import scipy.sparse as sp
 
 from .assembly import AssembledNlpFunctions, PointFunction, PointSet
 from .codegen import _as_list
+from .expr import symvec
 
 
 class AdaptiveLayout:
@@ -136,8 +137,8 @@ def build_adaptive_oracle(ocp, n_segments, poly_orders, collocation, mid_residua
         dyn_f, path_f, cost_f = o.get_dynamics(ph), o.get_path_constraints(ph), o.get_running_costs(ph)
 
         def scaled(loc_x, loc_u, loc_a):
-            return ([loc_x[a] * (1.0 / sx[a]) for a in range(nx)], [loc_u[b] * (1.0 / su[b]) for b in range(nu)],
-                    [loc_a[c] * (1.0 / sa[c]) for c in range(na)])
+            return (symvec([loc_x[a] * (1.0 / sx[a]) for a in range(nx)]), symvec([loc_u[b] * (1.0 / su[b]) for b in range(nu)]),
+                    symvec([loc_a[c] * (1.0 / sa[c]) for c in range(na)]))
 
         # ---- node function (mpopt.py:175-206) ---------------------------------------------------
         n_loc = nx + nu + 2 + na + 2
@@ -194,9 +195,9 @@ def build_adaptive_oracle(ocp, n_segments, poly_orders, collocation, mid_residua
         n_tl = 2 * nx + 2 + na
 
         def term_build(loc, cst, ph=ph):
-            xf = [loc[a] * (1.0 / sx[a]) for a in range(nx)]
-            a_ = [loc[2 * nx + 2 + c] * (1.0 / sa[c]) for c in range(na)]
-            x0 = [loc[nx + 1 + a] * (1.0 / sx[a]) for a in range(nx)]
+            xf = symvec([loc[a] * (1.0 / sx[a]) for a in range(nx)])
+            a_ = symvec([loc[2 * nx + 2 + c] * (1.0 / sa[c]) for c in range(na)])
+            x0 = symvec([loc[nx + 1 + a] * (1.0 / sx[a]) for a in range(nx)])
             tf, t0 = loc[nx] / st, loc[2 * nx + 1] / st
             out = [o.get_terminal_costs(ph)(xf, tf, x0, t0, a_)]
             if ntc[ph]:

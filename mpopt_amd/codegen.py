@@ -20,7 +20,7 @@ import hashlib
 
 import numpy as np
 
-from .expr import Tracer
+from .expr import Tracer, symvec
 
 # column kinds of a node row / terminal variable kinds (must match mpx.h)
 COL_X, COL_U, COL_T0, COL_TF, COL_A = 0, 1, 2, 3, 4
@@ -56,9 +56,9 @@ class PhaseProgram:
         As = [tr.var(f"As[{c}]") for c in range(na)]
         t0v, tfv = tr.var("t0v"), tr.var("tfv")
         kap, th, W = tr.var("kap"), tr.var("th"), tr.var("W")
-        x = [Xs[a] * (1.0 / sx[a]) for a in range(nx)]
-        u = [Us[b] * (1.0 / su[b]) for b in range(nu)]
-        a_ = [As[c] * (1.0 / sa[c]) for c in range(na)]
+        x = symvec([Xs[a] * (1.0 / sx[a]) for a in range(nx)])
+        u = symvec([Us[b] * (1.0 / su[b]) for b in range(nu)])
+        a_ = symvec([As[c] * (1.0 / sa[c]) for c in range(na)])
         t0, tf = t0v / st, tfv / st
         dt = tf - t0
         h = dt * kap
@@ -119,8 +119,8 @@ class PhaseProgram:
         # ---- terminal program --------------------------------------------------------
         XF = [tr.var(f"XF[{a}]") for a in range(nx)]
         X0 = [tr.var(f"X0[{a}]") for a in range(nx)]
-        xf = [XF[a] * (1.0 / sx[a]) for a in range(nx)]
-        x0 = [X0[a] * (1.0 / sx[a]) for a in range(nx)]
+        xf = symvec([XF[a] * (1.0 / sx[a]) for a in range(nx)])
+        x0 = symvec([X0[a] * (1.0 / sx[a]) for a in range(nx)])
         self.mayer = tr.wrap(ocp.get_terminal_costs(phase)(xf, tf, x0, t0, a_))
         if ocp.has_terminal_constraints(phase):
             self.tc = [tr.wrap(v) for v in _as_list(ocp.get_terminal_constraints(phase)(xf, tf, x0, t0, a_))]

@@ -516,6 +516,16 @@ _UFUNC_OPERATOR = {np.add: operator.add, np.subtract: operator.sub, np.multiply:
 _UFUNC_BINARY = {np.arctan2: "atan2", np.maximum: "fmax", np.minimum: "fmin", np.fmax: "fmax", np.fmin: "fmin"}
 
 
+def symvec(items):
+    """Vector of traced values handed to the user callables: a 1-D numpy object array, so that the statements the
+    reference's examples apply to CasADi column vectors work unchanged -- slices (``x[:3]``), ``scalar * x[3:6]``,
+    ``x[-1]``, ``len(x)``, numpy functions."""
+    out = np.empty(len(items), dtype=object)
+    for k, v in enumerate(items):
+        out[k] = v
+    return out
+
+
 def _math_fn(op, npfn):
     def f(x):
         if isinstance(x, Expr):
@@ -575,11 +585,14 @@ class _Math:
 
     @staticmethod
     def vertcat(*xs):
-        """ca.vertcat of scalars / lists -> a flat Python list (what the OCP callables return)."""
+        """ca.vertcat of scalars / vectors -> a flat numpy vector (float, or object for traced / symbolic entries), so that
+        ``scalar * vertcat(...)`` and indexing behave as on a CasADi column."""
         out = []
         for x in xs:
-            out += list(x) if isinstance(x, (list, tuple, np.ndarray)) else [x]
-        return out
+            out += list(np.asarray(x, dtype=object).reshape(-1)) if isinstance(x, (list, tuple, np.ndarray)) else [x]
+        if all(isinstance(v, (numbers.Real, np.floating, np.integer)) for v in out):
+            return np.array(out, dtype=float)
+        return symvec(out)  # traced (or sympy) entries: an object vector, arithmetic is element-wise
 
     @staticmethod
     def sumsqr(xs):

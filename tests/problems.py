@@ -270,8 +270,8 @@ def ascent_numpy_style(mp, fn=None, use_numpy=True):
 
     def dynamics(x, u, t):
         r, v, m = x[0:3], x[3:6], x[6]
-        if use_numpy:
-            r, v, uu = np.array(r), np.array(v), np.array(u)
+        if use_numpy:  # slices of the state vector are vectors: scalar * r, r + v, np.dot(r, r) work as on CasADi columns
+            uu = u
             rn = sqrt(np.dot(r, r))
             vn = sqrt(np.dot(v, v) + 1e-6)
             drag = -0.5 * cd_a * exp(-(rn - Re) / h0) * vn * v
@@ -296,4 +296,49 @@ def ascent_numpy_style(mp, fn=None, use_numpy=True):
     ocp.lbx[0][6] = 0.1
     ocp.lbtf[0], ocp.ubtf[0] = 0.5, 2.0
     ocp.tf0[0] = 1.0
+    return ocp
+
+
+def staged_ascent(mp, fn):
+    """Two-stage ascent written with the constructs of the reference's flagship example (examples/Multi-phase/
+    multistage_launch_vehicle.py:70-150): slices of the state (``x[:3]``), ``vertcat`` of symbols, scalar * vector products
+    indexed afterwards, one dynamics function specialised per phase through default arguments, ``xf[-1]``."""
+    ocp = mp.OCP(n_states=7, n_controls=3, n_phases=2)
+    mu, Re, omega, rho0, h_scale, sa_cd = 1.0, 1.0, 0.07, 1.2, 0.08, 0.4
+    thrust, mdot = [0.9, 0.5], [0.25, 0.12]
+
+    def dynamics(x, u, t, param=0, T=0.0, md=0.0):
+        r, v, m = x[:3], x[3:6], x[6]
+        r_mag = fn.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2])
+        v_rel = fn.vertcat(v[0] + r[1] * omega, v[1] - r[0] * omega, v[2])
+        v_rel_mag = fn.sqrt(v_rel[0] * v_rel[0] + v_rel[1] * v_rel[1] + v_rel[2] * v_rel[2] + 1e-8)
+        rho = rho0 * fn.exp(-(r_mag - Re) / h_scale)
+        D = -rho / (2 * m) * sa_cd * v_rel_mag * v_rel
+        g = -mu / (r_mag * r_mag * r_mag) * r
+        return [x[3], x[4], x[5], T / m * u[0] + param * D[0] + g[0], T / m * u[1] + param * D[1] + g[1],
+                T / m * u[2] + param * D[2] + g[2], -md]
+
+    ocp.dynamics = [lambda x, u, t: dynamics(x, u, t, param=1, T=thrust[0], md=mdot[0]),
+                    lambda x, u, t: dynamics(x, u, t, param=1, T=thrust[1], md=mdot[1])]
+    path = lambda x, u, t: [u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - 1, -u[0] * u[0] - u[1] * u[1] - u[2] * u[2] + 1,
+                            -fn.sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / Re + 1]
+    ocp.path_constraints = [path] * 2
+    ocp.terminal_costs[1] = lambda xf, tf, x0, t0: -xf[-1]
+
+    def terminal_constraints1(x, t, x0, t0):
+        h = fn.vertcat(x[1] * x[5] - x[4] * x[2], x[3] * x[2] - x[0] * x[5], x[0] * x[4] - x[1] * x[3])  # r x v
+        return [h[0] * h[0] + h[1] * h[1] + h[2] * h[2] - 1.3, x[0] * x[3] + x[1] * x[4] + x[2] * x[5]]
+
+    ocp.terminal_constraints[1] = terminal_constraints1
+    ocp.x00 = np.array([[1.0, 0.0, 0.02, 0.0, 0.07, 0.0, 1.0], [0.95, 0.4, 0.05, -0.3, 0.8, 0.05, 0.55]])
+    ocp.xf0 = np.array([[0.95, 0.4, 0.05, -0.3, 0.8, 0.05, 0.6], [0.2, 1.1, 0.1, -1.0, 0.2, 0.0, 0.3]])
+    ocp.u00 = np.array([[1, 0, 0], [0, 1, 0]])
+    ocp.uf0 = np.array([[0, 1, 0], [0, 1, 0]])
+    ocp.t00, ocp.tf0 = np.array([[0.0], [1.5]]), np.array([[1.5], [3.5]])
+    ocp.lbu, ocp.ubu = np.array([[-1.0] * 3] * 2), np.array([[1.0] * 3] * 2)
+    ocp.lbtf, ocp.ubtf = np.array([[1.5], [3.0]]), np.array([[1.5], [4.0]])
+    ocp.lbt0, ocp.ubt0 = np.array([[0.0], [1.5]]), np.array([[0.0], [1.5]])
+    ocp.lbe, ocp.ube = np.array([[0, 0, 0, 0, 0, 0, -0.05]]), np.array([[0, 0, 0, 0, 0, 0, -0.05]])  # stage mass drop
+    ocp.scale_x = np.array([1.0, 1.0, 1.0, 2.0, 2.0, 2.0, 1.5])
+    ocp.validate()
     return ocp

@@ -376,6 +376,52 @@ def test_contexts_do_not_leak_device_memory():
     assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 8 create/destroy cycles"
 
 
+def _fd_consistency(o, z, p, lam, sig, seed=5, ncols=12):
+    """grad_f / jac_g against central differences of f / g, hess_l against differences of the Lagrangian gradient."""
+    a = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], z, p, lam_g=lam, sigma=sig)
+    jr, jc = o.jac_pattern()
+    hr, hc = o.hess_pattern()
+    J = np.zeros((o.n_g, o.n_z))
+    J[jr, jc] = a["jac_g"]
+    H = np.zeros((o.n_z, o.n_z))
+    H[hr, hc] = a["hess_l"]
+    H = H + np.triu(H, 1).T
+    cols = np.random.default_rng(seed).choice(o.n_z, ncols, replace=False)
+    eps = 1e-6
+    Zp = np.stack([z + eps * np.eye(o.n_z)[c] for c in cols] + [z - eps * np.eye(o.n_z)[c] for c in cols])
+    q = o.eval(["f", "g", "grad_f", "jac_g"], Zp, p)
+    k = len(cols)
+    assert np.abs((q["f"][:k] - q["f"][k:]) / (2 * eps) - a["grad_f"][cols]).max() < 1e-6 * max(1.0, np.abs(a["grad_f"]).max())
+    assert np.abs((q["g"][:k] - q["g"][k:]).T / (2 * eps) - J[:, cols]).max() < 1e-6 * max(1.0, np.abs(J).max())
+    gl = np.zeros((2 * k, o.n_z))
+    for i in range(2 * k):
+        Jb = np.zeros((o.n_g, o.n_z))
+        Jb[jr, jc] = q["jac_g"][i]
+        gl[i] = sig * q["grad_f"][i] + lam @ Jb
+    assert np.abs((gl[:k] - gl[k:]).T / (2 * eps) - H[:, cols]).max() < 1e-5 * max(1.0, np.abs(H).max())
+    return a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_launch_vehicle_style_problem_on_gpu(adaptive):
+    """The constructs of the reference's flagship example (state slices, vertcat, scalar * vector, per-phase default
+    arguments, two linked phases with a mass drop): traced, compiled and consistent on the GPU, for the fixed-width and the
+    widths-as-variables transcription."""
+    import mpopt_amd as M
+    from mpopt_amd import mp
+
+    ocp = problems.staged_ascent(mp, M.math)
+    mpo = (mp.mpopt_adaptive(ocp, 2, [3, 3], "LGR") if adaptive else mp.mpopt(ocp, 3, [3, 4, 3], "LGR"))
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    rng = np.random.default_rng(8)
+    z = mpo.initialize_solution() * (1 + 0.02 * rng.uniform(-1, 1, o.n_z)) + 0.01 * rng.uniform(-1, 1, o.n_z)
+    p = None if adaptive else np.concatenate([[0.3, 0.4, 0.3], [0.25, 0.5, 0.25]])
+    a = _fd_consistency(o, z, p, rng.standard_normal(o.n_g), 0.8)
+    assert np.isfinite(a["g"]).all() and len(bounds["lbg"]) == o.n_g
+
+
 @pytest.mark.gpu
 def test_numpy_style_problem_on_gpu():
     """An OCP written with numpy functions on the symbols (the style of the reference's launch-vehicle examples):
