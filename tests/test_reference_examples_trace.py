@@ -1,0 +1,29 @@
+"""Drop-in check against the reference's own example scripts (build container only: /root/reference must exist; skipped on
+the GPU box).  Each script runs with ``mp`` = mpopt_amd.mp and ``ca`` = the mpopt_amd.math spellings until it creates an
+optimizer; the OCP it defined must validate and trace unchanged.  tools/compat_sweep.py does the work."""
+import importlib.util
+import io
+import os
+import contextlib
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/examples"), reason="the reference tree is not mounted")
+
+
+def test_every_reference_example_that_builds_an_optimizer_traces():
+    spec = importlib.util.spec_from_file_location("compat_sweep", os.path.join(ROOT, "tools", "compat_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    with contextlib.redirect_stdout(io.StringIO()):  # the demos print tables
+        spec.loader.exec_module(mod)
+    res = mod.results
+    ok = {k for k, v in res.items() if v.startswith("OK")}
+    failed = {k: v for k, v in res.items() if "failed" in v}
+    # CasADi's Callback / SX demos exercise CasADi itself, not mpopt: the only scripts allowed to fail
+    assert set(failed) <= {"Multi-phase/multistage_launch_vehicle_nlp_options_demo.py", "feature-demos/callback_demo.py",
+                           "feature-demos/mpopt_callback_demo.py"}, failed
+    assert len(ok) >= 16
+    for name in ("Multi-phase/multistage_launch_vehicle.py", "Multi-phase/falcon9_launcher.py", "singlephase/robot_arm.py",
+                 "singlephase/Betts/alpr01_alp_rider.py", "singlephase/dae_vdp.py"):
+        assert name in ok, res.get(name)
