@@ -48,12 +48,44 @@ class InteriorPoint:
         self.crow[self.eq] = np.arange(len(self.eq))
         self.crow[self.iq] = len(self.eq) + np.arange(self.nI)
         self.n_eval = {"f": 0, "g": 0, "grad_f": 0, "jac_g": 0, "hess_l": 0}
+        self.fs, self.gs = 1.0, np.ones(m)
 
     # -- oracle access -------------------------------------------------------------------------------
     def _ev(self, what, x, **kw):
+        """Oracle call in the SCALED problem (IPOPT's gradient-based scaling: objective factor fs, constraint-row factors gs)."""
         for w in what:
             self.n_eval[w] += 1
-        return self.o.eval(what, x, self.p, pinned=False, **kw)
+        if "lam_g" in kw:
+            kw = dict(kw, lam_g=np.asarray(kw["lam_g"]) * self.gs, sigma=np.asarray(kw["sigma"]) * self.fs)
+        r = self.o.eval(what, x, self.p, pinned=False, **kw)
+        out = {}
+        for k, v in r.items():
+            if k == "f":
+                out[k] = v * self.fs
+            elif k == "grad_f":
+                out[k] = v * self.fs
+            elif k == "g":
+                out[k] = v * self.gs
+            elif k == "jac_g":
+                out[k] = v * self.gs[self.jr]
+            else:
+                out[k] = v
+        return out
+
+    def _setup_scaling(self, x):
+        """fs = min(1, 100 / max|grad f|), gs_i = min(1, 100 / max_j |J_ij|) at the starting point (nlp_scaling_max_gradient)."""
+        self.fs, self.gs = 1.0, np.ones(self.m)
+        r = self.o.eval(["grad_f", "jac_g"], x, self.p)
+        gmax = np.abs(r["grad_f"]).max() if self.n else 0.0
+        fs = min(1.0, 100.0 / gmax) if gmax > 0 else 1.0
+        rowmax = np.zeros(self.m)
+        np.maximum.at(rowmax, self.jr, np.abs(r["jac_g"]))
+        gs = np.where(rowmax > 100.0, 100.0 / np.maximum(rowmax, 1e-300), 1.0)
+        self.fs, self.gs = max(fs, 1e-8), np.maximum(gs, 1e-8)
+        # rescale the row bounds that were split in __init__
+        self.b_eq = self.b_eq * self.gs[self.eq]
+        self.l[self.n:] = self.l[self.n:] * self.gs[self.iq]
+        self.u[self.n:] = self.u[self.n:] * self.gs[self.iq]
 
     def _c(self, g, s):
         return np.concatenate([g[self.eq] - self.b_eq, g[self.iq] - s])
@@ -113,6 +145,8 @@ class InteriorPoint:
         fx = self.fixed[:n]
         x[fx] = l[:n][fx]
         x[~fx] = push(x[~fx], l[:n][~fx], u[:n][~fx])
+        self._setup_scaling(x)
+        l, u = self.l, self.u
         r = self._ev(["f", "g", "grad_f", "jac_g"], x)
         s = r["g"][self.iq].copy()
         fs = self.fixed[n:]
@@ -120,7 +154,10 @@ class InteriorPoint:
         s[~fs] = push(s[~fs], l[n:][~fs], u[n:][~fs])
         y = np.concatenate([x, s])
         zl, zu = np.where(has_l, 1.0, 0.0), np.where(has_u, 1.0, 0.0)
-        lam = np.zeros(m) if lam0 is None else np.concatenate([np.asarray(lam0, float)[self.eq], np.asarray(lam0, float)[self.iq]])
+        lam = np.zeros(m)
+        if lam0 is not None:  # multipliers of the unscaled problem -> scaled
+            l0 = np.asarray(lam0, float) * self.fs / self.gs
+            lam = np.concatenate([l0[self.eq], l0[self.iq]])
         mu, dw_last = 0.1, 0.0
         filt, filt_mu = [], None
         th_init = float(np.abs(self._c(r["g"], y[n:])).sum())
@@ -312,6 +349,6 @@ class InteriorPoint:
             gradL = np.concatenate([gf, np.zeros(nI)]) + A.T @ lam - zl + zu
             if kkt_error(0.0, gradL, self._c(g, y[n:])) <= self.acc_tol:
                 status = "Solved_To_Acceptable_Level"
-        lam_g = self._lam_g(lam)
-        return {"x": y[:n].copy(), "f": float(r["f"]), "g": r["g"].copy(), "lam_g": lam_g, "lam_x": (zu - zl)[:n], "status": status,
+        lam_g = self._lam_g(lam) * self.gs / self.fs  # back to the unscaled problem
+        return {"x": y[:n].copy(), "f": float(r["f"]) / self.fs, "g": r["g"] / self.gs, "lam_g": lam_g, "lam_x": (zu - zl)[:n] / self.fs, "status": status,
                 "iter_count": it, "success": status in ("Solve_Succeeded", "Solved_To_Acceptable_Level")}
