@@ -38,6 +38,13 @@ def lib():
         L.orc_eval.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 8
         L.orc_eval_many_omp.restype = ctypes.c_int
         L.orc_eval_many_omp.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_hess_capacity.restype = ctypes.c_int64
+        L.orc_hess_capacity.argtypes = [ctypes.c_void_p]
+        L.orc_hess.restype = ctypes.c_int64
+        L.orc_hess.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double] + [ctypes.c_void_p] * 4
+        L.orc_ipopt_mix.restype = None
+        L.orc_ipopt_mix.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_double] + [ctypes.c_void_p] * 7
         L.orc_eval_many.restype = None
         L.orc_eval_many.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 6
         _lib = L
@@ -82,6 +89,40 @@ class COracle:
                        cols.ctypes.data, vals.ctypes.data)
         assert n == self.nnz, (n, self.nnz)
         return dict(f=f[0], g=g, grad_f=grad, jac_row=rows, jac_col=cols, jac_val=vals)
+
+    def hess(self, z, p, sigma, lam_g):
+        """hess_l as COO triplets of the upper triangle (duplicates add up): dict hess_row, hess_col, hess_val."""
+        L = lib()
+        z, p, lam = np.ascontiguousarray(z, float), np.ascontiguousarray(p, float), np.ascontiguousarray(lam_g, float)
+        cap = L.orc_hess_capacity(self._h)
+        rows, cols, vals = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap)
+        n = L.orc_hess(self._h, z.ctypes.data, p.ctypes.data, float(sigma), lam.ctypes.data, rows.ctypes.data, cols.ctypes.data,
+                       vals.ctypes.data)
+        return dict(hess_row=rows[:n].copy(), hess_col=cols[:n].copy(), hess_val=vals[:n].copy())
+
+    def hess_matrix(self, z, p, sigma, lam_g):
+        """Upper triangle of hess_l as a scipy CSR matrix (duplicates summed)."""
+        import scipy.sparse as sp
+
+        h = self.hess(z, p, sigma, lam_g)
+        return sp.coo_matrix((h["hess_val"], (h["hess_row"], h["hess_col"])), shape=(self.n_z, self.n_z)).tocsr()
+
+    def time_ipopt_mix(self, Z, p, sigma, lam_g, reps, n_g_calls=1):
+        """Wall seconds for ``reps`` passes over the points Z of: n_g_calls x nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l
+        (separate functions, one core)."""
+        import time
+
+        L = lib()
+        Z, p, lam = np.ascontiguousarray(Z, float), np.ascontiguousarray(p, float), np.ascontiguousarray(lam_g, float)
+        g, grad, vals = np.zeros(self.n_g), np.zeros(self.n_z), np.zeros(self.nnz)
+        cap = L.orc_hess_capacity(self._h)
+        hr, hc, hv = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap)
+        args = (Z.ctypes.data, p.ctypes.data, float(sigma), lam.ctypes.data, g.ctypes.data, grad.ctypes.data, vals.ctypes.data,
+                hr.ctypes.data, hc.ctypes.data, hv.ctypes.data)
+        L.orc_ipopt_mix(self._h, Z.shape[0], 1, int(n_g_calls), *args)
+        t = time.perf_counter()
+        L.orc_ipopt_mix(self._h, Z.shape[0], int(reps), int(n_g_calls), *args)
+        return time.perf_counter() - t
 
     def time_many(self, Z, p, reps):
         """Wall seconds for ``reps`` passes of f+g+grad_f+jac_g over the points Z (values only)."""

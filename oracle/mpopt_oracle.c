@@ -3,7 +3,9 @@
  * Scalar, single-threaded restatement of the reference's collocation hot path
  * (/root/reference/mpopt/mpopt.py) for the benchmark OCPs of BASELINE.json:
  *     f, g, grad_f, jac_g   = what CasADi's nlp_f / nlp_g / nlp_grad_f / nlp_jac_g compute for the
- *                             NLP built by mpopt.create_nlp (mpopt.py:574-639, 757).
+ *                             NLP built by mpopt.create_nlp (mpopt.py:574-639, 757);
+ *     hess_l                = upper triangle of the Hessian of  sigma*f + lam_g^T g  (CasADi's nlp_hess_l,
+ *                             derived inside ca.nlpsol at mpopt.py:757), orc_hess below.
  * Used (a) by tests/ as a second, independent checker of the HIP kernels and of the numpy oracle,
  * (b) by bench.py as the `cpu_baseline` ("kind": "port") timed on the GPU box's host cores.
  * Never linked into or called from the product (mpopt_amd/).
@@ -17,9 +19,10 @@
  * (mpopt.py:3842-3847), w by polyint (mpopt.py:3879-3880).  Node sets are an input (the caller
  * passes scipy's, as the reference does at mpopt.py:4220, 4246).
  *
- * The OCP functions and their first derivatives are hand-written below (independent of the
+ * The OCP functions and their first and second derivatives are hand-written below (independent of the
  * product's tracer); the chain rule through scaling, segment step h and node time t is done here
- * in the unscaled formulation (mpopt.py:175-206).
+ * in the unscaled formulation (mpopt.py:175-206).  Structural masks are hand-written too; none of the
+ * six problems depends on t explicitly, so the (t0, tf) border of the Hessian comes from h only.
  */
 #include <math.h>
 #include <stdint.h>
@@ -43,6 +46,16 @@ typedef struct {
   void (*term_d)(const double* xf, double tf, const double* x0, double t0, const double* a, double* dM, double* dtc);
   const unsigned char* m_M;
   const unsigned char* m_tc;
+  /* second derivatives, weighted: Hpsi[nv][nv] += wL * d2L + sum_c wd[c] * d2dyn_c ; Hchi[nv][nv] += sum_j wc[j] * d2pc_j
+   * (arrays arrive zeroed); masks: m1_L[nv] (dL), m2_psi / m2_chi [nv][nv] (union over the terms) */
+  void (*node_dd)(const double* x, const double* u, double t, const double* a, const double* wd, const double* wc, double wL,
+                  double* Hpsi, double* Hchi);
+  const unsigned char* m1_L;
+  const unsigned char* m2_psi;
+  const unsigned char* m2_chi;
+  /* Hw[ntv][ntv] += wM * d2M + sum_j wt[j] * d2tc_j ; mask m2_term[ntv][ntv] */
+  void (*term_dd)(const double* xf, double tf, const double* x0, double t0, const double* a, double wM, const double* wt, double* Hw);
+  const unsigned char* m2_term;
 } ocp_fns;
 
 /* ------------------------------------------------------------------ problems ---------------- */
@@ -177,13 +190,82 @@ static void sw_term1_d(const double* xf, double tf, const double* x0, double t0,
 }
 static const unsigned char sw_mM1[6] = {1, 1, 0, 0, 0, 0};
 
+
+/* ---- second derivatives (weighted sums, see ocp_fns) ---- */
+static void zero_node_dd(const double* x, const double* u, double t, const double* a, const double* wd, const double* wc, double wL,
+                         double* Hp, double* Hc) {}
+static void zero_term_dd(const double* xf, double tf, const double* x0, double t0, const double* a, double wM, const double* wt, double* Hw) {}
+/* moon lander: dyn and L are linear; L = u */
+static const unsigned char ml_m1L[4] = {0, 0, 1, 0};
+/* Van der Pol (nv = 4: x0 x1 u t): dyn0 = (1 - x1^2) x0 - x1 + u ; L = x0^2 + x1^2 + u^2 */
+static void vdp_node_dd(const double* x, const double* u, double t, const double* a, const double* wd, const double* wc, double wL,
+                        double* Hp, double* Hc) {
+  const int nv = 4;
+  Hp[0 * nv + 1] += wd[0] * (-2 * x[1]);
+  Hp[1 * nv + 0] += wd[0] * (-2 * x[1]);
+  Hp[1 * nv + 1] += wd[0] * (-2 * x[0]);
+  Hp[0 * nv + 0] += wL * 2, Hp[1 * nv + 1] += wL * 2, Hp[2 * nv + 2] += wL * 2;
+}
+static const unsigned char vdp_m1L[4] = {1, 1, 1, 0};
+static const unsigned char vdp_m2psi[16] = {1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0};
+/* dae_vdp (nv = 5: x0 x1 u t a0): same dyn and L, path row linear */
+static void dvdp_node_dd(const double* x, const double* u, double t, const double* a, const double* wd, const double* wc, double wL,
+                         double* Hp, double* Hc) {
+  const int nv = 5;
+  Hp[0 * nv + 1] += wd[0] * (-2 * x[1]);
+  Hp[1 * nv + 0] += wd[0] * (-2 * x[1]);
+  Hp[1 * nv + 1] += wd[0] * (-2 * x[0]);
+  Hp[0 * nv + 0] += wL * 2, Hp[1 * nv + 1] += wL * 2, Hp[2 * nv + 2] += wL * 2;
+}
+static const unsigned char dvdp_m1L[5] = {1, 1, 1, 0, 0};
+static const unsigned char dvdp_m2psi[25] = {1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+/* hypersensitive (nv = 3: x u t): dyn = -x^3 + u ; L = (x^2 + u^2)/2 */
+static void hs_node_dd(const double* x, const double* u, double t, const double* a, const double* wd, const double* wc, double wL,
+                       double* Hp, double* Hc) {
+  const int nv = 3;
+  Hp[0 * nv + 0] += wd[0] * (-6 * x[0]) + wL;
+  Hp[1 * nv + 1] += wL;
+}
+static const unsigned char hs_m1L[3] = {1, 1, 0};
+static const unsigned char hs_m2psi[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
+/* Schwartz (nv = 4: x0 x1 u t): dyn1 = u - 0.1 (1 + 2 x0^2) x1 ; phase 0 path row 1 - 9 (x0-1)^2 - (x1-0.4)^2/0.09 */
+static void sw_node0_dd(const double* x, const double* u, double t, const double* a, const double* wd, const double* wc, double wL,
+                        double* Hp, double* Hc) {
+  const int nv = 4;
+  Hp[0 * nv + 0] += wd[1] * (-0.1 * 4.0 * x[1]);
+  Hp[0 * nv + 1] += wd[1] * (-0.1 * 4.0 * x[0]);
+  Hp[1 * nv + 0] += wd[1] * (-0.1 * 4.0 * x[0]);
+  Hc[0 * nv + 0] += wc[0] * (-18.0);
+  Hc[1 * nv + 1] += wc[0] * (-2.0 / (0.3 * 0.3));
+}
+static void sw_node1_dd(const double* x, const double* u, double t, const double* a, const double* wd, const double* wc, double wL,
+                        double* Hp, double* Hc) {
+  const int nv = 4;
+  Hp[0 * nv + 0] += wd[1] * (-0.1 * 4.0 * x[1]);
+  Hp[0 * nv + 1] += wd[1] * (-0.1 * 4.0 * x[0]);
+  Hp[1 * nv + 0] += wd[1] * (-0.1 * 4.0 * x[0]);
+}
+static const unsigned char sw_m2psi[16] = {1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static const unsigned char sw_m2chi[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+/* Schwartz phase 1 Mayer term 5 (xf0^2 + xf1^2); ntv = 6: xf0 xf1 tf x00 x01 t0 */
+static void sw_term1_dd(const double* xf, double tf, const double* x0, double t0, const double* a, double wM, const double* wt, double* Hw) {
+  Hw[0 * 6 + 0] += wM * 10, Hw[1 * 6 + 1] += wM * 10;
+}
+static const unsigned char sw_m2term1[36] = {1, 0, 0, 0, 0, 0, 0, 1};
+
 static const ocp_fns PROBLEMS[] = {
-    {"moon_lander", 2, 1, 0, 0, 2, ml_node, ml_node_d, ml_mdyn, zeros_mask, ml_term, ml_term_d, ml_mM, ml_mtc},
-    {"van_der_pol", 2, 1, 0, 0, 0, vdp_node, vdp_node_d, vdp_mdyn, zeros_mask, none_term, none_term_d, zeros_mask, zeros_mask},
-    {"dae_vdp", 2, 1, 1, 1, 0, dvdp_node, dvdp_node_d, dvdp_mdyn, dvdp_mpc, none_term, none_term_d, zeros_mask, zeros_mask},
-    {"hyper_sensitive", 1, 1, 0, 0, 1, hs_node, hs_node_d, hs_mdyn, zeros_mask, hs_term, hs_term_d, zeros_mask, hs_mtc},
-    {"schwartz_phase0", 2, 1, 0, 1, 0, sw_node0, sw_node0_d, sw_mdyn, sw_mpc, none_term, none_term_d, zeros_mask, zeros_mask},
-    {"schwartz_phase1", 2, 1, 0, 0, 0, sw_node1, sw_node1_d, sw_mdyn, zeros_mask, sw_term1, sw_term1_d, sw_mM1, zeros_mask},
+    {"moon_lander", 2, 1, 0, 0, 2, ml_node, ml_node_d, ml_mdyn, zeros_mask, ml_term, ml_term_d, ml_mM, ml_mtc,
+     zero_node_dd, ml_m1L, zeros_mask, zeros_mask, zero_term_dd, zeros_mask},
+    {"van_der_pol", 2, 1, 0, 0, 0, vdp_node, vdp_node_d, vdp_mdyn, zeros_mask, none_term, none_term_d, zeros_mask, zeros_mask,
+     vdp_node_dd, vdp_m1L, vdp_m2psi, zeros_mask, zero_term_dd, zeros_mask},
+    {"dae_vdp", 2, 1, 1, 1, 0, dvdp_node, dvdp_node_d, dvdp_mdyn, dvdp_mpc, none_term, none_term_d, zeros_mask, zeros_mask,
+     dvdp_node_dd, dvdp_m1L, dvdp_m2psi, zeros_mask, zero_term_dd, zeros_mask},
+    {"hyper_sensitive", 1, 1, 0, 0, 1, hs_node, hs_node_d, hs_mdyn, zeros_mask, hs_term, hs_term_d, zeros_mask, hs_mtc,
+     hs_node_dd, hs_m1L, hs_m2psi, zeros_mask, zero_term_dd, zeros_mask},
+    {"schwartz_phase0", 2, 1, 0, 1, 0, sw_node0, sw_node0_d, sw_mdyn, sw_mpc, none_term, none_term_d, zeros_mask, zeros_mask,
+     sw_node0_dd, zeros_mask, sw_m2psi, sw_m2chi, zero_term_dd, zeros_mask},
+    {"schwartz_phase1", 2, 1, 0, 0, 0, sw_node1, sw_node1_d, sw_mdyn, zeros_mask, sw_term1, sw_term1_d, sw_mM1, zeros_mask,
+     sw_node1_dd, zeros_mask, sw_m2psi, zeros_mask, sw_term1_dd, sw_m2term1},
 };
 #define N_PROBLEMS ((int)(sizeof(PROBLEMS) / sizeof(PROBLEMS[0])))
 
@@ -377,7 +459,8 @@ int64_t orc_eval(const orc* o, const double* z, const double* p, double* f_out, 
   do {                                \
     if (rows) rows[q] = (int32_t)(r); \
     if (cols) cols[q] = (int32_t)(c); \
-    vals[q++] = (v);                  \
+    if (vals) vals[q] = (v);          \
+    ++q;                              \
   } while (0)
   for (int ph = 0; ph < o->n_ph; ++ph) {
     const ocp_fns* F = o->fn[ph];
@@ -410,13 +493,14 @@ int64_t orc_eval(const orc* o, const double* z, const double* p, double* f_out, 
       for (int c = 0; c < nx; ++c) x[c] = X[(int64_t)c * N + i] / o->sx[c]; /* mpopt.py:196 */
       for (int c = 0; c < nu; ++c) u[c] = U[(int64_t)c * N + i] / o->su[c]; /* mpopt.py:197 */
       F->node(x, u, t, a, dyn, pc, &L);
-      F->node_d(x, u, t, a, ddyn, dpc, dL);
+      if (grad || vals) F->node_d(x, u, t, a, ddyn, dpc, dL);
       for (int c = 0; c < nx; ++c) { /* defect rows, mpopt.py:201, 227-232 */
         const int64_t row = o->off_F[ph] + (int64_t)c * N + i;
         double acc = 0;
         for (int j = 0; j <= pdeg; ++j) acc += T->D[k * (pdeg + 1) + j] * X[(int64_t)c * N + st + j];
         const double fi = h * o->sx[c] * dyn[c];
-        g[row] = acc - fi;
+        if (g) g[row] = acc - fi;
+        if (!vals) continue;
         for (int j = 0; j <= pdeg; ++j) {
           double v = T->D[k * (pdeg + 1) + j];
           if (j == k) v -= h * o->sx[c] * ddyn[c * nv + c] / o->sx[c];
@@ -440,7 +524,8 @@ int64_t orc_eval(const orc* o, const double* z, const double* p, double* f_out, 
       }
       for (int j = 0; j < F->nc; ++j) { /* path rows, mpopt.py:204, 255 */
         const int64_t row = o->off_C[ph] + (int64_t)j * N + i;
-        g[row] = pc[j];
+        if (g) g[row] = pc[j];
+        if (!vals) continue;
         for (int v = 0; v < nv; ++v) {
           if (!F->m_pc[j * nv + v]) continue;
           const double d = dpc[j * nv + v];
@@ -475,7 +560,7 @@ int64_t orc_eval(const orc* o, const double* z, const double* p, double* f_out, 
               acc += T->Cmid[m * (pdeg + 1) + j] * U[(int64_t)b * N + st + j];
               EMIT(row, zb + (int64_t)(nx + b) * N + st + j, T->Cmid[m * (pdeg + 1) + j]);
             }
-            g[row] = acc;
+            if (g) g[row] = acc;
           }
         }
     }
@@ -483,11 +568,12 @@ int64_t orc_eval(const orc* o, const double* z, const double* p, double* f_out, 
     double xf[MAXV], x0[MAXV], M, tc[MAXV], dM[2 * MAXV + 2], dtc[MAXV * (2 * MAXV + 2)];
     for (int c = 0; c < nx; ++c) xf[c] = X[(int64_t)c * N + N - 1] / o->sx[c], x0[c] = X[(int64_t)c * N] / o->sx[c];
     F->term(xf, tf, x0, t0, a, &M, tc);
-    F->term_d(xf, tf, x0, t0, a, dM, dtc);
+    if (grad || vals) F->term_d(xf, tf, x0, t0, a, dM, dtc);
     ftot += M;
     for (int j = 0; j < F->ntc; ++j) {
       const int64_t row = o->off_TC[ph] + j;
-      g[row] = tc[j];
+      if (g) g[row] = tc[j];
+      if (!vals) continue;
       for (int v = 0; v < ntv; ++v) {
         if (!F->m_tc[j * ntv + v]) continue;
         const double d = dtc[j * ntv + v];
@@ -526,7 +612,7 @@ int64_t orc_eval(const orc* o, const double* z, const double* p, double* f_out, 
             int comp = blk == 0 ? c : nx + c;
             cj = zj + (int64_t)comp * N, ci = zi + (int64_t)comp * N + N - 1;
           }
-          g[row] = z[cj] - z[ci];
+          if (g) g[row] = z[cj] - z[ci];
           EMIT(row, cj, 1.0);
           EMIT(row, ci, -1.0);
           ++row;
@@ -536,6 +622,157 @@ int64_t orc_eval(const orc* o, const double* z, const double* p, double* f_out, 
   *f_out = ftot;
   return q;
 #undef EMIT
+}
+
+
+/* Upper bound on the number of triplets orc_hess emits. */
+int64_t orc_hess_capacity(const orc* o) {
+  const int ny = o->nx + o->nu + 2 + o->na, ntv = 2 * o->nx + 2 + o->na;
+  return (int64_t)o->n_ph * ((int64_t)o->N * ny * (ny + 1) / 2 + (int64_t)ntv * (ntv + 1) / 2 + (int64_t)(2 + o->na) * (3 + o->na) / 2);
+}
+
+/* hess_l: upper triangle (row <= col) of the Hessian of  sigma*f + lam_g^T g  with respect to z, as COO triplets
+ * (CasADi's nlp_hess_l, derived by ca.nlpsol at mpopt.py:757 from the dict built at mpopt.py:631).  A position may be
+ * emitted more than once (a node entry and a terminal entry of the last node): duplicates add up.  Only structural
+ * entries are emitted (masks of the problem).  Per node, with v = (x, u, t, a) the unscaled arguments, y = (X_i, U_i,
+ * t0_var, tf_var, A) the NLP variables they come from (v linear in y, mpopt.py:175-177, 196-198) and
+ *     phi_i = h * psi(v) + chi(v),   psi = sigma W_i L - sum_c lam_F[c] Sx_c dyn_c,   chi = sum_j lam_C[j] path_j,
+ * h = (tf - t0) kap linear in y:   d2 phi = Jv^T (h psi'' + chi'') Jv + dh (Jv^T psi')^T + (Jv^T psi') dh^T.
+ * Defect D.X terms, mid-point control rows and phase events are linear in z: no contribution.  Returns the count. */
+int64_t orc_hess(const orc* o, const double* z, const double* p, double sigma, const double* lam, int32_t* rows, int32_t* cols,
+                 double* vals) {
+  const int N = o->N, nx = o->nx, nu = o->nu, na = o->na, nv = nx + nu + 1 + na, ntv = 2 * nx + 2 + na, ny = nx + nu + 2 + na;
+  const int it = nx + nu; /* index of t in v; y: [0,nx) X, [nx,nx+nu) U, it -> t0, it+1 -> tf, it+2.. A */
+  int64_t q = 0;
+  for (int ph = 0; ph < o->n_ph; ++ph) {
+    const ocp_fns* F = o->fn[ph];
+    const double* zp = z + ph * o->n_zp;
+    const double* X = zp;
+    const double* U = zp + (int64_t)nx * N;
+    const int64_t zt = (int64_t)(nx + nu) * N, zb = ph * o->n_zp;
+    const double t0 = zp[zt] / o->st, tf = zp[zt + 1] / o->st;
+    double a[MAXV];
+    for (int c = 0; c < na; ++c) a[c] = zp[zt + 2 + c] / o->sa[c];
+    const double* w = p + ph * o->S;
+    const double dtau = o->tau1 - o->tau0;
+    double t_seg0 = t0, h = (tf - t0) / dtau * w[0];
+    /* (t0, tf, A) corner: summed over the nodes, emitted once */
+    double corner[MAXV * MAXV] = {0};
+    unsigned char scorner[MAXV * MAXV] = {0};
+    const int ncn = 2 + na;
+    /* structure of one node block (the same for every node) */
+    unsigned char S2[MAXV * MAXV] = {0}, S1[MAXV] = {0};
+    for (int r = 0; r < nv; ++r) {
+      S1[r] = F->m1_L[r];
+      for (int c = 0; c < nx; ++c) S1[r] |= F->m_dyn[c * nv + r];
+      for (int s = 0; s < nv; ++s) S2[r * nv + s] = F->m2_psi[r * nv + s] | F->m2_chi[r * nv + s];
+    }
+    for (int i = 0, s = 0; i < N; ++i) {
+      if (o->seg[i] != s) {
+        s = o->seg[i];
+        t_seg0 += h * dtau;
+        h = (tf - t0) / dtau * w[s];
+      }
+      const int pdeg = o->orders[s], k = o->pt[i];
+      const deg_table* T = tab(o, pdeg);
+      const double t = t_seg0 + h * (T->tau[k] - o->tau0);
+      const double theta = (t - t0) / (tf - t0), kap = w[s] / dtau, W = o->compW[i];
+      double x[MAXV], u[MAXV], dyn[MAXV], pc[MAXV], L, ddyn[MAXV * MAXV], dpc[MAXV * MAXV], dL[MAXV];
+      for (int c = 0; c < nx; ++c) x[c] = X[(int64_t)c * N + i] / o->sx[c];
+      for (int c = 0; c < nu; ++c) u[c] = U[(int64_t)c * N + i] / o->su[c];
+      F->node(x, u, t, a, dyn, pc, &L);
+      F->node_d(x, u, t, a, ddyn, dpc, dL);
+      double wd[MAXV], wc[MAXV];
+      for (int c = 0; c < nx; ++c) wd[c] = -lam[o->off_F[ph] + (int64_t)c * N + i] * o->sx[c];
+      for (int j = 0; j < F->nc; ++j) wc[j] = lam[o->off_C[ph] + (int64_t)j * N + i];
+      const double wL = sigma * W;
+      double Hp[MAXV * MAXV] = {0}, Hc[MAXV * MAXV] = {0}, g1[MAXV];
+      F->node_dd(x, u, t, a, wd, wc, wL, Hp, Hc);
+      for (int r = 0; r < nv; ++r) {
+        double v = F->m1_L[r] ? wL * dL[r] : 0.0;
+        for (int c = 0; c < nx; ++c)
+          if (F->m_dyn[c * nv + r]) v += wd[c] * ddyn[c * nv + r];
+        g1[r] = v; /* psi' */
+      }
+      /* Jv: v_r depends on y_m with factor jf; t depends on t0 and tf */
+      double Hy[MAXV * MAXV] = {0};
+      unsigned char Sy[MAXV * MAXV] = {0};
+      double jf[MAXV];
+      for (int r = 0; r < nx; ++r) jf[r] = 1.0 / o->sx[r];
+      for (int r = 0; r < nu; ++r) jf[nx + r] = 1.0 / o->su[r];
+      for (int r = 0; r < na; ++r) jf[it + 1 + r] = 1.0 / o->sa[r];
+      /* map v index r -> list of (y index, factor) */
+      int ymap[MAXV][2], ycnt[MAXV];
+      double yfac[MAXV][2];
+      for (int r = 0; r < nv; ++r) {
+        if (r < it) ymap[r][0] = r, yfac[r][0] = jf[r], ycnt[r] = 1;
+        else if (r == it) {
+          ymap[r][0] = it, yfac[r][0] = (1 - theta) / o->st;
+          ymap[r][1] = it + 1, yfac[r][1] = theta / o->st;
+          ycnt[r] = 2;
+        } else ymap[r][0] = r + 1, yfac[r][0] = jf[r], ycnt[r] = 1;
+      }
+      double gy[MAXV] = {0}; /* Jv^T psi' */
+      unsigned char sgy[MAXV] = {0};
+      for (int r = 0; r < nv; ++r)
+        for (int m = 0; m < ycnt[r]; ++m) gy[ymap[r][m]] += g1[r] * yfac[r][m], sgy[ymap[r][m]] |= S1[r];
+      for (int r = 0; r < nv; ++r)
+        for (int c = 0; c < nv; ++c) {
+          const double v2 = h * Hp[r * nv + c] + Hc[r * nv + c];
+          for (int m = 0; m < ycnt[r]; ++m)
+            for (int n = 0; n < ycnt[c]; ++n) {
+              Hy[ymap[r][m] * ny + ymap[c][n]] += v2 * yfac[r][m] * yfac[c][n];
+              Sy[ymap[r][m] * ny + ymap[c][n]] |= S2[r * nv + c];
+            }
+        }
+      double dh[MAXV] = {0};
+      dh[it] = -kap / o->st, dh[it + 1] = kap / o->st;
+      for (int m = 0; m < ny; ++m)
+        for (int n = 0; n < ny; ++n) {
+          Hy[m * ny + n] += dh[m] * gy[n] + gy[m] * dh[n];
+          Sy[m * ny + n] |= ((m == it || m == it + 1) && sgy[n]) | ((n == it || n == it + 1) && sgy[m]);
+        }
+      /* emit the upper triangle; pairs inside (t0, tf, A) go to the corner */
+      for (int m = 0; m < ny; ++m)
+        for (int n = m; n < ny; ++n) {
+          if (!Sy[m * ny + n]) continue;
+          if (m >= it) {
+            corner[(m - it) * ncn + (n - it)] += Hy[m * ny + n];
+            scorner[(m - it) * ncn + (n - it)] = 1;
+            continue;
+          }
+          const int64_t gm = zb + (int64_t)m * N + i;
+          const int64_t gn = n < it ? zb + (int64_t)n * N + i : zb + zt + (n - it);
+          rows[q] = (int32_t)gm, cols[q] = (int32_t)gn, vals[q++] = Hy[m * ny + n];
+        }
+    }
+    for (int m = 0; m < ncn; ++m)
+      for (int n = m; n < ncn; ++n)
+        if (scorner[m * ncn + n]) rows[q] = (int32_t)(zb + zt + m), cols[q] = (int32_t)(zb + zt + n), vals[q++] = corner[m * ncn + n];
+    /* terminal cost / constraints: w = (xf, tf, x0, t0, a), each a scaled NLP variable (mpopt.py:277-298) */
+    double xf[MAXV], x0[MAXV], wt[MAXV], Hw[4 * MAXV * MAXV] = {0};
+    for (int c = 0; c < nx; ++c) xf[c] = X[(int64_t)c * N + N - 1] / o->sx[c], x0[c] = X[(int64_t)c * N] / o->sx[c];
+    for (int j = 0; j < F->ntc; ++j) wt[j] = lam[o->off_TC[ph] + j];
+    F->term_dd(xf, tf, x0, t0, a, sigma, wt, Hw);
+    int64_t gidx[2 * MAXV + 2];
+    double gfac[2 * MAXV + 2];
+    for (int v = 0; v < ntv; ++v) {
+      if (v < nx) gidx[v] = zb + (int64_t)v * N + N - 1, gfac[v] = 1.0 / o->sx[v];
+      else if (v == nx) gidx[v] = zb + zt + 1, gfac[v] = 1.0 / o->st;
+      else if (v < 2 * nx + 1) gidx[v] = zb + (int64_t)(v - nx - 1) * N, gfac[v] = 1.0 / o->sx[v - nx - 1];
+      else if (v == 2 * nx + 1) gidx[v] = zb + zt, gfac[v] = 1.0 / o->st;
+      else gidx[v] = zb + zt + 2 + (v - 2 * nx - 2), gfac[v] = 1.0 / o->sa[v - 2 * nx - 2];
+    }
+    for (int m = 0; m < ntv; ++m)
+      for (int n = m; n < ntv; ++n) {
+        if (!(F->m2_term[m * ntv + n] | F->m2_term[n * ntv + m])) continue;
+        const double v = Hw[m * ntv + n] * gfac[m] * gfac[n];
+        int64_t r = gidx[m], c = gidx[n];
+        if (r > c) { int64_t tmp = r; r = c; c = tmp; }
+        rows[q] = (int32_t)r, cols[q] = (int32_t)c, vals[q++] = v;
+      }
+  }
+  return q;
 }
 
 /* All-host-cores variant of the timed loop: OpenMP over evaluation points, private output buffers per
@@ -577,4 +814,20 @@ void orc_eval_many(const orc* o, int64_t n_points, int reps, const double* Z, co
                    double* vals) {
   for (int r = 0; r < reps; ++r)
     for (int64_t b = 0; b < n_points; ++b) orc_eval(o, Z + b * o->n_z, p, f + b, g, grad, 0, 0, vals);
+}
+
+/* Timed loop for the "oracle time per IPOPT iteration" figure: per pass and point, the reference's recorded call mix
+ * (docs/source/notebooks/moon_lander.ipynb:192-198): n_g calls of nlp_g, then nlp_grad_f, nlp_jac_g, nlp_hess_l once each,
+ * as separate functions like CasADi's.  The caller clocks it. */
+void orc_ipopt_mix(const orc* o, int64_t n_points, int reps, int n_g_calls, const double* Z, const double* p, double sigma,
+                   const double* lam, double* g, double* grad, double* vals, int32_t* hr, int32_t* hc, double* hv) {
+  double f;
+  for (int r = 0; r < reps; ++r)
+    for (int64_t b = 0; b < n_points; ++b) {
+      const double* z = Z + b * o->n_z;
+      for (int k = 0; k < n_g_calls; ++k) orc_eval(o, z, p, &f, g, 0, 0, 0, 0);
+      orc_eval(o, z, p, &f, 0, grad, 0, 0, 0);
+      orc_eval(o, z, p, &f, g, 0, 0, 0, vals);
+      orc_hess(o, z, p, sigma, lam, hr, hc, hv);
+    }
 }

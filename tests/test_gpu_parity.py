@@ -1,6 +1,6 @@
 """GPU parity tests proper (through the C ABI): HIP kernels vs the oracles on seeded inputs, at
 reduced sizes against the numpy/sympy oracle (all five outputs) and at BASELINE.json's full sizes
-against the C oracle (f, g, grad_f, jac_g) plus size-independent derivative properties.
+against the C oracle (f, g, grad_f, jac_g, hess_l) plus size-independent derivative properties.
 Tolerance: 1e-10 relative for FP64 values (north_star); indices exact."""
 import numpy as np
 import pytest
@@ -103,6 +103,14 @@ def test_full_size_against_c_oracle_and_properties(name):
         Jc = sp.coo_matrix((c["jac_val"], (c["jac_row"], c["jac_col"])), shape=(o.n_g, o.n_z)).tocsr()
         d = (J - Jc)
         assert (abs(d).max() if d.nnz else 0.0) < TOL * max(1.0, abs(Jc).max())
+        # hess_l against the C oracle's hand-derived second derivatives (upper triangle, duplicates summed): every tile,
+        # the multi-tile partial sums of the (t0, tf, a) corner and the terminal entries at full size
+        Hg = sp.coo_matrix((r["hess_l"][b], (hr, hc)), shape=(o.n_z, o.n_z)).tocsr()
+        Hc = C.hess_matrix(Z[b], p, sig, lam)
+        dh = Hg - Hc
+        assert (abs(dh).max() if dh.nnz else 0.0) < TOL * max(1.0, abs(Hc).max())
+        pat_c = set(zip(*Hc.nonzero()))
+        assert pat_c <= set(zip(hr.tolist(), hc.tolist()))  # the oracle's structural entries all exist in the GPU pattern
     # size-independent derivative properties (central differences of the GPU's own f, g)
     rng = np.random.default_rng(5)
     v = rng.standard_normal(o.n_z)

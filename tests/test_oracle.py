@@ -65,6 +65,29 @@ def test_c_oracle_matches_reference(name):
     Jr = np.zeros_like(J)
     Jr[G["jac_row"], G["jac_col"]] = G["jac_val"]
     assert rel_err(J, Jr) < TOL
+    # hess_l: values and structural pattern (upper triangle) equal the reference's
+    h = C.hess(G["z"], G["p"], float(G["sigma"]), G["lam"])
+    assert (h["hess_row"] <= h["hess_col"]).all()
+    H = np.zeros((C.n_z, C.n_z))
+    np.add.at(H, (h["hess_row"], h["hess_col"]), h["hess_val"])
+    Hr = np.zeros_like(H)
+    Hr[G["hess_row"], G["hess_col"]] = G["hess_val"]
+    assert rel_err(H, Hr) < TOL
+    assert set(zip(h["hess_row"].tolist(), h["hess_col"].tolist())) == set(zip(G["hess_row"].tolist(), G["hess_col"].tolist()))
+    # the optional-output variants of the evaluation (what the separate nlp_* timings use) give the same numbers
+    import ctypes
+    from oracle import c_oracle
+
+    L = c_oracle.lib()
+    z, p = np.ascontiguousarray(G["z"], float), np.ascontiguousarray(G["p"], float)
+    f1, g1, gr1, v1 = np.zeros(1), np.zeros(C.n_g), np.zeros(C.n_z), np.zeros(C.nnz)
+    L.orc_eval(C._h, z.ctypes.data, p.ctypes.data, f1.ctypes.data, g1.ctypes.data, None, None, None, None)
+    assert np.array_equal(g1, r["g"]) and f1[0] == r["f"]
+    L.orc_eval(C._h, z.ctypes.data, p.ctypes.data, f1.ctypes.data, None, gr1.ctypes.data, None, None, None)
+    assert np.array_equal(gr1, r["grad_f"])
+    g1[:] = 0
+    L.orc_eval(C._h, z.ctypes.data, p.ctypes.data, f1.ctypes.data, g1.ctypes.data, None, None, None, v1.ctypes.data)
+    assert np.array_equal(g1, r["g"]) and np.array_equal(v1, r["jac_val"])
 
 
 def test_published_optimum_is_consistent_with_oracle_constraints():
