@@ -8,7 +8,10 @@ import ctypes
 import hashlib
 import os
 import shutil
+import contextlib
+import fcntl
 import subprocess
+import tempfile
 import threading
 
 PKG = os.path.dirname(os.path.abspath(__file__))
@@ -50,15 +53,37 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+@contextlib.contextmanager
+def _build_lock(path):
+    """Exclusive advisory lock for a build step: one process per GPU means N ranks may reach a cold cache at once."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
 def build_library(force=False, verbose=False):
-    """hipcc -> mpopt_amd/libmpx.so (host runtime + generic kernels, gfx950)."""
+    """hipcc -> mpopt_amd/libmpx.so (host runtime + generic kernels, gfx950).  Objects and the library are written under
+    private temporary names and moved into place atomically; a file lock serialises concurrent builders."""
     if not force and not _stale(LIB_PATH, _sources()):
         return LIB_PATH
+    with _build_lock(os.path.join(PKG, ".build.lock")):
+        if not force and not _stale(LIB_PATH, _sources()):
+            return LIB_PATH  # another process built it while we waited
+        with tempfile.TemporaryDirectory(dir=PKG, prefix=".build_") as tmp:
+            return _build_library_in(tmp, verbose)
+
+
+def _build_library_in(tmp, verbose):
     cc = hipcc()
-    obj = os.path.join(PKG, "mpx_colloc.o")
-    hobj = os.path.join(PKG, "mpx_host.o")
-    cobj = os.path.join(PKG, "mpx_casadi.o")
-    aobj = os.path.join(PKG, "mpx_assembly.o")
+    obj = os.path.join(tmp, "mpx_colloc.o")
+    hobj = os.path.join(tmp, "mpx_host.o")
+    cobj = os.path.join(tmp, "mpx_casadi.o")
+    aobj = os.path.join(tmp, "mpx_assembly.o")
+    out = os.path.join(tmp, "libmpx.so")
     cmds = [
         ["g++", "-O2", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", os.path.join(CSRC, "mpx_colloc.cpp"), "-o", obj],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", os.path.join(CSRC, "mpx_casadi.cpp"), "-o", cobj],
@@ -66,7 +91,7 @@ def build_library(force=False, verbose=False):
          os.path.join(CSRC, "mpx_host.cpp"), "-o", hobj],
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
          os.path.join(CSRC, "mpx_assembly.cpp"), "-o", aobj],
-        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, aobj, obj, cobj, "-o", LIB_PATH + ".tmp"],
+        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, aobj, obj, cobj, "-o", out],
     ]
     for cmd in cmds:
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -74,7 +99,7 @@ def build_library(force=False, verbose=False):
             print(" ".join(cmd), "\n", r.stdout, r.stderr)
         if r.returncode:
             raise MpxError("building libmpx failed: " + " ".join(cmd) + "\n" + r.stderr[:6000])
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(out, LIB_PATH)
     return LIB_PATH
 
 
@@ -202,10 +227,12 @@ def compile_kernels(source, verbose=False):
     os.makedirs(JIT_DIR, exist_ok=True)
     co = os.path.join(JIT_DIR, f"mpx_{key}.hsaco")
     if not os.path.exists(co):
-        src = os.path.join(JIT_DIR, f"mpx_{key}.hip")
-        with open(src, "w") as f:
+        # private temporary names (several ranks may compile the same key at once), atomic move into the cache
+        fd, src_tmp = tempfile.mkstemp(dir=JIT_DIR, prefix=f"mpx_{key}.", suffix=".hip")
+        with os.fdopen(fd, "w") as f:
             f.write(source)
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "--genco", "-I", CSRC, "-o", co + ".tmp", src]
+        co_tmp = src_tmp[:-4] + ".hsaco.tmp"
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "--genco", "-I", CSRC, "-o", co_tmp, src_tmp]
         extra = os.environ.get("MPX_HIPCC_FLAGS")
         if extra:
             cmd[1:1] = extra.split()
@@ -213,8 +240,12 @@ def compile_kernels(source, verbose=False):
         if verbose:
             print(" ".join(cmd), "\n", r.stdout, r.stderr)
         if r.returncode:
+            for t in (src_tmp, co_tmp):
+                with contextlib.suppress(OSError):
+                    os.remove(t)
             raise MpxError("kernel compilation failed: " + " ".join(cmd) + "\n" + r.stderr[:8000])
-        os.replace(co + ".tmp", co)
+        os.replace(src_tmp, os.path.join(JIT_DIR, f"mpx_{key}.hip"))  # kept next to the code object for inspection
+        os.replace(co_tmp, co)
     with open(co, "rb") as f:
         return f.read(), co
 

@@ -114,6 +114,13 @@ int build_tables(mpx_ctx* c) {
   distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
   for (int d : distinct) {
     if (d < 1 || d > 255) return fail(c, MPX_ERR_UNSUPPORTED, "polynomial degree %d outside 1..255", d);
+    {  // what the node kernel of this degree keeps in LDS (mpx_kernels.h: sD, sC above degree 12; the double-buffered X/U tile)
+      const int64_t P1 = d + 1, segs = MPX_TILE / d;
+      const int64_t lds = 8 * ((d > 12 ? P1 * P1 + (int64_t)d * P1 : 0) + 2 * (int64_t)(c->nx + c->nu) * segs * P1) + 8 * 2 * 4 * 64;
+      if (lds > 150 * 1024)
+        return fail(c, MPX_ERR_UNSUPPORTED, "polynomial degree %d needs %lld KB of LDS per workgroup (differentiation + mid-point tables and the "
+                    "state/control tile); the limit is 150 of the 160 KB of an MI355X compute unit", d, (long long)(lds / 1024));
+    }
     DegTable t;
     t.deg = d;
     int n = mpx_colloc_n_nodes(c->scheme, d);
@@ -688,7 +695,9 @@ extern "C" int mpx_create(const mpx_problem* prob, mpx_ctx** out) {
   int rc = parse_structure(c, prob->structure, prob->structure_len);
   if (!rc) rc = build_tables(c);
   if (!rc) rc = build_layout(c);
-  if (!rc && c->n_g >= (1LL << 31)) rc = fail(c, MPX_ERR_UNSUPPORTED, "problem too large for int32 patterns");
+  if (!rc && (c->n_g >= (1LL << 31) || c->n_z >= (1LL << 31) || c->nnz_j >= (1LL << 31) || c->nnz_h >= (1LL << 31)))
+    rc = fail(c, MPX_ERR_UNSUPPORTED, "problem too large for int32 patterns (n_z %lld, n_g %lld, nnz_jac %lld, nnz_hess %lld)", (long long)c->n_z,
+              (long long)c->n_g, (long long)c->nnz_j, (long long)c->nnz_h);
   if (!rc && prob->code_object) rc = load_device(c, prob);
   if (rc) {
     g_create_error = c->err;

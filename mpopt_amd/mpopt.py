@@ -910,7 +910,7 @@ class mpopt_h_adaptive(mpopt):
     _THRESHOLD_SLOPE = 1e-1
 
     def __init__(self, problem, n_segments=1, poly_orders=[9], scheme="LGR", **kwargs):
-        super().__init__(problem=problem, n_segments=n_segments, poly_orders=poly_orders, scheme=scheme)
+        super().__init__(problem=problem, n_segments=n_segments, poly_orders=poly_orders, scheme=scheme, **kwargs)
         P = self._ocp.n_phases
         self.lbh, self.ubh = [self._SEG_WIDTH_MIN] * P, [self._SEG_WIDTH_MAX] * P
         self.tol_residual = [self._TOL_RESIDUAL] * P
@@ -1304,8 +1304,8 @@ class mpopt_ph_adaptive(mpopt):
     _TOL_RESIDUAL = 1e-2
 
     def __init__(self, problem, n_segments=1, poly_orders=[9], scheme="LGR", grid_type="spectral", max_residual=1e-4,
-                 poly_order_min=3, poly_order_max=16, seg_min=1, seg_max=20, n_grid_points=20, non_smooth_threshold=1.05):
-        super().__init__(problem=problem, n_segments=n_segments, poly_orders=poly_orders, scheme=scheme)
+                 poly_order_min=3, poly_order_max=16, seg_min=1, seg_max=20, n_grid_points=20, non_smooth_threshold=1.05, **kwargs):
+        super().__init__(problem=problem, n_segments=n_segments, poly_orders=poly_orders, scheme=scheme, **kwargs)
         self.poly_order_min = min(poly_order_min, min(self.poly_orders))
         self.poly_order_max = max(poly_order_max, max(self.poly_orders))
         self.min_segments, self.max_segments = min(seg_min, n_segments), max(seg_max, n_segments)
@@ -1342,7 +1342,7 @@ class mpopt_ph_adaptive(mpopt):
         clip = lambda orders: [min(max(self.poly_order_min, int(p)), self.poly_order_max) for p in orders]
         widths = np.full(self.n_segments, 1.0 / self.n_segments)
         solution = None
-        for _ in range(max_iter):
+        for it in range(max_iter):
             opts = dict(solve_dict, mpopt_options=dict(solve_dict.get("mpopt_options", {}), nlp_sw_params=widths))
             solution = self.solve(reinitialize_nlp=True, **opts)
             seg_res = self._segment_residuals(solution)[0]
@@ -1370,6 +1370,8 @@ class mpopt_ph_adaptive(mpopt):
                 else:
                     orders.append(p)
                     new_w.append(w)
+            if it + 1 == max_iter:
+                break  # the returned solution belongs to the grid it was computed on: no regrid after the last solve
             widths = np.asarray(new_w)
             self._regrid(clip(orders), widths)
         return solution

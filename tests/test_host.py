@@ -85,6 +85,13 @@ def test_bad_inputs_are_reported_not_fatal():
     assert L.mpx_create(None, None) < 0 and b"null" in L.mpx_last_error(None)
 
 
+def test_degrees_whose_tables_exceed_lds_are_refused_with_a_message():
+    ocp = problems.moon_lander(mp, M.math)
+    M.NlpFunctions(ocp, 1, [60], "LGR", with_device=False).close()  # the largest degree the GPU tests exercise
+    with pytest.raises(M.MpxError, match="LDS"):
+        M.NlpFunctions(ocp, 1, [120], "LGR", with_device=False)
+
+
 def test_tracer_derivatives_against_sympy():
     import sympy as sp
 

@@ -18,7 +18,8 @@ mpopt_pkg = types.ModuleType("mpopt"); mpopt_pkg.mp = mp; sys.modules["mpopt"] =
 ctx = types.ModuleType("context"); ctx.mpopt = mpopt_pkg; sys.modules["context"] = ctx
 results = {}
 class Stop(Exception): pass
-for f in sorted(glob.glob('/root/reference/examples/**/*.py', recursive=True)):
+REF = os.environ.get('MPX_REFERENCE_DIR', '/root/reference')
+for f in sorted(glob.glob(REF + '/examples/**/*.py', recursive=True)):
     name = f.split('/examples/')[1]
     src = open(f).read()
     created = []
