@@ -206,6 +206,29 @@ int mpx_get_tile_weights(const mpx_ctx* ctx, int64_t* weights);
  * sum this buffer (and their disjoint output slices) before the MPX_BOUNDARY_ONLY pass. */
 int mpx_get_partials(mpx_ctx* ctx, int64_t batch, double** device_ptr, int64_t* count);
 
+/* Segment-sharded evaluation over `world` ranks (one process per GPU; the collective itself is the caller's: RCCL through
+ * torch.distributed, mpopt_amd/distributed.py).  mpx_shard_setup partitions the tiles into contiguous ranges balanced by
+ * Jacobian block size and puts the context into sharded mode (world == 1 leaves it):
+ *     1. mpx_eval_device(mask)                       node kernels of this rank's tiles only; g / grad_f go to the packed
+ *                                                    tile-ordered staging block of the context, not to the caller's arrays
+ *     2. mpx_shard_pack(mask, vals, send)            this rank's owned runs -> send[rank_len * batch]
+ *     3. all-gather of the send buffers              -> recv[world][rank_len * batch]               (caller, RCCL / gloo)
+ *     4. mpx_shard_unpack(mask, recv, vals)          the other ranks' runs -> jac_val / hess_val, staging block, tile partials
+ *     5. mpx_eval_device(mask | MPX_BOUNDARY_ONLY)   staging block -> g / grad_f; reductions, terminal and event rows
+ * after which every rank holds the complete result, bit-identical to the unsharded evaluation (every entry is produced by
+ * exactly one rank; reductions keep their fixed order).  `mask` selects the pass: with MPX_HESS the hess_l pass (vals =
+ * hess_val), otherwise the f/g/grad_f/jac_g pass (vals = jac_val, may be NULL without MPX_JAC); run the two passes one after
+ * the other.  mpx_shard_info: rank_len = padded per-rank, per-point length of the exchange buffer in doubles, n_entries =
+ * rows of mpx_shard_table, tile_cuts[world + 1] = the tile ranges.  mpx_shard_table: out[n_entries][6] = (rank, kind, offset,
+ * length, stride, packed_offset) of every owned run; kind 0 = jac_val / hess_val, 1 = staging block, 2 = tile partials; the
+ * run of evaluation point b starts at offset + b * stride in its array and at packed_offset * batch + b * length in the
+ * rank's exchange buffer (structure only: works without a device). */
+int mpx_shard_setup(mpx_ctx* ctx, int world, int rank);
+int mpx_shard_info(const mpx_ctx* ctx, int mask, int64_t* rank_len, int64_t* n_entries, int64_t* tile_cuts);
+int mpx_shard_table(const mpx_ctx* ctx, int mask, int64_t* out);
+int mpx_shard_pack(mpx_ctx* ctx, int mask, int64_t batch, const double* vals, double* send);
+int mpx_shard_unpack(mpx_ctx* ctx, int mask, int64_t batch, const double* recv, double* vals);
+
 /* ---------------------------------------------------------------------------------------------
  * Off-node evaluation ("next" row): what mpopt.interpolate_single_phase and
  * mpopt.get_dynamics_residuals_single_phase compute after a solve (mpopt.py:1428-1543), batched.

@@ -173,6 +173,11 @@ SYMBOLS = {
     "mpx_get_tile_jac_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p, c_int64_p]),
     "mpx_get_tile_weights": (ctypes.c_int, [ctypes.c_void_p, c_int64_p]),
     "mpx_get_partials": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), c_int64_p]),
+    "mpx_shard_setup": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "mpx_shard_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_int64_p, c_int64_p]),
+    "mpx_shard_table": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p]),
+    "mpx_shard_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "mpx_shard_unpack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "mpx_set_current": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_resid_plan_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_double_p, ctypes.POINTER(ctypes.c_void_p)]),
     "mpx_resid_plan_create_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_double_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),

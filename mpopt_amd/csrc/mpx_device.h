@@ -119,6 +119,14 @@ struct MpxResidArgs {
 
 #define MPX_ACCUM_BIT (1LL << 62)
 
+// Segment sharding: one contiguous run of values a rank owns.  kind 0: jac_val / hess_val of the caller, 1: packed g / grad_f
+// staging, 2: per-tile partial sums.  The run of evaluation point b starts at  src_off + b * stride  in its array and at
+// dst_off * B + b * len  in the rank's exchange buffer.
+struct MpxShardEnt {
+  int64_t src_off, len, stride, dst_off;
+  int32_t kind, rank;
+};
+
 // ---- assembled contexts (mpx_create_assembled) ---------------------------------------------------
 // One point set (device-resident array, fixed for the life of the context).
 struct MpxPtSet {

@@ -245,39 +245,39 @@ int build_layout(mpx_ctx* c) {
   c->tile_begin = 0;
   c->tile_end = (int64_t)c->tiles.size();
 
-  // ---- packed g / grad_f staging for mixed-degree phases (see MpxIO::gtmp) -------------------------------
+  // ---- packed g / grad_f staging (see MpxIO::gtmp): used by mixed-degree phases and by segment-sharded evaluations ----
   {
     std::vector<int> per_phase(c->n_phases, 0);
     for (auto& B : c->buckets) per_phase[B.phase]++;
-    c->g_packed = false;
+    c->g_packed = false;  // mixed-degree phase present: full evaluations stage g / grad_f through the packed block
     for (int v : per_phase) c->g_packed = c->g_packed || v > 1;
-    if (c->g_packed) {
-      c->gmap.assign((size_t)c->n_g, -1);
-      c->qmap.assign((size_t)c->n_z, -1);
-      int64_t pos = 0;
-      for (auto& B : c->buckets) {
-        const PhaseStruct& P = c->ph[B.phase];
-        const int sC = nx, sDU = nx + P.nc, sMU = sDU + (P.diff_u ? nu : 0), sQ = sMU + (P.midu ? nu : 0), nsg = sQ + nx + nu;
-        for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
-          MpxTile& T = c->tiles[t];
-          T.g_base = pos;
-          const int64_t n = T.n_own;
-          for (int64_t l = 0; l < n; ++l) {
-            const int64_t i = B.node_i[T.m0 + l];
-            const int k = B.node_sk[T.m0 + l] & 255;
-            for (int a = 0; a < nx; ++a) c->gmap[P.g_off_F + (int64_t)a * N + i] = pos + a * n + l;
-            for (int j = 0; j < P.nc; ++j) c->gmap[P.g_off_C + (int64_t)j * N + i] = pos + (sC + j) * n + l;
-            if (P.diff_u)
-              for (int q = 0; q < nu; ++q) c->gmap[P.g_off_DU + (int64_t)q * N + i] = pos + (sDU + q) * n + l;
-            if (P.midu && k >= 1)
-              for (int q = 0; q < nu; ++q) c->gmap[P.g_off_mU + (int64_t)q * (N - 1) + (i - 1)] = pos + (sMU + q) * n + l;
-            for (int a = 0; a < nx + nu; ++a) c->qmap[P.z_off + (int64_t)a * N + i] = pos + (sQ + a) * n + l;
-          }
-          pos += (int64_t)nsg * n;
+    c->gmap.assign((size_t)c->n_g, -1);
+    c->qmap.assign((size_t)c->n_z, -1);
+    c->tile_g_size.assign(c->tiles.size(), 0);
+    int64_t pos = 0;
+    for (auto& B : c->buckets) {
+      const PhaseStruct& P = c->ph[B.phase];
+      const int sC = nx, sDU = nx + P.nc, sMU = sDU + (P.diff_u ? nu : 0), sQ = sMU + (P.midu ? nu : 0), nsg = sQ + nx + nu;
+      for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
+        MpxTile& T = c->tiles[t];
+        T.g_base = pos;
+        const int64_t n = T.n_own;
+        for (int64_t l = 0; l < n; ++l) {
+          const int64_t i = B.node_i[T.m0 + l];
+          const int k = B.node_sk[T.m0 + l] & 255;
+          for (int a = 0; a < nx; ++a) c->gmap[P.g_off_F + (int64_t)a * N + i] = pos + a * n + l;
+          for (int j = 0; j < P.nc; ++j) c->gmap[P.g_off_C + (int64_t)j * N + i] = pos + (sC + j) * n + l;
+          if (P.diff_u)
+            for (int q = 0; q < nu; ++q) c->gmap[P.g_off_DU + (int64_t)q * N + i] = pos + (sDU + q) * n + l;
+          if (P.midu && k >= 1)
+            for (int q = 0; q < nu; ++q) c->gmap[P.g_off_mU + (int64_t)q * (N - 1) + (i - 1)] = pos + (sMU + q) * n + l;
+          for (int a = 0; a < nx + nu; ++a) c->qmap[P.z_off + (int64_t)a * N + i] = pos + (sQ + a) * n + l;
         }
+        c->tile_g_size[t] = (int64_t)nsg * n;
+        pos += (int64_t)nsg * n;
       }
-      c->gtmp_n = pos;
     }
+    c->gtmp_n = pos;
   }
 
   // ---- Jacobian pattern -----------------------------------------------------------------
@@ -289,6 +289,8 @@ int build_layout(mpx_ctx* c) {
     if (P.midu && !T.node0) sl += (int64_t)nu * (d + 1);
     return sl;
   };
+  c->tile_jac_size.assign(c->tiles.size(), 0);
+  c->tile_hess_size.assign(c->tiles.size(), 0);
   for (int pass = 0; pass < 2; ++pass)
     for (auto& B : c->buckets)
       for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
@@ -296,6 +298,7 @@ int build_layout(mpx_ctx* c) {
         const int64_t size = tile_slots(T, c->ph[B.phase], B.deg) * T.n_own;
         if ((int)(size & 1) != pass) continue;
         T.jac_base = jpos;
+        c->tile_jac_size[t] = size;
         jpos += size;
       }
   jr.assign(jpos, 0);
@@ -405,6 +408,7 @@ int build_layout(mpx_ctx* c) {
         const int64_t size = (int64_t)c->ph[B.phase].hn.size() * T.n_own;
         if ((int)(size & 1) != pass) continue;
         T.hess_base = hpos;
+        c->tile_hess_size[t] = size;
         hpos += size;
       }
   hr.assign(hpos, 0);
@@ -503,7 +507,7 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   if ((rc = upload(c, &c->d_mg_dst, c->mg_dst))) return rc;
   if ((rc = upload(c, &c->d_hc_dst, c->hc_dst))) return rc;
   if ((rc = upload(c, &c->d_th_dst, c->th_dst))) return rc;
-  if (c->g_packed && ((rc = upload(c, &c->d_gmap, c->gmap)) || (rc = upload(c, &c->d_qmap, c->qmap)))) return rc;
+  if ((rc = upload(c, &c->d_gmap, c->gmap)) || (rc = upload(c, &c->d_qmap, c->qmap))) return rc;
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   c->has_device = true;
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restric
 }
 
 int pick_bpb(const mpx_ctx* c, int64_t B) {
-  static const char* env = getenv("MPX_BPB");
+  const char* env = getenv("MPX_BPB");  // tuning / test override (read per call: tools switch it inside one process)
   if (env && atoi(env) > 0) return atoi(env);
   // measured on MI355X (moon lander 1000x5, B=4096, XCD-blocked mapping): 4-8 points per workgroup is the
   // sweet spot of the software-pipelined loop (2: -8 %, 16: -5 %, 64: -10 %); small batches get one point
@@ -577,10 +581,14 @@ int pick_bpb(const mpx_ctx* c, int64_t B) {
 int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
   MpxIO io = io0;
   io.b_per_block = pick_bpb(c, io.B);
-  // mixed-degree phases: stage g / grad_f in tile order (only for full evaluations: with a restricted tile range the
-  // direct stores keep every rank's slice disjoint for the all-reduce)
-  const bool packed = c->g_packed && nodes && mode != MPX_MODE_HESS && (io.g || io.grad) && c->tile_begin == 0 &&
-                      c->tile_end == (int64_t)c->tiles.size() && io.B <= 65535 && !getenv("MPX_NO_PACKED_G");
+  // Packed staging of g / grad_f in tile order: (a) mixed-degree phases, full evaluations (a plain mpx_set_tile_range keeps
+  // the direct stores); (b) every segment-sharded evaluation (mpx_shard_setup): a rank's tiles are one contiguous run of the
+  // staging block, which is what the ranks exchange; the boundary pass then moves the assembled block to g / grad_f.
+  const bool shard = c->shard_world > 1;
+  const bool want_g = mode != MPX_MODE_HESS && (io.g || io.grad);
+  if (shard && want_g && io.B > 65535) return fail(c, MPX_ERR_UNSUPPORTED, "segment-sharded evaluation: batch must be <= 65535");
+  const bool packed = want_g && io.B <= 65535 &&
+                      (shard || (c->g_packed && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_PACKED_G")));
   if (packed) {
     int rc = reserve(c, c->gtmp, (size_t)(io.B * c->gtmp_n));
     if (rc) return rc;
@@ -621,7 +629,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
     if (rc) return rc;
     if (c->profile) ++c->prof_launches;
   }
-  if (packed) {
+  if (packed && (!shard || !nodes)) {
     const int64_t rows = c->n_g + c->n_z;
     hipLaunchKernelGGL(mpx_unpack_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)io.B), dim3(256), 0, c->stream, c->gtmp.p, c->gtmp_n, io.g,
                        io.g_stride, c->d_gmap, c->n_g, io.grad, io.grad_stride, c->d_qmap, c->n_z);
@@ -631,7 +639,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
     int rc = prof_end(c, pe1);
     if (rc) return rc;
   }
-  if (!c->run_boundary) return MPX_OK;
+  if (shard ? nodes : !c->run_boundary) return MPX_OK;  // sharded: node pass and boundary pass are separate calls
   MpxBoundArgs G{};
   G.io = io;
   for (int p = 0; p < c->n_phases; ++p) {
@@ -723,7 +731,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
     fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
-    fr(c->d_gmap), fr(c->d_qmap), fr(c->gtmp.p);
+    fr(c->d_gmap), fr(c->d_qmap), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
@@ -789,6 +797,7 @@ extern "C" int mpx_set_stream(mpx_ctx* c, void* stream) {
 extern "C" int mpx_set_tile_range(mpx_ctx* c, int64_t b, int64_t e, int run_boundary) {
   if (!c || b < 0 || e > (int64_t)c->tiles.size() || b > e) return fail(c, MPX_ERR_INVALID, "bad tile range");
   if (c->kind != 0) return fail(c, MPX_ERR_UNSUPPORTED, "assembled contexts have no tiles");
+  if (c->shard_world > 1) return fail(c, MPX_ERR_INVALID, "mpx_set_tile_range on a context in segment-sharded mode (mpx_shard_setup(ctx, 1, 0) leaves it)");
   c->tile_begin = b;
   c->tile_end = e;
   c->run_boundary = run_boundary;
@@ -1083,6 +1092,166 @@ extern "C" int mpx_resid_eval(mpx_ctx* c, mpx_resid_plan* P, int64_t batch, cons
   return MPX_OK;
 }
 
+
+// ---- segment sharding -------------------------------------------------------------------------------
+// Ranks evaluate disjoint contiguous tile ranges; what a rank owns afterwards is a handful of contiguous runs: the value
+// blocks of its tiles (jac_val or hess_val), its run of the packed g / grad_f staging block and its per-tile partial sums.
+// mpx_shard_pack copies the runs into one exchange buffer, the caller all-gathers the buffers (RCCL over xGMI),
+// mpx_shard_unpack scatters the other ranks' runs into place, and the MPX_BOUNDARY_ONLY pass finishes the evaluation.
+namespace {
+
+__global__ __launch_bounds__(256) void mpx_shard_copy_kernel(const MpxShardEnt* __restrict__ ents, int64_t B, int64_t rank_len, int my_rank,
+                                                             int unpack, double* vals, double* gtmp, double* partial, double* buf) {
+  const MpxShardEnt E = ents[blockIdx.y];
+  if (unpack ? E.rank == my_rank : E.rank != my_rank) return;
+  double* __restrict__ base = E.kind == 0 ? vals : (E.kind == 1 ? gtmp : partial);
+  if (!base) return;
+  double* __restrict__ pk = buf + (unpack ? (int64_t)E.rank * rank_len * B : 0) + E.dst_off * B;
+  const int64_t n = B * E.len;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / E.len, i = e - b * E.len;
+    double* __restrict__ at = base + E.src_off + b * E.stride + i;
+    if (unpack)
+      *at = pk[e];
+    else
+      pk[e] = *at;
+  }
+}
+
+// greedy prefix split of the tiles by weight (Jacobian block size): contiguous ranges, possibly empty
+std::vector<int64_t> shard_cuts(const std::vector<int64_t>& w, int world) {
+  const int64_t n = (int64_t)w.size();
+  std::vector<double> cum(n + 1, 0.0);
+  for (int64_t t = 0; t < n; ++t) cum[t + 1] = cum[t] + (double)std::max<int64_t>(w[t], 1);
+  std::vector<int64_t> cuts(1, 0);
+  for (int r = 1; r < world; ++r) {
+    const double target = cum[n] * r / world;
+    int64_t k = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
+    if (k > 0 && std::abs(cum[k - 1] - target) <= std::abs(cum[std::min(k, n)] - target)) --k;
+    cuts.push_back(std::max(cuts.back(), std::min(k, n)));
+  }
+  cuts.push_back(n);
+  return cuts;
+}
+
+void shard_runs(const std::vector<MpxTile>& tiles, const std::vector<int64_t>& size, bool hess, int64_t tb, int64_t te,
+                std::vector<std::pair<int64_t, int64_t>>& runs) {
+  runs.clear();
+  for (int64_t t = tb; t < te; ++t)
+    if (size[t] > 0) runs.push_back({hess ? tiles[t].hess_base : tiles[t].jac_base, size[t]});
+  std::sort(runs.begin(), runs.end());
+  size_t o = 0;
+  for (size_t k = 0; k < runs.size(); ++k) {
+    if (o > 0 && runs[o - 1].first + runs[o - 1].second == runs[k].first)
+      runs[o - 1].second += runs[k].second;
+    else
+      runs[o++] = runs[k];
+  }
+  runs.resize(o);
+}
+
+}  // namespace
+
+extern "C" int mpx_shard_setup(mpx_ctx* c, int world, int rank) {
+  if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, MPX_ERR_INVALID, "mpx_shard_setup: bad world / rank");
+  if (c->kind != 0) return fail(c, MPX_ERR_UNSUPPORTED, "assembled contexts have no tiles to shard");
+  const int64_t nt = (int64_t)c->tiles.size();
+  c->shard_world = world;
+  c->shard_rank = rank;
+  for (int ps = 0; ps < 2; ++ps) {
+    c->shard_ent[ps].clear();
+    c->shard_ent_first[ps].assign(1, 0);
+    c->shard_len[ps] = 0;
+    if (c->d_shard_ent[ps]) (void)hipFree(c->d_shard_ent[ps]);
+    c->d_shard_ent[ps] = nullptr;
+  }
+  if (world == 1) {
+    c->shard_cuts = {0, nt};
+    c->tile_begin = 0, c->tile_end = nt, c->run_boundary = 1;
+    return MPX_OK;
+  }
+  c->shard_cuts = shard_cuts(c->tile_jac_size, world);
+  c->tile_begin = c->shard_cuts[rank];
+  c->tile_end = c->shard_cuts[rank + 1];
+  c->run_boundary = 0;
+  std::vector<std::pair<int64_t, int64_t>> runs;
+  for (int ps = 0; ps < 2; ++ps) {
+    for (int r = 0; r < world; ++r) {
+      const int64_t tb = c->shard_cuts[r], te = c->shard_cuts[r + 1];
+      int64_t pos = 0;
+      auto add = [&](int kind, int64_t off, int64_t len, int64_t stride) {
+        if (len <= 0) return;
+        c->shard_ent[ps].push_back(MpxShardEnt{off, len, stride, pos, kind, r});
+        pos += len;
+      };
+      shard_runs(c->tiles, ps ? c->tile_hess_size : c->tile_jac_size, ps == 1, tb, te, runs);
+      for (auto& q : runs) add(0, q.first, q.second, ps ? c->nnz_h : c->nnz_j);
+      if (ps == 0 && te > tb) add(1, c->tiles[tb].g_base, c->tiles[te - 1].g_base + c->tile_g_size[te - 1] - c->tiles[tb].g_base, c->gtmp_n);
+      add(2, tb * c->nred, (te - tb) * c->nred, nt * c->nred);
+      c->shard_len[ps] = std::max(c->shard_len[ps], pos);
+      c->shard_ent_first[ps].push_back((int32_t)c->shard_ent[ps].size());
+    }
+    c->shard_len[ps] += c->shard_len[ps] & 1;  // keep every rank's slot 16-byte aligned
+    if (c->has_device) {
+      HIPCHK(c, hipSetDevice(c->device));
+      int rc = upload(c, &c->d_shard_ent[ps], c->shard_ent[ps]);
+      if (rc) return rc;
+    }
+  }
+  return MPX_OK;
+}
+
+extern "C" int mpx_shard_info(const mpx_ctx* c, int mask, int64_t* rank_len, int64_t* n_entries, int64_t* tile_cuts) {
+  if (!c || c->shard_cuts.empty()) return MPX_ERR_INVALID;
+  const int ps = (mask & MPX_HESS) ? 1 : 0;
+  if (rank_len) *rank_len = c->shard_len[ps];
+  if (n_entries) *n_entries = (int64_t)c->shard_ent[ps].size();
+  if (tile_cuts) memcpy(tile_cuts, c->shard_cuts.data(), c->shard_cuts.size() * sizeof(int64_t));
+  return MPX_OK;
+}
+
+extern "C" int mpx_shard_table(const mpx_ctx* c, int mask, int64_t* out) {
+  if (!c || !out || c->shard_cuts.empty()) return MPX_ERR_INVALID;
+  const int ps = (mask & MPX_HESS) ? 1 : 0;
+  for (auto& e : c->shard_ent[ps]) {
+    *out++ = e.rank, *out++ = e.kind, *out++ = e.src_off, *out++ = e.len, *out++ = e.stride, *out++ = e.dst_off;
+  }
+  return MPX_OK;
+}
+
+static int shard_copy(mpx_ctx* c, int mask, int64_t batch, double* vals, double* buf, int unpack) {
+  if (!c || !buf || batch < 1) return MPX_ERR_INVALID;
+  if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "mpx_shard_pack/unpack: context has no device code; there is no CPU fallback");
+  if (c->shard_world <= 1) return fail(c, MPX_ERR_INVALID, "mpx_shard_pack/unpack without mpx_shard_setup(world > 1)");
+  const int ps = (mask & MPX_HESS) ? 1 : 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
+  double* gt = nullptr;
+  if (ps == 0 && (mask & (MPX_G | MPX_GRAD))) {
+    if ((rc = reserve(c, c->gtmp, (size_t)(batch * c->gtmp_n)))) return rc;
+    gt = c->gtmp.p;
+  }
+  const int32_t first = unpack ? 0 : c->shard_ent_first[ps][c->shard_rank];
+  const int32_t count = unpack ? (int32_t)c->shard_ent[ps].size() : c->shard_ent_first[ps][c->shard_rank + 1] - first;
+  if (count <= 0) return MPX_OK;
+  int64_t longest = 1;
+  for (int32_t k = first; k < first + count; ++k) longest = std::max(longest, c->shard_ent[ps][k].len * batch);
+  const unsigned gx = (unsigned)std::min<int64_t>((longest + 255) / 256, 2048);
+  hipLaunchKernelGGL(mpx_shard_copy_kernel, dim3(gx, (unsigned)count), dim3(256), 0, c->stream, c->d_shard_ent[ps] + first, batch, c->shard_len[ps],
+                     c->shard_rank, unpack, ((mask & (MPX_JAC | MPX_HESS)) ? vals : nullptr), gt, c->partial.p, buf);
+  HIPCHK(c, hipGetLastError());
+  return MPX_OK;
+}
+
+extern "C" int mpx_shard_pack(mpx_ctx* c, int mask, int64_t batch, const double* vals, double* send) {
+  return shard_copy(c, mask, batch, const_cast<double*>(vals), send, 0);
+}
+
+extern "C" int mpx_shard_unpack(mpx_ctx* c, int mask, int64_t batch, const double* recv, double* vals) {
+  return shard_copy(c, mask, batch, vals, const_cast<double*>(recv), 1);
+}
+
 static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
                      const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix);
 
@@ -1183,7 +1352,7 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
   io.nred = c->nred;
   io.B = (int32_t)batch;
   const bool nodes = !(mask & MPX_BOUNDARY_ONLY);
-  if (!nodes && !c->run_boundary) return fail(c, MPX_ERR_INVALID, "MPX_BOUNDARY_ONLY with the boundary pass disabled");
+  if (!nodes && !c->run_boundary && c->shard_world <= 1) return fail(c, MPX_ERR_INVALID, "MPX_BOUNDARY_ONLY with the boundary pass disabled");
   if (mask & (MPX_GRAD | MPX_JAC)) {
     if ((rc = run_mode(c, MPX_MODE_FGJ, io, nodes))) return rc;
   } else if (mask & (MPX_F | MPX_G)) {

@@ -104,6 +104,15 @@ struct mpx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t tile_begin = 0, tile_end = 0;
   int run_boundary = 1;
+  // host-side sizes of every tile's value blocks (doubles): jac, hess, packed g / grad_f staging
+  std::vector<int64_t> tile_jac_size, tile_hess_size, tile_g_size;
+  // segment sharding (mpx_shard_*): this context evaluates the tiles [shard_cuts[rank], shard_cuts[rank + 1]) of every point
+  int shard_world = 1, shard_rank = 0;
+  std::vector<int64_t> shard_cuts;                  // [world + 1]
+  std::vector<MpxShardEnt> shard_ent[2];            // pass 0: f/g/grad_f/jac_g, pass 1: hess_l; entries of ALL ranks
+  std::vector<int32_t> shard_ent_first[2];          // [world + 1] first entry of every rank
+  int64_t shard_len[2] = {0, 0};                    // padded per-rank, per-point length of the exchange buffer (doubles)
+  MpxShardEnt* d_shard_ent[2] = {nullptr, nullptr};
   // host path: widths of the previous mpx_eval (IPOPT never changes p between oracle calls, so the
   // upload and the prefix-sum launch are skipped while p is unchanged)
   std::vector<double> last_p;

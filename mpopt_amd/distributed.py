@@ -4,13 +4,17 @@
 Two ways the path shards:
 
 * **Evaluation points** are independent: each rank evaluates its own slice of a batch
-  (``shard_range``), no data-path collective.  This is what ``bench.py --gpus N`` measures.
-* **Segments of one evaluation**: ranks run the node kernels on disjoint, contiguous tile ranges
-  (``partition_tiles``), every output entry and every per-tile partial sum is produced by exactly one
-  rank and all others hold zeros, so one SUM all-reduce per array (``allreduce_disjoint``) assembles
-  the full result *exactly* (x + 0 + ... + 0); the boundary pass then runs on the assembled partials.
-  Results are bit-identical to the single-GPU evaluation.  The payloads are small (<= 20 MB), i.e. the
-  collective is latency-bound (~15 us): it pays only for large segment counts / batches.
+  (``shard_range``), no data-path collective.  This is what ``bench.py --gpus N`` measures by default.
+* **Segments of one evaluation** (``SegmentShardedEvaluator``): ranks run the node kernels on disjoint,
+  contiguous tile ranges balanced by Jacobian block size (libmpx, ``mpx_shard_setup``).  What a rank owns
+  afterwards is a handful of contiguous runs -- the value blocks of its tiles, its run of the packed
+  g / grad_f staging block, its per-tile partial sums -- which libmpx packs into one exchange buffer
+  (``mpx_shard_pack``).  ONE all-gather of the padded buffers (``all_gather_into_tensor``: RCCL over xGMI)
+  moves every rank's runs to every rank, ``mpx_shard_unpack`` scatters them into place and the boundary
+  pass finishes reductions, terminal and event rows on every rank.  Every entry is produced by exactly
+  one rank and reductions keep their fixed order, so the result is bit-identical to the single-GPU
+  evaluation for any rank count.  The payload of one evaluation is small (<= 20 MB), i.e. the collective
+  is latency-bound: sharding segments pays for large grids / memory capacity, not for throughput.
 """
 import os
 
@@ -74,49 +78,67 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
-def allreduce_disjoint(tensors):
-    """SUM all-reduce of tensors whose non-zero entries are owned by exactly one rank each."""
-    import torch.distributed as dist
-
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
-    for t in tensors:
-        if t is not None and t.numel():
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-
-
 class SegmentShardedEvaluator:
-    """One evaluation (or batch) split over ranks by collocation segments.
+    """One evaluation (or a small batch) split over the ranks of ``group`` by collocation segments.
 
-    ``oracle``: this rank's ``NlpFunctions`` (device-resident).  All tensors are torch CUDA tensors of
-    full size on every rank; ``z``/``p``/``lam_g``/``sigma`` must be identical on all ranks."""
+    ``oracle``: this rank's ``NlpFunctions`` with a device; its stream must be torch's current stream
+    (``oracle.set_stream(torch.cuda.current_stream().cuda_stream)``) so that kernels and collectives are
+    ordered.  Inputs ``z`` / ``p`` / ``lam_g`` / ``sigma`` are full-size torch tensors on the device,
+    identical on all ranks; the outputs are full-size on every rank when ``eval`` returns (asynchronously
+    on the stream with the nccl backend).  With the gloo backend the exchange buffers are staged through
+    host memory (tests: several ranks sharing one GPU)."""
 
-    def __init__(self, oracle, rank, world):
-        self.o, self.rank, self.world = oracle, rank, world
-        self.ranges = partition_tiles(oracle.tile_weights(), world)
+    def __init__(self, oracle, rank=None, world=None, group=None):
+        import torch.distributed as dist
 
-    def eval(self, mask, batch, z, p, lam_g=None, sigma=None, f=None, g=None, grad_f=None, jac_val=None, hess_val=None):
+        self.o, self.group = oracle, group
+        self.world = dist.get_world_size(group) if world is None else int(world)
+        self.rank = dist.get_rank(group) if rank is None else int(rank)
+        oracle.shard_setup(self.world, self.rank)
+        self._buf = {}
+        self.backend = dist.get_backend(group) if (dist.is_initialized() and self.world > 1) else None
+
+    def close(self):
+        """Leave sharded mode (the oracle evaluates all tiles again)."""
+        self.o.shard_setup(1, 0)
+
+    def _buffers(self, mask, batch, device):
+        import torch
+
+        key = (1 if mask & MPX_HESS else 0, int(batch))
+        if key not in self._buf:
+            n, _ = self.o.shard_info(mask)
+            send = torch.empty(max(n * batch, 2), dtype=torch.float64, device=device)
+            recv = torch.empty(self.world * max(n * batch, 2), dtype=torch.float64, device=device)
+            self._buf[key] = (send, recv)
+        return self._buf[key]
+
+    def eval(self, mask, batch, z, p, lam_g=None, sigma=None, f=None, g=None, grad_f=None, jac_val=None, hess_val=None, p_per_point=0):
         # the per-tile partial-sum buffer is shared by the (f,g,grad_f,jac_g) pass and the hess_l pass
         for sub in (mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC), mask & MPX_HESS):
             if sub:
-                self._eval_one(sub, batch, z, p, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
+                self._eval_one(sub, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
 
-    def _eval_one(self, mask, batch, z, p, lam_g, sigma, f, g, grad_f, jac_val, hess_val):
+    def _eval_one(self, mask, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val):
+        import torch.distributed as dist
+
         o = self.o
-        outs = [t for t, bit in ((g, MPX_G), (grad_f, MPX_GRAD), (jac_val, MPX_JAC), (hess_val, MPX_HESS)) if t is not None and mask & bit]
-        for t in outs:
-            t.zero_()
-        ptr, cnt = o.partials(batch)
-        part = _wrap_device_buffer(ptr, cnt, z.device)
-        part.zero_()
-        b, e = self.ranges[self.rank]
-        o.set_tile_range(b, e, run_boundary=False)
-        o.eval_device(mask, batch, z, p, 0, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
-        o.sync()
-        allreduce_disjoint(outs + [part])
-        o.set_tile_range(0, o.n_tiles, run_boundary=True)
-        o.eval_device(mask | MPX_BOUNDARY_ONLY, batch, z, p, 0, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
-        o.sync()
+        if self.world == 1:
+            o.eval_device(mask, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
+            return
+        vals = hess_val if mask & MPX_HESS else (jac_val if mask & MPX_JAC else None)
+        send, recv = self._buffers(mask, batch, z.device)
+        o.eval_device(mask, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val)  # node kernels of this rank's tiles
+        o.shard_pack(mask, batch, vals, send)
+        if self.backend == "gloo" and send.is_cuda:
+            o.sync()
+            hs, hr = send.cpu(), recv.cpu()
+            dist.all_gather_into_tensor(hr, hs, group=self.group)
+            recv.copy_(hr)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        o.shard_unpack(mask, batch, recv, vals)
+        o.eval_device(mask | MPX_BOUNDARY_ONLY, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
 
 
 def _wrap_device_buffer(ptr, count, device):

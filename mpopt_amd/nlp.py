@@ -304,6 +304,33 @@ class NlpFunctions:
     def set_tile_range(self, begin, end, run_boundary=True):
         _lib.check(self._L.mpx_set_tile_range(self._ctx, int(begin), int(end), int(bool(run_boundary))), self._ctx)
 
+    # -- segment sharding (include/mpx.h, mpx_shard_*) --------------------------------------
+    def shard_setup(self, world, rank):
+        """Put the context into segment-sharded mode for ``world`` ranks (``world == 1`` leaves it)."""
+        _lib.check(self._L.mpx_shard_setup(self._ctx, int(world), int(rank)), self._ctx)
+        self._shard_world = int(world)
+
+    def shard_info(self, mask):
+        """(rank_len, tile_cuts): padded per-rank, per-point length of the exchange buffer in doubles; tile ranges."""
+        n, ne = ctypes.c_int64(), ctypes.c_int64()
+        cuts = np.zeros(getattr(self, "_shard_world", 1) + 1, np.int64)
+        _lib.check(self._L.mpx_shard_info(self._ctx, int(mask), ctypes.byref(n), ctypes.byref(ne), cuts.ctypes.data_as(_lib.c_int64_p)), self._ctx)
+        return n.value, cuts
+
+    def shard_table(self, mask):
+        """int64 array [n_entries][6] = (rank, kind, offset, length, stride, packed_offset) of every owned run."""
+        n, ne = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._L.mpx_shard_info(self._ctx, int(mask), ctypes.byref(n), ctypes.byref(ne), None), self._ctx)
+        out = np.zeros((ne.value, 6), np.int64)
+        _lib.check(self._L.mpx_shard_table(self._ctx, int(mask), out.ctypes.data_as(_lib.c_int64_p)), self._ctx)
+        return out
+
+    def shard_pack(self, mask, batch, vals, send):
+        _lib.check(self._L.mpx_shard_pack(self._ctx, int(mask), int(batch), _ptr(vals), _ptr(send)), self._ctx)
+
+    def shard_unpack(self, mask, batch, recv, vals):
+        _lib.check(self._L.mpx_shard_unpack(self._ctx, int(mask), int(batch), _ptr(recv), _ptr(vals)), self._ctx)
+
     def tile_weights(self):
         w = np.empty(self.n_tiles, np.int64)
         _lib.check(self._L.mpx_get_tile_weights(self._ctx, w.ctypes.data_as(_lib.c_int64_p)), self._ctx)

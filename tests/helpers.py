@@ -53,3 +53,23 @@ def assert_coo_close(rows, cols, vals, rrows, rcols, rvals, rtol=1e-10, what="")
 def rel_err(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return np.abs(a - b).max() / max(1.0, np.abs(b).max()) if a.size else 0.0
+
+
+def emulate_shard_exchange(tables, rank_len, world, batch, arrays_by_rank, all_gather):
+    """TEST INFRASTRUCTURE: host-side restatement of mpx_shard_pack / all-gather / mpx_shard_unpack over numpy arrays, from the
+    table ``mpx_shard_table`` reports (CPU tests of the N>1 choreography; the product path uses the device kernels).
+    ``arrays_by_rank[kind]`` is this rank's flat array of that kind; ``all_gather(send) -> recv[world * len(send)]``."""
+    import numpy as np
+
+    me = arrays_by_rank["rank"]
+    send = np.zeros(max(rank_len * batch, 2))
+    for r, kind, off, ln, stride, dst in tables:
+        if r == me:
+            for b in range(batch):
+                send[dst * batch + b * ln: dst * batch + (b + 1) * ln] = arrays_by_rank[int(kind)][off + b * stride: off + b * stride + ln]
+    recv = all_gather(send)
+    n = len(send)
+    for r, kind, off, ln, stride, dst in tables:
+        if r != me:
+            for b in range(batch):
+                arrays_by_rank[int(kind)][off + b * stride: off + b * stride + ln] = recv[r * n + dst * batch + b * ln: r * n + dst * batch + (b + 1) * ln]

@@ -29,7 +29,6 @@ def _worker(rank, world, port, q):
     import mpopt_amd as M
     from mpopt_amd import mp, distributed as D
     import problems
-    from oracle.mpopt_oracle import OracleNLP
 
     r, w, lr = D.init_from_env(backend="gloo")
     assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
@@ -41,33 +40,53 @@ def _worker(rank, world, port, q):
     assert (cover == 1).all() and abs((e - b) - 1001 / w) <= 1
     # (2) max-over-ranks timing
     assert D.max_over_ranks(1.0 + r) == float(w)
-    # (3) segment sharding: every rank fills only the entries of its tile range; a SUM all-reduce
-    #     assembles exactly the full arrays (structure from libmpx, values from the numpy oracle)
-    S, po = 64, 5
-    ocp = problems.moon_lander(mp, M.math)
-    o = M.NlpFunctions(ocp, S, [po] * S, "LGR", with_device=False)
-    ranges = D.partition_tiles(o.tile_weights(), w)
-    assert ranges[0][0] == 0 and ranges[-1][1] == o.n_tiles and all(ranges[k][1] == ranges[k + 1][0] for k in range(w - 1))
-    O = OracleNLP(ocp, S, po, "LGR")
-    z = O.initial_guess() + 0.1
-    p = np.full(S, 1.0 / S)
-    jr, jc = o.jac_pattern()
-    Jfull = np.asarray(O.jac_g(z, p).todense())[jr, jc]
-    mine = np.zeros_like(Jfull)
-    owned = np.zeros(o.nnz_jac, bool)
-    for t in range(*ranges[r]):
-        a, b2 = o.tile_jac_range(t)
-        owned[a:b2] = True
-    if r == 0:  # entries outside all tiles (terminal rows, linking rows) come from the boundary pass
-        tiles_end = max(o.tile_jac_range(t)[1] for t in range(o.n_tiles))
-        owned[tiles_end:] = True
-    mine[owned] = Jfull[owned]
-    tj = torch.tensor(mine)
-    D.allreduce_disjoint([tj])
-    assert np.array_equal(tj.numpy(), Jfull)  # bit-exact assembly
-    cnt = torch.tensor(owned.astype(np.float64))
-    dist.all_reduce(cnt)
-    assert (cnt == 1).all()  # every entry owned exactly once
+    # (3) segment sharding (mpx_shard_*): every rank holds only the runs it owns (structure from libmpx, structure-only
+    #     context), ONE gloo all_gather_into_tensor of the padded exchange buffers moves them, and every rank ends up with
+    #     the complete arrays -- for the jac_g pass and the hess_l pass, mixed degrees, a batch of 2 points
+    from helpers import emulate_shard_exchange
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS
+
+    S = 24
+    po = [30 if s % 3 == 1 else 3 for s in range(S)]
+    ocp = problems.van_der_pol(mp, M.math)
+    o = M.NlpFunctions(ocp, S, po, "CGL", with_device=False)
+    o.shard_setup(w, r)
+    B = 2
+    rng = np.random.default_rng(7)  # same stream on every rank: the "true" full arrays
+    for mask, nnz in ((MPX_F | MPX_G | MPX_GRAD | MPX_JAC, o.nnz_jac), (MPX_HESS, o.nnz_hess)):
+        rank_len, cuts = o.shard_info(mask)
+        tab = o.shard_table(mask)
+        assert cuts[0] == 0 and cuts[-1] == o.n_tiles and (np.diff(cuts) >= 0).all()
+        sizes = {0: nnz, 1: int(tab[tab[:, 1] == 1][:, 2:4].sum(axis=1).max()) if (tab[:, 1] == 1).any() else 0,
+                 2: int(tab[tab[:, 1] == 2][0, 4])}
+        full = {k: rng.standard_normal(B * n) for k, n in sizes.items()}
+        mine = {k: np.full(B * n, np.nan) for k, n in sizes.items()}
+        owned = {k: np.zeros(B * n) for k, n in sizes.items()}
+        for rr, kind, off, ln, stride, dst in tab:
+            assert stride == sizes[int(kind)] or int(kind) == 1
+            for b_ in range(B):
+                sl = slice(off + b_ * stride, off + b_ * stride + ln)
+                owned[int(kind)][sl] += 1
+                if rr == r:
+                    mine[int(kind)][sl] = full[int(kind)][sl]
+        # every tile-produced value is owned exactly once; what nobody owns belongs to the boundary pass (terminal / linking entries)
+        jr, jc = (o.jac_pattern() if mask != MPX_HESS else o.hess_pattern())
+        assert owned[0].max() == 1 and owned[2].min() == 1 and owned[2].max() == 1
+        if 1 in sizes and sizes[1]:
+            stride1 = int(tab[tab[:, 1] == 1][0, 4])
+            assert owned[1].reshape(B, -1)[:, :stride1].min() == 1
+        mine["rank"] = r
+
+        def all_gather(send):
+            ts, tr = torch.tensor(send), torch.empty(w * len(send), dtype=torch.float64)
+            dist.all_gather_into_tensor(tr, ts)
+            return tr.numpy()
+
+        emulate_shard_exchange(tab, rank_len, w, B, mine, all_gather)
+        for k in sizes:
+            got, ok = mine[k], owned[k] > 0
+            assert np.array_equal(got[ok], full[k][ok]), (mask, k)  # bit-exact assembly on every rank
+            assert np.isnan(got[~ok]).all()
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))

@@ -1,0 +1,112 @@
+"""Segment-sharded evaluation under torch.distributed on the GPU: `world` processes (sharing the one GPU of the
+test box, gloo rendezvous; the same code runs one process per GPU over RCCL in bench.py --workload config3-shard) each run
+the node kernels of their tile range, exchange their owned runs with ONE all_gather_into_tensor and finish with the boundary
+pass.  Every rank must hold the complete result, bit-identical to its own unsharded evaluation."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import mpopt_amd as M
+    from mpopt_amd import mp, distributed as D
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS
+    import problems
+
+    D.init_from_env(backend="gloo")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    builder, S, po, scheme = {
+        "vdp_mixed": (problems.van_der_pol, 48, [30 if s % 3 == 1 else 3 for s in range(48)], "CGL"),   # config 3's pattern
+        "schwartz": (problems.two_phase_schwartz, 200, 3, "LGL"),                                        # config 4, reduced
+        "kitchen_sink": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR"),                           # parameters, DU rows, 2 phases
+        "hyper_sensitive": (problems.hyper_sensitive, 700, 3, "LGR"),                                    # config 5, reduced
+    }[case]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    if rank == 0:
+        nlp, _ = mpo.create_nlp()  # rank 0 compiles first, the others find the cached code object
+    dist.barrier()
+    if rank != 0:
+        nlp, _ = mpo.create_nlp()
+    o = nlp["oracle"]
+    o.set_stream(torch.cuda.current_stream().cuda_stream)
+    B = 3
+    rng = np.random.default_rng(5)  # identical inputs on every rank
+    Z = torch.tensor(mpo.initialize_solution()[None, :] + 0.05 * rng.standard_normal((B, o.n_z)), device=dev)
+    w = rng.uniform(0.5, 1.5, (ocp.n_phases, S))
+    p = torch.tensor((w / w.sum(axis=1, keepdims=True)).ravel(), device=dev)
+    lam = torch.tensor(rng.standard_normal((B, o.n_g)), device=dev)
+    sig = torch.tensor(rng.uniform(0.5, 1.5, B), device=dev)
+
+    def outputs(fill):
+        mk = lambda *s: torch.full(s, fill, dtype=torch.float64, device=dev)
+        return dict(f=mk(B), g=mk(B, o.n_g), grad_f=mk(B, o.n_z), jac_val=mk(B, o.nnz_jac), hess_val=mk(B, o.nnz_hess))
+
+    ref, ref_fg = outputs(0.0), outputs(0.0)
+    full = MPX_F | MPX_G | MPX_GRAD | MPX_JAC | MPX_HESS
+    o.eval_device(MPX_F | MPX_G | MPX_GRAD | MPX_JAC, B, Z, p, 0, None, None, ref["f"], ref["g"], ref["grad_f"], ref["jac_val"], None)
+    o.eval_device(MPX_HESS, B, Z, p, 0, lam, sig, None, None, None, None, ref["hess_val"])
+    o.eval_device(MPX_F | MPX_G, B, Z, p, 0, None, None, ref_fg["f"], ref_fg["g"], None, None, None)  # the values-only kernels
+    o.sync()
+    ev = D.SegmentShardedEvaluator(o)
+    assert (ev.rank, ev.world) == (rank, world)
+    _, cuts = o.shard_info(MPX_JAC)
+    assert cuts[-1] == o.n_tiles and (np.diff(cuts) > 0).all(), cuts  # every rank got tiles
+    out = outputs(float("nan"))
+    ev.eval(full, B, Z, p, lam, sig, **out)
+    o.sync()
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), (case, rank, k, float((out[k] - ref[k]).abs().max()))
+    # partial masks: only g (MODE_FG) and only jac values
+    out2 = outputs(float("nan"))
+    ev.eval(MPX_F | MPX_G, B, Z, p, f=out2["f"], g=out2["g"])
+    ev.eval(MPX_JAC, B, Z, p, jac_val=out2["jac_val"])
+    o.sync()
+    for k, want in (("g", ref_fg["g"]), ("f", ref_fg["f"]), ("jac_val", ref["jac_val"])):
+        assert torch.equal(out2[k], want), (case, rank, "partial mask", k, float((out2[k] - want).abs().max()))
+    ev.close()
+    out3 = outputs(float("nan"))  # back to a plain context
+    o.eval_device(MPX_F | MPX_G | MPX_GRAD | MPX_JAC, B, Z, p, 0, None, None, out3["f"], out3["g"], out3["grad_f"], out3["jac_val"], None)
+    o.sync()
+    assert torch.equal(out3["g"], ref["g"]) and torch.equal(out3["jac_val"], ref["jac_val"])
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+@pytest.mark.parametrize("case,world", [("vdp_mixed", 2), ("schwartz", 3), ("kitchen_sink", 2), ("hyper_sensitive", 2)])
+def test_segment_sharded_evaluator_under_torch_distributed(case, world):
+    import torch.multiprocessing as tmp
+
+    port = _free_port()
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, f"rank process exited with {p.exitcode}"
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(r, "ok") for r in range(world)]
