@@ -8,12 +8,20 @@ values.  One *step* = one fused launch sequence over a batch of B evaluation poi
 already resident in HBM (``mpx_eval_device``).  ``value`` = evaluations of all ranks / wall time.
 
 Multi-GPU (``--gpus N`` under torch.distributed.run): evaluation points are independent, so each
-rank processes its own batch of B points -- no data-path collective; weak scaling.
+rank processes its own batch of B points -- no data-path collective; weak scaling.  The ``*-shard``
+workloads instead split the SEGMENTS of every evaluation over the ranks (contiguous tile
+ranges per rank, one RCCL all-gather of the owned residual / Jacobian runs per evaluation, boundary pass
+on every rank; ``mpopt_amd.distributed.SegmentShardedEvaluator``): total work is fixed, strong scaling.
 
 Also on the JSON line:
   roofline      algorithmic bytes of the dominant (node) kernel / its HIP-event duration vs 8 TB/s
   cpu_baseline  the C oracle (oracle/mpopt_oracle.c, a scalar port of the reference algorithm)
                 timed on one host core on a bounded sample of the same workload (rank 0, N=1 only)
+  ipopt_iter    the second half of BASELINE.json's metric: oracle wall-clock per IPOPT iteration at B=1 through
+                HOST pointers (the CasADi-convention entry points nlp_g / nlp_grad_f / nlp_jac_g / nlp_hess_l of
+                libmpx.so, values in compressed-column order, caller arrays page-locked on first sight), with the
+                reference's recorded call mix 1.15 nlp_g + nlp_grad_f + nlp_jac_g + nlp_hess_l
+                (docs/source/notebooks/moon_lander.ipynb:192-198), next to the CPU port for the same mix
 """
 import argparse
 import json
@@ -40,6 +48,121 @@ def make_points(oracle, mpo, bounds, B, seed):
     return np.minimum(np.maximum(Z, bounds["lbx"][None, :]), bounds["ubx"][None, :])
 
 
+def ipopt_iter_report(builder, S, P, scheme, cnames, scale_t, midu, dev_id, seconds=0.6):
+    """Oracle time per IPOPT iteration at B=1, host pointers, through the nlp_* C entry points (ctypes: ~1 us per call
+    of overhead included), and the CPU port for the same call mix.  Returns a dict for the bench line."""
+    import ctypes
+
+    import mpopt_amd as M
+    from mpopt_amd import mp, _lib
+    from oracle.c_oracle import COracle
+
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, P, scheme, device=dev_id)
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    L = _lib.lib()
+    rng = np.random.default_rng(20260928)
+    z = np.ascontiguousarray(make_points(o, mpo, bounds, 1, 20260928)[0])
+    p = np.full(o.n_p, 1.0 / S)
+    lam, sig = rng.standard_normal(o.n_g), np.array([1.0])
+    f, g, gr = np.zeros(1), np.zeros(o.n_g), np.zeros(o.n_z)
+    jv, hv = np.zeros(max(o.nnz_jac, 1)), np.zeros(max(o.nnz_hess, 1))
+    o.make_current()
+    L.mpx_current_pin_buffers(1)
+
+    def call(fn, ins, outs):
+        arg = (ctypes.c_void_p * len(ins))(*[a.ctypes.data for a in ins])
+        res = (ctypes.c_void_p * len(outs))(*[a.ctypes.data for a in outs])
+        fun = getattr(L, fn)
+        for _ in range(20):
+            assert fun(arg, res, None, None, 0) == 0
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                fun(arg, res, None, None, 0)
+            n += 20
+        return (time.perf_counter() - t0) / n * 1e6
+
+    gpu = {"nlp_f": call("nlp_f", [z, p], [f]), "nlp_g": call("nlp_g", [z, p], [g]), "nlp_grad_f": call("nlp_grad_f", [z, p], [f, gr]),
+           "nlp_jac_g": call("nlp_jac_g", [z, p], [g, jv]), "nlp_hess_l": call("nlp_hess_l", [z, p, sig, lam], [hv])}
+    L.mpx_current_pin_buffers(0)
+    # parity of what was timed: the CCS-ordered values against the CPU port on the same point
+    C = COracle(cnames, S, P, scheme, scale_t=scale_t, midu=midu)
+    c = C.eval(z, p)
+    assert np.abs(c["g"] - g).max() < 1e-9 * max(1.0, np.abs(c["g"]).max())
+    import scipy.sparse as sp
+
+    perm, colind = o.ccs_perm("jac")
+    jr, jc = o.jac_pattern()
+    Jg = sp.coo_matrix((jv[:o.nnz_jac], (jr[perm], jc[perm])), shape=(o.n_g, o.n_z)).tocsr()
+    Jc = sp.coo_matrix((c["jac_val"], (c["jac_row"], c["jac_col"])), shape=(o.n_g, o.n_z)).tocsr()
+    assert abs(Jg - Jc).max() < 1e-9 * max(1.0, abs(Jc).max())
+    cpu = {k: C.time_fn(k, z[None, :], p, 1.0, lam, seconds) * 1e6 for k in gpu}
+    o.close()
+    mix = lambda d: 1.15 * d["nlp_g"] + d["nlp_grad_f"] + d["nlp_jac_g"] + d["nlp_hess_l"]
+    return {"us_per_iter": mix(gpu), "cpu_port_us_per_iter": mix(cpu), "speedup_vs_cpu_port": mix(cpu) / mix(gpu),
+            "per_call_us": {k: round(v, 2) for k, v in gpu.items()}, "cpu_port_per_call_us": {k: round(v, 2) for k, v in cpu.items()},
+            "n_z": o.n_z, "n_g": o.n_g, "nnz_jac": o.nnz_jac, "nnz_hess": o.nnz_hess}
+
+
+def segment_shard_report(dev, dev_id, rank, world, backend, B=4, K=20):
+    """Secondary measurement attached to the default line when N > 1 (so that the driver's --gpus 2/4/8 runs exercise RCCL on
+    the path): configs[2] (Van der Pol 2000 x [3,30,3], CGL), the segments of every evaluation sharded over the
+    ranks -- node kernels on this rank's tiles, ONE all_gather_into_tensor of the owned runs, boundary pass on every rank --
+    against the same evaluation done by one rank alone, with a bitwise comparison of the two results on every rank."""
+    import torch.distributed as dist
+
+    import mpopt_amd as M
+    from mpopt_amd import mp, distributed as mpd
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC
+    import problems
+
+    builder, S, P, scheme = problems.BENCH_CASES[1]
+    mpo = mp.mpopt(builder(mp, M.math), S, P, scheme, device=dev_id)
+    if rank == 0:
+        nlp, bounds = mpo.create_nlp()
+    dist.barrier()
+    if rank != 0:
+        nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    o.set_stream(torch.cuda.current_stream().cuda_stream)
+    Z = torch.tensor(make_points(o, mpo, bounds, B, 20260928), device=dev)
+    p = torch.tensor(np.full(o.n_p, 1.0 / S), device=dev)
+    mk = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
+    mask = MPX_F | MPX_G | MPX_GRAD | MPX_JAC
+    ref = (mk(B), mk(B, o.n_g), mk(B, o.n_z), mk(B, o.nnz_jac))
+    out = tuple(torch.full_like(t, float("nan")) for t in ref)
+
+    def timed(fn):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        return mpd.max_over_ranks(time.perf_counter() - t0, device=dev if backend == "nccl" else None) / K
+
+    t_one = timed(lambda: o.eval_device(mask, B, Z, p, 0, None, None, *ref, None))
+    ev = mpd.SegmentShardedEvaluator(o, rank, world)
+    t_shard = timed(lambda: ev.eval(mask, B, Z, p, None, None, *out, None))
+    same = all(torch.equal(a, b) for a, b in zip(out, ref))
+    flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev if backend == "nccl" else None)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    n, cuts = o.shard_info(mask)
+    ev.close()
+    o.close()
+    return {"workload": "Van der Pol 2000 x [3,30,3] CGL (configs[2]), f+g+grad_f+jac_g, segments of every evaluation sharded over the ranks",
+            "n_gpus": world, "batch": B, "steps": K, "backend": backend, "ms_per_step_sharded": t_shard * 1e3, "ms_per_step_one_rank_alone": t_one * 1e3,
+            "evals_per_s_sharded": B / t_shard, "exchange_bytes_per_rank_per_step": int(n) * B * 8, "tiles_per_rank": np.diff(cuts).tolist(),
+            "bit_identical_to_unsharded_on_every_rank": bool(flag.item() == 1.0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,7 +171,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="evaluation points per GPU per step")
     ap.add_argument("--segments", type=int, default=1000)
     ap.add_argument("--degree", type=int, default=5)
-    ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config2-hess", "adaptive-fgj"],
+    ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config2-hess", "adaptive-fgj", "config3-shard", "config4-shard"],
                     help="default: the metric's configuration (BASELINE configs[1], f+g+grad_f+jac_g).  The others are "
                          "secondary reports (configs[4]: nlp_hess_l on hypersensitive 4000x3; configs[2]: mixed-degree grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -84,14 +207,20 @@ def main():
 
     S, P, B, K, W = args.segments, args.degree, args.batch, args.steps, args.warmup
     hess_mode = args.workload.endswith("hess")
+    shard = args.workload.endswith("-shard")
     scheme, builder, label = "LGR", problems.moon_lander, f"moon-lander OCP, n_segments={S}, poly_orders={P}, LGR (BASELINE configs[1])"
     if args.workload == "config5-hess":
         builder, S, P, scheme = problems.BENCH_CASES[3]
         label = "hypersensitive OCP, n_segments=4000, poly_orders=3, LGR (BASELINE configs[4])"
-    elif args.workload == "config3-fgj":
+    elif args.workload in ("config3-fgj", "config3-shard"):
         builder, S, P, scheme = problems.BENCH_CASES[1]
         B = min(B, 512)
         label = "Van der Pol OCP, n_segments=2000, poly_orders=[3,30,3]*, CGL (BASELINE configs[2])"
+    elif args.workload == "config4-shard":
+        builder, S, P, scheme = problems.BENCH_CASES[2]
+        label = "two-phase Schwartz OCP, 500 segments per phase, poly_orders=3, LGL (BASELINE configs[3])"
+    if shard:  # every rank evaluates the SAME points, each its share of the segments
+        B = min(B, 16) if args.batch == 4096 else B
     adaptive = args.workload == "adaptive-fgj"
     if adaptive:  # widths as decision variables, assembled context (point kernels + gather)
         S, P = 20, 5
@@ -107,7 +236,10 @@ def main():
     o = nlp["oracle"]
     o.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    Zh = make_points(o, mpo, bounds, B, 20260928 + rank)
+    Zh = make_points(o, mpo, bounds, B, 20260928 + (0 if shard else rank))
+    ev = None
+    if shard:
+        ev = mpd.SegmentShardedEvaluator(o, rank, world)
     Z = torch.tensor(Zh, device=dev)
     p = torch.tensor(np.full(max(o.n_p, 1), 1.0 / S), device=dev)
     f = torch.empty(B, dtype=torch.float64, device=dev)
@@ -125,13 +257,19 @@ def main():
         jv = hv
 
     def step():
-        if hess_mode:
+        if shard:
+            ev.eval(mask, B, Z, p, None, None, f, g, gr, jv, None)
+        elif hess_mode:
             o.eval_device(mask, B, Z, p, 0, lam, sig, None, None, None, None, hv)
         else:
             o.eval_device(mask, B, Z, p, 0, None, None, f, g, gr, jv, None)
 
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.ramp_seconds:  # untimed; see --ramp-seconds
+    if shard:  # collectives inside the step: every rank must issue the same number of them (no time-based loop)
+        for _ in range(40):
+            step()
+        torch.cuda.synchronize()
+    while not shard and time.perf_counter() - t_ramp < args.ramp_seconds:  # untimed; see --ramp-seconds
         for _ in range(20):
             step()
         torch.cuda.synchronize()
@@ -157,7 +295,7 @@ def main():
     # secondary, opt-in mode (NOT the metric): only the (z,p)-dependent Jacobian entries are rewritten into
     # the resident buffers, which hold the grid constants from the full evaluations above
     extra = {}
-    if not hess_mode and not args.no_extras and not adaptive:
+    if not hess_mode and not args.no_extras and not adaptive and not shard:
         from mpopt_amd._lib import MPX_JAC_VARIABLE_ONLY
 
         torch.cuda.synchronize()
@@ -170,7 +308,7 @@ def main():
     # Also NOT the metric: the same kernel on freshly allocated output buffers.  Where the arrays land in physical
     # memory moves the node kernel by +-15 % within one process (not the box, not the TLB, pure-store
     # bandwidth per allocation is flat); `value` above is whatever the first allocation gave, this records the spread.
-    if not hess_mode and not args.no_extras and world == 1 and not adaptive:
+    if not hess_mode and not args.no_extras and world == 1 and not adaptive and not shard:
         sweep, hold = [], []
         for k in range(4):
             f2, g2 = torch.empty_like(f), torch.empty_like(g)
@@ -191,6 +329,13 @@ def main():
         del hold
         extra["placement_sweep_node_kernel_us"] = [round(v, 1) for v in sweep]
 
+    shard_extra = None
+    if world > 1 and args.workload == "config2-fgj" and not args.no_extras:
+        try:
+            shard_extra = segment_shard_report(dev, dev_id, rank, world, backend)
+        except Exception as e:  # never lose the headline line to the secondary measurement
+            shard_extra = {"error": repr(e)[:300]}
+
     # sanity: the timed outputs are real (finite, and f matches a host recomputation of one point)
     assert torch.isfinite(jv[0]).all() and (hess_mode or torch.isfinite(g[-1]).all())
 
@@ -201,28 +346,35 @@ def main():
         achieved = B * bytes_eval / kernel_s / 1e9
         out = {
             "metric": "NLP grad_f+jac_g evals/sec, 1000-seg LGR" if args.workload == "config2-fgj" else f"NLP evals/sec ({args.workload})",
-            "value": world * B * K / elapsed,
+            "value": (1 if shard else world) * B * K / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{label}; {'nlp_hess_l' if hess_mode else 'f+g+grad_f+jac_g'}, "
                                    f"{B} evaluation points per GPU per step, inputs resident in HBM",
                        "n_z": o.n_z, "n_g": o.n_g, "nnz_jac": o.nnz_jac, "batch_per_gpu": B,
-                       "parallelism": f"independent evaluation points x{world}"},
+                       "parallelism": (f"segments of every evaluation sharded over {world} rank(s), one all-gather of the owned runs per "
+                                       f"evaluation pass ({os.environ.get('MPX_DIST_BACKEND', 'nccl')})" if shard
+                                       else f"independent evaluation points x{world}")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS if not (shard and world > 1) else None, "traffic": None,
                          "kernel": "mpx_pts_jac + mpx_gather_kernel" if adaptive else f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*",
                          "kernel_us": kernel_s * 1e6,
                          "bytes_per_eval": bytes_eval, "evals_per_launch": B,
                          "algorithmic_bytes_per_launch": B * bytes_eval},
         }
+        if shard_extra is not None:
+            out["segment_shard"] = shard_extra
+        if "placement_sweep_node_kernel_us" in extra:  # the same kernel on four fresh allocations of the outputs + the timed one
+            fr = sorted(B * bytes_eval / (us * 1e-6) / 1e9 / HBM_PEAK_GBS for us in extra["placement_sweep_node_kernel_us"] + [kernel_s * 1e6])
+            out["roofline"].update(frac_placement_median=fr[len(fr) // 2], frac_placement_min=fr[0], frac_placement_max=fr[-1])
         if extra:
             out["extras"] = dict(extra, note="opt-in MPX_JAC_VARIABLE_ONLY (resident jac buffers keep the constant D / interpolation "
                                              "entries); not the metric: the headline rewrites every entry on every evaluation")
@@ -254,6 +406,12 @@ def main():
             ta, nthr = C.time_many_all_cores(Zh[:na], ph, ra)
             out["cpu_baseline_all_cores"] = {"value": na * ra / ta, "unit": "evals/s", "cores": nthr, "kind": "port",
                                              "sample": f"{na} evaluation points x {ra} passes, OpenMP over points, {ta:.1f} s"}
+            cfg2 = (problems.moon_lander, S, P, "LGR", ["moon_lander"], 1.0, [1])
+            cfg1 = (problems.moon_lander, 20, 3, "LGR", ["moon_lander"], 1.0, [1])
+            out["ipopt_iter"] = dict(ipopt_iter_report(*cfg2, dev_id), unit="us", config=f"moon lander {S}x{P} LGR (configs[1]), B=1, host pointers",
+                                     call_mix="1.15 nlp_g + nlp_grad_f + nlp_jac_g + nlp_hess_l (moon_lander.ipynb:192-198)")
+            out["ipopt_iter_config0"] = dict(ipopt_iter_report(*cfg1, dev_id, seconds=0.3), unit="us",
+                                             config="moon lander 20x3 LGR (configs[0]), B=1, host pointers")
             out["cpu_baseline"] = {"value": ns * reps / tt, "unit": "evals/s", "cores": 1, "kind": "port",
                                    "sample": f"{ns} of the same evaluation points x {reps} passes, oracle/mpopt_oracle.c "
                                              f"(gcc -O2, scalar, values only), {tt:.1f} s",

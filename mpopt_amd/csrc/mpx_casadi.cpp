@@ -130,6 +130,7 @@ extern "C" const long long* nlp_f_sparsity_out(long long i) { return i == 0 ? C.
 extern "C" int nlp_f(const double** arg, double** res, long long*, double*, int) {
   if (!C.ctx) return 1;
   double f;
+  if (C.pin) pin(arg ? arg[0] : 0, C.sz.n_z);
   if (mpx_eval(C.ctx, MPX_F, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, &f, 0, 0, 0, 0)) return 1;
   if (res && res[0]) res[0][0] = f;
   return 0;

@@ -113,6 +113,18 @@ struct mpx_ctx {
   std::vector<int32_t> shard_ent_first[2];          // [world + 1] first entry of every rank
   int64_t shard_len[2] = {0, 0};                    // padded per-rank, per-point length of the exchange buffer (doubles)
   MpxShardEnt* d_shard_ent[2] = {nullptr, nullptr};
+  // page-locked host ranges this context knows (mpx_host_alloc / mpx_host_register) with their device-side aliases: a single
+  // evaluation whose arrays all lie in such ranges runs zero-copy (kernels read z and write the results straight over PCIe)
+  struct PinRange {
+    char* base;
+    size_t bytes;
+    char* dev;
+    bool owned;  // hipHostMalloc'ed by mpx_host_alloc (else registered caller memory)
+  };
+  std::vector<PinRange> pins;
+  double* h_scratch = nullptr;  // page-locked scalars of the zero-copy path: [f (B) | sigma (B)]
+  double* h_scratch_dev = nullptr;
+  size_t h_scratch_cap = 0;
   // host path: widths of the previous mpx_eval (IPOPT never changes p between oracle calls, so the
   // upload and the prefix-sum launch are skipped while p is unchanged)
   std::vector<double> last_p;

@@ -35,7 +35,10 @@ def init_from_env(backend=None):
         if not dist.is_initialized():
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
-            kw = {}
+            import datetime
+
+            # a mismatch between ranks should fail in minutes, not after the default half hour
+            kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("MPX_DIST_TIMEOUT", "300")))}
             if backend == "nccl":
                 torch.cuda.set_device(local_rank)
                 kw["device_id"] = torch.device("cuda", local_rank)

@@ -45,6 +45,9 @@ def lib():
         L.orc_ipopt_mix.restype = None
         L.orc_ipopt_mix.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_double] + [ctypes.c_void_p] * 7
+        L.orc_eval_fn.restype = None
+        L.orc_eval_fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_double] + [ctypes.c_void_p] * 7
         L.orc_eval_many.restype = None
         L.orc_eval_many.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 6
         _lib = L
@@ -123,6 +126,29 @@ class COracle:
         t = time.perf_counter()
         L.orc_ipopt_mix(self._h, Z.shape[0], int(reps), int(n_g_calls), *args)
         return time.perf_counter() - t
+
+    def time_fn(self, which, Z, p, sigma, lam_g, seconds=1.0):
+        """Seconds per call of ONE oracle function on one core: which in {"nlp_g", "nlp_grad_f", "nlp_jac_g", "nlp_hess_l", "nlp_f"},
+        cycling over the points Z, for about ``seconds`` of wall time."""
+        import time
+
+        L = lib()
+        code = {"nlp_g": 0, "nlp_grad_f": 1, "nlp_jac_g": 2, "nlp_hess_l": 3, "nlp_f": 4}[which]
+        Z, p, lam = np.ascontiguousarray(Z, float).reshape(-1, self.n_z), np.ascontiguousarray(p, float), np.ascontiguousarray(lam_g, float)
+        g, grad, vals = np.zeros(self.n_g), np.zeros(self.n_z), np.zeros(self.nnz)
+        cap = L.orc_hess_capacity(self._h)
+        hr, hc, hv = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap)
+        args = (Z.ctypes.data, p.ctypes.data, float(sigma), lam.ctypes.data, g.ctypes.data, grad.ctypes.data, vals.ctypes.data,
+                hr.ctypes.data, hc.ctypes.data, hv.ctypes.data)
+        n = Z.shape[0]
+        L.orc_eval_fn(self._h, code, n, 1, *args)
+        t = time.perf_counter()
+        L.orc_eval_fn(self._h, code, n, 1, *args)
+        one = max(time.perf_counter() - t, 1e-7)
+        reps = max(1, int(seconds / one))
+        t = time.perf_counter()
+        L.orc_eval_fn(self._h, code, n, reps, *args)
+        return (time.perf_counter() - t) / (reps * n)
 
     def time_many(self, Z, p, reps):
         """Wall seconds for ``reps`` passes of f+g+grad_f+jac_g over the points Z (values only)."""

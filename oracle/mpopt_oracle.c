@@ -667,6 +667,27 @@ int64_t orc_hess(const orc* o, const double* z, const double* p, double sigma, c
       for (int c = 0; c < nx; ++c) S1[r] |= F->m_dyn[c * nv + r];
       for (int s = 0; s < nv; ++s) S2[r * nv + s] = F->m2_psi[r * nv + s] | F->m2_chi[r * nv + s];
     }
+    /* node-independent pieces: scale factors, v -> y map (t feeds t0 and tf), structure of the y-block */
+    double jf[MAXV];
+    for (int r = 0; r < nx; ++r) jf[r] = 1.0 / o->sx[r];
+    for (int r = 0; r < nu; ++r) jf[nx + r] = 1.0 / o->su[r];
+    for (int r = 0; r < na; ++r) jf[it + 1 + r] = 1.0 / o->sa[r];
+    int ymap[MAXV][2], ycnt[MAXV];
+    for (int r = 0; r < nv; ++r) {
+      if (r < it) ymap[r][0] = r, ycnt[r] = 1;
+      else if (r == it) ymap[r][0] = it, ymap[r][1] = it + 1, ycnt[r] = 2;
+      else ymap[r][0] = r + 1, ycnt[r] = 1;
+    }
+    unsigned char Sy[MAXV * MAXV] = {0}, sgy[MAXV] = {0};
+    for (int r = 0; r < nv; ++r)
+      for (int m = 0; m < ycnt[r]; ++m) sgy[ymap[r][m]] |= S1[r];
+    for (int r = 0; r < nv; ++r)
+      for (int c = 0; c < nv; ++c)
+        for (int m = 0; m < ycnt[r]; ++m)
+          for (int n = 0; n < ycnt[c]; ++n) Sy[ymap[r][m] * ny + ymap[c][n]] |= S2[r * nv + c];
+    for (int m = 0; m < ny; ++m)
+      for (int n = 0; n < ny; ++n) Sy[m * ny + n] |= ((m == it || m == it + 1) && sgy[n]) | ((n == it || n == it + 1) && sgy[m]);
+    const deg_table* T = 0;
     for (int i = 0, s = 0; i < N; ++i) {
       if (o->seg[i] != s) {
         s = o->seg[i];
@@ -674,7 +695,7 @@ int64_t orc_hess(const orc* o, const double* z, const double* p, double sigma, c
         h = (tf - t0) / dtau * w[s];
       }
       const int pdeg = o->orders[s], k = o->pt[i];
-      const deg_table* T = tab(o, pdeg);
+      if (!T || T->deg != pdeg) T = tab(o, pdeg);
       const double t = t_seg0 + h * (T->tau[k] - o->tau0);
       const double theta = (t - t0) / (tf - t0), kap = w[s] / dtau, W = o->compW[i];
       double x[MAXV], u[MAXV], dyn[MAXV], pc[MAXV], L, ddyn[MAXV * MAXV], dpc[MAXV * MAXV], dL[MAXV];
@@ -686,52 +707,34 @@ int64_t orc_hess(const orc* o, const double* z, const double* p, double sigma, c
       for (int c = 0; c < nx; ++c) wd[c] = -lam[o->off_F[ph] + (int64_t)c * N + i] * o->sx[c];
       for (int j = 0; j < F->nc; ++j) wc[j] = lam[o->off_C[ph] + (int64_t)j * N + i];
       const double wL = sigma * W;
-      double Hp[MAXV * MAXV] = {0}, Hc[MAXV * MAXV] = {0}, g1[MAXV];
+      double Hp[MAXV * MAXV], Hc[MAXV * MAXV], g1[MAXV], Hy[MAXV * MAXV], gy[MAXV], yfac[MAXV][2];
+      memset(Hp, 0, nv * nv * sizeof(double));
+      memset(Hc, 0, nv * nv * sizeof(double));
+      memset(Hy, 0, ny * ny * sizeof(double));
+      memset(gy, 0, ny * sizeof(double));
       F->node_dd(x, u, t, a, wd, wc, wL, Hp, Hc);
       for (int r = 0; r < nv; ++r) {
         double v = F->m1_L[r] ? wL * dL[r] : 0.0;
         for (int c = 0; c < nx; ++c)
           if (F->m_dyn[c * nv + r]) v += wd[c] * ddyn[c * nv + r];
         g1[r] = v; /* psi' */
+        yfac[r][0] = jf[r];
       }
-      /* Jv: v_r depends on y_m with factor jf; t depends on t0 and tf */
-      double Hy[MAXV * MAXV] = {0};
-      unsigned char Sy[MAXV * MAXV] = {0};
-      double jf[MAXV];
-      for (int r = 0; r < nx; ++r) jf[r] = 1.0 / o->sx[r];
-      for (int r = 0; r < nu; ++r) jf[nx + r] = 1.0 / o->su[r];
-      for (int r = 0; r < na; ++r) jf[it + 1 + r] = 1.0 / o->sa[r];
-      /* map v index r -> list of (y index, factor) */
-      int ymap[MAXV][2], ycnt[MAXV];
-      double yfac[MAXV][2];
-      for (int r = 0; r < nv; ++r) {
-        if (r < it) ymap[r][0] = r, yfac[r][0] = jf[r], ycnt[r] = 1;
-        else if (r == it) {
-          ymap[r][0] = it, yfac[r][0] = (1 - theta) / o->st;
-          ymap[r][1] = it + 1, yfac[r][1] = theta / o->st;
-          ycnt[r] = 2;
-        } else ymap[r][0] = r + 1, yfac[r][0] = jf[r], ycnt[r] = 1;
-      }
-      double gy[MAXV] = {0}; /* Jv^T psi' */
-      unsigned char sgy[MAXV] = {0};
+      yfac[it][0] = (1 - theta) / o->st, yfac[it][1] = theta / o->st;
       for (int r = 0; r < nv; ++r)
-        for (int m = 0; m < ycnt[r]; ++m) gy[ymap[r][m]] += g1[r] * yfac[r][m], sgy[ymap[r][m]] |= S1[r];
+        for (int m = 0; m < ycnt[r]; ++m) gy[ymap[r][m]] += g1[r] * yfac[r][m]; /* Jv^T psi' */
       for (int r = 0; r < nv; ++r)
         for (int c = 0; c < nv; ++c) {
+          if (!S2[r * nv + c]) continue;
           const double v2 = h * Hp[r * nv + c] + Hc[r * nv + c];
           for (int m = 0; m < ycnt[r]; ++m)
-            for (int n = 0; n < ycnt[c]; ++n) {
-              Hy[ymap[r][m] * ny + ymap[c][n]] += v2 * yfac[r][m] * yfac[c][n];
-              Sy[ymap[r][m] * ny + ymap[c][n]] |= S2[r * nv + c];
-            }
+            for (int n = 0; n < ycnt[c]; ++n) Hy[ymap[r][m] * ny + ymap[c][n]] += v2 * yfac[r][m] * yfac[c][n];
         }
-      double dh[MAXV] = {0};
-      dh[it] = -kap / o->st, dh[it + 1] = kap / o->st;
-      for (int m = 0; m < ny; ++m)
-        for (int n = 0; n < ny; ++n) {
-          Hy[m * ny + n] += dh[m] * gy[n] + gy[m] * dh[n];
-          Sy[m * ny + n] |= ((m == it || m == it + 1) && sgy[n]) | ((n == it || n == it + 1) && sgy[m]);
-        }
+      const double dh0 = -kap / o->st, dh1 = kap / o->st; /* dh / d(t0_var, tf_var) */
+      for (int n = 0; n < ny; ++n) {
+        Hy[it * ny + n] += dh0 * gy[n], Hy[(it + 1) * ny + n] += dh1 * gy[n];
+        Hy[n * ny + it] += gy[n] * dh0, Hy[n * ny + it + 1] += gy[n] * dh1;
+      }
       /* emit the upper triangle; pairs inside (t0, tf, A) go to the corner */
       for (int m = 0; m < ny; ++m)
         for (int n = m; n < ny; ++n) {
@@ -829,5 +832,23 @@ void orc_ipopt_mix(const orc* o, int64_t n_points, int reps, int n_g_calls, cons
       orc_eval(o, z, p, &f, 0, grad, 0, 0, 0);
       orc_eval(o, z, p, &f, g, 0, 0, 0, vals);
       orc_hess(o, z, p, sigma, lam, hr, hc, hv);
+    }
+}
+
+/* One oracle function at a time, as CasADi exposes them: which = 0 nlp_g, 1 nlp_grad_f (f + grad_f), 2 nlp_jac_g (g + values),
+ * 3 nlp_hess_l, 4 nlp_f.  `reps` passes over `n_points` points; the caller clocks it. */
+void orc_eval_fn(const orc* o, int which, int64_t n_points, int reps, const double* Z, const double* p, double sigma, const double* lam,
+                 double* g, double* grad, double* vals, int32_t* hr, int32_t* hc, double* hv) {
+  double f;
+  for (int r = 0; r < reps; ++r)
+    for (int64_t b = 0; b < n_points; ++b) {
+      const double* z = Z + b * o->n_z;
+      switch (which) {
+        case 0: orc_eval(o, z, p, &f, g, 0, 0, 0, 0); break;
+        case 1: orc_eval(o, z, p, &f, 0, grad, 0, 0, 0); break;
+        case 2: orc_eval(o, z, p, &f, g, 0, 0, 0, vals); break;
+        case 3: orc_hess(o, z, p, sigma, lam, hr, hc, hv); break;
+        default: orc_eval(o, z, p, &f, 0, 0, 0, 0, 0); break;
+      }
     }
 }
