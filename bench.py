@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="evaluation points per GPU per step")
     ap.add_argument("--segments", type=int, default=1000)
     ap.add_argument("--degree", type=int, default=5)
-    ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config2-hess", "adaptive-fgj", "config3-shard", "config4-shard"],
+    ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config2-hess", "adaptive-fgj", "config3-shard", "config4-shard", "config5-loop"],
                     help="default: the metric's configuration (BASELINE configs[1], f+g+grad_f+jac_g).  The others are "
                          "secondary reports (configs[4]: nlp_hess_l on hypersensitive 4000x3; configs[2]: mixed-degree grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -209,7 +209,8 @@ def main():
     hess_mode = args.workload.endswith("hess")
     shard = args.workload.endswith("-shard")
     scheme, builder, label = "LGR", problems.moon_lander, f"moon-lander OCP, n_segments={S}, poly_orders={P}, LGR (BASELINE configs[1])"
-    if args.workload == "config5-hess":
+    loop5 = args.workload == "config5-loop"
+    if args.workload in ("config5-hess", "config5-loop"):
         builder, S, P, scheme = problems.BENCH_CASES[3]
         label = "hypersensitive OCP, n_segments=4000, poly_orders=3, LGR (BASELINE configs[4])"
     elif args.workload in ("config3-fgj", "config3-shard"):
@@ -221,6 +222,9 @@ def main():
         label = "two-phase Schwartz OCP, 500 segments per phase, poly_orders=3, LGL (BASELINE configs[3])"
     if shard:  # every rank evaluates the SAME points, each its share of the segments
         B = min(B, 16) if args.batch == 4096 else B
+    if loop5:  # SURVEY 8(d) config-5 protocol: widths ~ Dirichlet(1), 5 outer iterations, device resident, one context
+        B = min(B, 512) if args.batch == 4096 else B
+        hess_mode = True
     adaptive = args.workload == "adaptive-fgj"
     if adaptive:  # widths as decision variables, assembled context (point kernels + gather)
         S, P = 20, 5
@@ -256,8 +260,23 @@ def main():
         hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
         jv = hv
 
+    if loop5:
+        mids = [(mpo.collocation._taus_fn(d)[:-1] + mpo.collocation._taus_fn(d)[1:]) / 2 for d in mpo.poly_orders]
+        plan = o.residual_plan(0, mids)
+        p0 = torch.tensor(np.random.default_rng(20260928 + rank).dirichlet(np.ones(S), B), device=dev)
+        pa, pb = torch.empty_like(p0), torch.empty_like(p0)
+        R = torch.empty(B, plan.n_pts, ocp.nx, dtype=torch.float64, device=dev)
+
     def step():
-        if shard:
+        if loop5:
+            pa.copy_(p0)
+            cur, nxt = pa, pb
+            for _ in range(5):
+                plan.eval_device(B, Z, cur, p_per_point=1, resid=R)
+                o.eval_device(mask | 256, B, Z, cur, 1, lam, sig, None, None, None, None, hv)  # MPX_WIDTHS_UNCHANGED: same p as the residual call
+                o.equal_area_widths_device(0, B, plan.n_pts, R, cur, nxt, damping=0.4, p_in_per_point=1)
+                cur, nxt = nxt, cur
+        elif shard:
             ev.eval(mask, B, Z, p, None, None, f, g, gr, jv, None)
         elif hess_mode:
             o.eval_device(mask, B, Z, p, 0, lam, sig, None, None, None, None, hv)
@@ -343,11 +362,15 @@ def main():
         n_buckets = 1 if adaptive else len(set(int(d) for d in mpo.poly_orders))
         kernel_s = node_ms / 1e3 / max(n_launch // n_buckets, 1)  # all node-kernel launches of one step
         bytes_eval = o.bytes_hess if hess_mode else o.bytes_fgj
+        if loop5:  # one step = 5 outer iterations of (residuals, hess_l, width update); the roofline object covers the whole loop
+            n_pts = plan.n_pts
+            bytes_eval = 5 * (o.bytes_hess + 8 * (o.n_z + 2 * o.n_p + n_pts * ocp.nx) + 8 * (n_pts * ocp.nx + 2 * o.n_p))
+            kernel_s = elapsed / K
         achieved = B * bytes_eval / kernel_s / 1e9
         out = {
             "metric": "NLP grad_f+jac_g evals/sec, 1000-seg LGR" if args.workload == "config2-fgj" else f"NLP evals/sec ({args.workload})",
-            "value": (1 if shard else world) * B * K / elapsed,
-            "unit": "evals/s",
+            "value": (1 if shard else world) * B * K * (5 if loop5 else 1) / elapsed,
+            "unit": "point-iterations/s (one = residuals at the mid-points + nlp_hess_l + equal-area width update)" if loop5 else "evals/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
@@ -357,7 +380,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{label}; {'nlp_hess_l' if hess_mode else 'f+g+grad_f+jac_g'}, "
+            "config": {"workload": f"{label}; {'h-adaptive loop, widths ~ Dirichlet(1), 5 outer iterations per step (SURVEY 8(d)), ' if loop5 else ''}"
+                                   f"{'nlp_hess_l' if hess_mode else 'f+g+grad_f+jac_g'}, "
                                    f"{B} evaluation points per GPU per step, inputs resident in HBM",
                        "n_z": o.n_z, "n_g": o.n_g, "nnz_jac": o.nnz_jac, "batch_per_gpu": B,
                        "parallelism": (f"segments of every evaluation sharded over {world} rank(s), one all-gather of the owned runs per "
@@ -365,7 +389,8 @@ def main():
                                        else f"independent evaluation points x{world}")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if not (shard and world > 1) else None, "traffic": None,
-                         "kernel": "mpx_pts_jac + mpx_gather_kernel" if adaptive else f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*",
+                         "kernel": ("whole loop: mpx_resid_0_3 + mpx_node_hess_0_3 + mpx_boundary_hess + mpx_equal_area_kernel (wall time of the step)" if loop5
+                                    else "mpx_pts_jac + mpx_gather_kernel" if adaptive else f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*"),
                          "kernel_us": kernel_s * 1e6,
                          "bytes_per_eval": bytes_eval, "evals_per_launch": B,
                          "algorithmic_bytes_per_launch": B * bytes_eval},

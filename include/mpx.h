@@ -71,6 +71,9 @@ extern "C" {
                              permutation pass after the evaluation (~3 us), so that the nlp_jac_g / nlp_hess_l
                              entry points need no host-side reordering.  Not combinable with
                              MPX_JAC_VARIABLE_ONLY / MPX_BOUNDARY_ONLY. */
+#define MPX_WIDTHS_UNCHANGED 256 /* mpx_eval_device only: `p`, p_per_point and batch are those of the previous device-pointer call
+                                    of this context (mpx_eval_device or mpx_resid_eval_device) and the memory behind `p` has not
+                                    changed since: the prefix sums kept on the device are reused.  The caller's assertion. */
 #define MPX_BOUNDARY_ONLY 32 /* skip the node kernels: finish reductions / terminal / linking rows only
                                 (second half of a segment-sharded evaluation, see mpx_set_tile_range) */
 
@@ -254,6 +257,16 @@ int mpx_resid_eval(mpx_ctx* ctx, mpx_resid_plan* plan, int64_t batch, const doub
 int mpx_resid_eval_device(mpx_ctx* ctx, mpx_resid_plan* plan, int64_t batch, const double* z, const double* p,
                           int p_per_point, double* ti, double* xi, double* ui, double* dxi, double* dui, double* dyn,
                           double* resid);
+
+/* Width update of the h-adaptive refinement loop on the device, batched: the equal-area rule
+ * mpopt_h_adaptive.get_roots_wrt_equal_area (mpopt.py:2636-2659) applied to r_i = || resid[b][i][0..nx) ||_2, i < n_pts (the
+ * residual samples of the phase in segment order, e.g. the `resid` output of mpx_resid_eval_device; mpopt.py:2620-2633),
+ * followed by the reference's damped update (mpopt.py:2587-2590):
+ *     p_out[b][phase*S + s] = damping * new_width_s + (1 - damping) * p_in[(b)][phase*S + s]        (the reference: 0.4)
+ * p_in is [n_p] (p_in_per_point == 0) or [batch][n_p]; p_out is [batch][n_p]; other phases' entries are not touched.
+ * Device pointers, asynchronous on the context's stream. */
+int mpx_equal_area_widths_device(mpx_ctx* ctx, int phase, int64_t batch, int64_t n_pts, const double* resid, const double* p_in,
+                                 int p_in_per_point, double* p_out, double damping);
 
 /* ---------------------------------------------------------------------------------------------
  * Assembled contexts: transcriptions whose NLP has the form

@@ -27,6 +27,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)
 
 MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MPX_BOUNDARY_ONLY, MPX_JAC_VARIABLE_ONLY, MPX_CCS_ORDER = 1, 2, 4, 8, 16, 32, 64, 128
+MPX_WIDTHS_UNCHANGED = 256
 SCHEMES = {"LGR": 0, "LGL": 1, "CGL": 2, "LG": 3}
 SCHEME_EQUI = 4
 
@@ -184,6 +185,8 @@ SYMBOLS = {
     "mpx_resid_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_resid_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mpx_resid_eval_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7),
+    "mpx_equal_area_widths_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_double]),
     "mpx_timer_start": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_timer_stop": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "mpx_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

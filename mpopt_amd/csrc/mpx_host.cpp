@@ -514,31 +514,36 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   return MPX_OK;
 }
 
-// exclusive prefix sums of the segment widths (the reference's running t_seg0, mpopt.py:192):
-// one workgroup per (width vector, phase); each lane scans a contiguous chunk, the chunk totals are
-// scanned by shuffles within a wavefront and through LDS across the four wavefronts.
+// exclusive prefix sums of the segment widths (the reference's running t_seg0, mpopt.py:192): one workgroup per
+// (width vector, phase).  Each of the four wavefronts owns a contiguous quarter and walks it 64 elements at a time with
+// coalesced loads: first the quarter totals (so that every wavefront knows its starting offset), then the scan proper --
+// shuffle scan inside the 64 elements, running carry across them.  Fixed order: results do not depend on anything else.
 __global__ __launch_bounds__(256) void mpx_prefix_kernel(const double* __restrict__ w, double* __restrict__ wcum, int S) {
   __shared__ double wave_tot[4];
-  const double* a = w + (int64_t)blockIdx.x * S;
-  double* o = wcum + (int64_t)blockIdx.x * S;
-  const int l = threadIdx.x, chunk = (S + 255) / 256;
-  const int s0 = l * chunk, s1 = min(S, s0 + chunk);
+  const double* __restrict__ a = w + (int64_t)blockIdx.x * S;
+  double* __restrict__ o = wcum + (int64_t)blockIdx.x * S;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int quarter = ((S + 3) / 4 + 63) / 64 * 64;  // multiple of 64: every step of a wavefront is one aligned run
+  const int q0 = wave * quarter, q1 = min(S, q0 + quarter);
   double tot = 0;
-  for (int s = s0; s < s1; ++s) tot += a[s];
-  double inc = tot;  // inclusive scan of the lane totals within the wavefront
+  for (int s = q0 + lane; s < q1; s += 64) tot += a[s];
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    double v = __shfl_up(inc, d, 64);
-    if ((l & 63) >= d) inc += v;
-  }
-  if ((l & 63) == 63) wave_tot[l >> 6] = inc;
-  __syncthreads();  // (the shuffle below is executed by all lanes: no divergence before it)
-  double off = __shfl_up(inc, 1, 64);  // exclusive prefix of the lane inside its wavefront
-  if ((l & 63) == 0) off = 0;
-  for (int q = 0; q < (l >> 6); ++q) off += wave_tot[q];
-  for (int s = s0; s < s1; ++s) {
-    o[s] = off;
-    off += a[s];
+  for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d, 64);
+  if (lane == 0) wave_tot[wave] = tot;
+  __syncthreads();
+  double carry = 0;
+  for (int q = 0; q < wave; ++q) carry += wave_tot[q];
+  for (int s0 = q0; s0 < q1; s0 += 64) {
+    const int s = s0 + lane;
+    const double v = s < q1 ? a[s] : 0.0;
+    double inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double u = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += u;
+    }
+    if (s < q1) o[s] = carry + (inc - v);
+    carry += __shfl(inc, 63, 64);
   }
 }
 
@@ -731,7 +736,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
     fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
-    fr(c->d_gmap), fr(c->d_qmap), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]);
+    fr(c->d_gmap), fr(c->d_qmap), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1278,14 +1283,157 @@ extern "C" int mpx_shard_unpack(mpx_ctx* c, int mask, int64_t batch, const doubl
   return shard_copy(c, mask, batch, vals, const_cast<double*>(recv), 1);
 }
 
+
+// ---- h-adaptive width update on the device ---------------------------------------------------
+// Equal-area rule of the reference (mpopt_h_adaptive.get_roots_wrt_equal_area, mpopt.py:2636-2659, fed with the per-point
+// 2-norms of the dynamics residuals, mpopt.py:2620-2633) and its damped update (mpopt.py:2587-2590), batched: one workgroup
+// per evaluation point, fixed-order block scan of the trapezoid areas, one binary search per new segment boundary.
+namespace {
+// (1024 lanes per workgroup: the cumulative areas of one evaluation point fill most of a compute unit's LDS, so a workgroup is
+// alone on its CU and its own 16 wavefronts are all there is to hide load and LDS latency: 4 wavefronts measured 2.3x slower)
+#define MPX_EA_THREADS 1024
+__global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const double* __restrict__ resid, int64_t n, int nx, const double* __restrict__ p_in,
+                                                             double* __restrict__ p_out, int64_t p_stride_in, int64_t p_stride_out, int S, int seg_off,
+                                                             double damping, double* __restrict__ cum_all, int cum_in_lds, long long* dbg) {
+#define MPX_EA_STAMP(k) if (dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) dbg[k] = wall_clock64()
+  extern __shared__ double s_dyn[];
+  MPX_EA_STAMP(0);  // cum_in_lds: [n] cumulative areas, then [S + 1] boundaries; else only the boundaries
+  constexpr int NT = MPX_EA_THREADS;
+  __shared__ double wave_tot[NT / 64];
+  __shared__ double total;
+  const int l = threadIdx.x;
+  const double* __restrict__ r = resid + (int64_t)blockIdx.x * n * nx;
+  double* __restrict__ cum = cum_in_lds ? s_dyn : cum_all + (int64_t)blockIdx.x * n;  // cum[i] = area of the first i trapezoids
+  double* __restrict__ pos = cum_in_lds ? s_dyn + n : s_dyn;
+  auto norm2 = [&](int64_t i) {
+    if (nx == 1) return fabs(r[i]);
+    double q = 0;
+    for (int a = 0; a < nx; ++a) q = fma(r[i * nx + a], r[i * nx + a], q);
+    return sqrt(q);
+  };
+  const int64_t m = n - 1, chunk = (m + NT - 1) / NT;  // m trapezoids; lane l owns the trapezoids [i0, i1)
+  const int64_t i0 = l * chunk < m ? l * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
+  if (cum_in_lds) {  // the residual norms enter LDS with coalesced loads; the scan below turns them into cumulative areas in place
+    // (one workgroup per compute unit at this LDS footprint: nothing else hides the load latency, so eight loads are in flight per lane)
+    for (int64_t i = l; i < n; i += 8 * NT) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = i + k * NT < n ? norm2(i + k * NT) : 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i + k * NT < n) cum[i + k * NT] = v[k];
+    }
+    __syncthreads();
+  }
+  MPX_EA_STAMP(1);
+  auto sample = [&](int64_t i) { return cum_in_lds ? cum[i] : norm2(i); };
+  const double first = i0 < i1 ? sample(i0) : 0.0;  // (read before the in-place pass of the neighbouring lane overwrites it)
+  double tot = 0, prev = first;
+  for (int64_t i = i0; i < i1; ++i) {
+    const double nxt = sample(i + 1);
+    tot += 0.5 * (prev + nxt);
+    prev = nxt;
+  }
+  double inc = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    double v = __shfl_up(inc, d, 64);
+    if ((l & 63) >= d) inc += v;
+  }
+  if ((l & 63) == 63) wave_tot[l >> 6] = inc;
+  __syncthreads();
+  double off = __shfl_up(inc, 1, 64);
+  if ((l & 63) == 0) off = 0;
+  for (int q = 0; q < (l >> 6); ++q) off += wave_tot[q];
+  if (l == NT - 1) total = off + tot;
+  __syncthreads();
+  MPX_EA_STAMP(2);
+  const double inv = 1.0 / total;
+  if (l == 0) cum[0] = 0.0;  // (lane 0 holds sample 0 in `first`)
+  prev = first;
+  for (int64_t i = i0; i < i1; ++i) {
+    const double nxt = sample(i + 1);  // position i + 1 is overwritten two lines down, by this lane only
+    off += 0.5 * (prev + nxt);
+    prev = nxt;
+    cum[i + 1] = i + 1 == m ? 1.0 : off * inv;  // (the reference divides by the last entry: exactly 1 there)
+  }
+  __syncthreads();
+  MPX_EA_STAMP(3);
+  if (l == 0) pos[0] = 0.0;
+  // lane l owns a contiguous run of boundaries: one binary search for the first, then a forward walk (targets are monotone)
+  const int per = (S + NT - 1) / NT, s0 = l * per < S ? l * per : S, s1 = s0 + per < S ? s0 + per : S;
+  int64_t j = 1;
+  for (int s = s0; s < s1; ++s) {
+    const double target = (double)(s + 1) / (double)S;
+    if (s == s0) {
+      int64_t lo = 0, hi = m;  // first j with cum[j] >= target
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cum[mid] >= target) hi = mid; else lo = mid + 1;
+      }
+      j = lo < 1 ? 1 : lo;
+    } else {
+      while (j < m && cum[j] < target) ++j;
+    }
+    pos[s + 1] = ((double)(j - 1) + (target - cum[j - 1]) / (cum[j] - cum[j - 1])) / (double)m;
+  }
+  __syncthreads();
+  MPX_EA_STAMP(4);
+  const double* __restrict__ pi = p_in + (int64_t)blockIdx.x * p_stride_in + seg_off;
+  double* __restrict__ po = p_out + (int64_t)blockIdx.x * p_stride_out + seg_off;
+  for (int s = l; s < S; s += 8 * NT) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = s + k * NT < S ? pi[s + k * NT] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (s + k * NT < S) po[s + k * NT] = damping * (pos[s + k * NT + 1] - pos[s + k * NT]) + (1.0 - damping) * v[k];
+  }
+  MPX_EA_STAMP(5);
+#undef MPX_EA_STAMP
+}
+}  // namespace
+
+extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch, int64_t n_pts, const double* resid, const double* p_in,
+                                            int p_in_per_point, double* p_out, double damping) {
+  if (!c || !resid || !p_in || !p_out || batch < 1 || n_pts < 2) return fail(c, MPX_ERR_INVALID, "mpx_equal_area_widths_device: bad arguments");
+  if (c->kind != 0 || phase < 0 || phase >= c->n_phases) return fail(c, MPX_ERR_INVALID, "mpx_equal_area_widths_device: phase out of range");
+  if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "mpx_equal_area_widths_device: context has no device code; there is no CPU fallback");
+  HIPCHK(c, hipSetDevice(c->device));
+  // cumulative areas in LDS when they fit next to the S + 1 boundaries (150 of the 160 KB of a compute unit), else in HBM scratch
+  const size_t lds_all = (size_t)(n_pts + c->S + 1) * 8, lds_pos = (size_t)(c->S + 1) * 8;
+  const int in_lds = lds_all <= 150 * 1024;
+  if (lds_pos > 150 * 1024) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_equal_area_widths_device: more than 19199 segments per phase");
+  int rc;
+  if (!in_lds && (rc = reserve(c, c->ea_scratch, (size_t)(batch * n_pts)))) return rc;
+  const size_t lds = in_lds ? lds_all : lds_pos;
+  static long long* dbg = nullptr;
+  if (!dbg && getenv("MPX_EA_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&dbg, 64, hipHostMallocMapped));
+  static size_t lds_allowed = 0;
+  if (lds > 48 * 1024 && lds > lds_allowed) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    lds_allowed = 150 * 1024;
+  }
+  hipLaunchKernelGGL(mpx_equal_area_kernel, dim3((unsigned)batch), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
+                     (int64_t)(p_in_per_point ? c->n_p : 0), c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, dbg);
+  HIPCHK(c, hipGetLastError());
+  if (dbg) {  // MPX_EA_DEBUG: phase stamps of the last workgroup (wall_clock64, 100 MHz)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fprintf(stderr, "equal_area phases (us): load %.2f  passA %.2f  passB %.2f  search %.2f  widths %.2f\n", (dbg[1] - dbg[0]) / 100.0, (dbg[2] - dbg[1]) / 100.0,
+            (dbg[3] - dbg[2]) / 100.0, (dbg[4] - dbg[3]) / 100.0, (dbg[5] - dbg[4]) / 100.0);
+  }
+  return MPX_OK;
+}
+
 static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
                      const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix);
 
 extern "C" int mpx_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point,
                                const double* lam_g, const double* sigma, double* f, double* g, double* grad_f,
                                double* jac_val, double* hess_val) {
-  if (c) c->wcum_valid = false;  // caller-owned device widths: cannot be compared cheaply
-  return eval_core(c, mask, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val, false);
+  if (c) c->wcum_valid = false;  // caller-owned device widths: cannot be compared cheaply; MPX_WIDTHS_UNCHANGED is the caller's word
+  return eval_core(c, mask & ~MPX_WIDTHS_UNCHANGED, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val,
+                   (mask & MPX_WIDTHS_UNCHANGED) != 0);
 }
 
 // out[b][k] = in[b][perm[k]]

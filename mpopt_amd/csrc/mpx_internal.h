@@ -98,6 +98,7 @@ struct mpx_ctx {
   std::vector<int64_t> gmap, qmap;  // row of g / entry of grad_f -> index in the staging block, -1: written elsewhere
   int64_t *d_gmap = nullptr, *d_qmap = nullptr;
   DevBuf<double> gtmp;
+  DevBuf<double> ea_scratch;  // mpx_equal_area_widths_device: cumulative areas + segment boundaries
   // MPX_CCS_ORDER: scratch in native order + device copies of the permutations (built on first use)
   DevBuf<double> ccs_j, ccs_h;
   int64_t *d_perm_j = nullptr, *d_perm_h = nullptr;

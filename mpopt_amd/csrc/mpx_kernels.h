@@ -404,15 +404,46 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
 // (mpopt.interpolate_single_phase / get_dynamics_residuals_single_phase, mpopt.py:1428-1543).
 // lane <-> target point; the point's interpolation and derivative rows stay in VGPRs over the batch.
 // ---------------------------------------------------------------------------------------------
+// Row-major output [row][W] of a wavefront whose 64 lanes hold 64 CONSECUTIVE rows: the wavefront's values are one contiguous
+// run of 64*W doubles, so lane l writes elements l, l+64, ... of that run (fetched from the owning lanes by shuffles) instead of
+// W stores of stride W*8 bytes per lane.  Anything else (ragged target grids, a partial last wavefront) stores directly.
+template <int W>
+__device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t row, const double* v, bool valid, bool contig, int64_t row0) {
+  if (!out) return;
+  if (W == 1 || !contig) {
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < W; ++a) out[row * W + a] = v[a];
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int e = j * 64 + lane, src = e / W, comp = e % W;
+    double x = 0;
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const double t = __shfl(v[c], src, 64);
+      if (c == comp) x = t;
+    }
+    out[row0 * W + e] = x;
+  }
+}
+
 template <int PH, int P>
 __device__ __forceinline__ void resid_body(const MpxResidArgs& A) {
   using G = mpxgen::Phase<PH>;
   constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC, P1 = P + 1;
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= A.n) return;
+  const int m_ = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = m_ < A.n;
+  const int m = valid ? m_ : A.n - 1;  // idle lanes shadow the last point (they take part in the shuffles of store_rows)
   const int row = A.pt_id[m], s = A.pt_seg[m];
   const int st = A.seg_start[s];
   const double tn = A.pt_tn[m];
+  // the wavefront's rows are consecutive (single-degree grids: always, except in the last wavefront)?
+  const int row0 = __shfl(row, 0, 64);
+  const bool contig = __all(valid && row == row0 + (int)(threadIdx.x & 63));
   double Crow[P1], Drow[P1];
 #pragma unroll
   for (int j = 0; j < P1; ++j) {
@@ -424,7 +455,7 @@ __device__ __forceinline__ void resid_body(const MpxResidArgs& A) {
   const int b1 = (b0 + A.b_per_block < A.B) ? b0 + A.b_per_block : A.B;
   for (int b = b0; b < b1; ++b) {
     const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride + A.z_off;
-    Vec<NX> Xi, DXi, fx;
+    Vec<NX> Xi, DXi, fx, res;
     Vec<NU> Ui, DUi;
     Vec<NA> As;
     Vec<NC> cc;
@@ -461,19 +492,17 @@ __device__ __forceinline__ void resid_body(const MpxResidArgs& A) {
     const double kap = ws * A.inv_dtau, th = wc + ws * tn;
     double qW;
     G::fg(Xi, Ui, t0v, tfv, As, kap, th, 0.0, fx, cc, qW);
-    const int64_t o = (int64_t)b * A.n_pts + row;
-    if (A.ti) A.ti[o] = G::node_time(t0v, tfv, th);
 #pragma unroll
-    for (int a = 0; a < NX; ++a) {
-      if (A.xi) A.xi[o * NX + a] = Xi[a];
-      if (A.dxi) A.dxi[o * NX + a] = DXi[a];
-      if (A.dyn) A.dyn[o * NX + a] = fx[a];
-      if (A.resid) A.resid[o * NX + a] = DXi[a] - fx[a];
-    }
-#pragma unroll
-    for (int c = 0; c < NU; ++c) {
-      if (A.ui) A.ui[o * NU + c] = Ui[c];
-      if (A.dui) A.dui[o * NU + c] = DUi[c];
+    for (int a = 0; a < NX; ++a) res[a] = DXi[a] - fx[a];
+    const int64_t ob = (int64_t)b * A.n_pts;
+    if (A.ti && valid) A.ti[ob + row] = G::node_time(t0v, tfv, th);
+    store_rows<NX>(A.xi ? A.xi + ob * NX : nullptr, row, Xi, valid, contig, row0);
+    store_rows<NX>(A.dxi ? A.dxi + ob * NX : nullptr, row, DXi, valid, contig, row0);
+    store_rows<NX>(A.dyn ? A.dyn + ob * NX : nullptr, row, fx, valid, contig, row0);
+    store_rows<NX>(A.resid ? A.resid + ob * NX : nullptr, row, res, valid, contig, row0);
+    if constexpr (NU > 0) {
+      store_rows<NU>(A.ui ? A.ui + ob * NU : nullptr, row, Ui, valid, contig, row0);
+      store_rows<NU>(A.dui ? A.dui + ob * NU : nullptr, row, DUi, valid, contig, row0);
     }
   }
 }

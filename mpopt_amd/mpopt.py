@@ -1022,7 +1022,7 @@ class mpopt_h_adaptive(mpopt):
         cum = np.append(0, np.cumsum(0.5 * (r[:-1] + r[1:])))
         cum = cum / cum[-1]
         target = (np.arange(n_segments) + 1) / n_segments
-        j = np.array([(cum >= t).argmax() for t in target])
+        j = np.maximum(np.searchsorted(cum, target, side="left"), 1)  # first index with cum >= target (cum[0] = 0 < target)
         pos = (j - 1 + (target - cum[j - 1]) / (cum[j] - cum[j - 1])) / (len(r) - 1)
         return list(np.diff(np.append(0, pos)))
 

@@ -331,6 +331,11 @@ class NlpFunctions:
     def shard_unpack(self, mask, batch, recv, vals):
         _lib.check(self._L.mpx_shard_unpack(self._ctx, int(mask), int(batch), _ptr(recv), _ptr(vals)), self._ctx)
 
+    def equal_area_widths_device(self, phase, batch, n_pts, resid, p_in, p_out, damping=0.4, p_in_per_point=0):
+        """Device-side equal-area width update of the h-adaptive loop (mpx_equal_area_widths_device)."""
+        _lib.check(self._L.mpx_equal_area_widths_device(self._ctx, int(phase), int(batch), int(n_pts), _ptr(resid), _ptr(p_in),
+                                                        int(p_in_per_point), _ptr(p_out), float(damping)), self._ctx)
+
     def tile_weights(self):
         w = np.empty(self.n_tiles, np.int64)
         _lib.check(self._L.mpx_get_tile_weights(self._ctx, w.ctypes.data_as(_lib.c_int64_p)), self._ctx)

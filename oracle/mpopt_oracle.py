@@ -365,6 +365,33 @@ class OracleNLP:
             idx += n
         return dict(ti=ti, xi=Xi, ui=Ui, dxi=DXi, dui=DUi, dyn=F, resid=DXi - F, xint=xint, xres=Xi - xint)
 
+    def residuals_of_segments(self, z, p, phase, taus_per_segment, segments):
+        """The same quantities as ``residuals`` for a SAMPLE of segments, without forming the composite matrices (they are
+        (n_points x N) dense: 1 GB at 4000 segments).  Per segment s: Xi = C_s X_s, DXi = D_s X_s with the segment's own
+        interpolation / differentiation rows (mpopt.py:1516-1526 restricted to the block of segment s, 4088-4095, 4123-4130),
+        ti from the segment's end times (mpopt.py:1545-1573), F = h_s Sx dyn (mpopt.py:1451-1480).
+        Returns {s: dict(ti, xi, ui, dxi, dui, dyn, resid)}."""
+        o, G = self.ocp, self.grid
+        X, U, t0v, tfv, A = self.split(z, phase)
+        t0, tf = t0v / self.st, tfv / self.st
+        w = np.asarray(p, float)[phase * self.S:(phase + 1) * self.S]
+        wc = np.concatenate([[0.0], np.cumsum(w)])
+        dyn = o.get_dynamics(phase)
+        out = {}
+        for s in segments:
+            d, st = G.orders[s], G.start[s]
+            taus = np.asarray(taus_per_segment[s], float)
+            C, D = G._interp(d, taus), G._diff(d, taus, 1)
+            Xs, Us = X[st:st + d + 1], U[st:st + d + 1]
+            Xi, Ui, DXi, DUi = C @ Xs, C @ Us, D @ Xs, D @ Us
+            ts0, ts1 = t0 + (tf - t0) * wc[s], t0 + (tf - t0) * wc[s + 1]
+            ti = ts0 + (ts1 - ts0) * ((taus - G.tau0) / (G.tau1 - G.tau0))
+            h_seg = (tf - t0) / (G.tau1 - G.tau0) * w[s]
+            F = np.array([h_seg * (np.array([float(v) for v in dyn(Xi[k] / self.sx, Ui[k] / self.su, ti[k], A / self.sa)]) * self.sx)
+                          for k in range(len(taus))]).reshape(len(taus), self.nx)
+            out[s] = dict(ti=ti, xi=Xi, ui=Ui, dxi=DXi, dui=DUi, dyn=F, resid=DXi - F)
+        return out
+
     # -- bounds and initial guess ---------------------------------------------------------------
     def bounds(self):
         """(lbx, ubx, lbg, ubg) following mpopt.py:546-570, 234-235, 257-258, 291-292, 323-324,

@@ -1,0 +1,94 @@
+"""SURVEY 8(d) config-5 protocol at full size: hypersensitive OCP, 4000 segments of degree 3 (LGR); segment widths drawn once as
+Dirichlet(1), then five outer iterations of the h-adaptive loop with everything resident on the device and ONE libmpx context:
+    dynamics residuals at the mid-points (mpx_resid_eval_device)  ->  nlp_hess_l (mpx_eval_device)  ->
+    equal-area width update, damped (mpx_equal_area_widths_device; mpopt.py:2636-2659, 2587-2590).
+Every iteration is checked: residuals against the numpy oracle on a sample of segments, hess_l against the C oracle (all
+entries), the new widths against the reference's rule (numpy restatement pinned by tests/golden/hadaptive.npz) at 1e-10."""
+import numpy as np
+import pytest
+
+import mpopt_amd as M
+from mpopt_amd import mp
+from mpopt_amd._lib import MPX_HESS, MPX_WIDTHS_UNCHANGED
+import problems
+from helpers import rel_err
+from oracle.mpopt_oracle import OracleNLP
+from oracle.c_oracle import COracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def test_config5_loop_device_resident():
+    import scipy.sparse as sp
+    import torch
+
+    builder, S, po, scheme = problems.BENCH_CASES[3]
+    assert (S, po) == (4000, 3)
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    dev = torch.device("cuda:0")
+    o.set_stream(torch.cuda.current_stream().cuda_stream)
+    O = OracleNLP(ocp, S, po, scheme)
+    C = COracle(["hyper_sensitive"], S, po, scheme, scale_t=1e-3, midu=[0])
+    rng = np.random.default_rng(20260928)
+    B, n_iter = 3, 5
+    Zh = mpo.initialize_solution()[None, :] + 0.05 * rng.standard_normal((B, o.n_z))
+    ph = rng.dirichlet(np.ones(S), B)  # widths ~ Dirichlet(1), one draw per evaluation point
+    lamh, sigh = rng.standard_normal((B, o.n_g)), rng.uniform(0.5, 1.5, B)
+    mids = [(mpo.collocation._taus_fn(d)[:-1] + mpo.collocation._taus_fn(d)[1:]) / 2 for d in mpo.poly_orders]
+    plan = o.residual_plan(0, mids)
+    n_pts = plan.n_pts
+    assert n_pts == 3 * S
+    t = lambda a: torch.tensor(a, device=dev)
+    Z, p, lam, sig = t(Zh), t(ph), t(lamh), t(sigh)
+    p_new = torch.empty_like(p)
+    R = torch.empty(B, n_pts, ocp.nx, dtype=torch.float64, device=dev)
+    H = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
+    hr, hc = o.hess_pattern()
+    A = mp.mpopt_h_adaptive
+    sample = sorted(set(rng.integers(0, S, 12).tolist()) | {0, 1, S - 1})
+    for it in range(n_iter):
+        plan.eval_device(B, Z, p, p_per_point=1, resid=R)
+        o.eval_device(MPX_HESS | (MPX_WIDTHS_UNCHANGED if it % 2 else 0), B, Z, p, 1, lam, sig, None, None, None, None, H)
+        o.equal_area_widths_device(0, B, n_pts, R, p, p_new, damping=0.4, p_in_per_point=1)
+        o.sync()
+        Rh, Hh, pn, pc = R.cpu().numpy(), H.cpu().numpy(), p_new.cpu().numpy(), p.cpu().numpy()
+        for b in range(B):
+            ro = O.residuals_of_segments(Zh[b], pc[b], 0, mids, sample)
+            for s in sample:
+                assert rel_err(Rh[b, 3 * s:3 * s + 3, :], ro[s]["resid"]) < TOL, (it, b, s)
+            Hg = sp.coo_matrix((Hh[b], (hr, hc)), shape=(o.n_z, o.n_z)).tocsr()
+            Hc = C.hess_matrix(Zh[b], pc[b], sigh[b], lamh[b])
+            d = Hg - Hc
+            assert (abs(d).max() if d.nnz else 0.0) < TOL * max(1.0, abs(Hc).max()), (it, b)
+            r1d = np.linalg.norm(Rh[b], 2, axis=1)
+            want = 0.4 * np.asarray(A.get_roots_wrt_equal_area(r1d, S)) + 0.6 * pc[b]
+            assert np.abs(pn[b] - want).max() < TOL * want.max(), (it, b, np.abs(pn[b] - want).max())
+            assert abs(pn[b].sum() - 1) < 1e-9 and pn[b].min() > 0
+        p, p_new = p_new, p
+    # the widths moved: the loop is not a fixed point of the first draw
+    assert np.abs(p.cpu().numpy() - ph).max() > 1e-6
+
+
+def test_equal_area_device_rule_on_reference_vectors():
+    """The device kernel on the reference's own equal-area vectors (tests/golden/hadaptive.npz), no damping."""
+    import os
+    import torch
+    from helpers import GOLDEN
+
+    Hh = np.load(os.path.join(GOLDEN, "hadaptive.npz"))
+    dev = torch.device("cuda:0")
+    for k in range(6):
+        r, n = Hh[f"equal_area/{k}/residuals"], int(Hh[f"equal_area/{k}/n"])
+        ocp = problems.hyper_sensitive(mp, M.math)  # nx = 1: residual samples are the norms themselves
+        mpo = mp.mpopt(ocp, n, 3, "LGR")
+        o = mpo.create_nlp()[0]["oracle"]
+        R = torch.tensor(np.ascontiguousarray(r, float).reshape(1, -1, 1), device=dev)
+        p_in = torch.full((n,), 1.0 / n, dtype=torch.float64, device=dev)
+        p_out = torch.empty(1, n, dtype=torch.float64, device=dev)
+        o.equal_area_widths_device(0, 1, len(r), R, p_in, p_out, damping=1.0)
+        o.sync()
+        assert np.allclose(p_out.cpu().numpy()[0], Hh[f"equal_area/{k}/widths"], rtol=1e-11, atol=1e-14), k

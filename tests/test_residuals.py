@@ -40,6 +40,14 @@ def test_oracle_residuals_match_reference(name):
                 # the reference's monomial arithmetic: compare those to 1e-7, everything else to 1e-12
                 tol = 1e-7 if k in ("xint", "xres") else 1e-12
                 assert rel_err(r[k].ravel(), ref.ravel()) < tol, (ph, gt, k)
+            # the per-segment form (used at sizes where the composite matrices do not fit) against the same reference vectors
+            grid, sp = _grid(R, ph, gt), R[f"ph{ph}/{gt}/seg_ptr"]
+            segs = [s_ for s_ in range(S) if len(grid[s_])]
+            rs = O.residuals_of_segments(G["z"], G["p"], ph, grid, segs)
+            for s_ in segs:
+                for k in FIELDS:
+                    ref = R[f"ph{ph}/{gt}/{k}"][sp[s_]:sp[s_ + 1]]
+                    assert rel_err(np.asarray(rs[s_][k]).reshape(ref.shape), ref) < 1e-12, (ph, gt, k, s_)
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -1,0 +1,7 @@
+mkdir -p gpurun_out/r2_k
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_config5_loop.py tests/test_gpu_parity.py tests/test_residuals.py -m gpu -x -q > gpurun_out/r2_k/pytest.log 2>&1; tail -3 gpurun_out/r2_k/pytest.log
+timeout 300 python bench.py --workload config5-loop --steps 20 2>/dev/null | tail -1 | cut -c1-330
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2_k/trace -o run -- python bench.py --workload config5-loop --steps 20 > gpurun_out/r2_k/under_rocprof.log 2>&1
+cp $(find gpurun_out/r2_k/trace -name '*kernel_stats.csv' | head -1) gpurun_out/r2_k/loop5_kernel_stats.csv; rm -rf gpurun_out/r2_k/trace
+head -6 gpurun_out/r2_k/loop5_kernel_stats.csv | cut -c1-60,100-200
