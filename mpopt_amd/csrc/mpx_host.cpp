@@ -553,23 +553,34 @@ int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size
   return MPX_OK;
 }
 
-// Move the packed g / grad_f values of the node kernels to their rows: lane <-> output entry, so the stores are
-// fully coalesced; entries written by the boundary kernel (map < 0) are left alone.
+// Move the packed g / grad_f values of the node kernels to their rows: lane <-> output entry, so the stores are fully
+// coalesced; entries written by the boundary kernel (map < 0) are left alone.  A lane keeps its map entry for MPX_UNPACK_PTS
+// evaluation points (one index load, that many independent value loads in flight).
+#define MPX_UNPACK_PTS 8
 __global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restrict__ tmp, int64_t tmp_stride, double* __restrict__ g, int64_t g_stride,
                                                          const int64_t* __restrict__ gmap, int64_t n_g, double* __restrict__ grad,
-                                                         int64_t grad_stride, const int64_t* __restrict__ qmap, int64_t n_z) {
+                                                         int64_t grad_stride, const int64_t* __restrict__ qmap, int64_t n_z, int B) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const double* __restrict__ tb = tmp + (int64_t)blockIdx.y * tmp_stride;
+  const int b0 = blockIdx.y * MPX_UNPACK_PTS, nb = min(MPX_UNPACK_PTS, B - b0);
+  double* __restrict__ out;
+  int64_t m, stride;
   if (r < n_g) {
-    const int64_t m = gmap[r];
-    if (g && m >= 0) g[(int64_t)blockIdx.y * g_stride + r] = tb[m];
-    return;
+    if (!g) return;
+    m = gmap[r], out = g + r, stride = g_stride;
+  } else {
+    r -= n_g;
+    if (r >= n_z || !grad) return;
+    m = qmap[r], out = grad + r, stride = grad_stride;
   }
-  r -= n_g;
-  if (r < n_z && grad) {
-    const int64_t m = qmap[r];
-    if (m >= 0) grad[(int64_t)blockIdx.y * grad_stride + r] = tb[m];
-  }
+  if (m < 0) return;
+  const double* __restrict__ src = tmp + (int64_t)b0 * tmp_stride + m;
+  out += (int64_t)b0 * stride;
+  double v[MPX_UNPACK_PTS];
+#pragma unroll
+  for (int k = 0; k < MPX_UNPACK_PTS; ++k) v[k] = k < nb ? src[(int64_t)k * tmp_stride] : 0.0;
+#pragma unroll
+  for (int k = 0; k < MPX_UNPACK_PTS; ++k)
+    if (k < nb) out[(int64_t)k * stride] = v[k];
 }
 
 int pick_bpb(const mpx_ctx* c, int64_t B) {
@@ -636,8 +647,8 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
   }
   if (packed && (!shard || !nodes)) {
     const int64_t rows = c->n_g + c->n_z;
-    hipLaunchKernelGGL(mpx_unpack_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)io.B), dim3(256), 0, c->stream, c->gtmp.p, c->gtmp_n, io.g,
-                       io.g_stride, c->d_gmap, c->n_g, io.grad, io.grad_stride, c->d_qmap, c->n_z);
+    hipLaunchKernelGGL(mpx_unpack_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)((io.B + MPX_UNPACK_PTS - 1) / MPX_UNPACK_PTS)), dim3(256), 0,
+                       c->stream, c->gtmp.p, c->gtmp_n, io.g, io.g_stride, c->d_gmap, c->n_g, io.grad, io.grad_stride, c->d_qmap, c->n_z, (int)io.B);
     HIPCHK(c, hipGetLastError());
   }
   {

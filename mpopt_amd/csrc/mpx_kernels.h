@@ -100,6 +100,76 @@ __device__ __forceinline__ void scatter_slots(double* __restrict__ blk, int64_t 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// High degrees (tables in LDS): the Jacobian block of a lane is mostly COPIES of table rows -- per state row the lane's row
+// of D (minus the dynamics derivative on the diagonal), per control row its row of D or of the mid-point interpolation
+// matrix: the same (P+1)-long constants for every segment.  Unrolling ~100 slots with a select per slot cost 170 VGPRs at
+// degree 30 (2 wavefronts per SIMD).  Here the rows are streamed by short runtime loops instead: values come from LDS by a
+// running index, leave in slot pairs (16-byte stores, same layout as scatter_slots), and the odd value a row may leave
+// over is carried into the next row (compile-time parity).  ~60 VGPRs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool VEC>
+struct SlotStream {
+  char* __restrict__ base;
+  uint32_t off;    // running byte offset of the next pair for this lane
+  uint32_t step;   // bytes between consecutive pairs: 2 * n * 8
+  double carry;
+  __device__ __forceinline__ void pair(double a, double b) {
+    if constexpr (VEC) {
+      mpx_d2 w;
+      w.x = a;
+      w.y = b;
+      *reinterpret_cast<mpx_d2*>(base + off) = w;
+    } else {
+      *reinterpret_cast<double*>(base + off) = a;
+      *reinterpret_cast<double*>(base + off + 8u) = b;
+    }
+    off += step;
+  }
+};
+
+// LEN values val(0..LEN-1) (val takes a RUNTIME index); HAVE: a value is waiting in S.carry.  Returns nothing; whether a value
+// is left in S.carry afterwards is the compile-time constant ((LEN + HAVE) & 1).
+template <bool HAVE, int LEN, bool VEC, class V>
+__device__ __forceinline__ void stream_run(SlotStream<VEC>& S, V val) {
+  int j = 0;
+  if constexpr (HAVE) {
+    S.pair(S.carry, val(0));
+    j = 1;
+  }
+  constexpr int NPAIR = (LEN - (HAVE ? 1 : 0)) / 2;
+#pragma unroll 4
+  for (int t = 0; t < NPAIR; ++t, j += 2) {
+    const double a = val(j), b = val(j + 1);
+    S.pair(a, b);
+  }
+  if constexpr (((LEN - (HAVE ? 1 : 0)) & 1) != 0) S.carry = val(LEN - 1);
+}
+
+// compile-time recursion over the NX state rows / NU control rows of a block (parity threads through the template)
+template <int R, int NR, bool HAVE, int LEN, bool VEC, class F>
+__device__ __forceinline__ void stream_rows(SlotStream<VEC>& S, F row_val) {
+  if constexpr (R < NR) {
+    stream_run<HAVE, LEN, VEC>(S, [&](int j) { return row_val(R, j); });
+    stream_rows<R + 1, NR, (((LEN + (HAVE ? 1 : 0)) & 1) != 0), LEN, VEC>(S, row_val);
+  }
+}
+template <int I, int NV, bool HAVE, bool VEC, class F>
+__device__ __forceinline__ void stream_regs(SlotStream<VEC>& S, F reg_val) {  // NV values from registers, compile-time indices
+  if constexpr (I < NV) {
+    if constexpr (HAVE) {
+      S.pair(S.carry, reg_val(I));
+      stream_regs<I + 1, NV, false, VEC>(S, reg_val);
+    } else if constexpr (I + 1 < NV) {
+      S.pair(reg_val(I), reg_val(I + 1));
+      stream_regs<I + 2, NV, false, VEC>(S, reg_val);
+    } else {
+      S.carry = reg_val(I);
+    }
+  }
+}
+
 template <int PH, int P, int MODE>
 __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   using G = mpxgen::Phase<PH>;
@@ -294,7 +364,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
 #pragma unroll
         for (int a = 0; a < NX; ++a) {  // defect  F = D.X - h*Sx*dyn      (mpopt.py:227-232)
           double acc = 0;
-#pragma unroll
+#pragma unroll(TAB_LDS ? 4 : P1)
           for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][a][base + j], acc);
           *gdst(a, gb + (A.g_off_F + (int64_t)a * N) + i) = acc - fx[a];
         }
@@ -304,7 +374,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
 #pragma unroll
           for (int c = 0; c < NU; ++c) {
             double acc = 0;
-#pragma unroll
+#pragma unroll(TAB_LDS ? 4 : P1)
             for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][NX + c][base + j], acc);
             *gdst(NX + NC + c, gb + (A.g_off_DU + (int64_t)c * N) + i) = acc;
           }
@@ -314,7 +384,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
               double acc = 0;
-#pragma unroll
+#pragma unroll(TAB_LDS ? 4 : P1)
               for (int j = 0; j < P1; ++j) acc = fma(Crow(j), sXU[buf][NX + c][base + j], acc);
               *gdst(NX + NC + (G::DIFF_U ? NU : 0) + c, gb + (A.g_off_mU + (int64_t)c * (N - 1)) + (i - 1)) = acc;
             }
@@ -371,10 +441,43 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
               scatter_slots<NS_MAIN, 0>(jb, n, l, own, false, sv, variable);
             else
               scatter_slots<NS_MAIN + NS_MID, 0>(jb, n, l, own, vec, sv, variable);
+          } else if constexpr (TAB_LDS) {
+            // high degree: stream the table rows (see SlotStream); slot order as everywhere: D rows of the states, variable
+            // entries, D rows of the controls (DIFF_U), mid-point rows of the controls (not for node 0)
+            if (own) {
+              auto emit = [&](auto& S, const bool with_mid) {
+                constexpr int LD = NX * P1, LV = G::NJV, LU = G::DIFF_U ? NU * P1 : 0;
+                constexpr bool H1 = (LD & 1) != 0, H2 = ((LD + LV) & 1) != 0, H3 = ((LD + LV + LU) & 1) != 0;
+                stream_rows<0, NX, false, P1>(S, [&](int a, int j) {
+                  const double d = sD[drow + j];
+                  return (j == k) ? d - dd[a] : d;
+                });
+                stream_regs<0, LV, H1>(S, [&](int q) { return jv[q]; });
+                if constexpr (G::DIFF_U) stream_rows<0, NU, H2, P1>(S, [&](int, int j) { return sD[drow + j]; });
+                if (with_mid) {
+                  if constexpr (NS_MID > 0) stream_rows<0, NU, H3, P1>(S, [&](int, int j) { return sC[crow + j]; });
+                  if constexpr (((NS_MAIN + NS_MID) & 1) != 0)
+                    *reinterpret_cast<double*>(S.base + (uint32_t)(NS_MAIN + NS_MID - 1) * ((uint32_t)n * 8u) + (uint32_t)l * 8u) = S.carry;
+                } else if constexpr ((NS_MAIN & 1) != 0) {
+                  *reinterpret_cast<double*>(S.base + (uint32_t)(NS_MAIN - 1) * ((uint32_t)n * 8u) + (uint32_t)l * 8u) = S.carry;
+                }
+              };
+              const uint32_t step = 2u * (uint32_t)n * 8u;
+              if (T.node0) {
+                SlotStream<false> S{reinterpret_cast<char*>(jb), (uint32_t)l * 16u, step, 0.0};
+                emit(S, false);
+              } else if (vec) {
+                SlotStream<true> S{reinterpret_cast<char*>(jb), (uint32_t)l * 16u, step, 0.0};
+                emit(S, true);
+              } else {
+                SlotStream<false> S{reinterpret_cast<char*>(jb), (uint32_t)l * 16u, step, 0.0};
+                emit(S, true);
+              }
+            }
           } else if (T.node0) {  // node 0 owns no mid-point row: its block ends after the main slots
-            scatter_slots<NS_MAIN, TAB_LDS ? 4 : 0>(jb, n, l, own, false, sv);
+            scatter_slots<NS_MAIN, 0>(jb, n, l, own, false, sv);
           } else {
-            scatter_slots<NS_MAIN + NS_MID, TAB_LDS ? 4 : 0>(jb, n, l, own, vec, sv);
+            scatter_slots<NS_MAIN + NS_MID, 0>(jb, n, l, own, vec, sv);
           }
         }
       }
@@ -629,11 +732,15 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A) {
 #ifndef MPX_MIN_WAVES
 #define MPX_MIN_WAVES 1
 #endif
+#ifndef MPX_MIN_WAVES_HIGH  // degrees with the tables in LDS: the register budget that gives 4 wavefronts per SIMD (<= 128 VGPRs)
+#define MPX_MIN_WAVES_HIGH 4
+#endif
+#define MPX_WAVES_FOR(P) ((P) > MPX_TABLES_IN_LDS_ABOVE ? MPX_MIN_WAVES_HIGH : MPX_MIN_WAVES)
 #define MPX_INSTANTIATE_NODE(PH, P)                                                                         \
   extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_fg_##PH##_##P(const MpxNodeArgs A) {      \
     mpxk::node_body<PH, P, MPX_MODE_FG>(A);                                                                 \
   }                                                                                                         \
-  extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_fgj_##PH##_##P(const MpxNodeArgs A) {     \
+  extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_WAVES_FOR(P)) void mpx_node_fgj_##PH##_##P(const MpxNodeArgs A) {  \
     mpxk::node_body<PH, P, MPX_MODE_FGJ>(A);                                                                \
   }                                                                                                         \
   extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_hess_##PH##_##P(const MpxNodeArgs A) {    \
