@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -583,20 +584,22 @@ __global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restric
     if (k < nb) out[(int64_t)k * stride] = v[k];
 }
 
-int pick_bpb(const mpx_ctx* c, int64_t B) {
+int pick_bpb(const mpx_ctx* c, int64_t B, int mode) {
   const char* env = getenv("MPX_BPB");  // tuning / test override (read per call: tools switch it inside one process)
   if (env && atoi(env) > 0) return atoi(env);
-  // measured on MI355X (moon lander 1000x5, B=4096, XCD-blocked mapping): 4-8 points per workgroup is the
-  // sweet spot of the software-pipelined loop (2: -8 %, 16: -5 %, 64: -10 %); small batches get one point
-  // per workgroup
-  int64_t work = B * (c->tile_end - c->tile_begin);
-  int64_t bpb = work / 16384;
-  return (int)std::min<int64_t>(std::max<int64_t>(bpb, 1), 8);
+  // Evaluation points per workgroup.  Round 1 picked 4-8 for large batches (best case of the software-pipelined loop).  Round 2
+  // measured it over physical placements of the output buffers on five boxes (tools/placement_ab.py, profiles/r2_headline):
+  // with 5 points per workgroup the headline kernel ranges 878 ... 1167 us, with ONE point 916 ... 1016 us -- every XCD then
+  // advances through one contiguous window of the outputs (~9 points deep) instead of 45 points at once, which the HBM
+  // controllers serve evenly wherever the pages lie (slow placements -13 %, the fastest +4 %).  Same on config 3 (+15 % on a
+  // slow box).  The Hessian kernels (one short burst per point) prefer 2.
+  (void)c;
+  return (mode == MPX_MODE_HESS && B >= 2) ? 2 : 1;
 }
 
 int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
   MpxIO io = io0;
-  io.b_per_block = pick_bpb(c, io.B);
+  io.b_per_block = pick_bpb(c, io.B, mode);
   // Packed staging of g / grad_f in tile order: (a) mixed-degree phases, full evaluations (a plain mpx_set_tile_range keeps
   // the direct stores); (b) every segment-sharded evaluation (mpx_shard_setup): a rank's tiles are one contiguous run of the
   // staging block, which is what the ranks exchange; the boundary pass then moves the assembled block to g / grad_f.
@@ -749,6 +752,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
     fr(c->d_gmap), fr(c->d_qmap), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
@@ -1549,6 +1553,28 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
   return MPX_OK;
 }
 
+// Completion of a zero-copy evaluation: the last kernel of the stream stores a sequence number into page-locked host memory
+// (system-scope release after a system fence) and the host spins on it.  hipStreamSynchronize costs ~5 us more per call on
+// this stack (tools/zc_probe.hip: empty kernel + sync 9.6 us, flag kernel + spin 6.0 us; 120 KB written to host memory:
+// 15.0 vs 10.0 us; no stale data in 600 checked hand-offs) -- a quarter of a single evaluation.
+__global__ void mpx_signal_kernel(unsigned long long* flag, unsigned long long seq) {
+  __threadfence_system();
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int wait_flag(mpx_ctx* c) {
+  hipLaunchKernelGGL(mpx_signal_kernel, dim3(1), dim3(64), 0, c->stream, c->h_flag_dev, ++c->flag_seq);
+  HIPCHK(c, hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spins = 1; __atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != c->flag_seq; ++spins) {
+    if ((spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // something is wrong (or very slow): let the runtime report it
+      break;
+    }
+  }
+  return MPX_OK;
+}
+
 extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point,
                         const double* lam_g, const double* sigma, double* f, double* g, double* grad_f, double* jac_val,
                         double* hess_val) {
@@ -1556,6 +1582,7 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   if (!c->has_device)
     return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
   if (batch < 1 || !z || (!p && c->n_p > 0)) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
+  const double t_entry = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   const size_t B = (size_t)batch;
@@ -1594,13 +1621,24 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
     if (ok) {
       if (c->h_scratch_cap < 2 * B) {  // page-locked scalars: f out, sigma in
         if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
         c->h_scratch = nullptr, c->h_scratch_cap = 0;
         const size_t cap = std::max<size_t>(2 * B, 64);
         HIPCHK(c, hipHostMalloc((void**)&c->h_scratch, cap * 8, hipHostMallocMapped));
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_scratch_dev, c->h_scratch, 0));
         c->h_scratch_cap = cap;
       }
+      if (!c->h_flag) {
+        HIPCHK(c, hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_flag_dev, c->h_flag, 0));
+        *c->h_flag = 0;
+      }
       if (mask & MPX_HESS) memcpy(c->h_scratch + B, sigma, B * 8);
+      static const bool lat_dbg = getenv("MPX_LAT_DEBUG") != nullptr;  // where a single evaluation spends its host time
+      static double acc[3] = {0, 0, 0};
+      static int n_acc = 0;
+      auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+      const double t1 = lat_dbg ? now() : 0;
       rc = eval_core(c, mask, batch, (const double*)zd, c->st_p.p, p_per_point, (const double*)ld, c->h_scratch_dev + B, c->h_scratch_dev, (double*)gd,
                      (double*)qd, (double*)jd, (double*)hd, same_p);
       if (rc) {
@@ -1608,7 +1646,20 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
         return rc;
       }
       c->wcum_valid = true;
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const double t2 = lat_dbg ? now() : 0;
+      static const bool no_flag = getenv("MPX_NO_FLAG_WAIT") != nullptr;
+      if (no_flag)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+      else if ((rc = wait_flag(c)))
+        return rc;
+      if (lat_dbg) {
+        const double t3 = now();
+        acc[0] += t1 - t_entry, acc[1] += t2 - t1, acc[2] += t3 - t2;
+        if (++n_acc == 2000) {
+          fprintf(stderr, "mpx_eval zero-copy (mask %d): setup %.2f us, launches %.2f us, sync wait %.2f us\n", mask, acc[0] / n_acc, acc[1] / n_acc, acc[2] / n_acc);
+          acc[0] = acc[1] = acc[2] = 0, n_acc = 0;
+        }
+      }
       if (mask & MPX_F) memcpy(f, c->h_scratch, B * 8);
       return MPX_OK;
     }

@@ -126,6 +126,8 @@ struct mpx_ctx {
   double* h_scratch = nullptr;  // page-locked scalars of the zero-copy path: [f (B) | sigma (B)]
   double* h_scratch_dev = nullptr;
   size_t h_scratch_cap = 0;
+  unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr;  // completion flag of the zero-copy path (page-locked, GPU-visible)
+  unsigned long long flag_seq = 0;
   // host path: widths of the previous mpx_eval (IPOPT never changes p between oracle calls, so the
   // upload and the prefix-sum launch are skipped while p is unchanged)
   std::vector<double> last_p;
