@@ -340,7 +340,7 @@ def main():
                 o.eval_device(mask, B, Z, p, 0, None, None, f2, g2, gr2, jv2, None)
             ms, nl = o.profile_read()
             o.profile(False)
-            sweep.append(ms / max(nl, 1) * 1e3)
+            sweep.append(ms / max(nl // max(len(set(int(d) for d in mpo.poly_orders)), 1), 1) * 1e3)  # all buckets of one step
             if k % 2 == 0:
                 hold.append((f2, g2, gr2, jv2))  # keeping some alive moves the next allocation elsewhere
             del f2, g2, gr2, jv2
