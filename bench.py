@@ -404,12 +404,12 @@ def main():
             out["extras"] = dict(extra, note="opt-in MPX_JAC_VARIABLE_ONLY (resident jac buffers keep the constant D / interpolation "
                                              "entries); not the metric: the headline rewrites every entry on every evaluation")
         # HBM traffic of the dominant kernel from the committed PMC passes (same workload only)
-        tf = os.path.join(ROOT, "profiles", "r1_xcd", "traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r2_headline", "traffic.json")
         if os.path.exists(tf):
             tr = json.load(open(tf))
             if args.workload == "config2-fgj" and tr["workload"] == {"segments": S, "degree": P, "batch": B}:
                 out["roofline"]["traffic"] = tr["bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r1_xcd/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+                out["roofline"]["traffic_source"] = "profiles/r2_headline/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
         if world == 1 and not args.no_cpu_baseline and args.workload == "config2-fgj":
             from oracle.c_oracle import COracle
 
