@@ -161,6 +161,7 @@ SYMBOLS = {
     "mpx_pattern_hess": (ctypes.c_int, [ctypes.c_void_p, c_int32_p, c_int32_p]),
     "mpx_ccs_perm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_int64_p]),
     "mpx_get_comp_weights": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+    "mpx_geometry_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mpx_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mpx_eval_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7),

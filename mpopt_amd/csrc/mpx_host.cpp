@@ -584,22 +584,68 @@ __global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restric
     if (k < nb) out[(int64_t)k * stride] = v[k];
 }
 
-int pick_bpb(const mpx_ctx* c, int64_t B, int mode) {
+// Evaluation points per workgroup.
+//  * Round 1 picked 4-8 for large batches (best case of the software-pipelined loop).  Round 2 measured both over physical
+//    placements of the output buffers on five boxes (tools/placement_ab.py, profiles/r2_headline): with 5 points per workgroup the
+//    headline kernel ranges 878 ... 1167 us, with ONE point 916 ... 1016 us -- every XCD then advances through one contiguous
+//    window of the outputs (~9 points deep) instead of 45 points at once, which the HBM controllers serve evenly wherever the
+//    pages lie (slow placements -13 %, the fastest +4 %); config 3: +15 % on a slow-state box.
+//  * Which of the two wins is a property of where the driver put THESE buffers, so for large batches the library measures it:
+//    the first four passes that write a given output array run the two geometries (order A B B A) between HIP events on the context's
+//    stream (no synchronisation: the timings are read with hipEventQuery once they exist), after which the faster one is used
+//    for that array.  Results do not depend on the geometry (fixed-order reductions; tests/test_gpu_parity.py).
+//  * The Hessian kernels (one short burst per point) take 2; small batches 1.  MPX_BPB overrides, MPX_NO_TUNE=1 pins 1.
+struct GeomPick {
+  int bpb;
+  hipEvent_t begin, end;  // non-null: bracket the node launches of this pass
+};
+
+GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key) {
   const char* env = getenv("MPX_BPB");  // tuning / test override (read per call: tools switch it inside one process)
-  if (env && atoi(env) > 0) return atoi(env);
-  // Evaluation points per workgroup.  Round 1 picked 4-8 for large batches (best case of the software-pipelined loop).  Round 2
-  // measured it over physical placements of the output buffers on five boxes (tools/placement_ab.py, profiles/r2_headline):
-  // with 5 points per workgroup the headline kernel ranges 878 ... 1167 us, with ONE point 916 ... 1016 us -- every XCD then
-  // advances through one contiguous window of the outputs (~9 points deep) instead of 45 points at once, which the HBM
-  // controllers serve evenly wherever the pages lie (slow placements -13 %, the fastest +4 %).  Same on config 3 (+15 % on a
-  // slow box).  The Hessian kernels (one short burst per point) prefer 2.
-  (void)c;
-  return (mode == MPX_MODE_HESS && B >= 2) ? 2 : 1;
+  if (env && atoi(env) > 0) return {atoi(env), nullptr, nullptr};
+  if (mode == MPX_MODE_HESS) return {B >= 2 ? 2 : 1, nullptr, nullptr};
+  const int64_t work = B * (c->tile_end - c->tile_begin);
+  static const bool no_tune = getenv("MPX_NO_TUNE") != nullptr;
+  if (no_tune || work < 32768 || !key || c->shard_world > 1) return {1, nullptr, nullptr};
+  mpx_ctx::GeomTune* T = nullptr;
+  for (auto& t : c->tune)
+    if (t.key == key && t.B == B && t.mode == mode) T = &t;
+  if (!T) {
+    if (c->tune.size() < 8) {
+      c->tune.emplace_back();
+      T = &c->tune.back();
+    } else {  // recycle the least recently used entry (its events are reused)
+      T = &c->tune[0];
+      for (auto& t : c->tune)
+        if (t.last_use < T->last_use) T = &t;
+    }
+    T->key = key, T->B = B, T->mode = mode, T->stage = 0, T->best = 1;
+    T->cand[0] = 1;
+    T->cand[1] = (int)std::min<int64_t>(std::max<int64_t>(work / 16384, 2), 8);
+    for (auto& e : T->ev)
+      if (!e && hipEventCreate(&e) != hipSuccess) return {1, nullptr, nullptr};
+  }
+  T->last_use = ++c->tune_clock;
+  if (T->stage == 5 && ++T->uses >= 512) T->stage = 0, T->uses = 0;  // placements can change behind the same address: look again now and then
+  if (T->stage < 4) {  // measurement passes in the order 0, 1, 1, 0: a clock that is still ramping up cancels out of the sums
+    const int k = T->stage++;
+    return {T->cand[(k == 1 || k == 2) ? 1 : 0], T->ev[2 * k], T->ev[2 * k + 1]};
+  }
+  if (T->stage == 4) {
+    if (hipEventQuery(T->ev[7]) != hipSuccess) return {T->cand[0], nullptr, nullptr};  // not there yet
+    float t[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k)
+      if (hipEventElapsedTime(&t[k], T->ev[2 * k], T->ev[2 * k + 1]) != hipSuccess) t[k] = 1e30f;
+    T->best = (t[1] + t[2]) < 0.99f * (t[0] + t[3]) ? T->cand[1] : T->cand[0];  // the robust geometry unless the other wins clearly
+    T->stage = 5;
+  }
+  return {T->best, nullptr, nullptr};
 }
 
 int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
   MpxIO io = io0;
-  io.b_per_block = pick_bpb(c, io.B, mode);
+  const GeomPick geom = pick_geometry(c, io.B, mode, mode == MPX_MODE_HESS ? (const void*)io.hess : (io.jac ? (const void*)io.jac : (const void*)io.g));
+  io.b_per_block = geom.bpb;
   // Packed staging of g / grad_f in tile order: (a) mixed-degree phases, full evaluations (a plain mpx_set_tile_range keeps
   // the direct stores); (b) every segment-sharded evaluation (mpx_shard_setup): a rank's tiles are one contiguous run of the
   // staging block, which is what the ranks exchange; the boundary pass then moves the assembled block to g / grad_f.
@@ -620,6 +666,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
     int rc = prof_begin(c, &pe1);
     if (rc) return rc;
   }
+  if (geom.begin && nodes) HIPCHK(c, hipEventRecord(geom.begin, c->stream));
   for (auto& B : c->buckets) {
     int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);
     if (hi <= lo || !nodes) continue;
@@ -654,6 +701,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
                        c->stream, c->gtmp.p, c->gtmp_n, io.g, io.g_stride, c->d_gmap, c->n_g, io.grad, io.grad_stride, c->d_qmap, c->n_z, (int)io.B);
     HIPCHK(c, hipGetLastError());
   }
+  if (geom.end && nodes) HIPCHK(c, hipEventRecord(geom.end, c->stream));
   {
     int rc = prof_end(c, pe1);
     if (rc) return rc;
@@ -756,6 +804,9 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
+    for (auto& t : c->tune)
+      for (auto e : t.ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->module) (void)hipModuleUnload(c->module);
   }
   delete c;
@@ -806,6 +857,12 @@ extern "C" int mpx_ccs_perm(const mpx_ctx* c, int which, int64_t* perm, int64_t*
 extern "C" int mpx_get_comp_weights(const mpx_ctx* c, double* w) {
   if (!c || !w || c->kind != 0) return MPX_ERR_INVALID;
   memcpy(w, c->compW.data(), c->compW.size() * sizeof(double));
+  return MPX_OK;
+}
+
+extern "C" int mpx_geometry_reset(mpx_ctx* c) {
+  if (!c) return MPX_ERR_INVALID;
+  for (auto& t : c->tune) t.stage = 0, t.uses = 0;
   return MPX_OK;
 }
 

@@ -132,6 +132,17 @@ struct mpx_ctx {
   // upload and the prefix-sum launch are skipped while p is unchanged)
   std::vector<double> last_p;
   bool wcum_valid = false;
+  // launch-geometry selection for large batches (run_mode): evaluation points per workgroup, measured once per output placement
+  struct GeomTune {
+    const void* key = nullptr;  // dominant output array of the pass
+    int64_t B = 0;
+    int mode = 0, stage = 0, best = 1, uses = 0;
+    int cand[2] = {1, 1};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t last_use = 0;
+  };
+  std::vector<GeomTune> tune;
+  uint64_t tune_clock = 0;
   // per-kernel profiling
   int profile = 0;
   std::vector<hipEvent_t> prof_ev;  // pairs

@@ -278,6 +278,10 @@ class NlpFunctions:
                                      _ptr(sigma), _ptr(f), _ptr(g), _ptr(grad_f), _ptr(jac_val), _ptr(hess_val))
         _lib.check(rc, self._ctx)
 
+    def geometry_reset(self):
+        """Void the launch-geometry measurements (call after re-allocating output arrays; include/mpx.h)."""
+        _lib.check(self._L.mpx_geometry_reset(self._ctx), self._ctx)
+
     def set_stream(self, stream):
         _lib.check(self._L.mpx_set_stream(self._ctx, ctypes.c_void_p(int(stream) if stream else None)), self._ctx)
 
