@@ -65,6 +65,13 @@ struct MpxNodeArgs {
   int64_t g_off_F, g_off_C, g_off_DU, g_off_mU;  // row offsets of the phase's blocks in g
   int32_t N, seg_off;      // nodes per phase; phase * n_segments (offset into the width vectors)
   int32_t tile_first, tile_count;  // tile sub-range to run (segment sharding)
+  int32_t regular, pad_;           // 1: the bucket holds every segment of the phase (node_i[m] == m, node_sk by arithmetic)
+  // regular buckets: the tile descriptors by arithmetic too (tile 0 = the node-0 mini tile, tiles 1 .. reg_last = whole segments,
+  // reg_lanes nodes each, the last one shorter).  Index 0: node-0 tile, 1: first full tile (the others follow at reg_size strides),
+  // 2: last tile.
+  int32_t reg_first_tile, reg_last, reg_lanes, reg_last_lanes;
+  int64_t reg_jac_base[3], reg_hess_base[3], reg_g_base[3];
+  int64_t reg_jac_size, reg_hess_size, reg_g_size;
 };
 
 // Linear rows handled by the boundary kernel (control-slope continuity dU, phase-link events):

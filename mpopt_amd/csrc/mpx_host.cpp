@@ -691,6 +691,30 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
     A.seg_off = B.phase * c->S;
     A.tile_first = (int32_t)lo;
     A.tile_count = (int32_t)(hi - lo);
+    // regular bucket (every segment of the phase has this degree, tiles = [node 0][full ...][last]): descriptors by arithmetic
+    {
+      const int nt = B.tile_count;
+      bool reg = (int64_t)B.node_i.size() == c->N && nt >= 2 && c->tiles[B.tile_first].node0;
+      const int lanes = reg ? c->tiles[B.tile_first + 1].n : 0;
+      for (int t = 1; reg && t < nt; ++t) {
+        const MpxTile& T = c->tiles[B.tile_first + t];
+        const MpxTile& F = c->tiles[B.tile_first + 1];
+        reg = T.m0 == 1 + (t - 1) * lanes && !T.node0 && T.n == T.n_own && (t == nt - 1 ? T.n <= lanes : T.n == lanes) && lanes % B.deg == 0;
+        if (reg && t < nt - 1 && t > 1)  // full tiles: equal blocks at equal strides
+          reg = T.jac_base - F.jac_base == (int64_t)(t - 1) * c->tile_jac_size[B.tile_first + 1] &&
+                T.hess_base - F.hess_base == (int64_t)(t - 1) * c->tile_hess_size[B.tile_first + 1] &&
+                T.g_base - F.g_base == (int64_t)(t - 1) * c->tile_g_size[B.tile_first + 1];
+      }
+      A.regular = reg ? 1 : 0;
+      if (reg) {
+        const int idx[3] = {B.tile_first, B.tile_first + 1, B.tile_first + nt - 1};
+        for (int w = 0; w < 3; ++w) {
+          A.reg_jac_base[w] = c->tiles[idx[w]].jac_base, A.reg_hess_base[w] = c->tiles[idx[w]].hess_base, A.reg_g_base[w] = c->tiles[idx[w]].g_base;
+        }
+        A.reg_first_tile = B.tile_first, A.reg_last = nt - 1, A.reg_lanes = lanes, A.reg_last_lanes = c->tiles[idx[2]].n;
+        A.reg_jac_size = c->tile_jac_size[B.tile_first + 1], A.reg_hess_size = c->tile_hess_size[B.tile_first + 1], A.reg_g_size = c->tile_g_size[B.tile_first + 1];
+      }
+    }
     int rc = launch(c, B.fn[mode], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A);
     if (rc) return rc;
     if (c->profile) ++c->prof_launches;
