@@ -73,6 +73,22 @@ def test_no_cpu_fallback():
     assert not o.has_device
     with pytest.raises(M.MpxError, match="no CPU fallback"):
         o.eval(["f"], mpo.initialize_solution(), np.full(20, 1 / 20))
+    # the round-2 entry points refuse just as loudly: sharded exchange, device-side width update; structure queries still work
+    o.shard_setup(2, 1)
+    n, cuts = o.shard_info(_lib.MPX_JAC)
+    assert n > 0 and cuts[0] == 0 and cuts[-1] == o.n_tiles
+    tab = o.shard_table(_lib.MPX_HESS)
+    assert tab.shape[1] == 6 and set(tab[:, 0]) <= {0, 1} and set(tab[:, 1]) <= {0, 2}
+    buf = np.zeros(8)
+    with pytest.raises(M.MpxError, match="no CPU fallback"):
+        o.shard_pack(_lib.MPX_JAC, 1, buf, buf)
+    with pytest.raises(M.MpxError, match="mpx_set_tile_range on a context in segment-sharded mode"):
+        o.set_tile_range(0, 1)
+    o.shard_setup(1, 0)
+    o.set_tile_range(0, o.n_tiles)
+    with pytest.raises(M.MpxError, match="no CPU fallback"):
+        o.equal_area_widths_device(0, 1, 60, buf, buf, buf)
+    o.geometry_reset()
 
 
 def test_bad_inputs_are_reported_not_fatal():
