@@ -653,11 +653,25 @@ __device__ __forceinline__ void boundary_phase(const MpxBoundArgs& A, int b, int
   static_assert(NRED <= MAXRED, "too many reduced quantities");
   const MpxIO& io = A.io;
   const MpxPhaseInfo& P = A.ph[PH];
-  if (l < NRED) {
+  // Sum of the tile partials in tile order (the fixed order every result is defined by).  The loads are what costs: one lane
+  // walking 21 ... 101 tiles with one load in flight took longer than the node kernel at a batch of one, so the workgroup fetches
+  // the partials 256 values at a time (all lanes, coalesced: the block of a phase is contiguous) into LDS and the NRED summing
+  // lanes add their column from there -- same additions, same order.
+  {
+    __shared__ double sPart[256];
+    const double* __restrict__ pp = io.partial + ((int64_t)b * io.n_tiles_total + P.tile_first) * io.nred;
+    const int nred = io.nred, total = P.tile_count * nred;
+    const int per = (256 / nred) * nred;  // whole tiles per chunk
     double s = 0;
-    const double* pp = io.partial + ((int64_t)b * io.n_tiles_total + P.tile_first) * io.nred + l;
-    for (int t = 0; t < P.tile_count; ++t) s += pp[(int64_t)t * io.nred];
-    red[l] = s;
+    for (int c0 = 0; c0 < total; c0 += per) {
+      const int cnt = total - c0 < per ? total - c0 : per;
+      if (l < cnt) sPart[l] = pp[c0 + l];
+      __syncthreads();
+      if (l < NRED)
+        for (int e = l; e < cnt; e += nred) s += sPart[e];
+      __syncthreads();
+    }
+    if (l < NRED) red[l] = s;
   }
   __syncthreads();
   if (l == 0) {
