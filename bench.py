@@ -399,6 +399,14 @@ def main():
         if extra:
             out["extras"] = dict(extra, note="opt-in MPX_JAC_VARIABLE_ONLY (resident jac buffers keep the constant D / interpolation "
                                              "entries); not the metric: the headline rewrites every entry on every evaluation")
+        # Hessian workloads: HBM traffic of the node kernel from the committed PMC passes (profiles/r2_config*_hess), and the fraction
+        # of peak that traffic amounts to over THIS run's kernel time
+        tfh = os.path.join(ROOT, "profiles", {"config5-hess": "r2_config5_hess", "config2-hess": "r2_config2_hess"}.get(args.workload, "-"), "traffic.json")
+        if os.path.exists(tfh) and B == 4096:
+            tr = json.load(open(tfh))
+            out["roofline"]["traffic"] = tr["bytes_per_launch"]
+            out["roofline"]["frac_by_traffic"] = tr["bytes_per_launch"] / kernel_s / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["traffic_source"] = os.path.relpath(tfh, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
         # HBM traffic of the dominant kernel from the committed PMC passes (same workload only)
         tf = os.path.join(ROOT, "profiles", "r2_headline", "traffic.json")
         if os.path.exists(tf):
