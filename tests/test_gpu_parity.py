@@ -70,6 +70,34 @@ def test_reduced_size_against_numpy_oracle(name):
     assert rel_err(H, O.hess_l(z, p, sig, lam)) < TOL
 
 
+def test_time_dependent_two_phase_multi_tile_against_numpy_oracle():
+    """The C oracle's problems do not depend on t explicitly, so at BASELINE sizes the (t0, tf, a) border and corner of hess_l and
+    the t0 / tf columns of jac_g are exercised through h only.  Here: kitchen sink (explicit time dependence, parameters, path
+    rows, control-slope rows, two phases) on 400 segments of degrees [2,5,3,4] -- several tiles per (phase, degree) bucket, i.e.
+    multi-tile fixed-order sums of the corner entries -- against the numpy / sympy oracle, all five outputs, sparse comparison."""
+    S, po = 400, [2, 5, 3, 4] * 100
+    ocp = problems.kitchen_sink(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, "LGR")
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    assert o.n_tiles >= 2 * 8  # every bucket has more than one tile
+    O = OracleNLP(ocp, S, po, "LGR")
+    z, p, lam, sig = random_point(o, mpo, bounds, 31, S, ocp.n_phases)
+    r = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], z, p, lam_g=lam, sigma=sig)
+    assert rel_err(r["f"], O.f(z, p)) < TOL and rel_err(r["g"], O.g(z, p)) < TOL and rel_err(r["grad_f"], O.grad_f(z, p)) < TOL
+    jr, jc = o.jac_pattern()
+    d = sp.coo_matrix((r["jac_g"], (jr, jc)), shape=(o.n_g, o.n_z)).tocsr() - sp.csr_matrix(O.jac_g(z, p))
+    assert (abs(d).max() if d.nnz else 0.0) < TOL * max(1.0, abs(r["jac_g"]).max())
+    hr, hc = o.hess_pattern()
+    Ho = sp.csr_matrix(np.triu(O.hess_l(z, p, sig, lam)))
+    d = sp.coo_matrix((r["hess_l"], (hr, hc)), shape=(o.n_z, o.n_z)).tocsr() - Ho
+    assert (abs(d).max() if d.nnz else 0.0) < TOL * max(1.0, abs(Ho).max())
+    # the corner really is populated (time-dependent dynamics: t0-t0, t0-tf, tf-tf, t-a entries are non-zero)
+    nzp = o.n_z // ocp.n_phases
+    t0 = (ocp.nx + ocp.nu) * o.n_nodes
+    assert abs(Ho[t0, t0]) > 0 and abs(Ho[t0, t0 + 1]) > 0 and abs(Ho[t0 + 1, t0 + 1]) > 0
+
+
 FULL = {
     "config2_moon_lander_1000x5_LGR": (problems.BENCH_CASES[0], ["moon_lander"], 1.0, [1]),
     "config3_vdp_2000_mixed_CGL": (problems.BENCH_CASES[1], ["van_der_pol"], 1.0, [1]),
