@@ -41,6 +41,7 @@ def _worker(rank, world, port, case, q):
         "schwartz": (problems.two_phase_schwartz, 200, 3, "LGL"),                                        # config 4, reduced
         "kitchen_sink": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR"),                           # parameters, DU rows, 2 phases
         "hyper_sensitive": (problems.hyper_sensitive, 700, 3, "LGR"),                                    # config 5, reduced
+        "kitchen_sink_400": (problems.kitchen_sink, 400, [2, 5, 3, 4] * 100, "LGR"),                     # several tiles per bucket: corner sums cross ranks
     }[case]
     ocp = builder(mp, M.math)
     mpo = mp.mpopt(ocp, S, po, scheme)
@@ -95,7 +96,7 @@ def _worker(rank, world, port, case, q):
     q.put((rank, "ok"))
 
 
-@pytest.mark.parametrize("case,world", [("vdp_mixed", 2), ("schwartz", 3), ("kitchen_sink", 2), ("hyper_sensitive", 2)])
+@pytest.mark.parametrize("case,world", [("vdp_mixed", 2), ("schwartz", 3), ("kitchen_sink", 2), ("hyper_sensitive", 2), ("kitchen_sink_400", 3)])
 def test_segment_sharded_evaluator_under_torch_distributed(case, world):
     import torch.multiprocessing as tmp
 
