@@ -184,7 +184,11 @@ class AssembledNlpFunctions(NlpFunctions):
         parts = ["// generated by mpopt_amd.assembly -- do not edit", "#include <hip/hip_runtime.h>", "namespace mpxgen {",
                  "template <int FID> struct Pt;"]
         parts += [f.source(k) for k, f in enumerate(funcs)]
-        parts += ["}  // namespace mpxgen", '#include "mpx_assembly_kernels.h"']
+        # evaluation points a lane takes through the gathers together (mpx_assembly_kernels.h): 4 for small point functions
+        # (MI355X, moon lander 20x5 at B = 4096: 1.05-1.45x on f+g+grad_f+jac_g, 1.1-2.1x on hess_l depending on the box); the
+        # generated code is replicated per point, so large functions (kitchen sink: 3x the compile time, no gain) keep 1.
+        n_stmt = sum(p.count(";") for p in parts)
+        parts += ["}  // namespace mpxgen", f"#define MPX_PTS_UNROLL {4 if n_stmt <= 1000 else 1}", '#include "mpx_assembly_kernels.h"']
         parts.append(f"MPX_INSTANTIATE_POINTS({len(funcs)})")
         return "\n".join(parts) + "\n"
 

@@ -41,6 +41,7 @@ struct mpx_asm_state {
   std::vector<DevSet> sets;
   MpxPtSet* d_sets = nullptr;  // device copy of the per-set argument blocks
   int n_blocks = 0;            // 64-lane blocks of the fused point launch
+  int points_per_lane = 1;     // evaluation points a lane of the generated kernels takes together (read from the code object)
   hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
   DevGather fgj, hess;
   int64_t raw_n = 0, rawh_n = 0;
@@ -64,6 +65,7 @@ __device__ __forceinline__ double* gather_out(const MpxGatherArgs& A, int64_t ro
   return A.seg_out[sg];
 }
 
+template <int UN>
 __global__ __launch_bounds__(256) void mpx_gather_kernel(const MpxGatherArgs A) {
   const int b0 = blockIdx.y * A.b_per_block;
   const int b1 = (b0 + A.b_per_block < A.B) ? b0 + A.b_per_block : A.B;
@@ -105,31 +107,31 @@ __global__ __launch_bounds__(256) void mpx_gather_kernel(const MpxGatherArgs A) 
   if (nt >= 2) k1 = A.src[e0 + 1], c1 = A.coef[e0 + 1];
   int b = b0;
   // The kernel is latency-bound (pointer -> source -> value -> store is a chain of dependent round trips and
-  // only 2048 workgroups are resident), so a lane takes MPX_GATHER_UNROLL evaluation points at a time with their
+  // only 2048 workgroups are resident), so a lane takes UN evaluation points at a time with their
   // loads in flight together.  Per point the terms are added in the same order as in the remainder loop below:
   // results are identical.
-  for (; b + MPX_GATHER_UNROLL <= b1; b += MPX_GATHER_UNROLL) {
+  for (; b + UN <= b1; b += UN) {
     const double* __restrict__ rb = A.raw + (int64_t)b * A.raw_stride;
     const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
-    double s[MPX_GATHER_UNROLL];
+    double s[UN];
 #pragma unroll
-    for (int u = 0; u < MPX_GATHER_UNROLL; ++u) s[u] = 0;
+    for (int u = 0; u < UN; ++u) s[u] = 0;
     if (nt >= 1) {
 #pragma unroll
-      for (int u = 0; u < MPX_GATHER_UNROLL; ++u) s[u] = fma(c0, gather_value(k0, rb + u * A.raw_stride, zb + u * A.z_stride), s[u]);
+      for (int u = 0; u < UN; ++u) s[u] = fma(c0, gather_value(k0, rb + u * A.raw_stride, zb + u * A.z_stride), s[u]);
     }
     if (nt >= 2) {
 #pragma unroll
-      for (int u = 0; u < MPX_GATHER_UNROLL; ++u) s[u] = fma(c1, gather_value(k1, rb + u * A.raw_stride, zb + u * A.z_stride), s[u]);
+      for (int u = 0; u < UN; ++u) s[u] = fma(c1, gather_value(k1, rb + u * A.raw_stride, zb + u * A.z_stride), s[u]);
     }
     for (int64_t e = e0 + 2; e < e1; ++e) {
       const int32_t k = A.src[e];
       const double cf = A.coef[e];
 #pragma unroll
-      for (int u = 0; u < MPX_GATHER_UNROLL; ++u) s[u] = fma(cf, gather_value(k, rb + u * A.raw_stride, zb + u * A.z_stride), s[u]);
+      for (int u = 0; u < UN; ++u) s[u] = fma(cf, gather_value(k, rb + u * A.raw_stride, zb + u * A.z_stride), s[u]);
     }
 #pragma unroll
-    for (int u = 0; u < MPX_GATHER_UNROLL; ++u) out[(int64_t)(b + u) * stride + local] = s[u];
+    for (int u = 0; u < UN; ++u) out[(int64_t)(b + u) * stride + local] = s[u];
   }
   for (; b < b1; ++b) {
     const double* __restrict__ rb = A.raw + (int64_t)b * A.raw_stride;
@@ -270,6 +272,15 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
   static const char* kname[3] = {"mpx_pts_val", "mpx_pts_jac", "mpx_pts_hes"};
   for (int m = 0; m < 3; ++m)
     if (hipModuleGetFunction(&a->fn[m], c->module, kname[m]) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "kernel %s missing from the code object", kname[m]));
+  {
+    hipDeviceptr_t sym = nullptr;
+    size_t bytes = 0;
+    int v = 1;
+    if (hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_pts_points_per_lane") == hipSuccess && bytes == sizeof(int) &&
+        hipMemcpyDtoH(&v, sym, sizeof(int)) == hipSuccess && v >= 1 && v <= 64)
+      a->points_per_lane = v;
+    (void)hipGetLastError();  // an older code object without the symbol is fine: one point per lane
+  }
   if (a->raw_n >= (1LL << 31) || a->rawh_n >= (1LL << 31)) return bail(fail(c, MPX_ERR_UNSUPPORTED, "raw buffer too large for int32 sources"));
   if ((rc = upload_gather(c, a->fgj, D->fgj, a->raw_n, D->n_z, "fgj gather")) || (rc = upload_gather(c, a->hess, D->hess, a->rawh_n, D->n_z, "hess gather")))
     return bail(rc);
@@ -290,6 +301,7 @@ static int launch_points(mpx_ctx* c, int mode, int64_t batch, const double* z, c
   MpxPtCall A{};
   A.sets = a->d_sets, A.n_sets = (int32_t)a->sets.size(), A.n_g = (int32_t)c->n_g, A.B = (int32_t)batch;
   A.b_per_block = pick_chunk(batch, a->n_blocks);
+  if (batch * a->n_blocks >= 16384) A.b_per_block = std::max(A.b_per_block, a->points_per_lane);  // see point_body
   A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma;
   A.raw = a->raw.p;
   A.raw_stride = mode == MPX_MODE_HESS ? a->rawh_n : a->raw_n;
@@ -313,8 +325,15 @@ static int launch_gather(mpx_ctx* c, const DevGather& g, int64_t batch, const do
   A.n_short_blocks = (int32_t)((g.n_rows + 255) / 256);
   const unsigned gx = (unsigned)(A.n_short_blocks + (g.n_long + 3) / 4);
   A.b_per_block = pick_chunk(batch, gx);
-  if (batch * gx >= 16384) A.b_per_block = std::max(A.b_per_block, MPX_GATHER_UNROLL);  // several points in flight per lane (see kernel)
-  hipLaunchKernelGGL(mpx_gather_kernel, dim3(gx, (unsigned)((batch + A.b_per_block - 1) / A.b_per_block)), dim3(256), 0, c->stream, A);
+  static const int un = getenv("MPX_GATHER_U") ? atoi(getenv("MPX_GATHER_U")) : MPX_GATHER_UNROLL;
+  if (batch * gx >= 16384) A.b_per_block = std::max(A.b_per_block, un);  // several points in flight per lane (see kernel)
+  const dim3 grid(gx, (unsigned)((batch + A.b_per_block - 1) / A.b_per_block));
+  if (un == 16)
+    hipLaunchKernelGGL(mpx_gather_kernel<16>, grid, dim3(256), 0, c->stream, A);
+  else if (un == 8)
+    hipLaunchKernelGGL(mpx_gather_kernel<8>, grid, dim3(256), 0, c->stream, A);
+  else
+    hipLaunchKernelGGL(mpx_gather_kernel<4>, grid, dim3(256), 0, c->stream, A);
   HIPCHK(c, hipGetLastError());
   return MPX_OK;
 }

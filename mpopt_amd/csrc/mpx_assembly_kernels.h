@@ -17,6 +17,74 @@
 
 namespace mpxk {
 
+#ifndef MPX_PTS_UNROLL
+#define MPX_PTS_UNROLL 1
+#endif
+
+template <int FID, int MODE, int U>
+__device__ __forceinline__ void point_eval(const MpxPtSet& S, const MpxPtCall& A, int p, int64_t n, const double* cst, double* __restrict__ raw0, int b) {
+  using F = mpxgen::Pt<FID>;
+  constexpr int NLOC = F::NLOC, NOUT = F::NOUT, NJ = F::NJ, NH = F::NH;
+  const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
+  double loc[U][NLOC > 0 ? NLOC : 1];
+#pragma unroll
+  for (int v = 0; v < NLOC; ++v) {
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0;
+    for (int t = S.loc_toff[v]; t < S.loc_toff[v + 1]; ++t) {
+      const double cf = S.loc_coef[(int64_t)t * n + p];
+      const int ix = S.loc_idx[(int64_t)t * n + p];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = fma(cf, zb[(int64_t)u * A.z_stride + ix], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) loc[u][v] = acc[u];
+  }
+  if constexpr (MODE == MPX_MODE_HESS) {
+    double mu[U][NOUT > 0 ? NOUT : 1];
+    const double* __restrict__ lb = A.lam + (int64_t)b * A.lam_stride;
+#pragma unroll
+    for (int r = 0; r < NOUT; ++r) {
+      double acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = 0;
+      for (int t = S.mu_toff[r]; t < S.mu_toff[r + 1]; ++t) {
+        const int ix = S.mu_idx[(int64_t)t * n + p];
+        const double cf = S.mu_coef[(int64_t)t * n + p];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = fma(cf, ix == A.n_g ? A.sigma[b + u] : lb[(int64_t)u * A.lam_stride + ix], acc[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) mu[u][r] = acc[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double* __restrict__ rb = raw0 + (int64_t)(b + u) * A.raw_stride;
+      double H[NH > 0 ? NH : 1];
+      F::hes(loc[u], cst, mu[u], H);
+#pragma unroll
+      for (int q = 0; q < NH; ++q) rb[(int64_t)q * n + p] = H[q];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double* __restrict__ rb = raw0 + (int64_t)(b + u) * A.raw_stride;
+      double out[NOUT > 0 ? NOUT : 1];
+      if constexpr (MODE == MPX_MODE_FGJ) {
+        double J[NJ > 0 ? NJ : 1];
+        F::jac(loc[u], cst, out, J);
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) rb[(int64_t)(NOUT + q) * n + p] = J[q];
+      } else {
+        F::val(loc[u], cst, out);
+      }
+#pragma unroll
+      for (int r = 0; r < NOUT; ++r) rb[(int64_t)r * n + p] = out[r];
+    }
+  }
+}
+
 template <int FID, int MODE>
 __device__ __forceinline__ void point_body(const MpxPtSet& S, const MpxPtCall& A, int blk) {
   using F = mpxgen::Pt<FID>;
@@ -31,47 +99,12 @@ __device__ __forceinline__ void point_body(const MpxPtSet& S, const MpxPtCall& A
   const int b0 = blockIdx.y * A.b_per_block;
   const int b1 = (b0 + A.b_per_block < A.B) ? b0 + A.b_per_block : A.B;
   double* __restrict__ raw0 = A.raw + (MODE == MPX_MODE_HESS ? S.rawh_off : S.raw_off);
-  for (int b = b0; b < b1; ++b) {
-    const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
-    double loc[NLOC > 0 ? NLOC : 1];
-#pragma unroll
-    for (int v = 0; v < NLOC; ++v) {
-      double acc = 0;
-      for (int t = S.loc_toff[v]; t < S.loc_toff[v + 1]; ++t) acc = fma(S.loc_coef[(int64_t)t * n + p], zb[S.loc_idx[(int64_t)t * n + p]], acc);
-      loc[v] = acc;
-    }
-    double* __restrict__ rb = raw0 + (int64_t)b * A.raw_stride;
-    if constexpr (MODE == MPX_MODE_HESS) {
-      double mu[NOUT > 0 ? NOUT : 1];
-      const double* __restrict__ lb = A.lam + (int64_t)b * A.lam_stride;
-      const double sg = A.sigma[b];
-#pragma unroll
-      for (int r = 0; r < NOUT; ++r) {
-        double acc = 0;
-        for (int t = S.mu_toff[r]; t < S.mu_toff[r + 1]; ++t) {
-          const int ix = S.mu_idx[(int64_t)t * n + p];
-          acc = fma(S.mu_coef[(int64_t)t * n + p], ix == A.n_g ? sg : lb[ix], acc);
-        }
-        mu[r] = acc;
-      }
-      double H[NH > 0 ? NH : 1];
-      F::hes(loc, cst, mu, H);
-#pragma unroll
-      for (int q = 0; q < NH; ++q) rb[(int64_t)q * n + p] = H[q];
-    } else {
-      double out[NOUT > 0 ? NOUT : 1];
-      if constexpr (MODE == MPX_MODE_FGJ) {
-        double J[NJ > 0 ? NJ : 1];
-        F::jac(loc, cst, out, J);
-#pragma unroll
-        for (int q = 0; q < NJ; ++q) rb[(int64_t)(NOUT + q) * n + p] = J[q];
-      } else {
-        F::val(loc, cst, out);
-      }
-#pragma unroll
-      for (int r = 0; r < NOUT; ++r) rb[(int64_t)r * n + p] = out[r];
-    }
-  }
+  int b = b0;
+  // Several evaluation points per lane go through the gathers TOGETHER (one read of a term's index and coefficient, U loads
+  // of z in flight); per point the terms are added in the same order as in the single-point pass, so results are identical.
+  if constexpr (MPX_PTS_UNROLL > 1)
+    for (; b + MPX_PTS_UNROLL <= b1; b += MPX_PTS_UNROLL) point_eval<FID, MODE, MPX_PTS_UNROLL>(S, A, p, n, cst, raw0, b);
+  for (; b < b1; ++b) point_eval<FID, MODE, 1>(S, A, p, n, cst, raw0, b);
 }
 
 template <int MODE, int FID>
@@ -101,7 +134,9 @@ __device__ __forceinline__ void points_body(const MpxPtCall& A) {
 
 }  // namespace mpxk
 
+// mpx_pts_points_per_lane tells the host how many evaluation points a lane of these kernels takes together.
 #define MPX_INSTANTIATE_POINTS(NF)                                                                       \
+  extern "C" __device__ __attribute__((used)) const int mpx_pts_points_per_lane = MPX_PTS_UNROLL;        \
   extern "C" __global__ __launch_bounds__(64) void mpx_pts_val(const MpxPtCall A) {                      \
     mpxk::points_body<MPX_MODE_FG, NF>(A);                                                               \
   }                                                                                                      \

@@ -212,3 +212,40 @@ def test_adaptive_device_pointer_api_matches_host_api():
         assert np.array_equal(ref[key], ten.cpu().numpy()), key
     with pytest.raises(M.MpxError):  # tiles do not exist on assembled contexts
         o.set_tile_range(0, 0)
+
+
+def test_adaptive_large_batch_equals_single_evaluations_bitwise():
+    """Past 16384 workgroups the generated point kernels take several evaluation points per lane (MPX_PTS_UNROLL, read by the
+    host from the code object) and the gather pass four: every point of a large batch -- including the remainder points of
+    a batch that is not a multiple of either -- must carry the bits of its own single evaluation."""
+    import torch
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_HESS, MPX_JAC
+
+    ocp = problems.moon_lander(mp, M.math)
+    mpo = mp.mpopt_adaptive(ocp, 20, 5, "LGR")
+    o = mpo.create_nlp()[0]["oracle"]
+    assert "#define MPX_PTS_UNROLL 4" in o.source  # small point functions: four points per lane
+    rng = np.random.default_rng(11)
+    B = 3500 + 3
+    Z = mpo.initialize_solution()[None, :] * (1 + 0.05 * rng.uniform(-1, 1, (B, o.n_z)))
+    lam, sig = rng.standard_normal((B, o.n_g)), rng.uniform(0.5, 1.5, B)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.tensor(a, device=dev)
+    f, g = torch.empty(B, dtype=torch.float64, device=dev), torch.empty(B, o.n_g, dtype=torch.float64, device=dev)
+    gr, jv = torch.empty(B, o.n_z, dtype=torch.float64, device=dev), torch.empty(B, o.nnz_jac, dtype=torch.float64, device=dev)
+    hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
+    o.eval_device(MPX_F | MPX_G | MPX_GRAD | MPX_JAC | MPX_HESS, B, t(Z), None, 0, t(lam), t(sig), f, g, gr, jv, hv)
+    o.sync()
+    got = {"f": f.cpu().numpy(), "g": g.cpu().numpy(), "grad_f": gr.cpu().numpy(), "jac_g": jv.cpu().numpy(), "hess_l": hv.cpu().numpy()}
+    for b in [0, 1, 2, 3, 4, 1777, B - 4, B - 3, B - 2, B - 1]:
+        one = o.eval(list(got), Z[b], None, lam_g=lam[b], sigma=sig[b])
+        for k in got:
+            assert np.array_equal(np.asarray(one[k]).ravel(), np.asarray(got[k][b]).ravel()), (b, k)
+    # and against the CPU oracle at one of the remainder points
+    from oracle.mpopt_oracle import OracleAdaptiveNLP
+
+    O = OracleAdaptiveNLP(ocp, 20, 5, "LGR")
+    assert rel_err(got["g"][B - 1], O.g(Z[B - 1])) < TOL
+    J = np.zeros((o.n_g, o.n_z))
+    J[o.jac_pattern()] = got["jac_g"][B - 1]
+    assert rel_err(J, O.jac_g(Z[B - 1]).toarray()) < TOL
