@@ -441,6 +441,9 @@ def main():
                                      call_mix="1.15 nlp_g + nlp_grad_f + nlp_jac_g + nlp_hess_l (moon_lander.ipynb:192-198)")
             out["ipopt_iter_config0"] = dict(ipopt_iter_report(*cfg1, dev_id, seconds=0.3), unit="us",
                                              config="moon lander 20x3 LGR (configs[0]), B=1, host pointers")
+            cfg5 = (problems.hyper_sensitive, 4000, 3, "LGR", ["hyper_sensitive"], 1e-3, [0])
+            out["ipopt_iter_config4"] = dict(ipopt_iter_report(*cfg5, dev_id, seconds=0.3), unit="us",
+                                             config="hyper-sensitive 4000x3 LGR (configs[4]), B=1, host pointers")
             out["cpu_baseline"] = {"value": ns * reps / tt, "unit": "evals/s", "cores": 1, "kind": "port",
                                    "sample": f"{ns} of the same evaluation points x {reps} passes, oracle/mpopt_oracle.c "
                                              f"(gcc -O2, scalar, values only), {tt:.1f} s",
