@@ -211,6 +211,11 @@ int mpx_set_tile_range(mpx_ctx* ctx, int64_t tile_begin, int64_t tile_end, int r
 int mpx_get_tile_jac_range(const mpx_ctx* ctx, int64_t tile, int64_t* begin, int64_t* end);
 /* Relative cost of every tile (its Jacobian block size), for balancing tile ranges over ranks. */
 int mpx_get_tile_weights(const mpx_ctx* ctx, int64_t* weights);
+/* Mixed-degree phases: which tiles write complete g / grad_f row spans themselves.  Per tile: first node
+ * and length of the span of phase nodes whose rows the tile stores (length 0: the tile stages its values for another tile or
+ * for the unpack pass) and the number of nodes of other tiles inside that span.  All zero on single-degree grids and on grids
+ * outside the limits of the scheme.  Arrays of n_tiles entries; host-only contexts answer too (the plan is host arithmetic). */
+int mpx_get_tile_spans(const mpx_ctx* ctx, int32_t* span_first, int32_t* span_len, int32_t* n_foreign);
 /* Device buffer holding the per-tile partial sums of the last mpx_eval_device call
  * ([batch][n_tiles][width] doubles; entries of tiles outside the tile range are untouched).  Ranks
  * sum this buffer (and their disjoint output slices) before the MPX_BOUNDARY_ONLY pass. */

@@ -24,6 +24,10 @@ struct MpxTile {
   int64_t jac_base;  // offset of the tile's block in the jac_g value array
   int64_t hess_base; // offset of the tile's block in the hess_l value array
   int64_t g_base;    // offset of the tile's block in the packed g / grad_f staging buffer (mixed-degree phases)
+  // Absorbing tiles (mixed-degree phases, see MpxNodeArgs::abs_cap): the tile writes the complete g / grad_f rows of the node span
+  // [span_lo, span_lo + span_len) -- its own nodes from registers, the other buckets' nodes in between (f_count of them, entries
+  // f_first .. of the abs_* lists) from the staging buffer.  span_len == 0: the tile stages its values.
+  int32_t span_lo, span_len, f_first, f_count;
 };
 
 // Batched I/O views: pointer + per-evaluation-point stride (in doubles).
@@ -72,6 +76,13 @@ struct MpxNodeArgs {
   int32_t reg_first_tile, reg_last, reg_lanes, reg_last_lanes;
   int64_t reg_jac_base[3], reg_hess_base[3], reg_g_base[3];
   int64_t reg_jac_size, reg_hess_size, reg_g_size;
+  // Mixed-degree phases without the unpack pass: the bucket with the most nodes is launched LAST and its tiles assemble whole
+  // row spans in LDS (abs_cap doubles per row slot; dynamic shared memory) and store them as full contiguous runs.  Foreign node
+  // f of a tile: position abs_fpos[f] in the span, staged values at gtmp[abs_fstage[f] + slot * abs_fn[f]].  abs_cap == 0: off.
+  const int32_t* abs_fpos;
+  const int64_t* abs_fstage;
+  const int32_t* abs_fn;
+  int32_t abs_cap, pad2_;
 };
 
 // Linear rows handled by the boundary kernel (control-slope continuity dU, phase-link events):

@@ -255,6 +255,8 @@ int build_layout(mpx_ctx* c) {
     c->gmap.assign((size_t)c->n_g, -1);
     c->qmap.assign((size_t)c->n_z, -1);
     c->tile_g_size.assign(c->tiles.size(), 0);
+    std::vector<int64_t> stage_pos((size_t)c->n_phases * N, -1);  // node -> slot-0 position of its staged values
+    std::vector<int32_t> stage_n((size_t)c->n_phases * N, 0);     //         slot stride (own lanes of its tile)
     int64_t pos = 0;
     for (auto& B : c->buckets) {
       const PhaseStruct& P = c->ph[B.phase];
@@ -273,12 +275,61 @@ int build_layout(mpx_ctx* c) {
           if (P.midu && k >= 1)
             for (int q = 0; q < nu; ++q) c->gmap[P.g_off_mU + (int64_t)q * (N - 1) + (i - 1)] = pos + (sMU + q) * n + l;
           for (int a = 0; a < nx + nu; ++a) c->qmap[P.z_off + (int64_t)a * N + i] = pos + (sQ + a) * n + l;
+          stage_pos[(size_t)B.phase * N + i] = pos + l, stage_n[(size_t)B.phase * N + i] = (int32_t)n;
         }
         c->tile_g_size[t] = (int64_t)nsg * n;
         pos += (int64_t)nsg * n;
       }
     }
     c->gtmp_n = pos;
+
+    // Absorbing buckets: per phase the bucket with the most nodes.  Its tiles (in segment order) cut [0, N) into contiguous
+    // spans -- tile j from its first own node up to the first own node of tile j + 1 -- and write the g / grad_f rows of their
+    // span completely: own nodes from registers, the nodes of other buckets in between from the staging block those buckets'
+    // kernels (launched earlier) filled.  The unpack pass is then not needed.  Limits: the span rows live in LDS (<= 32 KB per
+    // workgroup) and a tile's foreign nodes are fetched by one lane each (<= MPX_TILE); grids outside them keep the unpack pass.
+    c->absorb = c->g_packed && !getenv("MPX_NO_ABSORB");
+    c->abs_fpos.clear(), c->abs_fstage.clear(), c->abs_fn.clear();
+    for (auto& T : c->tiles) T.span_lo = T.span_len = T.f_first = T.f_count = 0;
+    for (int p = 0; p < c->n_phases && c->absorb; ++p) {
+      const PhaseStruct& P = c->ph[p];
+      Bucket* best = nullptr;
+      for (auto& B : c->buckets)
+        if (B.phase == p && (!best || B.node_i.size() > best->node_i.size())) best = &B;
+      if (!best) continue;
+      Bucket& B = *best;
+      std::vector<int> ts;  // the bucket's tiles of whole segments (not the node-0 mini tile), in segment order already
+      for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t)
+        if (!c->tiles[t].node0) ts.push_back(t);
+      if (ts.empty()) { c->absorb = false; break; }
+      const int nsg = nx + P.nc + (P.diff_u ? nu : 0) + (P.midu ? nu : 0) + nx + nu;
+      int cap = 0;
+      for (size_t j = 0; j < ts.size(); ++j) {
+        MpxTile& T = c->tiles[ts[j]];
+        const int64_t lo = j == 0 ? 0 : (int64_t)c->seg_start[T.seg0] + 1;
+        const int64_t hi = j + 1 < ts.size() ? (int64_t)c->seg_start[c->tiles[ts[j + 1]].seg0] + 1 : N;
+        T.span_lo = (int32_t)lo, T.span_len = (int32_t)(hi - lo), T.f_first = (int32_t)c->abs_fpos.size();
+        std::vector<char> mine((size_t)(hi - lo), 0);
+        for (int l = 0; l < T.n_own; ++l) mine[(size_t)(B.node_i[T.m0 + l] - lo)] = 1;
+        for (int64_t i = lo; i < hi; ++i)
+          if (!mine[(size_t)(i - lo)]) {
+            c->abs_fpos.push_back((int32_t)(i - lo));
+            c->abs_fstage.push_back(stage_pos[(size_t)p * N + i]);
+            c->abs_fn.push_back(stage_n[(size_t)p * N + i]);
+          }
+        T.f_count = (int32_t)c->abs_fpos.size() - T.f_first;
+        cap = std::max(cap, (int)T.span_len);
+        if (T.f_count > MPX_TILE) c->absorb = false;
+      }
+      cap += cap & 1;
+      if ((int64_t)cap * nsg * 8 > 32768) c->absorb = false;
+      B.abs_cap = cap, B.abs_slots = nsg;
+    }
+    if (!c->absorb) {
+      for (auto& T : c->tiles) T.span_lo = T.span_len = T.f_first = T.f_count = 0;
+      for (auto& B : c->buckets) B.abs_cap = 0;
+      c->abs_fpos.clear(), c->abs_fstage.clear(), c->abs_fn.clear();
+    }
   }
 
   // ---- Jacobian pattern -----------------------------------------------------------------
@@ -509,6 +560,7 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   if ((rc = upload(c, &c->d_hc_dst, c->hc_dst))) return rc;
   if ((rc = upload(c, &c->d_th_dst, c->th_dst))) return rc;
   if ((rc = upload(c, &c->d_gmap, c->gmap)) || (rc = upload(c, &c->d_qmap, c->qmap))) return rc;
+  if (c->absorb && ((rc = upload(c, &c->d_abs_fpos, c->abs_fpos)) || (rc = upload(c, &c->d_abs_fstage, c->abs_fstage)) || (rc = upload(c, &c->d_abs_fn, c->abs_fn)))) return rc;
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   c->has_device = true;
@@ -548,9 +600,9 @@ __global__ __launch_bounds__(256) void mpx_prefix_kernel(const double* __restric
   }
 }
 
-int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size_t size) {
+int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size_t size, unsigned lds_bytes = 0) {
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  HIPCHK(c, hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, c->stream, nullptr, cfg));
+  HIPCHK(c, hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, lds_bytes, c->stream, nullptr, cfg));
   return MPX_OK;
 }
 
@@ -667,8 +719,18 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
     if (rc) return rc;
   }
   if (geom.begin && nodes) HIPCHK(c, hipEventRecord(geom.begin, c->stream));
+  // absorbing buckets (see build_layout) go last: their tiles read what the other buckets staged
+  const bool absorb = packed && !shard && c->absorb;
+  for (int pass = 0; pass < 2; ++pass)
   for (auto& B : c->buckets) {
+    const bool absorber = absorb && B.abs_cap > 0;
     int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);
+    if (absorber) {  // its node-0 mini tile (if any) stages like the other buckets: first pass, the absorbing tiles in the second
+      const int64_t split = B.tile_first + (c->tiles[B.tile_first].node0 ? 1 : 0);
+      if (pass == 0) hi = std::min(hi, split); else lo = std::max(lo, split);
+    } else if (pass == 1) {
+      continue;
+    }
     if (hi <= lo || !nodes) continue;
     const PhaseStruct& P = c->ph[B.phase];
     const DegTable& t = c->degs[B.dt];
@@ -694,7 +756,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
     // regular bucket (every segment of the phase has this degree, tiles = [node 0][full ...][last]): descriptors by arithmetic
     {
       const int nt = B.tile_count;
-      bool reg = (int64_t)B.node_i.size() == c->N && nt >= 2 && c->tiles[B.tile_first].node0;
+      bool reg = (int64_t)B.node_i.size() == c->N && nt >= 2 && c->tiles[B.tile_first].node0 && !absorber;
       const int lanes = reg ? c->tiles[B.tile_first + 1].n : 0;
       for (int t = 1; reg && t < nt; ++t) {
         const MpxTile& T = c->tiles[B.tile_first + t];
@@ -715,11 +777,16 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
         A.reg_jac_size = c->tile_jac_size[B.tile_first + 1], A.reg_hess_size = c->tile_hess_size[B.tile_first + 1], A.reg_g_size = c->tile_g_size[B.tile_first + 1];
       }
     }
-    int rc = launch(c, B.fn[mode], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A);
+    unsigned lds = 0;
+    if (absorber && pass == 1) {
+      A.abs_fpos = c->d_abs_fpos, A.abs_fstage = c->d_abs_fstage, A.abs_fn = c->d_abs_fn, A.abs_cap = B.abs_cap;
+      lds = (unsigned)B.abs_cap * (unsigned)B.abs_slots * 8u;
+    }
+    int rc = launch(c, B.fn[mode], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A, lds);
     if (rc) return rc;
     if (c->profile) ++c->prof_launches;
   }
-  if (packed && (!shard || !nodes)) {
+  if (packed && (!shard || !nodes) && !absorb) {
     const int64_t rows = c->n_g + c->n_z;
     hipLaunchKernelGGL(mpx_unpack_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)((io.B + MPX_UNPACK_PTS - 1) / MPX_UNPACK_PTS)), dim3(256), 0,
                        c->stream, c->gtmp.p, c->gtmp_n, io.g, io.g_stride, c->d_gmap, c->n_g, io.grad, io.grad_stride, c->d_qmap, c->n_z, (int)io.B);
@@ -822,7 +889,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
     fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
-    fr(c->d_gmap), fr(c->d_qmap), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
+    fr(c->d_gmap), fr(c->d_qmap), fr(c->d_abs_fpos), fr(c->d_abs_fstage), fr(c->d_abs_fn), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -925,6 +992,13 @@ extern "C" int mpx_get_tile_weights(const mpx_ctx* c, int64_t* w) {
     mpx_get_tile_jac_range(c, (int64_t)t, &b, &e);
     w[t] = e - b;
   }
+  return MPX_OK;
+}
+
+extern "C" int mpx_get_tile_spans(const mpx_ctx* c, int32_t* first, int32_t* len, int32_t* n_foreign) {
+  if (!c || !first || !len || !n_foreign) return MPX_ERR_INVALID;
+  if (c->kind != 0) return MPX_ERR_UNSUPPORTED;
+  for (size_t t = 0; t < c->tiles.size(); ++t) first[t] = c->tiles[t].span_lo, len[t] = c->tiles[t].span_len, n_foreign[t] = c->tiles[t].f_count;
   return MPX_OK;
 }
 

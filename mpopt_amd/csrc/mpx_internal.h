@@ -42,6 +42,8 @@ struct Bucket {
   int phase = 0, deg = 0, dt = 0;  // dt: index into degree tables
   std::vector<int32_t> node_i, node_sk;
   int tile_first = 0, tile_count = 0;  // global tile ids
+  int abs_cap = 0;                     // > 0: absorbing bucket (MpxNodeArgs::abs_cap), row capacity of its LDS span buffer
+  int abs_slots = 0;                   // row slots of that buffer (g rows + grad_f rows per node)
   int32_t *d_node_i = nullptr, *d_node_sk = nullptr;
   hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
 };
@@ -98,6 +100,12 @@ struct mpx_ctx {
   std::vector<int64_t> gmap, qmap;  // row of g / entry of grad_f -> index in the staging block, -1: written elsewhere
   int64_t *d_gmap = nullptr, *d_qmap = nullptr;
   DevBuf<double> gtmp;
+  // ... without the unpack pass where the grid allows it (build_layout: absorbing buckets, MpxTile::span_*)
+  bool absorb = false;
+  std::vector<int32_t> abs_fpos, abs_fn;
+  std::vector<int64_t> abs_fstage;
+  int32_t *d_abs_fpos = nullptr, *d_abs_fn = nullptr;
+  int64_t* d_abs_fstage = nullptr;
   DevBuf<double> ea_scratch;  // mpx_equal_area_widths_device: cumulative areas + segment boundaries
   // MPX_CCS_ORDER: scratch in native order + device copies of the permutations (built on first use)
   DevBuf<double> ccs_j, ccs_h;

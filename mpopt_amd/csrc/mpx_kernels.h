@@ -185,6 +185,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   constexpr int NS_MID = G::MIDU ? NU * P1 : 0;
   __shared__ double sXU[2][NX + NU][SLOTS];
   __shared__ double sRed[2][MPX_TILE / 64][NRED1];
+  extern __shared__ double sAbs[];  // absorbing tiles: [row slot][abs_cap] g / grad_f values of the tile's node span
 
   // Workgroup -> (tile, batch chunk).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin;
   // here every XCD (id = linear id mod 8) walks a CONTIGUOUS range of (chunk, tile) items, so each XCD's L2
@@ -284,6 +285,15 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   const int b0 = by_ * io.b_per_block;
   const int b1 = (b0 + io.b_per_block < io.B) ? b0 + io.b_per_block : io.B;
   const int64_t tslot = (int64_t)T.tile_id * io.nred;
+  // Absorbing tile (mixed-degree phases, MpxNodeArgs::abs_cap): row slots as in the packed staging block -- defect, path, DU, mU
+  // rows, then the grad_f entries of the node.
+  constexpr int SG_C = NX, SG_DU = NX + NC, SG_MU = SG_DU + (G::DIFF_U ? NU : 0), SG_Q = SG_MU + (G::MIDU ? NU : 0), NSG = SG_Q + NX + NU;
+  const bool absorb = MODE != MPX_MODE_HESS && A.abs_cap > 0 && T.span_len > 0 && io.gtmp != nullptr;
+  const int cap = A.abs_cap;
+  const int ia = i - T.span_lo;  // the lane's node in the span
+  int fpos = -1, fn = 0;         // the foreign node this lane fetches from the staging block
+  int64_t fstage = 0;
+  if (absorb && l < T.f_count) fpos = A.abs_fpos[T.f_first + l], fstage = A.abs_fstage[T.f_first + l], fn = A.abs_fn[T.f_first + l];
 
   // One evaluation point's inputs of this lane.  The batch loop is software pipelined: the loads of
   // point b+1 are issued BEFORE the stores of point b.  vmcnt retires in order, so a wait for loads
@@ -322,6 +332,45 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
     q.ws = io.w[woff];
     q.wc = io.wcum[woff];
   };
+  // Absorbing tile: after the own lanes put their values in the span buffer, the foreign nodes' staged values join them and the
+  // whole workgroup stores every row of the span as one contiguous run (full cache lines except at the two ends).  The barrier
+  // waits for LDS only: a __syncthreads() here would also drain the store queue of the previous point's Jacobian block.
+  double fv[MODE == MPX_MODE_HESS ? 1 : NSG];  // staged values of the lane's foreign node (loaded at the top of the iteration)
+  int b_cur = 0;
+  auto span_store = [&]() {
+    constexpr int NSL = (MODE == MPX_MODE_FGJ) ? NSG : SG_Q;
+    if (fpos >= 0) {
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) sAbs[sl * cap + fpos] = fv[sl];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int len = T.span_len, lo = T.span_lo;
+    auto put_row = [&](int sl, double* __restrict__ row, int e0) {  // row[e] <- slot sl, e = e0 .. len - 1
+      for (int e = e0 + l; e < len; e += MPX_TILE) row[e] = sAbs[sl * cap + e];
+    };
+    if (io.g) {
+      double* __restrict__ gb = io.g + (int64_t)b_cur * io.g_stride;
+#pragma unroll
+      for (int a = 0; a < NX; ++a) put_row(a, gb + (A.g_off_F + (int64_t)a * N) + lo, 0);
+#pragma unroll
+      for (int j = 0; j < NC; ++j) put_row(SG_C + j, gb + (A.g_off_C + (int64_t)j * N) + lo, 0);
+      if constexpr (G::DIFF_U) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) put_row(SG_DU + c, gb + (A.g_off_DU + (int64_t)c * N) + lo, 0);
+      }
+      if constexpr (G::MIDU) {  // the row of node i is i - 1; node 0 of the phase has none
+#pragma unroll
+        for (int c = 0; c < NU; ++c) put_row(SG_MU + c, gb + (A.g_off_mU + (int64_t)c * (N - 1)) + (lo - 1), lo == 0 ? 1 : 0);
+      }
+    }
+    if constexpr (MODE == MPX_MODE_FGJ) {
+      if (io.grad) {
+        double* __restrict__ qb = io.grad + (int64_t)b_cur * io.grad_stride + A.z_off;
+#pragma unroll
+        for (int a = 0; a < NX + NU; ++a) put_row(SG_Q + a, qb + (int64_t)a * N + lo, 0);
+      }
+    }
+  };
   In cur, nxt;
   if (b0 < b1) load_point(b0, cur);
   int it = 0;
@@ -346,6 +395,14 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
       }
     }
     if (b + 1 < b1) load_point(b + 1, nxt);
+    b_cur = b;
+    if constexpr (MODE != MPX_MODE_HESS) {
+      if (fpos >= 0) {  // staged values of the lane's foreign node: in flight during the node's own work
+        const double* __restrict__ gt = io.gtmp + (int64_t)b * io.gtmp_stride + fstage;
+#pragma unroll
+        for (int sl = 0; sl < (MODE == MPX_MODE_FGJ ? NSG : SG_Q); ++sl) fv[sl] = gt[(int64_t)sl * fn];
+      }
+    }
 #ifndef MPX_ABL_NO_BARRIER
     __syncthreads();
 #endif
@@ -387,23 +444,29 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
         double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
         // destination of a g value: its row, or (mixed-degree phases) slot `sl` of the tile's packed block
         double* __restrict__ gp = io.gtmp ? io.gtmp + (int64_t)b * io.gtmp_stride + T.g_base + l : nullptr;
-        auto gdst = [&](int sl, double* row) -> double* { return gp ? gp + (int64_t)sl * n : row; };
+        // (absorbing tiles: slot `sl` of the span buffer in LDS)
+        auto gput = [&](int sl, double* row, double v) {
+          if (absorb)
+            sAbs[sl * cap + ia] = v;
+          else
+            *(gp ? gp + (int64_t)sl * n : row) = v;
+        };
 #pragma unroll
         for (int a = 0; a < NX; ++a) {  // defect  F = D.X - h*Sx*dyn      (mpopt.py:227-232)
           double acc = 0;
 #pragma unroll(TAB_LDS ? 4 : P1)
           for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][a][base + j], acc);
-          *gdst(a, gb + (A.g_off_F + (int64_t)a * N) + i) = acc - fx[a];
+          gput(a, gb + (A.g_off_F + (int64_t)a * N) + i, acc - fx[a]);
         }
 #pragma unroll
-        for (int j = 0; j < NC; ++j) *gdst(NX + j, gb + (A.g_off_C + (int64_t)j * N) + i) = cc[j];  // mpopt.py:204, 255
+        for (int j = 0; j < NC; ++j) gput(NX + j, gb + (A.g_off_C + (int64_t)j * N) + i, cc[j]);  // mpopt.py:204, 255
         if constexpr (G::DIFF_U) {  // DU = D.U                              (mpopt.py:315-324)
 #pragma unroll
           for (int c = 0; c < NU; ++c) {
             double acc = 0;
 #pragma unroll(TAB_LDS ? 4 : P1)
             for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][NX + c][base + j], acc);
-            *gdst(NX + NC + c, gb + (A.g_off_DU + (int64_t)c * N) + i) = acc;
+            gput(NX + NC + c, gb + (A.g_off_DU + (int64_t)c * N) + i, acc);
           }
         }
         if constexpr (G::MIDU) {  // control at the mid-points of the nodes  (mpopt.py:350-369)
@@ -413,10 +476,13 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
               double acc = 0;
 #pragma unroll(TAB_LDS ? 4 : P1)
               for (int j = 0; j < P1; ++j) acc = fma(Crow(j), sXU[buf][NX + c][base + j], acc);
-              *gdst(NX + NC + (G::DIFF_U ? NU : 0) + c, gb + (A.g_off_mU + (int64_t)c * (N - 1)) + (i - 1)) = acc;
+              gput(NX + NC + (G::DIFF_U ? NU : 0) + c, gb + (A.g_off_mU + (int64_t)c * (N - 1)) + (i - 1), acc);
             }
           }
         }
+      }
+      if constexpr (MODE == MPX_MODE_FG) {
+        if (absorb) span_store();
       }
       if constexpr (MODE == MPX_MODE_FGJ) {
 #ifdef MPX_ABL_NO_G
@@ -428,8 +494,14 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
           constexpr int SQ = NX + NC + (G::DIFF_U ? NU : 0) + (G::MIDU ? NU : 0);  // first grad_f slot of the packed block
           double* __restrict__ qp = io.gtmp ? io.gtmp + (int64_t)b * io.gtmp_stride + T.g_base + l : nullptr;
 #pragma unroll
-          for (int a = 0; a < NX + NU; ++a) *(qp ? qp + (int64_t)(SQ + a) * n : qb + (int64_t)a * N + i) = gn[a];
+          for (int a = 0; a < NX + NU; ++a) {
+            if (absorb)
+              sAbs[(SQ + a) * cap + ia] = gn[a];
+            else
+              *(qp ? qp + (int64_t)(SQ + a) * n : qb + (int64_t)a * N + i) = gn[a];
+          }
         }
+        if (absorb) span_store();
 #ifdef MPX_ABL_NO_JAC
         if (false) {
 #else

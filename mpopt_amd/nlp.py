@@ -345,6 +345,13 @@ class NlpFunctions:
         _lib.check(self._L.mpx_get_tile_weights(self._ctx, w.ctypes.data_as(_lib.c_int64_p)), self._ctx)
         return w
 
+    def tile_spans(self):
+        """Per tile: (first node, length, foreign nodes) of the g / grad_f row span the tile stores itself on mixed-degree grids
+        (mpx_get_tile_spans); all zero where the scheme does not apply."""
+        a = [np.zeros(self.n_tiles, np.int32) for _ in range(3)]
+        _lib.check(self._L.mpx_get_tile_spans(self._ctx, *[v.ctypes.data_as(_lib.c_int32_p) for v in a]), self._ctx)
+        return tuple(a)
+
     def partials(self, batch):
         """(device pointer, element count) of the per-tile partial-sum buffer for ``batch`` points."""
         ptr, cnt = ctypes.c_void_p(), ctypes.c_int64()

@@ -179,6 +179,58 @@ def test_launch_geometry_does_not_change_results(monkeypatch):
     assert len(digests) == 1
 
 
+ABSORB_CASES = {
+    "vdp_3_30_3_x16": (problems.van_der_pol, 48, mixed(48), "CGL"),            # config 3's pattern, two absorbing tiles
+    "vdp_3_30_3_x100": (problems.van_der_pol, 300, mixed(300), "CGL"),         # 13 absorbing tiles
+    "kitchen_sink_5_first": (problems.kitchen_sink, 40, [5, 2, 3, 4] * 10, "LGR"),  # 2 phases; segment 0 in the absorbing bucket
+    "kitchen_sink_5552": (problems.kitchen_sink, 400, [5, 5, 5, 2] * 100, "LGR"),   # path + DU rows, parameters, six absorbing tiles
+    "dae_vdp_mixed": (problems.dae_vdp, 60, [3, 6, 3] * 20, "LGL"),            # parameter + path row
+}
+
+
+@pytest.mark.parametrize("name", list(ABSORB_CASES))
+def test_mixed_degree_row_spans_equal_the_unpack_pass_bitwise(name, monkeypatch):
+    """Mixed-degree grids: the tiles that assemble whole g / grad_f row spans in LDS (mpx_get_tile_spans) against the same
+    library with the scheme switched off (MPX_NO_ABSORB: staging block + unpack pass) -- same bits for every mask that writes
+    g or grad_f, for one point and for a batch that is not a multiple of the points per workgroup."""
+    import torch
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC
+
+    builder, S, po, scheme = ABSORB_CASES[name]
+    ocp = builder(mp, M.math)
+
+    def make():
+        mpo = mp.mpopt(ocp, S, po, scheme)
+        return mpo, mpo.create_nlp()[0]["oracle"]
+
+    mpo, oa = make()
+    monkeypatch.setenv("MPX_NO_ABSORB", "1")
+    _, ob = make()
+    monkeypatch.delenv("MPX_NO_ABSORB")
+    assert oa.tile_spans()[1].any() and not ob.tile_spans()[1].any()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(17)
+    for B in (1, 7):
+        Z = torch.tensor(mpo.initialize_solution()[None, :] + 0.05 * rng.standard_normal((B, oa.n_z)), device=dev)
+        w = rng.uniform(0.4, 1.6, (ocp.n_phases, S))
+        p = torch.tensor((w / w.sum(axis=1, keepdims=True)).ravel(), device=dev)
+        for mask in (MPX_F | MPX_G | MPX_GRAD | MPX_JAC, MPX_F | MPX_G, MPX_GRAD, MPX_G | MPX_JAC):
+            got = []
+            for o in (oa, ob):
+                mk = lambda *s: torch.full(s, float("nan"), dtype=torch.float64, device=dev)
+                f, g, gr, jv = mk(B), mk(B, o.n_g), mk(B, o.n_z), mk(B, o.nnz_jac)
+                o.eval_device(mask, B, Z, p, 0, None, None, f if mask & MPX_F else None, g if mask & MPX_G else None,
+                              gr if mask & MPX_GRAD else None, jv if mask & MPX_JAC else None, None)
+                o.sync()
+                got.append((f, g, gr, jv))
+            for k, (x, y) in enumerate(zip(*got)):
+                assert torch.equal(x.isnan(), y.isnan()) and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y)), (name, B, mask, "f g grad_f jac".split()[k])
+            if mask & MPX_G:
+                assert not got[0][1].isnan().any()
+            if mask & MPX_GRAD:
+                assert not got[0][2].isnan().any()
+
+
 def test_device_pointer_api_matches_host_api():
     import torch
 

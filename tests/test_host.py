@@ -275,3 +275,35 @@ def test_numpy_functions_on_traced_symbols():
         assert abs(tr.evaluate([tr.wrap(e)], env)[0] - want) < 1e-14
     d = tr.diff(np.arctan2(y, x), x)
     assert abs(tr.evaluate([d], env)[0] + 0.7 / 0.58) < 1e-14
+
+
+def test_mixed_degree_row_span_plan(monkeypatch):
+    """Mixed-degree grids: the tiles of the bucket with the most nodes cut the phase's nodes into contiguous spans and store
+    the g / grad_f rows of their span themselves (mpx_get_tile_spans); single-degree grids and grids outside the limits of the
+    scheme (a tile would have to fetch more than 256 foreign nodes, or hold more than 32 KB of rows in LDS) keep none."""
+    def spans(builder, S, po, scheme):
+        ocp = builder(mp, M.math)
+        mpo = mp.mpopt(ocp, S, po, scheme)
+        mpo.compute_numerical_approximation()
+        o = M.NlpFunctions(ocp, S, mpo.poly_orders, scheme, tau0=mpo.tau0, tau1=mpo.tau1, with_device=False)
+        lo, ln, nf = o.tile_spans()
+        return o, lo, ln, nf, int(np.sum(mpo.poly_orders)) + 1
+
+    # config 3's pattern: degree-30 tiles absorb the degree-3 segments (and node 0) between them
+    o, lo, ln, nf, N = spans(problems.van_der_pol, 48, [30 if s % 3 == 1 else 3 for s in range(48)], "CGL")
+    act = ln > 0
+    assert act.sum() == 2 and lo[act][0] == 0 and (lo[act][1:] == (lo[act] + ln[act])[:-1]).all() and (lo[act] + ln[act])[-1] == N
+    assert nf[act].sum() == N - 16 * 30 and (nf[~act] == 0).all()
+    # two phases, segment 0 of the most populated degree: node 0 is staged by its mini tile and fetched like a foreign node
+    o, lo, ln, nf, N = spans(problems.kitchen_sink, 40, [5, 2, 3, 4] * 10, "LGR")
+    act = ln > 0
+    assert act.sum() == 2 * 1 and (ln[act] == N).all() and (nf[act] == N - 50).all()
+    # single degree: nothing to absorb
+    o, lo, ln, nf, N = spans(problems.moon_lander, 30, 4, "LGR")
+    assert not ln.any() and not nf.any()
+    # halves of different degree: one tile would fetch > 256 foreign nodes -> the unpack pass stays
+    o, lo, ln, nf, N = spans(problems.van_der_pol, 400, [3] * 200 + [6] * 200, "LGL")
+    assert not ln.any()
+    monkeypatch.setenv("MPX_NO_ABSORB", "1")
+    o, lo, ln, nf, N = spans(problems.van_der_pol, 48, [30 if s % 3 == 1 else 3 for s in range(48)], "CGL")
+    assert not ln.any()
