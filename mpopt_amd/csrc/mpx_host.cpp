@@ -322,7 +322,12 @@ int build_layout(mpx_ctx* c) {
         if (T.f_count > MPX_TILE) c->absorb = false;
       }
       cap += cap & 1;
-      if ((int64_t)cap * nsg * 8 > 32768) c->absorb = false;
+      {  // static LDS of the bucket's node kernel (same arithmetic as build_tables) + the span rows: inside the 64 KB a launch
+         // gets without raising the function's dynamic shared memory limit
+        const int64_t P1 = B.deg + 1, segs = MPX_TILE / B.deg;
+        const int64_t lds_static = 8 * ((B.deg > 12 ? P1 * P1 + (int64_t)B.deg * P1 : 0) + 2 * (int64_t)(nx + nu) * segs * P1) + 8 * 2 * 4 * 64;
+        if ((int64_t)cap * nsg * 8 > 32768 || lds_static + (int64_t)cap * nsg * 8 > 65536) c->absorb = false;
+      }
       B.abs_cap = cap, B.abs_slots = nsg;
     }
     if (!c->absorb) {

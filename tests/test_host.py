@@ -304,6 +304,9 @@ def test_mixed_degree_row_span_plan(monkeypatch):
     # halves of different degree: one tile would fetch > 256 foreign nodes -> the unpack pass stays
     o, lo, ln, nf, N = spans(problems.van_der_pol, 400, [3] * 200 + [6] * 200, "LGL")
     assert not ln.any()
+    # 7 states + 3 controls: the node kernel's own state/control tile leaves no room for the span rows within 64 KB of LDS
+    o, lo, ln, nf, N = spans(problems.staged_ascent, 30, [3, 4, 3] * 10, "LGR")
+    assert not ln.any()
     monkeypatch.setenv("MPX_NO_ABSORB", "1")
     o, lo, ln, nf, N = spans(problems.van_der_pol, 48, [30 if s % 3 == 1 else 3 for s in range(48)], "CGL")
     assert not ln.any()
