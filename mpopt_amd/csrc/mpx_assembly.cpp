@@ -301,7 +301,9 @@ static int launch_points(mpx_ctx* c, int mode, int64_t batch, const double* z, c
   MpxPtCall A{};
   A.sets = a->d_sets, A.n_sets = (int32_t)a->sets.size(), A.n_g = (int32_t)c->n_g, A.B = (int32_t)batch;
   A.b_per_block = pick_chunk(batch, a->n_blocks);
-  if (batch * a->n_blocks >= 16384) A.b_per_block = std::max(A.b_per_block, a->points_per_lane);  // see point_body
+  // (threshold measured with tools/r2_asm_ab.sh: 14336 workgroups of the 40x4 hypersensitive case gain 17 % from it, MPX_PTS_MIN_WG overrides)
+  static const int64_t min_wg = getenv("MPX_PTS_MIN_WG") ? atoll(getenv("MPX_PTS_MIN_WG")) : 4096;
+  if (batch * a->n_blocks >= min_wg) A.b_per_block = std::max(A.b_per_block, a->points_per_lane);  // see point_body
   A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma;
   A.raw = a->raw.p;
   A.raw_stride = mode == MPX_MODE_HESS ? a->rawh_n : a->raw_n;

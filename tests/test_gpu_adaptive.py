@@ -215,7 +215,7 @@ def test_adaptive_device_pointer_api_matches_host_api():
 
 
 def test_adaptive_large_batch_equals_single_evaluations_bitwise():
-    """Past 16384 workgroups the generated point kernels take several evaluation points per lane (MPX_PTS_UNROLL, read by the
+    """Past 4096 workgroups the generated point kernels take several evaluation points per lane (MPX_PTS_UNROLL, read by the
     host from the code object) and the gather pass four: every point of a large batch -- including the remainder points of
     a batch that is not a multiple of either -- must carry the bits of its own single evaluation."""
     import torch
