@@ -231,6 +231,53 @@ def test_mixed_degree_row_spans_equal_the_unpack_pass_bitwise(name, monkeypatch)
                 assert not got[0][2].isnan().any()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_mixed_degree_grids_spans_equal_unpack_and_oracle(seed, monkeypatch):
+    """Random degree sequences (degrees on both sides of the tables-in-LDS switch, runs of equal degree, isolated segments,
+    segment 0 inside or outside the absorbing bucket): row spans == unpack pass bitwise, and g / grad_f / jac_g against the
+    numpy oracle at 1e-10."""
+    import torch
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC
+
+    rng = np.random.default_rng(1000 + seed)
+    degs = rng.choice([1, 2, 3, 4, 6, 12, 13, 20], size=3, replace=False)
+    S = int(rng.integers(5, 90))
+    runs = rng.integers(1, 6, size=S)  # runs of equal degree of random length
+    po = np.repeat(rng.choice(degs, size=S), runs)[:S].tolist()
+    builder = [problems.van_der_pol, problems.dae_vdp, problems.kitchen_sink][seed % 3]
+    scheme = ["LGR", "LGL", "CGL"][seed % 3]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    oa = mpo.create_nlp()[0]["oracle"]
+    monkeypatch.setenv("MPX_NO_ABSORB", "1")
+    ob = mp.mpopt(ocp, S, po, scheme).create_nlp()[0]["oracle"]
+    monkeypatch.delenv("MPX_NO_ABSORB")
+    if len(set(po)) > 1:
+        assert not ob.tile_spans()[1].any()
+    dev = torch.device("cuda", 0)
+    B = 3
+    Zh = mpo.initialize_solution()[None, :] + 0.05 * rng.standard_normal((B, oa.n_z))
+    w = rng.uniform(0.4, 1.6, (ocp.n_phases, S))
+    ph = (w / w.sum(axis=1, keepdims=True)).ravel()
+    Z, p = torch.tensor(Zh, device=dev), torch.tensor(ph, device=dev)
+    got = []
+    for o in (oa, ob):
+        mk = lambda *s: torch.full(s, float("nan"), dtype=torch.float64, device=dev)
+        f, g, gr, jv = mk(B), mk(B, o.n_g), mk(B, o.n_z), mk(B, o.nnz_jac)
+        o.eval_device(MPX_F | MPX_G | MPX_GRAD | MPX_JAC, B, Z, p, 0, None, None, f, g, gr, jv, None)
+        o.sync()
+        got.append((f, g, gr, jv))
+    for x, y in zip(*got):
+        assert torch.equal(x, y) and not x.isnan().any(), (seed, S, po)
+    O = OracleNLP(ocp, S, po, scheme)
+    f, g, gr, jv = (t.cpu().numpy() for t in got[0])
+    jr, jc = oa.jac_pattern()
+    for b in (0, B - 1):
+        assert rel_err(g[b], O.g(Zh[b], ph)) < TOL and rel_err(gr[b], O.grad_f(Zh[b], ph)) < TOL
+        J = sp.coo_matrix((jv[b], (jr, jc)), shape=(oa.n_g, oa.n_z)).toarray()
+        assert rel_err(J, O.jac_g(Zh[b], ph).toarray()) < TOL
+
+
 def test_device_pointer_api_matches_host_api():
     import torch
 
