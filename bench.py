@@ -407,6 +407,11 @@ def main():
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["frac_by_traffic"] = tr["bytes_per_launch"] / kernel_s / 1e9 / HBM_PEAK_GBS
             out["roofline"]["traffic_source"] = os.path.relpath(tfh, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
+        # config 3: traffic of the degree-30 kernel (the degree-3 bucket and the boundary pass move another ~5 %)
+        tf3 = os.path.join(ROOT, "profiles", "r2_c3_spans", "traffic.json")
+        if args.workload == "config3-fgj" and B == 512 and os.path.exists(tf3):
+            out["roofline"]["traffic"] = json.load(open(tf3))["bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r2_c3_spans/traffic.json (mpx_node_fgj_0_30 only; rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
         # HBM traffic of the dominant kernel from the committed PMC passes (same workload only)
         tf = os.path.join(ROOT, "profiles", "r2_headline", "traffic.json")
         if os.path.exists(tf):
