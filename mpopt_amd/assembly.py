@@ -188,7 +188,7 @@ class AssembledNlpFunctions(NlpFunctions):
         # (MI355X, moon lander 20x5 at B = 4096: 1.05-1.45x on f+g+grad_f+jac_g, 1.1-2.1x on hess_l depending on the box); the
         # generated code is replicated per point, so large functions (kitchen sink: 3x the compile time, no gain) keep 1.
         n_stmt = sum(p.count(";") for p in parts)
-        parts += ["}  // namespace mpxgen", f"#define MPX_PTS_UNROLL {4 if n_stmt <= 1000 else 1}", '#include "mpx_assembly_kernels.h"']
+        parts += ["}  // namespace mpxgen", "#ifndef MPX_PTS_UNROLL  // (-DMPX_PTS_UNROLL=n in MPX_HIPCC_FLAGS overrides)", f"#define MPX_PTS_UNROLL {4 if n_stmt <= 1000 else 1}", "#endif", '#include "mpx_assembly_kernels.h"']
         parts.append(f"MPX_INSTANTIATE_POINTS({len(funcs)})")
         return "\n".join(parts) + "\n"
 
