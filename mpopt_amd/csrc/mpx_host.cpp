@@ -584,24 +584,41 @@ __global__ __launch_bounds__(256) void mpx_prefix_kernel(const double* __restric
   const int quarter = ((S + 3) / 4 + 63) / 64 * 64;  // multiple of 64: every step of a wavefront is one aligned run
   const int q0 = wave * quarter, q1 = min(S, q0 + quarter);
   double tot = 0;
-  for (int s = q0 + lane; s < q1; s += 64) tot += a[s];
+  for (int s0 = q0 + lane; s0 < q1; s0 += 64 * 8) {  // eight loads in flight, added in index order
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = s0 + k * 64 < q1 ? a[s0 + k * 64] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (s0 + k * 64 < q1) tot += v[k];
+  }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d, 64);
   if (lane == 0) wave_tot[wave] = tot;
   __syncthreads();
   double carry = 0;
   for (int q = 0; q < wave; ++q) carry += wave_tot[q];
-  for (int s0 = q0; s0 < q1; s0 += 64) {
-    const int s = s0 + lane;
-    const double v = s < q1 ? a[s] : 0.0;
-    double inc = v;
+  // eight 64-element steps at a time: their loads are in flight together, the scan itself (same additions, same order as one
+  // step at a time) runs on registers
+  for (int s0 = q0; s0 < q1; s0 += 64 * 8) {
+    double v[8];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const double u = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += u;
+    for (int k = 0; k < 8; ++k) {
+      const int s = s0 + k * 64 + lane;
+      v[k] = s < q1 ? a[s] : 0.0;
     }
-    if (s < q1) o[s] = carry + (inc - v);
-    carry += __shfl(inc, 63, 64);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int s = s0 + k * 64 + lane;
+      double inc = v[k];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double u = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += u;
+      }
+      if (s < q1) o[s] = carry + (inc - v[k]);
+      carry += __shfl(inc, 63, 64);
+    }
   }
 }
 
