@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="evaluation points per GPU per step")
     ap.add_argument("--segments", type=int, default=1000)
     ap.add_argument("--degree", type=int, default=5)
-    ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config2-hess", "adaptive-fgj", "config3-shard", "config4-shard", "config5-loop"],
+    ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config3-hess", "config2-hess", "adaptive-fgj", "config3-shard", "config4-shard", "config5-loop"],
                     help="default: the metric's configuration (BASELINE configs[1], f+g+grad_f+jac_g).  The others are "
                          "secondary reports (configs[4]: nlp_hess_l on hypersensitive 4000x3; configs[2]: mixed-degree grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,9 +213,9 @@ def main():
     if args.workload in ("config5-hess", "config5-loop"):
         builder, S, P, scheme = problems.BENCH_CASES[3]
         label = "hypersensitive OCP, n_segments=4000, poly_orders=3, LGR (BASELINE configs[4])"
-    elif args.workload in ("config3-fgj", "config3-shard"):
+    elif args.workload in ("config3-fgj", "config3-shard", "config3-hess"):
         builder, S, P, scheme = problems.BENCH_CASES[1]
-        B = min(B, 512)
+        B = min(B, 2048 if hess_mode else 512)
         label = "Van der Pol OCP, n_segments=2000, poly_orders=[3,30,3]*, CGL (BASELINE configs[2])"
     elif args.workload == "config4-shard":
         builder, S, P, scheme = problems.BENCH_CASES[2]
