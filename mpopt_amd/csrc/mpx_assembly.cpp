@@ -340,6 +340,21 @@ static int launch_gather(mpx_ctx* c, const DevGather& g, int64_t batch, const do
   return MPX_OK;
 }
 
+// Evaluation points per pass.  The raw point values are written by the point kernels and read back by the gather pass; while a
+// pass's raw values + outputs fit the 256 MB Infinity Cache of an MI355X the read-back does not go to HBM.  Measured
+// (tools/adaptive_batch_sweep.py, moon lander 20x5): f+g+grad_f+jac_g peaks at 2048 points (179 MB per pass: 31 M evals/s) and
+// falls to 24-26 M at 8192+; hess_l peaks at 8192 points (246 MB: 65 M) and falls to 44 M at 16384.  Batches of more than 1.5x
+// 256 MB are therefore cut into equal passes of at most 256 MB that reuse ONE raw buffer (smaller passes lose more to the
+// shorter launches than the cache gives back); every evaluation point is independent, results unchanged.
+static int64_t points_per_pass(int64_t batch, int64_t doubles_per_point) {
+  static const int64_t budget = getenv("MPX_ASM_PASS_MB") ? atoll(getenv("MPX_ASM_PASS_MB")) * 1000000 : 256000000;  // 0: one pass
+  if (budget <= 0) return batch;
+  const int64_t fit = std::max<int64_t>(budget / (8 * std::max<int64_t>(doubles_per_point, 1)), 256);
+  if (batch <= fit + fit / 2) return batch;
+  const int64_t n_pass = (batch + fit - 1) / fit;
+  return ((batch + n_pass - 1) / n_pass + 3) / 4 * 4;
+}
+
 // Device-pointer evaluation of an assembled context (called from eval_core in mpx_host.cpp after the
 // argument checks).  All pointers are device pointers.
 int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* lam_g, const double* sigma, double* f, double* g,
@@ -347,27 +362,39 @@ int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   mpx_asm_state* a = c->assembled;
   if (mask & (MPX_BOUNDARY_ONLY | MPX_JAC_VARIABLE_ONLY)) return fail(c, MPX_ERR_UNSUPPORTED, "mask bit not available on assembled contexts");
   int rc;
-  if ((rc = reserve(c, a->raw, (size_t)(batch * std::max(a->raw_n, a->rawh_n))))) return rc;
   if (mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC)) {
     const int mode = (mask & (MPX_GRAD | MPX_JAC)) ? MPX_MODE_FGJ : MPX_MODE_FG;
-    hipEvent_t pe = nullptr;  // mpx_profile: one bracket per pass (point kernels + gather), counted as one launch
+    const int64_t per = points_per_pass(batch, a->raw_n + c->n_z + ((mask & MPX_G) ? c->n_g : 0) + ((mask & MPX_GRAD) ? c->n_z : 0) + ((mask & MPX_JAC) ? c->nnz_j : 0));
+    if ((rc = reserve(c, a->raw, (size_t)(per * a->raw_n)))) return rc;
+    hipEvent_t pe = nullptr;  // mpx_profile: one bracket per evaluation (point kernels + gather of every pass), counted as one launch
     if ((rc = prof_begin(c, &pe))) return rc;
-    if ((rc = launch_points(c, mode, batch, z, nullptr, nullptr))) return rc;
-    const int64_t begin[4] = {0, 1, 1 + c->n_g, 1 + c->n_g + c->n_z};
-    double* outp[4] = {(mask & MPX_F) ? f : nullptr, (mask & MPX_G) ? g : nullptr, (mask & MPX_GRAD) ? grad_f : nullptr, (mask & MPX_JAC) ? jac_val : nullptr};
-    const int64_t stride[4] = {1, c->n_g, c->n_z, c->nnz_j};
-    if ((rc = launch_gather(c, a->fgj, batch, z, a->raw_n, 4, begin, outp, stride))) return rc;
+    for (int64_t b0 = 0; b0 < batch; b0 += per) {
+      const int64_t nb = std::min(per, batch - b0);
+      const double* zb = z + b0 * c->n_z;
+      if ((rc = launch_points(c, mode, nb, zb, nullptr, nullptr))) return rc;
+      const int64_t begin[4] = {0, 1, 1 + c->n_g, 1 + c->n_g + c->n_z};
+      double* outp[4] = {(mask & MPX_F) ? f + b0 : nullptr, (mask & MPX_G) ? g + b0 * c->n_g : nullptr, (mask & MPX_GRAD) ? grad_f + b0 * c->n_z : nullptr,
+                         (mask & MPX_JAC) ? jac_val + b0 * c->nnz_j : nullptr};
+      const int64_t stride[4] = {1, c->n_g, c->n_z, c->nnz_j};
+      if ((rc = launch_gather(c, a->fgj, nb, zb, a->raw_n, 4, begin, outp, stride))) return rc;
+    }
     if ((rc = prof_end(c, pe))) return rc;
     if (c->profile) ++c->prof_launches;
   }
   if (mask & MPX_HESS) {
+    const int64_t per = points_per_pass(batch, a->rawh_n + c->n_z + c->n_g + 1 + c->nnz_h);
+    if ((rc = reserve(c, a->raw, (size_t)(per * a->rawh_n)))) return rc;
     hipEvent_t pe = nullptr;
     if ((rc = prof_begin(c, &pe))) return rc;
-    if ((rc = launch_points(c, MPX_MODE_HESS, batch, z, lam_g, sigma))) return rc;
-    const int64_t begin[1] = {0};
-    double* outp[1] = {hess_val};
-    const int64_t stride[1] = {c->nnz_h};
-    if ((rc = launch_gather(c, a->hess, batch, z, a->rawh_n, 1, begin, outp, stride))) return rc;
+    for (int64_t b0 = 0; b0 < batch; b0 += per) {
+      const int64_t nb = std::min(per, batch - b0);
+      const double* zb = z + b0 * c->n_z;
+      if ((rc = launch_points(c, MPX_MODE_HESS, nb, zb, lam_g + b0 * c->n_g, sigma + b0))) return rc;
+      const int64_t begin[1] = {0};
+      double* outp[1] = {hess_val + b0 * c->nnz_h};
+      const int64_t stride[1] = {c->nnz_h};
+      if ((rc = launch_gather(c, a->hess, nb, zb, a->rawh_n, 1, begin, outp, stride))) return rc;
+    }
     if ((rc = prof_end(c, pe))) return rc;
     if (c->profile) ++c->prof_launches;
   }
