@@ -347,7 +347,8 @@ static int launch_gather(mpx_ctx* c, const DevGather& g, int64_t batch, const do
 // 256 MB are therefore cut into equal passes of at most 256 MB that reuse ONE raw buffer (smaller passes lose more to the
 // shorter launches than the cache gives back); every evaluation point is independent, results unchanged.
 static int64_t points_per_pass(int64_t batch, int64_t doubles_per_point) {
-  static const int64_t budget = getenv("MPX_ASM_PASS_MB") ? atoll(getenv("MPX_ASM_PASS_MB")) * 1000000 : 256000000;  // 0: one pass
+  const char* env = getenv("MPX_ASM_PASS_MB");  // (read per call: tests switch it inside one process)
+  const int64_t budget = env ? atoll(env) * 1000000 : 256000000;  // 0: one pass
   if (budget <= 0) return batch;
   const int64_t fit = std::max<int64_t>(budget / (8 * std::max<int64_t>(doubles_per_point, 1)), 256);
   if (batch <= fit + fit / 2) return batch;

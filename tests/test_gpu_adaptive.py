@@ -214,8 +214,10 @@ def test_adaptive_device_pointer_api_matches_host_api():
         o.set_tile_range(0, 0)
 
 
-def test_adaptive_large_batch_equals_single_evaluations_bitwise():
-    """Past 4096 workgroups the generated point kernels take several evaluation points per lane (MPX_PTS_UNROLL, read by the
+@pytest.mark.parametrize("pass_mb", [None, "40"])
+def test_adaptive_large_batch_equals_single_evaluations_bitwise(pass_mb, monkeypatch):
+    """(pass_mb: batches larger than the Infinity Cache are evaluated in several passes over one raw buffer -- here forced to 40 MB,
+    i.e. eight passes with a ragged last one.)  Past 4096 workgroups the generated point kernels take several evaluation points per lane (MPX_PTS_UNROLL, read by the
     host from the code object) and the gather pass four: every point of a large batch -- including the remainder points of
     a batch that is not a multiple of either -- must carry the bits of its own single evaluation."""
     import torch
@@ -225,6 +227,8 @@ def test_adaptive_large_batch_equals_single_evaluations_bitwise():
     mpo = mp.mpopt_adaptive(ocp, 20, 5, "LGR")
     o = mpo.create_nlp()[0]["oracle"]
     assert "#define MPX_PTS_UNROLL 4" in o.source  # small point functions: four points per lane
+    if pass_mb:
+        monkeypatch.setenv("MPX_ASM_PASS_MB", pass_mb)
     rng = np.random.default_rng(11)
     B = 3500 + 3
     Z = mpo.initialize_solution()[None, :] * (1 + 0.05 * rng.uniform(-1, 1, (B, o.n_z)))
