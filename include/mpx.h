@@ -341,7 +341,7 @@ int mpx_create_assembled(const mpx_assembly* desc, mpx_ctx** out);
 /* ---------------------------------------------------------------------------------------------
  * CasADi-external-compatible surface (mpx_casadi.cpp): the symbols nlp_f, nlp_g, nlp_grad_f,
  * nlp_jac_g, nlp_hess_l (+ _n_in/_n_out/_name_in/_name_out/_sparsity_in/_sparsity_out/_work/
- * _incref/_decref) follow the calling convention of CasADi-generated C code and act on the context
+ * _incref/_decref, and the optional _alloc_mem/_init_mem/_free_mem/_checkout/_release/_default_in) follow the calling convention of CasADi-generated C code and act on the context
  * selected here (process-wide; NULL clears it).  The context must outlive its selection.
  * ------------------------------------------------------------------------------------------- */
 int mpx_set_current(mpx_ctx* ctx);

@@ -5,6 +5,7 @@
 // Convention (CasADi's public generated-code interface; casadi_int = long long, casadi_real = double):
 //   int NAME(const double** arg, double** res, long long* iw, double* w, int mem);   0 = ok
 //   NAME_n_in / _n_out / _name_in / _name_out / _sparsity_in / _sparsity_out / _work / _incref / _decref
+//   and the optional _alloc_mem / _init_mem / _free_mem / _checkout / _release / _default_in (one stateless memory object)
 //   sparsity = {nrow, ncol, colind[ncol+1], row[nnz]} (compressed column)
 //   NULL arg[i] means zeros, NULL res[i] means "not requested".
 // These entry points carry no user pointer, so they act on the process-wide *current* context chosen
@@ -113,6 +114,13 @@ extern "C" int mpx_set_current(mpx_ctx* ctx) {
   extern "C" long long NAME##_n_out(void) { return NOUT; }                              \
   extern "C" void NAME##_incref(void) {}                                                \
   extern "C" void NAME##_decref(void) {}                                                \
+  /* optional memory-object protocol of generated code: one stateless object */         \
+  extern "C" int NAME##_alloc_mem(void) { return 0; }                                   \
+  extern "C" int NAME##_init_mem(int) { return 0; }                                     \
+  extern "C" void NAME##_free_mem(int) {}                                               \
+  extern "C" int NAME##_checkout(void) { return 0; }                                    \
+  extern "C" void NAME##_release(int) {}                                                \
+  extern "C" double NAME##_default_in(long long) { return 0.0; }                        \
   extern "C" int NAME##_work(long long* a, long long* r, long long* iw, long long* w) { \
     if (a) *a = NIN;                                                                    \
     if (r) *r = NOUT;                                                                   \

@@ -176,7 +176,8 @@ def test_casadi_external_surface_metadata():
     o.make_current()
     LL = ctypes.POINTER(ctypes.c_longlong)
     for name, (nin, nout) in CASADI_FUNCS.items():
-        for suffix in ("", "_n_in", "_n_out", "_name_in", "_name_out", "_sparsity_in", "_sparsity_out", "_work", "_incref", "_decref"):
+        for suffix in ("", "_n_in", "_n_out", "_name_in", "_name_out", "_sparsity_in", "_sparsity_out", "_work", "_incref", "_decref", "_alloc_mem", "_init_mem", "_free_mem",
+                       "_checkout", "_release", "_default_in"):
             assert hasattr(L, name + suffix), name + suffix
         getattr(L, name + "_n_in").restype = ctypes.c_longlong
         getattr(L, name + "_n_out").restype = ctypes.c_longlong
