@@ -681,6 +681,13 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key) {
   const int64_t work = B * (c->tile_end - c->tile_begin);
   static const bool no_tune = getenv("MPX_NO_TUNE") != nullptr;
   if (no_tune || work < 32768 || !key || c->shard_world > 1) return {1, nullptr, nullptr};
+  {  // no event records / queries inside a stream capture (the caller is building a hipGraph): the robust geometry, no measuring
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return {1, nullptr, nullptr};
+    }
+  }
   mpx_ctx::GeomTune* T = nullptr;
   for (auto& t : c->tune)
     if (t.key == key && t.B == B && t.mode == mode) T = &t;
@@ -688,12 +695,15 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key) {
     if (c->tune.size() < 8) {
       c->tune.emplace_back();
       T = &c->tune.back();
-    } else {  // recycle the least recently used entry (its events are reused)
-      T = &c->tune[0];
-      for (auto& t : c->tune)
-        if (t.last_use < T->last_use) T = &t;
+    } else {  // recycle the least recently used entry whose measurement is not in flight (its events are reused)
+      for (auto& t : c->tune) {
+        const bool idle = t.stage == 0 || t.stage == 5 || (t.ev[7] && hipEventQuery(t.ev[7]) == hipSuccess);
+        if (idle && (!T || t.last_use < T->last_use)) T = &t;
+      }
+      (void)hipGetLastError();  // hipErrorNotReady of the queries
+      if (!T) return {1, nullptr, nullptr};  // every entry is mid-measurement: this pass is not tuned
     }
-    T->key = key, T->B = B, T->mode = mode, T->stage = 0, T->best = 1;
+    T->key = key, T->B = B, T->mode = mode, T->stage = 0, T->best = 1, T->uses = 0;
     T->cand[0] = 1;
     T->cand[1] = (int)std::min<int64_t>(std::max<int64_t>(work / 16384, 2), 8);
     for (auto& e : T->ev)
@@ -914,6 +924,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->d_gmap), fr(c->d_qmap), fr(c->d_abs_fpos), fr(c->d_abs_fstage), fr(c->d_abs_fn), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
+    if (c->ea_dbg) (void)hipHostFree(c->ea_dbg);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
@@ -1599,12 +1610,11 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
   int rc;
   if (!in_lds && (rc = reserve(c, c->ea_scratch, (size_t)(batch * n_pts)))) return rc;
   const size_t lds = in_lds ? lds_all : lds_pos;
-  static long long* dbg = nullptr;
+  long long*& dbg = c->ea_dbg;  // per context: freed in mpx_destroy
   if (!dbg && getenv("MPX_EA_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&dbg, 64, hipHostMallocMapped));
-  static size_t lds_allowed = 0;
-  if (lds > 48 * 1024 && lds > lds_allowed) {
+  if (lds > 48 * 1024 && lds > c->ea_lds_allowed) {  // the attribute is per device: remembered per context, not per process
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    lds_allowed = 150 * 1024;
+    c->ea_lds_allowed = 150 * 1024;
   }
   hipLaunchKernelGGL(mpx_equal_area_kernel, dim3((unsigned)batch), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
                      (int64_t)(p_in_per_point ? c->n_p : 0), c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, dbg);
@@ -1652,6 +1662,7 @@ static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const
                      const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix) {
   if (!c || !(mask & MPX_CCS_ORDER)) return eval_native(c, mask, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val, skip_prefix);
   if (mask & (MPX_JAC_VARIABLE_ONLY | MPX_BOUNDARY_ONLY)) return fail(c, MPX_ERR_INVALID, "MPX_CCS_ORDER cannot be combined with MPX_JAC_VARIABLE_ONLY / MPX_BOUNDARY_ONLY");
+  if (c->shard_world > 1) return fail(c, MPX_ERR_INVALID, "MPX_CCS_ORDER on a context in segment-sharded mode");
   if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
   if (batch < 1 || batch > 65535) return fail(c, MPX_ERR_INVALID, "MPX_CCS_ORDER: batch must be 1..65535");
   if (((mask & MPX_JAC) && !jac_val) || ((mask & MPX_HESS) && !hess_val)) return fail(c, MPX_ERR_INVALID, "mpx_eval: output array is NULL");
@@ -1759,6 +1770,9 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   if (!c->has_device)
     return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
   if (batch < 1 || !z || (!p && c->n_p > 0)) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
+  if (c->shard_world > 1)  // a sharded context runs node pass / exchange / boundary pass as separate device-pointer calls
+    return fail(c, MPX_ERR_INVALID, "mpx_eval on a context in segment-sharded mode: the host-pointer path (and the nlp_* entry points) would return "
+                                    "this rank's share only; use the mpx_eval_device / mpx_shard_* sequence, or mpx_shard_setup(ctx, 1, 0) first");
   const double t_entry = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
@@ -1797,8 +1811,7 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
       ok = (c->nnz_h == 0 || (hd = pin_alias(c, hess_val, B * c->nnz_h * 8)) != nullptr) && (ld = pin_alias(c, lam_g, B * c->n_g * 8)) != nullptr;
     if (ok) {
       if (c->h_scratch_cap < 2 * B) {  // page-locked scalars: f out, sigma in
-        if (c->h_scratch) (void)hipHostFree(c->h_scratch);
-    if (c->h_flag) (void)hipHostFree(c->h_flag);
+        if (c->h_scratch) (void)hipHostFree(c->h_scratch);  // (the completion flag below does not depend on the batch size)
         c->h_scratch = nullptr, c->h_scratch_cap = 0;
         const size_t cap = std::max<size_t>(2 * B, 64);
         HIPCHK(c, hipHostMalloc((void**)&c->h_scratch, cap * 8, hipHostMallocMapped));

@@ -107,6 +107,8 @@ struct mpx_ctx {
   int32_t *d_abs_fpos = nullptr, *d_abs_fn = nullptr;
   int64_t* d_abs_fstage = nullptr;
   DevBuf<double> ea_scratch;  // mpx_equal_area_widths_device: cumulative areas + segment boundaries
+  size_t ea_lds_allowed = 0;  //   dynamic LDS limit already raised for the kernel on this context's device
+  long long* ea_dbg = nullptr;  //   MPX_EA_DEBUG phase stamps (page-locked)
   // MPX_CCS_ORDER: scratch in native order + device copies of the permutations (built on first use)
   DevBuf<double> ccs_j, ccs_h;
   int64_t *d_perm_j = nullptr, *d_perm_h = nullptr;

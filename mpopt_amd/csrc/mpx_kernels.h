@@ -209,7 +209,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   // The tile descriptor: a table load -- or, for regular buckets, arithmetic, so that the loads of z (and of the lane's table
   // rows) are the FIRST memory operations of the workgroup instead of the third level of a dependent chain.  Measured on MI355X
   // (one evaluation point per workgroup, same-process A/B): headline kernel 914 -> 863 us, hypersensitive 4000x3 1003 -> 908 us.
-  MpxTile T;
+  MpxTile T{};  // (span_* / f_* stay zero for regular buckets: they never absorb)
   if (regular) {
     const int t = A.tile_first + (int)bx_ - A.reg_first_tile;  // index in the bucket
     const int w = t == 0 ? 0 : (t == A.reg_last ? 2 : 1);

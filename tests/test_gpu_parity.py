@@ -450,6 +450,49 @@ def test_pinned_host_buffers_match_pageable():
 
 
 @pytest.mark.gpu
+def test_zero_copy_path_with_growing_batches_on_one_context():
+    """Zero-copy evaluations (every array page-locked) at batch 1 -> 64 -> 4096 -> 1 on ONE context: the page-locked scalar block
+    is re-allocated as the batch grows, the completion flag must survive that (round-2 advisor finding: it was freed with it and
+    the next wait spun on unmapped memory).  Results equal the pageable path bit for bit."""
+    ocp = problems.moon_lander(mp, M.math)
+    mpo = mp.mpopt(ocp, 8, 3, "LGR")
+    o = mpo.create_nlp()[0]["oracle"]
+    rng = np.random.default_rng(3)
+    p = np.full(o.n_p, 1.0 / 8)
+    what = ["f", "g", "grad_f", "jac_g", "hess_l"]
+    for B in (1, 64, 4096, 1, 33):
+        z = mpo.initialize_solution()[None, :] + 0.05 * rng.standard_normal((B, o.n_z))
+        lam, sig = rng.standard_normal((B, o.n_g)), rng.uniform(0.5, 1.5, B)
+        a = o.eval(what, z, p, lam_g=lam, sigma=sig)
+        b = o.eval(what, z, p, lam_g=lam, sigma=sig, pinned=True)
+        for k in what:
+            assert np.array_equal(a[k], b[k]), (B, k)
+    o.close()
+
+
+@pytest.mark.gpu
+def test_sharded_context_refuses_the_host_pointer_path():
+    """A context in segment-sharded mode holds only its rank's share after the node pass: mpx_eval (and with it the nlp_* entry
+    points) must fail loudly instead of returning MPX_OK with f, terminal and linking rows unwritten (round-2 advisor finding)."""
+    from mpopt_amd._lib import MpxError
+
+    ocp = problems.moon_lander(mp, M.math)
+    mpo = mp.mpopt(ocp, 120, 5, "LGR")
+    o = mpo.create_nlp()[0]["oracle"]
+    z, p = mpo.initialize_solution(), np.full(o.n_p, 1.0 / 120)
+    want = o.eval(["f", "g"], z, p)
+    o.shard_setup(2, 0)
+    with pytest.raises(MpxError, match="segment-sharded"):
+        o.eval(["f", "g"], z, p)
+    with pytest.raises(MpxError, match="segment-sharded"):
+        o.eval(["jac_g"], z, p, ccs_order=True)
+    o.shard_setup(1, 0)
+    got = o.eval(["f", "g"], z, p)
+    assert np.array_equal(got["g"], want["g"]) and got["f"] == want["f"]
+    o.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["kitchen_sink_mixed_CGL", "adaptive_generic_two_phase_LGR"])
 def test_ccs_order_is_the_device_side_permutation(name):
     """MPX_CCS_ORDER: jac_g / hess_l values in compressed-column order equal the native values gathered with
