@@ -109,8 +109,10 @@ def ipopt_iter_report(builder, S, P, scheme, cnames, scale_t, midu, dev_id, seco
 def segment_shard_report(dev, dev_id, rank, world, backend, B=4, K=20):
     """Secondary measurement attached to the default line when N > 1 (so that the driver's --gpus 2/4/8 runs exercise RCCL on
     the path): configs[2] (Van der Pol 2000 x [3,30,3], CGL), the segments of every evaluation sharded over the
-    ranks -- node kernels on this rank's tiles, ONE all_gather_into_tensor of the owned runs, boundary pass on every rank --
-    against the same evaluation done by one rank alone, with a bitwise comparison of the two results on every rank."""
+    ranks, finished in each of the three ways of mpopt_amd.distributed.SegmentShardedEvaluator -- "allgather" (ONE
+    all_gather_into_tensor of the owned runs, complete result on every rank), "root" (dist.gather of the same runs, complete
+    result on rank 0) and "owner" (every rank keeps its rows / value blocks, only the tile partials are all-gathered) -- against
+    the same evaluation done by one rank alone, with a bitwise comparison of what each mode promises to hold."""
     import torch.distributed as dist
 
     import mpopt_amd as M
@@ -132,7 +134,7 @@ def segment_shard_report(dev, dev_id, rank, world, backend, B=4, K=20):
     mk = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
     mask = MPX_F | MPX_G | MPX_GRAD | MPX_JAC
     ref = (mk(B), mk(B, o.n_g), mk(B, o.n_z), mk(B, o.nnz_jac))
-    out = tuple(torch.full_like(t, float("nan")) for t in ref)
+    cdev = dev if backend == "nccl" else None
 
     def timed(fn):
         for _ in range(10):
@@ -146,21 +148,40 @@ def segment_shard_report(dev, dev_id, rank, world, backend, B=4, K=20):
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        return mpd.max_over_ranks(time.perf_counter() - t0, device=dev if backend == "nccl" else None) / K
+        return mpd.max_over_ranks(time.perf_counter() - t0, device=cdev) / K
 
     t_one = timed(lambda: o.eval_device(mask, B, Z, p, 0, None, None, *ref, None))
-    ev = mpd.SegmentShardedEvaluator(o, rank, world)
-    t_shard = timed(lambda: ev.eval(mask, B, Z, p, None, None, *out, None))
-    same = all(torch.equal(a, b) for a, b in zip(out, ref))
-    flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev if backend == "nccl" else None)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    n, cuts = o.shard_info(mask)
-    ev.close()
+    modes = {}
+    for mode in mpd.SegmentShardedEvaluator.MODES:
+        out = tuple(torch.full_like(t, float("nan")) for t in ref)
+        ev = mpd.SegmentShardedEvaluator(o, rank, world, mode=mode)
+        t_shard = timed(lambda: ev.eval(mask, B, Z, p, None, None, *out, None))
+        if mode == "allgather":
+            same = all(torch.equal(a, b) for a, b in zip(out, ref))
+        elif mode == "root":
+            same = rank != 0 or all(torch.equal(a, b) for a, b in zip(out, ref))
+        else:  # owner-resident: f, this rank's runs and the replicated boundary entries
+            same = torch.equal(out[0], ref[0])
+            for name, a, b in (("g", out[1], ref[1]), ("grad_f", out[2], ref[2]), ("jac_g", out[3], ref[3])):
+                owner = np.full(a.shape[1], -1)
+                for r in range(world):
+                    for off, ln in ev.owned(name, r):
+                        owner[off:off + ln] = r
+                here = torch.tensor((owner == rank) | (owner == -1), device=dev)
+                same = same and torch.equal(a[:, here], b[:, here])
+        flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        sent, recvd = ev.exchange_doubles(mask, B)
+        _, cuts = o.shard_info(mask)
+        modes[mode] = {"ms_per_step": t_shard * 1e3, "evals_per_s": B / t_shard, "speedup_vs_one_rank_alone": t_one / t_shard,
+                       "exchange_bytes_sent_per_rank_per_step": int(sent) * 8, "exchange_bytes_received_rank0_per_step": int(recvd) * 8 if rank == 0 else None,
+                       "bit_identical_to_unsharded": bool(flag.item() == 1.0)}
+        ev.close()
     o.close()
     return {"workload": "Van der Pol 2000 x [3,30,3] CGL (configs[2]), f+g+grad_f+jac_g, segments of every evaluation sharded over the ranks",
-            "n_gpus": world, "batch": B, "steps": K, "backend": backend, "ms_per_step_sharded": t_shard * 1e3, "ms_per_step_one_rank_alone": t_one * 1e3,
-            "evals_per_s_sharded": B / t_shard, "exchange_bytes_per_rank_per_step": int(n) * B * 8, "tiles_per_rank": np.diff(cuts).tolist(),
-            "bit_identical_to_unsharded_on_every_rank": bool(flag.item() == 1.0)}
+            "n_gpus": world, "batch": B, "steps": K, "backend": backend, "ms_per_step_one_rank_alone": t_one * 1e3, "tiles_per_rank": np.diff(cuts).tolist(),
+            "modes": modes,
+            "holds": {"allgather": "complete result on every rank", "root": "complete result on rank 0", "owner": "f + own runs + boundary entries on every rank"}}
 
 
 def main():

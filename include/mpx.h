@@ -76,6 +76,10 @@ extern "C" {
                                     changed since: the prefix sums kept on the device are reused.  The caller's assertion. */
 #define MPX_BOUNDARY_ONLY 32 /* skip the node kernels: finish reductions / terminal / linking rows only
                                 (second half of a segment-sharded evaluation, see mpx_set_tile_range) */
+#define MPX_OWNER_RESIDENT 512 /* segment-sharded contexts only (mpx_shard_setup, world > 1): the owner-resident protocol --
+                                  every rank keeps the g / grad_f rows and the jac_val / hess_val blocks of ITS tiles where
+                                  they are (direct stores, no staging block) and only the per-tile partial sums are exchanged;
+                                  accepted by mpx_eval_device, mpx_shard_info / _pack / _unpack (see mpx_shard_setup below) */
 
 /* structure kinds (packed description produced by the host-side tracer) */
 #define MPX_COL_X 0
@@ -237,8 +241,25 @@ int mpx_get_partials(mpx_ctx* ctx, int64_t batch, double** device_ptr, int64_t* 
  * rows of mpx_shard_table, tile_cuts[world + 1] = the tile ranges.  mpx_shard_table: out[n_entries][6] = (rank, kind, offset,
  * length, stride, packed_offset) of every owned run; kind 0 = jac_val / hess_val, 1 = staging block, 2 = tile partials; the
  * run of evaluation point b starts at offset + b * stride in its array and at packed_offset * batch + b * length in the
- * rank's exchange buffer (structure only: works without a device). */
+ * rank's exchange buffer (structure only: works without a device).
+ *
+ * Three ways to finish a sharded evaluation (mpopt_amd/distributed.py drives them):
+ *   all-gather        steps 1-5 above: every rank ends with the complete result.
+ *   gather-to-root    the same packed runs, collected by ONE rank (dist.gather): only the root runs steps 4-5 and holds the
+ *                     complete result; the other ranks send rank_len * batch doubles and receive nothing.
+ *   owner-resident    every call of steps 1, 2, 4, 5 carries MPX_OWNER_RESIDENT: the node kernels store g / grad_f rows directly
+ *                     (no staging), pack / unpack move ONLY the tile partials (rank_len = max tiles per rank * nred doubles per
+ *                     point, a few KB), and after step 5 a rank holds: f; its own node rows of g, entries of grad_f and value
+ *                     blocks of jac_val / hess_val (mpx_shard_owned lists them as (offset, length) runs); and, replicated on
+ *                     every rank, everything the boundary pass writes (terminal rows, control-slope continuity and event rows
+ *                     with their Jacobian entries, the (t0, tf, a) entries of grad_f, the (t0, tf, a) corner of hess_l).
+ *                     Entries owned by other ranks are left as they were.  A distributed consumer indexes the owner's arrays.
+ */
 int mpx_shard_setup(mpx_ctx* ctx, int world, int rank);
+/* Owner-resident mode: the runs of output array `which` (MPX_G: rows of g, MPX_GRAD: entries of grad_f, MPX_JAC: jac_val,
+ * MPX_HESS: hess_val) that `rank` owns after an evaluation, as sorted, disjoint (offset, length) pairs in runs[2 * n_runs]
+ * (runs == NULL: count only).  Everything no rank owns is written by the boundary pass on every rank.  Structure only. */
+int mpx_shard_owned(const mpx_ctx* ctx, int which, int rank, int64_t* n_runs, int64_t* runs);
 int mpx_shard_info(const mpx_ctx* ctx, int mask, int64_t* rank_len, int64_t* n_entries, int64_t* tile_cuts);
 int mpx_shard_table(const mpx_ctx* ctx, int mask, int64_t* out);
 int mpx_shard_pack(mpx_ctx* ctx, int mask, int64_t batch, const double* vals, double* send);
@@ -353,6 +374,9 @@ int mpx_current_pin_buffers(int enable);
 /* ---------------------------------------------------------------------------------------------
  * Timing helper: HIP events on the context's stream (bench.py measures kernel time with these)
  * ------------------------------------------------------------------------------------------- */
+/* PCI bus id ("0000:c1:00.0") of HIP device `device` into out[len]: lets a multi-process caller prove that its ranks sit on
+ * distinct GPUs (bench.py's `rccl` object). */
+int mpx_device_pci_bus_id(int device, char* out, int len);
 int mpx_timer_start(mpx_ctx* ctx);
 int mpx_timer_stop(mpx_ctx* ctx, double* elapsed_ms); /* records stop, synchronises, returns ms */
 /* Per-kernel timing: while enabled, every mpx_eval_device brackets its node-kernel launches (the

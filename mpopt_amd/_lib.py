@@ -28,6 +28,7 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 
 MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MPX_BOUNDARY_ONLY, MPX_JAC_VARIABLE_ONLY, MPX_CCS_ORDER = 1, 2, 4, 8, 16, 32, 64, 128
 MPX_WIDTHS_UNCHANGED = 256
+MPX_OWNER_RESIDENT = 512
 SCHEMES = {"LGR": 0, "LGL": 1, "CGL": 2, "LG": 3}
 SCHEME_EQUI = 4
 
@@ -178,6 +179,8 @@ SYMBOLS = {
     "mpx_get_partials": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), c_int64_p]),
     "mpx_shard_setup": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "mpx_shard_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_int64_p, c_int64_p]),
+    "mpx_shard_owned": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_int64_p, c_int64_p]),
+    "mpx_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     "mpx_shard_table": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p]),
     "mpx_shard_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "mpx_shard_unpack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),

@@ -726,7 +726,7 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key) {
   return {T->best, nullptr, nullptr};
 }
 
-int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
+int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool owner = false) {
   MpxIO io = io0;
   const GeomPick geom = pick_geometry(c, io.B, mode, mode == MPX_MODE_HESS ? (const void*)io.hess : (io.jac ? (const void*)io.jac : (const void*)io.g));
   io.b_per_block = geom.bpb;
@@ -735,9 +735,11 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true) {
   // staging block, which is what the ranks exchange; the boundary pass then moves the assembled block to g / grad_f.
   const bool shard = c->shard_world > 1;
   const bool want_g = mode != MPX_MODE_HESS && (io.g || io.grad);
-  if (shard && want_g && io.B > 65535) return fail(c, MPX_ERR_UNSUPPORTED, "segment-sharded evaluation: batch must be <= 65535");
+  if (shard && !owner && want_g && io.B > 65535) return fail(c, MPX_ERR_UNSUPPORTED, "segment-sharded evaluation: batch must be <= 65535");
+  // (owner-resident sharding, MPX_OWNER_RESIDENT: nothing but the tile partials is exchanged, so the node kernels store their
+  // g / grad_f rows directly, like a plain tile sub-range)
   const bool packed = want_g && io.B <= 65535 &&
-                      (shard || (c->g_packed && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_PACKED_G")));
+                      ((shard && !owner) || (c->g_packed && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_PACKED_G")));
   if (packed) {
     int rc = reserve(c, c->gtmp, (size_t)(io.B * c->gtmp_n));
     if (rc) return rc;
@@ -1334,13 +1336,15 @@ extern "C" int mpx_resid_eval(mpx_ctx* c, mpx_resid_plan* P, int64_t batch, cons
 // mpx_shard_unpack scatters the other ranks' runs into place, and the MPX_BOUNDARY_ONLY pass finishes the evaluation.
 namespace {
 
+// (partials_only: the owner-resident exchange -- a rank's buffer holds nothing but its tile partials, at offset 0)
 __global__ __launch_bounds__(256) void mpx_shard_copy_kernel(const MpxShardEnt* __restrict__ ents, int64_t B, int64_t rank_len, int my_rank,
-                                                             int unpack, double* vals, double* gtmp, double* partial, double* buf) {
+                                                             int unpack, int partials_only, double* vals, double* gtmp, double* partial, double* buf) {
   const MpxShardEnt E = ents[blockIdx.y];
   if (unpack ? E.rank == my_rank : E.rank != my_rank) return;
+  if (partials_only && E.kind != 2) return;
   double* __restrict__ base = E.kind == 0 ? vals : (E.kind == 1 ? gtmp : partial);
   if (!base) return;
-  double* __restrict__ pk = buf + (unpack ? (int64_t)E.rank * rank_len * B : 0) + E.dst_off * B;
+  double* __restrict__ pk = buf + (unpack ? (int64_t)E.rank * rank_len * B : 0) + (partials_only ? 0 : E.dst_off * B);
   const int64_t n = B * E.len;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = e / E.len, i = e - b * E.len;
@@ -1426,6 +1430,9 @@ extern "C" int mpx_shard_setup(mpx_ctx* c, int world, int rank) {
       c->shard_ent_first[ps].push_back((int32_t)c->shard_ent[ps].size());
     }
     c->shard_len[ps] += c->shard_len[ps] & 1;  // keep every rank's slot 16-byte aligned
+    c->shard_len_part = 0;                     // owner-resident exchange: the tile partials only
+    for (int r = 0; r < world; ++r) c->shard_len_part = std::max(c->shard_len_part, (c->shard_cuts[r + 1] - c->shard_cuts[r]) * c->nred);
+    c->shard_len_part += c->shard_len_part & 1;
     if (c->has_device) {
       HIPCHK(c, hipSetDevice(c->device));
       int rc = upload(c, &c->d_shard_ent[ps], c->shard_ent[ps]);
@@ -1438,7 +1445,7 @@ extern "C" int mpx_shard_setup(mpx_ctx* c, int world, int rank) {
 extern "C" int mpx_shard_info(const mpx_ctx* c, int mask, int64_t* rank_len, int64_t* n_entries, int64_t* tile_cuts) {
   if (!c || c->shard_cuts.empty()) return MPX_ERR_INVALID;
   const int ps = (mask & MPX_HESS) ? 1 : 0;
-  if (rank_len) *rank_len = c->shard_len[ps];
+  if (rank_len) *rank_len = (mask & MPX_OWNER_RESIDENT) ? c->shard_len_part : c->shard_len[ps];
   if (n_entries) *n_entries = (int64_t)c->shard_ent[ps].size();
   if (tile_cuts) memcpy(tile_cuts, c->shard_cuts.data(), c->shard_cuts.size() * sizeof(int64_t));
   return MPX_OK;
@@ -1453,16 +1460,56 @@ extern "C" int mpx_shard_table(const mpx_ctx* c, int mask, int64_t* out) {
   return MPX_OK;
 }
 
+// Runs of `which` (MPX_G / MPX_GRAD / MPX_JAC / MPX_HESS) owned by `rank` in the owner-resident protocol.
+extern "C" int mpx_shard_owned(const mpx_ctx* c, int which, int rank, int64_t* n_runs, int64_t* runs) {
+  if (!c || !n_runs || c->shard_cuts.empty() || rank < 0 || rank + 1 >= (int)c->shard_cuts.size()) return MPX_ERR_INVALID;
+  if (c->kind != 0) return MPX_ERR_UNSUPPORTED;
+  const int64_t tb = c->shard_cuts[rank], te = c->shard_cuts[rank + 1];
+  std::vector<std::pair<int64_t, int64_t>> out;
+  if (which == MPX_JAC || which == MPX_HESS) {
+    shard_runs(c->tiles, which == MPX_HESS ? c->tile_hess_size : c->tile_jac_size, which == MPX_HESS, tb, te, out);
+  } else if (which == MPX_G || which == MPX_GRAD) {
+    // the packed staging map of build_layout knows which tile holds every node row: rows whose staged position falls into the
+    // staging run of the rank's tiles belong to the rank
+    std::vector<int64_t> rows;
+    if (te > tb) {
+      const int64_t lo = c->tiles[tb].g_base, hi = c->tiles[te - 1].g_base + c->tile_g_size[te - 1];
+      const std::vector<int64_t>& map = which == MPX_G ? c->gmap : c->qmap;
+      for (int64_t r = 0; r < (int64_t)map.size(); ++r)
+        if (map[r] >= lo && map[r] < hi) rows.push_back(r);
+    }
+    for (int64_t r : rows) {
+      if (!out.empty() && out.back().first + out.back().second == r)
+        ++out.back().second;
+      else
+        out.push_back({r, 1});
+    }
+  } else {
+    return MPX_ERR_INVALID;
+  }
+  *n_runs = (int64_t)out.size();
+  if (runs)
+    for (auto& q : out) *runs++ = q.first, *runs++ = q.second;
+  return MPX_OK;
+}
+
+extern "C" int mpx_device_pci_bus_id(int device, char* out, int len) {
+  if (!out || len < 16) return MPX_ERR_INVALID;
+  out[0] = 0;
+  return hipDeviceGetPCIBusId(out, len, device) == hipSuccess ? MPX_OK : MPX_ERR_HIP;
+}
+
 static int shard_copy(mpx_ctx* c, int mask, int64_t batch, double* vals, double* buf, int unpack) {
   if (!c || !buf || batch < 1) return MPX_ERR_INVALID;
   if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "mpx_shard_pack/unpack: context has no device code; there is no CPU fallback");
   if (c->shard_world <= 1) return fail(c, MPX_ERR_INVALID, "mpx_shard_pack/unpack without mpx_shard_setup(world > 1)");
   const int ps = (mask & MPX_HESS) ? 1 : 0;
+  const int part_only = (mask & MPX_OWNER_RESIDENT) ? 1 : 0;
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
   double* gt = nullptr;
-  if (ps == 0 && (mask & (MPX_G | MPX_GRAD))) {
+  if (!part_only && ps == 0 && (mask & (MPX_G | MPX_GRAD))) {
     if ((rc = reserve(c, c->gtmp, (size_t)(batch * c->gtmp_n)))) return rc;
     gt = c->gtmp.p;
   }
@@ -1470,10 +1517,12 @@ static int shard_copy(mpx_ctx* c, int mask, int64_t batch, double* vals, double*
   const int32_t count = unpack ? (int32_t)c->shard_ent[ps].size() : c->shard_ent_first[ps][c->shard_rank + 1] - first;
   if (count <= 0) return MPX_OK;
   int64_t longest = 1;
-  for (int32_t k = first; k < first + count; ++k) longest = std::max(longest, c->shard_ent[ps][k].len * batch);
+  for (int32_t k = first; k < first + count; ++k)
+    if (!part_only || c->shard_ent[ps][k].kind == 2) longest = std::max(longest, c->shard_ent[ps][k].len * batch);
   const unsigned gx = (unsigned)std::min<int64_t>((longest + 255) / 256, 2048);
-  hipLaunchKernelGGL(mpx_shard_copy_kernel, dim3(gx, (unsigned)count), dim3(256), 0, c->stream, c->d_shard_ent[ps] + first, batch, c->shard_len[ps],
-                     c->shard_rank, unpack, ((mask & (MPX_JAC | MPX_HESS)) ? vals : nullptr), gt, c->partial.p, buf);
+  hipLaunchKernelGGL(mpx_shard_copy_kernel, dim3(gx, (unsigned)count), dim3(256), 0, c->stream, c->d_shard_ent[ps] + first, batch,
+                     part_only ? c->shard_len_part : c->shard_len[ps], c->shard_rank, unpack, part_only,
+                     ((mask & (MPX_JAC | MPX_HESS)) && !part_only ? vals : nullptr), gt, c->partial.p, buf);
   HIPCHK(c, hipGetLastError());
   return MPX_OK;
 }
@@ -1634,6 +1683,8 @@ extern "C" int mpx_eval_device(mpx_ctx* c, int mask, int64_t batch, const double
                                const double* lam_g, const double* sigma, double* f, double* g, double* grad_f,
                                double* jac_val, double* hess_val) {
   if (c) c->wcum_valid = false;  // caller-owned device widths: cannot be compared cheaply; MPX_WIDTHS_UNCHANGED is the caller's word
+  if (c && (mask & MPX_OWNER_RESIDENT) && (c->kind != 0 || c->shard_world <= 1))
+    return fail(c, MPX_ERR_INVALID, "MPX_OWNER_RESIDENT without mpx_shard_setup(world > 1)");
   return eval_core(c, mask & ~MPX_WIDTHS_UNCHANGED, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val,
                    (mask & MPX_WIDTHS_UNCHANGED) != 0);
 }
@@ -1728,15 +1779,15 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
   io.n_tiles_total = (int32_t)c->tiles.size();
   io.nred = c->nred;
   io.B = (int32_t)batch;
-  const bool nodes = !(mask & MPX_BOUNDARY_ONLY);
+  const bool nodes = !(mask & MPX_BOUNDARY_ONLY), owner = (mask & MPX_OWNER_RESIDENT) != 0;
   if (!nodes && !c->run_boundary && c->shard_world <= 1) return fail(c, MPX_ERR_INVALID, "MPX_BOUNDARY_ONLY with the boundary pass disabled");
   if (mask & (MPX_GRAD | MPX_JAC)) {
-    if ((rc = run_mode(c, MPX_MODE_FGJ, io, nodes))) return rc;
+    if ((rc = run_mode(c, MPX_MODE_FGJ, io, nodes, owner))) return rc;
   } else if (mask & (MPX_F | MPX_G)) {
-    if ((rc = run_mode(c, MPX_MODE_FG, io, nodes))) return rc;
+    if ((rc = run_mode(c, MPX_MODE_FG, io, nodes, owner))) return rc;
   }
   if (mask & MPX_HESS) {
-    if ((rc = run_mode(c, MPX_MODE_HESS, io, nodes))) return rc;
+    if ((rc = run_mode(c, MPX_MODE_HESS, io, nodes, owner))) return rc;
   }
   return MPX_OK;
 }

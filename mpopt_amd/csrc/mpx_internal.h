@@ -123,6 +123,7 @@ struct mpx_ctx {
   std::vector<MpxShardEnt> shard_ent[2];            // pass 0: f/g/grad_f/jac_g, pass 1: hess_l; entries of ALL ranks
   std::vector<int32_t> shard_ent_first[2];          // [world + 1] first entry of every rank
   int64_t shard_len[2] = {0, 0};                    // padded per-rank, per-point length of the exchange buffer (doubles)
+  int64_t shard_len_part = 0;                       // the same for the owner-resident exchange (tile partials only)
   MpxShardEnt* d_shard_ent[2] = {nullptr, nullptr};
   // page-locked host ranges this context knows (mpx_host_alloc / mpx_host_register) with their device-side aliases: a single
   // evaluation whose arrays all lie in such ranges runs zero-copy (kernels read z and write the results straight over PCIe)

@@ -20,7 +20,7 @@ import os
 
 import numpy as np
 
-from ._lib import MPX_BOUNDARY_ONLY, MPX_F, MPX_G, MPX_GRAD, MPX_HESS, MPX_JAC
+from ._lib import MPX_BOUNDARY_ONLY, MPX_F, MPX_G, MPX_GRAD, MPX_HESS, MPX_JAC, MPX_OWNER_RESIDENT
 
 
 def init_from_env(backend=None):
@@ -87,32 +87,61 @@ class SegmentShardedEvaluator:
     ``oracle``: this rank's ``NlpFunctions`` with a device; its stream must be torch's current stream
     (``oracle.set_stream(torch.cuda.current_stream().cuda_stream)``) so that kernels and collectives are
     ordered.  Inputs ``z`` / ``p`` / ``lam_g`` / ``sigma`` are full-size torch tensors on the device,
-    identical on all ranks; the outputs are full-size on every rank when ``eval`` returns (asynchronously
-    on the stream with the nccl backend).  With the gloo backend the exchange buffers are staged through
+    identical on all ranks.  ``mode`` (include/mpx.h, mpx_shard_setup):
+
+    * ``"allgather"`` -- ONE ``all_gather_into_tensor`` of every rank's owned runs; every rank holds the complete
+      result when ``eval`` returns (north_star's "RCCL all-gather of residual / Jacobian blocks").
+    * ``"root"`` -- the same runs collected by rank ``root`` only (``dist.gather``): the root holds the complete
+      result, the others send ``rank_len * batch`` doubles and receive nothing.
+    * ``"owner"`` -- owner-resident: every rank keeps the rows / value blocks of its tiles in its own output arrays
+      (``owned(which)`` lists them as (offset, length) runs) and only the per-tile partial sums travel (one
+      all-gather of a few KB per point); f and everything the boundary pass writes is replicated.  The mode for
+      a consumer that is itself distributed, and the only one whose exchange does not grow with the grid.
+
+    Every entry is produced by exactly one rank and the reductions keep their fixed order: results are bit-identical
+    to the unsharded evaluation in all three modes.  With the gloo backend the exchange buffers are staged through
     host memory (tests: several ranks sharing one GPU)."""
 
-    def __init__(self, oracle, rank=None, world=None, group=None):
+    MODES = ("allgather", "root", "owner")
+
+    def __init__(self, oracle, rank=None, world=None, group=None, mode="allgather", root=0):
         import torch.distributed as dist
 
-        self.o, self.group = oracle, group
+        if mode not in self.MODES:
+            raise ValueError(f"mode must be one of {self.MODES}")
+        self.o, self.group, self.mode, self.root = oracle, group, mode, int(root)
         self.world = dist.get_world_size(group) if world is None else int(world)
         self.rank = dist.get_rank(group) if rank is None else int(rank)
         oracle.shard_setup(self.world, self.rank)
         self._buf = {}
         self.backend = dist.get_backend(group) if (dist.is_initialized() and self.world > 1) else None
+        self._flag = MPX_OWNER_RESIDENT if (mode == "owner" and self.world > 1) else 0
 
     def close(self):
         """Leave sharded mode (the oracle evaluates all tiles again)."""
         self.o.shard_setup(1, 0)
+
+    def owned(self, which, rank=None):
+        """(offset, length) runs of output ``which`` ("g", "grad_f", "jac_g", "hess_l") owned by ``rank`` (default: this one)."""
+        return self.o.shard_owned(which, self.rank if rank is None else rank)
+
+    def exchange_doubles(self, mask, batch):
+        """(sent, received) doubles per rank and pass: what one ``_eval_one`` moves through the collective."""
+        n, _ = self.o.shard_info(mask | self._flag)
+        n = max(n * batch, 2)
+        if self.mode == "root":
+            return n, (self.world * n if self.rank == self.root else 0)
+        return n, self.world * n
 
     def _buffers(self, mask, batch, device):
         import torch
 
         key = (1 if mask & MPX_HESS else 0, int(batch))
         if key not in self._buf:
-            n, _ = self.o.shard_info(mask)
+            n, _ = self.o.shard_info(mask | self._flag)
             send = torch.empty(max(n * batch, 2), dtype=torch.float64, device=device)
-            recv = torch.empty(self.world * max(n * batch, 2), dtype=torch.float64, device=device)
+            need_recv = self.mode != "root" or self.rank == self.root
+            recv = torch.empty(self.world * max(n * batch, 2), dtype=torch.float64, device=device) if need_recv else None
             self._buf[key] = (send, recv)
         return self._buf[key]
 
@@ -122,26 +151,72 @@ class SegmentShardedEvaluator:
             if sub:
                 self._eval_one(sub, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
 
-    def _eval_one(self, mask, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val):
+    def _collect(self, send, recv):
+        """The collective of the mode: recv[world][len(send)] <- every rank's send (on the root only in mode "root")."""
         import torch.distributed as dist
 
-        o = self.o
+        host = self.backend == "gloo" and send.is_cuda
+        if host:
+            self.o.sync()
+            hs = send.cpu()
+            hr = recv.cpu() if recv is not None else None
+        else:
+            hs, hr = send, recv
+        if self.mode == "root":
+            parts = list(hr.view(self.world, -1).unbind(0)) if self.rank == self.root else None
+            dist.gather(hs, parts, dst=self.root, group=self.group)
+        else:
+            dist.all_gather_into_tensor(hr, hs, group=self.group)
+        if host and recv is not None:
+            recv.copy_(hr)
+
+    def _eval_one(self, mask, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val):
+        o, fl = self.o, self._flag
         if self.world == 1:
             o.eval_device(mask, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
             return
         vals = hess_val if mask & MPX_HESS else (jac_val if mask & MPX_JAC else None)
         send, recv = self._buffers(mask, batch, z.device)
-        o.eval_device(mask, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val)  # node kernels of this rank's tiles
-        o.shard_pack(mask, batch, vals, send)
-        if self.backend == "gloo" and send.is_cuda:
-            o.sync()
-            hs, hr = send.cpu(), recv.cpu()
-            dist.all_gather_into_tensor(hr, hs, group=self.group)
-            recv.copy_(hr)
-        else:
-            dist.all_gather_into_tensor(recv, send, group=self.group)
-        o.shard_unpack(mask, batch, recv, vals)
-        o.eval_device(mask | MPX_BOUNDARY_ONLY, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
+        o.eval_device(mask | fl, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val)  # node kernels of this rank's tiles
+        o.shard_pack(mask | fl, batch, vals, send)
+        self._collect(send, recv)
+        if self.mode == "root" and self.rank != self.root:
+            return  # this rank's share is with the root; its own arrays stay partial
+        o.shard_unpack(mask | fl, batch, recv, vals)
+        o.eval_device(mask | fl | MPX_BOUNDARY_ONLY, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val)
+
+
+def device_census(device_index, group=None):
+    """What proves that the ranks of a multi-GPU run sat on distinct GPUs: every rank's (rank, host, HIP device index, PCI bus
+    id, device name, uuid if torch reports one), collected with ``all_gather_object``.  Returns a dict for a bench line:
+    backend, world, the per-rank list and the number of distinct (host, PCI bus id) pairs."""
+    import ctypes
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+
+    buf = ctypes.create_string_buffer(64)
+    rc = _lib.lib().mpx_device_pci_bus_id(int(device_index), buf, 64)
+    me = {"rank": dist.get_rank(group) if dist.is_initialized() else 0, "host": socket.gethostname(), "device": int(device_index),
+          "pci_bus_id": buf.value.decode() if rc == 0 else None}
+    try:
+        pr = torch.cuda.get_device_properties(int(device_index))
+        me["name"] = pr.name
+        if getattr(pr, "uuid", None) is not None:
+            me["uuid"] = str(pr.uuid)
+    except Exception:  # pragma: no cover
+        pass
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        allr = [None] * dist.get_world_size(group)
+        dist.all_gather_object(allr, me, group=group)
+        backend = dist.get_backend(group)
+    else:
+        allr, backend = [me], None
+    distinct = len({(r["host"], r["pci_bus_id"]) for r in allr})
+    return {"backend": backend, "world": len(allr), "distinct_gpus": distinct, "ranks": allr}
 
 
 def _wrap_device_buffer(ptr, count, device):

@@ -329,6 +329,18 @@ class NlpFunctions:
         _lib.check(self._L.mpx_shard_table(self._ctx, int(mask), out.ctypes.data_as(_lib.c_int64_p)), self._ctx)
         return out
 
+    def shard_owned(self, which, rank):
+        """Owner-resident sharding: int64 array [n_runs][2] of the (offset, length) runs of output ``which`` ("g", "grad_f",
+        "jac_g", "hess_l") that ``rank`` owns after an evaluation (mpx_shard_owned); what no rank owns is written by the
+        boundary pass on every rank."""
+        w = {"g": MPX_G, "grad_f": MPX_GRAD, "jac_g": MPX_JAC, "hess_l": MPX_HESS}[which]
+        n = ctypes.c_int64()
+        _lib.check(self._L.mpx_shard_owned(self._ctx, w, int(rank), ctypes.byref(n), None), self._ctx)
+        out = np.zeros((n.value, 2), np.int64)
+        if n.value:
+            _lib.check(self._L.mpx_shard_owned(self._ctx, w, int(rank), ctypes.byref(n), out.ctypes.data_as(_lib.c_int64_p)), self._ctx)
+        return out
+
     def shard_pack(self, mask, batch, vals, send):
         _lib.check(self._L.mpx_shard_pack(self._ctx, int(mask), int(batch), _ptr(vals), _ptr(send)), self._ctx)
 

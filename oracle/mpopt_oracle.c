@@ -22,7 +22,8 @@
  * The OCP functions and their first and second derivatives are hand-written below (independent of the
  * product's tracer); the chain rule through scaling, segment step h and node time t is done here
  * in the unscaled formulation (mpopt.py:175-206).  Structural masks are hand-written too; none of the
- * six problems depends on t explicitly, so the (t0, tf) border of the Hessian comes from h only.
+ * reference's six problems depends on t explicitly (there the (t0, tf) border of the Hessian comes from h only); the synthetic
+ * `time_dependent` problem does, in dynamics, path row, running and terminal functions, with a parameter and non-unit scaling.
  */
 #include <math.h>
 #include <stdint.h>
@@ -253,6 +254,76 @@ static void sw_term1_dd(const double* xf, double tf, const double* x0, double t0
 }
 static const unsigned char sw_m2term1[36] = {1, 0, 0, 0, 0, 0, 0, 1};
 
+/* Synthetic, explicitly time-dependent (tests/problems.py: time_dependent): nx = 2, nu = 1, na = 1, nv = 5: x0 x1 u t a0.
+ *   dyn0 = x1 cos(0.3 t) + a0 u          dyn1 = -x0 x1 + u exp(-0.1 t) - 0.3 t x0
+ *   path = x0 t - 3 - a0 x1              L    = u^2 + 0.1 x0 t + a0^2 x1^2
+ *   M    = 0.3 xf0 x01 + 0.2 tf a0 + 0.05 (tf - t0)^2          tc = xf1 tf - x00 a0       (ntv = 7: xf0 xf1 tf x00 x01 t0 a0)
+ * Every d/dt, d2/dt2 and d2/dt dv term of the chain rule through t(t0, tf) is non-zero here, which none of the reference's
+ * benchmark problems exercises. */
+static void td_node(const double* x, const double* u, double t, const double* a, double* d, double* pc, double* L) {
+  d[0] = x[1] * cos(0.3 * t) + a[0] * u[0];
+  d[1] = -x[0] * x[1] + u[0] * exp(-0.1 * t) - 0.3 * t * x[0];
+  pc[0] = x[0] * t - 3.0 - a[0] * x[1];
+  *L = u[0] * u[0] + 0.1 * x[0] * t + a[0] * a[0] * x[1] * x[1];
+}
+static void td_node_d(const double* x, const double* u, double t, const double* a, double* dd, double* dpc, double* dL) {
+  const double c = cos(0.3 * t), sn = sin(0.3 * t), e = exp(-0.1 * t);
+  memset(dd, 0, 10 * sizeof(double));
+  dd[0 * 5 + 1] = c, dd[0 * 5 + 2] = a[0], dd[0 * 5 + 3] = -0.3 * x[1] * sn, dd[0 * 5 + 4] = u[0];
+  dd[1 * 5 + 0] = -x[1] - 0.3 * t, dd[1 * 5 + 1] = -x[0], dd[1 * 5 + 2] = e, dd[1 * 5 + 3] = -0.1 * u[0] * e - 0.3 * x[0];
+  dpc[0] = t, dpc[1] = -a[0], dpc[2] = 0, dpc[3] = x[0], dpc[4] = -x[1];
+  dL[0] = 0.1 * t, dL[1] = 2 * a[0] * a[0] * x[1], dL[2] = 2 * u[0], dL[3] = 0.1 * x[0], dL[4] = 2 * a[0] * x[1] * x[1];
+}
+static const unsigned char td_mdyn[10] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 0};
+static const unsigned char td_mpc[5] = {1, 1, 0, 1, 1};
+static void td_term(const double* xf, double tf, const double* x0, double t0, const double* a, double* M, double* tc) {
+  *M = 0.3 * xf[0] * x0[1] + 0.2 * tf * a[0] + 0.05 * (tf - t0) * (tf - t0);
+  tc[0] = xf[1] * tf - x0[0] * a[0];
+}
+static void td_term_d(const double* xf, double tf, const double* x0, double t0, const double* a, double* dM, double* dtc) {
+  dM[0] = 0.3 * x0[1], dM[1] = 0, dM[2] = 0.2 * a[0] + 0.1 * (tf - t0), dM[3] = 0, dM[4] = 0.3 * xf[0], dM[5] = -0.1 * (tf - t0), dM[6] = 0.2 * tf;
+  dtc[0] = 0, dtc[1] = tf, dtc[2] = xf[1], dtc[3] = -a[0], dtc[4] = 0, dtc[5] = 0, dtc[6] = -x0[0];
+}
+static const unsigned char td_mM[7] = {1, 0, 1, 0, 1, 1, 1};
+static const unsigned char td_mtc[7] = {0, 1, 1, 1, 0, 0, 1};
+static void td_node_dd(const double* x, const double* u, double t, const double* a, const double* wd, const double* wc, double wL,
+                       double* Hp, double* Hc) {
+  const int nv = 5;
+  const double c = cos(0.3 * t), sn = sin(0.3 * t), e = exp(-0.1 * t);
+  /* dyn0 */
+  Hp[1 * nv + 3] += wd[0] * (-0.3 * sn), Hp[3 * nv + 1] += wd[0] * (-0.3 * sn);
+  Hp[3 * nv + 3] += wd[0] * (-0.09 * x[1] * c);
+  Hp[2 * nv + 4] += wd[0], Hp[4 * nv + 2] += wd[0];
+  /* dyn1 */
+  Hp[0 * nv + 1] += -wd[1], Hp[1 * nv + 0] += -wd[1];
+  Hp[0 * nv + 3] += wd[1] * (-0.3), Hp[3 * nv + 0] += wd[1] * (-0.3);
+  Hp[2 * nv + 3] += wd[1] * (-0.1 * e), Hp[3 * nv + 2] += wd[1] * (-0.1 * e);
+  Hp[3 * nv + 3] += wd[1] * (0.01 * u[0] * e);
+  /* L */
+  Hp[2 * nv + 2] += wL * 2;
+  Hp[0 * nv + 3] += wL * 0.1, Hp[3 * nv + 0] += wL * 0.1;
+  Hp[1 * nv + 1] += wL * 2 * a[0] * a[0];
+  Hp[1 * nv + 4] += wL * 4 * a[0] * x[1], Hp[4 * nv + 1] += wL * 4 * a[0] * x[1];
+  Hp[4 * nv + 4] += wL * 2 * x[1] * x[1];
+  /* path row */
+  Hc[0 * nv + 3] += wc[0], Hc[3 * nv + 0] += wc[0];
+  Hc[1 * nv + 4] += -wc[0], Hc[4 * nv + 1] += -wc[0];
+}
+static const unsigned char td_m1L[5] = {1, 1, 1, 1, 1};
+static const unsigned char td_m2psi[25] = {0, 1, 0, 1, 0, /**/ 1, 1, 0, 1, 1, /**/ 0, 0, 1, 1, 1, /**/ 1, 1, 1, 1, 0, /**/ 0, 1, 1, 0, 1};
+static const unsigned char td_m2chi[25] = {0, 0, 0, 1, 0, /**/ 0, 0, 0, 0, 1, /**/ 0, 0, 0, 0, 0, /**/ 1, 0, 0, 0, 0, /**/ 0, 1, 0, 0, 0};
+static void td_term_dd(const double* xf, double tf, const double* x0, double t0, const double* a, double wM, const double* wt, double* Hw) {
+  const int n = 7;
+  Hw[0 * n + 4] += wM * 0.3, Hw[4 * n + 0] += wM * 0.3;
+  Hw[2 * n + 6] += wM * 0.2, Hw[6 * n + 2] += wM * 0.2;
+  Hw[2 * n + 2] += wM * 0.1, Hw[5 * n + 5] += wM * 0.1;
+  Hw[2 * n + 5] += -wM * 0.1, Hw[5 * n + 2] += -wM * 0.1;
+  Hw[1 * n + 2] += wt[0], Hw[2 * n + 1] += wt[0];
+  Hw[3 * n + 6] += -wt[0], Hw[6 * n + 3] += -wt[0];
+}
+static const unsigned char td_m2term[49] = {0, 0, 0, 0, 1, 0, 0, /**/ 0, 0, 1, 0, 0, 0, 0, /**/ 0, 1, 1, 0, 0, 1, 1, /**/ 0, 0, 0, 0, 0, 0, 1,
+                                            /**/ 1, 0, 0, 0, 0, 0, 0, /**/ 0, 0, 1, 0, 0, 1, 0, /**/ 0, 0, 1, 1, 0, 0, 0};
+
 static const ocp_fns PROBLEMS[] = {
     {"moon_lander", 2, 1, 0, 0, 2, ml_node, ml_node_d, ml_mdyn, zeros_mask, ml_term, ml_term_d, ml_mM, ml_mtc,
      zero_node_dd, ml_m1L, zeros_mask, zeros_mask, zero_term_dd, zeros_mask},
@@ -266,6 +337,8 @@ static const ocp_fns PROBLEMS[] = {
      sw_node0_dd, zeros_mask, sw_m2psi, sw_m2chi, zero_term_dd, zeros_mask},
     {"schwartz_phase1", 2, 1, 0, 0, 0, sw_node1, sw_node1_d, sw_mdyn, zeros_mask, sw_term1, sw_term1_d, sw_mM1, zeros_mask,
      sw_node1_dd, zeros_mask, sw_m2psi, zeros_mask, sw_term1_dd, sw_m2term1},
+    {"time_dependent", 2, 1, 1, 1, 1, td_node, td_node_d, td_mdyn, td_mpc, td_term, td_term_d, td_mM, td_mtc,
+     td_node_dd, td_m1L, td_m2psi, td_m2chi, td_term_dd, td_m2term},
 };
 #define N_PROBLEMS ((int)(sizeof(PROBLEMS) / sizeof(PROBLEMS[0])))
 

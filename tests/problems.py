@@ -205,6 +205,34 @@ def kitchen_sink(mp, fn):
     return ocp
 
 
+def time_dependent(mp, fn):
+    """Synthetic, single phase: explicit time dependence in dynamics, path row, running cost; terminal cost and constraint in
+    (xf, tf, x0, t0, a); one parameter; non-unit scaling everywhere.  Hand-written counterpart with first and second
+    derivatives: `time_dependent` in oracle/mpopt_oracle.c (full-size parity of the d/dt chain rule, tests/test_gpu_parity.py)."""
+    ocp = mp.OCP(n_states=2, n_controls=1, n_params=1)
+    ocp.dynamics[0] = lambda x, u, t, a: [x[1] * fn.cos(0.3 * t) + a[0] * u[0], -x[0] * x[1] + u[0] * fn.exp(-0.1 * t) - 0.3 * t * x[0]]
+    ocp.path_constraints[0] = lambda x, u, t, a: [x[0] * t - 3.0 - a[0] * x[1]]
+    ocp.running_costs[0] = lambda x, u, t, a: u[0] * u[0] + 0.1 * x[0] * t + a[0] * a[0] * x[1] * x[1]
+    ocp.terminal_costs[0] = lambda xf, tf, x0, t0, a: 0.3 * xf[0] * x0[1] + 0.2 * tf * a[0] + 0.05 * (tf - t0) * (tf - t0)
+    ocp.terminal_constraints[0] = lambda xf, tf, x0, t0, a: [xf[1] * tf - x0[0] * a[0]]
+    ocp.scale_x = np.array([0.5, 2.0])
+    ocp.scale_u = np.array([4.0])
+    ocp.scale_a = np.array([2.0])
+    ocp.scale_t = 0.1
+    ocp.x00[0] = [1.0, -0.5]
+    ocp.xf0[0] = [0.5, 0.5]
+    ocp.u00[0], ocp.uf0[0] = [0.1], [0.3]
+    ocp.a0[0] = [0.3]
+    ocp.t00[0], ocp.tf0[0] = 0.5, 2.5
+    ocp.lbx[0], ocp.ubx[0] = [-5.0, -6.0], [5.0, 6.0]
+    ocp.lbu[0], ocp.ubu[0] = [-2.0], [2.0]
+    ocp.lba[0], ocp.uba[0] = [-1.0], [1.0]
+    ocp.lbt0[0], ocp.ubt0[0] = 0.0, 1.0
+    ocp.lbtf[0], ocp.ubtf[0] = 2.0, 3.0
+    ocp.validate()
+    return ocp
+
+
 #: name -> (builder, n_segments, poly_orders, scheme).  These are the parity cases for which
 #: tests/golden/ holds vectors produced by the reference's own transcription code.
 GOLDEN_CASES = {
@@ -236,6 +264,15 @@ BENCH_CASES = [
     (van_der_pol, 2000, [30 if s % 3 == 1 else 3 for s in range(2000)], "CGL"),  # configs[2]
     (two_phase_schwartz, 500, 3, "LGL"),                                     # configs[3]
     (hyper_sensitive, 4000, 3, "LGR"),                                       # configs[4]
+]
+
+
+#: full-size parity cases beyond the BASELINE configurations (tests/test_gpu_parity.py FULL): the configs[2] variant with a
+#: parameter column and a path row (examples/singlephase/dae_vdp.py:28-60), and the explicitly time-dependent problem
+FULL_EXTRA_CASES = [
+    (dae_vdp, 2000, [30 if s % 3 == 1 else 3 for s in range(2000)], "CGL"),
+    (time_dependent, 4000, 3, "LGR"),
+    (time_dependent, 2000, [30 if s % 3 == 1 else 3 for s in range(2000)], "CGL"),
 ]
 
 

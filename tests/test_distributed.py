@@ -87,6 +87,21 @@ def _worker(rank, world, port, q):
             got, ok = mine[k], owned[k] > 0
             assert np.array_equal(got[ok], full[k][ok]), (mask, k)  # bit-exact assembly on every rank
             assert np.isnan(got[~ok]).all()
+    # (4) gather-to-root of the same runs (mode "root" of SegmentShardedEvaluator): only the root receives; and the
+    #     owner-resident exchange (tile partials only) through the same collective
+    from mpopt_amd._lib import MPX_OWNER_RESIDENT
+
+    mask = MPX_F | MPX_G | MPX_GRAD | MPX_JAC
+    rank_len, _ = o.shard_info(mask)
+    send = torch.full((rank_len * B,), float(r), dtype=torch.float64)
+    parts = list(torch.empty(w, rank_len * B, dtype=torch.float64).unbind(0)) if r == 0 else None
+    dist.gather(send, parts, dst=0)
+    if r == 0:
+        assert all(bool((parts[k] == float(k)).all()) for k in range(w))
+    part_len, cuts = o.shard_info(mask | MPX_OWNER_RESIDENT)
+    tabp = o.shard_table(mask)
+    nred = int(tabp[tabp[:, 1] == 2][0, 3]) // max(int(cuts[1] - cuts[0]), 1)
+    assert part_len >= int(np.diff(cuts).max()) * nred and part_len < rank_len  # partials only: a small fraction of the runs
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))
@@ -120,3 +135,60 @@ def test_partition_tiles_properties():
                 loads = [w[a:b].sum() for a, b in parts]
                 assert max(loads) <= w.sum() / world + w.max()
     assert [shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+@pytest.mark.parametrize("case", ["vdp_mixed", "schwartz", "kitchen_sink"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_owner_resident_ownership_tables(case, world):
+    """mpx_shard_owned (structure only, no GPU): over all ranks every node row of g, every node entry of grad_f and every tile
+    value of jac_val / hess_val is owned exactly once; what nobody owns is exactly what the boundary pass writes (terminal rows,
+    control-slope continuity rows, event rows and their Jacobian entries; the t0 / tf / a entries of grad_f; the (t0, tf, a)
+    corner and terminal entries of hess_l); the value runs equal the kind-0 runs of mpx_shard_table."""
+    for p_ in (ROOT, os.path.join(ROOT, "tests")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    import mpopt_amd as M
+    from mpopt_amd import mp
+    from mpopt_amd._lib import MPX_HESS, MPX_JAC
+    import problems
+
+    builder, S, po, scheme = {"vdp_mixed": (problems.van_der_pol, 48, [30 if s % 3 == 1 else 3 for s in range(48)], "CGL"),
+                              "schwartz": (problems.two_phase_schwartz, 200, [3] * 200, "LGL"),
+                              "kitchen_sink": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR")}[case]
+    ocp = builder(mp, M.math)
+    o = M.NlpFunctions(ocp, S, po, scheme, with_device=False)
+    o.shard_setup(world, 0)
+    sizes = {"g": o.n_g, "grad_f": o.n_z, "jac_g": o.nnz_jac, "hess_l": o.nnz_hess}
+    count = {k: np.zeros(n, np.int64) for k, n in sizes.items()}
+    for r in range(world):
+        for k in sizes:
+            runs = o.shard_owned(k, r)
+            assert (runs[:, 1] > 0).all() and (np.diff(runs[:, 0]) > 0).all()  # sorted, disjoint, non-empty
+            assert (runs[1:, 0] >= runs[:-1, 0] + runs[:-1, 1]).all()
+            for off, ln in runs:
+                count[k][off:off + ln] += 1
+        for mask, k in ((MPX_JAC, "jac_g"), (MPX_HESS, "hess_l")):
+            tab = o.shard_table(mask)
+            mine = tab[(tab[:, 0] == r) & (tab[:, 1] == 0)][:, 2:4]
+            assert np.array_equal(mine, o.shard_owned(k, r))
+    for k in sizes:
+        assert count[k].max() == 1
+    N, nx, nu, na, nph = o.n_nodes, ocp.nx, ocp.nu, ocp.na, ocp.n_phases
+    # grad_f: everything but the (t0, tf, a) entries of every phase is a node entry
+    nzp = o.n_z // nph
+    is_node = np.ones(o.n_z, bool)
+    for ph in range(nph):
+        is_node[ph * nzp + (nx + nu) * N: (ph + 1) * nzp] = False
+    assert np.array_equal(count["grad_f"] == 1, is_node)
+    # g: the unowned rows are few (terminal, continuity, events) and the owned ones are whole node blocks
+    n_unowned = int((count["g"] == 0).sum())
+    assert n_unowned <= nph * (8 + nu * S) + 8 * nph and (n_unowned > 0 or case == "vdp_mixed")  # Van der Pol: no terminal / linking rows
+    jr, jc = o.jac_pattern()
+    assert set(np.unique(jr[count["jac_g"] == 0])) <= set(np.nonzero(count["g"] == 0)[0])  # unowned Jacobian values sit on unowned rows
+    hr, hc = o.hess_pattern()
+    un = count["hess_l"] == 0
+    if case != "vdp_mixed":  # (time-independent dynamics without terminal functions have no corner / terminal entries)
+        loc = (hc[un] % nzp) % N  # node index of a node column
+        assert un.sum() > 0 and ((~is_node[hc[un]]) | (loc == 0) | (loc == N - 1)).all()  # a global variable or a phase end
+    o.shard_setup(1, 0)
+    o.close()

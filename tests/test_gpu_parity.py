@@ -103,6 +103,12 @@ FULL = {
     "config3_vdp_2000_mixed_CGL": (problems.BENCH_CASES[1], ["van_der_pol"], 1.0, [1]),
     "config4_schwartz_2x500x3_LGL": (problems.BENCH_CASES[2], ["schwartz_phase0", "schwartz_phase1"], 1.0, [1, 0]),
     "config5_hyper_sensitive_4000x3_LGR": (problems.BENCH_CASES[3], ["hyper_sensitive"], 1e-3, [0]),
+    # SURVEY 8(d) C3 variant: parameter column + path row (examples/singlephase/dae_vdp.py:28-60) at configs[2]'s size
+    "config3_dae_vdp_2000_mixed_CGL": (problems.FULL_EXTRA_CASES[0], ["dae_vdp"], 1.0, [1]),
+    # explicit time dependence at full size: the (t0, tf, a) border and corner of hess_l and the t0 / tf columns of jac_g carry
+    # d/dt terms (not only h), summed over 49 ... 101 tiles, against hand-derived second derivatives (oracle/mpopt_oracle.c)
+    "time_dependent_4000x3_LGR": (problems.FULL_EXTRA_CASES[1], ["time_dependent"], 0.1, [1]),
+    "time_dependent_2000_mixed_CGL": (problems.FULL_EXTRA_CASES[2], ["time_dependent"], 0.1, [1]),
 }
 
 
@@ -113,7 +119,8 @@ def test_full_size_against_c_oracle_and_properties(name):
     mpo = mp.mpopt(ocp, S, po, scheme)
     nlp, bounds = mpo.create_nlp()
     o = nlp["oracle"]
-    C = COracle(cnames, S, po, scheme, scale_t=st, midu=midu)
+    assert st == float(ocp.scale_t)
+    C = COracle(cnames, S, po, scheme, scale_x=ocp.scale_x, scale_u=ocp.scale_u, scale_a=ocp.scale_a if ocp.na else None, scale_t=st, midu=midu)
     assert (o.n_z, o.n_g) == (C.n_z, C.n_g)
     z, p, lam, sig = random_point(o, mpo, bounds, 23, S, ocp.n_phases)
     B = 3

@@ -1,7 +1,9 @@
 """Segment-sharded evaluation under torch.distributed on the GPU: `world` processes (sharing the one GPU of the
 test box, gloo rendezvous; the same code runs one process per GPU over RCCL in bench.py --workload config3-shard) each run
 the node kernels of their tile range, exchange their owned runs with ONE all_gather_into_tensor and finish with the boundary
-pass.  Every rank must hold the complete result, bit-identical to its own unsharded evaluation."""
+pass.  Every rank must hold the complete result, bit-identical to its own unsharded evaluation.  The same for the two other
+ways to finish (gather-to-root: the root holds everything; owner-resident: a rank holds its own runs + the replicated boundary
+entries and nothing else is touched), and at BASELINE full size for configs 3 and 4."""
 import os
 import socket
 import sys
@@ -42,6 +44,8 @@ def _worker(rank, world, port, case, q):
         "kitchen_sink": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR"),                           # parameters, DU rows, 2 phases
         "hyper_sensitive": (problems.hyper_sensitive, 700, 3, "LGR"),                                    # config 5, reduced
         "kitchen_sink_400": (problems.kitchen_sink, 400, [2, 5, 3, 4] * 100, "LGR"),                     # several tiles per bucket: corner sums cross ranks
+        "config3_full": problems.BENCH_CASES[1],   # BASELINE configs[2] at full size: Van der Pol 2000 x [3,30,3], CGL
+        "config4_full": problems.BENCH_CASES[2],   # BASELINE configs[3] at full size: two-phase Schwartz, 500 x 3 per phase, LGL
     }[case]
     ocp = builder(mp, M.math)
     mpo = mp.mpopt(ocp, S, po, scheme)
@@ -87,6 +91,34 @@ def _worker(rank, world, port, case, q):
     for k, want in (("g", ref_fg["g"]), ("f", ref_fg["f"]), ("jac_val", ref["jac_val"])):
         assert torch.equal(out2[k], want), (case, rank, "partial mask", k, float((out2[k] - want).abs().max()))
     ev.close()
+    # gather-to-root: the root holds the complete result
+    ev = D.SegmentShardedEvaluator(o, mode="root", root=world - 1)
+    out4 = outputs(float("nan"))
+    ev.eval(full, B, Z, p, lam, sig, **out4)
+    o.sync()
+    if rank == world - 1:
+        for k in ref:
+            assert torch.equal(out4[k], ref[k]), (case, rank, "root", k)
+    assert ev.exchange_doubles(MPX_JAC, B)[1] == (0 if rank != world - 1 else world * ev.exchange_doubles(MPX_JAC, B)[0])
+    ev.close()
+    # owner-resident: own runs + everything the boundary pass writes (owned by nobody) are there, the rest is untouched
+    ev = D.SegmentShardedEvaluator(o, mode="owner")
+    out5 = outputs(float("nan"))
+    ev.eval(full, B, Z, p, lam, sig, **out5)
+    o.sync()
+    assert torch.equal(out5["f"], ref["f"])
+    assert ev.exchange_doubles(MPX_JAC, B)[0] * 20 < o.shard_info(MPX_JAC)[0] * B  # the partials are a sliver of the runs
+    for name, key in (("g", "g"), ("grad_f", "grad_f"), ("jac_g", "jac_val"), ("hess_l", "hess_val")):
+        n = ref[key].shape[1]
+        owner = np.full(n, -1)
+        for r in range(world):
+            for off, ln in ev.owned(name, r):
+                assert (owner[off:off + ln] == -1).all()
+                owner[off:off + ln] = r
+        here = torch.tensor((owner == rank) | (owner == -1), device=dev)
+        assert torch.equal(out5[key][:, here], ref[key][:, here]), (case, rank, "owner", name)
+        assert torch.isnan(out5[key][:, ~here]).all(), (case, rank, "owner: foreign entries were written", name)
+    ev.close()
     out3 = outputs(float("nan"))  # back to a plain context
     o.eval_device(MPX_F | MPX_G | MPX_GRAD | MPX_JAC, B, Z, p, 0, None, None, out3["f"], out3["g"], out3["grad_f"], out3["jac_val"], None)
     o.sync()
@@ -96,7 +128,8 @@ def _worker(rank, world, port, case, q):
     q.put((rank, "ok"))
 
 
-@pytest.mark.parametrize("case,world", [("vdp_mixed", 2), ("schwartz", 3), ("kitchen_sink", 2), ("hyper_sensitive", 2), ("kitchen_sink_400", 3)])
+@pytest.mark.parametrize("case,world", [("vdp_mixed", 2), ("schwartz", 3), ("kitchen_sink", 2), ("hyper_sensitive", 2), ("kitchen_sink_400", 3),
+                                        ("config3_full", 2), ("config4_full", 2)])
 def test_segment_sharded_evaluator_under_torch_distributed(case, world):
     import torch.multiprocessing as tmp
 

@@ -90,6 +90,33 @@ def test_c_oracle_matches_reference(name):
     assert np.array_equal(g1, r["g"]) and np.array_equal(v1, r["jac_val"])
 
 
+@pytest.mark.parametrize("S,po,scheme", [(5, 3, "LGR"), (3, [2, 4, 3], "CGL"), (1, [5], "LGL")])
+def test_c_oracle_time_dependent_problem_matches_numpy_oracle(S, po, scheme):
+    """The synthetic time-dependent problem of the C oracle (hand-written first and second derivatives incl. every d/dt term,
+    parameter, non-unit scaling) against the numpy / sympy oracle on the same problem statement (tests/problems.py); the numpy
+    oracle is itself pinned to the reference's goldens, among them the time-dependent kitchen-sink cases."""
+    ocp = problems.time_dependent(mp, M.math)
+    O = OracleNLP(ocp, S, po, scheme)
+    C = COracle(["time_dependent"], S, po, scheme, scale_x=ocp.scale_x, scale_u=ocp.scale_u, scale_a=ocp.scale_a, scale_t=ocp.scale_t, midu=[1])
+    assert (C.n_z, C.n_g) == (O.n_z, O.n_g)
+    rng = np.random.default_rng(12)
+    z = O.initial_guess() + 0.1 * rng.standard_normal(O.n_z)
+    w = rng.uniform(0.5, 1.5, S)
+    p, lam, sig = w / w.sum(), rng.standard_normal(O.n_g), 0.7
+    r = C.eval(z, p)
+    assert rel_err(r["f"], O.f(z, p)) < TOL and rel_err(r["g"], O.g(z, p)) < TOL and rel_err(r["grad_f"], O.grad_f(z, p)) < TOL
+    J = np.zeros((C.n_g, C.n_z))
+    J[r["jac_row"], r["jac_col"]] = r["jac_val"]
+    Jo = O.jac_g(z, p)
+    assert rel_err(J, Jo.toarray()) < TOL
+    assert set(zip(r["jac_row"].tolist(), r["jac_col"].tolist())) >= set(zip(*[a.tolist() for a in Jo.nonzero()]))
+    H = C.hess_matrix(z, p, sig, lam).toarray()
+    Ho = O.hess_l(z, p, sig, lam)
+    assert rel_err(H + np.triu(H, 1).T, Ho) < TOL
+    t0 = (ocp.nx + ocp.nu) * O.N
+    assert abs(Ho[t0, t0]) > 1e-6 and abs(Ho[t0, t0 + 1]) > 1e-6 and abs(Ho[t0 + 1, t0 + 2]) > 1e-6  # the (t0, tf, a) corner is alive
+
+
 def test_published_optimum_is_consistent_with_oracle_constraints():
     """The reference publishes J* = 8.24677 for moon lander 20x3 LGR (docs/source/notebooks/
     getting_started.ipynb:428).  The analytic optimum of the moon lander is bang-bang; check the
