@@ -18,10 +18,11 @@ Also on the JSON line:
   cpu_baseline  the C oracle (oracle/mpopt_oracle.c, a scalar port of the reference algorithm)
                 timed on one host core on a bounded sample of the same workload (rank 0, N=1 only)
   ipopt_iter    the second half of BASELINE.json's metric: oracle wall-clock per IPOPT iteration at B=1 through
-                HOST pointers (the CasADi-convention entry points nlp_g / nlp_grad_f / nlp_jac_g / nlp_hess_l of
-                libmpx.so, values in compressed-column order, caller arrays page-locked on first sight), with the
-                reference's recorded call mix 1.15 nlp_g + nlp_grad_f + nlp_jac_g + nlp_hess_l
+                HOST pointers (the CasADi-convention entry points nlp_f / nlp_g / nlp_grad_f / nlp_jac_g / nlp_hess_l of
+                libmpx.so, values in compressed-column order, caller arrays page-locked on first sight), called in a
+                solver's order at iterates that really change, with the reference's recorded call mix
                 (docs/source/notebooks/moon_lander.ipynb:192-198), next to the CPU port for the same mix
+  casadi        "absent", or the timings of CasADi's own nlp_* functions if `import casadi` succeeds on the box
 """
 import argparse
 import json
@@ -37,7 +38,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np
 import torch
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_MEASURED_GBS = 6290.0  # what a float4 copy sustains on this part (MI355X_MICROARCH.md: "~6.3 TB/s achievable")
 
 
 def make_points(oracle, mpo, bounds, B, seed):
@@ -49,8 +51,12 @@ def make_points(oracle, mpo, bounds, B, seed):
 
 
 def ipopt_iter_report(builder, S, P, scheme, cnames, scale_t, midu, dev_id, seconds=0.6):
-    """Oracle time per IPOPT iteration at B=1, host pointers, through the nlp_* C entry points (ctypes: ~1 us per call
-    of overhead included), and the CPU port for the same call mix.  Returns a dict for the bench line."""
+    """Oracle time per IPOPT iteration at B=1, host pointers, through the nlp_* C entry points (ctypes: ~1 us per call of overhead
+    included), in the ORDER an interior-point solver makes the calls: at every new iterate x  nlp_f, nlp_g  (trial point) and then
+    nlp_grad_f, nlp_jac_g (res[0] = NULL, as CasADi's IPOPT interface asks), nlp_hess_l  -- x really changes between iterates (two
+    points alternate in the caller's array), so the same-iterate cache of mpx_casadi.cpp sees what it would see under IPOPT.  One
+    iteration = 1.15 x (nlp_f + nlp_g) + nlp_grad_f + nlp_jac_g + nlp_hess_l (15 % rejected trial points, moon_lander.ipynb:192-198;
+    round 2 left nlp_f out of the sum).  Measured with the cache on and off (MPX_NO_COALESCE), next to the CPU port."""
     import ctypes
 
     import mpopt_amd as M
@@ -63,34 +69,50 @@ def ipopt_iter_report(builder, S, P, scheme, cnames, scale_t, midu, dev_id, seco
     o = nlp["oracle"]
     L = _lib.lib()
     rng = np.random.default_rng(20260928)
-    z = np.ascontiguousarray(make_points(o, mpo, bounds, 1, 20260928)[0])
+    Zs = make_points(o, mpo, bounds, 2, 20260928)
+    z = np.ascontiguousarray(Zs[0])
     p = np.full(o.n_p, 1.0 / S)
     lam, sig = rng.standard_normal(o.n_g), np.array([1.0])
     f, g, gr = np.zeros(1), np.zeros(o.n_g), np.zeros(o.n_z)
     jv, hv = np.zeros(max(o.nnz_jac, 1)), np.zeros(max(o.nnz_hess, 1))
+    vp = lambda arrs: (ctypes.c_void_p * len(arrs))(*[a.ctypes.data if a is not None else None for a in arrs])
+    calls = [("nlp_f", vp([z, p]), vp([f])), ("nlp_g", vp([z, p]), vp([g])), ("nlp_grad_f", vp([z, p]), vp([f, gr])),
+             ("nlp_jac_g", vp([z, p]), vp([None, jv])), ("nlp_hess_l", vp([z, p, sig, lam]), vp([hv]))]
+    funs = {n: getattr(L, n) for n, _, _ in calls}
+
+    def sequence(seconds):
+        for k in range(20):
+            z[:] = Zs[k & 1]
+            for n, a, r in calls:
+                assert funs[n](a, r, None, None, 0) == 0
+        acc, it, t_end = {n: [] for n, _, _ in calls}, 0, time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            it += 1
+            z[:] = Zs[it & 1]  # the solver's own write of the new iterate (not timed)
+            for n, a, r in calls:
+                t0 = time.perf_counter()
+                funs[n](a, r, None, None, 0)
+                acc[n].append(time.perf_counter() - t0)
+        return {n: float(np.median(v)) * 1e6 for n, v in acc.items()}, it
+
+    mix = lambda d: 1.15 * (d["nlp_f"] + d["nlp_g"]) + d["nlp_grad_f"] + d["nlp_jac_g"] + d["nlp_hess_l"]
+    os.environ["MPX_NO_COALESCE"] = "1"
     o.make_current()
     L.mpx_current_pin_buffers(1)
-
-    def call(fn, ins, outs):
-        arg = (ctypes.c_void_p * len(ins))(*[a.ctypes.data for a in ins])
-        res = (ctypes.c_void_p * len(outs))(*[a.ctypes.data for a in outs])
-        fun = getattr(L, fn)
-        for _ in range(20):
-            assert fun(arg, res, None, None, 0) == 0
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            for _ in range(20):
-                fun(arg, res, None, None, 0)
-            n += 20
-        return (time.perf_counter() - t0) / n * 1e6
-
-    gpu = {"nlp_f": call("nlp_f", [z, p], [f]), "nlp_g": call("nlp_g", [z, p], [g]), "nlp_grad_f": call("nlp_grad_f", [z, p], [f, gr]),
-           "nlp_jac_g": call("nlp_jac_g", [z, p], [g, jv]), "nlp_hess_l": call("nlp_hess_l", [z, p, sig, lam], [hv])}
+    plain, _ = sequence(seconds / 2)
+    L.mpx_current_pin_buffers(0)
+    del os.environ["MPX_NO_COALESCE"]
+    o.make_current()
+    L.mpx_current_pin_buffers(1)
+    gpu, n_it = sequence(seconds)
+    fused, served = ctypes.c_longlong(), ctypes.c_longlong()
+    L.mpx_current_cache_stats(ctypes.byref(fused), ctypes.byref(served))
     L.mpx_current_pin_buffers(0)
     # parity of what was timed: the CCS-ordered values against the CPU port on the same point
     C = COracle(cnames, S, P, scheme, scale_t=scale_t, midu=midu)
     c = C.eval(z, p)
-    assert np.abs(c["g"] - g).max() < 1e-9 * max(1.0, np.abs(c["g"]).max())
+    assert np.abs(c["g"] - g).max() < 1e-9 * max(1.0, np.abs(c["g"]).max()) and abs(c["f"] - f[0]) < 1e-9 * max(1.0, abs(c["f"]))
+    assert np.abs(c["grad_f"] - gr).max() < 1e-9 * max(1.0, np.abs(c["grad_f"]).max())
     import scipy.sparse as sp
 
     perm, colind = o.ccs_perm("jac")
@@ -100,13 +122,66 @@ def ipopt_iter_report(builder, S, P, scheme, cnames, scale_t, midu, dev_id, seco
     assert abs(Jg - Jc).max() < 1e-9 * max(1.0, abs(Jc).max())
     cpu = {k: C.time_fn(k, z[None, :], p, 1.0, lam, seconds) * 1e6 for k in gpu}
     o.close()
-    mix = lambda d: 1.15 * d["nlp_g"] + d["nlp_grad_f"] + d["nlp_jac_g"] + d["nlp_hess_l"]
-    return {"us_per_iter": mix(gpu), "cpu_port_us_per_iter": mix(cpu), "speedup_vs_cpu_port": mix(cpu) / mix(gpu),
-            "per_call_us": {k: round(v, 2) for k, v in gpu.items()}, "cpu_port_per_call_us": {k: round(v, 2) for k, v in cpu.items()},
+    return {"us_per_iter": mix(gpu), "us_per_iter_uncoalesced": mix(plain), "cpu_port_us_per_iter": mix(cpu), "speedup_vs_cpu_port": mix(cpu) / mix(gpu),
+            "per_call_us": {k: round(v, 2) for k, v in gpu.items()}, "per_call_us_uncoalesced": {k: round(v, 2) for k, v in plain.items()},
+            "cpu_port_per_call_us": {k: round(v, 2) for k, v in cpu.items()},
+            "cache": {"iterates": n_it + 20, "fused_device_passes": fused.value, "calls_served_without_a_device_pass": served.value},
             "n_z": o.n_z, "n_g": o.n_g, "nnz_jac": o.nnz_jac, "nnz_hess": o.nnz_hess}
 
 
-def segment_shard_report(dev, dev_id, rank, world, backend, B=4, K=20):
+def casadi_probe(S, P, Zs, p, g_gpu):
+    """"If `import casadi` succeeds ... time the real nlp_* functions obtained from the solver and report them as the
+    primary CPU reference."  CasADi is absent from the build image, so this leg has never executed; it is written against
+    CasADi's documented Python API and guarded: whatever goes wrong is reported as a string, never raised.  With CasADi present it
+    restates the moon-lander transcription (mpopt.py:154-237, 330-377, 415-462: defects, mid-point control rows, terminal rows,
+    J = compW . q) over SX with the product's collocation tables, lets `ca.nlpsol("solver", "ipopt", nlp)` derive nlp_f / nlp_g /
+    nlp_grad_f / nlp_jac_g / nlp_hess_l exactly as the reference does at mpopt.py:757, checks g against the GPU on the first
+    benchmarked point and times each function on one core (>= 30 repeats, median)."""
+    try:
+        import casadi as ca
+    except Exception:
+        return "absent"
+    try:
+        from mpopt_amd import mp
+
+        col = mp.Collocation([P] * S, "LGR")
+        N = S * P + 1
+        D = np.asarray(col.get_composite_differentiation_matrix([P] * S), float)
+        W = np.asarray(col.get_composite_quadrature_weights([P] * S), float).ravel()
+        r = np.asarray(col._taus_fn(P), float)
+        Im = np.asarray(col.get_composite_interpolation_matrix([(r[:-1] + r[1:]) / 2.0] * S, [P] * S), float)
+        X, U = ca.SX.sym("X", N, 2), ca.SX.sym("U", N, 1)
+        t0, tf, w = ca.SX.sym("t0"), ca.SX.sym("tf"), ca.SX.sym("w", S)
+        seg = np.concatenate([[0], np.repeat(np.arange(S), P)])
+        h = ca.vertcat(*[(tf - t0) / 2.0 * w[int(s)] for s in seg])
+        F = ca.horzcat(h * X[:, 1], h * (U[:, 0] - 1.5))
+        G = ca.vertcat(ca.vec(ca.mtimes(ca.DM(D), X) - F), ca.mtimes(ca.DM(Im), U), X[N - 1, 0], X[N - 1, 1])
+        J = ca.mtimes(ca.DM(W).T, h * U[:, 0])
+        Z = ca.vertcat(ca.vec(X), ca.vec(U), t0, tf)
+        solver = ca.nlpsol("solver", "ipopt", {"f": J, "x": Z, "g": G, "p": w}, {"ipopt.print_level": 0, "print_time": 0})
+        out, z0 = {}, np.asarray(Zs[0], float)
+        gg = np.asarray(solver.get_function("nlp_g")(z0, p)).ravel()
+        out["max_abs_g_vs_gpu"] = float(np.abs(gg - g_gpu).max())
+        lam = np.ones(gg.size)
+        for name, args in (("nlp_f", (z0, p)), ("nlp_g", (z0, p)), ("nlp_grad_f", (z0, p)), ("nlp_jac_g", (z0, p)), ("nlp_hess_l", (z0, p, 1.0, lam))):
+            fn = solver.get_function(name)
+            for _ in range(5):
+                fn(*args)
+            ts = []
+            for _ in range(30):
+                t = time.perf_counter()
+                fn(*args)
+                ts.append(time.perf_counter() - t)
+            ts.sort()
+            out[name + "_us"] = {"median": ts[15] * 1e6, "p10": ts[3] * 1e6, "p90": ts[27] * 1e6}
+        out["grad_f_plus_jac_g_evals_per_s"] = 1.0 / ((out["nlp_grad_f_us"]["median"] + out["nlp_jac_g_us"]["median"]) * 1e-6)
+        out["version"] = ca.__version__
+        return out
+    except Exception as e:  # pragma: no cover
+        return "present, probe failed: " + repr(e)[:300]
+
+
+def segment_shard_report(dev, dev_id, rank, world, backend, B=32, K=20):
     """Secondary measurement attached to the default line when N > 1 (so that the driver's --gpus 2/4/8 runs exercise RCCL on
     the path): configs[2] (Van der Pol 2000 x [3,30,3], CGL), the segments of every evaluation sharded over the
     ranks, finished in each of the three ways of mpopt_amd.distributed.SegmentShardedEvaluator -- "allgather" (ONE
@@ -187,7 +262,7 @@ def segment_shard_report(dev, dev_id, rank, world, backend, B=4, K=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a timed region of >= 0.2 s at the default workload)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="evaluation points per GPU per step")
     ap.add_argument("--segments", type=int, default=1000)
@@ -220,6 +295,14 @@ def main():
     dev_id = local_rank % n_dev
     dev = torch.device("cuda", dev_id)
     torch.cuda.set_device(dev)
+    # who took part: every rank's host / HIP device / PCI bus id through all_gather_object (the proof that an N > 1 line ran on N
+    # distinct GPUs over RCCL), plus one small all_reduce on the device as the first contact of the collective library
+    census = None
+    if world > 1:
+        census = mpd.device_census(dev_id)
+        probe = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else None)
+        dist.all_reduce(probe)
+        census["all_reduce_of_ones"] = float(probe.item())
 
     import mpopt_amd as M
     from mpopt_amd import mp
@@ -382,6 +465,7 @@ def main():
             bytes_eval = 5 * (o.bytes_hess + 8 * (o.n_z + 2 * o.n_p + n_pts * ocp.nx) + 8 * (n_pts * ocp.nx + 2 * o.n_p))
             kernel_s = elapsed / K
         achieved = B * bytes_eval / kernel_s / 1e9
+        sweep_us = extra.get("placement_sweep_node_kernel_us")
         out = {
             "metric": "NLP grad_f+jac_g evals/sec, 1000-seg LGR" if args.workload == "config2-fgj" else f"NLP evals/sec ({args.workload})",
             "value": (1 if shard else world) * B * K * (5 if loop5 else 1) / elapsed,
@@ -404,6 +488,8 @@ def main():
                                        else f"independent evaluation points x{world}")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if not (shard and world > 1) else None, "traffic": None,
+                         "frac_vs_measured_peak": achieved / HBM_MEASURED_GBS if not (shard and world > 1) else None,
+                         "measured_peak": HBM_MEASURED_GBS,
                          "kernel": ("whole loop: mpx_resid_0_3 + mpx_node_hess_0_3 + mpx_boundary_hess + mpx_equal_area_kernel (wall time of the step)" if loop5
                                     else "mpx_pts_jac + mpx_gather_kernel" if adaptive else f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*"),
                          "kernel_us": kernel_s * 1e6,
@@ -414,9 +500,14 @@ def main():
             out["roofline"]["note"] = ("SURVEY 8(d) byte model: it charges all n_g multipliers although the kernel reads only those of rows with second "
                                        "derivatives, and a working set this small is partly Infinity-Cache resident -- a fraction near or above 1 is "
                                        "not an HBM-roofline statement (no PMC traffic for this workload)")
-        if "placement_sweep_node_kernel_us" in extra:  # the same kernel on four fresh allocations of the outputs + the timed one
-            fr = sorted(B * bytes_eval / (us * 1e-6) / 1e9 / HBM_PEAK_GBS for us in extra["placement_sweep_node_kernel_us"] + [kernel_s * 1e6])
+        if sweep_us:  # the same kernel on four fresh allocations of the outputs + the timed one
+            fr = sorted(B * bytes_eval / (us * 1e-6) / 1e9 / HBM_PEAK_GBS for us in sweep_us + [kernel_s * 1e6])
             out["roofline"].update(frac_placement_median=fr[len(fr) // 2], frac_placement_min=fr[0], frac_placement_max=fr[-1])
+            # what a caller typically gets: the step with the MEDIAN node-kernel time over the five placements (the rest of the
+            # step -- prefix, boundary, launch gaps -- as measured in the timed region)
+            ks = sorted(sweep_us + [kernel_s * 1e6])
+            step_med = elapsed / K + (ks[len(ks) // 2] * 1e-6 - kernel_s)
+            out["value_placement_median"] = world * B / step_med
         if extra:
             out["extras"] = dict(extra, note="opt-in MPX_JAC_VARIABLE_ONLY (resident jac buffers keep the constant D / interpolation "
                                              "entries); not the metric: the headline rewrites every entry on every evaluation")
@@ -446,10 +537,16 @@ def main():
             C = COracle(["moon_lander"], S, P, "LGR")
             ns = min(B, 64)
             ph = np.full(o.n_p, 1.0 / S)
-            C.time_many(Zh[:ns], ph, 1)  # touch pages
+            # >= 5 warm-ups, >= 30 repeats, median + p10 / p90 (perf_counter around every repeat); one repeat = a few
+            # passes over the sample so that it lasts ~0.3 s
+            for _ in range(5):
+                C.time_many(Zh[:ns], ph, 1)
             t1 = C.time_many(Zh[:ns], ph, 2) / 2
-            reps = max(1, int(args.cpu_seconds / max(t1, 1e-6)))
-            tt = C.time_many(Zh[:ns], ph, reps)
+            n_rep = 35
+            inner = max(1, int(args.cpu_seconds / n_rep / max(t1, 1e-6)))
+            rates = sorted(ns * inner / C.time_many(Zh[:ns], ph, inner) for _ in range(n_rep))
+            tt, reps = sum(ns * inner / r_ for r_ in rates), inner * n_rep
+            cpu_med, cpu_p10, cpu_p90 = rates[n_rep // 2], rates[int(0.1 * n_rep)], rates[int(0.9 * n_rep)]
             r = C.eval(Zh[0], ph)  # the CPU port and the GPU agree on the benchmarked point
             assert abs(r["f"] - float(f[0].item())) < 1e-9 * max(1.0, abs(r["f"]))
             assert np.abs(r["g"] - g[0].cpu().numpy()).max() < 1e-9
@@ -464,16 +561,18 @@ def main():
             cfg2 = (problems.moon_lander, S, P, "LGR", ["moon_lander"], 1.0, [1])
             cfg1 = (problems.moon_lander, 20, 3, "LGR", ["moon_lander"], 1.0, [1])
             out["ipopt_iter"] = dict(ipopt_iter_report(*cfg2, dev_id), unit="us", config=f"moon lander {S}x{P} LGR (configs[1]), B=1, host pointers",
-                                     call_mix="1.15 nlp_g + nlp_grad_f + nlp_jac_g + nlp_hess_l (moon_lander.ipynb:192-198)")
+                                     call_mix="per iterate, in order: nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l; one iteration = 1.15 (nlp_f + nlp_g) + nlp_grad_f "
+                                              "+ nlp_jac_g + nlp_hess_l (moon_lander.ipynb:192-198); medians of the per-call times")
             out["ipopt_iter_config0"] = dict(ipopt_iter_report(*cfg1, dev_id, seconds=0.3), unit="us",
                                              config="moon lander 20x3 LGR (configs[0]), B=1, host pointers")
             cfg5 = (problems.hyper_sensitive, 4000, 3, "LGR", ["hyper_sensitive"], 1e-3, [0])
             out["ipopt_iter_config4"] = dict(ipopt_iter_report(*cfg5, dev_id, seconds=0.3), unit="us",
                                              config="hyper-sensitive 4000x3 LGR (configs[4]), B=1, host pointers")
-            out["cpu_baseline"] = {"value": ns * reps / tt, "unit": "evals/s", "cores": 1, "kind": "port",
-                                   "sample": f"{ns} of the same evaluation points x {reps} passes, oracle/mpopt_oracle.c "
-                                             f"(gcc -O2, scalar, values only), {tt:.1f} s",
+            out["cpu_baseline"] = {"value": cpu_med, "unit": "evals/s", "cores": 1, "kind": "port", "p10": cpu_p10, "p90": cpu_p90, "repeats": n_rep,
+                                   "sample": f"{ns} of the same evaluation points x {inner} passes per repeat, {n_rep} repeats (median; p10 / p90 beside it), "
+                                             f"oracle/mpopt_oracle.c (gcc -O2, scalar, values only), {tt:.1f} s",
                                    "host_cpus": os.cpu_count()}
+            out["casadi"] = casadi_probe(S, P, Zh[:ns], ph, g[0].cpu().numpy())
     # Secondary measurement on N > 1 lines (RCCL on the path).  It runs AFTER the headline is final and under a
     # watchdog: whatever happens in it -- an exception, a collective that never returns -- rank 0 still prints its ONE line.
     if world > 1 and args.workload == "config2-fgj" and not args.no_extras:
@@ -482,6 +581,7 @@ def main():
         def bail():
             if rank == 0:
                 out["segment_shard"] = {"error": "no result within 150 s (watchdog)"}
+                out["rccl"] = census
                 print(json.dumps(out), flush=True)
             os._exit(0)
 
@@ -496,6 +596,8 @@ def main():
         if rank == 0:
             out["segment_shard"] = shard_extra
     if rank == 0:
+        if census is not None:
+            out["rccl"] = census
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

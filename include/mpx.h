@@ -370,6 +370,15 @@ int mpx_set_current(mpx_ctx* ctx);
  * the same work-vector slices on every call), so that every transfer is a direct DMA.  The registrations are
  * released by mpx_set_current (any argument) and by mpx_current_pin_buffers(0); the arrays must outlive that. */
 int mpx_current_pin_buffers(int enable);
+/* Same-iterate coalescing of the nlp_* entry points (mpx_casadi.cpp): the first call at a new (x, p) evaluates f, g and grad_f
+ * (and jac_g when nnz_jac * 8 <= 64 KB) in one fused pass; nlp_f / nlp_g / nlp_grad_f (and that small nlp_jac_g) at the same
+ * point are then served from page-locked scratch of the context.  Counters since the context was selected: fused device passes
+ * made by the cache and calls answered without a device pass.  MPX_NO_COALESCE=1 (environment, read by mpx_set_current)
+ * switches the cache off. */
+int mpx_current_cache_stats(long long* fused_passes, long long* served_from_cache);
+/* Caller arrays page-locked so far by mpx_current_pin_buffers(1) and registrations that failed (remembered, not retried): a
+ * solver that passes the same work-vector slices on every call stops adding to these after its first iteration. */
+int mpx_current_pin_stats(long long* registered, long long* failed);
 
 /* ---------------------------------------------------------------------------------------------
  * Timing helper: HIP events on the context's stream (bench.py measures kernel time with these)

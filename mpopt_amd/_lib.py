@@ -172,6 +172,8 @@ SYMBOLS = {
     "mpx_host_register": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "mpx_host_unregister": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mpx_current_pin_buffers": (ctypes.c_int, [ctypes.c_int]),
+    "mpx_current_cache_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
+    "mpx_current_pin_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "mpx_set_tile_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "mpx_get_tile_jac_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p, c_int64_p]),
     "mpx_get_tile_weights": (ctypes.c_int, [ctypes.c_void_p, c_int64_p]),

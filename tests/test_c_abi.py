@@ -105,3 +105,117 @@ def test_c_caller_evaluates_on_the_gpu(name, tmp_path):
     ref = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], Z, G["p"], lam_g=lam, sigma=sig)  # same library through ctypes: bitwise
     assert np.array_equal(ref["jac_g"], out["jv"]) and np.array_equal(ref["hess_l"], out["hv"]) and np.array_equal(ref["g"], out["g"])
     o.close()
+
+
+# ---- a CasADi-shaped caller (tests/c_abi/nlpsol_like.c): dlopen + every nlp_* companion symbol + one work arena ----------------
+def build_nlpsol_like(tmp_path):
+    _lib.build_library()
+    exe = str(tmp_path / "nlpsol_like")
+    cmd = ["gcc", "-std=c99", "-D_GNU_SOURCE", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "c_abi", "nlpsol_like.c"),
+           "-o", exe, "-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def _read_ccs(raw, off, n_x):
+    nrow, ncol = struct.unpack_from("<2q", raw, off)
+    colind = np.frombuffer(raw, np.int64, ncol + 1, off + 16)
+    rows = np.frombuffer(raw, np.int64, int(colind[-1]), off + 16 + 8 * (ncol + 1))
+    return nrow, ncol, colind, rows, off + 16 + 8 * (ncol + 1) + 8 * int(colind[-1])
+
+
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL"])
+def test_nlpsol_like_caller_binds_every_symbol_without_a_gpu(name, tmp_path):
+    """The importer half of the hand-off (mpopt.py:757): dlopen, all companion symbols of the five functions, names, counts,
+    work sizes and sparsities consistent with mpx_get_sizes / the COO patterns; the numerical entry point of a structure-only
+    context returns non-zero (no CPU fallback)."""
+    exe = build_nlpsol_like(tmp_path)
+    ocp, mpo, o = build_case(name, with_device=False)
+    dump_problem(tmp_path / "problem.bin", o, code=False)
+    r = subprocess.run([exe, _lib.LIB_PATH, str(tmp_path / "problem.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(tmp_path / "out.bin", "rb").read()
+    n_x, n_p, n_g, nnz_j, nnz_h, K, rc_eval = struct.unpack_from("<7q", raw, 0)
+    assert (n_x, n_p, n_g, nnz_j, nnz_h, K) == (o.n_z, o.n_p, o.n_g, o.nnz_jac, o.nnz_hess, 0) and rc_eval != 0
+    nrow, ncol, colind, rows, off = _read_ccs(raw, 56, n_x)
+    jr, jc = o.jac_pattern()
+    perm, ci = o.ccs_perm("jac")
+    assert (nrow, ncol) == (o.n_g, o.n_z) and np.array_equal(colind, ci) and np.array_equal(rows, jr[perm])
+    nrow, ncol, colind, rows, off = _read_ccs(raw, off, n_x)
+    hr, hc = o.hess_pattern()
+    perm, ci = o.ccs_perm("hess")
+    assert (nrow, ncol) == (o.n_z, o.n_z) and np.array_equal(colind, ci) and np.array_equal(rows, hr[perm])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL", "moon_lander_60x5_big_jac"])
+def test_nlpsol_like_caller_runs_ipopt_call_sequence_on_the_gpu(name, tmp_path):
+    """The solver half: ONE work arena, arg / res carved from it, checkout / release, the calls of K interior-point iterates in
+    IPOPT's order (nlp_f, nlp_g at trial points -- some rejected --, then nlp_grad_f, nlp_jac_g with res[0] = NULL, nlp_hess_l), the
+    caller's slices page-locked on first sight (mpx_current_pin_buffers(1)).  Values of every iterate equal mpx_eval bit for bit
+    (same kernels), the goldens to 1e-10; no slice is registered after the first iterate; the same-iterate cache made ONE fused
+    pass per new point for f, g, grad_f (and jac_g where it is small)."""
+    exe = build_nlpsol_like(tmp_path)
+    if name == "moon_lander_60x5_big_jac":  # nnz_jac * 8 > 64 KB: the Jacobian is not part of the fused first pass
+        import problems
+        from mpopt_amd import mp
+
+        ocp = problems.moon_lander(mp, M.math)
+        mpo = mp.mpopt(ocp, 400, 5, "LGR")
+        o = mpo.create_nlp()[0]["oracle"]
+        G = None
+        z0, p = mpo.initialize_solution(), np.full(o.n_p, 1.0 / 400)
+    else:
+        G = load_golden(name)
+        ocp, mpo, o = build_case(name, with_device=True)
+        z0, p = G["z"], G["p"]
+    dump_problem(tmp_path / "problem.bin", o)
+    K = 7
+    rng = np.random.default_rng(4)
+    Z = z0[None, :] * (1 + 0.01 * rng.uniform(-1, 1, (K, o.n_z))) + 0.01 * rng.uniform(-1, 1, (K, o.n_z))
+    Z[0] = z0
+    lam = rng.standard_normal((K, o.n_g))
+    sig = rng.uniform(0.5, 1.5, K)
+    if G is not None:
+        lam[0], sig[0] = G["lam"], float(G["sigma"])
+    with open(tmp_path / "iterates.bin", "wb") as f:
+        f.write(struct.pack("<q", K))
+        for a in (Z, p, lam, sig):
+            f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    r = subprocess.run([exe, _lib.LIB_PATH, str(tmp_path / "problem.bin"), str(tmp_path / "iterates.bin"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(tmp_path / "out.bin", "rb").read()
+    head = struct.unpack_from("<7q", raw, 0)
+    assert head[:6] == (o.n_z, o.n_p, o.n_g, o.nnz_jac, o.nnz_hess, K)
+    per = 1 + o.n_g + o.n_z + o.nnz_jac + o.nnz_hess
+    vals = np.frombuffer(raw, np.float64, K * per, 56).reshape(K, per)
+    fused, served, pins_first, pins_end, pins_failed, rejected = struct.unpack_from("<6q", raw, 56 + 8 * K * per)
+    ref = o.eval(["f", "g", "grad_f"], Z, p)
+    refj = o.eval(["jac_g"], Z, p, ccs_order=True)
+    refh = o.eval(["hess_l"], Z, p, lam_g=lam, sigma=sig, ccs_order=True)
+    small = o.nnz_jac * 8 <= 65536
+    if small:  # the fused pass includes the Jacobian: same kernel launch as this mask
+        refj = o.eval(["f", "g", "grad_f", "jac_g"], Z, p, ccs_order=True)
+    for k in range(K):
+        f, g, gr, jv, hv = vals[k, 0], vals[k, 1:1 + o.n_g], vals[k, 1 + o.n_g:1 + o.n_g + o.n_z], vals[k, 1 + o.n_g + o.n_z:per - o.nnz_hess], vals[k, per - o.nnz_hess:]
+        assert f == ref["f"][k] and np.array_equal(g, ref["g"][k]) and np.array_equal(gr, ref["grad_f"][k]), k
+        assert np.array_equal(jv, refj["jac_g"][k]) and np.array_equal(hv, refh["hess_l"][k]), k
+    if G is not None:
+        f, g, gr = vals[0, 0], vals[0, 1:1 + o.n_g], vals[0, 1 + o.n_g:1 + o.n_g + o.n_z]
+        assert rel_err(f, G["f"]) < 1e-10 and rel_err(g, G["g"]) < 1e-10 and rel_err(gr, G["grad_f"]) < 1e-10
+        pj, _ = o.ccs_perm("jac")
+        ph, _ = o.ccs_perm("hess")
+        jr, jc = o.jac_pattern()
+        hr, hc = o.hess_pattern()
+        jv, hv = vals[0, 1 + o.n_g + o.n_z:per - o.nnz_hess], vals[0, per - o.nnz_hess:]
+        assert_coo_close(jr[pj], jc[pj], jv, G["jac_row"], G["jac_col"], G["jac_val"], 1e-10, "jac_g through the CasADi-shaped caller")
+        assert_coo_close(hr[ph], hc[ph], hv, G["hess_row"], G["hess_col"], G["hess_val"], 1e-10, "hess_l through the CasADi-shaped caller")
+    # page-locking: x, (g, grad_f are served by memcpy: not registered), the large jac slice, lam_g, hess -- all on the first iterate
+    assert pins_first == pins_end and pins_failed == 0 and pins_first >= 3, (pins_first, pins_end, pins_failed)
+    # the cache: one fused device pass per new point (K iterates + the rejected trial points), everything else of f / g / grad_f served
+    assert rejected == len([k for k in range(K) if k % 3 == 2])
+    assert fused == K + rejected, (fused, K, rejected)
+    assert served >= 2 * K + rejected, (served, K, rejected)
+    o.close()
