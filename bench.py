@@ -70,7 +70,7 @@ def ipopt_iter_report(builder, S, P, scheme, cnames, scale_t, midu, dev_id, seco
     L = _lib.lib()
     rng = np.random.default_rng(20260928)
     Zs = make_points(o, mpo, bounds, 2, 20260928)
-    z = np.ascontiguousarray(Zs[0])
+    z = Zs[0].copy()  # the caller's x vector: same address on every call, new content per iterate
     p = np.full(o.n_p, 1.0 / S)
     lam, sig = rng.standard_normal(o.n_g), np.array([1.0])
     f, g, gr = np.zeros(1), np.zeros(o.n_g), np.zeros(o.n_z)

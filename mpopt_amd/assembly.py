@@ -75,13 +75,15 @@ class PointFunction:
         names.update({f"cst[{i}]": f"cst[{i}]" for i in range(self.n_cst)})
         names.update({f"mu[{r}]": f"mu[{r}]" for r in range(self.n_out)})
         sig = "const double* __restrict__ loc, const double* __restrict__ cst"
+        # (#pragma clang fp contract(off): every kernel that inlines these bodies -- two-pass and fused -- rounds each operation
+        # the same way, so their results agree bit for bit whatever the surrounding code looks like)
         o = [f"template <> struct Pt<{fid}> {{",
              f"  static constexpr int NLOC = {self.n_loc}, NCST = {self.n_cst}, NOUT = {self.n_out}, NJ = {self.n_jac}, NH = {self.n_hess};",
-             f"  __device__ static __forceinline__ void val({sig}, double* out) {{"]
+             f"  __device__ static __forceinline__ void val({sig}, double* out) {{", "#pragma clang fp contract(off)"]
         o += tr.emit([(f"out[{r}]", e) for r, e in enumerate(self.out)], names, "    ")
-        o += ["  }", f"  __device__ static __forceinline__ void jac({sig}, double* out, double* J) {{"]
+        o += ["  }", f"  __device__ static __forceinline__ void jac({sig}, double* out, double* J) {{", "#pragma clang fp contract(off)"]
         o += tr.emit([(f"out[{r}]", e) for r, e in enumerate(self.out)] + [(f"J[{q}]", s[2]) for q, s in enumerate(self.J)], names, "    ")
-        o += ["  }", f"  __device__ static __forceinline__ void hes({sig}, const double* __restrict__ mu, double* H) {{"]
+        o += ["  }", f"  __device__ static __forceinline__ void hes({sig}, const double* __restrict__ mu, double* H) {{", "#pragma clang fp contract(off)"]
         o += tr.emit([(f"H[{q}]", s[2]) for q, s in enumerate(self.H)], names, "    ")
         o += ["  }", "};"]
         return "\n".join(o)
@@ -169,8 +171,19 @@ class AssembledNlpFunctions(NlpFunctions):
             if s.fn not in funcs:
                 funcs.append(s.fn)
         self.functions = funcs
-        self.source = self._source(funcs)
         self._expand(Gz, g0)
+        sizes = dict(RAW_N=self.raw_n, RAWH_N=self.rawh_n, NZ=self.n_z_, NG=self.n_g_, NNZJ=self.nnz_jac_, NNZH=self.nnz_hess_)
+        for tag, (ptr, _, _) in (("FGJ", self.fgj), ("HES", self.hess)):  # shape of the multi-term and long rows of each pass
+            nt = np.diff(ptr)
+            multi, longr = nt[(nt >= 2) & (nt <= 24)], nt[nt > 24]  # 24 = MPX_GATHER_LONG
+            # ELL width of the multi-term rows kept in registers: the smallest width <= 12 that leaves at most 16 wider rows to
+            # the one-wavefront-per-row path
+            mt = 0
+            if len(multi):
+                mt = next((w for w in range(2, 13) if (multi > w).sum() <= 16), 12)
+            sizes["MT_" + tag], sizes["NMULTI_" + tag] = int(mt), int(((multi <= mt)).sum()) if len(multi) else 0
+            sizes["NLONG_" + tag], sizes["LT_" + tag] = len(longr), int(longr.max()) if len(longr) else 0
+        self.source = self._source(funcs, sizes)
         if with_device is None:
             with_device = _lib.gpu_available()
         self.code_object = None
@@ -180,7 +193,7 @@ class AssembledNlpFunctions(NlpFunctions):
 
     # -- generated source ---------------------------------------------------------------------------
     @staticmethod
-    def _source(funcs):
+    def _source(funcs, sizes):
         parts = ["// generated by mpopt_amd.assembly -- do not edit", "#include <hip/hip_runtime.h>", "namespace mpxgen {",
                  "template <int FID> struct Pt;"]
         parts += [f.source(k) for k, f in enumerate(funcs)]
@@ -190,6 +203,10 @@ class AssembledNlpFunctions(NlpFunctions):
         n_stmt = sum(p.count(";") for p in parts)
         parts += ["}  // namespace mpxgen", "#ifndef MPX_PTS_UNROLL  // (-DMPX_PTS_UNROLL=n in MPX_HIPCC_FLAGS overrides)", f"#define MPX_PTS_UNROLL {4 if n_stmt <= 1000 else 1}", "#endif", '#include "mpx_assembly_kernels.h"']
         parts.append(f"MPX_INSTANTIATE_POINTS({len(funcs)})")
+        # fused persistent kernels for batches (mpx_assembly_fused.h): the sizes of this problem are compile-time constants there
+        # (row loops unroll, a lane's share of the row table lives in registers)
+        parts += [f"#define MPX_FUSE_{k} {int(v)}" for k, v in sizes.items()]
+        parts += ['#include "mpx_assembly_fused.h"', f"MPX_INSTANTIATE_FUSED({len(funcs)})"]
         return "\n".join(parts) + "\n"
 
     # -- expansion of the chain rule into gather rows -------------------------------------------------

@@ -37,7 +37,20 @@ struct DevGather {
 
 }  // namespace
 
+// Tables of the fused kernels (mpx_assembly_fused.h) for one pass: first term and term count per row, all terms with their
+// sources remapped to positions in V = [raw | z | 1], the rows with 2 .. MPX_GATHER_LONG terms and the longer ones.
+struct DevFused {
+  int32_t *r_idx = nullptr, *r_nt = nullptr, *idx = nullptr, *multi = nullptr, *mid = nullptr, *longr = nullptr, *m_idx = nullptr;
+  double *r_coef = nullptr, *m_coef = nullptr;
+  int32_t n_multi = 0, n_mid = 0, n_long = 0;
+};
+
 struct mpx_asm_state {
+  DevFused ffgj, fhess;
+  hipFunction_t fn_fused[3] = {nullptr, nullptr, nullptr};
+  int fuse_nt = 0, fuse_u[2] = {0, 0};  // lanes per workgroup; evaluation points per workgroup pass (first order, Hessian); 0: no kernel
+  int fuse_wg[3] = {0, 0, 0};           // resident workgroups per launch (compute units x occupancy)
+  long long* dbg = nullptr;             // MPX_FUSE_DEBUG
   std::vector<DevSet> sets;
   MpxPtSet* d_sets = nullptr;  // device copy of the per-set argument blocks
   int n_blocks = 0;            // 64-lane blocks of the fused point launch
@@ -175,6 +188,35 @@ int upload_gather(mpx_ctx* c, DevGather& d, const mpx_gather& g, int64_t raw_n, 
   return upload_n(c, &d.coef, g.coef, (size_t)d.nnz);
 }
 
+int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, int64_t n_z, int mt) {
+  const int64_t nnz = g.n_rows ? g.ptr[g.n_rows] : 0;
+  std::vector<int32_t> r_idx((size_t)std::max<int64_t>(g.n_rows, 1), 0), r_nt((size_t)std::max<int64_t>(g.n_rows, 1), 0), idx((size_t)std::max<int64_t>(nnz, 1), 0), multi, mid, longr;
+  std::vector<double> r_coef((size_t)std::max<int64_t>(g.n_rows, 1), 0.0);
+  auto pos = [&](int64_t k) -> int32_t { return (int32_t)(k >= 0 ? k : (k == -1 ? raw_n + n_z : raw_n + (-2 - k))); };
+  for (int64_t e = 0; e < nnz; ++e) idx[(size_t)e] = pos(g.src[e]);
+  for (int64_t r = 0; r < g.n_rows; ++r) {
+    const int64_t nt = g.ptr[r + 1] - g.ptr[r];
+    r_nt[(size_t)r] = (int32_t)nt;
+    r_idx[(size_t)r] = nt ? idx[(size_t)g.ptr[r]] : (int32_t)(raw_n + n_z);
+    r_coef[(size_t)r] = nt ? g.coef[g.ptr[r]] : 0.0;
+    if (nt > MPX_GATHER_LONG) longr.push_back((int32_t)r);
+    else if (nt > mt) mid.push_back((int32_t)r);
+    else if (nt >= 2) multi.push_back((int32_t)r);
+  }
+  f.n_multi = (int32_t)multi.size(), f.n_mid = (int32_t)mid.size(), f.n_long = (int32_t)longr.size();
+  // ELL copy of the multi-term rows: [t][row], padded with (the 1.0 slot, 0) -- padding terms are never added (t < nt)
+  std::vector<int32_t> m_idx((size_t)std::max<int64_t>((int64_t)mt * f.n_multi, 1), (int32_t)(raw_n + n_z));
+  std::vector<double> m_coef((size_t)std::max<int64_t>((int64_t)mt * f.n_multi, 1), 0.0);
+  for (int32_t m = 0; m < f.n_multi; ++m)
+    for (int64_t e = g.ptr[multi[m]], t = 0; e < g.ptr[multi[m] + 1]; ++e, ++t) m_idx[(size_t)(t * f.n_multi + m)] = idx[(size_t)e], m_coef[(size_t)(t * f.n_multi + m)] = g.coef[e];
+  int rc;
+  if ((rc = upload(c, &f.r_idx, r_idx)) || (rc = upload(c, &f.r_nt, r_nt)) || (rc = upload(c, &f.r_coef, r_coef)) || (rc = upload(c, &f.idx, idx)) ||
+      (rc = upload(c, &f.multi, multi)) || (rc = upload(c, &f.mid, mid)) || (rc = upload(c, &f.longr, longr)) || (rc = upload(c, &f.m_idx, m_idx)) ||
+      (rc = upload(c, &f.m_coef, m_coef)))
+    return rc;
+  return MPX_OK;
+}
+
 int check_terms(mpx_ctx* c, const int32_t* nterm, int nv, const int32_t* idx, int64_t n, int64_t limit, std::vector<int32_t>& toff, const char* what) {
   toff.assign((size_t)nv + 1, 0);
   for (int v = 0; v < nv; ++v) {
@@ -197,7 +239,9 @@ void mpx_asm_release(mpx_ctx* c) {
   };
   for (auto& s : a->sets) fr(s.loc_toff), fr(s.loc_idx), fr(s.mu_toff), fr(s.mu_idx), fr(s.loc_coef), fr(s.cst), fr(s.mu_coef);
   for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef), fr(g->long_rows);
+  for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef);
   fr(a->raw.p), fr(a->d_sets);
+  if (a->dbg) (void)hipHostFree(a->dbg);
   delete a;
   c->assembled = nullptr;
 }
@@ -284,6 +328,29 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
   if (a->raw_n >= (1LL << 31) || a->rawh_n >= (1LL << 31)) return bail(fail(c, MPX_ERR_UNSUPPORTED, "raw buffer too large for int32 sources"));
   if ((rc = upload_gather(c, a->fgj, D->fgj, a->raw_n, D->n_z, "fgj gather")) || (rc = upload_gather(c, a->hess, D->hess, a->rawh_n, D->n_z, "hess gather")))
     return bail(rc);
+  {  // fused persistent kernels (mpx_assembly_fused.h): present in code objects generated since round 3
+    hipDeviceptr_t sym = nullptr;
+    size_t bytes = 0;
+    int info[5] = {0, 0, 0, 0, 0};
+    static const char* fname[3] = {"mpx_asm_fg", "mpx_asm_fgj", "mpx_asm_hes"};
+    if (hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_fuse_info") == hipSuccess && bytes == sizeof info && hipMemcpyDtoH(info, sym, sizeof info) == hipSuccess &&
+        info[0] >= 64 && info[0] <= 1024) {
+      bool ok = true;
+      for (int m = 0; m < 3 && ok; ++m) ok = hipModuleGetFunction(&a->fn_fused[m], c->module, fname[m]) == hipSuccess;
+      if (ok && (info[1] > 0 || info[2] > 0)) {
+        if ((rc = upload_fused(c, a->ffgj, D->fgj, a->raw_n, D->n_z, info[3])) || (rc = upload_fused(c, a->fhess, D->hess, a->rawh_n, D->n_z, info[4]))) return bail(rc);
+        a->fuse_nt = info[0], a->fuse_u[0] = info[1], a->fuse_u[1] = info[2];
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+        for (int m = 0; m < 3; ++m) {
+          int per_cu = 1;
+          if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, a->fn_fused[m], a->fuse_nt, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+          a->fuse_wg[m] = n_cu * per_cu;
+        }
+      }
+    }
+    (void)hipGetLastError();
+  }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "hipEventCreate failed"));
   c->has_device = true;
   *out = c;
@@ -340,6 +407,47 @@ static int launch_gather(mpx_ctx* c, const DevGather& g, int64_t batch, const do
   return MPX_OK;
 }
 
+// Fused persistent launch (mpx_assembly_fused.h): one kernel per pass, raw values stay in LDS.  Used for batches (every
+// workgroup should see several evaluation points for its register-resident row table to pay); single evaluations keep the
+// two-pass kernels, whose many small workgroups finish a lone point sooner.  Results are bit-identical either way.
+// MPX_NO_FUSE=1 / MPX_FUSE_MIN_BATCH=n (read per call) switch.
+static bool use_fused(const mpx_asm_state* a, int mode, int64_t batch) {
+  if (!a->fuse_nt || a->fuse_u[mode == MPX_MODE_HESS ? 1 : 0] <= 0 || getenv("MPX_NO_FUSE")) return false;
+  const char* mb = getenv("MPX_FUSE_MIN_BATCH");
+  return batch >= (mb ? atoll(mb) : 256);
+}
+
+static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, const double* lam, const double* sigma, double* const* out, const int64_t* stride) {
+  mpx_asm_state* a = c->assembled;
+  const DevFused& f = mode == MPX_MODE_HESS ? a->fhess : a->ffgj;
+  const DevGather& g = mode == MPX_MODE_HESS ? a->hess : a->fgj;
+  MpxFusedArgs A{};
+  A.sets = a->d_sets, A.n_sets = (int32_t)a->sets.size(), A.n_blocks = a->n_blocks, A.n_g = (int32_t)c->n_g, A.B = (int32_t)batch;
+  A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma;
+  A.r_idx = f.r_idx, A.r_coef = f.r_coef, A.r_nt = f.r_nt, A.ptr = g.ptr, A.idx = f.idx, A.coef = g.coef;
+  A.multi_rows = f.multi, A.m_idx = f.m_idx, A.m_coef = f.m_coef, A.mid_rows = f.mid, A.long_rows = f.longr;
+  A.n_multi = f.n_multi, A.n_mid = f.n_mid, A.n_long = f.n_long;
+  for (int k = 0; k < 4; ++k) A.out[k] = out[k], A.out_stride[k] = stride[k];
+  const int U = a->fuse_u[mode == MPX_MODE_HESS ? 1 : 0];
+  const int64_t chunks = (batch + U - 1) / U;
+  static const int wg_env = getenv("MPX_FUSE_WG") ? atoi(getenv("MPX_FUSE_WG")) : 0;
+  const unsigned grid = (unsigned)std::min<int64_t>(chunks, wg_env > 0 ? wg_env : a->fuse_wg[mode]);
+  static const bool dbg_on = getenv("MPX_FUSE_DEBUG") != nullptr;
+  if (dbg_on && !a->dbg) HIPCHK(c, hipHostMalloc((void**)&a->dbg, 128, hipHostMallocMapped));
+  A.dbg = dbg_on ? a->dbg : nullptr;
+  size_t sz = sizeof(A);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIPCHK(c, hipModuleLaunchKernel(a->fn_fused[mode], grid, 1, 1, (unsigned)a->fuse_nt, 1, 1, 0, c->stream, nullptr, cfg));
+  if (dbg_on) {  // phase stamps of workgroup 1, third chunk (us): z->LDS, points, barrier, single rows, multi rows, mid rows, long rows, barrier
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const long long* d = a->dbg;
+    fprintf(stderr, "fused mode %d grid %u: z %.2f | points %.2f | wait %.2f | rows1 %.2f | multi %.2f | mid %.2f | long %.2f | wait %.2f  (chunk %.2f us)\n", mode, grid,
+            (d[1] - d[0]) / 100.0, (d[2] - d[1]) / 100.0, (d[3] - d[2]) / 100.0, (d[4] - d[3]) / 100.0, (d[5] - d[4]) / 100.0, (d[6] - d[5]) / 100.0, (d[7] - d[6]) / 100.0,
+            (d[8] - d[7]) / 100.0, (d[8] - d[0]) / 100.0);
+  }
+  return MPX_OK;
+}
+
 // Evaluation points per pass.  The raw point values are written by the point kernels and read back by the gather pass; while a
 // pass's raw values + outputs fit the 256 MB Infinity Cache of an MI355X the read-back does not go to HBM.  Measured
 // (tools/adaptive_batch_sweep.py, moon lander 20x5): f+g+grad_f+jac_g peaks at 2048 points (179 MB per pass: 31 M evals/s) and
@@ -363,7 +471,16 @@ int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   mpx_asm_state* a = c->assembled;
   if (mask & (MPX_BOUNDARY_ONLY | MPX_JAC_VARIABLE_ONLY)) return fail(c, MPX_ERR_UNSUPPORTED, "mask bit not available on assembled contexts");
   int rc;
-  if (mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC)) {
+  if ((mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC)) && use_fused(a, (mask & (MPX_GRAD | MPX_JAC)) ? MPX_MODE_FGJ : MPX_MODE_FG, batch)) {
+    const int mode = (mask & (MPX_GRAD | MPX_JAC)) ? MPX_MODE_FGJ : MPX_MODE_FG;
+    hipEvent_t pe = nullptr;
+    if ((rc = prof_begin(c, &pe))) return rc;
+    double* outp[4] = {(mask & MPX_F) ? f : nullptr, (mask & MPX_G) ? g : nullptr, (mask & MPX_GRAD) ? grad_f : nullptr, (mask & MPX_JAC) ? jac_val : nullptr};
+    const int64_t stride[4] = {1, c->n_g, c->n_z, c->nnz_j};
+    if ((rc = launch_fused(c, mode, batch, z, nullptr, nullptr, outp, stride))) return rc;
+    if ((rc = prof_end(c, pe))) return rc;
+    if (c->profile) ++c->prof_launches;
+  } else if (mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC)) {
     const int mode = (mask & (MPX_GRAD | MPX_JAC)) ? MPX_MODE_FGJ : MPX_MODE_FG;
     const int64_t per = points_per_pass(batch, a->raw_n + c->n_z + ((mask & MPX_G) ? c->n_g : 0) + ((mask & MPX_GRAD) ? c->n_z : 0) + ((mask & MPX_JAC) ? c->nnz_j : 0));
     if ((rc = reserve(c, a->raw, (size_t)(per * a->raw_n)))) return rc;
@@ -382,7 +499,15 @@ int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, co
     if ((rc = prof_end(c, pe))) return rc;
     if (c->profile) ++c->prof_launches;
   }
-  if (mask & MPX_HESS) {
+  if ((mask & MPX_HESS) && use_fused(a, MPX_MODE_HESS, batch)) {
+    hipEvent_t pe = nullptr;
+    if ((rc = prof_begin(c, &pe))) return rc;
+    double* outp[4] = {hess_val, nullptr, nullptr, nullptr};
+    const int64_t stride[4] = {c->nnz_h, 0, 0, 0};
+    if ((rc = launch_fused(c, MPX_MODE_HESS, batch, z, lam_g, sigma, outp, stride))) return rc;
+    if ((rc = prof_end(c, pe))) return rc;
+    if (c->profile) ++c->prof_launches;
+  } else if (mask & MPX_HESS) {
     const int64_t per = points_per_pass(batch, a->rawh_n + c->n_z + c->n_g + 1 + c->nnz_h);
     if ((rc = reserve(c, a->raw, (size_t)(per * a->rawh_n)))) return rc;
     hipEvent_t pe = nullptr;

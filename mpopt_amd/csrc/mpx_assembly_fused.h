@@ -1,0 +1,471 @@
+// mpx_assembly_fused.h -- fused, persistent evaluation kernels of assembled contexts (include/mpx.h, mpx_create_assembled).
+//
+// Round 3 replacement of the two-pass scheme (mpx_assembly_kernels.h point kernels -> raw buffer in HBM -> mpx_gather_kernel)
+// for batches: the counters of profiles/r3_adaptive show that pass bound by the instruction stream of a table interpreter
+// (~80 instructions per stored wavefront-row, a three-level dependent load chain per row) with the raw values written to and
+// read back from HBM on top (traffic 1.88x the algorithmic bytes).  Here
+//   * one workgroup evaluates U evaluation points at a time, entirely out of LDS:  V[u] = [raw point values | z | 1.0],
+//     the vector every output row is a fixed-order sum  sum_t coef_t * V[idx_t]  over (mpx_gather in mpx.h, sources remapped
+//     to positions in V by the host).  Raw values never leave the compute unit;
+//   * workgroups are persistent: a lane owns the same rows (row = k * NT + lane inside each output array) for every
+//     evaluation point it sees, and keeps their first term (position, coefficient) in REGISTERS, loaded once per kernel
+//     instead of once per evaluation -- the per-problem row counts are compile-time constants of the generated source
+//     (MPX_FUSE_*), so the row loops unroll and the table is straight-line register code;
+//   * the row phase is then nothing but  ds_read -> v_fma -> global_store  with a uniform base and a running lane offset:
+//     each store instruction of a wavefront writes one contiguous 512-byte run;
+//   * rows with 2 .. MPX_GATHER_LONG terms (a few hundred: defect rows = D.X - f, mid-point residual entries) are summed by one
+//     lane each from a compact CSR (L1 / L2 resident), rows with more terms (objective, d/dt0, d/dtf, d/dwidths) by one
+//     wavefront each with the same shuffle tree as mpx_gather_kernel.
+// Every sum keeps the term order and the fma chain of the two-pass kernels: results are bit-identical to them (tested), so the
+// host may pick either path by batch size.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mpx_device.h"
+
+#ifndef MPX_FUSE_LOC_G
+#define MPX_FUSE_LOC_G 1  // table entries of a local variable fetched together
+#endif
+#ifndef MPX_FUSE_TASK_PER_U
+#define MPX_FUSE_TASK_PER_U 1
+#endif
+#ifndef MPX_FUSE_MULTI_EARLY
+#define MPX_FUSE_MULTI_EARLY 0
+#endif
+#ifndef MPX_FUSE_MID_WAVE
+#define MPX_FUSE_MID_WAVE 0
+#endif
+#ifndef MPX_FUSE_NT
+#define MPX_FUSE_NT 512  // lanes per workgroup
+#endif
+
+namespace mpxk {
+
+template <int NA, int NT>
+struct RowRegs {  // first terms of the rows k * NT + lane, k < K, of one output array; idx < 0: not a single-term row of this lane
+  static constexpr int K = (NA + NT - 1) / NT;
+  int idx[K > 0 ? K : 1];
+  double coef[K > 0 ? K : 1];
+  __device__ __forceinline__ void load(const ::MpxFusedArgs& A, int base, int l) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int r = k * NT + l;
+      const bool ok = r < NA && A.r_nt[base + (r < NA ? r : 0)] <= 1;
+      idx[k] = ok ? A.r_idx[base + r] : -1;
+      coef[k] = ok ? A.r_coef[base + r] : 0.0;
+    }
+  }
+  // out[r] = fma(coef, V[idx], 0) for the lane's single-term rows (the fma with a zero addend is what the two-pass kernel
+  // computes: it differs from a plain product in the sign of a zero result)
+  __device__ __forceinline__ void store(const double* __restrict__ V, double* __restrict__ out, int l) const {
+    if (!out) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (idx[k] >= 0) out[k * NT + l] = fma(coef[k], V[idx[k]], 0.0);
+  }
+};
+
+// point functions of one 64-point block for the U evaluation points of a chunk: a term's table entry (position, coefficient) is
+// read once and applied to all of them (per evaluation point the terms are added in the stored order, as in the two-pass point
+// kernels); local variables from z in LDS, results to raw in LDS
+template <int FID, int MODE, int U, int VN, int RAWN>
+__device__ __forceinline__ void fused_point(const MpxPtSet& S, const ::MpxFusedArgs& A, int blk, int lane, double (*V)[VN], int b0, int nu) {
+  using F = mpxgen::Pt<FID>;
+  constexpr int NLOC = F::NLOC, NCST = F::NCST, NOUT = F::NOUT, NJ = F::NJ, NH = F::NH;
+  if constexpr (MODE == MPX_MODE_HESS && NH == 0) return;
+  const int p = blk * 64 + lane;
+  if (p >= S.n) return;
+  const int64_t n = S.n;
+  double cst[NCST > 0 ? NCST : 1];
+#pragma unroll
+  for (int k = 0; k < NCST; ++k) cst[k] = S.cst[(int64_t)k * n + p];
+  double loc[U][NLOC > 0 ? NLOC : 1];
+#pragma unroll
+  for (int v = 0; v < NLOC; ++v) {
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0;
+    // (MPX_FUSE_LOC_G table entries are fetched together -- independent loads; one at a time would chain  L2 load -> LDS read ->
+    // fma  up to 50 times per point, which was the critical path of a chunk: 10 us for the mid-point block -- then added in order)
+    const int t1 = S.loc_toff[v + 1];
+    for (int t = S.loc_toff[v]; t < t1; t += MPX_FUSE_LOC_G) {
+      int ix[MPX_FUSE_LOC_G];
+      double cf[MPX_FUSE_LOC_G];
+#pragma unroll
+      for (int q = 0; q < MPX_FUSE_LOC_G; ++q) {
+        const int tt = t + q < t1 ? t + q : t1 - 1;  // (clamped: a valid address; the value is not used)
+        ix[q] = S.loc_idx[(int64_t)tt * n + p], cf[q] = S.loc_coef[(int64_t)tt * n + p];
+      }
+#pragma unroll
+      for (int q = 0; q < MPX_FUSE_LOC_G; ++q)
+        if (t + q < t1) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = fma(cf[q], V[u][RAWN + ix[q]], acc[u]);  // (slots past the batch hold stale values: never used)
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) loc[u][v] = acc[u];
+  }
+  if constexpr (MODE == MPX_MODE_HESS) {
+    double mu[U][NOUT > 0 ? NOUT : 1];
+#pragma unroll
+    for (int r = 0; r < NOUT; ++r) {
+      double acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = 0;
+      for (int t = S.mu_toff[r]; t < S.mu_toff[r + 1]; ++t) {
+        const int ix = S.mu_idx[(int64_t)t * n + p];
+        const double cf = S.mu_coef[(int64_t)t * n + p];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int b = b0 + (u < nu ? u : 0);
+          acc[u] = fma(cf, ix == A.n_g ? A.sigma[b] : A.lam[(int64_t)b * A.lam_stride + ix], acc[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) mu[u][r] = acc[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u >= nu) break;
+      double H[NH > 0 ? NH : 1];
+      F::hes(loc[u], cst, mu[u], H);
+      double* __restrict__ rb = &V[u][0] + S.rawh_off;
+#pragma unroll
+      for (int q = 0; q < NH; ++q) rb[(int64_t)q * n + p] = H[q];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u >= nu) break;
+      double* __restrict__ rb = &V[u][0] + S.raw_off;
+      double out[NOUT > 0 ? NOUT : 1];
+      if constexpr (MODE == MPX_MODE_FGJ) {
+        double J[NJ > 0 ? NJ : 1];
+        F::jac(loc[u], cst, out, J);
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) rb[(int64_t)(NOUT + q) * n + p] = J[q];
+      } else {
+        F::val(loc[u], cst, out);
+      }
+#pragma unroll
+      for (int r = 0; r < NOUT; ++r) rb[(int64_t)r * n + p] = out[r];
+    }
+  }
+}
+
+template <int MODE, int FID, int U, int VN, int RAWN>
+struct FusedDispatch {
+  __device__ static __forceinline__ void run(const MpxPtSet& S, const ::MpxFusedArgs& A, int blk, int lane, double (*V)[VN], int b0, int nu) {
+    if (S.fid == FID)
+      fused_point<FID, MODE, U, VN, RAWN>(S, A, blk, lane, V, b0, nu);
+    else
+      FusedDispatch<MODE, FID - 1, U, VN, RAWN>::run(S, A, blk, lane, V, b0, nu);
+  }
+};
+template <int MODE, int U, int VN, int RAWN>
+struct FusedDispatch<MODE, -1, U, VN, RAWN> {
+  __device__ static __forceinline__ void run(const MpxPtSet&, const ::MpxFusedArgs&, int, int, double (*)[VN], int, int) {}
+};
+
+// MODE_FG / MODE_FGJ: arrays f (1 row), g (NG), grad_f (NZ), jac_val (NNZJ); MODE_HESS: hess_val (NNZH).
+// MT: ELL width of the multi-term rows (rows with 2 .. MT terms); RL x TL: long rows per wavefront x 64-term rounds
+// per long row when their table fits the register budget (RL == 0: read from global memory per chunk).
+template <int MODE, int NF, int NT, int U, int RAWN, int NZ, int N0, int N1, int N2, int N3, int MT, int RM, int RL, int TL>
+__device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
+  constexpr int VN = RAWN + NZ + 1;  // [raw | z | 1.0]
+  __shared__ double V[U][VN];
+  // (the wavefront index through readfirstlane: the compiler then knows that everything derived from it -- the point set of a
+  // task, its table pointers and term counts, the long row of a wavefront -- is uniform: scalar loads and branches, global_load
+  // with a scalar base instead of flat_load with per-lane 64-bit addresses; without it the point phase was 2x slower)
+  const int l = threadIdx.x, lane = l & 63, wave = __builtin_amdgcn_readfirstlane(l >> 6);
+  constexpr int NW = NT / 64;
+  RowRegs<N0, NT> R0;
+  RowRegs<N1, NT> R1;
+  RowRegs<N2, NT> R2;
+  RowRegs<N3, NT> R3;
+  R0.load(A, 0, l);
+  R1.load(A, N0, l);
+  R2.load(A, N0 + N1, l);
+  R3.load(A, N0 + N1 + N2, l);
+  auto out_of = [&](int row, int64_t b) -> double* {
+    int a = 0, loc = row;
+    if (loc >= N0) { loc -= N0, a = 1; if (loc >= N1) { loc -= N1, a = 2; if (loc >= N2) { loc -= N2, a = 3; } } }
+    return A.out[a] ? A.out[a] + b * A.out_stride[a] + loc : nullptr;
+  };
+  // long rows of this wavefront (rows wave, wave + NW, ...): lane j holds terms j, j + 64, ... of each
+  int lidx[RL > 0 ? RL : 1][TL > 0 ? TL : 1];
+  double lcf[RL > 0 ? RL : 1][TL > 0 ? TL : 1];
+  if constexpr (RL > 0) {
+#pragma unroll
+    for (int r = 0; r < RL; ++r) {
+      const int w = wave + r * NW;
+      const int64_t e0 = w < A.n_long ? A.ptr[A.long_rows[w]] : 0, e1 = w < A.n_long ? A.ptr[A.long_rows[w] + 1] : 0;
+#pragma unroll
+      for (int t = 0; t < TL; ++t) {
+        const int64_t e = e0 + lane + 64 * t;
+        lidx[r][t] = e < e1 ? A.idx[e] : -1;
+        lcf[r][t] = e < e1 ? A.coef[e] : 0.0;
+      }
+    }
+  }
+  // the handful of rows with MT + 1 .. MPX_GATHER_LONG terms: wavefront w holds rows w, w + NW, ... (lane t: term t)
+  constexpr int RMID = MPX_FUSE_MID_WAVE ? (16 + NW - 1) / NW : 0;  // (the code generator leaves at most 16 such rows)
+  int qix[RMID > 0 ? RMID : 1], qnt[RMID > 0 ? RMID : 1], qrow[RMID > 0 ? RMID : 1];
+  double qcf[RMID > 0 ? RMID : 1];
+#pragma unroll
+  for (int r = 0; r < RMID; ++r) {
+    const int w = wave + r * NW;
+    qrow[r] = w < A.n_mid ? A.mid_rows[w] : 0;
+    const int64_t e0 = w < A.n_mid ? A.ptr[qrow[r]] : 0;
+    qnt[r] = w < A.n_mid ? (int)(A.ptr[qrow[r] + 1] - e0) : 0;
+    qix[r] = lane < qnt[r] ? A.idx[e0 + lane] : 0;
+    qcf[r] = lane < qnt[r] ? A.coef[e0 + lane] : 0.0;
+  }
+  constexpr int ZR = (U * (NZ + 1) + NT - 1) / NT;  // z staging: elements per lane and chunk
+  double zr[ZR];
+  auto z_load = [&](int c) {  // z of chunk c (and the 1.0 closing every V[u]) into registers
+    const int b0 = c * U, nu = (A.B - b0 < U) ? A.B - b0 : U;
+#pragma unroll
+    for (int q = 0; q < ZR; ++q) {
+      const int e = q * NT + l, u = e / (NZ + 1), i = e - u * (NZ + 1);
+      zr[q] = (u < nu && i < NZ) ? A.z[(int64_t)(b0 + u) * A.z_stride + i] : 1.0;
+    }
+  };
+  const int n_chunks = (A.B + U - 1) / U;
+  if ((int)blockIdx.x < n_chunks) z_load(blockIdx.x);
+  int it_ = 0;
+#define MPX_FUSE_STAMP(k) do { if (A.dbg && blockIdx.x == 1 && l == 0 && it_ == 2) A.dbg[k] = wall_clock64(); } while (0)
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x, ++it_) {
+    const int b0 = c * U, nu = (A.B - b0 < U) ? A.B - b0 : U;
+    MPX_FUSE_STAMP(0);
+#pragma unroll
+    for (int q = 0; q < ZR; ++q) {
+      const int e = q * NT + l, u = e / (NZ + 1), i = e - u * (NZ + 1);
+      if (u < U) V[u][RAWN + i] = zr[q];
+    }
+    __syncthreads();
+    MPX_FUSE_STAMP(1);
+    if (c + (int)gridDim.x < n_chunks) z_load(c + gridDim.x);  // in flight during this chunk's work
+    // ---- point functions: wavefront <-> (64-point block, evaluation point) ----
+#if MPX_FUSE_TASK_PER_U  // wavefront <-> (64-point block, evaluation point): more tasks, fewer live registers
+    for (int w = wave; w < A.n_blocks * nu; w += NW) {
+      const int u = w / A.n_blocks, bx = w - u * A.n_blocks;
+      int k = 0;
+      while (k + 1 < A.n_sets && bx >= A.sets[k + 1].block_first) ++k;
+      const MpxPtSet S = A.sets[k];
+      FusedDispatch<MODE, NF - 1, 1, VN, RAWN>::run(S, A, bx - S.block_first, lane, &V[u], b0 + u, 1);
+    }
+#else
+    for (int bx = wave; bx < A.n_blocks; bx += NW) {  // wavefront <-> 64-point block, all evaluation points of the chunk
+      int k = 0;
+      while (k + 1 < A.n_sets && bx >= A.sets[k + 1].block_first) ++k;
+      const MpxPtSet S = A.sets[k];
+      FusedDispatch<MODE, NF - 1, U, VN, RAWN>::run(S, A, bx - S.block_first, lane, V, b0, nu);
+    }
+#endif
+    // table entries of this lane's multi-term rows: loads issued before the barrier, used after the single-term rows
+    MPX_FUSE_STAMP(2);
+    __syncthreads();
+    MPX_FUSE_STAMP(3);
+#if MPX_FUSE_MULTI_EARLY
+    // table entries of this lane's multi-term rows, requested BEFORE the burst of single-row stores: memory operations of a
+    // wavefront retire in order, loads issued behind the stores would wait for the store queue to drain
+    int eix[RM > 0 ? RM : 1][MT > 0 ? MT : 1], ent[RM > 0 ? RM : 1], erow[RM > 0 ? RM : 1];
+    double ecf[RM > 0 ? RM : 1][MT > 0 ? MT : 1];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int m = r * NT + l, mm = m < A.n_multi ? m : 0;
+      erow[r] = A.multi_rows[mm];
+      ent[r] = m < A.n_multi ? A.r_nt[erow[r]] : 0;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) eix[r][t] = A.m_idx[(int64_t)t * A.n_multi + mm], ecf[r][t] = A.m_coef[(int64_t)t * A.n_multi + mm];
+    }
+#endif
+    // ---- rows with one term: registers -> LDS read -> store ----
+    for (int u = 0; u < nu; ++u) {
+      const double* __restrict__ Vu = V[u];
+      const int64_t b = b0 + u;
+      R0.store(Vu, A.out[0] ? A.out[0] + b * A.out_stride[0] : nullptr, l);
+      R1.store(Vu, A.out[1] ? A.out[1] + b * A.out_stride[1] : nullptr, l);
+      R2.store(Vu, A.out[2] ? A.out[2] + b * A.out_stride[2] : nullptr, l);
+      R3.store(Vu, A.out[3] ? A.out[3] + b * A.out_stride[3] : nullptr, l);
+    }
+    // ---- rows with 2 .. MT terms: one lane per row, ELL table [t][row] (the MT loads of a row are independent), added in stored order ----
+#if MPX_FUSE_MULTI_EARLY
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      if (ent[r] > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (u >= nu) break;
+          double sm = 0;
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+            if (t < ent[r]) sm = fma(ecf[r][t], V[u][eix[r][t]], sm);
+          double* o = out_of(erow[r], b0 + u);
+          if (o) *o = sm;
+        }
+      }
+    }
+    for (int m = A.n_multi; m < A.n_multi; m += NT) {
+#else
+    for (int m = l; m < A.n_multi; m += NT) {
+#endif
+      const int row = A.multi_rows[m], nt = A.r_nt[row];
+      int ix[MT > 0 ? MT : 1];
+      double cf[MT > 0 ? MT : 1];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) ix[t] = A.m_idx[(int64_t)t * A.n_multi + m], cf[t] = A.m_coef[(int64_t)t * A.n_multi + m];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (u >= nu) break;
+        double s = 0;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          if (t < nt) s = fma(cf[t], V[u][ix[t]], s);
+        double* o = out_of(row, b0 + u);
+        if (o) *o = s;
+      }
+    }
+    MPX_FUSE_STAMP(5);
+    // ---- rows with MT + 1 .. MPX_GATHER_LONG terms (a handful): one wavefront per row -- lane t fetches term t, then the terms are
+    // added one after the other in stored order (values passed around by shuffles): the two-pass kernel's sum, without its chain of
+    // dependent loads ----
+    if constexpr (RMID > 0) {
+#pragma unroll
+      for (int r = 0; r < RMID; ++r) {
+        if (qnt[r] > 0) {
+          for (int u = 0; u < nu; ++u) {
+            const double vv = lane < qnt[r] ? V[u][qix[r]] : 0.0;
+            double s = 0;
+            for (int t = 0; t < qnt[r]; ++t) s = fma(__shfl(qcf[r], t, 64), __shfl(vv, t, 64), s);
+            if (lane == 0) {
+              double* op = out_of(qrow[r], b0 + u);
+              if (op) *op = s;
+            }
+          }
+        }
+      }
+    } else {
+      for (int m = l; m < A.n_mid; m += NT) {  // one lane per row, terms from the CSR in stored order
+        const int row = A.mid_rows[m];
+        const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
+        double s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = 0;
+        for (int64_t e = e0; e < e1; ++e) {
+          const int ixe = A.idx[e];
+          const double cfe = A.coef[e];
+#pragma unroll
+          for (int u = 0; u < U; ++u) s[u] = fma(cfe, V[u][ixe], s[u]);  // (slots past the batch: computed, never stored)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (u < nu) {
+            double* o = out_of(row, b0 + u);
+            if (o) *o = s[u];
+          }
+      }
+    }
+    MPX_FUSE_STAMP(6);
+    // ---- long rows: one wavefront per row, lane j sums terms j, j + 64, ... in order, fixed shuffle tree (as mpx_gather_kernel) ----
+    if constexpr (RL > 0) {
+#pragma unroll
+      for (int r = 0; r < RL; ++r) {
+        const int w = wave + r * NW;
+        if (w < A.n_long) {
+          const int row = A.long_rows[w];
+          for (int u = 0; u < nu; ++u) {
+            double s = 0;
+#pragma unroll
+            for (int t = 0; t < TL; ++t)
+              if (lidx[r][t] >= 0) s = fma(lcf[r][t], V[u][lidx[r][t]], s);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+            if (lane == 0) {
+              double* op = out_of(row, b0 + u);
+              if (op) *op = s;
+            }
+          }
+        }
+      }
+    } else {
+      for (int w = wave; w < A.n_long * nu; w += NW) {
+        const int u = w / A.n_long, row = A.long_rows[w - u * A.n_long];
+        const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
+        double s = 0;
+        for (int64_t e = e0 + lane; e < e1; e += 64) s = fma(A.coef[e], V[u][A.idx[e]], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) {
+          double* op = out_of(row, b0 + u);
+          if (op) *op = s;
+        }
+      }
+    }
+    MPX_FUSE_STAMP(7);
+    __syncthreads();  // V is rewritten by the next chunk
+    MPX_FUSE_STAMP(8);
+  }
+#undef MPX_FUSE_STAMP
+}
+
+}  // namespace mpxk
+
+// LDS budget: U evaluation points of [raw | z | 1] must fit 60 KB (a launch gets 64 KB without raising the function's limit);
+// register budget: a lane keeps 3 dwords per row it owns, at most MPX_FUSE_MAX_ROWS_PER_LANE rows (else the kernel is not built
+// and the host keeps the two-pass path for this problem).
+#ifndef MPX_FUSE_MIN_WAVES  // wavefronts per SIMD the register allocation must allow (these kernels live on occupancy)
+#define MPX_FUSE_MIN_WAVES 4
+#endif
+#ifndef MPX_FUSE_LDS_BYTES
+#define MPX_FUSE_LDS_BYTES 61440
+#endif
+#ifndef MPX_FUSE_MAX_U
+#define MPX_FUSE_MAX_U 2
+#endif
+#ifndef MPX_FUSE_MAX_ROWS_PER_LANE
+#define MPX_FUSE_MAX_ROWS_PER_LANE 48
+#endif
+#define MPX_FUSE_CEIL(n) (((n) + MPX_FUSE_NT - 1) / MPX_FUSE_NT)
+#define MPX_FUSE_U_FOR(RAWN, ROWS) ((ROWS) > MPX_FUSE_MAX_ROWS_PER_LANE ? 0 : ((int)(MPX_FUSE_LDS_BYTES / (8 * ((RAWN) + MPX_FUSE_NZ + 1))) > MPX_FUSE_MAX_U ? MPX_FUSE_MAX_U : (int)(MPX_FUSE_LDS_BYTES / (8 * ((RAWN) + MPX_FUSE_NZ + 1)))))
+#ifndef MPX_FUSE_U_FGJ
+#define MPX_FUSE_U_FGJ MPX_FUSE_U_FOR(MPX_FUSE_RAW_N, 1 + MPX_FUSE_CEIL(MPX_FUSE_NG) + MPX_FUSE_CEIL(MPX_FUSE_NZ) + MPX_FUSE_CEIL(MPX_FUSE_NNZJ))
+#endif
+#ifndef MPX_FUSE_U_HES
+#define MPX_FUSE_U_HES MPX_FUSE_U_FOR(MPX_FUSE_RAWH_N, MPX_FUSE_CEIL(MPX_FUSE_NNZH))
+#endif
+
+// Long-row tables in registers when a wavefront's share is at most 16 (position, coefficient) pairs per lane.
+#define MPX_FUSE_RL(NLONG) (((NLONG) + MPX_FUSE_NT / 64 - 1) / (MPX_FUSE_NT / 64))
+#define MPX_FUSE_TL(LT) (((LT) + 63) / 64)
+#ifndef MPX_FUSE_LONG_REGS
+#define MPX_FUSE_LONG_REGS 0
+#endif
+#define MPX_FUSE_RL_OK(NLONG, LT) ((NLONG) > 0 && MPX_FUSE_RL(NLONG) * MPX_FUSE_TL(LT) <= MPX_FUSE_LONG_REGS ? MPX_FUSE_RL(NLONG) : 0)
+
+// mpx_fuse_info = {lanes per workgroup, U of the first-order kernels, U of the Hessian kernel, ELL width of the multi-term rows
+// of the first-order pass, of the Hessian pass} (U == 0: that kernel does not exist: one evaluation point does not fit the
+// budgets); the host reads it from the code object.
+#define MPX_INSTANTIATE_FUSED(NF)                                                                                              \
+  extern "C" __device__ __attribute__((used)) const int mpx_fuse_info[5] = {MPX_FUSE_NT, MPX_FUSE_U_FGJ, MPX_FUSE_U_HES,       \
+                                                                              MPX_FUSE_MT_FGJ, MPX_FUSE_MT_HES};               \
+  extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_fg(const MpxFusedArgs A) {                                \
+    if constexpr (MPX_FUSE_U_FGJ > 0)                                                                                          \
+      mpxk::fused_body<MPX_MODE_FG, NF, MPX_FUSE_NT, (MPX_FUSE_U_FGJ > 0 ? MPX_FUSE_U_FGJ : 1), MPX_FUSE_RAW_N, MPX_FUSE_NZ, 1, \
+                       MPX_FUSE_NG, MPX_FUSE_NZ, MPX_FUSE_NNZJ, MPX_FUSE_MT_FGJ, MPX_FUSE_CEIL(MPX_FUSE_NMULTI_FGJ), MPX_FUSE_RL_OK(MPX_FUSE_NLONG_FGJ, MPX_FUSE_LT_FGJ), \
+                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ)>(A);                                                                       \
+  }                                                                                                                            \
+  extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_fgj(const MpxFusedArgs A) {                               \
+    if constexpr (MPX_FUSE_U_FGJ > 0)                                                                                          \
+      mpxk::fused_body<MPX_MODE_FGJ, NF, MPX_FUSE_NT, (MPX_FUSE_U_FGJ > 0 ? MPX_FUSE_U_FGJ : 1), MPX_FUSE_RAW_N, MPX_FUSE_NZ, 1, \
+                       MPX_FUSE_NG, MPX_FUSE_NZ, MPX_FUSE_NNZJ, MPX_FUSE_MT_FGJ, MPX_FUSE_CEIL(MPX_FUSE_NMULTI_FGJ), MPX_FUSE_RL_OK(MPX_FUSE_NLONG_FGJ, MPX_FUSE_LT_FGJ), \
+                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ)>(A);                                                                       \
+  }                                                                                                                            \
+  extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_hes(const MpxFusedArgs A) {                               \
+    if constexpr (MPX_FUSE_U_HES > 0)                                                                                          \
+      mpxk::fused_body<MPX_MODE_HESS, NF, MPX_FUSE_NT, (MPX_FUSE_U_HES > 0 ? MPX_FUSE_U_HES : 1), MPX_FUSE_RAWH_N, MPX_FUSE_NZ, \
+                       MPX_FUSE_NNZH, 0, 0, 0, MPX_FUSE_MT_HES, MPX_FUSE_CEIL(MPX_FUSE_NMULTI_HES), MPX_FUSE_RL_OK(MPX_FUSE_NLONG_HES, MPX_FUSE_LT_HES),          \
+                       MPX_FUSE_TL(MPX_FUSE_LT_HES)>(A);                                                                       \
+  }

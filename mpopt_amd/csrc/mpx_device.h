@@ -191,4 +191,32 @@ struct MpxGatherArgs {
   int64_t seg_stride[4];
   int32_t n_seg, B, b_per_block;
 };
+// Arguments of the fused kernels of assembled contexts (mpx_assembly_fused.h; device arrays are built once per context by
+// mpx_assembly.cpp).
+struct MpxFusedArgs {
+  const MpxPtSet* sets;
+  int32_t n_sets, n_blocks;  // 64-point blocks over all sets (MpxPtSet::block_first)
+  int32_t n_g, B;
+  const double* z;
+  int64_t z_stride;
+  const double* lam;
+  int64_t lam_stride;
+  const double* sigma;
+  // rows of this pass, all output arrays concatenated (f | g | grad_f | jac_val, or hess_val)
+  const int32_t* r_idx;   // position in V of the first term (the 1.0 slot for rows without terms)
+  const double* r_coef;   // its coefficient (0 for rows without terms)
+  const int32_t* r_nt;    // number of terms
+  const int64_t* ptr;     // CSR of all terms, positions in V
+  const int32_t* idx;
+  const double* coef;
+  const int32_t* multi_rows;  // rows with 2 .. MT terms (MT = ELL width of the pass, <= 8): m_idx / m_coef [t][n_multi], padded
+  const int32_t* m_idx;
+  const double* m_coef;
+  const int32_t* mid_rows;    // rows with MT + 1 .. MPX_GATHER_LONG terms
+  const int32_t* long_rows;   // rows with more
+  int32_t n_multi, n_mid, n_long, pad_;
+  double* out[4];
+  int64_t out_stride[4];
+  long long* dbg;  // MPX_FUSE_DEBUG: phase stamps of one workgroup (wall_clock64, 100 MHz), else NULL
+};
 #endif

@@ -214,7 +214,7 @@ def test_adaptive_device_pointer_api_matches_host_api():
         o.set_tile_range(0, 0)
 
 
-@pytest.mark.parametrize("pass_mb", [None, "40"])
+@pytest.mark.parametrize("pass_mb", [None, "40", "fused"])
 def test_adaptive_large_batch_equals_single_evaluations_bitwise(pass_mb, monkeypatch):
     """(pass_mb: batches larger than the Infinity Cache are evaluated in several passes over one raw buffer -- here forced to 40 MB,
     i.e. eight passes with a ragged last one.)  Past 4096 workgroups the generated point kernels take several evaluation points per lane (MPX_PTS_UNROLL, read by the
@@ -227,8 +227,12 @@ def test_adaptive_large_batch_equals_single_evaluations_bitwise(pass_mb, monkeyp
     mpo = mp.mpopt_adaptive(ocp, 20, 5, "LGR")
     o = mpo.create_nlp()[0]["oracle"]
     assert "#define MPX_PTS_UNROLL 4" in o.source  # small point functions: four points per lane
-    if pass_mb:
-        monkeypatch.setenv("MPX_ASM_PASS_MB", pass_mb)
+    if pass_mb == "fused":  # the batch goes through the fused persistent kernels (mpx_assembly_fused.h), single evaluations through the two-pass ones
+        assert "MPX_INSTANTIATE_FUSED" in o.source
+    else:
+        monkeypatch.setenv("MPX_NO_FUSE", "1")
+        if pass_mb:
+            monkeypatch.setenv("MPX_ASM_PASS_MB", pass_mb)
     rng = np.random.default_rng(11)
     B = 3500 + 3
     Z = mpo.initialize_solution()[None, :] * (1 + 0.05 * rng.uniform(-1, 1, (B, o.n_z)))
@@ -253,3 +257,53 @@ def test_adaptive_large_batch_equals_single_evaluations_bitwise(pass_mb, monkeyp
     J = np.zeros((o.n_g, o.n_z))
     J[o.jac_pattern()] = got["jac_g"][B - 1]
     assert rel_err(J, O.jac_g(Z[B - 1]).toarray()) < TOL
+
+
+FUSED_CASES = {
+    "moon_lander_20x5": (problems.moon_lander, 20, 5, "LGR"),
+    "van_der_pol_mixed": (problems.van_der_pol, 9, [2, 4, 3] * 3, "CGL"),
+    "hyper_sensitive_40x4": (problems.hyper_sensitive, 40, 4, "LGL"),
+    "generic_two_phase": (problems.generic_two_phase, 4, [2, 3, 3, 2], "LGR"),
+    "kitchen_sink_6x4": (problems.kitchen_sink, 6, 4, "LGR"),          # two phases, parameters, explicit time dependence
+    "time_dependent_5x3": (problems.time_dependent, 5, 3, "LGR"),
+}
+
+
+@pytest.mark.parametrize("name", list(FUSED_CASES))
+def test_fused_kernels_equal_the_two_pass_kernels_bitwise(name, monkeypatch):
+    """Round 3: batches of an assembled context run through one fused persistent kernel per pass (raw point values in LDS, a
+    lane's rows in registers) instead of point kernels -> raw buffer -> gather kernel.  Same sums in the same order: every output
+    of every mask, for a batch that is not a multiple of the evaluation points a workgroup takes per pass, equals the two-pass
+    result bit for bit (MPX_NO_FUSE=1 selects the latter)."""
+    import torch
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_HESS, MPX_JAC
+
+    builder, S, po, scheme = FUSED_CASES[name]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt_adaptive(ocp, S, po, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    rng = np.random.default_rng(21)
+    B = 301
+    dev = torch.device("cuda", 0)
+    Z = torch.tensor(mpo.initialize_solution()[None, :] * (1 + 0.05 * rng.uniform(-1, 1, (B, o.n_z))) + 0.02 * rng.uniform(-1, 1, (B, o.n_z)), device=dev)
+    lam, sig = torch.tensor(rng.standard_normal((B, o.n_g)), device=dev), torch.tensor(rng.uniform(0.5, 1.5, B), device=dev)
+
+    def run(mask):
+        mk = lambda *s_: torch.full(s_, float("nan"), dtype=torch.float64, device=dev)
+        bufs = (mk(B), mk(B, o.n_g), mk(B, o.n_z), mk(B, o.nnz_jac), mk(B, o.nnz_hess))
+        o.eval_device(mask, B, Z, None, 0, lam, sig, *bufs)
+        o.sync()
+        return bufs
+
+    n_fused = 0
+    for mask in (MPX_F | MPX_G | MPX_GRAD | MPX_JAC, MPX_F | MPX_G, MPX_JAC, MPX_GRAD, MPX_HESS, MPX_F | MPX_G | MPX_GRAD | MPX_JAC | MPX_HESS):
+        monkeypatch.setenv("MPX_NO_FUSE", "1")
+        ref = run(mask)
+        monkeypatch.delenv("MPX_NO_FUSE")
+        got = run(mask)
+        for k, (a, b) in enumerate(zip(ref, got)):
+            same = torch.equal(a, b) or (bool(torch.isnan(a).all()) and bool(torch.isnan(b).all()))
+            assert same, (name, mask, k, float((a - b).abs().nan_to_num(0).max()))
+        n_fused += 1
+    assert n_fused == 6
+    o.close()
