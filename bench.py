@@ -370,14 +370,21 @@ def main():
         p0 = torch.tensor(np.random.default_rng(20260928 + rank).dirichlet(np.ones(S), B), device=dev)
         pa, pb = torch.empty_like(p0), torch.empty_like(p0)
         R = torch.empty(B, plan.n_pts, ocp.nx, dtype=torch.float64, device=dev)
+        o.set_mid_resid_output(R)
+        unfused_loop = bool(os.environ.get("MPX_BENCH_UNFUSED_LOOP"))
 
     def step():
         if loop5:
             pa.copy_(p0)
             cur, nxt = pa, pb
-            for _ in range(5):
-                plan.eval_device(B, Z, cur, p_per_point=1, resid=R)
-                o.eval_device(mask | 256, B, Z, cur, 1, lam, sig, None, None, None, None, hv)  # MPX_WIDTHS_UNCHANGED: same p as the residual call
+            for it5 in range(5):
+                if unfused_loop:  # round-2 form: residual plan, then hess_l with MPX_WIDTHS_UNCHANGED (same p as the residual call)
+                    plan.eval_device(B, Z, cur, p_per_point=1, resid=R)
+                    o.eval_device(mask | 256, B, Z, cur, 1, lam, sig, None, None, None, None, hv)
+                else:  # MPX_MID_RESID: the hess_l pass writes the mid-point residuals itself (one pass over z)
+                    # (from the second iteration on the widths are the previous equal-area update's output, which left their prefix
+                    # sums on the device: MPX_WIDTHS_UNCHANGED = 256, no prefix launch)
+                    o.eval_device(mask | 1024 | (256 if it5 else 0), B, Z, cur, 1, lam, sig, None, None, None, None, hv)
                 o.equal_area_widths_device(0, B, plan.n_pts, R, cur, nxt, damping=0.4, p_in_per_point=1)
                 cur, nxt = nxt, cur
         elif shard:
@@ -490,7 +497,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS if not (shard and world > 1) else None, "traffic": None,
                          "frac_vs_measured_peak": achieved / HBM_MEASURED_GBS if not (shard and world > 1) else None,
                          "measured_peak": HBM_MEASURED_GBS,
-                         "kernel": ("whole loop: mpx_resid_0_3 + mpx_node_hess_0_3 + mpx_boundary_hess + mpx_equal_area_kernel (wall time of the step)" if loop5
+                         "kernel": ("whole loop: mpx_node_hess_0_3 (with the mid-point residuals, MPX_MID_RESID) + mpx_boundary_hess + mpx_equal_area_kernel (wall time of the step)" if loop5
                                     else "mpx_pts_jac + mpx_gather_kernel" if adaptive else f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*"),
                          "kernel_us": kernel_s * 1e6,
                          "bytes_per_eval": bytes_eval, "evals_per_launch": B,

@@ -74,6 +74,11 @@ extern "C" {
 #define MPX_WIDTHS_UNCHANGED 256 /* mpx_eval_device only: `p`, p_per_point and batch are those of the previous device-pointer call
                                     of this context (mpx_eval_device or mpx_resid_eval_device) and the memory behind `p` has not
                                     changed since: the prefix sums kept on the device are reused.  The caller's assertion. */
+#define MPX_MID_RESID 1024 /* mpx_eval_device, with MPX_HESS: the node kernels of the hess_l pass also evaluate the dynamics residuals
+                              D_mid.X - h_s Sx dyn(I_mid.X, I_mid.U, t_mid, a) at the mid-points between consecutive nodes of every
+                              segment -- what mpx_resid_eval_device(resid) gives for the plan whose targets are those mid-points
+                              (the samples the h-adaptive loop refines on, mpopt.py:2620-2633) -- into the array registered
+                              with mpx_set_mid_resid_output: one pass over z instead of two.  Degrees <= 12. */
 #define MPX_BOUNDARY_ONLY 32 /* skip the node kernels: finish reductions / terminal / linking rows only
                                 (second half of a segment-sharded evaluation, see mpx_set_tile_range) */
 #define MPX_OWNER_RESIDENT 512 /* segment-sharded contexts only (mpx_shard_setup, world > 1): the owner-resident protocol --
@@ -290,6 +295,10 @@ int mpx_resid_eval(mpx_ctx* ctx, mpx_resid_plan* plan, int64_t batch, const doub
 int mpx_resid_eval_device(mpx_ctx* ctx, mpx_resid_plan* plan, int64_t batch, const double* z, const double* p,
                           int p_per_point, double* ti, double* xi, double* ui, double* dxi, double* dui, double* dyn,
                           double* resid);
+
+/* Output of the MPX_MID_RESID passes: device array [batch][n_phases * (N - 1)][nx]; row ph * (N - 1) + i - 1 = the mid-point
+ * between nodes i - 1 and i of phase ph (segment order, the order of a residual plan over the mid-points).  NULL switches off. */
+int mpx_set_mid_resid_output(mpx_ctx* ctx, double* resid);
 
 /* Width update of the h-adaptive refinement loop on the device, batched: the equal-area rule
  * mpopt_h_adaptive.get_roots_wrt_equal_area (mpopt.py:2636-2659) applied to r_i = || resid[b][i][0..nx) ||_2, i < n_pts (the

@@ -29,6 +29,7 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS, MPX_BOUNDARY_ONLY, MPX_JAC_VARIABLE_ONLY, MPX_CCS_ORDER = 1, 2, 4, 8, 16, 32, 64, 128
 MPX_WIDTHS_UNCHANGED = 256
 MPX_OWNER_RESIDENT = 512
+MPX_MID_RESID = 1024
 SCHEMES = {"LGR": 0, "LGL": 1, "CGL": 2, "LG": 3}
 SCHEME_EQUI = 4
 
@@ -164,6 +165,7 @@ SYMBOLS = {
     "mpx_get_comp_weights": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "mpx_geometry_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "mpx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mpx_set_mid_resid_output": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mpx_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mpx_eval_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mpx_sync": (ctypes.c_int, [ctypes.c_void_p]),

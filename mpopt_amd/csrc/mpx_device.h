@@ -52,6 +52,9 @@ struct MpxIO {
   // 4x the cost per byte on config 3).  Non-NULL: node kernels write [tile][slot][lane] here (coalesced) and
   // mpx_unpack_kernel moves the values to their rows with fully coalesced stores.
   double* gtmp;         int64_t gtmp_stride;
+  // MPX_MID_RESID (with the hess_l pass): dynamics residuals at the mid-points between consecutive nodes of every segment,
+  // [B][n_phases * (N - 1)][nx]; the row of the mid-point between nodes i - 1 and i of phase ph is ph * (N - 1) + i - 1.  NULL: off.
+  double* mid_resid;    int64_t mid_stride;
 };
 
 // Node kernels: one launch per (phase, degree) bucket.
@@ -63,6 +66,9 @@ struct MpxNodeArgs {
   const double* Dmat;      // (P+1)x(P+1) row-major first-derivative matrix of this degree
   const double* Cmid;      // P x (P+1) interpolation to the mid-points between consecutive nodes
   const double* tk;        // (tau_k - tau0)/(tau1 - tau0), k = 0..P
+  const double* Dmid;      // P x (P+1): first derivative of the Lagrange basis at the mid-points (MPX_MID_RESID)
+  const double* tkm;       // ((tau_{k-1} + tau_k)/2 - tau0)/(tau1 - tau0), k = 1..P at index k - 1
+  int32_t phase, pad3_;
   const double* Wnode;     // composite quadrature weight per node of this phase
   double inv_dtau;         // 1/(tau1 - tau0)
   int64_t z_off;           // offset of the phase's block in z / grad_f

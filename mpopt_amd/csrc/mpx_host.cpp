@@ -138,6 +138,12 @@ int build_tables(mpx_ctx* c) {
     mpx_colloc_interp_matrix(t.roots.data(), n, mids.data(), d, t.Cmid.data());
     t.tk.resize(n);
     for (int k = 0; k < n; ++k) t.tk[k] = (t.roots[k] - c->tau0) / (c->tau1 - c->tau0);
+    // derivative rows and normalised positions of the same mid-points (residuals fused into the hess_l pass, MPX_MID_RESID;
+    // what mpx_resid_plan_create computes for the target points (tau_{k-1} + tau_k) / 2, mpopt.py:1428-1543)
+    t.Dmid.resize((size_t)d * n);
+    mpx_colloc_diff_matrix(t.roots.data(), n, mids.data(), d, 1, t.Dmid.data());
+    t.tkm.resize(d);
+    for (int k = 0; k < d; ++k) t.tkm[k] = (mids[k] - c->tau0) / (c->tau1 - c->tau0);
     c->degs.push_back(std::move(t));
   }
   return MPX_OK;
@@ -549,6 +555,7 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     if ((rc = upload(c, &t.d_D, t.D))) return rc;
     if ((rc = upload(c, &t.d_Cmid, t.Cmid))) return rc;
     if ((rc = upload(c, &t.d_tk, t.tk))) return rc;
+    if ((rc = upload(c, &t.d_Dmid, t.Dmid)) || (rc = upload(c, &t.d_tkm, t.tkm))) return rc;
   }
   for (auto& B : c->buckets) {
     if ((rc = upload(c, &B.d_node_i, B.node_i))) return rc;
@@ -573,31 +580,35 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
 }
 
 // exclusive prefix sums of the segment widths (the reference's running t_seg0, mpopt.py:192): one workgroup per
-// (width vector, phase).  Each of the four wavefronts owns a contiguous quarter and walks it 64 elements at a time with
+// (width vector, phase).  Each of the sixteen wavefronts owns a contiguous share and walks it 64 elements at a time with
 // coalesced loads: first the quarter totals (so that every wavefront knows its starting offset), then the scan proper --
 // shuffle scan inside the 64 elements, running carry across them.  Fixed order: results do not depend on anything else.
-__global__ __launch_bounds__(256) void mpx_prefix_kernel(const double* __restrict__ w, double* __restrict__ wcum, int S) {
-  __shared__ double wave_tot[4];
-  const double* __restrict__ a = w + (int64_t)blockIdx.x * S;
-  double* __restrict__ o = wcum + (int64_t)blockIdx.x * S;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int quarter = ((S + 3) / 4 + 63) / 64 * 64;  // multiple of 64: every step of a wavefront is one aligned run
-  const int q0 = wave * quarter, q1 = min(S, q0 + quarter);
+// (the scan itself is a device function: mpx_equal_area_kernel runs it on the widths it has just produced, with the same
+// additions in the same order, so that the prefix sums it leaves behind are the ones this kernel would compute)
+#define MPX_PREFIX_THREADS 1024
+template <class Load>  // a(s): the s-th width (global memory in mpx_prefix_kernel, LDS in mpx_equal_area_kernel)
+__device__ __forceinline__ void prefix_scan_block(Load a, double* __restrict__ o, int S, int tid, double* wave_tot) {
+  constexpr int NWV = MPX_PREFIX_THREADS / 64;
+  const bool active = true;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int quarter = ((S + NWV - 1) / NWV + 63) / 64 * 64;  // a wavefront's share: a multiple of 64, every step is one aligned run
+  const int q0 = wave * quarter, q1 = active ? min(S, q0 + quarter) : 0;
   double tot = 0;
   for (int s0 = q0 + lane; s0 < q1; s0 += 64 * 8) {  // eight loads in flight, added in index order
     double v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = s0 + k * 64 < q1 ? a[s0 + k * 64] : 0.0;
+    for (int k = 0; k < 8; ++k) v[k] = s0 + k * 64 < q1 ? a(s0 + k * 64) : 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       if (s0 + k * 64 < q1) tot += v[k];
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d, 64);
-  if (lane == 0) wave_tot[wave] = tot;
+  if (active && lane == 0) wave_tot[wave] = tot;
   __syncthreads();
   double carry = 0;
-  for (int q = 0; q < wave; ++q) carry += wave_tot[q];
+  if (active)
+    for (int q = 0; q < wave; ++q) carry += wave_tot[q];
   // eight 64-element steps at a time: their loads are in flight together, the scan itself (same additions, same order as one
   // step at a time) runs on registers
   for (int s0 = q0; s0 < q1; s0 += 64 * 8) {
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(256) void mpx_prefix_kernel(const double* __restric
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int s = s0 + k * 64 + lane;
-      v[k] = s < q1 ? a[s] : 0.0;
+      v[k] = s < q1 ? a(s) : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -620,6 +631,12 @@ __global__ __launch_bounds__(256) void mpx_prefix_kernel(const double* __restric
       carry += __shfl(inc, 63, 64);
     }
   }
+}
+
+__global__ __launch_bounds__(MPX_PREFIX_THREADS) void mpx_prefix_kernel(const double* __restrict__ w, double* __restrict__ wcum, int S) {
+  __shared__ double wave_tot[MPX_PREFIX_THREADS / 64];
+  const double* __restrict__ a = w + (int64_t)blockIdx.x * S;
+  prefix_scan_block([&](int s) { return a[s]; }, wcum + (int64_t)blockIdx.x * S, S, threadIdx.x, wave_tot);
 }
 
 int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size_t size, unsigned lds_bytes = 0) {
@@ -776,6 +793,9 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
     A.Dmat = t.d_D;
     A.Cmid = t.d_Cmid;
     A.tk = t.d_tk;
+    A.Dmid = t.d_Dmid;
+    A.tkm = t.d_tkm;
+    A.phase = B.phase;
     A.Wnode = c->d_Wnode;
     A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
     A.z_off = P.z_off;
@@ -916,7 +936,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     auto fr = [](void* p) {
       if (p) (void)hipFree(p);
     };
-    for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk);
+    for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk), fr(t.d_Dmid), fr(t.d_tkm);
     for (auto& B : c->buckets) fr(B.d_node_i), fr(B.d_node_sk);
     fr(c->d_tiles), fr(c->d_Wnode), fr(c->d_seg_start), fr(c->d_lin_ptr), fr(c->d_lin_idx), fr(c->d_lin_row), fr(c->d_lin_coef);
     fr(c->d_mg_dst), fr(c->d_hc_dst), fr(c->d_th_dst);
@@ -989,6 +1009,13 @@ extern "C" int mpx_get_comp_weights(const mpx_ctx* c, double* w) {
 extern "C" int mpx_geometry_reset(mpx_ctx* c) {
   if (!c) return MPX_ERR_INVALID;
   for (auto& t : c->tune) t.stage = 0, t.uses = 0;
+  return MPX_OK;
+}
+
+extern "C" int mpx_set_mid_resid_output(mpx_ctx* c, double* resid) {
+  if (!c) return MPX_ERR_INVALID;
+  if (c->kind != 0) return fail(c, MPX_ERR_UNSUPPORTED, "assembled contexts have no mid-point residual pass");
+  c->mid_resid_out = resid;
   return MPX_OK;
 }
 
@@ -1266,7 +1293,7 @@ extern "C" int mpx_resid_eval_device(mpx_ctx* c, mpx_resid_plan* P, int64_t batc
   int rc;
   if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
   c->wcum_valid = false;
-  hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(256), 0, c->stream, p, c->wcum.p, c->S);
+  hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(MPX_PREFIX_THREADS), 0, c->stream, p, c->wcum.p, c->S);
   HIPCHK(c, hipGetLastError());
   const PhaseStruct& Ph = c->ph[P->phase];
   for (auto& B : P->buckets) {
@@ -1544,104 +1571,161 @@ namespace {
 // (1024 lanes per workgroup: the cumulative areas of one evaluation point fill most of a compute unit's LDS, so a workgroup is
 // alone on its CU and its own 16 wavefronts are all there is to hide load and LDS latency: 4 wavefronts measured 2.3x slower)
 #define MPX_EA_THREADS 1024
+#define MPX_EA_PF 12  // residual samples a lane can prefetch for the next evaluation point (n <= 12 * 1024)
+// Round 3: (i) workgroups are persistent (one per compute unit; the cumulative areas of one evaluation point fill most of its LDS)
+// and, for scalar residuals, fetch the NEXT point's samples into registers before they scan and search the current one -- the
+// load phase (9.6 of 24 us per point, profiles/r3_config5_loop) disappears behind the search; (ii) the exclusive prefix sums of
+// the new widths -- what mpx_prefix_kernel would compute from p_out, same additions in the same order (prefix_scan_256) -- are
+// left in `wcum` when the caller passes it, so that the next evaluation needs no prefix launch (MPX_WIDTHS_UNCHANGED).
+// FAST: scalar residuals, cumulative areas in LDS, next point prefetched, prefix sums of the new widths emitted -- the config-5
+// protocol; the generic instantiation keeps every other case (vector residuals, long sample lists in HBM scratch) and emits none.
+template <bool FAST>
 __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const double* __restrict__ resid, int64_t n, int nx, const double* __restrict__ p_in,
                                                              double* __restrict__ p_out, int64_t p_stride_in, int64_t p_stride_out, int S, int seg_off,
-                                                             double damping, double* __restrict__ cum_all, int cum_in_lds, long long* dbg) {
-#define MPX_EA_STAMP(k) if (dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) dbg[k] = wall_clock64()
-  extern __shared__ double s_dyn[];
-  MPX_EA_STAMP(0);  // cum_in_lds: [n] cumulative areas, then [S + 1] boundaries; else only the boundaries
+                                                             double damping, double* __restrict__ cum_all, int cum_in_lds, double* __restrict__ wcum,
+                                                             int64_t wcum_stride, int B, long long* dbg) {
+#define MPX_EA_STAMP(k) if (dbg && threadIdx.x == 0 && b == (int)gridDim.x * ((B - 1) / (int)gridDim.x > 0 ? 1 : 0) + 0 && blockIdx.x == 0) dbg[k] = wall_clock64()
+  extern __shared__ double s_dyn[];  // cum_in_lds: [n] cumulative areas, then [S + 1] boundaries; else only the boundaries
   constexpr int NT = MPX_EA_THREADS;
   __shared__ double wave_tot[NT / 64];
   __shared__ double total;
+  __shared__ double pre_tot[MPX_PREFIX_THREADS / 64];
   const int l = threadIdx.x;
-  const double* __restrict__ r = resid + (int64_t)blockIdx.x * n * nx;
-  double* __restrict__ cum = cum_in_lds ? s_dyn : cum_all + (int64_t)blockIdx.x * n;  // cum[i] = area of the first i trapezoids
-  double* __restrict__ pos = cum_in_lds ? s_dyn + n : s_dyn;
-  auto norm2 = [&](int64_t i) {
-    if (nx == 1) return fabs(r[i]);
-    double q = 0;
-    for (int a = 0; a < nx; ++a) q = fma(r[i * nx + a], r[i * nx + a], q);
-    return sqrt(q);
-  };
+  const int64_t pos_off = cum_in_lds ? n : 0;
+  double* __restrict__ pos = s_dyn + pos_off;
   const int64_t m = n - 1, chunk = (m + NT - 1) / NT;  // m trapezoids; lane l owns the trapezoids [i0, i1)
   const int64_t i0 = l * chunk < m ? l * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
-  if (cum_in_lds) {  // the residual norms enter LDS with coalesced loads; the scan below turns them into cumulative areas in place
-    // (one workgroup per compute unit at this LDS footprint: nothing else hides the load latency, so eight loads are in flight per lane)
-    for (int64_t i = l; i < n; i += 8 * NT) {
-      double v[8];
+  constexpr bool prefetch = FAST;  // (host side: cum_in_lds && nx == 1 && n <= MPX_EA_PF * NT && S <= WR * NT && single phase)
+  if constexpr (FAST) cum_in_lds = 1, nx = 1;
+  double pf[FAST ? MPX_EA_PF : 1];
+  auto fetch = [&](int b) {  // |r_i| of the lane's samples l, l + NT, ... of evaluation point b
+    if constexpr (FAST) {
+      const double* __restrict__ r = resid + (int64_t)b * n;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = i + k * NT < n ? norm2(i + k * NT) : 0.0;
+      for (int k = 0; k < MPX_EA_PF; ++k) pf[k] = (int64_t)k * NT + l < n ? r[(int64_t)k * NT + l] : 0.0;
+    }
+  };
+  if (prefetch && (int)blockIdx.x < B) fetch(blockIdx.x);
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    MPX_EA_STAMP(0);
+    const double* __restrict__ r = resid + (int64_t)b * n * nx;
+    double* __restrict__ cum = cum_in_lds ? s_dyn : cum_all + (int64_t)b * n;  // cum[i] = area of the first i trapezoids
+    auto norm2 = [&](int64_t i) {
+      if (nx == 1) return fabs(r[i]);
+      double q = 0;
+      for (int a = 0; a < nx; ++a) q = fma(r[i * nx + a], r[i * nx + a], q);
+      return sqrt(q);
+    };
+    if constexpr (FAST) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (i + k * NT < n) cum[i + k * NT] = v[k];
+      for (int k = 0; k < MPX_EA_PF; ++k)
+        if ((int64_t)k * NT + l < n) cum[(int64_t)k * NT + l] = fabs(pf[k]);
+      __syncthreads();
+      if (b + (int)gridDim.x < B) fetch(b + gridDim.x);  // in flight during the scan and the search of this point
+    } else if (cum_in_lds) {  // the residual norms enter LDS with coalesced loads; the scan below turns them into cumulative areas in place
+      for (int64_t i = l; i < n; i += 8 * NT) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = i + k * NT < n ? norm2(i + k * NT) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (i + k * NT < n) cum[i + k * NT] = v[k];
+      }
+      __syncthreads();
+    }
+    MPX_EA_STAMP(1);
+    constexpr int WR = 4;  // S <= 4 * NT with the prefix sums (else the caller gets none: host side)
+    double pin[WR];        // the lane's old widths: requested now, used after the search
+    if constexpr (FAST) {
+      const double* __restrict__ pi_ = p_in + (int64_t)b * p_stride_in + seg_off;
+#pragma unroll
+      for (int k = 0; k < WR; ++k) pin[k] = l + k * NT < S ? pi_[l + k * NT] : 0.0;
+    }
+    auto sample = [&](int64_t i) { return cum_in_lds ? cum[i] : norm2(i); };
+    const double first = i0 < i1 ? sample(i0) : 0.0;  // (read before the in-place pass of the neighbouring lane overwrites it)
+    double tot = 0, prev = first;
+    for (int64_t i = i0; i < i1; ++i) {
+      const double nxt = sample(i + 1);
+      tot += 0.5 * (prev + nxt);
+      prev = nxt;
+    }
+    double inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      double v = __shfl_up(inc, d, 64);
+      if ((l & 63) >= d) inc += v;
+    }
+    if ((l & 63) == 63) wave_tot[l >> 6] = inc;
+    __syncthreads();
+    double off = __shfl_up(inc, 1, 64);
+    if ((l & 63) == 0) off = 0;
+    for (int q = 0; q < (l >> 6); ++q) off += wave_tot[q];
+    if (l == NT - 1) total = off + tot;
+    __syncthreads();
+    MPX_EA_STAMP(2);
+    const double inv = 1.0 / total;
+    if (l == 0) cum[0] = 0.0;  // (lane 0 holds sample 0 in `first`)
+    prev = first;
+    for (int64_t i = i0; i < i1; ++i) {
+      const double nxt = sample(i + 1);  // position i + 1 is overwritten two lines down, by this lane only
+      off += 0.5 * (prev + nxt);
+      prev = nxt;
+      cum[i + 1] = i + 1 == m ? 1.0 : off * inv;  // (the reference divides by the last entry: exactly 1 there)
     }
     __syncthreads();
-  }
-  MPX_EA_STAMP(1);
-  auto sample = [&](int64_t i) { return cum_in_lds ? cum[i] : norm2(i); };
-  const double first = i0 < i1 ? sample(i0) : 0.0;  // (read before the in-place pass of the neighbouring lane overwrites it)
-  double tot = 0, prev = first;
-  for (int64_t i = i0; i < i1; ++i) {
-    const double nxt = sample(i + 1);
-    tot += 0.5 * (prev + nxt);
-    prev = nxt;
-  }
-  double inc = tot;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    double v = __shfl_up(inc, d, 64);
-    if ((l & 63) >= d) inc += v;
-  }
-  if ((l & 63) == 63) wave_tot[l >> 6] = inc;
-  __syncthreads();
-  double off = __shfl_up(inc, 1, 64);
-  if ((l & 63) == 0) off = 0;
-  for (int q = 0; q < (l >> 6); ++q) off += wave_tot[q];
-  if (l == NT - 1) total = off + tot;
-  __syncthreads();
-  MPX_EA_STAMP(2);
-  const double inv = 1.0 / total;
-  if (l == 0) cum[0] = 0.0;  // (lane 0 holds sample 0 in `first`)
-  prev = first;
-  for (int64_t i = i0; i < i1; ++i) {
-    const double nxt = sample(i + 1);  // position i + 1 is overwritten two lines down, by this lane only
-    off += 0.5 * (prev + nxt);
-    prev = nxt;
-    cum[i + 1] = i + 1 == m ? 1.0 : off * inv;  // (the reference divides by the last entry: exactly 1 there)
-  }
-  __syncthreads();
-  MPX_EA_STAMP(3);
-  if (l == 0) pos[0] = 0.0;
-  // lane l owns a contiguous run of boundaries: one binary search for the first, then a forward walk (targets are monotone)
-  const int per = (S + NT - 1) / NT, s0 = l * per < S ? l * per : S, s1 = s0 + per < S ? s0 + per : S;
-  int64_t j = 1;
-  for (int s = s0; s < s1; ++s) {
-    const double target = (double)(s + 1) / (double)S;
-    if (s == s0) {
-      int64_t lo = 0, hi = m;  // first j with cum[j] >= target
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (cum[mid] >= target) hi = mid; else lo = mid + 1;
+    MPX_EA_STAMP(3);
+    if (l == 0) pos[0] = 0.0;
+    // lane l owns a contiguous run of boundaries: one binary search for the first, then a forward walk (targets are monotone)
+    const int per = (S + NT - 1) / NT, s0 = l * per < S ? l * per : S, s1 = s0 + per < S ? s0 + per : S;
+    int64_t j = 1;
+    for (int s = s0; s < s1; ++s) {
+      const double target = (double)(s + 1) / (double)S;
+      if (s == s0) {
+        int64_t lo = 0, hi = m;  // first j with cum[j] >= target
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (cum[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        j = lo < 1 ? 1 : lo;
+      } else {
+        while (j < m && cum[j] < target) ++j;
       }
-      j = lo < 1 ? 1 : lo;
-    } else {
-      while (j < m && cum[j] < target) ++j;
+      pos[s + 1] = ((double)(j - 1) + (target - cum[j - 1]) / (cum[j] - cum[j - 1])) / (double)m;
     }
-    pos[s + 1] = ((double)(j - 1) + (target - cum[j - 1]) / (cum[j] - cum[j - 1])) / (double)m;
-  }
-  __syncthreads();
-  MPX_EA_STAMP(4);
-  const double* __restrict__ pi = p_in + (int64_t)blockIdx.x * p_stride_in + seg_off;
-  double* __restrict__ po = p_out + (int64_t)blockIdx.x * p_stride_out + seg_off;
-  for (int s = l; s < S; s += 8 * NT) {
-    double v[8];
+    __syncthreads();
+    MPX_EA_STAMP(4);
+    const double* __restrict__ pi = p_in + (int64_t)b * p_stride_in + seg_off;
+    double* __restrict__ po = p_out + (int64_t)b * p_stride_out + seg_off;
+    if constexpr (!FAST) {
+      for (int s = l; s < S; s += 8 * NT) {
+        double v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = s + k * NT < S ? pi[s + k * NT] : 0.0;
+        for (int k = 0; k < 8; ++k) v[k] = s + k * NT < S ? pi[s + k * NT] : 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (s + k * NT < S) po[s + k * NT] = damping * (pos[s + k * NT + 1] - pos[s + k * NT]) + (1.0 - damping) * v[k];
+        for (int k = 0; k < 8; ++k)
+          if (s + k * NT < S) po[s + k * NT] = damping * (pos[s + k * NT + 1] - pos[s + k * NT]) + (1.0 - damping) * v[k];
+      }
+    } else {
+      // the new widths also replace the boundaries in LDS (registers first: a lane's pos[s + 1] is its neighbour's pos[s]), then
+      // the workgroup scans them exactly as mpx_prefix_kernel scans p_out (MPX_PREFIX_THREADS == MPX_EA_THREADS)
+      double wn[WR];
+#pragma unroll
+      for (int k = 0; k < WR; ++k) {
+        const int s = l + k * NT;
+        wn[k] = s < S ? damping * (pos[s + 1] - pos[s]) + (1.0 - damping) * pin[k] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < WR; ++k) {
+        const int s = l + k * NT;
+        if (s < S) pos[s] = wn[k], po[s] = wn[k];
+      }
+      __syncthreads();
+      prefix_scan_block([&](int s) { return s_dyn[pos_off + s]; }, wcum + (int64_t)b * wcum_stride + seg_off, S, l, pre_tot);
+    }
+    MPX_EA_STAMP(5);
+    __syncthreads();  // LDS is rewritten by the next point
   }
-  MPX_EA_STAMP(5);
 #undef MPX_EA_STAMP
 }
 }  // namespace
@@ -1662,12 +1746,30 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
   long long*& dbg = c->ea_dbg;  // per context: freed in mpx_destroy
   if (!dbg && getenv("MPX_EA_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&dbg, 64, hipHostMallocMapped));
   if (lds > 48 * 1024 && lds > c->ea_lds_allowed) {  // the attribute is per device: remembered per context, not per process
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     c->ea_lds_allowed = 150 * 1024;
   }
-  hipLaunchKernelGGL(mpx_equal_area_kernel, dim3((unsigned)batch), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
-                     (int64_t)(p_in_per_point ? c->n_p : 0), c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, dbg);
+  // prefix sums of the new widths for the next evaluation (single-phase contexts: the update then covers every width of p_out)
+  const bool fast = in_lds && c->nx == 1 && c->n_phases == 1 && n_pts <= (int64_t)MPX_EA_PF * MPX_EA_THREADS && c->S <= 4 * MPX_EA_THREADS;
+  double* wc = nullptr;
+  if (fast) {
+    if ((rc = reserve(c, c->wcum, (size_t)(batch * c->n_p)))) return rc;
+    wc = c->wcum.p;
+  }
+  int n_cu = 256;
+  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+  const unsigned grid = (unsigned)std::min<int64_t>(batch, fast ? n_cu : batch);  // persistent where a workgroup owns its compute unit's LDS
+  if (fast)
+    hipLaunchKernelGGL(mpx_equal_area_kernel<true>, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
+                       (int64_t)(p_in_per_point ? c->n_p : 0), c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, wc, c->n_p, (int)batch, dbg);
+  else
+    hipLaunchKernelGGL(mpx_equal_area_kernel<false>, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
+                       (int64_t)(p_in_per_point ? c->n_p : 0), c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, wc, c->n_p, (int)batch, dbg);
   HIPCHK(c, hipGetLastError());
+  // the context's prefix sums now belong to p_out: a following mpx_eval_device(... | MPX_WIDTHS_UNCHANGED, p = p_out, per point,
+  // same batch) may use them (the caller's assertion, as always with that flag)
+  c->wcum_valid = false;
   if (dbg) {  // MPX_EA_DEBUG: phase stamps of the last workgroup (wall_clock64, 100 MHz)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fprintf(stderr, "equal_area phases (us): load %.2f  passA %.2f  passB %.2f  search %.2f  widths %.2f\n", (dbg[1] - dbg[0]) / 100.0, (dbg[2] - dbg[1]) / 100.0,
@@ -1753,7 +1855,7 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
   if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
   if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
   if (!skip_prefix) {
-    hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(256), 0, c->stream, p, c->wcum.p, c->S);
+    hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(MPX_PREFIX_THREADS), 0, c->stream, p, c->wcum.p, c->S);
     HIPCHK(c, hipGetLastError());
   }
   MpxIO io{};
@@ -1775,6 +1877,14 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
   io.jac_stride = c->nnz_j;
   io.hess = hess_val;
   io.hess_stride = c->nnz_h;
+  if (mask & MPX_MID_RESID) {
+    if (!(mask & MPX_HESS) || !c->mid_resid_out) return fail(c, MPX_ERR_INVALID, "MPX_MID_RESID needs MPX_HESS and mpx_set_mid_resid_output");
+    for (auto& t : c->degs)
+      if (t.deg > 12) return fail(c, MPX_ERR_UNSUPPORTED, "MPX_MID_RESID: polynomial degree %d > 12 (use a residual plan)", t.deg);
+    if (c->shard_world > 1) return fail(c, MPX_ERR_UNSUPPORTED, "MPX_MID_RESID on a context in segment-sharded mode");
+    io.mid_resid = c->mid_resid_out;
+    io.mid_stride = (int64_t)c->n_phases * (c->N - 1) * c->nx;
+  }
   io.partial = c->partial.p;
   io.n_tiles_total = (int32_t)c->tiles.size();
   io.nred = c->nred;

@@ -34,8 +34,8 @@ struct PhaseStruct {
 
 struct DegTable {
   int deg = 0;
-  std::vector<double> roots, D, Cmid, w, tk;
-  double *d_D = nullptr, *d_Cmid = nullptr, *d_tk = nullptr;
+  std::vector<double> roots, D, Cmid, w, tk, Dmid, tkm;
+  double *d_D = nullptr, *d_Cmid = nullptr, *d_tk = nullptr, *d_Dmid = nullptr, *d_tkm = nullptr;
 };
 
 struct Bucket {
@@ -113,6 +113,7 @@ struct mpx_ctx {
   DevBuf<double> ccs_j, ccs_h;
   int64_t *d_perm_j = nullptr, *d_perm_h = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double* mid_resid_out = nullptr;  // mpx_set_mid_resid_output: device array the MPX_MID_RESID passes write
   int64_t tile_begin = 0, tile_end = 0;
   int run_boundary = 1;
   // host-side sizes of every tile's value blocks (doubles): jac, hess, packed g / grad_f staging

@@ -176,7 +176,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
   constexpr int P1 = P + 1;
   constexpr int SEGS = MPX_TILE / P;
-  constexpr int SLOTS = (MODE == MPX_MODE_HESS) ? 1 : SEGS * P1;
+  constexpr int SLOTS = SEGS * P1;  // (the hess_l pass stages X / U too when it evaluates the mid-point residuals, MPX_MID_RESID)
   constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : (MODE == MPX_MODE_FGJ ? G::NRED : G::NHC);
   constexpr int NRED1 = NRED > 0 ? NRED : 1;
   // Jacobian slots of a node: D-blocks of the defect rows, variable entries, D-blocks of the
@@ -257,8 +257,10 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   constexpr int NREG = TAB_LDS ? 1 : P1;
   __shared__ double sD[TAB_LDS ? P1 * P1 : 1];
   __shared__ double sC[TAB_LDS ? P * P1 : 1];
-  double Drow_[NREG], Crow_[NREG];
+  double Drow_[NREG], Crow_[NREG], Dmrow_[NREG];
   const int drow = k * P1, crow = (k >= 1 ? k - 1 : 0) * P1;
+  // MPX_MID_RESID (hess_l pass only, degrees with the tables in registers): residual of the dynamics at the mid-point before node k
+  const bool midres = MODE == MPX_MODE_HESS && !TAB_LDS && A.io.mid_resid != nullptr;
   if constexpr (TAB_LDS) {
     for (int e = l; e < P1 * P1; e += MPX_TILE) sD[e] = A.Dmat[e];
     for (int e = l; e < P * P1; e += MPX_TILE) sC[e] = A.Cmid[e];
@@ -268,8 +270,10 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
     for (int j = 0; j < P1; ++j) {
       Drow_[j] = A.Dmat[drow + j];
       Crow_[j] = (k >= 1) ? A.Cmid[crow + j] : 0.0;
+      Dmrow_[j] = (midres && k >= 1) ? A.Dmid[crow + j] : 0.0;
     }
   }
+  const double tkm = (midres && k >= 1) ? A.tkm[k - 1] : 0.0;
   auto Drow = [&](int j) -> double {
     if constexpr (TAB_LDS) return sD[drow + j];
     else return Drow_[j];
@@ -317,7 +321,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
     for (int a = 0; a < NX; ++a) q.Xs[a] = (zb + (int64_t)a * N)[i];
 #pragma unroll
     for (int c = 0; c < NU; ++c) q.Us[c] = (zb + (int64_t)(NX + c) * N)[i];
-    if constexpr (MODE != MPX_MODE_HESS) {
+    if (MODE != MPX_MODE_HESS || midres) {
       if (halo) {  // first node of the segment belongs to the previous segment (mpopt.py:190-195)
 #pragma unroll
         for (int a = 0; a < NX + NU; ++a) q.Hl[a] = (zb + (int64_t)a * N)[i - 1];
@@ -382,7 +386,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
     const double kap = cur.ws * A.inv_dtau;    // h = (tf - t0) * kap            (mpopt.py:184)
     const double th = cur.wc + cur.ws * tkk;   // t = t0 + (tf - t0) * th        (mpopt.py:192, 198)
     const int buf = it & 1;
-    if constexpr (MODE != MPX_MODE_HESS) {
+    if (MODE != MPX_MODE_HESS || midres) {
       if (act) {
 #pragma unroll
         for (int a = 0; a < NX; ++a) sXU[buf][a][base + k] = Xs[a];
@@ -425,6 +429,38 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
       Vec<G::NHN> hn;
       G::hess(Xs, Us, t0v, tfv, As, kap, th, Wn, io.sigma[b], lF, lC, hn, red);
       scatter_slots<G::NHN>(io.hess + (int64_t)b * io.hess_stride + T.hess_base, n, l, own, vech, [&](int q) { return hn[q]; });
+      if constexpr (!TAB_LDS) {
+      if (midres && own && k >= 1) {
+        // D_mid.X - h Sx dyn(I_mid.X, I_mid.U, t_mid, a) at the mid-point between nodes i - 1 and i: the same fma chains, in the
+        // same order, as mpx_resid_<ph>_<deg> runs for that target point (mpopt.py:1466-1481), from the segment's X / U in LDS
+        Vec<NX> Xi, DXi, fxm;
+        Vec<NU> Ui;
+        Vec<NC> ccm;
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+          double v = 0, d = 0;
+#pragma unroll
+          for (int j = 0; j < P1; ++j) {
+            const double x = sXU[buf][a][base + j];
+            v = fma(Crow_[j], x, v);
+            d = fma(Dmrow_[j], x, d);
+          }
+          Xi[a] = v, DXi[a] = d;
+        }
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+          double v = 0;
+#pragma unroll
+          for (int j = 0; j < P1; ++j) v = fma(Crow_[j], sXU[buf][NX + c][base + j], v);
+          Ui[c] = v;
+        }
+        double qWm;
+        G::fg(Xi, Ui, t0v, tfv, As, kap, cur.wc + cur.ws * tkm, 0.0, fxm, ccm, qWm);
+        double* __restrict__ rb = io.mid_resid + (int64_t)b * io.mid_stride + ((int64_t)A.phase * (N - 1) + (i - 1)) * NX;
+#pragma unroll
+        for (int a = 0; a < NX; ++a) rb[a] = DXi[a] - fxm[a];
+      }
+      }
     } else {
       Vec<NX> fx;
       Vec<NC> cc;

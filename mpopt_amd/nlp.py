@@ -282,6 +282,10 @@ class NlpFunctions:
         """Void the launch-geometry measurements (call after re-allocating output arrays; include/mpx.h)."""
         _lib.check(self._L.mpx_geometry_reset(self._ctx), self._ctx)
 
+    def set_mid_resid_output(self, resid):
+        """Device array [batch][n_phases * (N - 1)][nx] the MPX_MID_RESID passes write (mpx_set_mid_resid_output); None: off."""
+        _lib.check(self._L.mpx_set_mid_resid_output(self._ctx, ctypes.c_void_p(_ptr(resid))), self._ctx)
+
     def set_stream(self, stream):
         _lib.check(self._L.mpx_set_stream(self._ctx, ctypes.c_void_p(int(stream) if stream else None)), self._ctx)
 

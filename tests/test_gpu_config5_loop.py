@@ -73,6 +73,76 @@ def test_config5_loop_device_resident():
     assert np.abs(p.cpu().numpy() - ph).max() > 1e-6
 
 
+@pytest.mark.parametrize("case", ["hyper_sensitive_4000x3", "kitchen_sink_mixed", "dae_vdp_30x7"])
+def test_mid_point_residuals_fused_into_the_hess_pass(case):
+    """MPX_MID_RESID: the node kernels of the hess_l pass also write the dynamics residuals at the mid-points of every segment.  They
+    equal the residual plan over the same target points (same fma chains: compared at 1e-13, and bit for bit where the compiler
+    keeps the generated node function identical in both kernels), hess_l itself is unchanged bit for bit, and the numpy oracle
+    confirms a sample of segments -- single phase at config-5 size, and a two-phase problem with parameters, several states and
+    mixed degrees."""
+    import torch
+    from mpopt_amd._lib import MPX_MID_RESID
+
+    builder, S, po, scheme = {"hyper_sensitive_4000x3": (problems.hyper_sensitive, 4000, 3, "LGR"),
+                              "kitchen_sink_mixed": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR"),
+                              "dae_vdp_30x7": (problems.dae_vdp, 30, 7, "LGL")}[case]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(8)
+    B = 5
+    Zh = mpo.initialize_solution()[None, :] + 0.05 * rng.standard_normal((B, o.n_z))
+    w = rng.uniform(0.5, 1.5, (B, ocp.n_phases, S))
+    ph = (w / w.sum(axis=2, keepdims=True)).reshape(B, -1)
+    t = lambda a: torch.tensor(a, device=dev)
+    Z, p, lam, sig = t(Zh), t(ph), t(rng.standard_normal((B, o.n_g))), t(rng.uniform(0.5, 1.5, B))
+    N = o.n_nodes
+    mids = [(mpo.collocation._taus_fn(d)[:-1] + mpo.collocation._taus_fn(d)[1:]) / 2 for d in mpo.poly_orders]
+    H0 = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
+    H1 = torch.full_like(H0, float("nan"))
+    o.eval_device(MPX_HESS, B, Z, p, 1, lam, sig, None, None, None, None, H0)
+    Rf = torch.full((B, ocp.n_phases * (N - 1), ocp.nx), float("nan"), dtype=torch.float64, device=dev)
+    o.set_mid_resid_output(Rf)
+    o.eval_device(MPX_HESS | MPX_MID_RESID, B, Z, p, 1, lam, sig, None, None, None, None, H1)
+    o.sync()
+    assert torch.equal(H0, H1)
+    O = OracleNLP(ocp, S, po, scheme)
+    for phase in range(ocp.n_phases):
+        plan = o.residual_plan(phase, mids)
+        assert plan.n_pts == N - 1
+        Rp = torch.empty(B, N - 1, ocp.nx, dtype=torch.float64, device=dev)
+        plan.eval_device(B, Z, p, p_per_point=1, resid=Rp)
+        o.sync()
+        got = Rf[:, phase * (N - 1):(phase + 1) * (N - 1), :]
+        assert not torch.isnan(got).any()
+        assert float((got - Rp).abs().max()) <= 1e-13 * max(1.0, float(Rp.abs().max())), (case, phase, float((got - Rp).abs().max()))
+        start = np.concatenate([[0], np.cumsum(mpo.poly_orders)])
+        for s in sorted(set(rng.integers(0, S, 6).tolist()) | {0, S - 1}):
+            ro = O.residuals_of_segments(Zh[1], ph[1], phase, mids, [s])
+            assert rel_err(got[1, start[s]:start[s + 1], :].cpu().numpy(), ro[s]["resid"]) < TOL, (case, phase, s)
+        plan.close()
+    if ocp.n_phases == 1:
+        # the equal-area update leaves the prefix sums of ITS output on the device: evaluating at those widths with
+        # MPX_WIDTHS_UNCHANGED (no prefix launch) gives the bits of the evaluation that recomputes them
+        p2 = torch.empty_like(p)
+        o.equal_area_widths_device(0, B, N - 1, Rf, p, p2, damping=0.4, p_in_per_point=1)
+        Ha, Ra = torch.empty_like(H0), torch.empty_like(Rf)
+        o.set_mid_resid_output(Ra)
+        o.eval_device(MPX_HESS | MPX_MID_RESID | MPX_WIDTHS_UNCHANGED, B, Z, p2, 1, lam, sig, None, None, None, None, Ha)
+        Hb, Rb = torch.empty_like(H0), torch.empty_like(Rf)
+        o.set_mid_resid_output(Rb)
+        o.eval_device(MPX_HESS | MPX_MID_RESID, B, Z, p2, 1, lam, sig, None, None, None, None, Hb)
+        o.sync()
+        assert torch.equal(Ha, Hb) and torch.equal(Ra, Rb) and not torch.equal(Ha, H0)
+        p2h = p2.cpu().numpy()
+        assert np.abs(p2h.sum(axis=1) - 1).max() < 1e-9 and p2h.min() > 0
+    o.set_mid_resid_output(None)
+    with pytest.raises(M.MpxError):
+        o.eval_device(MPX_HESS | MPX_MID_RESID, B, Z, p, 1, lam, sig, None, None, None, None, H1)
+    o.close()
+
+
 def test_equal_area_device_rule_on_reference_vectors():
     """The device kernel on the reference's own equal-area vectors (tests/golden/hadaptive.npz), no damping."""
     import os
