@@ -29,6 +29,7 @@ struct DevSet {
 };
 
 struct DevGather {
+  int32_t long_threshold = MPX_GATHER_LONG;  // rows with more terms are summed by a wavefront (both paths of the pass use it)
   int64_t n_rows = 0, nnz = 0, n_long = 0;
   int64_t *ptr = nullptr, *long_rows = nullptr;
   int32_t* src = nullptr;
@@ -51,6 +52,12 @@ struct mpx_asm_state {
   int fuse_nt = 0, fuse_u[2] = {0, 0};  // lanes per workgroup; evaluation points per workgroup pass (first order, Hessian); 0: no kernel
   int fuse_wg[3] = {0, 0, 0};           // resident workgroups per launch (compute units x occupancy)
   long long* dbg = nullptr;             // MPX_FUSE_DEBUG
+  int32_t *d_task_ptr[2] = {nullptr, nullptr}, *d_task_list[2] = {nullptr, nullptr};  // point-phase schedules (first order, Hessian)
+  // chained local variables (MpxPtSet::chain_v): shared term lists and the per-point slots
+  int32_t *d_ch_ptr = nullptr, *d_ch_idx = nullptr, *d_ch_slot = nullptr;
+  double* d_ch_coef = nullptr;
+  int32_t n_chains = 0;
+  std::vector<int32_t*> d_chain_pos;
   std::vector<DevSet> sets;
   MpxPtSet* d_sets = nullptr;  // device copy of the per-set argument blocks
   int n_blocks = 0;            // 64-lane blocks of the fused point launch
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256) void mpx_gather_kernel(const MpxGatherArgs A) 
   if (row >= A.n_rows) return;
   const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
   const int nt = (int)(e1 - e0);
-  if (nt > MPX_GATHER_LONG) return;
+  if (nt > A.long_threshold) return;
   int64_t local, stride;
   double* out = gather_out(A, row, local, stride);
   if (!out) return;
@@ -166,7 +173,8 @@ int upload_n(mpx_ctx* c, T** dst, const T* src, size_t n) {
   return MPX_OK;
 }
 
-int upload_gather(mpx_ctx* c, DevGather& d, const mpx_gather& g, int64_t raw_n, int64_t n_z, const char* what) {
+int upload_gather(mpx_ctx* c, DevGather& d, const mpx_gather& g, int64_t raw_n, int64_t n_z, const char* what, int long_threshold) {
+  d.long_threshold = long_threshold;
   if (g.n_rows < 0 || (g.n_rows && (!g.ptr || g.ptr[0] != 0))) return fail(c, MPX_ERR_INVALID, "%s: bad row pointers", what);
   d.n_rows = g.n_rows;
   d.nnz = g.n_rows ? g.ptr[g.n_rows] : 0;
@@ -182,7 +190,7 @@ int upload_gather(mpx_ctx* c, DevGather& d, const mpx_gather& g, int64_t raw_n, 
   if ((rc = upload_n(c, &d.src, g.src, (size_t)d.nnz))) return rc;
   std::vector<int64_t> lr;
   for (int64_t r = 0; r < g.n_rows; ++r)
-    if (g.ptr[r + 1] - g.ptr[r] > MPX_GATHER_LONG) lr.push_back(r);
+    if (g.ptr[r + 1] - g.ptr[r] > d.long_threshold) lr.push_back(r);
   d.n_long = (int64_t)lr.size();
   if ((rc = upload(c, &d.long_rows, lr))) return rc;
   return upload_n(c, &d.coef, g.coef, (size_t)d.nnz);
@@ -199,8 +207,7 @@ int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, in
     r_nt[(size_t)r] = (int32_t)nt;
     r_idx[(size_t)r] = nt ? idx[(size_t)g.ptr[r]] : (int32_t)(raw_n + n_z);
     r_coef[(size_t)r] = nt ? g.coef[g.ptr[r]] : 0.0;
-    if (nt > MPX_GATHER_LONG) longr.push_back((int32_t)r);
-    else if (nt > mt) mid.push_back((int32_t)r);
+    if (nt > mt) longr.push_back((int32_t)r);  // (mt = the pass's long-row threshold, DevGather::long_threshold)
     else if (nt >= 2) multi.push_back((int32_t)r);
   }
   f.n_multi = (int32_t)multi.size(), f.n_mid = (int32_t)mid.size(), f.n_long = (int32_t)longr.size();
@@ -240,7 +247,9 @@ void mpx_asm_release(mpx_ctx* c) {
   for (auto& s : a->sets) fr(s.loc_toff), fr(s.loc_idx), fr(s.mu_toff), fr(s.mu_idx), fr(s.loc_coef), fr(s.cst), fr(s.mu_coef);
   for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef), fr(g->long_rows);
   for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef);
-  fr(a->raw.p), fr(a->d_sets);
+  fr(a->d_ch_ptr), fr(a->d_ch_idx), fr(a->d_ch_slot), fr(a->d_ch_coef);
+  for (auto q : a->d_chain_pos) fr(q);
+  fr(a->raw.p), fr(a->d_sets), fr(a->d_task_ptr[0]), fr(a->d_task_ptr[1]), fr(a->d_task_list[0]), fr(a->d_task_list[1]);
   if (a->dbg) (void)hipHostFree(a->dbg);
   delete a;
   c->assembled = nullptr;
@@ -308,9 +317,74 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
     h.loc_toff = d.loc_toff, h.loc_idx = d.loc_idx, h.loc_coef = d.loc_coef, h.cst = d.cst;
     h.mu_toff = d.mu_toff, h.mu_idx = d.mu_idx, h.mu_coef = d.mu_coef;
     h.raw_off = a->raw_n, h.rawh_off = a->rawh_n;
+    h.n_loc = d.n_loc, h.n_out = d.n_out, h.chain_v = -1, h.chain_pos = nullptr;
     a->n_blocks += (d.n + 63) / 64;
     a->raw_n += (int64_t)d.n * (d.n_out + d.n_jac);
     a->rawh_n += (int64_t)d.n * d.n_hess;
+  }
+  {  // Chained local variables: variable v of set k qualifies when, over its points, the (non-padding) term lists are all prefixes
+     // of the longest one -- same z indices, same coefficients, same order.  Chains with identical term lists are shared
+     // between sets (the running width sum of the node set and of the mid-point set of a phase).  At most one variable per set,
+     // the one with the most table terms; total slots bounded by the LDS array of the kernels (256).
+    std::vector<std::vector<std::pair<int32_t, double>>> chains;
+    std::vector<int32_t> ch_slot;
+    int32_t slots = 0;
+    a->d_chain_pos.assign(D->n_sets, nullptr);
+    for (int k = 0; k < D->n_sets; ++k) {
+      const mpx_point_set& S = D->sets[k];
+      hs[k].chain_v = -1, hs[k].chain_pos = nullptr;
+      const int64_t n = S.n_points;
+      int best_v = -1, best_T = 3;  // (not worth it below four terms)
+      std::vector<std::pair<int32_t, double>> best_list;
+      std::vector<int32_t> best_len;
+      int64_t toff = 0;
+      for (int v = 0; v < S.n_loc; toff += S.loc_nterm[v], ++v) {
+        const int T = S.loc_nterm[v];
+        if (T <= best_T) continue;
+        std::vector<int32_t> len((size_t)n, 0);
+        int64_t longest = 0;
+        bool ok = true;
+        for (int64_t p = 0; p < n && ok; ++p) {
+          int L = 0;
+          while (L < T && S.loc_coef[(toff + L) * n + p] != 0.0) ++L;
+          for (int t = L; t < T && ok; ++t) ok = S.loc_coef[(toff + t) * n + p] == 0.0;  // padding trails
+          len[(size_t)p] = L;
+          if (L > len[(size_t)longest]) longest = p;
+        }
+        std::vector<std::pair<int32_t, double>> list;
+        for (int t = 0; ok && t < len[(size_t)longest]; ++t) list.push_back({S.loc_idx[(toff + t) * n + longest], S.loc_coef[(toff + t) * n + longest]});
+        for (int64_t p = 0; p < n && ok; ++p)
+          for (int t = 0; t < len[(size_t)p] && ok; ++t)
+            ok = S.loc_idx[(toff + t) * n + p] == list[(size_t)t].first && S.loc_coef[(toff + t) * n + p] == list[(size_t)t].second;
+        if (ok && !list.empty()) best_v = v, best_T = T, best_list = list, best_len = len;
+      }
+      if (best_v < 0) continue;
+      int cid = -1;
+      for (size_t q = 0; q < chains.size(); ++q) {  // an existing chain this list is a prefix of (or equal to)
+        if (chains[q].size() >= best_list.size() && std::equal(best_list.begin(), best_list.end(), chains[q].begin())) cid = (int)q;
+      }
+      if (cid < 0) {
+        if (slots + (int32_t)best_list.size() + 1 > 256) continue;
+        cid = (int)chains.size();
+        chains.push_back(best_list);
+        ch_slot.push_back(slots);
+        slots += (int32_t)best_list.size() + 1;
+      }
+      std::vector<int32_t> pos((size_t)n);
+      for (int64_t p = 0; p < n; ++p) pos[(size_t)p] = ch_slot[(size_t)cid] + best_len[(size_t)p];
+      if ((rc = upload(c, &a->d_chain_pos[k], pos))) return bail(rc);
+      hs[k].chain_v = best_v, hs[k].chain_pos = a->d_chain_pos[k];
+    }
+    std::vector<int32_t> ch_ptr(1, 0), ch_idx;
+    std::vector<double> ch_coef;
+    for (auto& l : chains) {
+      for (auto& t : l) ch_idx.push_back(t.first), ch_coef.push_back(t.second);
+      ch_ptr.push_back((int32_t)ch_idx.size());
+    }
+    a->n_chains = (int32_t)chains.size();
+    if ((rc = upload(c, &a->d_ch_ptr, ch_ptr)) || (rc = upload(c, &a->d_ch_idx, ch_idx)) || (rc = upload(c, &a->d_ch_coef, ch_coef)) ||
+        (rc = upload(c, &a->d_ch_slot, ch_slot)))
+      return bail(rc);
   }
   if ((rc = upload(c, &a->d_sets, hs))) return bail(rc);
   static const char* kname[3] = {"mpx_pts_val", "mpx_pts_jac", "mpx_pts_hes"};
@@ -326,20 +400,59 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
     (void)hipGetLastError();  // an older code object without the symbol is fine: one point per lane
   }
   if (a->raw_n >= (1LL << 31) || a->rawh_n >= (1LL << 31)) return bail(fail(c, MPX_ERR_UNSUPPORTED, "raw buffer too large for int32 sources"));
-  if ((rc = upload_gather(c, a->fgj, D->fgj, a->raw_n, D->n_z, "fgj gather")) || (rc = upload_gather(c, a->hess, D->hess, a->rawh_n, D->n_z, "hess gather")))
-    return bail(rc);
   {  // fused persistent kernels (mpx_assembly_fused.h): present in code objects generated since round 3
     hipDeviceptr_t sym = nullptr;
     size_t bytes = 0;
     int info[5] = {0, 0, 0, 0, 0};
     static const char* fname[3] = {"mpx_asm_fg", "mpx_asm_fgj", "mpx_asm_hes"};
-    if (hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_fuse_info") == hipSuccess && bytes == sizeof info && hipMemcpyDtoH(info, sym, sizeof info) == hipSuccess &&
-        info[0] >= 64 && info[0] <= 1024) {
+    const bool have_info = hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_fuse_info") == hipSuccess && bytes == sizeof info &&
+                           hipMemcpyDtoH(info, sym, sizeof info) == hipSuccess && info[0] >= 64 && info[0] <= 1024;
+    // rows with more terms than the pass's ELL width are summed by a wavefront (lane-strided partial sums + shuffle tree) in BOTH
+    // the two-pass gather kernel and the fused kernel -- one definition of every sum, so the two paths agree bit for bit
+    const int thr_fgj = have_info && info[3] >= 2 ? info[3] : MPX_GATHER_LONG, thr_hes = have_info && info[4] >= 2 ? info[4] : MPX_GATHER_LONG;
+    if ((rc = upload_gather(c, a->fgj, D->fgj, a->raw_n, D->n_z, "fgj gather", thr_fgj)) ||
+        (rc = upload_gather(c, a->hess, D->hess, a->rawh_n, D->n_z, "hess gather", thr_hes)))
+      return bail(rc);
+    if (have_info) {
       bool ok = true;
       for (int m = 0; m < 3 && ok; ++m) ok = hipModuleGetFunction(&a->fn_fused[m], c->module, fname[m]) == hipSuccess;
+      for (auto& d : a->sets) ok = ok && d.n_loc < 48 && d.n_out < 48;  // (LDS copies of the offset arrays in the fused kernels)
+      ok = ok && a->sets.size() <= 16;
       if (ok && (info[1] > 0 || info[2] > 0)) {
-        if ((rc = upload_fused(c, a->ffgj, D->fgj, a->raw_n, D->n_z, info[3])) || (rc = upload_fused(c, a->fhess, D->hess, a->rawh_n, D->n_z, info[4]))) return bail(rc);
+        if ((rc = upload_fused(c, a->ffgj, D->fgj, a->raw_n, D->n_z, thr_fgj)) || (rc = upload_fused(c, a->fhess, D->hess, a->rawh_n, D->n_z, thr_hes))) return bail(rc);
         a->fuse_nt = info[0], a->fuse_u[0] = info[1], a->fuse_u[1] = info[2];
+        // point-phase schedule per pass: tasks (evaluation point u, 64-point block) of one chunk onto the NT / 64 wavefronts, longest
+        // first onto the least loaded (cost ~ table terms of the block's set + a constant for the function itself)
+        for (int ps = 0; ps < 2; ++ps) {
+          const int U = std::max(a->fuse_u[ps], 1), NW = a->fuse_nt / 64;
+          std::vector<std::pair<double, int>> tasks;
+          for (int u = 0; u < U; ++u)
+            for (int k = 0; k < (int)a->sets.size(); ++k) {
+              const mpx_point_set& S = D->sets[k];
+              double terms = 8;
+              for (int v = 0; v < S.n_loc; ++v) terms += S.loc_nterm[v];
+              if (ps == 1)
+                for (int r = 0; r < S.n_out; ++r) terms += S.mu_nterm[r];
+              terms += 0.25 * (ps == 1 ? S.n_hess : S.n_jac + S.n_out);
+              for (int blk = 0; blk < (S.n_points + 63) / 64; ++blk) tasks.push_back({terms, u * a->n_blocks + hs[k].block_first + blk});
+            }
+          std::stable_sort(tasks.begin(), tasks.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
+          std::vector<double> load((size_t)NW, 0.0);
+          std::vector<std::vector<int32_t>> per((size_t)NW);
+          for (auto& t : tasks) {
+            int w = 0;
+            for (int q = 1; q < NW; ++q)
+              if (load[q] < load[w]) w = q;
+            load[w] += t.first;
+            per[w].push_back(t.second);
+          }
+          std::vector<int32_t> tptr(1, 0), tlist;
+          for (int w = 0; w < NW; ++w) {
+            tlist.insert(tlist.end(), per[w].begin(), per[w].end());
+            tptr.push_back((int32_t)tlist.size());
+          }
+          if ((rc = upload(c, &a->d_task_ptr[ps], tptr)) || (rc = upload(c, &a->d_task_list[ps], tlist))) return bail(rc);
+        }
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
         for (int m = 0; m < 3; ++m) {
@@ -391,6 +504,7 @@ static int launch_gather(mpx_ctx* c, const DevGather& g, int64_t batch, const do
   A.seg_begin[n_seg] = g.n_rows;
   A.B = (int32_t)batch;
   A.long_rows = g.long_rows, A.n_long = g.n_long;
+  A.long_threshold = g.long_threshold;
   A.n_short_blocks = (int32_t)((g.n_rows + 255) / 256);
   const unsigned gx = (unsigned)(A.n_short_blocks + (g.n_long + 3) / 4);
   A.b_per_block = pick_chunk(batch, gx);
@@ -427,13 +541,15 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
   A.r_idx = f.r_idx, A.r_coef = f.r_coef, A.r_nt = f.r_nt, A.ptr = g.ptr, A.idx = f.idx, A.coef = g.coef;
   A.multi_rows = f.multi, A.m_idx = f.m_idx, A.m_coef = f.m_coef, A.mid_rows = f.mid, A.long_rows = f.longr;
   A.n_multi = f.n_multi, A.n_mid = f.n_mid, A.n_long = f.n_long;
+  A.task_ptr = a->d_task_ptr[mode == MPX_MODE_HESS ? 1 : 0], A.task_list = a->d_task_list[mode == MPX_MODE_HESS ? 1 : 0];
+  A.ch_ptr = a->d_ch_ptr, A.ch_idx = a->d_ch_idx, A.ch_coef = a->d_ch_coef, A.ch_slot = a->d_ch_slot, A.n_chains = a->n_chains;
   for (int k = 0; k < 4; ++k) A.out[k] = out[k], A.out_stride[k] = stride[k];
   const int U = a->fuse_u[mode == MPX_MODE_HESS ? 1 : 0];
   const int64_t chunks = (batch + U - 1) / U;
   static const int wg_env = getenv("MPX_FUSE_WG") ? atoi(getenv("MPX_FUSE_WG")) : 0;
   const unsigned grid = (unsigned)std::min<int64_t>(chunks, wg_env > 0 ? wg_env : a->fuse_wg[mode]);
   static const bool dbg_on = getenv("MPX_FUSE_DEBUG") != nullptr;
-  if (dbg_on && !a->dbg) HIPCHK(c, hipHostMalloc((void**)&a->dbg, 128, hipHostMallocMapped));
+  if (dbg_on && !a->dbg) HIPCHK(c, hipHostMalloc((void**)&a->dbg, 256, hipHostMallocMapped));
   A.dbg = dbg_on ? a->dbg : nullptr;
   size_t sz = sizeof(A);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -444,6 +560,9 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
     fprintf(stderr, "fused mode %d grid %u: z %.2f | points %.2f | wait %.2f | rows1 %.2f | multi %.2f | mid %.2f | long %.2f | wait %.2f  (chunk %.2f us)\n", mode, grid,
             (d[1] - d[0]) / 100.0, (d[2] - d[1]) / 100.0, (d[3] - d[2]) / 100.0, (d[4] - d[3]) / 100.0, (d[5] - d[4]) / 100.0, (d[6] - d[5]) / 100.0, (d[7] - d[6]) / 100.0,
             (d[8] - d[7]) / 100.0, (d[8] - d[0]) / 100.0);
+    if (getenv("MPX_FUSE_PT_STAMPS"))
+      fprintf(stderr, "  point task of wave 0: start +%.2f | gather %.2f | function %.2f | raw stores %.2f\n", (d[16] - d[1]) / 100.0, (d[17] - d[16]) / 100.0,
+              (d[18] - d[17]) / 100.0, (d[19] - d[18]) / 100.0);
   }
   return MPX_OK;
 }

@@ -13,9 +13,10 @@
 //     (MPX_FUSE_*), so the row loops unroll and the table is straight-line register code;
 //   * the row phase is then nothing but  ds_read -> v_fma -> global_store  with a uniform base and a running lane offset:
 //     each store instruction of a wavefront writes one contiguous 512-byte run;
-//   * rows with 2 .. MPX_GATHER_LONG terms (a few hundred: defect rows = D.X - f, mid-point residual entries) are summed by one
-//     lane each from a compact CSR (L1 / L2 resident), rows with more terms (objective, d/dt0, d/dtf, d/dwidths) by one
-//     wavefront each with the same shuffle tree as mpx_gather_kernel.
+//   * rows with 2 .. MT terms (a few hundred: defect rows = D.X - f, mid-point residual entries; MT = the ELL width the code
+//     generator picks per pass) are summed by one lane each from an ELL table (L1 / L2 resident), rows with more terms
+//     (objective, d/dt0, d/dtf, d/dwidths, the sum-to-one row of the widths) by one wavefront each with the same shuffle tree
+//     as mpx_gather_kernel, which uses the same threshold (MpxGatherArgs::long_threshold).
 // Every sum keeps the term order and the fma chain of the two-pass kernels: results are bit-identical to them (tested), so the
 // host may pick either path by batch size.
 #pragma once
@@ -24,10 +25,16 @@
 #include "mpx_device.h"
 
 #ifndef MPX_FUSE_LOC_G
-#define MPX_FUSE_LOC_G 1  // table entries of a local variable fetched together
+#define MPX_FUSE_LOC_G 4  // table entries of a local variable fetched together
 #endif
 #ifndef MPX_FUSE_TASK_PER_U
 #define MPX_FUSE_TASK_PER_U 1
+#endif
+#ifndef MPX_FUSE_CHAINS
+#define MPX_FUSE_CHAINS 0
+#endif
+#ifndef MPX_FUSE_CHAIN_MAX
+#define MPX_FUSE_CHAIN_MAX 256  // LDS slots for the partial sums of chained local variables (all chains of the context together)
 #endif
 #ifndef MPX_FUSE_MULTI_EARLY
 #define MPX_FUSE_MULTI_EARLY 0
@@ -69,26 +76,40 @@ struct RowRegs {  // first terms of the rows k * NT + lane, k < K, of one output
 // read once and applied to all of them (per evaluation point the terms are added in the stored order, as in the two-pass point
 // kernels); local variables from z in LDS, results to raw in LDS
 template <int FID, int MODE, int U, int VN, int RAWN>
-__device__ __forceinline__ void fused_point(const MpxPtSet& S, const ::MpxFusedArgs& A, int blk, int lane, double (*V)[VN], int b0, int nu) {
+__device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __restrict__ ltoff, const int* __restrict__ mtoff, const ::MpxFusedArgs& A, int blk, int lane,
+                                            double (*V)[VN], int b0, int nu, const double* __restrict__ CH) {
   using F = mpxgen::Pt<FID>;
   constexpr int NLOC = F::NLOC, NCST = F::NCST, NOUT = F::NOUT, NJ = F::NJ, NH = F::NH;
   if constexpr (MODE == MPX_MODE_HESS && NH == 0) return;
   const int p = blk * 64 + lane;
+#ifdef MPX_FUSE_PT_STAMPS
+  long long* dq = (A.dbg && blockIdx.x == 1 && threadIdx.x == 0 && CH[MPX_FUSE_CHAIN_MAX - 1] == 2.0) ? A.dbg + 16 : nullptr;
+  if (dq) dq[0] = wall_clock64();
+#endif
   if (p >= S.n) return;
   const int64_t n = S.n;
   double cst[NCST > 0 ? NCST : 1];
 #pragma unroll
   for (int k = 0; k < NCST; ++k) cst[k] = S.cst[(int64_t)k * n + p];
   double loc[U][NLOC > 0 ? NLOC : 1];
+  // Local variables: fixed-order sums over z (in LDS), terms added in stored order as in the two-pass point kernels.  Measured
+  // (MPX_FUSE_PT_STAMPS, moon lander 20x5): this gather is 7.6 us of a 9 us point task -- one memory round trip per variable more
+  // than per term: fetching 4 or 8 table entries of a variable together gains 15-25 % of it, a term-major loop over all variables
+  // (one round trip per term index) or taking the 19-term running width sum out of it (MPX_FUSE_CHAINS) lose more to registers
+  // and to the extra phase than they save.
 #pragma unroll
   for (int v = 0; v < NLOC; ++v) {
     double acc[U];
+    if (MPX_FUSE_CHAINS && v == S.chain_v) {  // chained variable: the shared partial sums are in LDS (fused_body), this point reads its prefix
+      const int slot = S.chain_pos[p];
+#pragma unroll
+      for (int u = 0; u < U; ++u) loc[u][v] = CH[u * MPX_FUSE_CHAIN_MAX + slot];
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) acc[u] = 0;
-    // (MPX_FUSE_LOC_G table entries are fetched together -- independent loads; one at a time would chain  L2 load -> LDS read ->
-    // fma  up to 50 times per point, which was the critical path of a chunk: 10 us for the mid-point block -- then added in order)
-    const int t1 = S.loc_toff[v + 1];
-    for (int t = S.loc_toff[v]; t < t1; t += MPX_FUSE_LOC_G) {
+    const int t1 = ltoff[v + 1];
+    for (int t = ltoff[v]; t < t1; t += MPX_FUSE_LOC_G) {
       int ix[MPX_FUSE_LOC_G];
       double cf[MPX_FUSE_LOC_G];
 #pragma unroll
@@ -106,6 +127,9 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const ::MpxFusedA
 #pragma unroll
     for (int u = 0; u < U; ++u) loc[u][v] = acc[u];
   }
+#ifdef MPX_FUSE_PT_STAMPS
+  if (dq) dq[1] = wall_clock64();
+#endif
   if constexpr (MODE == MPX_MODE_HESS) {
     double mu[U][NOUT > 0 ? NOUT : 1];
 #pragma unroll
@@ -113,7 +137,7 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const ::MpxFusedA
       double acc[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) acc[u] = 0;
-      for (int t = S.mu_toff[r]; t < S.mu_toff[r + 1]; ++t) {
+      for (int t = mtoff[r]; t < mtoff[r + 1]; ++t) {
         const int ix = S.mu_idx[(int64_t)t * n + p];
         const double cf = S.mu_coef[(int64_t)t * n + p];
 #pragma unroll
@@ -143,6 +167,9 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const ::MpxFusedA
       if constexpr (MODE == MPX_MODE_FGJ) {
         double J[NJ > 0 ? NJ : 1];
         F::jac(loc[u], cst, out, J);
+#ifdef MPX_FUSE_PT_STAMPS
+        if (dq) dq[2] = wall_clock64() + (long long)(J[0] == 1.2345e300);
+#endif
 #pragma unroll
         for (int q = 0; q < NJ; ++q) rb[(int64_t)(NOUT + q) * n + p] = J[q];
       } else {
@@ -152,20 +179,24 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const ::MpxFusedA
       for (int r = 0; r < NOUT; ++r) rb[(int64_t)r * n + p] = out[r];
     }
   }
+#ifdef MPX_FUSE_PT_STAMPS
+  if (dq) dq[3] = wall_clock64();
+#endif
 }
 
 template <int MODE, int FID, int U, int VN, int RAWN>
 struct FusedDispatch {
-  __device__ static __forceinline__ void run(const MpxPtSet& S, const ::MpxFusedArgs& A, int blk, int lane, double (*V)[VN], int b0, int nu) {
+  __device__ static __forceinline__ void run(const MpxPtSet& S, const int* lt, const int* mt, const ::MpxFusedArgs& A, int blk, int lane, double (*V)[VN], int b0, int nu,
+                                             const double* CH) {
     if (S.fid == FID)
-      fused_point<FID, MODE, U, VN, RAWN>(S, A, blk, lane, V, b0, nu);
+      fused_point<FID, MODE, U, VN, RAWN>(S, lt, mt, A, blk, lane, V, b0, nu, CH);
     else
-      FusedDispatch<MODE, FID - 1, U, VN, RAWN>::run(S, A, blk, lane, V, b0, nu);
+      FusedDispatch<MODE, FID - 1, U, VN, RAWN>::run(S, lt, mt, A, blk, lane, V, b0, nu, CH);
   }
 };
 template <int MODE, int U, int VN, int RAWN>
 struct FusedDispatch<MODE, -1, U, VN, RAWN> {
-  __device__ static __forceinline__ void run(const MpxPtSet&, const ::MpxFusedArgs&, int, int, double (*)[VN], int, int) {}
+  __device__ static __forceinline__ void run(const MpxPtSet&, const int*, const int*, const ::MpxFusedArgs&, int, int, double (*)[VN], int, int, const double*) {}
 };
 
 // MODE_FG / MODE_FGJ: arrays f (1 row), g (NG), grad_f (NZ), jac_val (NNZJ); MODE_HESS: hess_val (NNZH).
@@ -175,11 +206,30 @@ template <int MODE, int NF, int NT, int U, int RAWN, int NZ, int N0, int N1, int
 __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
   constexpr int VN = RAWN + NZ + 1;  // [raw | z | 1.0]
   __shared__ double V[U][VN];
+  __shared__ double CH[2][U][MPX_FUSE_CHAIN_MAX];  // partial sums of the chained local variables (MpxPtSet::chain_v), this chunk's and the next one's
   // (the wavefront index through readfirstlane: the compiler then knows that everything derived from it -- the point set of a
   // task, its table pointers and term counts, the long row of a wavefront -- is uniform: scalar loads and branches, global_load
   // with a scalar base instead of flat_load with per-lane 64-bit addresses; without it the point phase was 2x slower)
   const int l = threadIdx.x, lane = l & 63, wave = __builtin_amdgcn_readfirstlane(l >> 6);
   constexpr int NW = NT / 64;
+  // Set descriptors and their term-offset arrays, copied to LDS once per kernel: a point task reads its set, the offsets of its
+  // local variables and of its multipliers from here.  From global memory each of these was a dependent round trip per local
+  // variable (descriptor -> offsets -> table entries): ~10 us per task, the whole point phase of a chunk.
+  constexpr int MAXS = 16, MAXV = 48;
+  __shared__ MpxPtSet sS[MAXS];
+  __shared__ int sLt[MAXS][MAXV], sMt[MAXS][MAXV];
+  {
+    const int ns = A.n_sets < MAXS ? A.n_sets : MAXS;
+    for (int k = l; k < ns; k += NT) sS[k] = A.sets[k];
+    __syncthreads();
+    for (int e = l; e < ns * MAXV; e += NT) {
+      const int k = e / MAXV, v = e - k * MAXV;
+      // (offset arrays have n_loc + 1 / n_out + 1 entries; the generated functions know those counts, the kernel reads only them)
+      sLt[k][v] = v <= sS[k].n_loc ? sS[k].loc_toff[v] : 0;
+      sMt[k][v] = v <= sS[k].n_out ? sS[k].mu_toff[v] : 0;
+    }
+    __syncthreads();
+  }
   RowRegs<N0, NT> R0;
   RowRegs<N1, NT> R1;
   RowRegs<N2, NT> R2;
@@ -209,19 +259,6 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       }
     }
   }
-  // the handful of rows with MT + 1 .. MPX_GATHER_LONG terms: wavefront w holds rows w, w + NW, ... (lane t: term t)
-  constexpr int RMID = MPX_FUSE_MID_WAVE ? (16 + NW - 1) / NW : 0;  // (the code generator leaves at most 16 such rows)
-  int qix[RMID > 0 ? RMID : 1], qnt[RMID > 0 ? RMID : 1], qrow[RMID > 0 ? RMID : 1];
-  double qcf[RMID > 0 ? RMID : 1];
-#pragma unroll
-  for (int r = 0; r < RMID; ++r) {
-    const int w = wave + r * NW;
-    qrow[r] = w < A.n_mid ? A.mid_rows[w] : 0;
-    const int64_t e0 = w < A.n_mid ? A.ptr[qrow[r]] : 0;
-    qnt[r] = w < A.n_mid ? (int)(A.ptr[qrow[r] + 1] - e0) : 0;
-    qix[r] = lane < qnt[r] ? A.idx[e0 + lane] : 0;
-    qcf[r] = lane < qnt[r] ? A.coef[e0 + lane] : 0.0;
-  }
   constexpr int ZR = (U * (NZ + 1) + NT - 1) / NT;  // z staging: elements per lane and chunk
   double zr[ZR];
   auto z_load = [&](int c) {  // z of chunk c (and the 1.0 closing every V[u]) into registers
@@ -232,13 +269,42 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       zr[q] = (u < nu && i < NZ) ? A.z[(int64_t)(b0 + u) * A.z_stride + i] : 1.0;
     }
   };
+  // Chained local variables: lane (c, u) of the LAST wavefront runs chain c for evaluation point u of a chunk -- a sequential fma
+  // chain over z read straight from global memory (all loads first), i.e. the partial sums every point would compute itself --
+  // one chunk AHEAD of its use (double-buffered), so that it costs the point phase nothing.
+  auto chains_of = [&](int c, int slot) {
+    if (MPX_FUSE_CHAINS && l >= NT - 64 && lane < A.n_chains * U) {
+      const int cch = lane / U, u = lane - cch * U, b0 = c * U;
+      if (b0 + u < A.B) {
+        const int e0 = A.ch_ptr[cch], e1 = A.ch_ptr[cch + 1];
+        const double* __restrict__ zb = A.z + (int64_t)(b0 + u) * A.z_stride;
+        double* __restrict__ o = &CH[slot][u][A.ch_slot[cch]];
+        double acc = 0;
+        o[0] = acc;
+        for (int e = e0; e < e1; e += 8) {
+          double zv[8], cv[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int ee = e + q < e1 ? e + q : e1 - 1;
+            zv[q] = zb[A.ch_idx[ee]], cv[q] = A.ch_coef[ee];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (e + q < e1) acc = fma(cv[q], zv[q], acc), o[e + q - e0 + 1] = acc;
+        }
+      }
+    }
+  };
   const int n_chunks = (A.B + U - 1) / U;
-  if ((int)blockIdx.x < n_chunks) z_load(blockIdx.x);
+  if ((int)blockIdx.x < n_chunks) z_load(blockIdx.x), chains_of(blockIdx.x, 0);
   int it_ = 0;
 #define MPX_FUSE_STAMP(k) do { if (A.dbg && blockIdx.x == 1 && l == 0 && it_ == 2) A.dbg[k] = wall_clock64(); } while (0)
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x, ++it_) {
     const int b0 = c * U, nu = (A.B - b0 < U) ? A.B - b0 : U;
     MPX_FUSE_STAMP(0);
+#ifdef MPX_FUSE_PT_STAMPS
+    if (l == 0) CH[it_ & 1][0][MPX_FUSE_CHAIN_MAX - 1] = (double)it_;
+#endif
 #pragma unroll
     for (int q = 0; q < ZR; ++q) {
       const int e = q * NT + l, u = e / (NZ + 1), i = e - u * (NZ + 1);
@@ -246,24 +312,16 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     }
     __syncthreads();
     MPX_FUSE_STAMP(1);
-    if (c + (int)gridDim.x < n_chunks) z_load(c + gridDim.x);  // in flight during this chunk's work
+    if (c + (int)gridDim.x < n_chunks) z_load(c + gridDim.x), chains_of(c + gridDim.x, (it_ + 1) & 1);  // in flight during this chunk's work
     // ---- point functions: wavefront <-> (64-point block, evaluation point) ----
-#if MPX_FUSE_TASK_PER_U  // wavefront <-> (64-point block, evaluation point): more tasks, fewer live registers
-    for (int w = wave; w < A.n_blocks * nu; w += NW) {
-      const int u = w / A.n_blocks, bx = w - u * A.n_blocks;
+    // wavefront <-> its scheduled (64-point block, evaluation point) tasks
+    for (int q = A.task_ptr[wave]; q < A.task_ptr[wave + 1]; ++q) {
+      const int t = A.task_list[q], u = t / A.n_blocks, bx = t - u * A.n_blocks;
+      if (u >= nu) continue;
       int k = 0;
-      while (k + 1 < A.n_sets && bx >= A.sets[k + 1].block_first) ++k;
-      const MpxPtSet S = A.sets[k];
-      FusedDispatch<MODE, NF - 1, 1, VN, RAWN>::run(S, A, bx - S.block_first, lane, &V[u], b0 + u, 1);
+      while (k + 1 < A.n_sets && bx >= sS[k + 1].block_first) ++k;
+      FusedDispatch<MODE, NF - 1, 1, VN, RAWN>::run(sS[k], sLt[k], sMt[k], A, bx - sS[k].block_first, lane, &V[u], b0 + u, 1, &CH[it_ & 1][u][0]);
     }
-#else
-    for (int bx = wave; bx < A.n_blocks; bx += NW) {  // wavefront <-> 64-point block, all evaluation points of the chunk
-      int k = 0;
-      while (k + 1 < A.n_sets && bx >= A.sets[k + 1].block_first) ++k;
-      const MpxPtSet S = A.sets[k];
-      FusedDispatch<MODE, NF - 1, U, VN, RAWN>::run(S, A, bx - S.block_first, lane, V, b0, nu);
-    }
-#endif
     // table entries of this lane's multi-term rows: loads issued before the barrier, used after the single-term rows
     MPX_FUSE_STAMP(2);
     __syncthreads();
@@ -329,45 +387,6 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       }
     }
     MPX_FUSE_STAMP(5);
-    // ---- rows with MT + 1 .. MPX_GATHER_LONG terms (a handful): one wavefront per row -- lane t fetches term t, then the terms are
-    // added one after the other in stored order (values passed around by shuffles): the two-pass kernel's sum, without its chain of
-    // dependent loads ----
-    if constexpr (RMID > 0) {
-#pragma unroll
-      for (int r = 0; r < RMID; ++r) {
-        if (qnt[r] > 0) {
-          for (int u = 0; u < nu; ++u) {
-            const double vv = lane < qnt[r] ? V[u][qix[r]] : 0.0;
-            double s = 0;
-            for (int t = 0; t < qnt[r]; ++t) s = fma(__shfl(qcf[r], t, 64), __shfl(vv, t, 64), s);
-            if (lane == 0) {
-              double* op = out_of(qrow[r], b0 + u);
-              if (op) *op = s;
-            }
-          }
-        }
-      }
-    } else {
-      for (int m = l; m < A.n_mid; m += NT) {  // one lane per row, terms from the CSR in stored order
-        const int row = A.mid_rows[m];
-        const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
-        double s[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) s[u] = 0;
-        for (int64_t e = e0; e < e1; ++e) {
-          const int ixe = A.idx[e];
-          const double cfe = A.coef[e];
-#pragma unroll
-          for (int u = 0; u < U; ++u) s[u] = fma(cfe, V[u][ixe], s[u]);  // (slots past the batch: computed, never stored)
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (u < nu) {
-            double* o = out_of(row, b0 + u);
-            if (o) *o = s[u];
-          }
-      }
-    }
     MPX_FUSE_STAMP(6);
     // ---- long rows: one wavefront per row, lane j sums terms j, j + 64, ... in order, fixed shuffle tree (as mpx_gather_kernel) ----
     if constexpr (RL > 0) {

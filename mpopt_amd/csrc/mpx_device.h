@@ -163,6 +163,13 @@ struct MpxPtSet {
   const int32_t* mu_idx;
   const double* mu_coef;
   int64_t raw_off, rawh_off;
+  // Chained local variable (fused kernels): variable chain_v of every point is a PREFIX of one shared term list (the running sum of
+  // the earlier segment widths, mpopt.py:186-195: 19 of the 25 / 52 table terms of a moon-lander node / mid-point).  The list is
+  // summed once per evaluation point -- a sequential fma chain, i.e. exactly the partial sums every point would compute -- into
+  // the chain slots of LDS, and point p reads slot chain_pos[p].  chain_v < 0: none.
+  int32_t chain_v, n_loc;
+  const int32_t* chain_pos;  // [n]
+  int32_t n_out, pad_;       // (n_loc / n_out: lengths - 1 of loc_toff / mu_toff, for kernels that copy them)
 };
 
 // Per-call arguments of the fused point kernels (all sets of the context in one launch).
@@ -178,7 +185,7 @@ struct MpxPtCall {
   int64_t raw_stride;
 };
 
-#define MPX_GATHER_LONG 24  // rows with more terms are summed by a whole wavefront
+#define MPX_GATHER_LONG 24  // rows with more terms are summed by a whole wavefront (default; MpxGatherArgs::long_threshold)
 
 struct MpxGatherArgs {
   int64_t n_rows;
@@ -196,6 +203,7 @@ struct MpxGatherArgs {
   double* seg_out[4];       // NULL: not requested
   int64_t seg_stride[4];
   int32_t n_seg, B, b_per_block;
+  int32_t long_threshold, pad_;  // rows with more terms than this are the long rows of this pass
 };
 // Arguments of the fused kernels of assembled contexts (mpx_assembly_fused.h; device arrays are built once per context by
 // mpx_assembly.cpp).
@@ -224,5 +232,16 @@ struct MpxFusedArgs {
   double* out[4];
   int64_t out_stride[4];
   long long* dbg;  // MPX_FUSE_DEBUG: phase stamps of one workgroup (wall_clock64, 100 MHz), else NULL
+  // point-phase schedule: wavefront w runs the tasks task_list[task_ptr[w] .. task_ptr[w + 1]), task = u * n_blocks + block
+  // (longest-processing-time-first assignment by the host: the blocks of a chunk differ 5x in cost)
+  const int32_t* task_ptr;
+  const int32_t* task_list;
+  // shared term lists of the chained local variables: chain c = terms ch_ptr[c] .. ch_ptr[c + 1) (z index, coefficient), its partial
+  // sums occupy the LDS chain slots ch_slot[c] .. ch_slot[c] + length (slot 0 of a chain = the empty sum)
+  const int32_t* ch_ptr;
+  const int32_t* ch_idx;
+  const double* ch_coef;
+  const int32_t* ch_slot;
+  int32_t n_chains, pad2_;
 };
 #endif
