@@ -217,6 +217,8 @@ int mpx_host_unregister(mpx_ctx* ctx, void* ptr);
  * can all-gather disjoint slices.  Default: all tiles.  The boundary kernel (reductions,
  * terminal and event rows) runs only when `run_boundary` is non-zero. */
 int mpx_set_tile_range(mpx_ctx* ctx, int64_t tile_begin, int64_t tile_end, int run_boundary);
+/* (Mixed-degree grids: the hess_l pass runs over its own node-ordered tiles -- runs of 256 consecutive nodes, every read
+ * contiguous --; a tile range maps proportionally onto them, and mpx_shard_* reports their value runs and partial-sum slots.) */
 int mpx_get_tile_jac_range(const mpx_ctx* ctx, int64_t tile, int64_t* begin, int64_t* end);
 /* Relative cost of every tile (its Jacobian block size), for balancing tile ranges over ranks. */
 int mpx_get_tile_weights(const mpx_ctx* ctx, int64_t* weights);

@@ -272,6 +272,8 @@ class ProblemProgram:
         for ph in range(nph):
             for d in self.degrees:
                 parts.append(f"MPX_INSTANTIATE_NODE({ph}, {d})")
+        if len(self.degrees) > 1:  # mixed-degree grid: the hess_l node pass runs over node-ordered tiles (mpx_kernels.h)
+            parts += [f"MPX_INSTANTIATE_HESS_BY_NODE({ph})" for ph in range(nph)]
         parts.append("MPX_INSTANTIATE_BOUNDARY()")
         return "\n".join(parts) + "\n"
 

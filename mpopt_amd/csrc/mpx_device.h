@@ -91,11 +91,31 @@ struct MpxNodeArgs {
   int32_t abs_cap, pad2_;
 };
 
+// Mixed-degree grids, hess_l pass: the node Hessian does not depend on the polynomial degree (no D.X contraction), so its tiles
+// are runs of MPX_TILE CONSECUTIVE nodes of a phase instead of the (phase, degree) buckets' tiles: every z / lam_g read is one
+// contiguous run (the degree-3 bucket of config 3 fetched whole cache lines for 48-byte runs: 26 % of the pass for 1/6 of the
+// nodes) and the pass is one launch per phase.
+struct MpxHTile {
+  int32_t i0, n;        // first node of the tile, nodes (= owning lanes)
+  int32_t tile_id, pad; // slot in the partial-sum buffer
+  int64_t hess_base;    // offset of the tile's block in the hess_l value array
+};
+struct MpxHessNodeArgs {
+  MpxIO io;
+  const MpxHTile* htiles;   // all phases; blockIdx.x + tile_first indexes it
+  const int32_t* node_seg;  // [N] segment that owns node i (the earlier one at a shared node, mpopt.py:189-195)
+  const double* node_tk;    // [N] (tau_k - tau0)/(tau1 - tau0) of node i in its segment
+  const double* Wnode;      // [N] composite quadrature weight
+  double inv_dtau;
+  int64_t z_off, g_off_F, g_off_C;
+  int32_t N, seg_off, tile_first, tile_count;
+};
+
 // Linear rows handled by the boundary kernel (control-slope continuity dU, phase-link events):
 // g[row] = sum_e coef[e] * z[idx[e]], Jacobian values = coef.
 struct MpxPhaseInfo {
   int64_t z_off;
-  int32_t N, tile_first, tile_count, pad;
+  int32_t N, tile_first, tile_count, tile_count_h;  // tile_count_h: tiles of the hess_l pass (== tile_count unless its tiles are node-ordered)
   int64_t g_off_TC;      // first terminal-constraint row
   int64_t jac_TC;        // first terminal-constraint Jacobian value
 };
@@ -149,6 +169,7 @@ struct MpxResidArgs {
 struct MpxShardEnt {
   int64_t src_off, len, stride, dst_off;
   int32_t kind, rank;
+  int64_t part_off;  // kind 2: offset among the rank's partial-sum runs (the owner-resident exchange carries nothing else)
 };
 
 // ---- assembled contexts (mpx_create_assembled) ---------------------------------------------------

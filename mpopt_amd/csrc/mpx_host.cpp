@@ -460,10 +460,62 @@ int build_layout(mpx_ctx* c) {
     }
   c->nnz_j = jpos;
 
+  // ---- node-ordered tiles of the hess_l pass on mixed-degree grids (MpxHTile) ------------------
+  c->hess_by_node = c->degs.size() > 1 && !getenv("MPX_NO_HESS_BY_NODE");
+  c->htiles.clear(), c->ph_htile_first.assign(c->n_phases, 0), c->ph_htile_count.assign(c->n_phases, 0);
+  if (c->hess_by_node) {
+    c->node_seg.assign((size_t)N, 0), c->node_tk.assign((size_t)N, 0.0);
+    for (int s = 0; s < S; ++s) {
+      const DegTable& t = c->degs[deg_index(c, c->orders[s])];
+      for (int k = (s == 0 ? 0 : 1); k <= c->orders[s]; ++k) c->node_seg[c->seg_start[s] + k] = s, c->node_tk[c->seg_start[s] + k] = t.tk[k];
+    }
+    for (int p = 0; p < c->n_phases && c->hess_by_node; ++p) {
+      c->ph_htile_first[p] = (int32_t)c->htiles.size();
+      for (int64_t i0 = 0; i0 < N; i0 += MPX_TILE) {
+        MpxHTile T{};
+        T.i0 = (int32_t)i0, T.n = (int32_t)std::min<int64_t>(MPX_TILE, N - i0);
+        T.tile_id = c->ph[p].tile_first + (int32_t)(c->htiles.size() - c->ph_htile_first[p]);
+        c->htiles.push_back(T);
+      }
+      c->ph_htile_count[p] = (int32_t)c->htiles.size() - c->ph_htile_first[p];
+      if (c->ph_htile_count[p] > c->ph[p].tile_count) c->hess_by_node = false;  // (their partial sums use the phase's tile slots)
+    }
+    if (!c->hess_by_node) c->htiles.clear();
+  }
+
   // ---- Hessian pattern (upper triangle) -----------------------------------------------------
   std::vector<int32_t>&hr = c->hrow, &hc = c->hcol;
   int64_t hpos = 0;
   std::vector<std::map<std::pair<int64_t, int64_t>, int64_t>> edge(c->n_phases);
+  if (c->hess_by_node) {
+    for (int pass = 0; pass < 2; ++pass)  // even-sized blocks first: they all start 16-byte aligned
+      for (auto& T : c->htiles) {
+        int p = 0;
+        while (p + 1 < c->n_phases && T.tile_id >= c->ph[p + 1].tile_first) ++p;
+        const int64_t size = (int64_t)c->ph[p].hn.size() * T.n;
+        if ((int)(size & 1) != pass) continue;
+        T.hess_base = hpos;
+        hpos += size;
+      }
+    hr.assign(hpos, 0), hc.assign(hpos, 0);
+    for (auto& T : c->htiles) {
+      int p = 0;
+      while (p + 1 < c->n_phases && T.tile_id >= c->ph[p + 1].tile_first) ++p;
+      const PhaseStruct& P = c->ph[p];
+      const int64_t ns = (int64_t)P.hn.size();
+      for (int64_t l = 0; l < T.n; ++l) {
+        const int64_t i = T.i0 + l;
+        int64_t q = 0;
+        for (auto& e : P.hn) {
+          const int64_t r = zcol(*c, P, e.a, e.b, i), cc = zcol(*c, P, e.c, e.d, i);
+          const int64_t at = T.hess_base + slot_index(q, l, T.n, ns);
+          hr[at] = (int32_t)r, hc[at] = (int32_t)cc;
+          if (i == 0 || i == N - 1) edge[p][{r, cc}] = at;
+          ++q;
+        }
+      }
+    }
+  } else {
   for (int pass = 0; pass < 2; ++pass)
     for (auto& B : c->buckets)
       for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
@@ -496,6 +548,7 @@ int build_layout(mpx_ctx* c) {
       }
     }
   }
+  }  // (bucket-ordered hess_l tiles)
   c->mg_off.assign(MPX_MAX_PHASES, 0);
   c->hc_off.assign(MPX_MAX_PHASES, 0);
   c->th_off.assign(MPX_MAX_PHASES, 0);
@@ -551,6 +604,15 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     if (e != hipSuccess) return fail(c, MPX_ERR_INVALID, "code object lacks kernel %s", name);
   }
   int rc;
+  if (c->hess_by_node) {
+    for (int p = 0; p < c->n_phases; ++p) {
+      char name[64];
+      snprintf(name, sizeof name, "mpx_node_hessn_%d", p);
+      if (hipModuleGetFunction(&c->fn_hessn[p], c->module, name) != hipSuccess)
+        return fail(c, MPX_ERR_INVALID, "code object lacks kernel %s (mixed-degree grid: node-ordered hess_l tiles)", name);
+    }
+    if ((rc = upload(c, &c->d_htiles, c->htiles)) || (rc = upload(c, &c->d_node_seg, c->node_seg)) || (rc = upload(c, &c->d_node_tk, c->node_tk))) return rc;
+  }
   for (auto& t : c->degs) {
     if ((rc = upload(c, &t.d_D, t.D))) return rc;
     if ((rc = upload(c, &t.d_Cmid, t.Cmid))) return rc;
@@ -772,7 +834,34 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   if (geom.begin && nodes) HIPCHK(c, hipEventRecord(geom.begin, c->stream));
   // absorbing buckets (see build_layout) go last: their tiles read what the other buckets staged
   const bool absorb = packed && !shard && c->absorb;
-  for (int pass = 0; pass < 2; ++pass)
+  const bool by_node = mode == MPX_MODE_HESS && c->hess_by_node;
+  if (by_node && nodes) {  // mixed-degree grid: one launch per phase over node-ordered tiles
+    for (int p = 0; p < c->n_phases; ++p) {
+      int64_t lo = c->ph_htile_first[p], hi = lo + c->ph_htile_count[p];
+      if (shard) {  // the rank's share of every phase's tiles (same fractions in every phase)
+        const int64_t cnt = c->ph_htile_count[p];
+        const int64_t a0 = c->shard_cuts_h[c->shard_rank] * cnt / c->shard_cuts_h.back(), a1 = c->shard_cuts_h[c->shard_rank + 1] * cnt / c->shard_cuts_h.back();
+        hi = lo + a1, lo = lo + a0;
+      } else if (c->tile_begin != 0 || c->tile_end != (int64_t)c->tiles.size()) {
+        // mpx_set_tile_range: the range [b, e) of the context's tiles maps proportionally onto every phase's node-ordered tiles
+        // (ranges that partition the tiles partition these too)
+        const int64_t cnt = c->ph_htile_count[p], nt = (int64_t)c->tiles.size();
+        hi = lo + c->tile_end * cnt / nt, lo = lo + c->tile_begin * cnt / nt;
+      }
+      if (hi <= lo) continue;
+      const PhaseStruct& P = c->ph[p];
+      MpxHessNodeArgs A{};
+      A.io = io;
+      A.htiles = c->d_htiles, A.node_seg = c->d_node_seg, A.node_tk = c->d_node_tk, A.Wnode = c->d_Wnode;
+      A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
+      A.z_off = P.z_off, A.g_off_F = P.g_off_F, A.g_off_C = P.g_off_C;
+      A.N = (int32_t)c->N, A.seg_off = p * c->S, A.tile_first = (int32_t)lo, A.tile_count = (int32_t)(hi - lo);
+      int rc = launch(c, c->fn_hessn[p], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A);
+      if (rc) return rc;
+      if (c->profile) ++c->prof_launches;
+    }
+  }
+  for (int pass = 0; pass < 2 && !by_node; ++pass)
   for (auto& B : c->buckets) {
     const bool absorber = absorb && B.abs_cap > 0;
     int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);
@@ -860,6 +949,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
     G.ph[p].N = (int32_t)c->N;
     G.ph[p].tile_first = P.tile_first;
     G.ph[p].tile_count = P.tile_count;
+    G.ph[p].tile_count_h = c->hess_by_node ? c->ph_htile_count[p] : P.tile_count;
     G.ph[p].g_off_TC = P.g_off_TC;
     G.ph[p].jac_TC = P.jac_TC;
     G.mg_off[p] = c->mg_off[p];
@@ -938,6 +1028,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     };
     for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk), fr(t.d_Dmid), fr(t.d_tkm);
     for (auto& B : c->buckets) fr(B.d_node_i), fr(B.d_node_sk);
+    fr(c->d_htiles), fr(c->d_node_seg), fr(c->d_node_tk);
     fr(c->d_tiles), fr(c->d_Wnode), fr(c->d_seg_start), fr(c->d_lin_ptr), fr(c->d_lin_idx), fr(c->d_lin_row), fr(c->d_lin_coef);
     fr(c->d_mg_dst), fr(c->d_hc_dst), fr(c->d_th_dst);
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
@@ -1371,7 +1462,7 @@ __global__ __launch_bounds__(256) void mpx_shard_copy_kernel(const MpxShardEnt* 
   if (partials_only && E.kind != 2) return;
   double* __restrict__ base = E.kind == 0 ? vals : (E.kind == 1 ? gtmp : partial);
   if (!base) return;
-  double* __restrict__ pk = buf + (unpack ? (int64_t)E.rank * rank_len * B : 0) + (partials_only ? 0 : E.dst_off * B);
+  double* __restrict__ pk = buf + (unpack ? (int64_t)E.rank * rank_len * B : 0) + (partials_only ? E.part_off : E.dst_off) * B;
   const int64_t n = B * E.len;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = e / E.len, i = e - b * E.len;
@@ -1397,6 +1488,26 @@ std::vector<int64_t> shard_cuts(const std::vector<int64_t>& w, int world) {
   }
   cuts.push_back(n);
   return cuts;
+}
+
+// value runs of the node-ordered hess_l tiles rank r owns (merged where adjacent)
+void hess_node_runs(const mpx_ctx* c, int r, std::vector<std::pair<int64_t, int64_t>>& runs) {
+  runs.clear();
+  for (int p = 0; p < c->n_phases; ++p) {
+    const int64_t cnt = c->ph_htile_count[p], a0 = c->shard_cuts_h[r] * cnt / c->shard_cuts_h.back(), a1 = c->shard_cuts_h[r + 1] * cnt / c->shard_cuts_h.back();
+    for (int64_t h = c->ph_htile_first[p] + a0; h < c->ph_htile_first[p] + a1; ++h)
+      runs.push_back({c->htiles[(size_t)h].hess_base, (int64_t)c->ph[p].hn.size() * c->htiles[(size_t)h].n});
+  }
+  std::sort(runs.begin(), runs.end());
+  size_t o = 0;
+  for (size_t k = 0; k < runs.size(); ++k) {
+    if (runs[k].second <= 0) continue;
+    if (o > 0 && runs[o - 1].first + runs[o - 1].second == runs[k].first)
+      runs[o - 1].second += runs[k].second;
+    else
+      runs[o++] = runs[k];
+  }
+  runs.resize(o);
 }
 
 void shard_runs(const std::vector<MpxTile>& tiles, const std::vector<int64_t>& size, bool hess, int64_t tb, int64_t te,
@@ -1436,19 +1547,37 @@ extern "C" int mpx_shard_setup(mpx_ctx* c, int world, int rank) {
     return MPX_OK;
   }
   c->shard_cuts = shard_cuts(c->tile_jac_size, world);
+  if (c->hess_by_node) {  // hess_l pass: ranks split the node-ordered tiles of every phase in the same proportions
+    const int64_t cnt = c->ph_htile_count.empty() ? 0 : c->ph_htile_count[0];
+    c->shard_cuts_h.assign(1, 0);
+    for (int r = 1; r <= world; ++r) c->shard_cuts_h.push_back(cnt * r / world);
+  }
   c->tile_begin = c->shard_cuts[rank];
   c->tile_end = c->shard_cuts[rank + 1];
   c->run_boundary = 0;
   std::vector<std::pair<int64_t, int64_t>> runs;
+  c->shard_len_part = 0;  // owner-resident exchange: the tile partials only (max over ranks and passes)
   for (int ps = 0; ps < 2; ++ps) {
     for (int r = 0; r < world; ++r) {
       const int64_t tb = c->shard_cuts[r], te = c->shard_cuts[r + 1];
-      int64_t pos = 0;
+      int64_t pos = 0, ppos = 0;
       auto add = [&](int kind, int64_t off, int64_t len, int64_t stride) {
         if (len <= 0) return;
-        c->shard_ent[ps].push_back(MpxShardEnt{off, len, stride, pos, kind, r});
+        c->shard_ent[ps].push_back(MpxShardEnt{off, len, stride, pos, kind, r, kind == 2 ? ppos : 0});
         pos += len;
+        if (kind == 2) ppos += len, c->shard_len_part = std::max(c->shard_len_part, ppos);
       };
+      if (ps == 1 && c->hess_by_node) {
+        hess_node_runs(c, r, runs);
+        for (auto& q : runs) add(0, q.first, q.second, c->nnz_h);
+        for (int p = 0; p < c->n_phases; ++p) {  // the partial sums of its tiles: one run of tile slots per phase
+          const int64_t cnt = c->ph_htile_count[p], a0 = c->shard_cuts_h[r] * cnt / c->shard_cuts_h.back(), a1 = c->shard_cuts_h[r + 1] * cnt / c->shard_cuts_h.back();
+          add(2, (c->ph[p].tile_first + a0) * c->nred, (a1 - a0) * c->nred, nt * c->nred);
+        }
+        c->shard_len[ps] = std::max(c->shard_len[ps], pos);
+        c->shard_ent_first[ps].push_back((int32_t)c->shard_ent[ps].size());
+        continue;
+      }
       shard_runs(c->tiles, ps ? c->tile_hess_size : c->tile_jac_size, ps == 1, tb, te, runs);
       for (auto& q : runs) add(0, q.first, q.second, ps ? c->nnz_h : c->nnz_j);
       if (ps == 0 && te > tb) add(1, c->tiles[tb].g_base, c->tiles[te - 1].g_base + c->tile_g_size[te - 1] - c->tiles[tb].g_base, c->gtmp_n);
@@ -1457,9 +1586,8 @@ extern "C" int mpx_shard_setup(mpx_ctx* c, int world, int rank) {
       c->shard_ent_first[ps].push_back((int32_t)c->shard_ent[ps].size());
     }
     c->shard_len[ps] += c->shard_len[ps] & 1;  // keep every rank's slot 16-byte aligned
-    c->shard_len_part = 0;                     // owner-resident exchange: the tile partials only
-    for (int r = 0; r < world; ++r) c->shard_len_part = std::max(c->shard_len_part, (c->shard_cuts[r + 1] - c->shard_cuts[r]) * c->nred);
     c->shard_len_part += c->shard_len_part & 1;
+
     if (c->has_device) {
       HIPCHK(c, hipSetDevice(c->device));
       int rc = upload(c, &c->d_shard_ent[ps], c->shard_ent[ps]);
@@ -1493,7 +1621,9 @@ extern "C" int mpx_shard_owned(const mpx_ctx* c, int which, int rank, int64_t* n
   if (c->kind != 0) return MPX_ERR_UNSUPPORTED;
   const int64_t tb = c->shard_cuts[rank], te = c->shard_cuts[rank + 1];
   std::vector<std::pair<int64_t, int64_t>> out;
-  if (which == MPX_JAC || which == MPX_HESS) {
+  if (which == MPX_HESS && c->hess_by_node) {
+    hess_node_runs(c, rank, out);
+  } else if (which == MPX_JAC || which == MPX_HESS) {
     shard_runs(c->tiles, which == MPX_HESS ? c->tile_hess_size : c->tile_jac_size, which == MPX_HESS, tb, te, out);
   } else if (which == MPX_G || which == MPX_GRAD) {
     // the packed staging map of build_layout knows which tile holds every node row: rows whose staged position falls into the
@@ -1882,6 +2012,7 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
     for (auto& t : c->degs)
       if (t.deg > 12) return fail(c, MPX_ERR_UNSUPPORTED, "MPX_MID_RESID: polynomial degree %d > 12 (use a residual plan)", t.deg);
     if (c->shard_world > 1) return fail(c, MPX_ERR_UNSUPPORTED, "MPX_MID_RESID on a context in segment-sharded mode");
+    if (c->hess_by_node) return fail(c, MPX_ERR_UNSUPPORTED, "MPX_MID_RESID on a mixed-degree grid (its hess_l tiles are node-ordered: use a residual plan)");
     io.mid_resid = c->mid_resid_out;
     io.mid_stride = (int64_t)c->n_phases * (c->N - 1) * c->nx;
   }

@@ -118,6 +118,17 @@ struct mpx_ctx {
   int run_boundary = 1;
   // host-side sizes of every tile's value blocks (doubles): jac, hess, packed g / grad_f staging
   std::vector<int64_t> tile_jac_size, tile_hess_size, tile_g_size;
+  // mixed-degree grids: node-ordered tiles of the hess_l pass (MpxHTile, mpx_device.h)
+  bool hess_by_node = false;
+  std::vector<MpxHTile> htiles;                     // all phases, phase-major
+  std::vector<int32_t> ph_htile_first, ph_htile_count;
+  std::vector<int32_t> node_seg;
+  std::vector<double> node_tk;
+  MpxHTile* d_htiles = nullptr;
+  int32_t* d_node_seg = nullptr;
+  double* d_node_tk = nullptr;
+  hipFunction_t fn_hessn[MPX_MAX_PHASES] = {};
+  std::vector<int64_t> shard_cuts_h;                // [world + 1] ranges of htiles (per phase the same fractions)
   // segment sharding (mpx_shard_*): this context evaluates the tiles [shard_cuts[rank], shard_cuts[rank + 1]) of every point
   int shard_world = 1, shard_rank = 0;
   std::vector<int64_t> shard_cuts;                  // [world + 1]

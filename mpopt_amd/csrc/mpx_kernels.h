@@ -637,6 +637,95 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// hess_l node pass over node-ordered tiles (mixed-degree grids, MpxHessNodeArgs): lane <-> node i0 + l.  Same arithmetic as the
+// MODE_HESS branch of node_body (G::hess, slot layout of scatter_slots, fixed-order tile sums), without anything that depends
+// on the degree; segment and reference position of a node come from two per-node tables instead of the bucket's node list.
+// ---------------------------------------------------------------------------------------------
+template <int PH>
+__device__ __forceinline__ void hess_by_node_body(const MpxHessNodeArgs& A) {
+  using G = mpxgen::Phase<PH>;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
+  constexpr int NRED = G::NHC, NRED1 = NRED > 0 ? NRED : 1;
+  __shared__ double sRed[2][MPX_TILE / 64][NRED1];
+  const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x, tot_ = gridDim.x * gridDim.y;  // XCD-blocked walk, as node_body
+  const unsigned xcd_ = lin_ % 8, q_ = tot_ / 8, r_ = tot_ % 8;
+  const unsigned item_ = xcd_ * q_ + (xcd_ < r_ ? xcd_ : r_) + lin_ / 8;
+  const unsigned bx_ = item_ % gridDim.x, by_ = item_ / gridDim.x;
+  const MpxHTile T = A.htiles[A.tile_first + bx_];
+  const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
+  const bool own = l < T.n;
+  const int i = T.i0 + (own ? l : 0);
+  const int s = A.node_seg[i];
+  const double tkk = A.node_tk[i], Wn = A.Wnode[i];
+  const int N = A.N;
+  const int64_t n = T.n;
+  const bool vech = (T.hess_base & 1) == 0;
+  const MpxIO& io = A.io;
+  const int b0 = by_ * io.b_per_block;
+  const int b1 = (b0 + io.b_per_block < io.B) ? b0 + io.b_per_block : io.B;
+  const int64_t tslot = (int64_t)T.tile_id * io.nred;
+  struct In {
+    Vec<NX> Xs;
+    Vec<NU> Us;
+    Vec<NA> As;
+    Vec<NX> lF;
+    Vec<NC> lC;
+    double t0v, tfv, ws, wc, sig;
+  };
+  auto load_point = [&](int b, In& q) {
+    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + A.z_off;
+#pragma unroll
+    for (int a = 0; a < NX; ++a) q.Xs[a] = (zb + (int64_t)a * N)[i];
+#pragma unroll
+    for (int c = 0; c < NU; ++c) q.Us[c] = (zb + (int64_t)(NX + c) * N)[i];
+    const double* __restrict__ zt = zb + (int64_t)(NX + NU) * N;
+    q.t0v = zt[0], q.tfv = zt[1];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) q.As[c] = zt[2 + c];
+    const int64_t woff = (int64_t)b * io.w_stride + A.seg_off + s;
+    q.ws = io.w[woff], q.wc = io.wcum[woff];
+    const double* __restrict__ lb = io.lam_g + (int64_t)b * io.lam_stride;
+#pragma unroll
+    for (int a = 0; a < NX; ++a) q.lF[a] = (lb + (A.g_off_F + (int64_t)a * N))[i];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) q.lC[j] = (lb + (A.g_off_C + (int64_t)j * N))[i];
+    q.sig = io.sigma[b];
+  };
+  In cur, nxt;
+  if (b0 < b1) load_point(b0, cur);
+  int it = 0;
+  for (int b = b0; b < b1; ++b, ++it) {
+    const int buf = it & 1;
+    if (b + 1 < b1) load_point(b + 1, nxt);  // before this point's stores: memory operations retire in order
+    __syncthreads();
+    if (it > 0 && l < NRED) {  // publish the previous point's tile sums
+      double v = 0;
+#pragma unroll
+      for (int w = 0; w < MPX_TILE / 64; ++w) v += sRed[buf ^ 1][w][l];
+      io.partial[((int64_t)(b - 1) * io.n_tiles_total) * io.nred + tslot + l] = v;
+    }
+    const double kap = cur.ws * A.inv_dtau, th = cur.wc + cur.ws * tkk;
+    Vec<G::NHN> hn;
+    Vec<NRED> red;
+    G::hess(cur.Xs, cur.Us, cur.t0v, cur.tfv, cur.As, kap, th, Wn, cur.sig, cur.lF, cur.lC, hn, red);
+    scatter_slots<G::NHN>(io.hess + (int64_t)b * io.hess_stride + T.hess_base, n, l, own, vech, [&](int q) { return hn[q]; });
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) {
+      double v = wave_sum(own ? red[r] : 0.0);
+      if (lane == 0) sRed[buf][wave][r] = v;
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  if (it > 0 && l < NRED) {
+    double v = 0;
+#pragma unroll
+    for (int w = 0; w < MPX_TILE / 64; ++w) v += sRed[(it - 1) & 1][w][l];
+    io.partial[((int64_t)(b1 - 1) * io.n_tiles_total) * io.nred + tslot + l] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Off-node evaluation: interpolated states/controls, their polynomial derivatives and the dynamics
 // residual  DXi - h_s*Sx*dyn(Xi/Sx, Ui/Su, ti, a)  at arbitrary points of every segment
 // (mpopt.interpolate_single_phase / get_dynamics_residuals_single_phase, mpopt.py:1428-1543).
@@ -768,7 +857,7 @@ __device__ __forceinline__ void boundary_phase(const MpxBoundArgs& A, int b, int
   {
     __shared__ double sPart[256];
     const double* __restrict__ pp = io.partial + ((int64_t)b * io.n_tiles_total + P.tile_first) * io.nred;
-    const int nred = io.nred, total = P.tile_count * nred;
+    const int nred = io.nred, total = (MODE == MPX_MODE_HESS ? P.tile_count_h : P.tile_count) * nred;
     const int per = (256 / nred) * nred;  // whole tiles per chunk
     double s = 0;
     for (int c0 = 0; c0 < total; c0 += per) {
@@ -897,6 +986,11 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A) {
   }                                                                                                         \
   extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_resid_##PH##_##P(const MpxResidArgs A) {       \
     mpxk::resid_body<PH, P>(A);                                                                             \
+  }
+
+#define MPX_INSTANTIATE_HESS_BY_NODE(PH)                                                                    \
+  extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_hessn_##PH(const MpxHessNodeArgs A) {  \
+    mpxk::hess_by_node_body<PH>(A);                                                                         \
   }
 
 #define MPX_INSTANTIATE_BOUNDARY()                                                                          \

@@ -71,7 +71,9 @@ def _worker(rank, world, port, q):
                     mine[int(kind)][sl] = full[int(kind)][sl]
         # every tile-produced value is owned exactly once; what nobody owns belongs to the boundary pass (terminal / linking entries)
         jr, jc = (o.jac_pattern() if mask != MPX_HESS else o.hess_pattern())
-        assert owned[0].max() == 1 and owned[2].min() == 1 and owned[2].max() == 1
+        assert owned[0].max() == 1 and owned[2].max() == 1
+        # (hess_l on a mixed-degree grid runs over node-ordered tiles: fewer of them than bucket tiles, the spare slots are nobody's)
+        assert owned[2].min() == 1 or mask == MPX_HESS
         if 1 in sizes and sizes[1]:
             stride1 = int(tab[tab[:, 1] == 1][0, 4])
             assert owned[1].reshape(B, -1)[:, :stride1].min() == 1

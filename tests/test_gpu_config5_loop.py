@@ -73,18 +73,18 @@ def test_config5_loop_device_resident():
     assert np.abs(p.cpu().numpy() - ph).max() > 1e-6
 
 
-@pytest.mark.parametrize("case", ["hyper_sensitive_4000x3", "kitchen_sink_mixed", "dae_vdp_30x7"])
+@pytest.mark.parametrize("case", ["hyper_sensitive_4000x3", "kitchen_sink_40x4", "dae_vdp_30x7"])
 def test_mid_point_residuals_fused_into_the_hess_pass(case):
     """MPX_MID_RESID: the node kernels of the hess_l pass also write the dynamics residuals at the mid-points of every segment.  They
     equal the residual plan over the same target points (same fma chains: compared at 1e-13, and bit for bit where the compiler
     keeps the generated node function identical in both kernels), hess_l itself is unchanged bit for bit, and the numpy oracle
-    confirms a sample of segments -- single phase at config-5 size, and a two-phase problem with parameters, several states and
-    mixed degrees."""
+    confirms a sample of segments -- single phase at config-5 size, and a two-phase problem with parameters and several states.
+    (Mixed-degree grids run hess_l over node-ordered tiles and refuse the flag: a residual plan serves them.)"""
     import torch
     from mpopt_amd._lib import MPX_MID_RESID
 
     builder, S, po, scheme = {"hyper_sensitive_4000x3": (problems.hyper_sensitive, 4000, 3, "LGR"),
-                              "kitchen_sink_mixed": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR"),
+                              "kitchen_sink_40x4": (problems.kitchen_sink, 40, 4, "LGR"),
                               "dae_vdp_30x7": (problems.dae_vdp, 30, 7, "LGL")}[case]
     ocp = builder(mp, M.math)
     mpo = mp.mpopt(ocp, S, po, scheme)
@@ -141,6 +141,18 @@ def test_mid_point_residuals_fused_into_the_hess_pass(case):
     with pytest.raises(M.MpxError):
         o.eval_device(MPX_HESS | MPX_MID_RESID, B, Z, p, 1, lam, sig, None, None, None, None, H1)
     o.close()
+    if case == "dae_vdp_30x7":  # a mixed-degree grid refuses the flag
+        mpo2 = mp.mpopt(ocp, 6, [3, 6, 3] * 2, scheme)
+        o2 = mpo2.create_nlp()[0]["oracle"]
+        R2 = torch.empty(B, o2.n_nodes - 1, ocp.nx, dtype=torch.float64, device=dev)
+        o2.set_mid_resid_output(R2)
+        z2 = torch.tensor(mpo2.initialize_solution()[None, :].repeat(B, 0), device=dev)
+        p2 = torch.full((6,), 1 / 6, dtype=torch.float64, device=dev)
+        h2 = torch.empty(B, o2.nnz_hess, dtype=torch.float64, device=dev)
+        l2 = torch.zeros(B, o2.n_g, dtype=torch.float64, device=dev)
+        with pytest.raises(M.MpxError, match="mixed-degree"):
+            o2.eval_device(MPX_HESS | MPX_MID_RESID, B, z2, p2, 0, l2, sig, None, None, None, None, h2)
+        o2.close()
 
 
 def test_equal_area_device_rule_on_reference_vectors():
