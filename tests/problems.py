@@ -276,6 +276,22 @@ FULL_EXTRA_CASES = [
 ]
 
 
+#: seeds of the random mixed-degree grids of tests/test_gpu_parity.py::test_random_mixed_degree_grids (round 2's tools/span_soak.py
+#: as a test); __graft_entry__.build() compiles their kernels so that the GPU box finds them in the cache
+SOAK_SEEDS = [3, 11, 12, 22, 29, 40]
+
+
+def soak_case(seed):
+    """(builder, n_segments, poly_orders, scheme) of a random mixed-degree grid: 2-3 distinct degrees in runs of random length."""
+    rng = np.random.default_rng(seed)
+    degs = rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 13, 16, 20, 30], size=int(rng.integers(2, 4)), replace=False)
+    S = int(rng.integers(2, 400))
+    runs = rng.integers(1, int(rng.integers(2, 40)), size=S)
+    po = np.repeat(rng.choice(degs, size=S), runs)[:S].tolist()
+    builder = [van_der_pol, dae_vdp, kitchen_sink, two_phase_schwartz, hyper_sensitive][seed % 5]
+    return builder, S, po, ["LGR", "LGL", "CGL"][seed % 3]
+
+
 def sample_point(name, n_z, n_p, n_g, z0, lbx, ubx):
     """Deterministic evaluation point: Z0 + seeded perturbation clipped
     to the bounds, non-uniform positive widths summing to one per phase, N(0,1) multipliers."""

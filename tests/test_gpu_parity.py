@@ -647,3 +647,60 @@ def test_numpy_style_problem_on_gpu():
         Jb[jr, jc] = q["jac_g"][i]
         gl[i] = sig * q["grad_f"][i] + lam @ Jb
     assert np.abs((gl[:k] - gl[k:]).T / (2 * eps) - H[:, cols]).max() < 1e-5 * max(1.0, np.abs(H).max())
+
+
+@pytest.mark.parametrize("seed", problems.SOAK_SEEDS)
+def test_random_mixed_degree_grids(seed, monkeypatch):
+    """Round 2's soak of the row-span scheme (tools/span_soak.py) as a test: a random mixed-degree grid (2-3 distinct degrees in
+    runs of random length, 2-400 segments, five problems, three schemes).  (i) The tiles that assemble whole g / grad_f row
+    spans in LDS against the staging block + unpack pass (MPX_NO_ABSORB), bit for bit, three masks, two batch sizes; (ii) hess_l
+    over node-ordered tiles (round 3) against the bucket-ordered pass (MPX_NO_HESS_BY_NODE) as matrices at 1e-13 -- two layouts
+    of the same entries -- and against the numpy oracle at 1e-10."""
+    import torch
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_HESS, MPX_JAC
+
+    builder, S, po, scheme = problems.soak_case(seed)
+    ocp = builder(mp, M.math)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(seed)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    oa = mpo.create_nlp()[0]["oracle"]
+    monkeypatch.setenv("MPX_NO_ABSORB", "1")
+    monkeypatch.setenv("MPX_NO_HESS_BY_NODE", "1")
+    ob = mp.mpopt(ocp, S, po, scheme).create_nlp()[0]["oracle"]
+    monkeypatch.delenv("MPX_NO_ABSORB")
+    monkeypatch.delenv("MPX_NO_HESS_BY_NODE")
+    for B in (1, 5):
+        Zh = mpo.initialize_solution()[None, :] + 0.05 * rng.standard_normal((B, oa.n_z))
+        Z = torch.tensor(Zh, device=dev)
+        w = rng.uniform(0.4, 1.6, (ocp.n_phases, S))
+        ph = (w / w.sum(axis=1, keepdims=True)).ravel()
+        p = torch.tensor(ph, device=dev)
+        for mask in (MPX_F | MPX_G | MPX_GRAD | MPX_JAC, MPX_F | MPX_G, MPX_GRAD):
+            got = []
+            for o in (oa, ob):
+                mk = lambda *s_: torch.full(s_, float("nan"), dtype=torch.float64, device=dev)
+                f, g, gr, jv = mk(B), mk(B, o.n_g), mk(B, o.n_z), mk(B, o.nnz_jac)
+                o.eval_device(mask, B, Z, p, 0, None, None, f if mask & MPX_F else None, g if mask & MPX_G else None,
+                              gr if mask & MPX_GRAD else None, jv if mask & MPX_JAC else None, None)
+                o.sync()
+                got.append((f, g, gr, jv))
+            for x, y in zip(*got):
+                assert torch.equal(x.isnan(), y.isnan()) and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y)), (seed, B, mask)
+            assert not (mask & MPX_G and got[0][1].isnan().any())
+        lamh, sigh = rng.standard_normal((B, oa.n_g)), rng.uniform(0.5, 1.5, B)
+        ha = oa.eval(["hess_l"], Zh, ph, lam_g=lamh, sigma=sigh)["hess_l"].reshape(B, -1)
+        hb = ob.eval(["hess_l"], Zh, ph, lam_g=lamh, sigma=sigh)["hess_l"].reshape(B, -1)
+        (ra, ca), (rb, cb) = oa.hess_pattern(), ob.hess_pattern()
+        assert set(zip(ra.tolist(), ca.tolist())) == set(zip(rb.tolist(), cb.tolist()))
+        for b in range(B):
+            Ha = sp.coo_matrix((ha[b], (ra, ca)), shape=(oa.n_z, oa.n_z)).tocsr()
+            Hb = sp.coo_matrix((hb[b], (rb, cb)), shape=(oa.n_z, oa.n_z)).tocsr()
+            d = Ha - Hb
+            assert (abs(d).max() if d.nnz else 0.0) <= 1e-13 * max(1.0, abs(Hb).max()), (seed, B, b)
+    if oa.n_z <= 2500:  # sympy Hessian of the whole NLP stays affordable
+        O = OracleNLP(ocp, S, po, scheme)
+        Ho = sp.csr_matrix(np.triu(O.hess_l(Zh[0], ph, sigh[0], lamh[0])))
+        d = sp.coo_matrix((ha[0], (ra, ca)), shape=(oa.n_z, oa.n_z)).tocsr() - Ho
+        assert (abs(d).max() if d.nnz else 0.0) < TOL * max(1.0, abs(Ho).max())
+    oa.close(), ob.close()
