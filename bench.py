@@ -497,7 +497,9 @@ def main():
                          "frac_vs_measured_peak": achieved / HBM_MEASURED_GBS if not (shard and world > 1) else None,
                          "measured_peak": HBM_MEASURED_GBS,
                          "kernel": ("whole loop: mpx_node_hess_0_3 (with the mid-point residuals, MPX_MID_RESID) + mpx_boundary_hess + mpx_equal_area_kernel (wall time of the step)" if loop5
-                                    else "mpx_pts_jac + mpx_gather_kernel" if adaptive else f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*"),
+                                    else ("mpx_pts_jac + mpx_gather_kernel (MPX_NO_FUSE)" if os.environ.get("MPX_NO_FUSE") else "mpx_asm_fgj (fused point + gather pass)") if adaptive
+                                    else "mpx_node_hessn_* (node-ordered tiles of the mixed-degree grid)" if hess_mode and isinstance(P, (list, tuple)) and len(set(P)) > 1
+                                    else f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*"),
                          "kernel_us": kernel_s * 1e6,
                          "bytes_per_eval": bytes_eval, "evals_per_launch": B,
                          "algorithmic_bytes_per_launch": B * bytes_eval},
@@ -517,26 +519,26 @@ def main():
         if extra:
             out["extras"] = dict(extra, note="opt-in MPX_JAC_VARIABLE_ONLY (resident jac buffers keep the constant D / interpolation "
                                              "entries); not the metric: the headline rewrites every entry on every evaluation")
-        # Hessian workloads: HBM traffic of the node kernel from the committed PMC passes (profiles/r2_config*_hess), and the fraction
-        # of peak that traffic amounts to over THIS run's kernel time
-        tfh = os.path.join(ROOT, "profiles", {"config5-hess": "r2_config5_hess", "config2-hess": "r2_config2_hess"}.get(args.workload, "-"), "traffic.json")
-        if os.path.exists(tfh) and B == 4096:
-            tr = json.load(open(tfh))
-            out["roofline"]["traffic"] = tr["bytes_per_launch"]
-            out["roofline"]["frac_by_traffic"] = tr["bytes_per_launch"] / kernel_s / 1e9 / HBM_PEAK_GBS
-            out["roofline"]["traffic_source"] = os.path.relpath(tfh, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
-        # config 3: traffic of the degree-30 kernel (the degree-3 bucket and the boundary pass move another ~5 %)
-        tf3 = os.path.join(ROOT, "profiles", "r2_c3_spans", "traffic.json")
-        if args.workload == "config3-fgj" and B == 512 and os.path.exists(tf3):
-            out["roofline"]["traffic"] = json.load(open(tf3))["bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r2_c3_spans/traffic.json (mpx_node_fgj_0_30 only; rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
-        # HBM traffic of the dominant kernel from the committed PMC passes (same workload only)
-        tf = os.path.join(ROOT, "profiles", "r2_headline", "traffic.json")
-        if os.path.exists(tf):
-            tr = json.load(open(tf))
-            if args.workload == "config2-fgj" and tr["workload"] == {"segments": S, "degree": P, "batch": B}:
-                out["roofline"]["traffic"] = tr["bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r2_headline/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+        # this same command, newest round first), and the fraction of peak that traffic amounts to over THIS run's kernel time
+        def _first(*rel):
+            for r_ in rel:
+                p_ = os.path.join(ROOT, "profiles", r_, "traffic.json")
+                if os.path.exists(p_):
+                    return p_, json.load(open(p_))
+            return None, None
+        tsrc = {"config2-fgj": (("r3_final/headline", "r2_headline"), 4096), "config3-fgj": (("r3_final/c3_fgj", "r2_c3_spans"), 512),
+                "config3-hess": (("r3_final/c3_hess",), 2048), "config5-hess": (("r2_config5_hess",), 4096), "config2-hess": (("r2_config2_hess",), 4096),
+                "adaptive-fgj": (("r3_adaptive2",), 4096)}.get(args.workload)
+        if tsrc and B == tsrc[1]:
+            tfp, tr = _first(*tsrc[0])
+            wl = tr.get("workload") if tr else None
+            if tr and (not isinstance(wl, dict) or wl == {"segments": S, "degree": P, "batch": B}):
+                tb = tr.get("bytes_per_launch", tr.get("bytes_per_pass"))
+                out["roofline"]["traffic"] = tb
+                out["roofline"]["frac_by_traffic"] = tb / kernel_s / 1e9 / HBM_PEAK_GBS
+                out["roofline"]["traffic_source"] = (os.path.relpath(tfp, ROOT) + " (" + str(tr.get("kernel", "the timed kernels")) +
+                                                     "; rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; 2 x FETCH + WRITE)")
         if world == 1 and not args.no_cpu_baseline and args.workload == "config2-fgj":
             from oracle.c_oracle import COracle
 
