@@ -87,13 +87,14 @@ def _build_library_in(tmp, verbose):
     cobj = os.path.join(tmp, "mpx_casadi.o")
     aobj = os.path.join(tmp, "mpx_assembly.o")
     out = os.path.join(tmp, "libmpx.so")
+    extra = os.environ.get("MPX_LIB_HIPCC_FLAGS", "").split()  # diagnostics builds (-DMPX_EA_STAMPS ...)
     cmds = [
         ["g++", "-O2", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", os.path.join(CSRC, "mpx_colloc.cpp"), "-o", obj],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", os.path.join(CSRC, "mpx_casadi.cpp"), "-o", cobj],
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
-         os.path.join(CSRC, "mpx_host.cpp"), "-o", hobj],
+         os.path.join(CSRC, "mpx_host.cpp"), "-o", hobj] + extra,
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
-         os.path.join(CSRC, "mpx_assembly.cpp"), "-o", aobj],
+         os.path.join(CSRC, "mpx_assembly.cpp"), "-o", aobj] + extra,
         [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, aobj, obj, cobj, "-o", out],
     ]
     for cmd in cmds:

@@ -647,6 +647,28 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
 // shuffle scan inside the 64 elements, running carry across them.  Fixed order: results do not depend on anything else.
 // (the scan itself is a device function: mpx_equal_area_kernel runs it on the widths it has just produced, with the same
 // additions in the same order, so that the prefix sums it leaves behind are the ones this kernel would compute)
+// Wavefront scans on the DPP path (row shifts inside the 16-lane rows, then the row broadcasts 15 / 31): six v_mov_dpp pairs + six
+// additions, no LDS crossbar (__shfl_up costs two ds_bpermute per level and their latency six times in a row: the scans of the
+// equal-area kernel spent most of their time there, profiles/r3_config5_loop).  Lanes without a source add +0.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_scan_inclusive(double x) {
+  x += dpp_or_zero<0x111, 0xf>(x);  // row_shr:1
+  x += dpp_or_zero<0x112, 0xf>(x);  // row_shr:2
+  x += dpp_or_zero<0x114, 0xf>(x);  // row_shr:4
+  x += dpp_or_zero<0x118, 0xf>(x);  // row_shr:8
+  x += dpp_or_zero<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+  x += dpp_or_zero<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+__device__ __forceinline__ double wave_shift_up_1(double x) { return dpp_or_zero<0x138, 0xf>(x); }  // wave_shr:1 (lane 0: +0.0)
+__device__ __forceinline__ double wave_last(double x) {  // lane 63's value, in every lane
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
 #define MPX_PREFIX_THREADS 1024
 template <class Load>  // a(s): the s-th width (global memory in mpx_prefix_kernel, LDS in mpx_equal_area_kernel)
 __device__ __forceinline__ void prefix_scan_block(Load a, double* __restrict__ o, int S, int tid, double* wave_tot) {
@@ -664,8 +686,7 @@ __device__ __forceinline__ void prefix_scan_block(Load a, double* __restrict__ o
     for (int k = 0; k < 8; ++k)
       if (s0 + k * 64 < q1) tot += v[k];
   }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d, 64);
+  tot = wave_last(wave_scan_inclusive(tot));
   if (active && lane == 0) wave_tot[wave] = tot;
   __syncthreads();
   double carry = 0;
@@ -683,14 +704,9 @@ __device__ __forceinline__ void prefix_scan_block(Load a, double* __restrict__ o
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int s = s0 + k * 64 + lane;
-      double inc = v[k];
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const double u = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += u;
-      }
-      if (s < q1) o[s] = carry + (inc - v[k]);
-      carry += __shfl(inc, 63, 64);
+      const double inc = wave_scan_inclusive(v[k]);
+      if (s < q1) o[s] = carry + wave_shift_up_1(inc);
+      carry += wave_last(inc);
     }
   }
 }
@@ -1702,42 +1718,22 @@ namespace {
 // alone on its CU and its own 16 wavefronts are all there is to hide load and LDS latency: 4 wavefronts measured 2.3x slower)
 #define MPX_EA_THREADS 1024
 #define MPX_EA_PF 12  // residual samples a lane can prefetch for the next evaluation point (n <= 12 * 1024)
-// Round 3: (i) workgroups are persistent (one per compute unit; the cumulative areas of one evaluation point fill most of its LDS)
-// and, for scalar residuals, fetch the NEXT point's samples into registers before they scan and search the current one -- the
-// load phase (9.6 of 24 us per point, profiles/r3_config5_loop) disappears behind the search; (ii) the exclusive prefix sums of
-// the new widths -- what mpx_prefix_kernel would compute from p_out, same additions in the same order (prefix_scan_256) -- are
-// left in `wcum` when the caller passes it, so that the next evaluation needs no prefix launch (MPX_WIDTHS_UNCHANGED).
-// FAST: scalar residuals, cumulative areas in LDS, next point prefetched, prefix sums of the new widths emitted -- the config-5
-// protocol; the generic instantiation keeps every other case (vector residuals, long sample lists in HBM scratch) and emits none.
-template <bool FAST>
+#define MPX_EA_WR 4   // new segment boundaries per lane in the fast kernel (S <= 4 * 1024)
+// Generic kernel: vector residuals, sample lists of any length (cumulative areas in LDS when they fit, else in HBM scratch), any
+// number of phases.  One workgroup per evaluation point.
 __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const double* __restrict__ resid, int64_t n, int nx, const double* __restrict__ p_in,
                                                              double* __restrict__ p_out, int64_t p_stride_in, int64_t p_stride_out, int S, int seg_off,
-                                                             double damping, double* __restrict__ cum_all, int cum_in_lds, double* __restrict__ wcum,
-                                                             int64_t wcum_stride, int B, long long* dbg) {
-#define MPX_EA_STAMP(k) if (dbg && threadIdx.x == 0 && b == (int)gridDim.x * ((B - 1) / (int)gridDim.x > 0 ? 1 : 0) + 0 && blockIdx.x == 0) dbg[k] = wall_clock64()
+                                                             double damping, double* __restrict__ cum_all, int cum_in_lds, int B) {
   extern __shared__ double s_dyn[];  // cum_in_lds: [n] cumulative areas, then [S + 1] boundaries; else only the boundaries
   constexpr int NT = MPX_EA_THREADS;
   __shared__ double wave_tot[NT / 64];
   __shared__ double total;
-  __shared__ double pre_tot[MPX_PREFIX_THREADS / 64];
   const int l = threadIdx.x;
   const int64_t pos_off = cum_in_lds ? n : 0;
   double* __restrict__ pos = s_dyn + pos_off;
   const int64_t m = n - 1, chunk = (m + NT - 1) / NT;  // m trapezoids; lane l owns the trapezoids [i0, i1)
   const int64_t i0 = l * chunk < m ? l * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
-  constexpr bool prefetch = FAST;  // (host side: cum_in_lds && nx == 1 && n <= MPX_EA_PF * NT && S <= WR * NT && single phase)
-  if constexpr (FAST) cum_in_lds = 1, nx = 1;
-  double pf[FAST ? MPX_EA_PF : 1];
-  auto fetch = [&](int b) {  // |r_i| of the lane's samples l, l + NT, ... of evaluation point b
-    if constexpr (FAST) {
-      const double* __restrict__ r = resid + (int64_t)b * n;
-#pragma unroll
-      for (int k = 0; k < MPX_EA_PF; ++k) pf[k] = (int64_t)k * NT + l < n ? r[(int64_t)k * NT + l] : 0.0;
-    }
-  };
-  if (prefetch && (int)blockIdx.x < B) fetch(blockIdx.x);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    MPX_EA_STAMP(0);
     const double* __restrict__ r = resid + (int64_t)b * n * nx;
     double* __restrict__ cum = cum_in_lds ? s_dyn : cum_all + (int64_t)b * n;  // cum[i] = area of the first i trapezoids
     auto norm2 = [&](int64_t i) {
@@ -1746,13 +1742,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const do
       for (int a = 0; a < nx; ++a) q = fma(r[i * nx + a], r[i * nx + a], q);
       return sqrt(q);
     };
-    if constexpr (FAST) {
-#pragma unroll
-      for (int k = 0; k < MPX_EA_PF; ++k)
-        if ((int64_t)k * NT + l < n) cum[(int64_t)k * NT + l] = fabs(pf[k]);
-      __syncthreads();
-      if (b + (int)gridDim.x < B) fetch(b + gridDim.x);  // in flight during the scan and the search of this point
-    } else if (cum_in_lds) {  // the residual norms enter LDS with coalesced loads; the scan below turns them into cumulative areas in place
+    if (cum_in_lds) {  // the residual norms enter LDS with coalesced loads; the scan below turns them into cumulative areas in place
       for (int64_t i = l; i < n; i += 8 * NT) {
         double v[8];
 #pragma unroll
@@ -1763,14 +1753,6 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const do
       }
       __syncthreads();
     }
-    MPX_EA_STAMP(1);
-    constexpr int WR = 4;  // S <= 4 * NT with the prefix sums (else the caller gets none: host side)
-    double pin[WR];        // the lane's old widths: requested now, used after the search
-    if constexpr (FAST) {
-      const double* __restrict__ pi_ = p_in + (int64_t)b * p_stride_in + seg_off;
-#pragma unroll
-      for (int k = 0; k < WR; ++k) pin[k] = l + k * NT < S ? pi_[l + k * NT] : 0.0;
-    }
     auto sample = [&](int64_t i) { return cum_in_lds ? cum[i] : norm2(i); };
     const double first = i0 < i1 ? sample(i0) : 0.0;  // (read before the in-place pass of the neighbouring lane overwrites it)
     double tot = 0, prev = first;
@@ -1779,20 +1761,13 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const do
       tot += 0.5 * (prev + nxt);
       prev = nxt;
     }
-    double inc = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      double v = __shfl_up(inc, d, 64);
-      if ((l & 63) >= d) inc += v;
-    }
+    const double inc = wave_scan_inclusive(tot);
     if ((l & 63) == 63) wave_tot[l >> 6] = inc;
     __syncthreads();
-    double off = __shfl_up(inc, 1, 64);
-    if ((l & 63) == 0) off = 0;
+    double off = wave_shift_up_1(inc);
     for (int q = 0; q < (l >> 6); ++q) off += wave_tot[q];
     if (l == NT - 1) total = off + tot;
     __syncthreads();
-    MPX_EA_STAMP(2);
     const double inv = 1.0 / total;
     if (l == 0) cum[0] = 0.0;  // (lane 0 holds sample 0 in `first`)
     prev = first;
@@ -1803,7 +1778,6 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const do
       cum[i + 1] = i + 1 == m ? 1.0 : off * inv;  // (the reference divides by the last entry: exactly 1 there)
     }
     __syncthreads();
-    MPX_EA_STAMP(3);
     if (l == 0) pos[0] = 0.0;
     // lane l owns a contiguous run of boundaries: one binary search for the first, then a forward walk (targets are monotone)
     const int per = (S + NT - 1) / NT, s0 = l * per < S ? l * per : S, s1 = s0 + per < S ? s0 + per : S;
@@ -1823,37 +1797,159 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const do
       pos[s + 1] = ((double)(j - 1) + (target - cum[j - 1]) / (cum[j] - cum[j - 1])) / (double)m;
     }
     __syncthreads();
-    MPX_EA_STAMP(4);
     const double* __restrict__ pi = p_in + (int64_t)b * p_stride_in + seg_off;
     double* __restrict__ po = p_out + (int64_t)b * p_stride_out + seg_off;
-    if constexpr (!FAST) {
-      for (int s = l; s < S; s += 8 * NT) {
-        double v[8];
+    for (int s = l; s < S; s += 8 * NT) {
+      double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = s + k * NT < S ? pi[s + k * NT] : 0.0;
+      for (int k = 0; k < 8; ++k) v[k] = s + k * NT < S ? pi[s + k * NT] : 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (s + k * NT < S) po[s + k * NT] = damping * (pos[s + k * NT + 1] - pos[s + k * NT]) + (1.0 - damping) * v[k];
-      }
-    } else {
-      // the new widths also replace the boundaries in LDS (registers first: a lane's pos[s + 1] is its neighbour's pos[s]), then
-      // the workgroup scans them exactly as mpx_prefix_kernel scans p_out (MPX_PREFIX_THREADS == MPX_EA_THREADS)
-      double wn[WR];
-#pragma unroll
-      for (int k = 0; k < WR; ++k) {
-        const int s = l + k * NT;
-        wn[k] = s < S ? damping * (pos[s + 1] - pos[s]) + (1.0 - damping) * pin[k] : 0.0;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < WR; ++k) {
-        const int s = l + k * NT;
-        if (s < S) pos[s] = wn[k], po[s] = wn[k];
-      }
-      __syncthreads();
-      prefix_scan_block([&](int s) { return s_dyn[pos_off + s]; }, wcum + (int64_t)b * wcum_stride + seg_off, S, l, pre_tot);
+      for (int k = 0; k < 8; ++k)
+        if (s + k * NT < S) po[s + k * NT] = damping * (pos[s + k * NT + 1] - pos[s + k * NT]) + (1.0 - damping) * v[k];
     }
+    __syncthreads();  // LDS is rewritten by the next point
+  }
+}
+
+// Fast kernel -- the config-5 protocol: scalar residuals, single phase, n <= 12 * 1024 samples, S <= 4 * 1024 segments.
+//  * persistent: one workgroup per compute unit; the NEXT point's samples are fetched into registers (coalesced) before the current
+//    point is scanned and searched, so the load phase disappears behind the rest;
+//  * the samples live in LDS in rows of `chunk` (= the trapezoids of one lane) padded to an odd number of doubles: a lane reads its
+//    row into registers and writes the cumulative areas back over it without bank conflicts (the unpadded layout of the generic
+//    kernel serialises every access four-fold at chunk = 12), one pass over LDS instead of two;
+//  * every new boundary is found by its own branch-free binary search, the lane's four searches interleaved (targets l, l + 1024,
+//    ...): the walk of the generic kernel is as long as the flattest stretch of the residual curve -- the slowest lane set the pace;
+//  * the exclusive prefix sums of the new widths -- what mpx_prefix_kernel would compute from p_out, same additions in the same
+//    order (prefix_scan_block) -- are left in `wcum`, so that the next evaluation needs no prefix launch (MPX_WIDTHS_UNCHANGED).
+// Same rule, same searches (first j with cum[j] >= target) as the generic kernel; the cumulative sums associate differently.
+__global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(const double* __restrict__ resid, int n, const double* __restrict__ p_in,
+                                                                  double* __restrict__ p_out, int64_t p_stride_in, int64_t p_stride_out, int S,
+                                                                  double damping, double* __restrict__ wcum, int64_t wcum_stride, int B, int chunk,
+                                                                  unsigned magic, int pad, int pos_off, long long* dbg) {
+#ifdef MPX_EA_STAMPS  // phase stamps of the second point of workgroup 0 (-DMPX_EA_STAMPS + MPX_EA_DEBUG=1)
+#define MPX_EA_STAMP(k) if (dbg && threadIdx.x == 0 && blockIdx.x == 0 && b == (int)gridDim.x * ((B - 1) / (int)gridDim.x > 0 ? 1 : 0)) dbg[k] = wall_clock64()
+#else
+#define MPX_EA_STAMP(k)
+#endif
+  extern __shared__ double s_dyn[];  // padded samples / cumulative areas, then [S + 1] boundaries at pos_off
+  constexpr int NT = MPX_EA_THREADS, PF = MPX_EA_PF, WR = MPX_EA_WR;
+  __shared__ double wave_tot[NT / 64];
+  __shared__ double pre_tot[MPX_PREFIX_THREADS / 64];
+  const int m = n - 1;
+  auto phys = [&](int i) { return i + (pad ? (int)__umulhi((unsigned)i, magic) : 0); };  // i + i / chunk (exact for i < 2^32 / chunk)
+  double* __restrict__ cum = s_dyn;
+  double* __restrict__ pos = s_dyn + pos_off;
+  double pf[PF];
+  auto fetch = [&](int b, int l) {  // (indices clamped, not predicated: the loads of one point are issued back to back)
+    const double* __restrict__ r = resid + (int64_t)b * n;
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (k * NT < n) pf[k] = r[min(k * NT + l, m)];
+  };
+  if ((int)blockIdx.x < B) fetch(blockIdx.x, threadIdx.x);
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    // (the lane id is opaque per point: everything derived from it is recomputed here with a few integer operations instead of
+    // being hoisted out of the loop into registers the 128-VGPR budget of a 1024-lane workgroup does not have)
+    int l = threadIdx.x;
+    asm volatile("" : "+v"(l));
+    MPX_EA_STAMP(0);
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (k * NT < n) cum[phys(k * NT + l)] = fabs(pf[k]);  // (slots past sample m are never read: the host sized the rows for them)
+    __syncthreads();
+    if (b + (int)gridDim.x < B) fetch(b + gridDim.x, l);  // in flight during the scan and the search of this point
+    double pin[WR];  // the lane's old widths: requested now, used after the search
+    {
+      const double* __restrict__ pi_ = p_in + (int64_t)b * p_stride_in;
+#pragma unroll
+      for (int k = 0; k < WR; ++k) pin[k] = pi_[min(l + k * NT, S - 1)];
+    }
+    MPX_EA_STAMP(1);
+    // lane l owns the trapezoids [i0, i0 + cnt) = its row of the padded layout; its samples i0 ... i0 + cnt are read twice (row sums,
+    // then cumulative areas written back over them); the last one is the next lane's first -- the first slot of the next row,
+    // overwritten by THIS lane only, so the next lane keeps its copy (`first`)
+    const int i0 = l * chunk < m ? l * chunk : m, cnt = (i0 + chunk < m ? i0 + chunk : m) - i0;
+    const int row = cnt > 0 ? i0 + (pad ? l : 0) : 0;  // phys(i0); lanes without trapezoids read row 0 and use nothing of it
+    const int last = row + chunk + pad;                // slot of sample i0 + chunk
+    const double first = cum[row];
+    double tot = 0, prev = first;
+#pragma unroll
+    for (int t = 0; t < PF; ++t)
+      if (t < chunk) {
+        const double nxt = cum[t + 1 < chunk ? row + t + 1 : last];
+        tot += t < cnt ? 0.5 * (prev + nxt) : 0.0;
+        prev = nxt;
+      }
+    const double inc = wave_scan_inclusive(tot);
+    if ((l & 63) == 63) wave_tot[l >> 6] = inc;
+    __syncthreads();  // (also: every lane has read its `first`)
+    double off = wave_shift_up_1(inc);
+    double total = 0;
+#pragma unroll
+    for (int q = 0; q < NT / 64; ++q) {
+      if (q == (l >> 6)) off += total;
+      total += wave_tot[q];
+    }
+    MPX_EA_STAMP(2);
+    const double inv = 1.0 / total;
+    prev = first;
+#pragma unroll
+    for (int t = 0; t < PF; ++t)
+      if (t < chunk) {
+        const int at = t + 1 < chunk ? row + t + 1 : last;
+        const double nxt = cum[at];
+        off += 0.5 * (prev + nxt);
+        prev = nxt;
+        if (t < cnt) cum[at] = off * inv;
+      }
+    if (l == 0) cum[0] = 0.0, pos[0] = 0.0;
+    if (cnt > 0 && i0 + cnt == m) cum[cnt < chunk ? row + cnt : last] = 1.0;  // (the reference divides by the last entry: exactly 1 there)
+    __syncthreads();
+    MPX_EA_STAMP(3);
+    // first j with cum[j] >= target, j in [0, m]: branch-free lower bound, the same number of probes for every target
+    double target[WR];
+    int base[WR];
+#pragma unroll
+    for (int k = 0; k < WR; ++k) target[k] = (double)(l + k * NT + 1) / (double)S, base[k] = 0;
+#pragma unroll 1
+    for (int len = m + 1; len > 1;) {
+      const int half = len >> 1;
+#pragma unroll
+      for (int k = 0; k < WR; ++k) {
+        const double v = cum[phys(base[k] + half - 1)];
+        base[k] = v < target[k] ? base[k] + half : base[k];
+      }
+      len -= half;
+    }
+#pragma unroll
+    for (int k = 0; k < WR; ++k) {
+      const int s = l + k * NT;
+      int j = base[k] + (cum[phys(base[k])] < target[k] ? 1 : 0);
+      j = j < 1 ? 1 : (j > m ? m : j);
+      const double c0 = cum[phys(j - 1)], c1 = cum[phys(j)];
+      if (s < S) pos[s + 1] = ((double)(j - 1) + (target[k] - c0) / (c1 - c0)) / (double)m;
+    }
+    __syncthreads();
+    MPX_EA_STAMP(4);
+    double* __restrict__ po = p_out + (int64_t)b * p_stride_out;
+    // the new widths also replace the boundaries in LDS (registers first: a lane's pos[s + 1] is its neighbour's pos[s]), then
+    // the workgroup scans them exactly as mpx_prefix_kernel scans p_out (MPX_PREFIX_THREADS == MPX_EA_THREADS)
+    double wn[WR];
+#pragma unroll
+    for (int k = 0; k < WR; ++k) {
+      const int s = min(l + k * NT, S - 1);
+      wn[k] = damping * (pos[s + 1] - pos[s]) + (1.0 - damping) * pin[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WR; ++k) {
+      const int s = l + k * NT;
+      if (s < S) pos[s] = wn[k], po[s] = wn[k];
+    }
+    __syncthreads();
     MPX_EA_STAMP(5);
+    prefix_scan_block([&](int s) { return pos[s]; }, wcum + (int64_t)b * wcum_stride, S, l, pre_tot);
+    MPX_EA_STAMP(6);
     __syncthreads();  // LDS is rewritten by the next point
   }
 #undef MPX_EA_STAMP
@@ -1870,40 +1966,45 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
   const size_t lds_all = (size_t)(n_pts + c->S + 1) * 8, lds_pos = (size_t)(c->S + 1) * 8;
   const int in_lds = lds_all <= 150 * 1024;
   if (lds_pos > 150 * 1024) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_equal_area_widths_device: more than 19199 segments per phase");
+  // the fast kernel (scalar residuals, single phase: the update then covers every width of p_out and leaves the prefix sums of
+  // the new widths for the next evaluation): rows of `chunk` samples padded to an odd stride
+  const int chunk = (int)((n_pts - 1 + MPX_EA_THREADS - 1) / MPX_EA_THREADS), pad = chunk % 2 == 0;
+  // (rows for every staged slot: the lanes stage ceil(n / 1024) * 1024 samples, the ones past the last sample are never read)
+  const int64_t staged = (n_pts + MPX_EA_THREADS - 1) / MPX_EA_THREADS * MPX_EA_THREADS;
+  const int64_t pos_off = (staged + (pad ? staged / chunk : 0) + 2) & ~(int64_t)1;
+  const size_t lds_fast = (size_t)(pos_off + c->S + 1) * 8;
+  const bool fast = c->nx == 1 && c->n_phases == 1 && n_pts <= (int64_t)MPX_EA_PF * MPX_EA_THREADS && c->S <= MPX_EA_WR * MPX_EA_THREADS &&
+                    lds_fast <= 150 * 1024 && !getenv("MPX_EA_GENERIC");
   int rc;
-  if (!in_lds && (rc = reserve(c, c->ea_scratch, (size_t)(batch * n_pts)))) return rc;
-  const size_t lds = in_lds ? lds_all : lds_pos;
+  if (!fast && !in_lds && (rc = reserve(c, c->ea_scratch, (size_t)(batch * n_pts)))) return rc;
+  const size_t lds = fast ? lds_fast : in_lds ? lds_all : lds_pos;
   long long*& dbg = c->ea_dbg;  // per context: freed in mpx_destroy
   if (!dbg && getenv("MPX_EA_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&dbg, 64, hipHostMallocMapped));
   if (lds > 48 * 1024 && lds > c->ea_lds_allowed) {  // the attribute is per device: remembered per context, not per process
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     c->ea_lds_allowed = 150 * 1024;
   }
-  // prefix sums of the new widths for the next evaluation (single-phase contexts: the update then covers every width of p_out)
-  const bool fast = in_lds && c->nx == 1 && c->n_phases == 1 && n_pts <= (int64_t)MPX_EA_PF * MPX_EA_THREADS && c->S <= 4 * MPX_EA_THREADS;
-  double* wc = nullptr;
   if (fast) {
     if ((rc = reserve(c, c->wcum, (size_t)(batch * c->n_p)))) return rc;
-    wc = c->wcum.p;
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    const unsigned grid = (unsigned)std::min<int64_t>(batch, n_cu);  // persistent: a workgroup owns its compute unit's LDS
+    const unsigned magic = (unsigned)((((uint64_t)1 << 32) + chunk - 1) / chunk);  // i / chunk = umulhi(i, magic) for i < 2^32 / chunk
+    hipLaunchKernelGGL(mpx_equal_area_fast_kernel, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream, resid, (int)n_pts, p_in, p_out,
+                       (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, damping, c->wcum.p, (int64_t)c->n_p, (int)batch, chunk, magic, pad, (int)pos_off, dbg);
+  } else {
+    hipLaunchKernelGGL(mpx_equal_area_kernel, dim3((unsigned)batch), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
+                       (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, (int)batch);
   }
-  int n_cu = 256;
-  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-  const unsigned grid = (unsigned)std::min<int64_t>(batch, fast ? n_cu : batch);  // persistent where a workgroup owns its compute unit's LDS
-  if (fast)
-    hipLaunchKernelGGL(mpx_equal_area_kernel<true>, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
-                       (int64_t)(p_in_per_point ? c->n_p : 0), c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, wc, c->n_p, (int)batch, dbg);
-  else
-    hipLaunchKernelGGL(mpx_equal_area_kernel<false>, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
-                       (int64_t)(p_in_per_point ? c->n_p : 0), c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, wc, c->n_p, (int)batch, dbg);
   HIPCHK(c, hipGetLastError());
   // the context's prefix sums now belong to p_out: a following mpx_eval_device(... | MPX_WIDTHS_UNCHANGED, p = p_out, per point,
   // same batch) may use them (the caller's assertion, as always with that flag)
   c->wcum_valid = false;
   if (dbg) {  // MPX_EA_DEBUG: phase stamps of the last workgroup (wall_clock64, 100 MHz)
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    fprintf(stderr, "equal_area phases (us): load %.2f  passA %.2f  passB %.2f  search %.2f  widths %.2f\n", (dbg[1] - dbg[0]) / 100.0, (dbg[2] - dbg[1]) / 100.0,
-            (dbg[3] - dbg[2]) / 100.0, (dbg[4] - dbg[3]) / 100.0, (dbg[5] - dbg[4]) / 100.0);
+    fprintf(stderr, "equal_area phases (us): stage %.2f  row sums %.2f  cumulative areas %.2f  search %.2f  widths %.2f  prefix %.2f\n", (dbg[1] - dbg[0]) / 100.0,
+            (dbg[2] - dbg[1]) / 100.0, (dbg[3] - dbg[2]) / 100.0, (dbg[4] - dbg[3]) / 100.0, (dbg[5] - dbg[4]) / 100.0, (dbg[6] - dbg[5]) / 100.0);
   }
   return MPX_OK;
 }
