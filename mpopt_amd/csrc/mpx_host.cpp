@@ -665,6 +665,15 @@ __device__ __forceinline__ double wave_scan_inclusive(double x) {
   x += dpp_or_zero<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
   return x;
 }
+__device__ __forceinline__ int wave_max_scan_inclusive(int x) {  // x >= 0; lanes without a source contribute 0
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+  return x;
+}
 __device__ __forceinline__ double wave_shift_up_1(double x) { return dpp_or_zero<0x138, 0xf>(x); }  // wave_shr:1 (lane 0: +0.0)
 __device__ __forceinline__ double wave_last(double x) {  // lane 63's value, in every lane
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
@@ -1836,9 +1845,12 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
   __shared__ double wave_tot[NT / 64];
   __shared__ double pre_tot[MPX_PREFIX_THREADS / 64];
   const int m = n - 1;
+  const double inv_m = 1.0 / (double)m;
   auto phys = [&](int i) { return i + (pad ? (int)__umulhi((unsigned)i, magic) : 0); };  // i + i / chunk (exact for i < 2^32 / chunk)
   double* __restrict__ cum = s_dyn;
   double* __restrict__ pos = s_dyn + pos_off;
+  int* __restrict__ jmap = reinterpret_cast<int*>(pos);  // [WR * NT] first-target marks: live between the area scan and the boundaries
+  __shared__ int wave_j[NT / 64];
   double pf[PF];
   auto fetch = [&](int b, int l) {  // (indices clamped, not predicated: the loads of one point are issued back to back)
     const double* __restrict__ r = resid + (int64_t)b * n;
@@ -1856,6 +1868,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
 #pragma unroll
     for (int k = 0; k < PF; ++k)
       if (k * NT < n) cum[phys(k * NT + l)] = fabs(pf[k]);  // (slots past sample m are never read: the host sized the rows for them)
+    reinterpret_cast<int4*>(jmap)[l] = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);  // (the boundaries of the previous point are spent)
     __syncthreads();
     if (b + (int)gridDim.x < B) fetch(b + gridDim.x, l);  // in flight during the scan and the search of this point
     double pin[WR];  // the lane's old widths: requested now, used after the search
@@ -1871,15 +1884,19 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
     const int i0 = l * chunk < m ? l * chunk : m, cnt = (i0 + chunk < m ? i0 + chunk : m) - i0;
     const int row = cnt > 0 ? i0 + (pad ? l : 0) : 0;  // phys(i0); lanes without trapezoids read row 0 and use nothing of it
     const int last = row + chunk + pad;                // slot of sample i0 + chunk
-    const double first = cum[row];
-    double tot = 0, prev = first;
+    // (the row is fetched whole, then used: thirteen LDS reads in flight instead of a read, a wait and an addition thirteen times;
+    // slots past the row's end repeat `last` and are masked by t < cnt)
+    double a[PF + 1];
+    auto load_row = [&]() {
+      a[0] = cum[row];
 #pragma unroll
-    for (int t = 0; t < PF; ++t)
-      if (t < chunk) {
-        const double nxt = cum[t + 1 < chunk ? row + t + 1 : last];
-        tot += t < cnt ? 0.5 * (prev + nxt) : 0.0;
-        prev = nxt;
-      }
+      for (int t = 0; t < PF; ++t) a[t + 1] = cum[t + 1 < chunk ? row + t + 1 : last];
+    };
+    load_row();
+    const double first = a[0];
+    double tot = 0;
+#pragma unroll
+    for (int t = 0; t < PF; ++t) tot += t < cnt ? 0.5 * (a[t] + a[t + 1]) : 0.0;
     const double inc = wave_scan_inclusive(tot);
     if ((l & 63) == 63) wave_tot[l >> 6] = inc;
     __syncthreads();  // (also: every lane has read its `first`)
@@ -1892,43 +1909,77 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
     }
     MPX_EA_STAMP(2);
     const double inv = 1.0 / total;
-    prev = first;
+    load_row();
+    a[0] = first;
 #pragma unroll
-    for (int t = 0; t < PF; ++t)
-      if (t < chunk) {
-        const int at = t + 1 < chunk ? row + t + 1 : last;
-        const double nxt = cum[at];
-        off += 0.5 * (prev + nxt);
-        prev = nxt;
-        if (t < cnt) cum[at] = off * inv;
-      }
-    if (l == 0) cum[0] = 0.0, pos[0] = 0.0;
+    for (int t = 0; t < PF; ++t) {
+      off += 0.5 * (a[t] + a[t + 1]);
+      if (t < cnt) cum[t + 1 < chunk ? row + t + 1 : last] = off * inv;
+    }
+    if (l == 0) cum[0] = 0.0;
     if (cnt > 0 && i0 + cnt == m) cum[cnt < chunk ? row + cnt : last] = 1.0;  // (the reference divides by the last entry: exactly 1 there)
     __syncthreads();
     MPX_EA_STAMP(3);
-    // first j with cum[j] >= target, j in [0, m]: branch-free lower bound, the same number of probes for every target
-    double target[WR];
-    int base[WR];
+    // New boundaries without a search.  kc(j) = number of targets T_s = (s + 1) / S not above cum[j] is a product and a floor
+    // (an fma and a division settle the rare products within rounding of an integer); sample j is the first one at or above T_s
+    // exactly for s in [kc(j - 1), kc(j)), so every lane marks, for its own samples, the FIRST such target (jmap, aliased on the
+    // boundaries, cleared above) and a running maximum over the targets -- four per lane, a DPP scan per wavefront, sixteen
+    // wavefront totals -- fills in the rest.  (14 dependent, divergent LDS probes per target, conflicts included, were 6 of the
+    // 13.6 us of a point: profiles/r3_config5_loop.)  Same answer as the generic kernel's searches: first j with
+    // cum[j] >= fl((s + 1) / S), j >= 1.
+    {
+      const double Sd = (double)S;
+      auto not_above = [&](double c) {  // #{s in [0, S): fl((s + 1) / S) <= c}, c in [0, 1]
+        const double x = c * Sd, xf = floor(x), d = x - xf;
+        int q = (int)xf;
+        if (d == 0.0 || d > 1.0 - 2e-12) {  // (rare: the rounded product is an integer, or within rounding below the next one)
+          if (fma(c, Sd, -xf) < 0.0) --q;   // the product was rounded up to an integer: q = floor(c S) exactly now
+          // s + 1 <= q: (s + 1) / S <= c before rounding, hence after.  s + 1 = q + 1 is above c, but the quotient may round down to it
+          if (q < S && (double)(q + 1) / Sd <= c) ++q;
+        }
+        return q < S ? q : S;
+      };
+      load_row();
+      int kprev = not_above(a[0]);
 #pragma unroll
-    for (int k = 0; k < WR; ++k) target[k] = (double)(l + k * NT + 1) / (double)S, base[k] = 0;
-#pragma unroll 1
-    for (int len = m + 1; len > 1;) {
-      const int half = len >> 1;
-#pragma unroll
-      for (int k = 0; k < WR; ++k) {
-        const double v = cum[phys(base[k] + half - 1)];
-        base[k] = v < target[k] ? base[k] + half : base[k];
+      for (int t = 0; t < PF; ++t) {
+        const int kc = not_above(a[t + 1]);
+        if (t < cnt && kc > kprev) atomicMin(&jmap[kprev], i0 + t + 1);
+        kprev = kc;
       }
-      len -= half;
     }
+    MPX_EA_STAMP(7);
+    __syncthreads();
+    MPX_EA_STAMP(8);
+    int jj[WR];
+    {
+      const int4 mk = reinterpret_cast<const int4*>(jmap)[l];  // the marks of targets 4 l ... 4 l + 3 (0x7fffffff: none)
+      jj[0] = mk.x, jj[1] = mk.y, jj[2] = mk.z, jj[3] = mk.w;
+      static_assert(WR == 4, "one 16-byte read per lane");
+#pragma unroll
+      for (int k = 0; k < WR; ++k) jj[k] = jj[k] == 0x7fffffff ? 0 : jj[k];
+#pragma unroll
+      for (int k = 1; k < WR; ++k) jj[k] = max(jj[k], jj[k - 1]);
+      const int inc_j = wave_max_scan_inclusive(jj[WR - 1]);
+      if ((l & 63) == 63) wave_j[l >> 6] = inc_j;
+      int before = __builtin_amdgcn_update_dpp(0, inc_j, 0x138, 0xf, 0xf, false);  // wave_shr:1
+      __syncthreads();  // (also: every lane has read its marks; the boundaries may overwrite them)
+#pragma unroll
+      for (int q = 0; q < NT / 64; ++q)
+        if (q < (l >> 6)) before = max(before, wave_j[q]);
+#pragma unroll
+      for (int k = 0; k < WR; ++k) jj[k] = max(jj[k], before);
+    }
+    MPX_EA_STAMP(9);
 #pragma unroll
     for (int k = 0; k < WR; ++k) {
-      const int s = l + k * NT;
-      int j = base[k] + (cum[phys(base[k])] < target[k] ? 1 : 0);
-      j = j < 1 ? 1 : (j > m ? m : j);
+      const int s = WR * l + k;
+      const int j = jj[k] < 1 ? 1 : jj[k];
+      const double target = (double)(WR * (int)threadIdx.x + k + 1) / (double)S;  // (of the lane, not of the point: hoisted)
       const double c0 = cum[phys(j - 1)], c1 = cum[phys(j)];
-      if (s < S) pos[s + 1] = ((double)(j - 1) + (target[k] - c0) / (c1 - c0)) / (double)m;
+      if (s < S) pos[s + 1] = ((double)(j - 1) + (target - c0) / (c1 - c0)) * inv_m;
     }
+    if (l == 0) pos[0] = 0.0;
     __syncthreads();
     MPX_EA_STAMP(4);
     double* __restrict__ po = p_out + (int64_t)b * p_stride_out;
@@ -1972,14 +2023,14 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
   // (rows for every staged slot: the lanes stage ceil(n / 1024) * 1024 samples, the ones past the last sample are never read)
   const int64_t staged = (n_pts + MPX_EA_THREADS - 1) / MPX_EA_THREADS * MPX_EA_THREADS;
   const int64_t pos_off = (staged + (pad ? staged / chunk : 0) + 2) & ~(int64_t)1;
-  const size_t lds_fast = (size_t)(pos_off + c->S + 1) * 8;
+  const size_t lds_fast = (size_t)(pos_off + std::max<int64_t>(c->S + 1, MPX_EA_WR * MPX_EA_THREADS / 2)) * 8;  // (boundaries, or the marks they alias)
   const bool fast = c->nx == 1 && c->n_phases == 1 && n_pts <= (int64_t)MPX_EA_PF * MPX_EA_THREADS && c->S <= MPX_EA_WR * MPX_EA_THREADS &&
                     lds_fast <= 150 * 1024 && !getenv("MPX_EA_GENERIC");
   int rc;
   if (!fast && !in_lds && (rc = reserve(c, c->ea_scratch, (size_t)(batch * n_pts)))) return rc;
   const size_t lds = fast ? lds_fast : in_lds ? lds_all : lds_pos;
   long long*& dbg = c->ea_dbg;  // per context: freed in mpx_destroy
-  if (!dbg && getenv("MPX_EA_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&dbg, 64, hipHostMallocMapped));
+  if (!dbg && getenv("MPX_EA_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&dbg, 128, hipHostMallocMapped));
   if (lds > 48 * 1024 && lds > c->ea_lds_allowed) {  // the attribute is per device: remembered per context, not per process
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -2005,6 +2056,8 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fprintf(stderr, "equal_area phases (us): stage %.2f  row sums %.2f  cumulative areas %.2f  search %.2f  widths %.2f  prefix %.2f\n", (dbg[1] - dbg[0]) / 100.0,
             (dbg[2] - dbg[1]) / 100.0, (dbg[3] - dbg[2]) / 100.0, (dbg[4] - dbg[3]) / 100.0, (dbg[5] - dbg[4]) / 100.0, (dbg[6] - dbg[5]) / 100.0);
+    fprintf(stderr, "  search = marks %.2f  barrier %.2f  running maximum %.2f  boundaries %.2f\n", (dbg[7] - dbg[3]) / 100.0, (dbg[8] - dbg[7]) / 100.0,
+            (dbg[9] - dbg[8]) / 100.0, (dbg[4] - dbg[9]) / 100.0);
   }
   return MPX_OK;
 }

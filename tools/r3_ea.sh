@@ -13,7 +13,7 @@ PY
 MPX_LIB_HIPCC_FLAGS=-DMPX_EA_STAMPS python -c "
 from mpopt_amd import _lib
 _lib.build_library(force=True)"
-MPX_EA_DEBUG=1 timeout 300 python bench.py --workload config5-loop --no-cpu-baseline --steps 3 --warmup 1 2>&1 | grep "equal_area phases" | tail -4 > $o/stamps.txt; cat $o/stamps.txt
+MPX_EA_DEBUG=1 timeout 300 python bench.py --workload config5-loop --no-cpu-baseline --steps 3 --warmup 1 2>&1 | grep -A1 "equal_area phases" | tail -6 > $o/stamps.txt; cat $o/stamps.txt
 python -c "
 from mpopt_amd import _lib
 _lib.build_library(force=True)"
