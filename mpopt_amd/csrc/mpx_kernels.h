@@ -455,10 +455,19 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
           Ui[c] = v;
         }
         double qWm;
+#ifdef MPX_ABL_MID_NOCOMPUTE  // ablation (tools/r3_midres_ab.py): the stores without the interpolation and the dynamics
+#pragma unroll
+        for (int a = 0; a < NX; ++a) fxm[a] = Xs[a], DXi[a] = 0;
+#else
         G::fg(Xi, Ui, t0v, tfv, As, kap, cur.wc + cur.ws * tkm, 0.0, fxm, ccm, qWm);
+#endif
         double* __restrict__ rb = io.mid_resid + (int64_t)b * io.mid_stride + ((int64_t)A.phase * (N - 1) + (i - 1)) * NX;
 #pragma unroll
-        for (int a = 0; a < NX; ++a) rb[a] = DXi[a] - fxm[a];
+        for (int a = 0; a < NX; ++a)
+#ifdef MPX_ABL_MID_NOSTORE  // ablation: the arithmetic without the stores
+          if (DXi[a] - fxm[a] == 1.2345e300)
+#endif
+            rb[a] = DXi[a] - fxm[a];
       }
       }
     } else {

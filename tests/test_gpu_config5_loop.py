@@ -174,3 +174,49 @@ def test_equal_area_device_rule_on_reference_vectors():
         o.equal_area_widths_device(0, 1, len(r), R, p_in, p_out, damping=1.0)
         o.sync()
         assert np.allclose(p_out.cpu().numpy()[0], Hh[f"equal_area/{k}/widths"], rtol=1e-11, atol=1e-14), k
+
+
+@pytest.mark.parametrize("S", [3, 40, 257, 4096])
+def test_equal_area_kernels_over_sample_counts_and_residual_shapes(S):
+    """mpx_equal_area_widths_device against the reference's rule (numpy restatement pinned by tests/golden/hadaptive.npz) over the
+    shapes that steer the kernels: sample counts around the row lengths of the fast kernel (one to twelve trapezoids per lane, odd
+    and even -- padded or not --, the last lanes empty or partly filled), one past its limit (generic kernel), more evaluation
+    points than compute units (persistent workgroups, prefetch of the next point), and residual curves that are flat, zero over
+    long stretches, a single spike (thousands of boundaries inside one trapezoid) or a ramp.  Damped, widths per point."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    mpo = mp.mpopt(problems.hyper_sensitive(mp, M.math), S, 3, "LGR")
+    o = mpo.create_nlp()[0]["oracle"]
+    A = mp.mpopt_h_adaptive
+    rng = np.random.default_rng(S)
+
+    def curves(B, n):
+        r = rng.uniform(0.1, 1.0, (B, n))
+        r[1 % B] = 1.0                                      # flat
+        if n >= 6:
+            r[2 % B, n // 3: 2 * n // 3 + 1] = 0.0          # no area over a third of the samples
+        if B > 3:
+            r[3] = 1e-6
+            r[3, n // 2] = 1e3                              # a spike
+        if B > 4:
+            r[4] = np.linspace(0.0, 1.0, n)                 # ramp from zero
+        if B > 5 and n >= 8:
+            r[5, : n - n // 4] = 0.0                        # everything in the last quarter
+        return r
+
+    for n, B in ((2, 6), (3, 6), (13, 6), (65, 6), (1024, 6), (1025, 6), (1026, 6), (2049, 6), (2050, 6), (3074, 6), (5000, 6), (11264, 6),
+                 (12288, 6), (12289, 6), (700, 600)):
+        r = curves(B, n)
+        p_in = rng.dirichlet(np.ones(S), B)
+        R = torch.tensor(r.reshape(B, n, 1), device=dev)
+        pi = torch.tensor(p_in, device=dev)
+        po = torch.full((B, S), float("nan"), dtype=torch.float64, device=dev)
+        o.equal_area_widths_device(0, B, n, R, pi, po, damping=0.4, p_in_per_point=1)
+        o.sync()
+        got = po.cpu().numpy()
+        for b in range(B):
+            want = 0.4 * np.asarray(A.get_roots_wrt_equal_area(r[b], S)) + 0.6 * p_in[b]
+            assert np.abs(got[b] - want).max() < 1e-11, (n, b, np.abs(got[b] - want).max())
+            assert abs(got[b].sum() - 1) < 1e-9 and got[b].min() > 0
+    o.close()
