@@ -84,8 +84,8 @@ def max_over_ranks(value, device=None):
 class SegmentShardedEvaluator:
     """One evaluation (or a small batch) split over the ranks of ``group`` by collocation segments.
 
-    ``oracle``: this rank's ``NlpFunctions`` with a device; its stream must be torch's current stream
-    (``oracle.set_stream(torch.cuda.current_stream().cuda_stream)``) so that kernels and collectives are
+    ``oracle``: this rank's ``NlpFunctions`` with a device; every ``eval`` puts it on torch's current stream
+    (``oracle.set_stream(torch.cuda.current_stream().cuda_stream)``) so that kernels and RCCL collectives are
     ordered.  Inputs ``z`` / ``p`` / ``lam_g`` / ``sigma`` are full-size torch tensors on the device,
     identical on all ranks.  ``mode`` (include/mpx.h, mpx_shard_setup):
 
@@ -177,6 +177,11 @@ class SegmentShardedEvaluator:
             return
         vals = hess_val if mask & MPX_HESS else (jac_val if mask & MPX_JAC else None)
         send, recv = self._buffers(mask, batch, z.device)
+        if z.is_cuda and self.backend != "gloo":
+            # RCCL orders its collectives against torch's CURRENT stream: the pack / unpack kernels must be on it too
+            import torch
+
+            o.set_stream(torch.cuda.current_stream(z.device).cuda_stream)
         o.eval_device(mask | fl, batch, z, p, ppp, lam_g, sigma, f, g, grad_f, jac_val, hess_val)  # node kernels of this rank's tiles
         o.shard_pack(mask | fl, batch, vals, send)
         self._collect(send, recv)

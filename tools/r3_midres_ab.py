@@ -29,12 +29,16 @@ lam = torch.randn(B, o.n_g, dtype=torch.float64, device=dev)
 sig = torch.ones(B, dtype=torch.float64, device=dev)
 hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
 R = torch.empty(B, 3 * S, 1, dtype=torch.float64, device=dev)
-res = {(v, m): [] for v in variants for m in ("hess", "hess+mid")}
+bpbs = [int(x) for x in os.environ.get("BPBS", "0").split(",")]  # 0: the library's choice (MPX_BPB unset)
+res = {(v, m, q): [] for v in variants for m in ("hess", "hess+mid") for q in bpbs}
 for ob in objs:
     ob.set_mid_resid_output(R)
 for rnd in range(6):
     for v, ob in zip(variants, objs):
-        for name, mask in (("hess", 16 | 256), ("hess+mid", 16 | 256 | 1024)):
+        for name, mask, q in [(nm, mk, q) for nm, mk in (("hess", 16 | 256), ("hess+mid", 16 | 256 | 1024)) for q in bpbs]:
+            os.environ.pop("MPX_BPB", None)
+            if q:
+                os.environ["MPX_BPB"] = str(q)
             ob.eval_device(16, B, Z, p, 1, lam, sig, None, None, None, None, hv)  # prefix sums of p
             for _ in range(3):
                 ob.eval_device(mask, B, Z, p, 1, lam, sig, None, None, None, None, hv)
@@ -42,6 +46,6 @@ for rnd in range(6):
             ob.timer_start()
             for _ in range(20):
                 ob.eval_device(mask, B, Z, p, 1, lam, sig, None, None, None, None, hv)
-            res[(v, name)].append(ob.timer_stop() / 20 * 1e3)
-for (v, name), t in res.items():
-    print(f"{v or '(default)':40s} {name:9s} median {sorted(t)[len(t) // 2]:7.1f} us   min {min(t):7.1f}")
+            res[(v, name, q)].append(ob.timer_stop() / 20 * 1e3)
+for (v, name, q), t in res.items():
+    print(f"{v or '(default)':40s} {name:9s} bpb {q} median {sorted(t)[len(t) // 2]:7.1f} us   min {min(t):7.1f}")
