@@ -97,6 +97,17 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
   // than per term: fetching 4 or 8 table entries of a variable together gains 15-25 % of it, a term-major loop over all variables
   // (one round trip per term index) or taking the 19-term running width sum out of it (MPX_FUSE_CHAINS) lose more to registers
   // and to the extra phase than they save.
+  // Round 3, late: the FIRST table entry of every variable is requested before any is used (one memory round trip for all the
+  // single-term variables -- states, controls, t0, tf, the segment's width -- instead of one each: the unrolled loop over v with a
+  // run-time term loop inside would not let the compiler overlap them), the remaining terms of the long ones follow in groups of
+  // MPX_FUSE_LOC_G.  Same terms, same order, same fma chains.
+  int ix0[NLOC > 0 ? NLOC : 1];
+  double cf0[NLOC > 0 ? NLOC : 1];
+#pragma unroll
+  for (int v = 0; v < NLOC; ++v) {
+    const int t0 = ltoff[v] < ltoff[v + 1] ? ltoff[v] : (ltoff[v] > 0 ? ltoff[v] - 1 : 0);  // (a variable without terms reads a valid entry it does not use)
+    ix0[v] = S.loc_idx[(int64_t)t0 * n + p], cf0[v] = S.loc_coef[(int64_t)t0 * n + p];
+  }
 #pragma unroll
   for (int v = 0; v < NLOC; ++v) {
     double acc[U];
@@ -106,10 +117,10 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
       for (int u = 0; u < U; ++u) loc[u][v] = CH[u * MPX_FUSE_CHAIN_MAX + slot];
       continue;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc[u] = 0;
     const int t1 = ltoff[v + 1];
-    for (int t = ltoff[v]; t < t1; t += MPX_FUSE_LOC_G) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = ltoff[v] < t1 ? fma(cf0[v], V[u][RAWN + ix0[v]], 0.0) : 0.0;
+    for (int t = ltoff[v] + 1; t < t1; t += MPX_FUSE_LOC_G) {
       int ix[MPX_FUSE_LOC_G];
       double cf[MPX_FUSE_LOC_G];
 #pragma unroll
