@@ -316,6 +316,16 @@ def test_device_pointer_api_matches_host_api():
     o.eval_device(1 | 2, B, Z, p, 0, None, None, f, g, None, None, None)
     o.sync()
     assert (jv == 7.0).all() and np.array_equal(g.cpu().numpy(), ref["g"])
+    # output arrays placed by measurement (alloc_outputs): right shapes, None for outputs the mask does not name, same results
+    outs, rep = o.alloc_outputs(1 | 2 | 4 | 8, B, Z, p, 0, None, None, tries=3)
+    assert outs[4] is None and len(rep["node_us_per_pass"]) == 3 and 0 <= rep["kept"] < 3
+    assert [tuple(x.shape) for x in outs[:4]] == [(B,), (B, o.n_g), (B, o.n_z), (B, o.nnz_jac)]
+    o.eval_device(15, B, Z, p, 0, None, None, *outs)
+    o.sync()
+    for k, v in zip(("f", "g", "grad_f", "jac_g"), outs):
+        assert np.array_equal(v.cpu().numpy(), ref[k]), k
+    outs, rep = o.alloc_outputs(16, B, Z, p, 0, lam, sig, tries=2)
+    assert outs[:4] == [None] * 4 and np.array_equal(outs[4].cpu().numpy(), ref["hess_l"])
 
 
 @pytest.mark.parametrize("case,world", [("kitchen_sink_40", 3), ("vdp_mixed_3_30_3", 2), ("moon_lander_60x5", 4)])
