@@ -364,18 +364,18 @@ def main():
         sig = torch.ones(B, dtype=torch.float64, device=dev)
         hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
         jv = hv
-    # Output arrays placed by measurement (NlpFunctions.alloc_outputs: the fastest of four candidate allocations for THIS kernel and
+    # Output arrays placed by measurement (NlpFunctions.alloc_outputs: the fastest of up to six candidate allocations for THIS kernel and
     # THESE inputs, a one-time set-up step a caller can take as well).  --plain-outputs keeps the plain
     # torch.empty arrays above; `value_placement_median` / `frac_placement_*` below always describe plain allocations.
     placed = None
     if not args.plain_outputs and not adaptive and not shard and not loop5:
         if hess_mode:
             del hv, jv
-            outs, placed = o.alloc_outputs(mask, B, Z, p, 0, lam, sig, tries=4)
+            outs, placed = o.alloc_outputs(mask, B, Z, p, 0, lam, sig, tries=6)
             hv = jv = outs[4]
         else:
             del f, g, gr, jv
-            outs, placed = o.alloc_outputs(mask, B, Z, p, 0, None, None, tries=4)
+            outs, placed = o.alloc_outputs(mask, B, Z, p, 0, None, None, tries=6)
             f, g, gr, jv = outs[:4]
         o.geometry_reset()
 
@@ -523,7 +523,7 @@ def main():
             out["roofline"]["note"] = ("SURVEY 8(d) byte model: it charges all n_g multipliers although the kernel reads only those of rows with second "
                                        "derivatives, and a working set this small is partly Infinity-Cache resident -- a fraction near or above 1 is "
                                        "not an HBM-roofline statement (no PMC traffic for this workload)")
-        out["outputs"] = ("NlpFunctions.alloc_outputs: the fastest of four candidate allocations by measured node-kernel time, one-time set-up "
+        out["outputs"] = ("NlpFunctions.alloc_outputs: the fastest of up to six candidate allocations by measured node-kernel time, one-time set-up "
                           "(candidates, us per pass: %s); value_placement_median / frac_placement_* are plain torch.empty allocations" % placed["node_us_per_pass"]
                           if placed else "plain torch.empty allocations")
         if sweep_us:  # the same kernel on plain allocations: four fresh ones + (the timed one | the four candidates of alloc_outputs)
