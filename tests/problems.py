@@ -16,6 +16,8 @@ two-phase Schwartz  tests/test_mpopt.py:165-202 (examples/Multi-phase/tpschwartz
 generic 2-phase fixture  tests/test_mpopt.py:89-110.
 ``kitchen_sink`` is synthetic: it exercises every feature flag of the transcription at once.
 """
+import os
+
 import numpy as np
 
 
@@ -278,7 +280,7 @@ FULL_EXTRA_CASES = [
 
 #: seeds of the random mixed-degree grids of tests/test_gpu_parity.py::test_random_mixed_degree_grids (round 2's tools/span_soak.py
 #: as a test); __graft_entry__.build() compiles their kernels so that the GPU box finds them in the cache
-SOAK_SEEDS = [3, 11, 12, 22, 29, 40]
+SOAK_SEEDS = [int(x) for x in os.environ["MPX_SOAK_SEEDS"].split(",")] if os.environ.get("MPX_SOAK_SEEDS") else [3, 11, 12, 22, 29, 40]  # (env: one-off wider soaks)
 
 
 def soak_case(seed):
