@@ -1,5 +1,7 @@
 """mpopt_adaptive on the GPU: assembled context (point kernels + gather) against the
 golden vectors produced by the reference's own mpopt_adaptive.create_nlp, and against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -267,6 +269,12 @@ FUSED_CASES = {
     "kitchen_sink_6x4": (problems.kitchen_sink, 6, 4, "LGR"),          # two phases, parameters, explicit time dependence
     "time_dependent_5x3": (problems.time_dependent, 5, 3, "LGR"),
 }
+
+
+for _seed in (int(x) for x in os.environ.get("MPX_FUSED_SOAK_SEEDS", "").split(",") if x):  # one-off wider soaks: random small mixed grids
+    _b, _S, _po, _sch = problems.soak_case(_seed)
+    _S = 3 + _S % 12  # (small enough for the fused kernels to exist: two evaluation points of raw values + z in 60 KB of LDS)
+    FUSED_CASES[f"soak_{_seed}"] = (_b, _S, [1 + q % 5 for q in _po[:_S]] + [2] * max(0, _S - len(_po)), _sch)
 
 
 @pytest.mark.parametrize("name", list(FUSED_CASES))
