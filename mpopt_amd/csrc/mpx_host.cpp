@@ -778,7 +778,8 @@ struct GeomPick {
   hipEvent_t begin, end;  // non-null: bracket the node launches of this pass
 };
 
-GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key) {
+GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig = 0) {
+  const bool light = !(sig & 8);
   const char* env = getenv("MPX_BPB");  // tuning / test override (read per call: tools switch it inside one process)
   if (env && atoi(env) > 0) return {atoi(env), nullptr, nullptr};
   if (mode == MPX_MODE_HESS) return {B >= 2 ? 2 : 1, nullptr, nullptr};
@@ -794,7 +795,7 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key) {
   }
   mpx_ctx::GeomTune* T = nullptr;
   for (auto& t : c->tune)
-    if (t.key == key && t.B == B && t.mode == mode) T = &t;
+    if (t.key == key && t.B == B && t.mode == mode && t.sig == sig) T = &t;
   if (!T) {
     if (c->tune.size() < 8) {
       c->tune.emplace_back();
@@ -807,9 +808,11 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key) {
       (void)hipGetLastError();  // hipErrorNotReady of the queries
       if (!T) return {1, nullptr, nullptr};  // every entry is mid-measurement: this pass is not tuned
     }
-    T->key = key, T->B = B, T->mode = mode, T->stage = 0, T->best = 1, T->uses = 0;
+    T->key = key, T->B = B, T->mode = mode, T->sig = sig, T->stage = 0, T->best = 1, T->uses = 0;
     T->cand[0] = 1;
-    T->cand[1] = (int)std::min<int64_t>(std::max<int64_t>(work / 16384, 2), 8);
+    // (passes without the Jacobian values write little: they are bound by the lifetime of a workgroup, not by HBM -- f alone 272 ->
+    // 156 us, grad_f alone 456 -> 271 us at 16 points per workgroup, config 2, B = 4096; tools/r3_single_oracle_bpb.py)
+    T->cand[1] = light ? (int)std::min<int64_t>(std::max<int64_t>(work / 4096, 2), 16) : (int)std::min<int64_t>(std::max<int64_t>(work / 16384, 2), 8);
     for (auto& e : T->ev)
       if (!e && hipEventCreate(&e) != hipSuccess) return {1, nullptr, nullptr};
   }
@@ -832,7 +835,9 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key) {
 
 int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool owner = false) {
   MpxIO io = io0;
-  const GeomPick geom = pick_geometry(c, io.B, mode, mode == MPX_MODE_HESS ? (const void*)io.hess : (io.jac ? (const void*)io.jac : (const void*)io.g));
+  // (the array that identifies the pass for the geometry measurement: its largest output)
+  const void* geom_key = mode == MPX_MODE_HESS ? (const void*)io.hess : io.jac ? (const void*)io.jac : io.g ? (const void*)io.g : io.grad ? (const void*)io.grad : (const void*)io.f;
+  const GeomPick geom = pick_geometry(c, io.B, mode, geom_key, (io.f ? 1 : 0) | (io.g ? 2 : 0) | (io.grad ? 4 : 0) | (io.jac ? 8 : 0));
   io.b_per_block = geom.bpb;
   // Packed staging of g / grad_f in tile order: (a) mixed-degree phases, full evaluations (a plain mpx_set_tile_range keeps
   // the direct stores); (b) every segment-sharded evaluation (mpx_shard_setup): a rank's tiles are one contiguous run of the

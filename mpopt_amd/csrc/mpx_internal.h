@@ -160,6 +160,7 @@ struct mpx_ctx {
     const void* key = nullptr;  // dominant output array of the pass
     int64_t B = 0;
     int mode = 0, stage = 0, best = 1, uses = 0;
+    int sig = 0;  // which outputs the pass writes (f 1, g 2, grad_f 4, jac 8): the same array is written by passes of different weight
     int cand[2] = {1, 1};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint64_t last_use = 0;
