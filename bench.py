@@ -548,7 +548,7 @@ def main():
             return None, None
         tsrc = {"config2-fgj": (("r3_final/headline", "r2_headline"), 4096), "config3-fgj": (("r3_final/c3_fgj", "r2_c3_spans"), 512),
                 "config3-hess": (("r3_final/c3_hess",), 2048), "config5-hess": (("r2_config5_hess",), 4096), "config2-hess": (("r2_config2_hess",), 4096),
-                "adaptive-fgj": (("r3_adaptive2",), 4096)}.get(args.workload)
+                "adaptive-fgj": (("r3_final/adaptive", "r3_adaptive2"), 4096)}.get(args.workload)
         if tsrc and B == tsrc[1]:
             tfp, tr = _first(*tsrc[0])
             wl = tr.get("workload") if tr else None
