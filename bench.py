@@ -459,7 +459,7 @@ def main():
             f2, g2 = torch.empty_like(f), torch.empty_like(g)
             gr2, jv2 = torch.empty_like(gr), torch.empty_like(jv)
             o.geometry_reset()  # new physical pages (possibly behind old addresses): let the library measure them again
-            for _ in range(6):
+            for _ in range(8):
                 o.eval_device(mask, B, Z, p, 0, None, None, f2, g2, gr2, jv2, None)
             torch.cuda.synchronize()
             o.profile(True)

@@ -176,7 +176,7 @@ int mpx_ccs_perm(const mpx_ctx* ctx, int which, int64_t* perm, int64_t* colind);
 int mpx_get_comp_weights(const mpx_ctx* ctx, double* compW);
 
 /* Large device-pointer batches: the library picks the launch geometry (evaluation points per workgroup) per output array by
- * timing the first four passes that write it (HIP events on the context's stream, no synchronisation; results never depend on
+ * timing four of the first six passes that write it (two unmeasured ones first; HIP events on the context's stream, no synchronisation; results never depend on
  * the geometry), because which geometry streams best depends on where the driver placed the array physically.  A caller that
  * re-allocates its arrays (the same address may come back on other pages) can void the measurements here; they are also
  * repeated every 512 passes. */

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restric
 //    window of the outputs (~9 points deep) instead of 45 points at once, which the HBM controllers serve evenly wherever the
 //    pages lie (slow placements -13 %, the fastest +4 %); config 3: +15 % on a slow-state box.
 //  * Which of the two wins is a property of where the driver put THESE buffers, so for large batches the library measures it:
-//    the first four passes that write a given output array run the two geometries (order A B B A) between HIP events on the context's
+//    after two unmeasured ones the next four passes that write a given output array run the two geometries (order A B B A) between HIP events on the context's
 //    stream (no synchronisation: the timings are read with hipEventQuery once they exist), after which the faster one is used
 //    for that array.  Results do not depend on the geometry (fixed-order reductions; tests/test_gpu_parity.py).
 //  * The Hessian kernels (one short burst per point) take 2; small batches 1.  MPX_BPB overrides, MPX_NO_TUNE=1 pins 1.
@@ -808,7 +808,7 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
       (void)hipGetLastError();  // hipErrorNotReady of the queries
       if (!T) return {1, nullptr, nullptr};  // every entry is mid-measurement: this pass is not tuned
     }
-    T->key = key, T->B = B, T->mode = mode, T->sig = sig, T->stage = 0, T->best = 1, T->uses = 0;
+    T->key = key, T->B = B, T->mode = mode, T->sig = sig, T->stage = -2, T->best = 1, T->uses = 0;
     T->cand[0] = 1;
     // (passes without the Jacobian values write little: they are bound by the lifetime of a workgroup, not by HBM -- f alone 272 ->
     // 156 us, grad_f alone 456 -> 271 us at 16 points per workgroup, config 2, B = 4096; tools/r3_single_oracle_bpb.py)
@@ -818,6 +818,10 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
   }
   T->last_use = ++c->tune_clock;
   if (T->stage == 5 && ++T->uses >= 512) T->stage = 0, T->uses = 0;  // placements can change behind the same address: look again now and then
+  if (T->stage < 0) {  // two unmeasured passes first, one per geometry: the first kernels to touch freshly allocated arrays run slow
+    const int k = T->stage++;  // (measured from the first pass on, the first candidate paid for that and lost: config 4, +8 % left behind)
+    return {T->cand[k == -2 ? 0 : 1], nullptr, nullptr};
+  }
   if (T->stage < 4) {  // measurement passes in the order 0, 1, 1, 0: a clock that is still ramping up cancels out of the sums
     const int k = T->stage++;
     return {T->cand[(k == 1 || k == 2) ? 1 : 0], T->ev[2 * k], T->ev[2 * k + 1]};
@@ -827,7 +831,7 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
     float t[4] = {0, 0, 0, 0};
     for (int k = 0; k < 4; ++k)
       if (hipEventElapsedTime(&t[k], T->ev[2 * k], T->ev[2 * k + 1]) != hipSuccess) t[k] = 1e30f;
-    T->best = (t[1] + t[2]) < 0.99f * (t[0] + t[3]) ? T->cand[1] : T->cand[0];  // the robust geometry unless the other wins clearly
+    T->best = (t[1] + t[2]) < 0.98f * (t[0] + t[3]) ? T->cand[1] : T->cand[0];  // the robust geometry unless the other wins clearly
     T->stage = 5;
   }
   return {T->best, nullptr, nullptr};

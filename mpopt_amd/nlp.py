@@ -299,7 +299,7 @@ class NlpFunctions:
         cands, times = [], []
         for _ in range(max(1, int(tries))):
             outs = [torch.empty(sh, dtype=torch.float64, device=dev) if mask & bit else None for bit, sh in shapes]
-            for _ in range(6):  # (the first four passes into new arrays are the library's own geometry measurement, include/mpx.h)
+            for _ in range(8):  # (the first six passes into new arrays are the library's own geometry measurement, include/mpx.h)
                 self.eval_device(mask, batch, z, p, p_per_point, lam_g, sigma, *outs)
             self.sync()
             self.profile(True)

@@ -24,13 +24,19 @@ f = torch.empty(B, dtype=torch.float64, device=dev)
 g = torch.empty(B, o.n_g, dtype=torch.float64, device=dev)
 gr = torch.empty(B, o.n_z, dtype=torch.float64, device=dev)
 jv = torch.empty(B, o.nnz_jac, dtype=torch.float64, device=dev)
-for name, mask in (("f", 1), ("g", 2), ("grad_f", 4), ("f+g", 3), ("f+g+grad_f", 7), ("jac_g", 8), ("all four", 15)):
+lam = torch.randn(B, o.n_g, dtype=torch.float64, device=dev)
+sig = torch.ones(B, dtype=torch.float64, device=dev)
+hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
+ONLY = os.environ.get("ONLY", "").split(",") if os.environ.get("ONLY") else None
+for name, mask in (("f", 1), ("g", 2), ("grad_f", 4), ("f+g", 3), ("f+g+grad_f", 7), ("jac_g", 8), ("all four", 15), ("hess_l", 16)):
+    if ONLY and name not in ONLY:
+        continue
     row = []
     for bpb in (0, 1, 2, 4, 8, 16):
         os.environ.pop("MPX_BPB", None)
         if bpb:
             os.environ["MPX_BPB"] = str(bpb)
-        args = (mask, B, Z, p, 0, None, None, f if mask & 1 else None, g if mask & 2 else None, gr if mask & 4 else None, jv if mask & 8 else None, None)
+        args = (mask, B, Z, p, 0, lam if mask & 16 else None, sig if mask & 16 else None, f if mask & 1 else None, g if mask & 2 else None, gr if mask & 4 else None, jv if mask & 8 else None, hv if mask & 16 else None)
         for _ in range(8):
             o.eval_device(*args)
         o.sync()
