@@ -308,7 +308,10 @@ int mpx_set_mid_resid_output(mpx_ctx* ctx, double* resid);
  * followed by the reference's damped update (mpopt.py:2587-2590):
  *     p_out[b][phase*S + s] = damping * new_width_s + (1 - damping) * p_in[(b)][phase*S + s]        (the reference: 0.4)
  * p_in is [n_p] (p_in_per_point == 0) or [batch][n_p]; p_out is [batch][n_p]; other phases' entries are not touched.
- * Device pointers, asynchronous on the context's stream. */
+ * Device pointers, asynchronous on the context's stream.  For n_pts <= 12288 samples and <= 4096 segments per phase the update also
+ * leaves the exclusive prefix sums of the phase's new widths on the device (what the next evaluation would compute from p_out, same
+ * additions in the same order): once every phase has been updated, mpx_eval_device(..., p = p_out, p_per_point = 1, same batch) may
+ * pass MPX_WIDTHS_UNCHANGED. */
 int mpx_equal_area_widths_device(mpx_ctx* ctx, int phase, int64_t batch, int64_t n_pts, const double* resid, const double* p_in,
                                  int p_in_per_point, double* p_out, double damping);
 

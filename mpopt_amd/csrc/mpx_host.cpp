@@ -1829,7 +1829,8 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const do
   }
 }
 
-// Fast kernel -- the config-5 protocol: scalar residuals, single phase, n <= 12 * 1024 samples, S <= 4 * 1024 segments.
+// Fast kernel: n <= 12 * 1024 samples, S <= 4 * 1024 segments per phase (the config-5 protocol and everything of its size; scalar or
+// vector residuals -- the 2-norms are formed while the next point is fetched --, one call per phase).
 //  * persistent: one workgroup per compute unit; the NEXT point's samples are fetched into registers (coalesced) before the current
 //    point is scanned and searched, so the load phase disappears behind the rest;
 //  * the samples live in LDS in rows of `chunk` (= the trapezoids of one lane) padded to an odd number of doubles: a lane reads its
@@ -1843,7 +1844,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const do
 __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(const double* __restrict__ resid, int n, const double* __restrict__ p_in,
                                                                   double* __restrict__ p_out, int64_t p_stride_in, int64_t p_stride_out, int S,
                                                                   double damping, double* __restrict__ wcum, int64_t wcum_stride, int B, int chunk,
-                                                                  unsigned magic, int pad, int pos_off, long long* dbg) {
+                                                                  unsigned magic, int pad, int pos_off, int nx, int seg_off, long long* dbg) {
 #ifdef MPX_EA_STAMPS  // phase stamps of the second point of workgroup 0 (-DMPX_EA_STAMPS + MPX_EA_DEBUG=1)
 #define MPX_EA_STAMP(k) if (dbg && threadIdx.x == 0 && blockIdx.x == 0 && b == (int)gridDim.x * ((B - 1) / (int)gridDim.x > 0 ? 1 : 0)) dbg[k] = wall_clock64()
 #else
@@ -1862,10 +1863,21 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
   __shared__ int wave_j[NT / 64];
   double pf[PF];
   auto fetch = [&](int b, int l) {  // (indices clamped, not predicated: the loads of one point are issued back to back)
-    const double* __restrict__ r = resid + (int64_t)b * n;
+    const double* __restrict__ r = resid + (int64_t)b * n * nx;
+    if (nx == 1) {
 #pragma unroll
-    for (int k = 0; k < PF; ++k)
-      if (k * NT < n) pf[k] = r[min(k * NT + l, m)];
+      for (int k = 0; k < PF; ++k)
+        if (k * NT < n) pf[k] = r[min(k * NT + l, m)];
+    } else {  // vector residuals: the 2-norm of a sample, accumulated like the generic kernel's (fma over the components, then sqrt)
+#pragma unroll
+      for (int k = 0; k < PF; ++k)
+        if (k * NT < n) {
+          const double* __restrict__ ri = r + (int64_t)min(k * NT + l, m) * nx;
+          double q = 0;
+          for (int a = 0; a < nx; ++a) q = fma(ri[a], ri[a], q);
+          pf[k] = sqrt(q);
+        }
+    }
   };
   if ((int)blockIdx.x < B) fetch(blockIdx.x, threadIdx.x);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -1882,7 +1894,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
     if (b + (int)gridDim.x < B) fetch(b + gridDim.x, l);  // in flight during the scan and the search of this point
     double pin[WR];  // the lane's old widths: requested now, used after the search
     {
-      const double* __restrict__ pi_ = p_in + (int64_t)b * p_stride_in;
+      const double* __restrict__ pi_ = p_in + (int64_t)b * p_stride_in + seg_off;
 #pragma unroll
       for (int k = 0; k < WR; ++k) pin[k] = pi_[min(l + k * NT, S - 1)];
     }
@@ -1991,7 +2003,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
     if (l == 0) pos[0] = 0.0;
     __syncthreads();
     MPX_EA_STAMP(4);
-    double* __restrict__ po = p_out + (int64_t)b * p_stride_out;
+    double* __restrict__ po = p_out + (int64_t)b * p_stride_out + seg_off;
     // the new widths also replace the boundaries in LDS (registers first: a lane's pos[s + 1] is its neighbour's pos[s]), then
     // the workgroup scans them exactly as mpx_prefix_kernel scans p_out (MPX_PREFIX_THREADS == MPX_EA_THREADS)
     double wn[WR];
@@ -2008,7 +2020,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
     }
     __syncthreads();
     MPX_EA_STAMP(5);
-    prefix_scan_block([&](int s) { return pos[s]; }, wcum + (int64_t)b * wcum_stride, S, l, pre_tot);
+    prefix_scan_block([&](int s) { return pos[s]; }, wcum + (int64_t)b * wcum_stride + seg_off, S, l, pre_tot);
     MPX_EA_STAMP(6);
     __syncthreads();  // LDS is rewritten by the next point
   }
@@ -2026,14 +2038,14 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
   const size_t lds_all = (size_t)(n_pts + c->S + 1) * 8, lds_pos = (size_t)(c->S + 1) * 8;
   const int in_lds = lds_all <= 150 * 1024;
   if (lds_pos > 150 * 1024) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_equal_area_widths_device: more than 19199 segments per phase");
-  // the fast kernel (scalar residuals, single phase: the update then covers every width of p_out and leaves the prefix sums of
-  // the new widths for the next evaluation): rows of `chunk` samples padded to an odd stride
+  // the fast kernel (it leaves the prefix sums of the phase's new widths for the next evaluation; MPX_WIDTHS_UNCHANGED is the caller's
+  // word that every phase has been updated): rows of `chunk` samples padded to an odd stride
   const int chunk = (int)((n_pts - 1 + MPX_EA_THREADS - 1) / MPX_EA_THREADS), pad = chunk % 2 == 0;
   // (rows for every staged slot: the lanes stage ceil(n / 1024) * 1024 samples, the ones past the last sample are never read)
   const int64_t staged = (n_pts + MPX_EA_THREADS - 1) / MPX_EA_THREADS * MPX_EA_THREADS;
   const int64_t pos_off = (staged + (pad ? staged / chunk : 0) + 2) & ~(int64_t)1;
   const size_t lds_fast = (size_t)(pos_off + std::max<int64_t>(c->S + 1, MPX_EA_WR * MPX_EA_THREADS / 2)) * 8;  // (boundaries, or the marks they alias)
-  const bool fast = c->nx == 1 && c->n_phases == 1 && n_pts <= (int64_t)MPX_EA_PF * MPX_EA_THREADS && c->S <= MPX_EA_WR * MPX_EA_THREADS &&
+  const bool fast = n_pts <= (int64_t)MPX_EA_PF * MPX_EA_THREADS && c->S <= MPX_EA_WR * MPX_EA_THREADS &&
                     lds_fast <= 150 * 1024 && !getenv("MPX_EA_GENERIC");
   int rc;
   if (!fast && !in_lds && (rc = reserve(c, c->ea_scratch, (size_t)(batch * n_pts)))) return rc;
@@ -2052,7 +2064,7 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
     const unsigned grid = (unsigned)std::min<int64_t>(batch, n_cu);  // persistent: a workgroup owns its compute unit's LDS
     const unsigned magic = (unsigned)((((uint64_t)1 << 32) + chunk - 1) / chunk);  // i / chunk = umulhi(i, magic) for i < 2^32 / chunk
     hipLaunchKernelGGL(mpx_equal_area_fast_kernel, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream, resid, (int)n_pts, p_in, p_out,
-                       (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, damping, c->wcum.p, (int64_t)c->n_p, (int)batch, chunk, magic, pad, (int)pos_off, dbg);
+                       (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, damping, c->wcum.p, (int64_t)c->n_p, (int)batch, chunk, magic, pad, (int)pos_off, c->nx, phase * c->S, dbg);
   } else {
     hipLaunchKernelGGL(mpx_equal_area_kernel, dim3((unsigned)batch), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
                        (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, (int)batch);

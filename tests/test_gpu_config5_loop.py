@@ -220,3 +220,45 @@ def test_equal_area_kernels_over_sample_counts_and_residual_shapes(S):
             assert np.abs(got[b] - want).max() < 1e-11, (n, b, np.abs(got[b] - want).max())
             assert abs(got[b].sum() - 1) < 1e-9 and got[b].min() > 0
     o.close()
+
+
+@pytest.mark.parametrize("builder,S,nph", [(problems.van_der_pol, 37, 1), (problems.two_phase_schwartz, 300, 2), (problems.kitchen_sink, 9, 2)])
+def test_equal_area_vector_residuals_and_phases(builder, S, nph):
+    """The same rule on the 2-norms of VECTOR residual samples (nx = 2, 3) and per phase of a multi-phase context: the update of one
+    phase leaves the other phase's widths alone, both phases' prefix sums are on the device afterwards (MPX_WIDTHS_UNCHANGED gives
+    the bits of a recomputation), sample counts on both sides of the fast kernel's limit."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    ocp = builder(mp, M.math)
+    assert ocp.n_phases == nph
+    mpo = mp.mpopt(ocp, S, 3, "LGR")
+    o = mpo.create_nlp()[0]["oracle"]
+    A = mp.mpopt_h_adaptive
+    rng = np.random.default_rng(5)
+    B = 7
+    nx = ocp.nx
+    for n in (3 * S, 12289):
+        p_in = np.concatenate([rng.dirichlet(np.ones(S), B) for _ in range(nph)], axis=1)
+        pi = torch.tensor(p_in, device=dev)
+        po = pi.clone()
+        want = p_in.copy()
+        for ph in range(nph):
+            r = rng.uniform(0.0, 1.0, (B, n, nx)) * rng.uniform(0.1, 3.0, (B, n, 1))
+            r[0, n // 4: n // 2] = 0.0
+            R = torch.tensor(r, device=dev)
+            o.equal_area_widths_device(ph, B, n, R, pi, po, damping=0.4, p_in_per_point=1)
+            for b in range(B):
+                want[b, ph * S:(ph + 1) * S] = 0.4 * np.asarray(A.get_roots_wrt_equal_area(np.linalg.norm(r[b], 2, axis=1), S)) + 0.6 * p_in[b, ph * S:(ph + 1) * S]
+            o.sync()
+            got = po.cpu().numpy()
+            assert np.abs(got - want).max() < 1e-11, (n, ph, np.abs(got - want).max())  # (phases not yet updated: still p_in)
+        if n <= 12288:  # both phases updated by the fast kernel: their prefix sums are on the device
+            Z = torch.tensor(mpo.initialize_solution()[None, :] + 0.01 * rng.standard_normal((B, o.n_z)), device=dev)
+            lam, sig = torch.tensor(rng.standard_normal((B, o.n_g)), device=dev), torch.ones(B, dtype=torch.float64, device=dev)
+            H1, H2 = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev), torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
+            o.eval_device(MPX_HESS | MPX_WIDTHS_UNCHANGED, B, Z, po, 1, lam, sig, None, None, None, None, H1)
+            o.eval_device(MPX_HESS, B, Z, po, 1, lam, sig, None, None, None, None, H2)
+            o.sync()
+            assert torch.equal(H1, H2), n
+    o.close()
