@@ -785,7 +785,7 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
   if (mode == MPX_MODE_HESS) return {B >= 2 ? 2 : 1, nullptr, nullptr};
   const int64_t work = B * (c->tile_end - c->tile_begin);
   static const bool no_tune = getenv("MPX_NO_TUNE") != nullptr;
-  if (no_tune || work < 32768 || !key || c->shard_world > 1) return {1, nullptr, nullptr};
+  if (no_tune || work < (light ? 8192 : 32768) || !key || c->shard_world > 1) return {1, nullptr, nullptr};
   {  // no event records / queries inside a stream capture (the caller is building a hipGraph): the robust geometry, no measuring
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -812,7 +812,7 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
     T->cand[0] = 1;
     // (passes without the Jacobian values write little: they are bound by the lifetime of a workgroup, not by HBM -- f alone 272 ->
     // 156 us, grad_f alone 456 -> 271 us at 16 points per workgroup, config 2, B = 4096; tools/r3_single_oracle_bpb.py)
-    T->cand[1] = light ? (int)std::min<int64_t>(std::max<int64_t>(work / 4096, 2), 16) : (int)std::min<int64_t>(std::max<int64_t>(work / 16384, 2), 8);
+    T->cand[1] = light ? (int)std::min<int64_t>(std::max<int64_t>(work / 2048, 2), 16) : (int)std::min<int64_t>(std::max<int64_t>(work / 16384, 2), 8);
     for (auto& e : T->ev)
       if (!e && hipEventCreate(&e) != hipSuccess) return {1, nullptr, nullptr};
   }
@@ -827,7 +827,8 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
     return {T->cand[(k == 1 || k == 2) ? 1 : 0], T->ev[2 * k], T->ev[2 * k + 1]};
   }
   if (T->stage == 4) {
-    if (hipEventQuery(T->ev[7]) != hipSuccess) return {T->cand[0], nullptr, nullptr};  // not there yet
+    // not there yet (the host is running ahead of the device): the prior -- light passes want several points per workgroup
+    if (hipEventQuery(T->ev[7]) != hipSuccess) return {T->cand[light ? 1 : 0], nullptr, nullptr};
     float t[4] = {0, 0, 0, 0};
     for (int k = 0; k < 4; ++k)
       if (hipEventElapsedTime(&t[k], T->ev[2 * k], T->ev[2 * k + 1]) != hipSuccess) t[k] = 1e30f;
