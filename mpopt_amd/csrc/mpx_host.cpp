@@ -785,7 +785,7 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
   if (mode == MPX_MODE_HESS) return {B >= 2 ? 2 : 1, nullptr, nullptr};
   const int64_t work = B * (c->tile_end - c->tile_begin);
   static const bool no_tune = getenv("MPX_NO_TUNE") != nullptr;
-  if (no_tune || work < (light ? 8192 : 32768) || !key || c->shard_world > 1) return {1, nullptr, nullptr};
+  if (no_tune || work < 8192 || !key || c->shard_world > 1) return {1, nullptr, nullptr};
   {  // no event records / queries inside a stream capture (the caller is building a hipGraph): the robust geometry, no measuring
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -827,8 +827,13 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
     return {T->cand[(k == 1 || k == 2) ? 1 : 0], T->ev[2 * k], T->ev[2 * k + 1]};
   }
   if (T->stage == 4) {
-    // not there yet (the host is running ahead of the device): the prior -- light passes want several points per workgroup
-    if (hipEventQuery(T->ev[7]) != hipSuccess) return {T->cand[light ? 1 : 0], nullptr, nullptr};
+    // not there yet (the host is running ahead of the device): the prior -- light passes want several points per workgroup, and so
+    // do passes whose workgroups write little per point (low degrees: 14 KB of Jacobian values per tile at 4000 x 3 against 46 KB at
+    // 1000 x 5 -- the workgroup's prologue then weighs more than the placement effect one point per workgroup is robust against)
+    if (hipEventQuery(T->ev[7]) != hipSuccess) {
+      const bool small_tiles = c->nnz_j * 8 < (int64_t)24576 * (int64_t)std::max<size_t>(c->tiles.size(), 1);
+      return {T->cand[(light || small_tiles) ? 1 : 0], nullptr, nullptr};
+    }
     float t[4] = {0, 0, 0, 0};
     for (int k = 0; k < 4; ++k)
       if (hipEventElapsedTime(&t[k], T->ev[2 * k], T->ev[2 * k + 1]) != hipSuccess) t[k] = 1e30f;
