@@ -318,7 +318,7 @@ def test_device_pointer_api_matches_host_api():
     assert (jv == 7.0).all() and np.array_equal(g.cpu().numpy(), ref["g"])
     # output arrays placed by measurement (alloc_outputs): right shapes, None for outputs the mask does not name, same results
     outs, rep = o.alloc_outputs(1 | 2 | 4 | 8, B, Z, p, 0, None, None, tries=3)
-    assert outs[4] is None and len(rep["node_us_per_pass"]) == 3 and 0 <= rep["kept"] < 3
+    assert outs[4] is None and 1 <= len(rep["node_us_per_pass"]) <= 3 and 0 <= rep["kept"] < len(rep["node_us_per_pass"])  # (the search may stop early)
     assert [tuple(x.shape) for x in outs[:4]] == [(B,), (B, o.n_g), (B, o.n_z), (B, o.nnz_jac)]
     o.eval_device(15, B, Z, p, 0, None, None, *outs)
     o.sync()
