@@ -183,6 +183,12 @@ class AssembledNlpFunctions(NlpFunctions):
                 mt = next((w for w in range(2, 13) if (multi > w).sum() <= 16), 12)
             sizes["MT_" + tag], sizes["NMULTI_" + tag] = int(mt), int(((multi <= mt)).sum()) if len(multi) else 0
             sizes["NLONG_" + tag], sizes["LT_" + tag] = len(longr), int(longr.max()) if len(longr) else 0
+            # distinct coefficients (bit patterns) of the rows with at most one term: the dictionary of the packed row registers
+            # of the fused kernels (mpx_assembly_fused.h, RowRegsPacked; libmpx builds the same dictionary and checks the count)
+            cf = np.ascontiguousarray(self.fgj[2] if tag == "FGJ" else self.hess[2], dtype=np.float64)
+            first = cf[ptr[:-1][nt == 1]] if (nt == 1).any() else np.zeros(0)
+            vals = np.concatenate([first, np.zeros(1 if (nt == 0).any() else 0)])
+            sizes["NDICT_" + tag] = len(np.unique(vals.view(np.int64))) if len(vals) else 0
         self.source = self._source(funcs, sizes)
         if with_device is None:
             with_device = _lib.gpu_available()

@@ -10,6 +10,7 @@
 
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "mpx_internal.h"
@@ -44,6 +45,9 @@ struct DevFused {
   int32_t *r_idx = nullptr, *r_nt = nullptr, *idx = nullptr, *multi = nullptr, *mid = nullptr, *longr = nullptr, *m_idx = nullptr;
   double *r_coef = nullptr, *m_coef = nullptr;
   int32_t n_multi = 0, n_mid = 0, n_long = 0;
+  uint32_t* r_pack = nullptr;  // single-term rows packed (MpxFusedArgs::r_pack); n_dict = 0: not representable (an index or the dictionary past 16 bits)
+  double* r_dict = nullptr;
+  int32_t n_dict = 0;
 };
 
 struct mpx_asm_state {
@@ -216,7 +220,28 @@ int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, in
   std::vector<double> m_coef((size_t)std::max<int64_t>((int64_t)mt * f.n_multi, 1), 0.0);
   for (int32_t m = 0; m < f.n_multi; ++m)
     for (int64_t e = g.ptr[multi[m]], t = 0; e < g.ptr[multi[m] + 1]; ++e, ++t) m_idx[(size_t)(t * f.n_multi + m)] = idx[(size_t)e], m_coef[(size_t)(t * f.n_multi + m)] = g.coef[e];
+  // packed form of the rows with at most one term: position | code << 16, dictionary of the distinct coefficients (bit patterns)
+  std::vector<uint32_t> r_pack((size_t)std::max<int64_t>(g.n_rows, 1), 0xffffffffu);
+  std::vector<double> r_dict;
+  {
+    std::map<uint64_t, uint32_t> code_of;
+    bool ok = raw_n + n_z + 1 <= 65536;
+    for (int64_t r = 0; r < g.n_rows && ok; ++r) {
+      if (r_nt[(size_t)r] > 1) continue;
+      uint64_t bits;
+      memcpy(&bits, &r_coef[(size_t)r], 8);
+      auto it = code_of.find(bits);
+      if (it == code_of.end()) {
+        ok = r_dict.size() < 65535;
+        it = code_of.emplace(bits, (uint32_t)r_dict.size()).first;
+        r_dict.push_back(r_coef[(size_t)r]);
+      }
+      r_pack[(size_t)r] = (uint32_t)r_idx[(size_t)r] | (it->second << 16);
+    }
+    f.n_dict = ok ? (int32_t)r_dict.size() : 0;
+  }
   int rc;
+  if ((rc = upload(c, &f.r_pack, r_pack)) || (rc = upload(c, &f.r_dict, r_dict))) return rc;
   if ((rc = upload(c, &f.r_idx, r_idx)) || (rc = upload(c, &f.r_nt, r_nt)) || (rc = upload(c, &f.r_coef, r_coef)) || (rc = upload(c, &f.idx, idx)) ||
       (rc = upload(c, &f.multi, multi)) || (rc = upload(c, &f.mid, mid)) || (rc = upload(c, &f.longr, longr)) || (rc = upload(c, &f.m_idx, m_idx)) ||
       (rc = upload(c, &f.m_coef, m_coef)))
@@ -246,7 +271,7 @@ void mpx_asm_release(mpx_ctx* c) {
   };
   for (auto& s : a->sets) fr(s.loc_toff), fr(s.loc_idx), fr(s.mu_toff), fr(s.mu_idx), fr(s.loc_coef), fr(s.cst), fr(s.mu_coef);
   for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef), fr(g->long_rows);
-  for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef);
+  for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef), fr(f->r_pack), fr(f->r_dict);
   fr(a->d_ch_ptr), fr(a->d_ch_idx), fr(a->d_ch_slot), fr(a->d_ch_coef);
   for (auto q : a->d_chain_pos) fr(q);
   fr(a->raw.p), fr(a->d_sets), fr(a->d_task_ptr[0]), fr(a->d_task_ptr[1]), fr(a->d_task_list[0]), fr(a->d_task_list[1]);
@@ -403,7 +428,7 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
   {  // fused persistent kernels (mpx_assembly_fused.h): present in code objects generated since round 3
     hipDeviceptr_t sym = nullptr;
     size_t bytes = 0;
-    int info[5] = {0, 0, 0, 0, 0};
+    int info[7] = {0, 0, 0, 0, 0, 0, 0};
     static const char* fname[3] = {"mpx_asm_fg", "mpx_asm_fgj", "mpx_asm_hes"};
     const bool have_info = hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_fuse_info") == hipSuccess && bytes == sizeof info &&
                            hipMemcpyDtoH(info, sym, sizeof info) == hipSuccess && info[0] >= 64 && info[0] <= 1024;
@@ -420,6 +445,10 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
       ok = ok && a->sets.size() <= 16;
       if (ok && (info[1] > 0 || info[2] > 0)) {
         if ((rc = upload_fused(c, a->ffgj, D->fgj, a->raw_n, D->n_z, thr_fgj)) || (rc = upload_fused(c, a->fhess, D->hess, a->rawh_n, D->n_z, thr_hes))) return bail(rc);
+        // kernels compiled for packed single-term rows: the dictionary the generator counted must be the one built here
+        if ((info[5] > 0 && (a->ffgj.n_dict < 1 || a->ffgj.n_dict > info[5])) || (info[6] > 0 && (a->fhess.n_dict < 1 || a->fhess.n_dict > info[6])))
+          return bail(fail(c, MPX_ERR_INVALID, "fused kernels: coefficient dictionary of the single-term rows (%d / %d entries) does not fit the compiled capacity (%d / %d)",
+                           a->ffgj.n_dict, a->fhess.n_dict, info[5], info[6]));
         a->fuse_nt = info[0], a->fuse_u[0] = info[1], a->fuse_u[1] = info[2];
         // point-phase schedule per pass: tasks (evaluation point u, 64-point block) of one chunk onto the NT / 64 wavefronts, longest
         // first onto the least loaded (cost ~ table terms of the block's set + a constant for the function itself)
@@ -539,6 +568,7 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
   A.sets = a->d_sets, A.n_sets = (int32_t)a->sets.size(), A.n_blocks = a->n_blocks, A.n_g = (int32_t)c->n_g, A.B = (int32_t)batch;
   A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma;
   A.r_idx = f.r_idx, A.r_coef = f.r_coef, A.r_nt = f.r_nt, A.ptr = g.ptr, A.idx = f.idx, A.coef = g.coef;
+  A.r_pack = f.r_pack, A.r_dict = f.r_dict, A.n_dict = f.n_dict;
   A.multi_rows = f.multi, A.m_idx = f.m_idx, A.m_coef = f.m_coef, A.mid_rows = f.mid, A.long_rows = f.longr;
   A.n_multi = f.n_multi, A.n_mid = f.n_mid, A.n_long = f.n_long;
   A.task_ptr = a->d_task_ptr[mode == MPX_MODE_HESS ? 1 : 0], A.task_list = a->d_task_list[mode == MPX_MODE_HESS ? 1 : 0];

@@ -22,10 +22,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "mpx_device.h"
 
-#ifndef MPX_FUSE_LOC_G
-#define MPX_FUSE_LOC_G 4  // table entries of a local variable fetched together
+#ifndef MPX_FUSE_LOC_G  // table entries of a local variable fetched together: 6 where the packed row registers leave room, else 4
+#if defined(MPX_FUSE_NDICT_FGJ) && MPX_FUSE_NDICT_FGJ > 0 && MPX_FUSE_NDICT_FGJ <= 2048
+#define MPX_FUSE_LOC_G 6
+#else
+#define MPX_FUSE_LOC_G 4
+#endif
 #endif
 #ifndef MPX_FUSE_TASK_PER_U
 #define MPX_FUSE_TASK_PER_U 1
@@ -38,6 +44,9 @@
 #endif
 #ifndef MPX_FUSE_MULTI_EARLY
 #define MPX_FUSE_MULTI_EARLY 0
+#endif
+#ifndef MPX_FUSE_MROW_HES
+#define MPX_FUSE_MROW_HES 0
 #endif
 #ifndef MPX_FUSE_MID_WAVE
 #define MPX_FUSE_MID_WAVE 0
@@ -69,6 +78,28 @@ struct RowRegs {  // first terms of the rows k * NT + lane, k < K, of one output
 #pragma unroll
     for (int k = 0; k < K; ++k)
       if (idx[k] >= 0) out[k * NT + l] = fma(coef[k], V[idx[k]], 0.0);
+  }
+};
+
+// The same with ONE register per row: position in V and a 16-bit code of the coefficient (MpxFusedArgs::r_pack / r_dict, the
+// dictionary in LDS).  Frees two thirds of the row registers -- 36 of 128 VGPRs for moon lander 20x5 -- for the table entries the
+// point tasks want in flight.
+template <int NA, int NT>
+struct RowRegsPacked {
+  static constexpr int K = (NA + NT - 1) / NT;
+  uint32_t pk[K > 0 ? K : 1];
+  __device__ __forceinline__ void load(const ::MpxFusedArgs& A, int base, int l) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int r = k * NT + l;
+      pk[k] = r < NA ? A.r_pack[base + r] : 0xffffffffu;
+    }
+  }
+  __device__ __forceinline__ void store(const double* __restrict__ V, const double* __restrict__ dict, double* __restrict__ out, int l) const {
+    if (!out) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (pk[k] != 0xffffffffu) out[k * NT + l] = fma(dict[pk[k] >> 16], V[pk[k] & 0xffffu], 0.0);
   }
 };
 
@@ -213,7 +244,7 @@ struct FusedDispatch<MODE, -1, U, VN, RAWN> {
 // MODE_FG / MODE_FGJ: arrays f (1 row), g (NG), grad_f (NZ), jac_val (NNZJ); MODE_HESS: hess_val (NNZH).
 // MT: ELL width of the multi-term rows (rows with 2 .. MT terms); RL x TL: long rows per wavefront x 64-term rounds
 // per long row when their table fits the register budget (RL == 0: read from global memory per chunk).
-template <int MODE, int NF, int NT, int U, int RAWN, int NZ, int N0, int N1, int N2, int N3, int MT, int RM, int RL, int TL>
+template <int MODE, int NF, int NT, int U, int RAWN, int NZ, int N0, int N1, int N2, int N3, int MT, int RM, int RL, int TL, int NDICT>
 __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
   constexpr int VN = RAWN + NZ + 1;  // [raw | z | 1.0]
   __shared__ double V[U][VN];
@@ -241,14 +272,30 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     }
     __syncthreads();
   }
-  RowRegs<N0, NT> R0;
-  RowRegs<N1, NT> R1;
-  RowRegs<N2, NT> R2;
-  RowRegs<N3, NT> R3;
+  __shared__ double sDict[NDICT > 0 ? NDICT : 1];  // coefficient dictionary of the packed single-term rows
+  if constexpr (NDICT > 0) {
+    for (int e = l; e < NDICT; e += NT) sDict[e] = e < A.n_dict ? A.r_dict[e] : 0.0;
+    __syncthreads();
+  }
+  std::conditional_t<(NDICT > 0), RowRegsPacked<N0, NT>, RowRegs<N0, NT>> R0;
+  std::conditional_t<(NDICT > 0), RowRegsPacked<N1, NT>, RowRegs<N1, NT>> R1;
+  std::conditional_t<(NDICT > 0), RowRegsPacked<N2, NT>, RowRegs<N2, NT>> R2;
+  std::conditional_t<(NDICT > 0), RowRegsPacked<N3, NT>, RowRegs<N3, NT>> R3;
   R0.load(A, 0, l);
   R1.load(A, N0, l);
   R2.load(A, N0 + N1, l);
   R3.load(A, N0 + N1 + N2, l);
+  // (not in the Hessian kernel by default: four more registers there cost a workgroup per compute unit, MPX_FUSE_MROW_HES)
+  constexpr bool MROW = RM > 0 && RM <= 4 && (MODE != MPX_MODE_HESS || MPX_FUSE_MROW_HES);
+  int mrow_[MROW ? RM : 1], mnt_[MROW ? RM : 1];
+  if constexpr (MROW) {
+#pragma unroll
+    for (int q = 0; q < RM; ++q) {
+      const int m = q * NT + l;
+      mrow_[q] = m < A.n_multi ? A.multi_rows[m] : 0;
+      mnt_[q] = m < A.n_multi ? A.r_nt[mrow_[q]] : 0;
+    }
+  }
   auto out_of = [&](int row, int64_t b) -> double* {
     int a = 0, loc = row;
     if (loc >= N0) { loc -= N0, a = 1; if (loc >= N1) { loc -= N1, a = 2; if (loc >= N2) { loc -= N2, a = 3; } } }
@@ -355,10 +402,17 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     for (int u = 0; u < nu; ++u) {
       const double* __restrict__ Vu = V[u];
       const int64_t b = b0 + u;
-      R0.store(Vu, A.out[0] ? A.out[0] + b * A.out_stride[0] : nullptr, l);
-      R1.store(Vu, A.out[1] ? A.out[1] + b * A.out_stride[1] : nullptr, l);
-      R2.store(Vu, A.out[2] ? A.out[2] + b * A.out_stride[2] : nullptr, l);
-      R3.store(Vu, A.out[3] ? A.out[3] + b * A.out_stride[3] : nullptr, l);
+      if constexpr (NDICT > 0) {
+        R0.store(Vu, sDict, A.out[0] ? A.out[0] + b * A.out_stride[0] : nullptr, l);
+        R1.store(Vu, sDict, A.out[1] ? A.out[1] + b * A.out_stride[1] : nullptr, l);
+        R2.store(Vu, sDict, A.out[2] ? A.out[2] + b * A.out_stride[2] : nullptr, l);
+        R3.store(Vu, sDict, A.out[3] ? A.out[3] + b * A.out_stride[3] : nullptr, l);
+      } else {
+        R0.store(Vu, A.out[0] ? A.out[0] + b * A.out_stride[0] : nullptr, l);
+        R1.store(Vu, A.out[1] ? A.out[1] + b * A.out_stride[1] : nullptr, l);
+        R2.store(Vu, A.out[2] ? A.out[2] + b * A.out_stride[2] : nullptr, l);
+        R3.store(Vu, A.out[3] ? A.out[3] + b * A.out_stride[3] : nullptr, l);
+      }
     }
     // ---- rows with 2 .. MT terms: one lane per row, ELL table [t][row] (the MT loads of a row are independent), added in stored order ----
 #if MPX_FUSE_MULTI_EARLY
@@ -379,9 +433,21 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     }
     for (int m = A.n_multi; m < A.n_multi; m += NT) {
 #else
-    for (int m = l; m < A.n_multi; m += NT) {
+    int lm = l;
+    asm volatile("" : "+v"(lm));  // (opaque per chunk: else the 2 MT table addresses of every round are hoisted out of the chunk loop -- registers)
+    for (int m = lm, r_ = 0; m < A.n_multi; m += NT, ++r_) {
 #endif
-      const int row = A.multi_rows[m], nt = A.r_nt[row];
+      // (row and term count of the lane's r_-th multi-term row: registers for the life of the workgroup where the row count is a
+      // compile-time constant -- two dependent loads per round less)
+      int row, nt;
+      if constexpr (MROW) {
+        row = mrow_[0], nt = mnt_[0];
+#pragma unroll
+        for (int q = 1; q < RM; ++q)
+          if (r_ == q) row = mrow_[q], nt = mnt_[q];
+      } else {
+        row = A.multi_rows[m], nt = A.r_nt[row];
+      }
       int ix[MT > 0 ? MT : 1];
       double cf[MT > 0 ? MT : 1];
 #pragma unroll
@@ -475,27 +541,40 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 #endif
 #define MPX_FUSE_RL_OK(NLONG, LT) ((NLONG) > 0 && MPX_FUSE_RL(NLONG) * MPX_FUSE_TL(LT) <= MPX_FUSE_LONG_REGS ? MPX_FUSE_RL(NLONG) : 0)
 
+// Packed single-term rows (RowRegsPacked) when the generator found few enough distinct coefficients (MPX_FUSE_NDICT_*, exact counts)
+#ifndef MPX_FUSE_NDICT_FGJ
+#define MPX_FUSE_NDICT_FGJ 0
+#endif
+#ifndef MPX_FUSE_NDICT_HES
+#define MPX_FUSE_NDICT_HES 0
+#endif
+#ifndef MPX_FUSE_DICT_MAX
+#define MPX_FUSE_DICT_MAX 2048
+#endif
+#define MPX_FUSE_PACK(N) ((N) > 0 && (N) <= MPX_FUSE_DICT_MAX ? (N) : 0)
+
 // mpx_fuse_info = {lanes per workgroup, U of the first-order kernels, U of the Hessian kernel, ELL width of the multi-term rows
-// of the first-order pass, of the Hessian pass} (U == 0: that kernel does not exist: one evaluation point does not fit the
-// budgets); the host reads it from the code object.
+// of the first-order pass, of the Hessian pass, dictionary capacity of the packed single-term rows of the two passes (0: unpacked)}
+// (U == 0: that kernel does not exist: one evaluation point does not fit the budgets); the host reads it from the code object.
 #define MPX_INSTANTIATE_FUSED(NF)                                                                                              \
-  extern "C" __device__ __attribute__((used)) const int mpx_fuse_info[5] = {MPX_FUSE_NT, MPX_FUSE_U_FGJ, MPX_FUSE_U_HES,       \
-                                                                              MPX_FUSE_MT_FGJ, MPX_FUSE_MT_HES};               \
+  extern "C" __device__ __attribute__((used)) const int mpx_fuse_info[7] = {MPX_FUSE_NT, MPX_FUSE_U_FGJ, MPX_FUSE_U_HES,       \
+                                                                              MPX_FUSE_MT_FGJ, MPX_FUSE_MT_HES,                \
+                                                                              MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_HES)}; \
   extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_fg(const MpxFusedArgs A) {                                \
     if constexpr (MPX_FUSE_U_FGJ > 0)                                                                                          \
       mpxk::fused_body<MPX_MODE_FG, NF, MPX_FUSE_NT, (MPX_FUSE_U_FGJ > 0 ? MPX_FUSE_U_FGJ : 1), MPX_FUSE_RAW_N, MPX_FUSE_NZ, 1, \
                        MPX_FUSE_NG, MPX_FUSE_NZ, MPX_FUSE_NNZJ, MPX_FUSE_MT_FGJ, MPX_FUSE_CEIL(MPX_FUSE_NMULTI_FGJ), MPX_FUSE_RL_OK(MPX_FUSE_NLONG_FGJ, MPX_FUSE_LT_FGJ), \
-                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ)>(A);                                                                       \
+                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ)>(A);                                    \
   }                                                                                                                            \
   extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_fgj(const MpxFusedArgs A) {                               \
     if constexpr (MPX_FUSE_U_FGJ > 0)                                                                                          \
       mpxk::fused_body<MPX_MODE_FGJ, NF, MPX_FUSE_NT, (MPX_FUSE_U_FGJ > 0 ? MPX_FUSE_U_FGJ : 1), MPX_FUSE_RAW_N, MPX_FUSE_NZ, 1, \
                        MPX_FUSE_NG, MPX_FUSE_NZ, MPX_FUSE_NNZJ, MPX_FUSE_MT_FGJ, MPX_FUSE_CEIL(MPX_FUSE_NMULTI_FGJ), MPX_FUSE_RL_OK(MPX_FUSE_NLONG_FGJ, MPX_FUSE_LT_FGJ), \
-                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ)>(A);                                                                       \
+                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ)>(A);                                    \
   }                                                                                                                            \
   extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_hes(const MpxFusedArgs A) {                               \
     if constexpr (MPX_FUSE_U_HES > 0)                                                                                          \
       mpxk::fused_body<MPX_MODE_HESS, NF, MPX_FUSE_NT, (MPX_FUSE_U_HES > 0 ? MPX_FUSE_U_HES : 1), MPX_FUSE_RAWH_N, MPX_FUSE_NZ, \
                        MPX_FUSE_NNZH, 0, 0, 0, MPX_FUSE_MT_HES, MPX_FUSE_CEIL(MPX_FUSE_NMULTI_HES), MPX_FUSE_RL_OK(MPX_FUSE_NLONG_HES, MPX_FUSE_LT_HES),          \
-                       MPX_FUSE_TL(MPX_FUSE_LT_HES)>(A);                                                                       \
+                       MPX_FUSE_TL(MPX_FUSE_LT_HES), MPX_FUSE_PACK(MPX_FUSE_NDICT_HES)>(A);                                    \
   }

@@ -264,5 +264,11 @@ struct MpxFusedArgs {
   const double* ch_coef;
   const int32_t* ch_slot;
   int32_t n_chains, pad2_;
+  // single-term rows, packed: position in V | code << 16, code = index of the coefficient in r_dict (the distinct coefficients of the
+  // pass's rows with at most one term; 0xffffffff: the row has more terms).  One register per row instead of three in the fused
+  // kernels (code objects built with MPX_FUSE_NDICT_* > 0; mpx_fuse_info[5..6])
+  const uint32_t* r_pack;
+  const double* r_dict;
+  int32_t n_dict, pad3_;
 };
 #endif
