@@ -173,6 +173,26 @@ class AssembledNlpFunctions(NlpFunctions):
         self.functions = funcs
         self._expand(Gz, g0)
         sizes = dict(RAW_N=self.raw_n, RAWH_N=self.rawh_n, NZ=self.n_z_, NG=self.n_g_, NNZJ=self.nnz_jac_, NNZH=self.nnz_hess_)
+        # ELL tables of the local variables and of the multipliers of every set (what _create hands to libmpx), and the number of
+        # distinct coefficients (bit patterns, padding included) in each family: the dictionaries of the packed tables of the fused
+        # kernels (mpx_assembly_fused.h: one 32-bit entry per term = index | code << 16; libmpx builds the same dictionaries)
+        self._ell = []
+        for s in self.sets:
+            fn = s.fn
+            loc = PointSet._ell(s.n, fn.n_loc, [s._rows(v)[1:] for v in range(fn.n_loc)])
+            mu = []
+            for r in range(fn.n_out):
+                gp, gi, gc = s._gcols(r)
+                nzp = np.nonzero(s.fw[:, r])[0]
+                mu.append((np.concatenate([gp, nzp]), np.concatenate([gi, np.full(len(nzp), self.n_g_, np.int64)]), np.concatenate([gc, s.fw[nzp, r]])))
+            self._ell.append((loc, PointSet._ell(s.n, fn.n_out, mu)))
+
+        def _ndistinct(arrs):
+            v = np.concatenate([np.ascontiguousarray(a, dtype=np.float64).ravel() for a in arrs]) if arrs else np.zeros(0)
+            return len(np.unique(v.view(np.int64))) if len(v) else 0
+
+        sizes["NDICT_LOC"] = _ndistinct([e[0][2] for e in self._ell]) if self.n_z_ + 1 < 65536 else 0
+        sizes["NDICT_MU"] = _ndistinct([e[1][2] for e in self._ell]) if self.n_g_ + 1 < 65536 else 0
         for tag, (ptr, _, _) in (("FGJ", self.fgj), ("HES", self.hess)):  # shape of the multi-term and long rows of each pass
             nt = np.diff(ptr)
             multi, longr = nt[(nt >= 2) & (nt <= 24)], nt[nt > 24]  # 24 = MPX_GATHER_LONG
@@ -187,7 +207,9 @@ class AssembledNlpFunctions(NlpFunctions):
             # of the fused kernels (mpx_assembly_fused.h, RowRegsPacked; libmpx builds the same dictionary and checks the count)
             cf = np.ascontiguousarray(self.fgj[2] if tag == "FGJ" else self.hess[2], dtype=np.float64)
             first = cf[ptr[:-1][nt == 1]] if (nt == 1).any() else np.zeros(0)
-            vals = np.concatenate([first, np.zeros(1 if (nt == 0).any() else 0)])
+            rows_m = np.flatnonzero((nt >= 2) & (nt <= mt)) if mt else np.zeros(0, dtype=np.int64)
+            terms_m = np.concatenate([cf[ptr[r]:ptr[r + 1]] for r in rows_m]) if len(rows_m) else np.zeros(0)  # ELL table of the multi-term rows
+            vals = np.concatenate([first, np.zeros(1 if (nt == 0).any() else 0), terms_m])
             sizes["NDICT_" + tag] = len(np.unique(vals.view(np.int64))) if len(vals) else 0
         self.source = self._source(funcs, sizes)
         if with_device is None:
@@ -323,16 +345,10 @@ class AssembledNlpFunctions(NlpFunctions):
             fn, d = s.fn, arr[k]
             d.fid, d.n_points = self.functions.index(fn), s.n
             d.n_loc, d.n_cst, d.n_out, d.n_jac, d.n_hess = fn.n_loc, fn.n_cst, fn.n_out, fn.n_jac, fn.n_hess
-            nt, ix, cf = PointSet._ell(s.n, fn.n_loc, [s._rows(v)[1:] for v in range(fn.n_loc)])
+            (nt, ix, cf), (mnt, mix, mcf) = self._ell[k]
             d.loc_nterm, d.loc_idx, d.loc_coef = i32(nt), i32(ix), f64(cf)
             d.cst = f64(s.cst.T.copy() if s.cst.size else np.zeros(1))
-            mu = []
-            for r in range(fn.n_out):
-                gp, gi, gc = s._gcols(r)
-                nzp = np.nonzero(s.fw[:, r])[0]
-                mu.append((np.concatenate([gp, nzp]), np.concatenate([gi, np.full(len(nzp), self.n_g_, np.int64)]), np.concatenate([gc, s.fw[nzp, r]])))
-            nt, ix, cf = PointSet._ell(s.n, fn.n_out, mu)
-            d.mu_nterm, d.mu_idx, d.mu_coef = i32(nt), i32(ix), f64(cf)
+            d.mu_nterm, d.mu_idx, d.mu_coef = i32(mnt), i32(mix), f64(mcf)
         D = mpx_assembly()
         D.version = 1
         D.n_z, D.n_g, D.nnz_jac, D.nnz_hess = self.n_z_, self.n_g_, self.nnz_jac_, self.nnz_hess_

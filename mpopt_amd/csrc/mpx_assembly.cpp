@@ -45,6 +45,7 @@ struct DevFused {
   int32_t *r_idx = nullptr, *r_nt = nullptr, *idx = nullptr, *multi = nullptr, *mid = nullptr, *longr = nullptr, *m_idx = nullptr;
   double *r_coef = nullptr, *m_coef = nullptr;
   int32_t n_multi = 0, n_mid = 0, n_long = 0;
+  uint32_t* m_pack = nullptr;  // ELL table of the multi-term rows packed the same way, same dictionary
   uint32_t* r_pack = nullptr;  // single-term rows packed (MpxFusedArgs::r_pack); n_dict = 0: not representable (an index or the dictionary past 16 bits)
   double* r_dict = nullptr;
   int32_t n_dict = 0;
@@ -62,6 +63,10 @@ struct mpx_asm_state {
   double* d_ch_coef = nullptr;
   int32_t n_chains = 0;
   std::vector<int32_t*> d_chain_pos;
+  // packed tables of the local variables / multipliers (MpxPtSet::loc_pack, mu_pack) and their dictionaries
+  std::vector<uint32_t*> d_loc_pack, d_mu_pack;
+  double *d_l_dict = nullptr, *d_m_dict = nullptr;
+  int32_t n_ldict = 0, n_mdict = 0;
   std::vector<DevSet> sets;
   MpxPtSet* d_sets = nullptr;  // device copy of the per-set argument blocks
   int n_blocks = 0;            // 64-lane blocks of the fused point launch
@@ -220,28 +225,33 @@ int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, in
   std::vector<double> m_coef((size_t)std::max<int64_t>((int64_t)mt * f.n_multi, 1), 0.0);
   for (int32_t m = 0; m < f.n_multi; ++m)
     for (int64_t e = g.ptr[multi[m]], t = 0; e < g.ptr[multi[m] + 1]; ++e, ++t) m_idx[(size_t)(t * f.n_multi + m)] = idx[(size_t)e], m_coef[(size_t)(t * f.n_multi + m)] = g.coef[e];
-  // packed form of the rows with at most one term: position | code << 16, dictionary of the distinct coefficients (bit patterns)
-  std::vector<uint32_t> r_pack((size_t)std::max<int64_t>(g.n_rows, 1), 0xffffffffu);
+  // packed form of the rows with at most one term and of the ELL table of the multi-term rows: position | code << 16, one dictionary
+  // of the distinct coefficients (bit patterns) for both
+  std::vector<uint32_t> r_pack((size_t)std::max<int64_t>(g.n_rows, 1), 0xffffffffu), m_pack(m_idx.size(), 0u);
   std::vector<double> r_dict;
   {
     std::map<uint64_t, uint32_t> code_of;
     bool ok = raw_n + n_z + 1 <= 65536;
-    for (int64_t r = 0; r < g.n_rows && ok; ++r) {
-      if (r_nt[(size_t)r] > 1) continue;
+    auto code = [&](double v) -> uint32_t {
       uint64_t bits;
-      memcpy(&bits, &r_coef[(size_t)r], 8);
+      memcpy(&bits, &v, 8);
       auto it = code_of.find(bits);
       if (it == code_of.end()) {
-        ok = r_dict.size() < 65535;
+        ok = ok && r_dict.size() < 65535;
         it = code_of.emplace(bits, (uint32_t)r_dict.size()).first;
-        r_dict.push_back(r_coef[(size_t)r]);
+        r_dict.push_back(v);
       }
-      r_pack[(size_t)r] = (uint32_t)r_idx[(size_t)r] | (it->second << 16);
-    }
+      return it->second;
+    };
+    for (int64_t r = 0; r < g.n_rows && ok; ++r)
+      if (r_nt[(size_t)r] <= 1) r_pack[(size_t)r] = (uint32_t)r_idx[(size_t)r] | (code(r_coef[(size_t)r]) << 16);
+    for (int32_t m = 0; m < f.n_multi && ok; ++m)
+      for (int64_t e = g.ptr[multi[m]], t = 0; e < g.ptr[multi[m] + 1]; ++e, ++t)
+        m_pack[(size_t)(t * f.n_multi + m)] = (uint32_t)idx[(size_t)e] | (code(g.coef[e]) << 16);
     f.n_dict = ok ? (int32_t)r_dict.size() : 0;
   }
   int rc;
-  if ((rc = upload(c, &f.r_pack, r_pack)) || (rc = upload(c, &f.r_dict, r_dict))) return rc;
+  if ((rc = upload(c, &f.r_pack, r_pack)) || (rc = upload(c, &f.r_dict, r_dict)) || (rc = upload(c, &f.m_pack, m_pack))) return rc;
   if ((rc = upload(c, &f.r_idx, r_idx)) || (rc = upload(c, &f.r_nt, r_nt)) || (rc = upload(c, &f.r_coef, r_coef)) || (rc = upload(c, &f.idx, idx)) ||
       (rc = upload(c, &f.multi, multi)) || (rc = upload(c, &f.mid, mid)) || (rc = upload(c, &f.longr, longr)) || (rc = upload(c, &f.m_idx, m_idx)) ||
       (rc = upload(c, &f.m_coef, m_coef)))
@@ -271,9 +281,12 @@ void mpx_asm_release(mpx_ctx* c) {
   };
   for (auto& s : a->sets) fr(s.loc_toff), fr(s.loc_idx), fr(s.mu_toff), fr(s.mu_idx), fr(s.loc_coef), fr(s.cst), fr(s.mu_coef);
   for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef), fr(g->long_rows);
-  for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef), fr(f->r_pack), fr(f->r_dict);
+  for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef), fr(f->r_pack), fr(f->r_dict), fr(f->m_pack);
   fr(a->d_ch_ptr), fr(a->d_ch_idx), fr(a->d_ch_slot), fr(a->d_ch_coef);
   for (auto q : a->d_chain_pos) fr(q);
+  for (auto q : a->d_loc_pack) fr(q);
+  for (auto q : a->d_mu_pack) fr(q);
+  fr(a->d_l_dict), fr(a->d_m_dict);
   fr(a->raw.p), fr(a->d_sets), fr(a->d_task_ptr[0]), fr(a->d_task_ptr[1]), fr(a->d_task_list[0]), fr(a->d_task_list[1]);
   if (a->dbg) (void)hipHostFree(a->dbg);
   delete a;
@@ -342,10 +355,42 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
     h.loc_toff = d.loc_toff, h.loc_idx = d.loc_idx, h.loc_coef = d.loc_coef, h.cst = d.cst;
     h.mu_toff = d.mu_toff, h.mu_idx = d.mu_idx, h.mu_coef = d.mu_coef;
     h.raw_off = a->raw_n, h.rawh_off = a->rawh_n;
-    h.n_loc = d.n_loc, h.n_out = d.n_out, h.chain_v = -1, h.chain_pos = nullptr;
+    h.n_loc = d.n_loc, h.n_out = d.n_out, h.chain_v = -1, h.chain_pos = nullptr, h.loc_pack = nullptr, h.mu_pack = nullptr;
     a->n_blocks += (d.n + 63) / 64;
     a->raw_n += (int64_t)d.n * (d.n_out + d.n_jac);
     a->rawh_n += (int64_t)d.n * d.n_hess;
+  }
+  {  // packed copies of the local-variable and multiplier tables of every set (index | code << 16) with context-wide dictionaries
+    std::vector<double> ldict, mdict;
+    std::map<uint64_t, uint32_t> lcode, mcode;
+    bool lok = D->n_z + 1 < 65536, mok = D->n_g + 1 < 65536;
+    auto code = [](std::map<uint64_t, uint32_t>& m, std::vector<double>& dict, double v, bool& ok) -> uint32_t {
+      uint64_t bits;
+      memcpy(&bits, &v, 8);
+      auto it = m.find(bits);
+      if (it == m.end()) {
+        ok = ok && dict.size() < 65535;
+        it = m.emplace(bits, (uint32_t)dict.size()).first;
+        dict.push_back(v);
+      }
+      return it->second;
+    };
+    a->d_loc_pack.assign(D->n_sets, nullptr), a->d_mu_pack.assign(D->n_sets, nullptr);
+    for (int k = 0; k < D->n_sets; ++k) {
+      const mpx_point_set& S = D->sets[k];
+      int64_t lt = 0, mt_ = 0;
+      for (int v = 0; v < S.n_loc; ++v) lt += S.loc_nterm[v];
+      for (int r = 0; r < S.n_out; ++r) mt_ += S.mu_nterm[r];
+      std::vector<uint32_t> lp((size_t)std::max<int64_t>(lt * S.n_points, 1), 0u), mp((size_t)std::max<int64_t>(mt_ * S.n_points, 1), 0u);
+      for (int64_t e = 0; e < lt * S.n_points; ++e) lp[(size_t)e] = (uint32_t)S.loc_idx[e] | (code(lcode, ldict, S.loc_coef[e], lok) << 16);
+      for (int64_t e = 0; e < mt_ * S.n_points; ++e) mp[(size_t)e] = (uint32_t)S.mu_idx[e] | (code(mcode, mdict, S.mu_coef[e], mok) << 16);
+      if ((rc = upload(c, &a->d_loc_pack[k], lp)) || (rc = upload(c, &a->d_mu_pack[k], mp))) return bail(rc);
+      hs[k].loc_pack = a->d_loc_pack[k], hs[k].mu_pack = a->d_mu_pack[k];
+    }
+    a->n_ldict = lok ? (int32_t)ldict.size() : 0, a->n_mdict = mok ? (int32_t)mdict.size() : 0;
+    if (ldict.empty()) ldict.push_back(0.0);
+    if (mdict.empty()) mdict.push_back(0.0);
+    if ((rc = upload(c, &a->d_l_dict, ldict)) || (rc = upload(c, &a->d_m_dict, mdict))) return bail(rc);
   }
   {  // Chained local variables: variable v of set k qualifies when, over its points, the (non-padding) term lists are all prefixes
      // of the longest one -- same z indices, same coefficients, same order.  Chains with identical term lists are shared
@@ -428,7 +473,7 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
   {  // fused persistent kernels (mpx_assembly_fused.h): present in code objects generated since round 3
     hipDeviceptr_t sym = nullptr;
     size_t bytes = 0;
-    int info[7] = {0, 0, 0, 0, 0, 0, 0};
+    int info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     static const char* fname[3] = {"mpx_asm_fg", "mpx_asm_fgj", "mpx_asm_hes"};
     const bool have_info = hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_fuse_info") == hipSuccess && bytes == sizeof info &&
                            hipMemcpyDtoH(info, sym, sizeof info) == hipSuccess && info[0] >= 64 && info[0] <= 1024;
@@ -445,6 +490,9 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
       ok = ok && a->sets.size() <= 16;
       if (ok && (info[1] > 0 || info[2] > 0)) {
         if ((rc = upload_fused(c, a->ffgj, D->fgj, a->raw_n, D->n_z, thr_fgj)) || (rc = upload_fused(c, a->fhess, D->hess, a->rawh_n, D->n_z, thr_hes))) return bail(rc);
+        if ((info[7] > 0 && (a->n_ldict < 1 || a->n_ldict > info[7])) || (info[8] > 0 && (a->n_mdict < 1 || a->n_mdict > info[8])))
+          return bail(fail(c, MPX_ERR_INVALID, "fused kernels: dictionaries of the packed local-variable / multiplier tables (%d / %d entries) do not fit the compiled capacity (%d / %d)",
+                           a->n_ldict, a->n_mdict, info[7], info[8]));
         // kernels compiled for packed single-term rows: the dictionary the generator counted must be the one built here
         if ((info[5] > 0 && (a->ffgj.n_dict < 1 || a->ffgj.n_dict > info[5])) || (info[6] > 0 && (a->fhess.n_dict < 1 || a->fhess.n_dict > info[6])))
           return bail(fail(c, MPX_ERR_INVALID, "fused kernels: coefficient dictionary of the single-term rows (%d / %d entries) does not fit the compiled capacity (%d / %d)",
@@ -568,7 +616,8 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
   A.sets = a->d_sets, A.n_sets = (int32_t)a->sets.size(), A.n_blocks = a->n_blocks, A.n_g = (int32_t)c->n_g, A.B = (int32_t)batch;
   A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma;
   A.r_idx = f.r_idx, A.r_coef = f.r_coef, A.r_nt = f.r_nt, A.ptr = g.ptr, A.idx = f.idx, A.coef = g.coef;
-  A.r_pack = f.r_pack, A.r_dict = f.r_dict, A.n_dict = f.n_dict;
+  A.r_pack = f.r_pack, A.r_dict = f.r_dict, A.n_dict = f.n_dict, A.m_pack = f.m_pack;
+  A.l_dict = a->d_l_dict, A.m_dict = a->d_m_dict, A.n_ldict = a->n_ldict, A.n_mdict = a->n_mdict;
   A.multi_rows = f.multi, A.m_idx = f.m_idx, A.m_coef = f.m_coef, A.mid_rows = f.mid, A.long_rows = f.longr;
   A.n_multi = f.n_multi, A.n_mid = f.n_mid, A.n_long = f.n_long;
   A.task_ptr = a->d_task_ptr[mode == MPX_MODE_HESS ? 1 : 0], A.task_list = a->d_task_list[mode == MPX_MODE_HESS ? 1 : 0];

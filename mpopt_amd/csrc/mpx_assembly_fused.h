@@ -33,6 +33,20 @@
 #define MPX_FUSE_LOC_G 4
 #endif
 #endif
+// Packed tables of the local variables / multipliers (MpxPtSet::loc_pack, mu_pack) when the generator found at most 1024 distinct
+// coefficients in each family (MPX_FUSE_NDICT_LOC / _MU, exact counts): one 32-bit load per term instead of an index and a double,
+// one register per entry in flight instead of three
+#ifndef MPX_FUSE_NDICT_LOC
+#define MPX_FUSE_NDICT_LOC 0
+#endif
+#ifndef MPX_FUSE_NDICT_MU
+#define MPX_FUSE_NDICT_MU 0
+#endif
+#define MPX_FUSE_NLD ((MPX_FUSE_NDICT_LOC) > 0 && (MPX_FUSE_NDICT_LOC) <= 1024 ? (MPX_FUSE_NDICT_LOC) : 0)
+#define MPX_FUSE_NMD ((MPX_FUSE_NDICT_MU) > 0 && (MPX_FUSE_NDICT_MU) <= 1024 ? (MPX_FUSE_NDICT_MU) : 0)
+#ifndef MPX_FUSE_LOC_GP
+#define MPX_FUSE_LOC_GP 5  // packed entries of a local variable fetched together (3 ... 20 measured: 5 completes the 6-term interpolation variables in one round)
+#endif
 #ifndef MPX_FUSE_TASK_PER_U
 #define MPX_FUSE_TASK_PER_U 1
 #endif
@@ -44,6 +58,9 @@
 #endif
 #ifndef MPX_FUSE_MULTI_EARLY
 #define MPX_FUSE_MULTI_EARLY 0
+#endif
+#ifndef MPX_FUSE_PACKED_EARLY
+#define MPX_FUSE_PACKED_EARLY 1
 #endif
 #ifndef MPX_FUSE_MROW_HES
 #define MPX_FUSE_MROW_HES 0
@@ -108,8 +125,10 @@ struct RowRegsPacked {
 // kernels); local variables from z in LDS, results to raw in LDS
 template <int FID, int MODE, int U, int VN, int RAWN>
 __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __restrict__ ltoff, const int* __restrict__ mtoff, const ::MpxFusedArgs& A, int blk, int lane,
-                                            double (*V)[VN], int b0, int nu, const double* __restrict__ CH) {
+                                            double (*V)[VN], int b0, int nu, const double* __restrict__ CH, const double* __restrict__ ldict,
+                                            const double* __restrict__ mdict) {
   using F = mpxgen::Pt<FID>;
+  constexpr int NLD = MPX_FUSE_NLD, NMD = MPX_FUSE_NMD;
   constexpr int NLOC = F::NLOC, NCST = F::NCST, NOUT = F::NOUT, NJ = F::NJ, NH = F::NH;
   if constexpr (MODE == MPX_MODE_HESS && NH == 0) return;
   const int p = blk * 64 + lane;
@@ -132,6 +151,45 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
   // single-term variables -- states, controls, t0, tf, the segment's width -- instead of one each: the unrolled loop over v with a
   // run-time term loop inside would not let the compiler overlap them), the remaining terms of the long ones follow in groups of
   // MPX_FUSE_LOC_G.  Same terms, same order, same fma chains.
+  if constexpr (NLD > 0) {
+    // packed tables: the first entry of every variable in one round trip (one register each), the rest in groups of MPX_FUSE_LOC_GP
+    uint32_t e0[NLOC > 0 ? NLOC : 1];
+#pragma unroll
+    for (int v = 0; v < NLOC; ++v) {
+      const int t0 = ltoff[v] < ltoff[v + 1] ? ltoff[v] : (ltoff[v] > 0 ? ltoff[v] - 1 : 0);
+      e0[v] = S.loc_pack[(int64_t)t0 * n + p];
+    }
+#pragma unroll
+    for (int v = 0; v < NLOC; ++v) {
+      double acc[U];
+      if (MPX_FUSE_CHAINS && v == S.chain_v) {
+        const int slot = S.chain_pos[p];
+#pragma unroll
+        for (int u = 0; u < U; ++u) loc[u][v] = CH[u * MPX_FUSE_CHAIN_MAX + slot];
+        continue;
+      }
+      const int t1 = ltoff[v + 1];
+      {
+        const double c0 = ldict[e0[v] >> 16];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = ltoff[v] < t1 ? fma(c0, V[u][RAWN + (int)(e0[v] & 0xffffu)], 0.0) : 0.0;
+      }
+      for (int t = ltoff[v] + 1; t < t1; t += MPX_FUSE_LOC_GP) {
+        uint32_t pe[MPX_FUSE_LOC_GP];
+#pragma unroll
+        for (int q = 0; q < MPX_FUSE_LOC_GP; ++q) pe[q] = S.loc_pack[(int64_t)(t + q < t1 ? t + q : t1 - 1) * n + p];
+#pragma unroll
+        for (int q = 0; q < MPX_FUSE_LOC_GP; ++q)
+          if (t + q < t1) {
+            const double cq = ldict[pe[q] >> 16];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = fma(cq, V[u][RAWN + (int)(pe[q] & 0xffffu)], acc[u]);
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) loc[u][v] = acc[u];
+    }
+  } else {
   int ix0[NLOC > 0 ? NLOC : 1];
   double cf0[NLOC > 0 ? NLOC : 1];
 #pragma unroll
@@ -169,6 +227,7 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
 #pragma unroll
     for (int u = 0; u < U; ++u) loc[u][v] = acc[u];
   }
+  }
 #ifdef MPX_FUSE_PT_STAMPS
   if (dq) dq[1] = wall_clock64();
 #endif
@@ -179,14 +238,33 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
       double acc[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) acc[u] = 0;
-      for (int t = mtoff[r]; t < mtoff[r + 1]; ++t) {
-        const int ix = S.mu_idx[(int64_t)t * n + p];
-        const double cf = S.mu_coef[(int64_t)t * n + p];
+      // (four table entries and their multipliers in flight: one term at a time was a dependent pair of round trips per term)
+      for (int t = mtoff[r]; t < mtoff[r + 1]; t += 4) {
+        int ix[4];
+        double cf[4], lm[U][4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int b = b0 + (u < nu ? u : 0);
-          acc[u] = fma(cf, ix == A.n_g ? A.sigma[b] : A.lam[(int64_t)b * A.lam_stride + ix], acc[u]);
+        for (int q = 0; q < 4; ++q) {
+          const int64_t tt = (int64_t)(t + q < mtoff[r + 1] ? t + q : mtoff[r + 1] - 1) * n + p;
+          if constexpr (NMD > 0) {
+            const uint32_t e = S.mu_pack[tt];
+            ix[q] = (int)(e & 0xffffu), cf[q] = mdict[e >> 16];
+          } else {
+            ix[q] = S.mu_idx[tt], cf[q] = S.mu_coef[tt];
+          }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int b = b0 + (u < nu ? u : 0);
+            lm[u][q] = ix[q] == A.n_g ? A.sigma[b] : A.lam[(int64_t)b * A.lam_stride + ix[q]];
+          }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (t + q < mtoff[r + 1]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = fma(cf[q], lm[u][q], acc[u]);
+          }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) mu[u][r] = acc[u];
@@ -229,16 +307,17 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
 template <int MODE, int FID, int U, int VN, int RAWN>
 struct FusedDispatch {
   __device__ static __forceinline__ void run(const MpxPtSet& S, const int* lt, const int* mt, const ::MpxFusedArgs& A, int blk, int lane, double (*V)[VN], int b0, int nu,
-                                             const double* CH) {
+                                             const double* CH, const double* ld, const double* md) {
     if (S.fid == FID)
-      fused_point<FID, MODE, U, VN, RAWN>(S, lt, mt, A, blk, lane, V, b0, nu, CH);
+      fused_point<FID, MODE, U, VN, RAWN>(S, lt, mt, A, blk, lane, V, b0, nu, CH, ld, md);
     else
-      FusedDispatch<MODE, FID - 1, U, VN, RAWN>::run(S, lt, mt, A, blk, lane, V, b0, nu, CH);
+      FusedDispatch<MODE, FID - 1, U, VN, RAWN>::run(S, lt, mt, A, blk, lane, V, b0, nu, CH, ld, md);
   }
 };
 template <int MODE, int U, int VN, int RAWN>
 struct FusedDispatch<MODE, -1, U, VN, RAWN> {
-  __device__ static __forceinline__ void run(const MpxPtSet&, const int*, const int*, const ::MpxFusedArgs&, int, int, double (*)[VN], int, int, const double*) {}
+  __device__ static __forceinline__ void run(const MpxPtSet&, const int*, const int*, const ::MpxFusedArgs&, int, int, double (*)[VN], int, int, const double*, const double*,
+                                             const double*) {}
 };
 
 // MODE_FG / MODE_FGJ: arrays f (1 row), g (NG), grad_f (NZ), jac_val (NNZJ); MODE_HESS: hess_val (NNZH).
@@ -272,6 +351,12 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     }
     __syncthreads();
   }
+  __shared__ double sLDict[MPX_FUSE_NLD > 0 ? MPX_FUSE_NLD : 1], sMDict[MPX_FUSE_NMD > 0 ? MPX_FUSE_NMD : 1];  // ... of the packed local / multiplier tables
+  if constexpr (MPX_FUSE_NLD > 0)
+    for (int e = l; e < MPX_FUSE_NLD; e += NT) sLDict[e] = e < A.n_ldict ? A.l_dict[e] : 0.0;
+  if constexpr (MPX_FUSE_NMD > 0)
+    for (int e = l; e < MPX_FUSE_NMD; e += NT) sMDict[e] = e < A.n_mdict ? A.m_dict[e] : 0.0;
+  if constexpr (MPX_FUSE_NLD > 0 || MPX_FUSE_NMD > 0) __syncthreads();
   __shared__ double sDict[NDICT > 0 ? NDICT : 1];  // coefficient dictionary of the packed single-term rows
   if constexpr (NDICT > 0) {
     for (int e = l; e < NDICT; e += NT) sDict[e] = e < A.n_dict ? A.r_dict[e] : 0.0;
@@ -378,7 +463,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       if (u >= nu) continue;
       int k = 0;
       while (k + 1 < A.n_sets && bx >= sS[k + 1].block_first) ++k;
-      FusedDispatch<MODE, NF - 1, 1, VN, RAWN>::run(sS[k], sLt[k], sMt[k], A, bx - sS[k].block_first, lane, &V[u], b0 + u, 1, &CH[it_ & 1][u][0]);
+      FusedDispatch<MODE, NF - 1, 1, VN, RAWN>::run(sS[k], sLt[k], sMt[k], A, bx - sS[k].block_first, lane, &V[u], b0 + u, 1, &CH[it_ & 1][u][0], sLDict, sMDict);
     }
     // table entries of this lane's multi-term rows: loads issued before the barrier, used after the single-term rows
     MPX_FUSE_STAMP(2);
@@ -398,6 +483,22 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       for (int t = 0; t < MT; ++t) eix[r][t] = A.m_idx[(int64_t)t * A.n_multi + mm], ecf[r][t] = A.m_coef[(int64_t)t * A.n_multi + mm];
     }
 #endif
+    // Packed ELL table (NDICT > 0): one 32-bit entry per term (position | coefficient code) -- a third of the registers and half
+    // the load instructions of the unpacked table, so the entries of ALL the lane's multi-term rows can be requested BEFORE the
+    // burst of single-term stores (memory operations of a wavefront retire in order: loads issued behind the stores wait for the
+    // store queue to drain -- the multi-term phase was 5 us of a 15 us chunk) and used after it.
+    constexpr bool PE = NDICT > 0 && MROW && MPX_FUSE_PACKED_EARLY && !MPX_FUSE_MULTI_EARLY;
+    uint32_t epk[PE ? RM : 1][PE ? (MT > 0 ? MT : 1) : 1];
+    if constexpr (PE) {
+      int le = l;
+      asm volatile("" : "+v"(le));  // (opaque per chunk: the table addresses are recomputed, not hoisted into registers)
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        const int m = r * NT + le, mm = m < A.n_multi ? m : 0;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) epk[r][t] = A.m_pack[(int64_t)t * A.n_multi + mm];
+      }
+    }
     // ---- rows with one term: registers -> LDS read -> store ----
     for (int u = 0; u < nu; ++u) {
       const double* __restrict__ Vu = V[u];
@@ -433,9 +534,25 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     }
     for (int m = A.n_multi; m < A.n_multi; m += NT) {
 #else
+    if constexpr (PE) {
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+        if (mnt_[r] > 0) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (u >= nu) break;
+            double sm = 0;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+              if (t < mnt_[r]) sm = fma(sDict[epk[r][t] >> 16], V[u][epk[r][t] & 0xffffu], sm);
+            double* o = out_of(mrow_[r], b0 + u);
+            if (o) *o = sm;
+          }
+        }
+    }
     int lm = l;
     asm volatile("" : "+v"(lm));  // (opaque per chunk: else the 2 MT table addresses of every round are hoisted out of the chunk loop -- registers)
-    for (int m = lm, r_ = 0; m < A.n_multi; m += NT, ++r_) {
+    for (int m = PE ? A.n_multi : lm, r_ = 0; m < A.n_multi; m += NT, ++r_) {
 #endif
       // (row and term count of the lane's r_-th multi-term row: registers for the life of the workgroup where the row count is a
       // compile-time constant -- two dependent loads per round less)
@@ -450,8 +567,16 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       }
       int ix[MT > 0 ? MT : 1];
       double cf[MT > 0 ? MT : 1];
+      if constexpr (NDICT > 0) {
 #pragma unroll
-      for (int t = 0; t < MT; ++t) ix[t] = A.m_idx[(int64_t)t * A.n_multi + m], cf[t] = A.m_coef[(int64_t)t * A.n_multi + m];
+        for (int t = 0; t < MT; ++t) {
+          const uint32_t e = A.m_pack[(int64_t)t * A.n_multi + m];
+          ix[t] = (int)(e & 0xffffu), cf[t] = sDict[e >> 16];
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) ix[t] = A.m_idx[(int64_t)t * A.n_multi + m], cf[t] = A.m_coef[(int64_t)t * A.n_multi + m];
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (u >= nu) break;
@@ -557,9 +682,9 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 // of the first-order pass, of the Hessian pass, dictionary capacity of the packed single-term rows of the two passes (0: unpacked)}
 // (U == 0: that kernel does not exist: one evaluation point does not fit the budgets); the host reads it from the code object.
 #define MPX_INSTANTIATE_FUSED(NF)                                                                                              \
-  extern "C" __device__ __attribute__((used)) const int mpx_fuse_info[7] = {MPX_FUSE_NT, MPX_FUSE_U_FGJ, MPX_FUSE_U_HES,       \
+  extern "C" __device__ __attribute__((used)) const int mpx_fuse_info[9] = {MPX_FUSE_NT, MPX_FUSE_U_FGJ, MPX_FUSE_U_HES,       \
                                                                               MPX_FUSE_MT_FGJ, MPX_FUSE_MT_HES,                \
-                                                                              MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_HES)}; \
+                                                                              MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_HES), MPX_FUSE_NLD, MPX_FUSE_NMD}; \
   extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_fg(const MpxFusedArgs A) {                                \
     if constexpr (MPX_FUSE_U_FGJ > 0)                                                                                          \
       mpxk::fused_body<MPX_MODE_FG, NF, MPX_FUSE_NT, (MPX_FUSE_U_FGJ > 0 ? MPX_FUSE_U_FGJ : 1), MPX_FUSE_RAW_N, MPX_FUSE_NZ, 1, \

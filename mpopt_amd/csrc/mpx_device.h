@@ -191,6 +191,10 @@ struct MpxPtSet {
   int32_t chain_v, n_loc;
   const int32_t* chain_pos;  // [n]
   int32_t n_out, pad_;       // (n_loc / n_out: lengths - 1 of loc_toff / mu_toff, for kernels that copy them)
+  // the same two tables packed, one 32-bit entry per term: index | code << 16, code = position of the coefficient in the context's
+  // dictionaries (MpxFusedArgs::l_dict / m_dict); fused kernels built with MPX_FUSE_NDICT_LOC / _MU > 0 read these (half the loads)
+  const uint32_t* loc_pack;
+  const uint32_t* mu_pack;
 };
 
 // Per-call arguments of the fused point kernels (all sets of the context in one launch).
@@ -270,5 +274,9 @@ struct MpxFusedArgs {
   const uint32_t* r_pack;
   const double* r_dict;
   int32_t n_dict, pad3_;
+  const uint32_t* m_pack;  // [t][n_multi] ELL table of the multi-term rows, packed with the same dictionary
+  const double* l_dict;    // dictionaries of MpxPtSet::loc_pack / mu_pack (all sets of the context)
+  const double* m_dict;
+  int32_t n_ldict, n_mdict;
 };
 #endif
