@@ -202,6 +202,9 @@ class AssembledNlpFunctions(NlpFunctions):
             if len(multi):
                 mt = next((w for w in range(2, 13) if (multi > w).sum() <= 16), 12)
             sizes["MT_" + tag], sizes["NMULTI_" + tag] = int(mt), int(((multi <= mt)).sum()) if len(multi) else 0
+            # rows past the ELL width are the "long" rows of the fused kernels (one wavefront per row; libmpx uses the same threshold:
+            # MT, or MPX_GATHER_LONG = 24 where no row has 2 .. 24 terms)
+            longr = nt[nt > (mt if mt >= 2 else 24)]
             sizes["NLONG_" + tag], sizes["LT_" + tag] = len(longr), int(longr.max()) if len(longr) else 0
             # distinct coefficients (bit patterns) of the rows with at most one term: the dictionary of the packed row registers
             # of the fused kernels (mpx_assembly_fused.h, RowRegsPacked; libmpx builds the same dictionary and checks the count)

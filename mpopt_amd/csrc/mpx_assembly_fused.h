@@ -438,6 +438,11 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       }
     }
   };
+  constexpr int MAXT = 4;
+  const int tq0 = A.task_ptr[wave], n_my = A.task_ptr[wave + 1] - tq0;
+  int my_t[MAXT];
+#pragma unroll
+  for (int q = 0; q < MAXT; ++q) my_t[q] = q < n_my ? A.task_list[tq0 + q] : 0;
   const int n_chunks = (A.B + U - 1) / U;
   if ((int)blockIdx.x < n_chunks) z_load(blockIdx.x), chains_of(blockIdx.x, 0);
   int it_ = 0;
@@ -458,8 +463,11 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     if (c + (int)gridDim.x < n_chunks) z_load(c + gridDim.x), chains_of(c + gridDim.x, (it_ + 1) & 1);  // in flight during this chunk's work
     // ---- point functions: wavefront <-> (64-point block, evaluation point) ----
     // wavefront <-> its scheduled (64-point block, evaluation point) tasks
-    for (int q = A.task_ptr[wave]; q < A.task_ptr[wave + 1]; ++q) {
-      const int t = A.task_list[q], u = t / A.n_blocks, bx = t - u * A.n_blocks;
+    for (int q = 0; q < n_my; ++q) {
+      // (the wavefront's schedule and the point set of every task: read once per kernel -- per chunk they were two dependent
+      // scalar round trips and a search in front of every task, 2 us of a 5.4 us point phase)
+      const int t = q < MAXT ? (q == 0 ? my_t[0] : q == 1 ? my_t[1] : q == 2 ? my_t[2] : my_t[3]) : A.task_list[tq0 + q];
+      const int u = t / A.n_blocks, bx = t - u * A.n_blocks;
       if (u >= nu) continue;
       int k = 0;
       while (k + 1 < A.n_sets && bx >= sS[k + 1].block_first) ++k;
@@ -611,6 +619,21 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
           }
         }
       }
+      // (rows past the register table, should the host ever find more long rows than the generator counted: from global memory)
+      for (int w = wave + RL * NW; w < A.n_long; w += NW) {
+        const int row = A.long_rows[w];
+        const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
+        for (int u = 0; u < nu; ++u) {
+          double s = 0;
+          for (int64_t e = e0 + lane; e < e1; e += 64) s = fma(A.coef[e], V[u][A.idx[e]], s);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+          if (lane == 0) {
+            double* op = out_of(row, b0 + u);
+            if (op) *op = s;
+          }
+        }
+      }
     } else {
       for (int w = wave; w < A.n_long * nu; w += NW) {
         const int u = w / A.n_long, row = A.long_rows[w - u * A.n_long];
@@ -662,7 +685,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 #define MPX_FUSE_RL(NLONG) (((NLONG) + MPX_FUSE_NT / 64 - 1) / (MPX_FUSE_NT / 64))
 #define MPX_FUSE_TL(LT) (((LT) + 63) / 64)
 #ifndef MPX_FUSE_LONG_REGS
-#define MPX_FUSE_LONG_REGS 0
+#define MPX_FUSE_LONG_REGS 4  // (position, coefficient) pairs per lane a wavefront may keep of its long rows
 #endif
 #define MPX_FUSE_RL_OK(NLONG, LT) ((NLONG) > 0 && MPX_FUSE_RL(NLONG) * MPX_FUSE_TL(LT) <= MPX_FUSE_LONG_REGS ? MPX_FUSE_RL(NLONG) : 0)
 
