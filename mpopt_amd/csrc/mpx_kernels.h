@@ -266,11 +266,36 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
     for (int e = l; e < P * P1; e += MPX_TILE) sC[e] = A.Cmid[e];
     __syncthreads();
   } else {
+    // hess_l passes, tables of at most 64 entries: ONE load per table, lane and wavefront (lane e holds entry e), the lane's rows are
+    // fetched from the lanes that hold them (ds_bpermute, no memory) instead of 2-3 (P + 1) loads per lane in front of every
+    // workgroup -- an ablation without the table loads gains 3-8 % on these short workgroups (profiles/r3_soak.md).  Same box,
+    // -DMPX_NO_TAB_SHUFFLE against this: hess_l config 2 296 -> 268 us, config 5 680 -> 639 us, config 4 260 -> 250 us; the
+    // loop's hess_l + residual pass 107.6 -> 104.0 us.  A loss for the first-order kernels (their 18 fetches per lane cost more
+    // than they save: 1002 -> 1032 us), which keep the loads.
+#ifndef MPX_NO_TAB_SHUFFLE
+    if constexpr (MODE == MPX_MODE_HESS && P1 * P1 <= 64) {
+      // (the hess_l kernels use the tables for the mid-point residuals only: a pass without MPX_MID_RESID fetches none)
+#pragma unroll
+      for (int j = 0; j < P1; ++j) Drow_[j] = 0.0, Crow_[j] = 0.0, Dmrow_[j] = 0.0;
+      if (midres) {
+        const int ln = l & 63;
+        const double tC = A.Cmid[ln < P * P1 ? ln : 0], tM = A.Dmid[ln < P * P1 ? ln : 0];
+#pragma unroll
+        for (int j = 0; j < P1; ++j) {
+          const double c = __shfl(tC, crow + j, 64), m = __shfl(tM, crow + j, 64);
+          Crow_[j] = (k >= 1) ? c : 0.0;
+          Dmrow_[j] = (k >= 1) ? m : 0.0;
+        }
+      }
+    } else
+#endif
+    {
 #pragma unroll
     for (int j = 0; j < P1; ++j) {
       Drow_[j] = A.Dmat[drow + j];
       Crow_[j] = (k >= 1) ? A.Cmid[crow + j] : 0.0;
       Dmrow_[j] = (midres && k >= 1) ? A.Dmid[crow + j] : 0.0;
+    }
     }
   }
   const double tkm = (midres && k >= 1) ? A.tkm[k - 1] : 0.0;
