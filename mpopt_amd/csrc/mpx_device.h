@@ -46,6 +46,7 @@ struct MpxIO {
   double* partial;      // [B][n_tiles_total][nred]
   int32_t n_tiles_total, nred;
   int32_t B, b_per_block;
+  int32_t b_first, pad_b_;  // first evaluation point of this launch (batches of more than 65535 points per workgroup row are launched in slices)
   int32_t jac_variable_only, pad_;
   // Mixed-degree phases: the nodes of one (phase, degree) bucket are NOT contiguous in the node index, so direct
   // stores to g / grad_f are short runs with gaps that another kernel fills later (partial cache lines: measured

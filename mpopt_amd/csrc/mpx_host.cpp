@@ -781,8 +781,13 @@ struct GeomPick {
 GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig = 0) {
   const bool light = !(sig & 8);
   const char* env = getenv("MPX_BPB");  // tuning / test override (read per call: tools switch it inside one process)
-  if (env && atoi(env) > 0) return {atoi(env), nullptr, nullptr};
-  if (mode == MPX_MODE_HESS) return {B >= 2 ? 2 : 1, nullptr, nullptr};
+  if (env && atoi(env) > 0 && mode != MPX_MODE_HESS) return {atoi(env), nullptr, nullptr};
+  // (the hess_l node kernels take one evaluation point per workgroup as a compile-time fact, mpx_kernels.h: MPX_HESS_ONE_POINT;
+  // MPX_BPB_HESS=n only for code objects built with -DMPX_HESS_ONE_POINT=0)
+  if (mode == MPX_MODE_HESS) {
+    const char* eh = getenv("MPX_BPB_HESS");
+    return {eh && atoi(eh) > 0 ? atoi(eh) : 1, nullptr, nullptr};
+  }
   const int64_t work = B * (c->tile_end - c->tile_begin);
   static const bool no_tune = getenv("MPX_NO_TUNE") != nullptr;
   if (no_tune || work < 8192 || !key || c->shard_world > 1) return {1, nullptr, nullptr};
@@ -849,6 +854,10 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   const void* geom_key = mode == MPX_MODE_HESS ? (const void*)io.hess : io.jac ? (const void*)io.jac : io.g ? (const void*)io.g : io.grad ? (const void*)io.grad : (const void*)io.f;
   const GeomPick geom = pick_geometry(c, io.B, mode, geom_key, (io.f ? 1 : 0) | (io.g ? 2 : 0) | (io.grad ? 4 : 0) | (io.jac ? 8 : 0));
   io.b_per_block = geom.bpb;
+  // (a workgroup row per chunk of evaluation points: at most 65535 rows per launch -- the first-order passes take more points per
+  // workgroup past that, the hess_l passes (one point per workgroup, compile-time) are launched in slices, MpxIO::b_first)
+  if (mode != MPX_MODE_HESS)
+    while ((io.B + io.b_per_block - 1) / io.b_per_block > 65535) ++io.b_per_block;
   // Packed staging of g / grad_f in tile order: (a) mixed-degree phases, full evaluations (a plain mpx_set_tile_range keeps
   // the direct stores); (b) every segment-sharded evaluation (mpx_shard_setup): a rank's tiles are one contiguous run of the
   // staging block, which is what the ranks exchange; the boundary pass then moves the assembled block to g / grad_f.
@@ -896,9 +905,13 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
       A.z_off = P.z_off, A.g_off_F = P.g_off_F, A.g_off_C = P.g_off_C;
       A.N = (int32_t)c->N, A.seg_off = p * c->S, A.tile_first = (int32_t)lo, A.tile_count = (int32_t)(hi - lo);
-      int rc = launch(c, c->fn_hessn[p], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A);
-      if (rc) return rc;
-      if (c->profile) ++c->prof_launches;
+      for (int64_t bf = 0; bf < (int64_t)gy * io.b_per_block; bf += (int64_t)65535 * io.b_per_block) {
+        A.io.b_first = (int32_t)bf;
+        const int gys = (int)std::min<int64_t>(65535, gy - bf / io.b_per_block);
+        int rc = launch(c, c->fn_hessn[p], dim3((unsigned)(hi - lo), gys, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A);
+        if (rc) return rc;
+        if (c->profile) ++c->prof_launches;
+      }
     }
   }
   for (int pass = 0; pass < 2 && !by_node; ++pass)
@@ -965,9 +978,13 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       A.abs_fpos = c->d_abs_fpos, A.abs_fstage = c->d_abs_fstage, A.abs_fn = c->d_abs_fn, A.abs_cap = B.abs_cap;
       lds = (unsigned)B.abs_cap * (unsigned)B.abs_slots * 8u;
     }
-    int rc = launch(c, B.fn[mode], dim3((unsigned)(hi - lo), gy, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A, lds);
-    if (rc) return rc;
-    if (c->profile) ++c->prof_launches;
+    for (int64_t bf = 0; bf < (int64_t)gy * io.b_per_block; bf += (int64_t)65535 * io.b_per_block) {
+      A.io.b_first = (int32_t)bf;
+      const int gys = (int)std::min<int64_t>(65535, gy - bf / io.b_per_block);
+      int rc = launch(c, B.fn[mode], dim3((unsigned)(hi - lo), gys, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A, lds);
+      if (rc) return rc;
+      if (c->profile) ++c->prof_launches;
+    }
   }
   if (packed && (!shard || !nodes) && !absorb) {
     const int64_t rows = c->n_g + c->n_z;

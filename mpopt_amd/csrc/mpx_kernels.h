@@ -311,8 +311,21 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   const double Wn = A.Wnode[i];
 
   const MpxIO& io = A.io;
-  const int b0 = by_ * io.b_per_block;
-  const int b1 = (b0 + io.b_per_block < io.B) ? b0 + io.b_per_block : io.B;
+  // hess_l passes: ONE evaluation point per workgroup as a compile-time fact (the host launches them so).  Without the state of the
+  // software-pipelined batch loop the kernel needs 52 instead of 85 VGPRs (degree 5) and runs 3-5 % faster than the loop at its
+  // best setting (config 2: 279 -> 265 us, config 5: 643 -> 624 us, the config-5 loop's pass 105.7 -> 102.8 us;
+  // tools/r3_bpb1_ab.py).  Not for the first-order kernels: at twice the occupancy they are SLOWER (948 -> 1236 us at config 2 --
+  // more workgroups per compute unit writing at once is what one point per workgroup was chosen against).
+#ifndef MPX_HESS_ONE_POINT
+#define MPX_HESS_ONE_POINT 1
+#endif
+#ifdef MPX_ABL_BPB1  // (experiment switch of tools/r3_bpb1_ab.py: every mode)
+  constexpr bool ONE_POINT = true;
+#else
+  constexpr bool ONE_POINT = MODE == MPX_MODE_HESS && MPX_HESS_ONE_POINT;
+#endif
+  const int b0 = io.b_first + (ONE_POINT ? by_ : by_ * io.b_per_block);
+  const int b1 = ONE_POINT ? (b0 + 1 < io.B ? b0 + 1 : io.B) : ((b0 + io.b_per_block < io.B) ? b0 + io.b_per_block : io.B);
   const int64_t tslot = (int64_t)T.tile_id * io.nred;
   // Absorbing tile (mixed-degree phases, MpxNodeArgs::abs_cap): row slots as in the packed staging block -- defect, path, DU, mU
   // rows, then the grad_f entries of the node.
@@ -695,8 +708,9 @@ __device__ __forceinline__ void hess_by_node_body(const MpxHessNodeArgs& A) {
   const int64_t n = T.n;
   const bool vech = (T.hess_base & 1) == 0;
   const MpxIO& io = A.io;
-  const int b0 = by_ * io.b_per_block;
-  const int b1 = (b0 + io.b_per_block < io.B) ? b0 + io.b_per_block : io.B;
+  constexpr bool ONE_POINT = MPX_HESS_ONE_POINT;  // (one evaluation point per workgroup, compile-time: see node_body)
+  const int b0 = io.b_first + (ONE_POINT ? by_ : by_ * io.b_per_block);
+  const int b1 = ONE_POINT ? (b0 + 1 < io.B ? b0 + 1 : io.B) : ((b0 + io.b_per_block < io.B) ? b0 + io.b_per_block : io.B);
   const int64_t tslot = (int64_t)T.tile_id * io.nred;
   struct In {
     Vec<NX> Xs;

@@ -714,3 +714,32 @@ def test_random_mixed_degree_grids(seed, monkeypatch):
         d = sp.coo_matrix((ha[0], (ra, ca)), shape=(oa.n_z, oa.n_z)).tocsr() - Ho
         assert (abs(d).max() if d.nnz else 0.0) < TOL * max(1.0, abs(Ho).max())
     oa.close(), ob.close()
+
+
+def test_batches_beyond_the_grid_row_limit():
+    """More evaluation points than a launch has workgroup rows (65535): the hess_l passes (one point per workgroup, compile-time) go
+    out in slices, the first-order passes take more points per workgroup; every point equals the same point evaluated in a small batch."""
+    import torch
+
+    ocp, S = problems.moon_lander(mp, M.math), 20
+    mpo = mp.mpopt(ocp, S, 3, "LGR")
+    o = mpo.create_nlp()[0]["oracle"]
+    dev = torch.device("cuda:0")
+    B = 65535 + 4100
+    rng = np.random.default_rng(3)
+    Z = torch.tensor(mpo.initialize_solution()[None, :] + 0.03 * rng.standard_normal((B, o.n_z)), device=dev)
+    p = torch.tensor(np.full(o.n_p, 1 / S), device=dev)
+    lam, sig = torch.tensor(rng.standard_normal((B, o.n_g)), device=dev), torch.tensor(rng.uniform(0.5, 1.5, B), device=dev)
+    mk = lambda *s_: torch.full(s_, float("nan"), dtype=torch.float64, device=dev)
+    big = (mk(B), mk(B, o.n_g), mk(B, o.n_z), mk(B, o.nnz_jac), mk(B, o.nnz_hess))
+    o.eval_device(31, B, Z, p, 0, lam, sig, *big)
+    o.sync()
+    assert all(bool(torch.isfinite(x).all()) for x in big)
+    for lo in (0, 65530, B - 7):
+        n = 7
+        small = (mk(n), mk(n, o.n_g), mk(n, o.n_z), mk(n, o.nnz_jac), mk(n, o.nnz_hess))
+        o.eval_device(31, n, Z[lo:lo + n].contiguous(), p, 0, lam[lo:lo + n].contiguous(), sig[lo:lo + n].contiguous(), *small)
+        o.sync()
+        for a, b in zip(big, small):
+            assert torch.equal(a[lo:lo + n], b), lo
+    o.close()
