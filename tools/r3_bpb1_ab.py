@@ -17,7 +17,7 @@ builder, S, P, scheme = problems.BENCH_CASES[case]
 B = int(os.environ.get("B", 4096 if case != 1 else 512))
 dev = torch.device("cuda", 0)
 objs = {}
-for name, fl in (("loop", ""), ("bpb1", "-DMPX_ABL_BPB1=1")):
+for name, fl in (("loop", ""), ("bpb1", os.environ.get("BPB1_FLAGS", "-DMPX_ABL_BPB1=1"))):
     os.environ["MPX_HIPCC_FLAGS"] = fl
     mpo = mp.mpopt(builder(mp, M.math), S, P, scheme)
     objs[name] = mpo.create_nlp()[0]["oracle"]
