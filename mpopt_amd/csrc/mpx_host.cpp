@@ -772,7 +772,8 @@ __global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restric
 //    after two unmeasured ones the next four passes that write a given output array run the two geometries (order A B B A) between HIP events on the context's
 //    stream (no synchronisation: the timings are read with hipEventQuery once they exist), after which the faster one is used
 //    for that array.  Results do not depend on the geometry (fixed-order reductions; tests/test_gpu_parity.py).
-//  * The Hessian kernels (one short burst per point) take 2; small batches 1.  MPX_BPB overrides, MPX_NO_TUNE=1 pins 1.
+//  * The Hessian kernels take ONE point per workgroup as a compile-time fact (round 3: half the registers without the batch loop's
+//    state, mpx_kernels.h); small batches 1.  MPX_BPB overrides (first-order passes), MPX_NO_TUNE=1 pins 1.
 struct GeomPick {
   int bpb;
   hipEvent_t begin, end;  // non-null: bracket the node launches of this pass
