@@ -34,7 +34,7 @@
 #endif
 #endif
 // Packed tables of the local variables / multipliers (MpxPtSet::loc_pack, mu_pack) when the generator found at most 1024 distinct
-// coefficients in each family (MPX_FUSE_NDICT_LOC / _MU, exact counts): one 32-bit load per term instead of an index and a double,
+// coefficients (MPX_FUSE_LOC_DICT_MAX) in each family (MPX_FUSE_NDICT_LOC / _MU, exact counts): one 32-bit load per term instead of an index and a double,
 // one register per entry in flight instead of three
 #ifndef MPX_FUSE_NDICT_LOC
 #define MPX_FUSE_NDICT_LOC 0
@@ -42,8 +42,11 @@
 #ifndef MPX_FUSE_NDICT_MU
 #define MPX_FUSE_NDICT_MU 0
 #endif
-#define MPX_FUSE_NLD ((MPX_FUSE_NDICT_LOC) > 0 && (MPX_FUSE_NDICT_LOC) <= 1024 ? (MPX_FUSE_NDICT_LOC) : 0)
-#define MPX_FUSE_NMD ((MPX_FUSE_NDICT_MU) > 0 && (MPX_FUSE_NDICT_MU) <= 1024 ? (MPX_FUSE_NDICT_MU) : 0)
+#ifndef MPX_FUSE_LOC_DICT_MAX
+#define MPX_FUSE_LOC_DICT_MAX 1024
+#endif
+#define MPX_FUSE_NLD ((MPX_FUSE_NDICT_LOC) > 0 && (MPX_FUSE_NDICT_LOC) <= MPX_FUSE_LOC_DICT_MAX ? (MPX_FUSE_NDICT_LOC) : 0)
+#define MPX_FUSE_NMD ((MPX_FUSE_NDICT_MU) > 0 && (MPX_FUSE_NDICT_MU) <= MPX_FUSE_LOC_DICT_MAX ? (MPX_FUSE_NDICT_MU) : 0)
 #ifndef MPX_FUSE_LOC_GP
 #define MPX_FUSE_LOC_GP 5  // packed entries of a local variable fetched together (3 ... 20 measured: 5 completes the 6-term interpolation variables in one round)
 #endif

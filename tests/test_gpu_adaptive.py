@@ -315,3 +315,13 @@ def test_fused_kernels_equal_the_two_pass_kernels_bitwise(name, monkeypatch):
         n_fused += 1
     assert n_fused == 6
     o.close()
+
+
+@pytest.mark.parametrize("flags", ["-DMPX_FUSE_DICT_MAX=8", "-DMPX_FUSE_LOC_DICT_MAX=0", "-DMPX_FUSE_DICT_MAX=8 -DMPX_FUSE_LOC_DICT_MAX=0 -DMPX_FUSE_LONG_REGS=0"])
+def test_fused_kernels_without_the_packed_tables(flags, monkeypatch):
+    """The fused kernels keep an unpacked form of every table for problems whose coefficient dictionaries are too large (more than
+    2048 / 1024 distinct values) -- built here by lowering the limits -- and a long-row path through global memory: same bits as
+    the two-pass kernels."""
+    monkeypatch.setenv("MPX_HIPCC_FLAGS", flags)
+    test_fused_kernels_equal_the_two_pass_kernels_bitwise("kitchen_sink_6x4", monkeypatch)
+    test_fused_kernels_equal_the_two_pass_kernels_bitwise("moon_lander_20x5", monkeypatch)
