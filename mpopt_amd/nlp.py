@@ -297,7 +297,10 @@ class NlpFunctions:
         shapes = ((MPX_F, (batch,)), (MPX_G, (batch, self.n_g)), (MPX_GRAD, (batch, self.n_z)), (MPX_JAC, (batch, self.nnz_jac)),
                   (MPX_HESS, (batch, self.nnz_hess)))
         cands, times = [], []
+        need = 8 * sum(int(np.prod(sh)) for bit, sh in shapes if mask & bit)
         for _ in range(max(1, int(tries))):
+            if cands and torch.cuda.mem_get_info(dev)[0] < 1.25 * need:
+                break  # (the candidates are all held until the end: never search the device out of memory)
             outs = [torch.empty(sh, dtype=torch.float64, device=dev) if mask & bit else None for bit, sh in shapes]
             for _ in range(8):  # (the first six passes into new arrays are the library's own geometry measurement, include/mpx.h)
                 self.eval_device(mask, batch, z, p, p_per_point, lam_g, sigma, *outs)
