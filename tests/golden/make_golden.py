@@ -177,6 +177,18 @@ def make_case(name, builder, n_segments, poly_orders, scheme, adaptive=False):
                 hr.append(zpos[s]), hc.append(zpos[s]), he.append(d2)
     out["hess_row"], out["hess_col"] = np.array(hr, dtype=np.int64), np.array(hc, dtype=np.int64)
     out["hess_val"] = ev(he, z, p) if he else np.zeros(0)
+    # nlp_grad, the sixth oracle ca.nlpsol derives (mpopt.py:757; "nlp_grad | ... n_eval 1" in every recorded solve,
+    # docs/source/notebooks/moon_lander.ipynb:206): gradient of gamma = lam_f * f + lam_g^T g w.r.t. x and w.r.t. the
+    # parameters p (the segment widths); -grad_gamma_p at the solution is the lam_p the solver returns (tests/test_examples.py:44-45)
+    ggx = np.zeros(n_z)
+    ggx[[zpos[s] for s in lsyms]] = ev([sp.diff(lag, s) for s in lsyms], z, p)
+    out["grad_gamma_x"] = ggx
+    ggp = np.zeros(n_p)
+    ppos = {s: i for i, s in enumerate(ps)}
+    psyms = sorted(lag.free_symbols & set(ps), key=lambda q: ppos[q])
+    if psyms:
+        ggp[[ppos[s] for s in psyms]] = ev([sp.diff(lag, s) for s in psyms], z, p)
+    out["grad_gamma_p"] = ggp
     np.savez_compressed(os.path.join(HERE, f"nlp_{name}.npz"), **out)
     print(f"nlp_{name}.npz: n_z={n_z} n_g={n_g} nnz_j={len(jr)} nnz_h={len(hr)}  ({time.time()-t0:.1f}s)")
 
