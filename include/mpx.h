@@ -202,6 +202,22 @@ int mpx_eval_device(mpx_ctx* ctx, int what_mask, int64_t batch, const double* z,
 /* Block until the context's stream is idle. */
 int mpx_sync(mpx_ctx* ctx);
 
+/* nlp_grad, the sixth oracle ca.nlpsol derives from mpopt's NLP (mpopt.py:757; "nlp_grad ... n_eval 1" in every recorded solve,
+ * docs/source/notebooks/moon_lander.ipynb:206): with gamma = sigma * f + lam_g^T g
+ *     grad_gamma_x [batch][n_z] = sigma * grad_f + jac_g^T lam_g
+ *     grad_gamma_p [batch][n_p] = d gamma / d p      (p = the segment widths: through h_s = (tf - t0) w_s / (tau1 - tau0) of the
+ *                                                     segment's own nodes and through the time of every later node, mpopt.py:184-198)
+ * CasADi calls it once after the last iterate with lam_f = 1 and the final multipliers; lam_p of the solver's result
+ * (tests/test_examples.py:44-45) is -grad_gamma_p.  Either output may be NULL (not computed).  One fused node pass (no Jacobian is
+ * stored; the transposed D / interpolation contractions run out of LDS) + one finishing pass, fixed-order sums: results do not
+ * depend on the batch split.  Assembled contexts (n_p = 0) form grad_gamma_x from their gather pass.  Host-pointer variant:
+ * synchronous, copies in and out; device-pointer variant: asynchronous on the context's stream.  Not available in segment-sharded
+ * mode or with a tile sub-range. */
+int mpx_eval_grad_gamma(mpx_ctx* ctx, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                        const double* sigma, double* grad_gamma_x, double* grad_gamma_p);
+int mpx_eval_grad_gamma_device(mpx_ctx* ctx, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                               const double* sigma, double* grad_gamma_x, double* grad_gamma_p);
+
 /* Page-locked host memory for the buffers handed to mpx_eval / mpx_resid_eval: with pageable memory
  * every transfer is staged by the runtime (~2x the latency of a single evaluation); buffers from
  * mpx_host_alloc are DMA targets.  Free with mpx_host_free before mpx_destroy. */
@@ -374,10 +390,11 @@ typedef struct mpx_assembly {
 int mpx_create_assembled(const mpx_assembly* desc, mpx_ctx** out);
 
 /* ---------------------------------------------------------------------------------------------
- * CasADi-external-compatible surface (mpx_casadi.cpp): the symbols nlp_f, nlp_g, nlp_grad_f,
- * nlp_jac_g, nlp_hess_l (+ _n_in/_n_out/_name_in/_name_out/_sparsity_in/_sparsity_out/_work/
- * _incref/_decref, and the optional _alloc_mem/_init_mem/_free_mem/_checkout/_release/_default_in) follow the calling convention of CasADi-generated C code and act on the context
- * selected here (process-wide; NULL clears it).  The context must outlive its selection.
+ * CasADi-external-compatible surface (mpx_casadi.cpp): the symbols nlp (the base oracle (x, p) -> (f, g) that
+ * ca.nlpsol(name, solver, "libmpx.so") resolves first, as external("nlp", ...)), nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l and
+ * nlp_grad (+ _n_in/_n_out/_name_in/_name_out/_sparsity_in/_sparsity_out/_work/_incref/_decref, and the optional
+ * _alloc_mem/_init_mem/_free_mem/_checkout/_release/_default_in) follow the calling convention of CasADi-generated C code and act on
+ * the context selected here (process-wide; NULL clears it).  The context must outlive its selection.
  * ------------------------------------------------------------------------------------------- */
 int mpx_set_current(mpx_ctx* ctx);
 /* Opt-in: page-lock the argument / result arrays handed to nlp_* the first time each pointer is seen (CasADi passes

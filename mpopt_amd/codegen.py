@@ -116,6 +116,12 @@ class PhaseProgram:
                     self.hn.append((k1, c1, k2, c2, d2))
                 else:
                     self.hc.append((k1, c1, k2, c2, d2))
+        # first derivatives of the node Lagrangian: the nonlinear part of nlp_grad's grad_gamma_x (the D / interpolation blocks are
+        # linear rows, contracted in the kernel) and, through kap = w_s / (tau1 - tau0) and th = sum_{r<s} w_r + w_s (tau_k - tau0) /
+        # (tau1 - tau0) (mpopt.py:184-198), everything grad_gamma_p needs
+        self.gl_x = [tr.diff(lag, v, dmemo[id(v)]) for ck, cc, v in nv if ck in (COL_X, COL_U)]
+        self.gl_r = [tr.diff(lag, v, dmemo[id(v)]) for ck, cc, v in nv if ck not in (COL_X, COL_U)]
+        self.gl_k, self.gl_th = tr.diff(lag, kap), tr.diff(lag, th)
         # ---- terminal program --------------------------------------------------------
         XF = [tr.var(f"XF[{a}]") for a in range(nx)]
         X0 = [tr.var(f"X0[{a}]") for a in range(nx)]
@@ -152,6 +158,7 @@ class PhaseProgram:
                 d2 = tr.diff(g1, v2)
                 if not d2.is_zero:
                     self.th.append((k1, c1, k2, c2, d2))
+        self.tg = [tr.diff(lagT, v) for k, c, v in tv]  # dense over (XF, tf, X0, t0, A): terminal part of grad_gamma_x
 
     # -- emission ----------------------------------------------------------------------
     def _names(self):
@@ -205,6 +212,12 @@ class PhaseProgram:
         asg = [(f"hn[{k}]", s[4]) for k, s in enumerate(self.hn)] + [(f"hc[{k}]", s[4]) for k, s in enumerate(self.hc)]
         out += tr.emit(asg, names, "    ")
         out.append("  }")
+        # gradl: d/d(X, U), d/d(t0, tf, A), d/dkap, d/dth of  sig * qW - lF . fx + lC . c  (nlp_grad, mpx_node_gradl_*)
+        out.append(f"  __device__ static __forceinline__ void gradl({node_sig}, double sig, const double* __restrict__ lF, const double* __restrict__ lC, double* gx, double* gr, double& gk, double& gth) {{")
+        asg = ([(f"gx[{k}]", e) for k, e in enumerate(self.gl_x)] + [(f"gr[{k}]", e) for k, e in enumerate(self.gl_r)]
+               + [("gk", self.gl_k), ("gth", self.gl_th)])
+        out += tr.emit(asg, names, "    ")
+        out.append("  }")
         # terminal
         out.append(f"  __device__ static __forceinline__ void term_fg({term_sig}, double& M, double* tc) {{")
         out += tr.emit([("M", self.mayer)] + [(f"tc[{j}]", e) for j, e in enumerate(self.tc)], names, "    ")
@@ -216,6 +229,9 @@ class PhaseProgram:
         out.append("  }")
         out.append(f"  __device__ static __forceinline__ void term_hess({term_sig}, double sig, const double* __restrict__ lT, double* th) {{")
         out += tr.emit([(f"th[{k}]", s[4]) for k, s in enumerate(self.th)], names, "    ")
+        out.append("  }")
+        out.append(f"  __device__ static __forceinline__ void term_gradl({term_sig}, double sig, const double* __restrict__ lT, double* tg) {{")
+        out += tr.emit([(f"tg[{k}]", e) for k, e in enumerate(self.tg)], names, "    ")
         out.append("  }")
         out.append("};")
         return "\n".join(out)
@@ -274,6 +290,9 @@ class ProblemProgram:
                 parts.append(f"MPX_INSTANTIATE_NODE({ph}, {d})")
         if len(self.degrees) > 1:  # mixed-degree grid: the hess_l node pass runs over node-ordered tiles (mpx_kernels.h)
             parts += [f"MPX_INSTANTIATE_HESS_BY_NODE({ph})" for ph in range(nph)]
+        for ph in range(nph):
+            for d in self.degrees:
+                parts.append(f"MPX_INSTANTIATE_GRADL({ph}, {d})")
         parts.append("MPX_INSTANTIATE_BOUNDARY()")
         return "\n".join(parts) + "\n"
 

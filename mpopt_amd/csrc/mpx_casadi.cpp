@@ -1,4 +1,4 @@
-// mpx_casadi.cpp -- the five NLP oracles with the calling convention of CasADi-generated C code, so
+// mpx_casadi.cpp -- the NLP oracles (nlp, nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l, nlp_grad) with the calling convention of CasADi-generated C code, so
 // that `ca.nlpsol("solver", "ipopt", "libmpx.so", opts)` can load this library in place of the SX
 // graph that mpopt hands to nlpsol (mpopt.py:757).  SURVEY.md section 8(b), second surface.
 //
@@ -316,4 +316,58 @@ extern "C" int nlp_hess_l(const double** arg, double** res, long long*, double*,
   double* hv = res && res[0] ? res[0] : C.buf_h.data();
   if (C.pin) pin(arg ? arg[0] : 0, C.sz.n_z), pin(arg ? arg[3] : 0, C.sz.n_g), pin(res ? res[0] : 0, C.sz.nnz_hess);
   return mpx_eval(C.ctx, MPX_HESS | MPX_CCS_ORDER, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, in(arg, 3, C.zl), &sigma, 0, 0, 0, 0, hv) ? 1 : 0;
+}
+
+// ---- nlp : (x, p) -> (f, g) ----------------------------------------------------------------------
+// The base oracle.  `ca.nlpsol(name, solver, "libmpx.so", opts)` is `nlpsol(name, solver, external("nlp", "libmpx.so"), opts)`:
+// CasADi resolves THIS symbol first (it sizes the problem from its sparsities) and then asks the same library for nlp_f, nlp_g,
+// nlp_grad_f, nlp_jac_g, nlp_hess_l and nlp_grad by name (OracleFunction::create_function on an external oracle).
+MPX_COMMON(nlp, 2, 2)
+extern "C" const char* nlp_name_in(long long i) { return nlp_f_name_in(i); }
+extern "C" const char* nlp_name_out(long long i) { return i == 0 ? "f" : (i == 1 ? "g" : 0); }
+extern "C" const long long* nlp_sparsity_in(long long i) { return nlp_f_sparsity_in(i); }
+extern "C" const long long* nlp_sparsity_out(long long i) { return i == 0 ? C.sp_one.data() : (i == 1 ? C.sp_g.data() : 0); }
+extern "C" int nlp(const double** arg, double** res, long long*, double*, int) {
+  if (!C.ctx) return 1;
+  const bool want_f = res && res[0], want_g = res && res[1];
+  const double *x = in(arg, 0, C.zx), *pp = in(arg, 1, C.zp);
+  if (C.pin) pin(arg ? arg[0] : 0, C.sz.n_z);
+  if (C.coalesce) {
+    if (ensure_cached(x, pp, (want_f ? MPX_F : 0) | (want_g ? MPX_G : 0))) return 1;
+    if (want_f) res[0][0] = C.cf;
+    if (want_g) memcpy(res[1], C.sg, (size_t)C.sz.n_g * 8);
+    return 0;
+  }
+  double f = 0;
+  if (!want_f && !want_g) return 0;
+  if (mpx_eval(C.ctx, (want_f ? MPX_F : 0) | (want_g ? MPX_G : 0), 1, x, pp, 0, 0, 0, &f, want_g ? res[1] : 0, 0, 0, 0)) return 1;
+  if (want_f) res[0][0] = f;
+  return 0;
+}
+
+// ---- nlp_grad : (x, p, lam_f, lam_g) -> (f, g, grad_gamma_x, grad_gamma_p) -------------------------
+// gamma = lam_f * f + lam_g^T g.  CasADi's Nlpsol calls it once after the last iterate (lam_f = 1, the final multipliers) for the
+// outputs its options ask for -- by default only grad_gamma_p, whose negative is the lam_p of the result dict (calc_lam_p;
+// calc_lam_x / calc_f / calc_g add the others).
+MPX_COMMON(nlp_grad, 4, 4)
+extern "C" const char* nlp_grad_name_in(long long i) { return nlp_hess_l_name_in(i); }
+extern "C" const char* nlp_grad_name_out(long long i) {
+  static const char* n[] = {"f", "g", "grad_gamma_x", "grad_gamma_p"};
+  return i >= 0 && i < 4 ? n[i] : 0;
+}
+extern "C" const long long* nlp_grad_sparsity_in(long long i) { return nlp_hess_l_sparsity_in(i); }
+extern "C" const long long* nlp_grad_sparsity_out(long long i) {
+  return i == 0 ? C.sp_one.data() : (i == 1 ? C.sp_g.data() : (i == 2 ? C.sp_x.data() : (i == 3 ? C.sp_p.data() : 0)));
+}
+extern "C" int nlp_grad(const double** arg, double** res, long long* iw, double* w, int mem) {
+  if (!C.ctx) return 1;
+  if (res && (res[0] || res[1])) {
+    double* r2[2] = {res[0], res[1]};
+    if (nlp(arg, r2, iw, w, mem)) return 1;
+  }
+  double* gx = res ? res[2] : 0;
+  double* gp = res && C.sz.n_p > 0 ? res[3] : 0;
+  if (!gx && !gp) return 0;
+  const double sigma = arg && arg[2] ? arg[2][0] : 0.0;
+  return mpx_eval_grad_gamma(C.ctx, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, in(arg, 3, C.zl), &sigma, gx, gp) ? 1 : 0;
 }

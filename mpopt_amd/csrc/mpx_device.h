@@ -139,6 +139,53 @@ struct MpxBoundArgs {
   int32_t n_lin;
 };
 
+// nlp_grad (the sixth oracle of ca.nlpsol, mpopt.py:757): gradient of gamma = sigma * f + lam_g^T g w.r.t. x and w.r.t. the
+// parameters p (segment widths).  Node pass mpx_node_gradl_<ph>_<deg>: one launch per (phase, degree) bucket, lane <-> node,
+// ONE evaluation point per workgroup; finishing pass mpx_gradl_finish: one workgroup per evaluation point.
+struct MpxGradlArgs {
+  const double* z;      int64_t z_stride;
+  const double* w;      const double* wcum; int64_t w_stride;
+  const double* lam_g;  int64_t lam_stride;
+  const double* sigma;
+  double* gx;           int64_t gx_stride;  // grad_gamma_x [B][n_z]; NULL: only what grad_gamma_p needs is computed
+  double* halo;         // [B][n_phases * S][nx + nu]: what the rows of segment s >= 1 contribute to the columns of ITS FIRST node --
+                        //   the last node of segment s - 1, owned by another lane (often another workgroup); added by the finishing pass
+  double* pnode;        // [B][n_phases * N][2]: per node (d gamma_i / d w_s of its own segment, d gamma_i / d th)
+  double* partial;      // [B][n_tiles_total][nred]: tile sums of d gamma_i / d (t0, tf, A)
+  int32_t n_tiles_total, nred;
+  int32_t B, b_first;
+  const MpxTile* tiles;
+  const int32_t* node_i;
+  const int32_t* node_sk;
+  const double* Dmat;
+  const double* Cmid;
+  const double* tk;
+  const double* Wnode;
+  double inv_dtau;
+  int64_t z_off, g_off_F, g_off_C, g_off_DU, g_off_mU;
+  int32_t N, seg_off, tile_first, phase, S, pad_;
+};
+struct MpxGradlFinArgs {
+  const double* z;      int64_t z_stride;
+  const double* lam_g;  int64_t lam_stride;
+  const double* sigma;
+  double* gx;           int64_t gx_stride;
+  double* gp;           int64_t gp_stride;  // grad_gamma_p [B][n_phases * S]; NULL: not requested
+  const double* halo;
+  const double* pnode;
+  const double* partial;
+  int32_t n_tiles_total, nred;
+  MpxPhaseInfo ph[MPX_MAX_PHASES];
+  const int32_t* seg_start;  // [S + 1]
+  int32_t S, n_lt;
+  // linear rows (control-slope continuity, phase events) transposed: column lt_col[c] of z receives
+  // sum_{e in [lt_ptr[c], lt_ptr[c + 1])} lam_g[lt_row[e]] * lt_coef[e]
+  const int64_t* lt_ptr;
+  const int64_t* lt_col;
+  const int64_t* lt_row;
+  const double* lt_coef;
+};
+
 // Off-node evaluation (interpolated trajectories and dynamics residuals, mpopt.py:1428-1543):
 // one launch per degree bucket of a residual plan; lane <-> target point.
 struct MpxResidArgs {

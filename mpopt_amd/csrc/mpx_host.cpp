@@ -459,6 +459,17 @@ int build_layout(mpx_ctx* c) {
       ++jpos;
     }
   c->nnz_j = jpos;
+  {  // the same rows by column (nlp_grad: grad_gamma_x += J^T lam_g of these rows; entries in row order inside a column)
+    std::map<int64_t, std::vector<std::pair<int64_t, double>>> cols;
+    for (size_t r = 0; r + 1 < c->lin_ptr.size(); ++r)
+      for (int64_t e = c->lin_ptr[r]; e < c->lin_ptr[r + 1]; ++e) cols[c->lin_idx[e]].push_back({c->lin_row[r], c->lin_coef[e]});
+    c->lt_ptr.assign(1, 0), c->lt_col.clear(), c->lt_row.clear(), c->lt_coef.clear();
+    for (auto& kv : cols) {
+      c->lt_col.push_back(kv.first);
+      for (auto& e : kv.second) c->lt_row.push_back(e.first), c->lt_coef.push_back(e.second);
+      c->lt_ptr.push_back((int64_t)c->lt_row.size());
+    }
+  }
 
   // ---- node-ordered tiles of the hess_l pass on mixed-degree grids (MpxHTile) ------------------
   c->hess_by_node = c->degs.size() > 1 && !getenv("MPX_NO_HESS_BY_NODE");
@@ -603,7 +614,17 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     hipError_t e = hipModuleGetFunction(&c->fn_bound[m], c->module, name);
     if (e != hipSuccess) return fail(c, MPX_ERR_INVALID, "code object lacks kernel %s", name);
   }
+  // nlp_grad kernels (code objects generated before they existed lack them: mpx_eval_grad_gamma then says so)
+  for (auto& B : c->buckets) {
+    char name[96];
+    snprintf(name, sizeof name, "mpx_node_gradl_%d_%d", B.phase, B.deg);
+    if (hipModuleGetFunction(&B.fn_gradl, c->module, name) != hipSuccess) B.fn_gradl = nullptr, (void)hipGetLastError();
+  }
+  if (hipModuleGetFunction(&c->fn_gradl_fin, c->module, "mpx_gradl_finish") != hipSuccess) c->fn_gradl_fin = nullptr, (void)hipGetLastError();
   int rc;
+  if ((rc = upload(c, &c->d_lt_ptr, c->lt_ptr)) || (rc = upload(c, &c->d_lt_col, c->lt_col)) || (rc = upload(c, &c->d_lt_row, c->lt_row)) ||
+      (rc = upload(c, &c->d_lt_coef, c->lt_coef)))
+    return rc;
   if (c->hess_by_node) {
     for (int p = 0; p < c->n_phases; ++p) {
       char name[64];
@@ -1092,6 +1113,8 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
     fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
+    fr(c->gl_halo.p), fr(c->gl_pnode.p), fr(c->st_ggx.p), fr(c->st_ggp.p), fr(c->gl_grad.p), fr(c->gl_jac.p);
+    fr(c->d_lt_ptr), fr(c->d_lt_col), fr(c->d_lt_row), fr(c->d_lt_coef), fr(c->d_colind_j), fr(c->d_jrow);
     fr(c->d_gmap), fr(c->d_qmap), fr(c->d_abs_fpos), fr(c->d_abs_fstage), fr(c->d_abs_fn), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
@@ -2370,6 +2393,147 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   if (mask & MPX_GRAD) HIPCHK(c, hipMemcpyAsync(grad_f, c->st_grad.p, B * c->n_z * 8, hipMemcpyDeviceToHost, c->stream));
   if (mask & MPX_JAC) HIPCHK(c, hipMemcpyAsync(jac_val, c->st_jac.p, B * c->nnz_j * 8, hipMemcpyDeviceToHost, c->stream));
   if (mask & MPX_HESS) HIPCHK(c, hipMemcpyAsync(hess_val, c->st_hess.p, B * c->nnz_h * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPX_OK;
+}
+
+// ---- nlp_grad: grad_gamma_x, grad_gamma_p (the sixth oracle of ca.nlpsol, mpopt.py:757) ----------------------------------
+// out[b][col] = sigma[b] * grad_f[b][col] + sum over the entries of column col of  jac_val[b][e] * lam_g[b][row[e]]  in
+// compressed-column order: the generic route (assembled contexts, whose Jacobian comes out of a gather pass; MPX_GRADL_GENERIC=1
+// for the tiled contexts as a cross-check of the fused pass).  One lane per column, fixed order.
+__global__ __launch_bounds__(256) void mpx_jtvec_kernel(const double* __restrict__ jac, int64_t nnz, const double* __restrict__ grad, const double* __restrict__ lam,
+                                                        int64_t n_g, const double* __restrict__ sigma, const int64_t* __restrict__ colind,
+                                                        const int64_t* __restrict__ perm, const int32_t* __restrict__ jrow, int64_t n_z,
+                                                        double* __restrict__ out) {
+  const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (col >= n_z) return;
+  const double* __restrict__ jb = jac + b * nnz;
+  const double* __restrict__ lb = lam + b * n_g;
+  double s = sigma[b] * grad[b * n_z + col];
+  for (int64_t k = colind[col]; k < colind[col + 1]; ++k) {
+    const int64_t e = perm[k];
+    s = fma(jb[e], lb[jrow[e]], s);
+  }
+  out[b * n_z + col] = s;
+}
+
+static int grad_gamma_generic(mpx_ctx* c, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                              const double* sigma, double* ggx) {
+  if (batch > 65535) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_eval_grad_gamma: batch must be <= 65535 on this route");
+  int rc;
+  if (!c->d_colind_j) {
+    std::vector<int64_t> perm((size_t)std::max<int64_t>(c->nnz_j, 1)), colind((size_t)c->n_z + 1);
+    if ((rc = mpx_ccs_perm(c, MPX_JAC, perm.data(), colind.data()))) return rc;
+    if ((rc = upload(c, &c->d_colind_j, colind)) || (rc = upload(c, &c->d_jrow, c->jrow))) return rc;
+  }
+  if ((rc = upload_ccs_perm(c, MPX_JAC, &c->d_perm_j))) return rc;
+  if ((rc = reserve(c, c->gl_grad, (size_t)(batch * c->n_z))) || (rc = reserve(c, c->gl_jac, (size_t)(batch * std::max<int64_t>(c->nnz_j, 1))))) return rc;
+  if ((rc = eval_native(c, MPX_GRAD | MPX_JAC, batch, z, p, p_per_point, nullptr, nullptr, nullptr, nullptr, c->gl_grad.p, c->gl_jac.p, nullptr, false))) return rc;
+  hipLaunchKernelGGL(mpx_jtvec_kernel, dim3((unsigned)((c->n_z + 255) / 256), (unsigned)batch), dim3(256), 0, c->stream, c->gl_jac.p, c->nnz_j, c->gl_grad.p, lam_g,
+                     c->n_g, sigma, c->d_colind_j, c->d_perm_j, c->d_jrow, c->n_z, ggx);
+  HIPCHK(c, hipGetLastError());
+  return MPX_OK;
+}
+
+extern "C" int mpx_eval_grad_gamma_device(mpx_ctx* c, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                                          const double* sigma, double* grad_gamma_x, double* grad_gamma_p) {
+  if (!c) return MPX_ERR_INVALID;
+  if (!c->has_device)
+    return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval_grad_gamma: context was created without a gfx950 code object; there is no CPU fallback");
+  if (batch < 1 || batch > (1 << 30) || !z || (!p && c->n_p > 0) || !lam_g || !sigma) return fail(c, MPX_ERR_INVALID, "mpx_eval_grad_gamma: batch/z/p/lam_g/sigma invalid");
+  if (c->shard_world > 1) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_eval_grad_gamma on a context in segment-sharded mode (mpx_shard_setup(ctx, 1, 0) leaves it)");
+  if (c->kind == 0 && (c->tile_begin != 0 || c->tile_end != (int64_t)c->tiles.size())) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_eval_grad_gamma with a tile sub-range");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->wcum_valid = false;
+  if (!grad_gamma_x && (!grad_gamma_p || c->n_p == 0)) return MPX_OK;
+  const bool generic = getenv("MPX_GRADL_GENERIC") != nullptr;  // (read per call: tests switch it inside one process)
+  if (c->kind == 1) return grad_gamma_x ? grad_gamma_generic(c, batch, z, p, p_per_point, lam_g, sigma, grad_gamma_x) : MPX_OK;  // (n_p == 0 there)
+  if (generic && grad_gamma_x) {
+    int rc = grad_gamma_generic(c, batch, z, p, p_per_point, lam_g, sigma, grad_gamma_x);
+    if (rc) return rc;
+    grad_gamma_x = nullptr;
+    if (!grad_gamma_p) return MPX_OK;
+  }
+  if (!c->fn_gradl_fin) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_eval_grad_gamma: the code object has no nlp_grad kernels (generated by an older mpopt_amd)");
+  for (auto& B : c->buckets)
+    if (!B.fn_gradl) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_eval_grad_gamma: the code object has no nlp_grad kernels (generated by an older mpopt_amd)");
+  const int64_t n_w = p_per_point ? batch : 1, nt = (int64_t)c->tiles.size();
+  int rc;
+  if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p))) || (rc = reserve(c, c->partial, (size_t)(batch * nt * c->nred))) ||
+      (rc = reserve(c, c->gl_pnode, (size_t)(batch * c->n_phases * c->N * 2))) ||
+      (rc = reserve(c, c->gl_halo, (size_t)(batch * c->n_phases * c->S * (c->nx + c->nu)))))
+    return rc;
+  hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(MPX_PREFIX_THREADS), 0, c->stream, p, c->wcum.p, c->S);
+  HIPCHK(c, hipGetLastError());
+  for (auto& B : c->buckets) {
+    const PhaseStruct& P = c->ph[B.phase];
+    const DegTable& t = c->degs[B.dt];
+    MpxGradlArgs A{};
+    A.z = z, A.z_stride = c->n_z;
+    A.w = p, A.wcum = c->wcum.p, A.w_stride = p_per_point ? c->n_p : 0;
+    A.lam_g = lam_g, A.lam_stride = c->n_g, A.sigma = sigma;
+    A.gx = grad_gamma_x, A.gx_stride = c->n_z;
+    A.halo = c->gl_halo.p, A.pnode = c->gl_pnode.p, A.partial = c->partial.p;
+    A.n_tiles_total = (int32_t)nt, A.nred = c->nred, A.B = (int32_t)batch;
+    A.tiles = c->d_tiles, A.node_i = B.d_node_i, A.node_sk = B.d_node_sk;
+    A.Dmat = t.d_D, A.Cmid = t.d_Cmid, A.tk = t.d_tk, A.Wnode = c->d_Wnode;
+    A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
+    A.z_off = P.z_off, A.g_off_F = P.g_off_F, A.g_off_C = P.g_off_C, A.g_off_DU = P.g_off_DU, A.g_off_mU = P.g_off_mU;
+    A.N = (int32_t)c->N, A.seg_off = B.phase * c->S, A.tile_first = B.tile_first, A.phase = B.phase, A.S = c->S;
+    for (int64_t bf = 0; bf < batch; bf += 65535) {
+      A.b_first = (int32_t)bf;
+      if ((rc = launch(c, B.fn_gradl, dim3((unsigned)B.tile_count, (unsigned)std::min<int64_t>(65535, batch - bf), 1), dim3(MPX_TILE, 1, 1), &A, sizeof A))) return rc;
+    }
+  }
+  MpxGradlFinArgs F{};
+  F.z = z, F.z_stride = c->n_z, F.lam_g = lam_g, F.lam_stride = c->n_g, F.sigma = sigma;
+  F.gx = grad_gamma_x, F.gx_stride = c->n_z;
+  F.gp = c->n_p ? grad_gamma_p : nullptr, F.gp_stride = c->n_p;
+  F.halo = c->gl_halo.p, F.pnode = c->gl_pnode.p, F.partial = c->partial.p;
+  F.n_tiles_total = (int32_t)nt, F.nred = c->nred;
+  for (int p_ = 0; p_ < c->n_phases; ++p_) {
+    const PhaseStruct& P = c->ph[p_];
+    F.ph[p_].z_off = P.z_off, F.ph[p_].N = (int32_t)c->N, F.ph[p_].tile_first = P.tile_first, F.ph[p_].tile_count = P.tile_count;
+    F.ph[p_].tile_count_h = P.tile_count, F.ph[p_].g_off_TC = P.g_off_TC, F.ph[p_].jac_TC = P.jac_TC;
+  }
+  F.seg_start = c->d_seg_start, F.S = c->S, F.n_lt = (int32_t)c->lt_col.size();
+  F.lt_ptr = c->d_lt_ptr, F.lt_col = c->d_lt_col, F.lt_row = c->d_lt_row, F.lt_coef = c->d_lt_coef;
+  for (int64_t bf = 0; bf < batch; bf += 1 << 20) {  // (one workgroup per evaluation point; slices keep gridDim.x small)
+    MpxGradlFinArgs Fs = F;
+    const int64_t nb = std::min<int64_t>(1 << 20, batch - bf);
+    Fs.z += bf * c->n_z, Fs.lam_g += bf * c->n_g, Fs.sigma += bf;
+    if (Fs.gx) Fs.gx += bf * c->n_z;
+    if (Fs.gp) Fs.gp += bf * c->n_p;
+    Fs.halo += bf * c->n_phases * c->S * (c->nx + c->nu), Fs.pnode += bf * c->n_phases * c->N * 2, Fs.partial += bf * nt * c->nred;
+    if ((rc = launch(c, c->fn_gradl_fin, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), &Fs, sizeof Fs))) return rc;
+  }
+  return MPX_OK;
+}
+
+extern "C" int mpx_eval_grad_gamma(mpx_ctx* c, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                                   const double* sigma, double* grad_gamma_x, double* grad_gamma_p) {
+  if (!c) return MPX_ERR_INVALID;
+  if (!c->has_device)
+    return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval_grad_gamma: context was created without a gfx950 code object; there is no CPU fallback");
+  if (batch < 1 || !z || (!p && c->n_p > 0) || !lam_g || !sigma) return fail(c, MPX_ERR_INVALID, "mpx_eval_grad_gamma: batch/z/p/lam_g/sigma invalid");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t B = (size_t)batch, npv = (size_t)(p_per_point ? batch : 1) * c->n_p;
+  int rc;
+  if ((rc = reserve(c, c->st_z, B * c->n_z)) || (rc = reserve(c, c->st_p, std::max<size_t>(npv, 1))) || (rc = reserve(c, c->st_lam, B * std::max<int64_t>(c->n_g, 1))) ||
+      (rc = reserve(c, c->st_sig, B)))
+    return rc;
+  if (grad_gamma_x && (rc = reserve(c, c->st_ggx, B * c->n_z))) return rc;
+  if (grad_gamma_p && c->n_p && (rc = reserve(c, c->st_ggp, B * c->n_p))) return rc;
+  c->last_p.clear();  // (the staged widths are overwritten: the host path's "same p" shortcut must not trust them)
+  HIPCHK(c, hipMemcpyAsync(c->st_z.p, z, B * c->n_z * 8, hipMemcpyHostToDevice, c->stream));
+  if (npv) HIPCHK(c, hipMemcpyAsync(c->st_p.p, p, npv * 8, hipMemcpyHostToDevice, c->stream));
+  if (c->n_g) HIPCHK(c, hipMemcpyAsync(c->st_lam.p, lam_g, B * c->n_g * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_sig.p, sigma, B * 8, hipMemcpyHostToDevice, c->stream));
+  if ((rc = mpx_eval_grad_gamma_device(c, batch, c->st_z.p, c->st_p.p, p_per_point, c->st_lam.p, c->st_sig.p, grad_gamma_x ? c->st_ggx.p : nullptr,
+                                       grad_gamma_p && c->n_p ? c->st_ggp.p : nullptr)))
+    return rc;
+  if (grad_gamma_x) HIPCHK(c, hipMemcpyAsync(grad_gamma_x, c->st_ggx.p, B * c->n_z * 8, hipMemcpyDeviceToHost, c->stream));
+  if (grad_gamma_p && c->n_p) HIPCHK(c, hipMemcpyAsync(grad_gamma_p, c->st_ggp.p, B * c->n_p * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return MPX_OK;
 }

@@ -46,6 +46,7 @@ struct Bucket {
   int abs_slots = 0;                   // row slots of that buffer (g rows + grad_f rows per node)
   int32_t *d_node_i = nullptr, *d_node_sk = nullptr;
   hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
+  hipFunction_t fn_gradl = nullptr;  // mpx_node_gradl_<phase>_<deg> (nlp_grad)
 };
 
 template <class T>
@@ -82,6 +83,9 @@ struct mpx_ctx {
   std::vector<int64_t> mg_dst, hc_dst, th_dst;
   std::vector<int32_t> mg_off, hc_off, th_off;
   int nred = 1;
+  // linear rows transposed (nlp_grad: J^T lam_g of the control-slope continuity and event rows), CSC over the columns they touch
+  std::vector<int64_t> lt_ptr, lt_col, lt_row;
+  std::vector<double> lt_coef;
   // device
   bool has_device = false;
   hipModule_t module = nullptr;
@@ -94,6 +98,13 @@ struct mpx_ctx {
           *d_hc_dst = nullptr, *d_th_dst = nullptr;
   double* d_lin_coef = nullptr;
   DevBuf<double> partial, wcum, st_z, st_p, st_lam, st_sig, st_f, st_g, st_grad, st_jac, st_hess;
+  // nlp_grad (mpx_eval_grad_gamma*): finishing kernel, staging of the node pass (MpxGradlArgs::halo / pnode), host-path outputs,
+  // and the generic J^T lam route (assembled contexts; MPX_GRADL_GENERIC=1): scratch grad_f / jac_val + compressed-column tables
+  hipFunction_t fn_gradl_fin = nullptr;
+  DevBuf<double> gl_halo, gl_pnode, st_ggx, st_ggp, gl_grad, gl_jac;
+  int64_t *d_lt_ptr = nullptr, *d_lt_col = nullptr, *d_lt_row = nullptr, *d_colind_j = nullptr;
+  double* d_lt_coef = nullptr;
+  int32_t* d_jrow = nullptr;
   // mixed-degree phases: packed staging of g / grad_f (MpxIO::gtmp) and the maps of mpx_unpack_kernel
   bool g_packed = false;
   int64_t gtmp_n = 0;

@@ -1013,6 +1013,261 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A) {
     if (l == 0 && io.f) io.f[b] = facc;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nlp_grad: grad_gamma_x = sigma * grad_f + J^T lam_g and grad_gamma_p = d gamma / d (segment widths), gamma = sigma f + lam_g^T g
+// -- the sixth oracle ca.nlpsol derives from mpopt's NLP (mpopt.py:757; evaluated once per solve, its -grad_gamma_p is the lam_p
+// the solver returns).  No Jacobian is stored: per node
+//   * the nonlinear part comes from the generated first derivatives of the node Lagrangian sig*qW - lF.fx + lC.c (G::gradl), which
+//     also give d/dkap and d/dth -- the two ways a segment width enters a node (h = (tf - t0) kap, t = t0 + (tf - t0) th,
+//     mpopt.py:184-198);
+//   * the D / mid-point interpolation blocks are linear rows: column (segment s, point j) of z receives sum_k lam[s, k] * D[k][j],
+//     a TRANSPOSED contraction over the segment's multipliers, which the workgroup stages in LDS like node_body stages X / U.  The
+//     first point of a segment is the last node of the previous one (mpopt.py:189-195), i.e. another lane's entry: its sum goes to
+//     the `halo` staging array and the finishing pass adds it (one addition, fixed order).
+// grad_gamma_p[s] = sum_{i in s} (gk_i / (tau1 - tau0) + gth_i * tk_i) + sum_{i in later segments} gth_i: the node pass leaves the two
+// per-node terms in `pnode`, the finishing pass forms the per-segment sums and the suffix sums in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PH, int P>
+__device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
+  using G = mpxgen::Phase<PH>;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
+  constexpr int P1 = P + 1, SEGS = MPX_TILE / P, SLOTS = SEGS * P1;
+  constexpr int NRED = 2 + NA;
+  // multiplier rows staged per segment: defect rows, control-slope rows (DIFF_U), mid-point control rows (MIDU)
+  constexpr int L_DU = NX, L_MU = NX + (G::DIFF_U ? NU : 0), NL = L_MU + (G::MIDU ? NU : 0);
+  __shared__ double sL[NL][SLOTS];
+  __shared__ double sD[P1 * P1];
+  __shared__ double sC[P * P1];
+  __shared__ double sRed[MPX_TILE / 64][NRED];
+  const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x, tot_ = gridDim.x * gridDim.y;  // XCD-blocked walk, as node_body
+  const unsigned xcd_ = lin_ % 8, q_ = tot_ / 8, r_ = tot_ % 8;
+  const unsigned item_ = xcd_ * q_ + (xcd_ < r_ ? xcd_ : r_) + lin_ / 8;
+  const unsigned bx_ = item_ % gridDim.x, by_ = item_ / gridDim.x;
+  const MpxTile T = A.tiles[A.tile_first + bx_];
+  const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
+  const bool act = l < T.n, own = l < T.n_own;
+  const int m = T.m0 + (act ? l : 0);
+  const int i = A.node_i[m], sk = A.node_sk[m];
+  const int s = sk >> 8, k = sk & 255;
+  const int base = ((k == 0) ? 0 : (l - T.node0) / P) * P1;
+  const bool halo = act && k == 1 && !T.node0;  // loads the multipliers of the segment's first node (owned by the previous segment)
+  const int N = A.N;
+  const int b = A.b_first + (int)by_;
+  for (int e = l; e < P1 * P1; e += MPX_TILE) sD[e] = A.Dmat[e];
+  for (int e = l; e < P * P1; e += MPX_TILE) sC[e] = A.Cmid[e];
+  const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride + A.z_off;
+  const double* __restrict__ lb = A.lam_g + (int64_t)b * A.lam_stride;
+  Vec<NX> Xs, lF;
+  Vec<NU> Us;
+  Vec<NA> As;
+  Vec<NC> lC;
+#pragma unroll
+  for (int a = 0; a < NX; ++a) Xs[a] = (zb + (int64_t)a * N)[i], lF[a] = (lb + (A.g_off_F + (int64_t)a * N))[i];
+#pragma unroll
+  for (int c = 0; c < NU; ++c) Us[c] = (zb + (int64_t)(NX + c) * N)[i];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) lC[j] = (lb + (A.g_off_C + (int64_t)j * N))[i];
+  const double* __restrict__ zt = zb + (int64_t)(NX + NU) * N;
+  const double t0v = zt[0], tfv = zt[1];
+#pragma unroll
+  for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
+  const int64_t woff = (int64_t)b * A.w_stride + A.seg_off + s;
+  const double ws = A.w[woff], wc = A.wcum[woff];
+  const double tkk = A.tk[k], Wn = A.Wnode[i];
+  if (act) {
+#pragma unroll
+    for (int a = 0; a < NX; ++a) sL[a][base + k] = lF[a];
+    if constexpr (G::DIFF_U) {
+#pragma unroll
+      for (int c = 0; c < NU; ++c) sL[L_DU + c][base + k] = (lb + (A.g_off_DU + (int64_t)c * N))[i];
+    }
+    if constexpr (G::MIDU) {  // the row of the mid-point before node i is i - 1 (mpopt.py:350-369); node 0 has none
+#pragma unroll
+      for (int c = 0; c < NU; ++c) sL[L_MU + c][base + k] = k >= 1 ? (lb + (A.g_off_mU + (int64_t)c * (N - 1)))[i - 1] : 0.0;
+    }
+    if (halo) {
+#pragma unroll
+      for (int a = 0; a < NX; ++a) sL[a][base] = (lb + (A.g_off_F + (int64_t)a * N))[i - 1];
+      if constexpr (G::DIFF_U) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) sL[L_DU + c][base] = (lb + (A.g_off_DU + (int64_t)c * N))[i - 1];
+      }
+      if constexpr (G::MIDU) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) sL[L_MU + c][base] = 0.0;
+      }
+    }
+  }
+  __syncthreads();
+  const double kap = ws * A.inv_dtau, th = wc + ws * tkk;
+  Vec<NX + NU> gx;
+  Vec<NRED> gr;
+  double gk, gth;
+  G::gradl(Xs, Us, t0v, tfv, As, kap, th, Wn, A.sigma[b], lF, lC, gx, gr, gk, gth);
+  // rows of the segment that reach column j: points 1..P, and point 0 in segment 0 only (node 0 owns the first row of D there;
+  // in every later segment that row belongs to the previous segment's block, mpopt.py:4035-4038)
+  const int klo = s == 0 ? 0 : 1;
+  auto col_D = [&](int row, int j) {
+    double acc = 0;
+    for (int kp = klo; kp < P1; ++kp) acc = fma(sL[row][base + kp], sD[kp * P1 + j], acc);
+    return acc;
+  };
+  auto col_C = [&](int row, int j) {
+    double acc = 0;
+    for (int kp = 1; kp < P1; ++kp) acc = fma(sL[row][base + kp], sC[(kp - 1) * P1 + j], acc);
+    return acc;
+  };
+  if (own && A.gx) {
+    double* __restrict__ gb = A.gx + (int64_t)b * A.gx_stride + A.z_off;
+#pragma unroll
+    for (int a = 0; a < NX; ++a) gb[(int64_t)a * N + i] = gx[a] + col_D(a, k);
+#pragma unroll
+    for (int c = 0; c < NU; ++c) {
+      double v = gx[NX + c];
+      if constexpr (G::DIFF_U) v += col_D(L_DU + c, k);
+      if constexpr (G::MIDU) v += col_C(L_MU + c, k);
+      gb[(int64_t)(NX + c) * N + i] = v;
+    }
+    if (halo && s >= 1) {
+      double* __restrict__ hb = A.halo + ((int64_t)b * A.S * MPX_NPH + A.seg_off + s) * (NX + NU);
+#pragma unroll
+      for (int a = 0; a < NX; ++a) hb[a] = col_D(a, 0);
+#pragma unroll
+      for (int c = 0; c < NU; ++c) {
+        double v = 0;
+        if constexpr (G::DIFF_U) v += col_D(L_DU + c, 0);
+        if constexpr (G::MIDU) v += col_C(L_MU + c, 0);
+        hb[NX + c] = v;
+      }
+    }
+  }
+  if (own) {
+    double* __restrict__ pn = A.pnode + (((int64_t)b * MPX_NPH + A.phase) * N + i) * 2;
+    pn[0] = fma(gth, tkk, gk * A.inv_dtau);
+    pn[1] = gth;
+  }
+#pragma unroll
+  for (int r = 0; r < NRED; ++r) {
+    const double v = wave_sum(own ? gr[r] : 0.0);
+    if (lane == 0) sRed[wave][r] = v;
+  }
+  __syncthreads();
+  if (l < NRED) {
+    double v = 0;
+#pragma unroll
+    for (int w = 0; w < MPX_TILE / 64; ++w) v += sRed[w][l];
+    A.partial[((int64_t)b * A.n_tiles_total + T.tile_id) * A.nred + l] = v;
+  }
+}
+
+template <int PH>
+__device__ __forceinline__ void gradl_finish_phase(const MpxGradlFinArgs& A, int b, int l, double* red, double* sScan) {
+  using G = mpxgen::Phase<PH>;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA;
+  constexpr int NRED = 2 + NA;
+  static_assert(NRED <= MAXRED, "too many reduced quantities");
+  const MpxPhaseInfo& P = A.ph[PH];
+  const int N = P.N, S = A.S;
+  {  // (t0, tf, A) sums of the tile partials, in tile order (as boundary_phase)
+    __shared__ double sPart[256];
+    const double* __restrict__ pp = A.partial + ((int64_t)b * A.n_tiles_total + P.tile_first) * A.nred;
+    const int nred = A.nred, total = P.tile_count * nred;
+    const int per = (256 / nred) * nred;
+    double s = 0;
+    for (int c0 = 0; c0 < total; c0 += per) {
+      const int cnt = total - c0 < per ? total - c0 : per;
+      if (l < cnt) sPart[l] = pp[c0 + l];
+      __syncthreads();
+      if (l < NRED)
+        for (int e = l; e < cnt; e += nred) s += sPart[e];
+      __syncthreads();
+    }
+    if (l < NRED) red[l] = s;
+  }
+  __syncthreads();
+  if (A.gx) {
+    double* __restrict__ gb = A.gx + (int64_t)b * A.gx_stride + P.z_off;
+    if (l == 0) {  // terminal cost / constraints (mpopt.py:277-298): d (sig M + lT . tc) / d (XF, tf, X0, t0, A)
+      const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride + P.z_off;
+      Vec<NX> XF, X0;
+      Vec<NA> As;
+      Vec<G::NTC> lT;
+#pragma unroll
+      for (int a = 0; a < NX; ++a) XF[a] = zb[(int64_t)a * N + N - 1], X0[a] = zb[(int64_t)a * N];
+      const double* zt = zb + (int64_t)(NX + NU) * N;
+#pragma unroll
+      for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
+      const double* lb = A.lam_g + (int64_t)b * A.lam_stride + P.g_off_TC;
+      for (int j = 0; j < G::NTC; ++j) lT[j] = lb[j];
+      Vec<2 * NX + 2 + NA> tg;
+      G::term_gradl(XF, zt[1], X0, zt[0], As, A.sigma[b], lT, tg);
+      for (int a = 0; a < NX; ++a) gb[(int64_t)a * N + N - 1] += tg[a], gb[(int64_t)a * N] += tg[NX + 1 + a];
+      double* gt = gb + (int64_t)(NX + NU) * N;
+      gt[0] = red[0] + tg[2 * NX + 1];
+      gt[1] = red[1] + tg[NX];
+      for (int c = 0; c < NA; ++c) gt[2 + c] = red[2 + c] + tg[2 * NX + 2 + c];
+    }
+    // first node of segment s >= 1 = last node of segment s - 1: add what the rows of segment s contribute to its columns
+    const double* __restrict__ hb = A.halo + ((int64_t)b * S * MPX_NPH + (int64_t)PH * S) * (NX + NU);
+    for (int e = l; e < (S - 1) * (NX + NU); e += 256) {
+      const int s = 1 + e / (NX + NU), r = e % (NX + NU);
+      gb[(int64_t)r * N + A.seg_start[s]] += hb[(int64_t)s * (NX + NU) + r];
+    }
+  }
+  if (A.gp) {
+    // grad_gamma_p[s] = (sum of pnode[i][0] over the nodes segment s owns) + (sum of pnode[i][1] over the nodes of all LATER segments):
+    // a lane owns a contiguous chunk of segments, chunk totals meet in LDS, every sum runs from the last segment down
+    const double* __restrict__ pn = A.pnode + ((int64_t)b * MPX_NPH + PH) * (int64_t)N * 2;
+    double* __restrict__ gp = A.gp + (int64_t)b * A.gp_stride + (int64_t)PH * S;
+    const int chunk = (S + 255) / 256, s0 = l * chunk < S ? l * chunk : S, s1 = s0 + chunk < S ? s0 + chunk : S;
+    auto seg_sum = [&](int s, int which) {
+      double v = 0;
+      for (int i = A.seg_start[s + 1]; i > A.seg_start[s]; --i) v += pn[(int64_t)i * 2 + which];
+      if (s == 0) v += pn[which];  // node 0 belongs to segment 0
+      return v;
+    };
+    double tot = 0;
+    for (int s = s1 - 1; s >= s0; --s) tot += seg_sum(s, 1);
+    sScan[l] = tot;
+    __syncthreads();
+    double off = 0;
+    for (int q = 255; q > l; --q) off += sScan[q];
+    for (int s = s1 - 1; s >= s0; --s) {
+      gp[s] = seg_sum(s, 0) + off;
+      off += seg_sum(s, 1);
+    }
+  }
+  __syncthreads();
+}
+
+template <int PH>
+struct GradlFinLoop {
+  __device__ static __forceinline__ void run(const MpxGradlFinArgs& A, int b, int l, double* red, double* sScan) {
+    GradlFinLoop<PH - 1>::run(A, b, l, red, sScan);
+    gradl_finish_phase<PH>(A, b, l, red, sScan);
+  }
+};
+template <>
+struct GradlFinLoop<-1> {
+  __device__ static __forceinline__ void run(const MpxGradlFinArgs&, int, int, double*, double*) {}
+};
+
+__device__ __forceinline__ void gradl_finish_body(const MpxGradlFinArgs& A) {
+  __shared__ double red[MAXRED];
+  __shared__ double sScan[256];
+  const int b = blockIdx.x, l = threadIdx.x;
+  GradlFinLoop<MPX_NPH - 1>::run(A, b, l, red, sScan);
+  if (A.gx) {  // J^T lam_g of the linear rows (control-slope continuity, phase events), one lane per column they touch
+    double* __restrict__ gb = A.gx + (int64_t)b * A.gx_stride;
+    const double* __restrict__ lb = A.lam_g + (int64_t)b * A.lam_stride;
+    for (int c = l; c < A.n_lt; c += 256) {
+      double s = 0;
+      for (int64_t e = A.lt_ptr[c]; e < A.lt_ptr[c + 1]; ++e) s = fma(lb[A.lt_row[e]], A.lt_coef[e], s);
+      gb[A.lt_col[c]] += s;
+    }
+  }
+}
 }  // namespace mpxk
 
 #ifndef MPX_MIN_WAVES
@@ -1041,7 +1296,15 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A) {
     mpxk::hess_by_node_body<PH>(A);                                                                         \
   }
 
+#define MPX_INSTANTIATE_GRADL(PH, P)                                                                        \
+  extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_node_gradl_##PH##_##P(const MpxGradlArgs A) {  \
+    mpxk::gradl_body<PH, P>(A);                                                                             \
+  }
+
 #define MPX_INSTANTIATE_BOUNDARY()                                                                          \
+  extern "C" __global__ __launch_bounds__(256) void mpx_gradl_finish(const MpxGradlFinArgs A) {             \
+    mpxk::gradl_finish_body(A);                                                                             \
+  }                                                                                                         \
   extern "C" __global__ __launch_bounds__(256) void mpx_boundary_fg(const MpxBoundArgs A) {                 \
     mpxk::boundary_body<MPX_MODE_FG>(A);                                                                    \
   }                                                                                                         \

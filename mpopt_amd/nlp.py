@@ -1,6 +1,6 @@
-"""``NlpFunctions``: the five NLP oracle functions of a transcribed OCP, evaluated on the GPU.
+"""``NlpFunctions``: the NLP oracle functions of a transcribed OCP, evaluated on the GPU.
 
-This object stands where ``ca.nlpsol`` keeps ``nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l``
+This object stands where ``ca.nlpsol`` keeps ``nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l, nlp_grad``
 after differentiating mpopt's ``{"f","x","g","p"}`` dict (mpopt.py:757).  It owns one ``mpx_ctx``
 (include/mpx.h) and adds a batch dimension: every call evaluates ``B`` points in one launch.
 """
@@ -278,6 +278,37 @@ class NlpFunctions:
                                      _ptr(sigma), _ptr(f), _ptr(g), _ptr(grad_f), _ptr(jac_val), _ptr(hess_val))
         _lib.check(rc, self._ctx)
 
+    def eval_grad_gamma(self, z, p, lam_g, sigma, what=("grad_gamma_x", "grad_gamma_p")):
+        """``nlp_grad``: gradient of gamma = sigma * f + lam_g^T g w.r.t. x and w.r.t. the parameters p (mpx_eval_grad_gamma).
+        Host arrays; ``z`` (n_z,) or (B, n_z), ``lam_g`` / ``sigma`` broadcast over the batch.  Returns a dict."""
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        single = z.ndim == 1
+        z = z.reshape(-1, self.n_z)
+        B = z.shape[0]
+        p = np.zeros(0) if (p is None or self.n_p == 0) else np.ascontiguousarray(p, dtype=np.float64)
+        if p.size not in (self.n_p, B * self.n_p):
+            raise ValueError(f"p has {p.size} values, expected {self.n_p} or {B}x{self.n_p}")
+        per_point = int(p.size == B * self.n_p and B > 1)
+        lam = np.ascontiguousarray(np.broadcast_to(np.asarray(lam_g, dtype=np.float64).reshape(-1, self.n_g), (B, self.n_g)))
+        sig = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype=np.float64).reshape(-1), (B,)))
+        gx = np.empty((B, self.n_z)) if "grad_gamma_x" in what else None
+        gp = np.empty((B, self.n_p)) if "grad_gamma_p" in what else None
+        rc = self._L.mpx_eval_grad_gamma(self._ctx, B, _ptr(z), _ptr(p), per_point, _ptr(lam), _ptr(sig), _ptr(gx),
+                                         _ptr(gp) if self.n_p else None)
+        _lib.check(rc, self._ctx)
+        out = {}
+        if gx is not None:
+            out["grad_gamma_x"] = gx[0] if single else gx
+        if gp is not None:
+            out["grad_gamma_p"] = gp[0] if single else gp
+        return out
+
+    def eval_grad_gamma_device(self, batch, z, p, lam_g, sigma, grad_gamma_x=None, grad_gamma_p=None, p_per_point=0):
+        """Device pointers (torch tensors or ints), asynchronous on the context stream (mpx_eval_grad_gamma_device)."""
+        rc = self._L.mpx_eval_grad_gamma_device(self._ctx, int(batch), _ptr(z), _ptr(p), int(p_per_point), _ptr(lam_g), _ptr(sigma),
+                                                _ptr(grad_gamma_x), _ptr(grad_gamma_p))
+        _lib.check(rc, self._ctx)
+
     def alloc_outputs(self, mask, batch, z, p, p_per_point=0, lam_g=None, sigma=None, tries=6):
         """Output arrays for ``eval_device(mask, batch, ...)`` -- torch tensors f [batch], g [batch, n_g], grad_f [batch, n_z],
         jac_val [batch, nnz_jac], hess_val [batch, nnz_hess] for the outputs ``mask`` names, ``None`` for the others -- placed by
@@ -438,3 +469,14 @@ class NlpFunctions:
 
     def nlp_hess_l(self, x, p, lam_f, lam_g):
         return self.eval(["hess_l"], x, p, lam_g=lam_g, sigma=lam_f)["hess_l"]
+
+    def nlp(self, x, p):
+        r = self.eval(["f", "g"], x, p)
+        return r["f"], r["g"]
+
+    def nlp_grad(self, x, p, lam_f, lam_g):
+        """(f, g, grad_gamma_x, grad_gamma_p) -- what CasADi's Nlpsol evaluates once after the last iterate; ``lam_p`` of its result
+        is ``-grad_gamma_p`` at ``lam_f = 1``."""
+        r = self.eval(["f", "g"], x, p)
+        q = self.eval_grad_gamma(x, p, lam_g, lam_f)
+        return r["f"], r["g"], q["grad_gamma_x"], q["grad_gamma_p"]

@@ -42,6 +42,8 @@ def lib():
         L.orc_hess_capacity.argtypes = [ctypes.c_void_p]
         L.orc_hess.restype = ctypes.c_int64
         L.orc_hess.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double] + [ctypes.c_void_p] * 4
+        L.orc_grad_gamma.restype = ctypes.c_int
+        L.orc_grad_gamma.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double] + [ctypes.c_void_p] * 3
         L.orc_ipopt_mix.restype = None
         L.orc_ipopt_mix.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_double] + [ctypes.c_void_p] * 7
@@ -102,6 +104,14 @@ class COracle:
         n = L.orc_hess(self._h, z.ctypes.data, p.ctypes.data, float(sigma), lam.ctypes.data, rows.ctypes.data, cols.ctypes.data,
                        vals.ctypes.data)
         return dict(hess_row=rows[:n].copy(), hess_col=cols[:n].copy(), hess_val=vals[:n].copy())
+
+    def grad_gamma(self, z, p, sigma, lam_g):
+        """``nlp_grad``: (grad_gamma_x [n_z], grad_gamma_p [n_p]) of gamma = sigma*f + lam_g^T g."""
+        L = lib()
+        z, p, lam = np.ascontiguousarray(z, float), np.ascontiguousarray(p, float), np.ascontiguousarray(lam_g, float)
+        ggx, ggp = np.zeros(self.n_z), np.zeros(len(p))
+        assert L.orc_grad_gamma(self._h, z.ctypes.data, p.ctypes.data, float(sigma), lam.ctypes.data, ggx.ctypes.data, ggp.ctypes.data) == 0
+        return ggx, ggp
 
     def hess_matrix(self, z, p, sigma, lam_g):
         """Upper triangle of hess_l as a scipy CSR matrix (duplicates summed)."""

@@ -884,6 +884,72 @@ int orc_eval_many_omp(const orc* o, int64_t n_points, int reps, const double* Z,
   return nthreads;
 }
 
+/* nlp_grad (the sixth oracle ca.nlpsol derives at mpopt.py:757): gradient of gamma = sigma*f + lam_g^T g with respect to z
+ * (ggx[n_z] = sigma grad_f + J^T lam_g, accumulated over the hand-derived triplets of orc_eval) and with respect to the
+ * parameters p (ggp[n_ph*S]).  A width w_s enters node i of segment s through h = (tf - t0)/dtau * w_s (mpopt.py:184) and
+ * through t = t_seg0 + h (tau_k - tau0), t_seg0 = t0 + sum_{r<s} (tf - t0) w_r (mpopt.py:192-198):
+ *     d gamma_i / d w_s = d gamma_i/dh * (tf - t0)/dtau + d gamma_i/dt * (tf - t0)/dtau * (tau_k - tau0)     (own segment)
+ *     d gamma_i / d w_r = d gamma_i/dt * (tf - t0)                                                          (every r < s)
+ * with gamma_i = -sum_c lam_F[c,i] h Sx_c dyn_c + sum_j lam_C[j,i] pc_j + sigma W_i h L in the unscaled arguments. */
+int orc_grad_gamma(const orc* o, const double* z, const double* p, double sigma, const double* lam, double* ggx, double* ggp) {
+  const int N = o->N, nx = o->nx, nu = o->nu, na = o->na, nv = nx + nu + 1 + na;
+  if (ggx) {
+    double f, *grad = (double*)malloc(o->n_z * sizeof(double)), *vals = (double*)malloc((o->nnz + 1) * sizeof(double));
+    int32_t *rows = (int32_t*)malloc((o->nnz + 1) * sizeof(int32_t)), *cols = (int32_t*)malloc((o->nnz + 1) * sizeof(int32_t));
+    const int64_t n = orc_eval(o, z, p, &f, 0, grad, rows, cols, vals);
+    for (int64_t c = 0; c < o->n_z; ++c) ggx[c] = sigma * grad[c];
+    for (int64_t e = 0; e < n; ++e) ggx[cols[e]] += lam[rows[e]] * vals[e];
+    free(grad), free(vals), free(rows), free(cols);
+  }
+  if (!ggp) return 0;
+  double* later = (double*)malloc(o->S * sizeof(double)); /* sum over the nodes of segment s of d gamma_i/dt * (tf - t0) */
+  for (int ph = 0; ph < o->n_ph; ++ph) {
+    const ocp_fns* F = o->fn[ph];
+    const double* zp = z + ph * o->n_zp;
+    const double *X = zp, *U = zp + (int64_t)nx * N;
+    const int64_t zt = (int64_t)(nx + nu) * N;
+    const double t0 = zp[zt] / o->st, tf = zp[zt + 1] / o->st;
+    double a[MAXV];
+    for (int c = 0; c < na; ++c) a[c] = zp[zt + 2 + c] / o->sa[c];
+    const double* w = p + ph * o->S;
+    double* out = ggp + ph * o->S;
+    const double dtau = o->tau1 - o->tau0;
+    for (int s = 0; s < o->S; ++s) out[s] = 0, later[s] = 0;
+    double t_seg0 = t0, h = (tf - t0) / dtau * w[0];
+    for (int i = 0, s = 0; i < N; ++i) {
+      if (o->seg[i] != s) {
+        s = o->seg[i];
+        t_seg0 += h * dtau;
+        h = (tf - t0) / dtau * w[s];
+      }
+      const deg_table* T = tab(o, o->orders[s]);
+      const double tk = T->tau[o->pt[i]] - o->tau0, t = t_seg0 + h * tk;
+      double x[MAXV], u[MAXV], dyn[MAXV], pc[MAXV], L, ddyn[MAXV * MAXV], dpc[MAXV * MAXV], dL[MAXV];
+      for (int c = 0; c < nx; ++c) x[c] = X[(int64_t)c * N + i] / o->sx[c];
+      for (int c = 0; c < nu; ++c) u[c] = U[(int64_t)c * N + i] / o->su[c];
+      F->node(x, u, t, a, dyn, pc, &L);
+      F->node_d(x, u, t, a, ddyn, dpc, dL);
+      const int vt = nx + nu; /* index of t among the arguments */
+      double gh = sigma * o->compW[i] * L, gt = sigma * o->compW[i] * h * dL[vt];
+      for (int c = 0; c < nx; ++c) {
+        const double lf = lam[o->off_F[ph] + (int64_t)c * N + i];
+        gh -= lf * o->sx[c] * dyn[c];
+        gt -= lf * h * o->sx[c] * ddyn[c * nv + vt];
+      }
+      for (int j = 0; j < F->nc; ++j) gt += lam[o->off_C[ph] + (int64_t)j * N + i] * dpc[j * nv + vt];
+      out[s] += gh * (tf - t0) / dtau + gt * (tf - t0) / dtau * tk;
+      later[s] += gt * (tf - t0);
+    }
+    double run = 0;
+    for (int s = o->S - 1; s >= 0; --s) {
+      out[s] += run;
+      run += later[s];
+    }
+  }
+  free(later);
+  return 0;
+}
+
 /* Timed loop for bench.py: `reps` evaluations of f+g+grad_f+jac_g (values only) on `n_points`
  * different points; returns nothing, the caller clocks it. */
 void orc_eval_many(const orc* o, int64_t n_points, int reps, const double* Z, const double* p, double* f, double* g, double* grad,

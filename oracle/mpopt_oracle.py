@@ -478,6 +478,7 @@ class OracleNLP:
             d = dict(nc=len(c), ntc=len(TC), v=v, tvars=tvars,
                      vals=L(fx + c + [q], args),
                      jac=L([[sy.diff(e, s) for s in v] for e in fx + c + [q]], args),
+                     jacw=L([[sy.diff(e, kap), sy.diff(e, th)] for e in fx + c + [q]], args),
                      hes=L([[[sy.diff(e, s1, s2) for s2 in v] for s1 in v] for e in fx + c + [q]], args),
                      tvals=L([M] + TC, tvars),
                      tjac=L([[sy.diff(e, s) for s in tvars] for e in [M] + TC], tvars),
@@ -592,6 +593,29 @@ class OracleNLP:
             TJ = d["tjac"](*self._term_args(z, ph))
             np.add.at(g, np.array(self._tcols(ph)), np.array(TJ[0], float))
         return g
+
+    def grad_gamma(self, z, p, sigma, lam):
+        """``nlp_grad`` (derived by ca.nlpsol at mpopt.py:757): (d gamma / d x, d gamma / d p) of gamma = sigma*f + lam^T g.
+        x part: sigma * grad_f + jac_g^T lam through the full sparse Jacobian (the product never forms it on this path).
+        p part: a width w_s enters node i through kap_i = w_s / (tau1 - tau0) (i in segment s: h_s, mpopt.py:184) and through
+        th_i = sum_{r<s(i)} w_r + w_s(i) * tk_i (the running t_seg0 and the node's own offset, mpopt.py:192-198)."""
+        lam = np.asarray(lam, float)
+        ggx = sigma * self.grad_f(z, p) + self.jac_g(z, p).T @ lam
+        G, N, nx = self.grid, self.N, self.nx
+        offs, _ = self.row_offsets()
+        ggp = np.zeros(self.n_p)
+        tk = np.array([(G.taus[G.orders[s]][k] - G.tau0) / (G.tau1 - G.tau0) for s, k in zip(self.seg, self.pt)])
+        for ph in range(self.n_ph):
+            d, off = self.sym[ph], offs[ph]
+            Jw = d["jacw"](*self._node_args(z, p, ph))
+            wts = [-lam[off["F"] + a * N:off["F"] + (a + 1) * N] for a in range(nx)] + \
+                  [lam[off["C"] + j * N:off["C"] + (j + 1) * N] for j in range(d["nc"])] + [sigma * self.compW]
+            gk = sum(wt * self._bc(Jw[e][0]) for e, wt in enumerate(wts))   # d gamma_i / d kap_i
+            gth = sum(wt * self._bc(Jw[e][1]) for e, wt in enumerate(wts))  # d gamma_i / d th_i
+            for s in range(self.S):
+                own = self.seg == s
+                ggp[ph * self.S + s] = (gk[own] / (G.tau1 - G.tau0) + gth[own] * tk[own]).sum() + gth[self.seg > s].sum()
+        return ggx, ggp
 
     def hess_l(self, z, p, sigma, lam):
         """Dense symmetric Hessian of sigma*f + lam^T g."""
@@ -823,6 +847,10 @@ class OracleAdaptiveNLP(OracleNLP):
         if "grad" not in C:
             C["grad"] = sy.lambdify(C["syms"], [sy.diff(C["f"], s) for s in C["syms"]], "math", cse=True)
         return np.array(C["grad"](*[float(v) for v in z]), float)
+
+    def grad_gamma(self, z, p, sigma, lam):
+        """(d gamma / d x, empty): the adaptive NLP has no parameters (mpopt.py:3190-3192)."""
+        return sigma * self.grad_f(z) + self.jac_g(z).T @ np.asarray(lam, float), np.zeros(0)
 
     def hess_l(self, z, p, sigma, lam):
         """Dense symmetric Hessian of sigma*f + lam^T g (lam, sigma enter as symbols: one lambdify)."""

@@ -39,6 +39,10 @@ def test_numpy_oracle_matches_reference(name):
     Hr = Hr + np.triu(Hr, 1).T
     assert rel_err(H, Hr) < TOL
     assert np.abs(H - H.T).max() == 0 or rel_err(H, H.T) < 1e-14
+    # nlp_grad: gradient of sigma*f + lam^T g w.r.t. x and w.r.t. the parameters (segment widths)
+    ggx, ggp = O.grad_gamma(z, p, sig, lam)
+    assert rel_err(ggx, G["grad_gamma_x"]) < TOL and rel_err(ggp, G["grad_gamma_p"]) < TOL
+    assert np.abs(G["grad_gamma_p"]).max() > 1e-3  # (the goldens exercise it)
 
 
 C_CASES = {
@@ -74,6 +78,8 @@ def test_c_oracle_matches_reference(name):
     Hr[G["hess_row"], G["hess_col"]] = G["hess_val"]
     assert rel_err(H, Hr) < TOL
     assert set(zip(h["hess_row"].tolist(), h["hess_col"].tolist())) == set(zip(G["hess_row"].tolist(), G["hess_col"].tolist()))
+    ggx, ggp = C.grad_gamma(G["z"], G["p"], float(G["sigma"]), G["lam"])
+    assert rel_err(ggx, G["grad_gamma_x"]) < TOL and rel_err(ggp, G["grad_gamma_p"]) < TOL
     # the optional-output variants of the evaluation (what the separate nlp_* timings use) give the same numbers
     import ctypes
     from oracle import c_oracle
@@ -113,6 +119,15 @@ def test_c_oracle_time_dependent_problem_matches_numpy_oracle(S, po, scheme):
     H = C.hess_matrix(z, p, sig, lam).toarray()
     Ho = O.hess_l(z, p, sig, lam)
     assert rel_err(H + np.triu(H, 1).T, Ho) < TOL
+    gx, gp = C.grad_gamma(z, p, sig, lam)
+    gxo, gpo = O.grad_gamma(z, p, sig, lam)
+    assert rel_err(gx, gxo) < TOL and rel_err(gp, gpo) < TOL
+    # ... and d gamma / d p against central differences of gamma itself (d/dt terms of dynamics, path row and running cost alive)
+    gam = lambda pp: sig * O.f(z, pp) + lam @ O.g(z, pp)
+    for s_ in range(S):
+        e = np.zeros(S)
+        e[s_] = 1e-6
+        assert abs((gam(p + e) - gam(p - e)) / 2e-6 - gpo[s_]) < 1e-6 * max(1.0, np.abs(gpo).max())
     t0 = (ocp.nx + ocp.nu) * O.N
     assert abs(Ho[t0, t0]) > 1e-6 and abs(Ho[t0, t0 + 1]) > 1e-6 and abs(Ho[t0 + 1, t0 + 2]) > 1e-6  # the (t0, tf, a) corner is alive
 
@@ -152,6 +167,8 @@ def test_adaptive_oracle_matches_reference(name):
     Jr = np.zeros_like(J)
     Jr[G["jac_row"], G["jac_col"]] = G["jac_val"]
     assert rel_err(J, Jr) < TOL
+    ggx, ggp = O.grad_gamma(z, None, sig, lam)
+    assert rel_err(ggx, G["grad_gamma_x"]) < TOL and ggp.size == 0 and G["grad_gamma_p"].size == 0
     if O.n_z <= 40:  # whole-NLP sympy Hessians of the larger cases take too long for the CPU tier
         H = O.hess_l(z, None, sig, lam)
         Hr = np.zeros_like(H)
