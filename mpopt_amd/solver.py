@@ -27,6 +27,22 @@ class NlpSolver:
     def __call__(self, x0=None, p=None, lbx=None, ubx=None, lbg=None, ubg=None, lam_x0=None, lam_g0=None):
         orc = self.oracle
         p = np.zeros(0) if p is None else np.asarray(p, dtype=float).ravel()
+        return self._with_lam_p(self._solve(x0, p, lbx, ubx, lbg, ubg, lam_g0), p)
+
+    def _with_lam_p(self, sol, p):
+        """What CasADi's Nlpsol does after the last iterate (option ``calc_lam_p``, default true): ONE evaluation of ``nlp_grad`` at
+        the solution with ``lam_f = 1`` and the final multipliers; ``lam_p = -grad_gamma_p`` (the reference's tests assert the key,
+        tests/test_examples.py:44-45; "nlp_grad ... n_eval 1" in its recorded solves, moon_lander.ipynb:206).  On the GPU
+        (mpx_eval_grad_gamma)."""
+        if p.size and self.options.get("calc_lam_p", True):
+            q = self.oracle.eval_grad_gamma(np.asarray(sol["x"], float).ravel(), p, np.asarray(sol["lam_g"], float).ravel(), 1.0,
+                                            what=("grad_gamma_p",))
+            sol["lam_p"] = -q["grad_gamma_p"]
+            if isinstance(self.stats.get("n_eval"), dict):
+                self.stats["n_eval"]["nlp_grad"] = 1
+        return sol
+
+    def _solve(self, x0, p, lbx, ubx, lbg, ubg, lam_g0):
         standin = self.options.get("standin", "auto")
         if standin == "trust-constr":
             return self._trust_constr(x0, p, lbx, ubx, lbg, ubg)

@@ -3,8 +3,9 @@
  * not installable in the build image.  No CasADi source was available either: the protocol below is CasADi's documented
  * generated-code interface (the symbols a `CodeGenerator` emits and `external()` / `Importer` binds).
  *
- *   1. dlopen the library (no link-time dependency), dlsym EVERY companion symbol of nlp_f, nlp_g, nlp_grad_f, nlp_jac_g,
- *      nlp_hess_l: NAME, NAME_incref/_decref, NAME_n_in/_n_out, NAME_name_in/_name_out, NAME_sparsity_in/_sparsity_out,
+ *   1. dlopen the library (no link-time dependency), dlsym EVERY companion symbol of the base oracle nlp ((x, p) -> (f, g):
+ *      `nlpsol(name, solver, "lib.so")` is `nlpsol(name, solver, external("nlp", "lib.so"))`, so it is resolved FIRST and the
+ *      problem is sized from ITS sparsities) and then of nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l, nlp_grad: NAME, NAME_incref/_decref, NAME_n_in/_n_out, NAME_name_in/_name_out, NAME_sparsity_in/_sparsity_out,
  *      NAME_work and the optional NAME_alloc_mem/_init_mem/_free_mem/_checkout/_release/_default_in;
  *   2. read the sparsities (compressed column {nrow, ncol, colind[ncol+1], row[nnz]}; a dense pattern may stop after colind)
  *      and size ONE double arena `w` and ONE integer arena `iw` from them and from NAME_work, the way an nlpsol memory object
@@ -17,6 +18,9 @@
  *      with the SAME arena slices on every call (this is what lets mpx_current_pin_buffers(1) page-lock them once), a new x
  *      written into its slice per iterate, a rejected trial point now and then, and the NULL conventions (NULL arg = zeros,
  *      NULL res = not requested); NAME_release(mem); NAME_decref.
+ *   3b. after the last iterate, what Nlpsol does to fill lam_p (calc_lam_p, on by default): ONE call of
+ *          nlp_grad (x, p, lam_f = 1, lam_g) -> (NULL, NULL, NULL, grad_gamma_p)
+ *      and, as with calc_f / calc_g / calc_lam_x, once more with all four outputs; the base oracle nlp at the same point.
  *   4. Results of every iterate go to a file; the test compares them with the goldens and with mpx_eval.
  *
  * The context itself is created through the context API of the same library (in a deployment Python's mp.mpopt does that and
@@ -129,14 +133,20 @@ int main(int argc, char** argv) {
   if (p_sizes(ctx, &sz) != MPX_OK) return 2;
   if (p_set_current(ctx) != MPX_OK) return 2;
 
-  /* ---- 1. bind the five functions like an importer ---- */
-  static const char* NAMES[5] = {"nlp_f", "nlp_g", "nlp_grad_f", "nlp_jac_g", "nlp_hess_l"};
-  static const cint NIN[5] = {2, 2, 2, 2, 4}, NOUT[5] = {1, 1, 2, 2, 1};
+  /* ---- 1. bind the functions like an importer: the base oracle first, then the derived ones by name ---- */
+#define NFN 7
+#define I_NLP 5
+#define I_GRAD 6
+  static const char* NAMES[NFN] = {"nlp_f", "nlp_g", "nlp_grad_f", "nlp_jac_g", "nlp_hess_l", "nlp", "nlp_grad"};
+  static const cint NIN[NFN] = {2, 2, 2, 2, 4, 2, 4}, NOUT[NFN] = {1, 1, 2, 2, 1, 2, 4};
   static const char* IN_NAMES[4] = {"x", "p", "lam_f", "lam_g"};
-  static const char* OUT_NAMES[5][2] = {{"f", 0}, {"g", 0}, {"f", "grad_f_x"}, {"g", "jac_g_x"}, {"hess_gamma_x_x", 0}};
-  fn_t F[5];
+  static const char* OUT_NAMES[NFN][4] = {{"f", 0, 0, 0}, {"g", 0, 0, 0}, {"f", "grad_f_x", 0, 0}, {"g", "jac_g_x", 0, 0}, {"hess_gamma_x_x", 0, 0, 0},
+                                         {"f", "g", 0, 0}, {"f", "g", "grad_gamma_x", "grad_gamma_p"}};
+  static const int ORDER[NFN] = {I_NLP, 0, 1, 2, 3, 4, I_GRAD};
+  fn_t F[NFN];
   cint max_arg = 0, max_res = 0, max_iw = 0, max_w = 0;
-  for (int k = 0; k < 5; ++k) {
+  for (int kk = 0; kk < NFN; ++kk) {
+    const int k = ORDER[kk];
     fn_t* f = &F[k];
     memset(f, 0, sizeof *f);
     f->name = NAMES[k];
@@ -166,15 +176,18 @@ int main(int argc, char** argv) {
     f->incref();
   }
   /* ---- 2. sparsities -> sizes; ONE arena ---- */
-  const cint* sx = F[0].sp_in(0); const cint* spp = F[0].sp_in(1);
-  const cint* sg = F[1].sp_out(0); const cint* sj = F[3].sp_out(1); const cint* sh = F[4].sp_out(0);
+  const cint* sx = F[I_NLP].sp_in(0); const cint* spp = F[I_NLP].sp_in(1);  /* the base oracle sizes the problem */
+  const cint* sg = F[I_NLP].sp_out(1); const cint* sj = F[3].sp_out(1); const cint* sh = F[4].sp_out(0);
   const cint n_x = sx[0], n_p = spp[0], n_g = sg[0], nnz_j = sp_nnz(sj), nnz_h = sp_nnz(sh);
   if (n_x != sz.n_z || n_p != sz.n_p || n_g != sz.n_g || nnz_j != sz.nnz_jac || nnz_h != sz.nnz_hess) DIE(4, "sparsities disagree with mpx_get_sizes");
   if (sx[1] != 1 || sp_nnz(sx) != n_x || sj[0] != n_g || sj[1] != n_x || sh[0] != n_x || sh[1] != n_x) DIE(4, "sparsity shapes");
-  for (int k = 0; k < 5; ++k) {  /* every function sees the same x / p patterns; grad_f is dense n_x, lam_g dense n_g */
+  for (int k = 0; k < NFN; ++k) {  /* every function sees the same x / p patterns; grad_f is dense n_x, lam_g dense n_g */
     if (F[k].sp_in(0)[0] != n_x || F[k].sp_in(1)[0] != n_p) DIE(4, "%s: input patterns", NAMES[k]);
   }
   if (F[2].sp_out(1)[0] != n_x || F[4].sp_in(3)[0] != n_g || F[4].sp_in(2)[0] != 1 || F[0].sp_out(0)[0] != 1) DIE(4, "dense patterns");
+  if (F[1].sp_out(0)[0] != n_g || F[I_NLP].sp_out(0)[0] != 1 || F[I_GRAD].sp_in(2)[0] != 1 || F[I_GRAD].sp_in(3)[0] != n_g || F[I_GRAD].sp_out(0)[0] != 1 ||
+      F[I_GRAD].sp_out(1)[0] != n_g || F[I_GRAD].sp_out(2)[0] != n_x || F[I_GRAD].sp_out(3)[0] != n_p || sp_nnz(F[I_GRAD].sp_out(3)) != n_p)
+    DIE(4, "patterns of nlp / nlp_grad");
   for (cint j = 0; j < n_x; ++j) {  /* column pointers monotone, rows sorted inside a column, hess upper triangular */
     if (sj[2 + j + 1] < sj[2 + j] || sh[2 + j + 1] < sh[2 + j]) DIE(4, "colind not monotone");
     for (cint e = sj[2 + j]; e + 1 < sj[2 + j + 1]; ++e)
@@ -182,15 +195,15 @@ int main(int argc, char** argv) {
     for (cint e = sh[2 + j]; e < sh[2 + j + 1]; ++e)
       if (sh[2 + n_x + 1 + e] > j) DIE(4, "hess entry below the diagonal");
   }
-  /* arena layout (doubles): x | p | lam_f | lam_g | f | g | grad_f | jac | hess | function scratch */
+  /* arena layout (doubles): x | p | lam_f | lam_g | f | g | grad_f | jac | hess | grad_gamma_x | lam_p | function scratch */
   const cint o_x = 0, o_p = o_x + n_x, o_lf = o_p + n_p, o_lg = o_lf + 1, o_f = o_lg + n_g, o_g = o_f + 1, o_gr = o_g + n_g,
-             o_j = o_gr + n_x, o_h = o_j + nnz_j, o_w = o_h + nnz_h, n_w = o_w + max_w;
+             o_j = o_gr + n_x, o_h = o_j + nnz_j, o_ggx = o_h + nnz_h, o_lp = o_ggx + n_x, o_w = o_lp + n_p, n_w = o_w + max_w;
   double* w = calloc((size_t)n_w + 1, sizeof(double));
   cint* iw = calloc((size_t)max_iw + 1, sizeof(cint));
   const double** arg = calloc((size_t)max_arg + 1, sizeof(double*));
   double** res = calloc((size_t)max_res + 1, sizeof(double*));
   if (!w || !iw || !arg || !res) return 70;
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < NFN; ++k) {
     F[k].mem = F[k].checkout();
     if (F[k].mem < 0) DIE(5, "%s_checkout", NAMES[k]);
   }
@@ -267,6 +280,25 @@ int main(int argc, char** argv) {
     if (F[4].eval(arg, res, iw, w + o_w, F[4].mem)) DIE(7, "nlp_hess_l with NULL multipliers");
     for (cint e = 0; e < nnz_h; ++e)
       if (h0[e] != 0.0) DIE(7, "Hessian with zero multipliers is not zero at %lld", e);
+    /* 3b. after the last iterate: the base oracle at the same point, then nlp_grad the way Nlpsol calls it for lam_p (only the
+       fourth output, lam_f = 1), then with all four outputs */
+    double fg_f = -1;
+    double* fg_g = malloc(8 * (size_t)n_g + 8);
+    arg[0] = w + o_x; arg[1] = w + o_p; res[0] = &fg_f; res[1] = fg_g;
+    if (F[I_NLP].eval(arg, res, iw, w + o_w, F[I_NLP].mem) || fg_f != w[o_f] || memcmp(fg_g, w + o_g, 8 * (size_t)n_g)) DIE(8, "nlp (x, p) -> (f, g)");
+    const double one = 1.0;
+    arg[2] = &one; arg[3] = w + o_lg; res[0] = NULL; res[1] = NULL; res[2] = NULL; res[3] = w + o_lp;
+    if (F[I_GRAD].eval(arg, res, iw, w + o_w, F[I_GRAD].mem)) DIE(8, "nlp_grad (lam_p only)");
+    fwrite(w + o_lp, 8, (size_t)n_p, out);
+    double f3 = -1;
+    arg[2] = w + o_lf; res[0] = &f3; res[1] = fg_g; res[2] = w + o_ggx; res[3] = w + o_lp;
+    memset(fg_g, 0, 8 * (size_t)n_g);
+    if (F[I_GRAD].eval(arg, res, iw, w + o_w, F[I_GRAD].mem) || f3 != w[o_f] || memcmp(fg_g, w + o_g, 8 * (size_t)n_g)) DIE(8, "nlp_grad (all outputs)");
+    fwrite(w + o_ggx, 8, (size_t)n_x, out);
+    fwrite(w + o_lp, 8, (size_t)n_p, out);
+    res[0] = res[1] = res[2] = res[3] = NULL;
+    if (F[I_GRAD].eval(arg, res, iw, w + o_w, F[I_GRAD].mem)) DIE(8, "nlp_grad with all-NULL res");
+    free(fg_g);
     p_cache(&stats[0], &stats[1]);
     fwrite(stats, 8, 6, out);
     if (p_pin(0) != MPX_OK) return 2; /* unregisters h0 too: only now may it be freed */
@@ -274,7 +306,7 @@ int main(int argc, char** argv) {
     free(in);
   }
   fclose(out);
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < NFN; ++k) {
     F[k].release(F[k].mem);
     F[k].decref();
   }

@@ -55,6 +55,36 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(1.0, np.abs(b).max()) if a.size else 0.0
 
 
+def entry_errors(a, b, floor=None):
+    """Per-ENTRY relative error |a - b| / max(|b|, floor) of two arrays.  ``floor`` (scalar or array): the magnitude below which an
+    entry is compared absolutely -- the scale of the terms the entry is a sum of (an entry that is a difference of large terms
+    cannot be relatively accurate with respect to ITSELF).  Default: the median magnitude of the non-zero reference entries, i.e.
+    the typical size of an entry of this class -- NOT the largest entry of the array."""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    if a.shape != b.shape:
+        raise AssertionError(f"shape {a.shape} vs {b.shape}")
+    if a.size == 0:
+        return np.zeros(0), 1.0
+    if floor is None:
+        nz = np.abs(b[b != 0])
+        floor = float(np.median(nz)) if nz.size else 1.0
+    return np.abs(a - b) / np.maximum(np.abs(b), floor), floor
+
+
+def assert_entries(a, b, tol=1e-10, floor=None, what="", report=True):
+    """Every entry within ``tol`` relative (north_star: "within 1e-10 relative for FP64 residuals/derivatives"), see entry_errors.
+    Prints the worst per-entry relative error of the class so that it lands in the test log (-s / GPUTEST)."""
+    e, fl = entry_errors(a, b, floor)
+    worst = float(e.max()) if e.size else 0.0
+    if report:
+        print(f"[entries] {what}: n={e.size} worst per-entry rel err {worst:.2e} (floor {np.max(fl):.2e})")
+    if not worst <= tol:  # (also catches NaN)
+        k = int(np.nanargmax(e)) if not np.isnan(e).all() else 0
+        raise AssertionError(f"{what}: entry {np.unravel_index(k, e.shape)}: {np.asarray(a).ravel()[k]!r} vs {np.asarray(b).ravel()[k]!r}, "
+                             f"rel err {worst:.3e} > {tol:.1e} (floor {np.max(fl):.3e})")
+    return worst
+
+
 def emulate_shard_exchange(tables, rank_len, world, batch, arrays_by_rank, all_gather):
     """TEST INFRASTRUCTURE: host-side restatement of mpx_shard_pack / all-gather / mpx_shard_unpack over numpy arrays, from the
     table ``mpx_shard_table`` reports (CPU tests of the N>1 choreography; the product path uses the device kernels).

@@ -127,7 +127,8 @@ def _read_ccs(raw, off, n_x):
 
 @pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL"])
 def test_nlpsol_like_caller_binds_every_symbol_without_a_gpu(name, tmp_path):
-    """The importer half of the hand-off (mpopt.py:757): dlopen, all companion symbols of the five functions, names, counts,
+    """The importer half of the hand-off (mpopt.py:757): dlopen, all companion symbols of the base oracle nlp (resolved first) and
+    of nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l, nlp_grad, names, counts,
     work sizes and sparsities consistent with mpx_get_sizes / the COO patterns; the numerical entry point of a structure-only
     context returns non-zero (no CPU fallback)."""
     exe = build_nlpsol_like(tmp_path)
@@ -191,7 +192,13 @@ def test_nlpsol_like_caller_runs_ipopt_call_sequence_on_the_gpu(name, tmp_path):
     assert head[:6] == (o.n_z, o.n_p, o.n_g, o.nnz_jac, o.nnz_hess, K)
     per = 1 + o.n_g + o.n_z + o.nnz_jac + o.nnz_hess
     vals = np.frombuffer(raw, np.float64, K * per, 56).reshape(K, per)
-    fused, served, pins_first, pins_end, pins_failed, rejected = struct.unpack_from("<6q", raw, 56 + 8 * K * per)
+    tail = np.frombuffer(raw, np.float64, o.n_p + o.n_z + o.n_p, 56 + 8 * K * per)  # nlp_grad after the last iterate
+    lam_p_only, ggx, ggp = tail[:o.n_p], tail[o.n_p:o.n_p + o.n_z], tail[o.n_p + o.n_z:]
+    q1 = o.eval_grad_gamma(Z[K - 1], p, lam[K - 1], 1.0)          # as Nlpsol calls it for lam_p: lam_f = 1
+    q2 = o.eval_grad_gamma(Z[K - 1], p, lam[K - 1], sig[K - 1])   # all outputs, the iterate's own lam_f
+    assert np.array_equal(lam_p_only, q1["grad_gamma_p"]) and np.array_equal(ggx, q2["grad_gamma_x"]) and np.array_equal(ggp, q2["grad_gamma_p"])
+    assert np.abs(ggp).max() > 0
+    fused, served, pins_first, pins_end, pins_failed, rejected = struct.unpack_from("<6q", raw, 56 + 8 * K * per + 8 * (2 * o.n_p + o.n_z))
     ref = o.eval(["f", "g", "grad_f"], Z, p)
     refj = o.eval(["jac_g"], Z, p, ccs_order=True)
     refh = o.eval(["hess_l"], Z, p, lam_g=lam, sigma=sig, ccs_order=True)
