@@ -7,8 +7,11 @@ of CasADi's ``nlp_grad_f`` plus one call of ``nlp_jac_g`` produce: f, grad_f, g 
 values.  One *step* = one fused launch sequence over a batch of B evaluation points that are
 already resident in HBM (``mpx_eval_device``).  ``value`` = evaluations of all ranks / wall time.
 
-Multi-GPU (``--gpus N`` under torch.distributed.run): evaluation points are independent, so each
-rank processes its own batch of B points -- no data-path collective; weak scaling.  The ``*-shard``
+Multi-GPU (``--gpus N``): evaluation points are independent, so each rank processes its own batch of
+B points -- no data-path collective; weak scaling.  One process per GPU: under
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` the ranks are the launcher's;
+a plain ``python bench.py --gpus N`` re-launches ITSELF that way (N ranks on 127.0.0.1, rank 0 prints the
+one JSON line) after checking that N GPUs are visible.  The ``*-shard``
 workloads instead split the SEGMENTS of every evaluation over the ranks (contiguous tile
 ranges per rank, one RCCL all-gather of the owned residual / Jacobian runs per evaluation, boundary pass
 on every rank; ``mpopt_amd.distributed.SegmentShardedEvaluator``): total work is fixed, strong scaling.
@@ -279,18 +282,61 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed clock ramp before the warm-up steps: a fresh box starts in a low-power state and "
                          "runs ~18%% slower for the first few hundred milliseconds")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="stop after the process group is up: every rank joins, rank 0 prints {\"launch_check\": ...}; needs no GPU with "
+                         "MPX_DIST_BACKEND=gloo (what the CPU test of the N-rank launch runs)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    backend = os.environ.get("MPX_DIST_BACKEND", "nccl")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by hand (or by a driver that does not wrap it in torchrun): become the launcher -- one process
+        # per GPU under torch.distributed.run on 127.0.0.1 (the container's host name may not resolve), the ranks run this file again
+        # with RANK / LOCAL_RANK / WORLD_SIZE set and rank 0 prints the line.
+        import socket
+        import subprocess
+
+        if backend == "nccl":  # RCCL: one GPU per rank (MPX_DIST_BACKEND=gloo lets ranks share a GPU: 1-GPU smoke tests)
+            n_vis = torch.cuda.device_count()
+            if n_vis < args.gpus:
+                sys.exit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible (one process per GPU over RCCL)")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     from mpopt_amd import distributed as mpd
+
+    if args.launch_check:
+        rank, world, local_rank = mpd.init_from_env(backend)
+        assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} rank(s)"
+        seen = 1.0
+        if world > 1:
+            import torch.distributed as dist
+
+            t = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)) if backend == "nccl" else None)
+            dist.all_reduce(t)
+            seen = float(t.item())
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "backend": backend if world > 1 else None, "all_reduce_of_ones": seen}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # nccl == RCCL on ROCm.  MPX_DIST_BACKEND=gloo lets several ranks share one GPU (smoke test of the
     # multi-rank code path on a 1-GPU box); the device is then local_rank modulo the visible GPUs.
-    backend = os.environ.get("MPX_DIST_BACKEND", "nccl")
     n_dev = torch.cuda.device_count()
     if backend == "nccl":
         assert int(os.environ.get("LOCAL_RANK", "0")) < n_dev, "one process per GPU: LOCAL_RANK exceeds the visible GPUs"
     rank, world, local_rank = mpd.init_from_env(backend)
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} rank(s): n_gpus on the line is the number of ranks that ran"
     if world > 1:
         import torch.distributed as dist
     dev_id = local_rank % n_dev
@@ -304,6 +350,9 @@ def main():
         probe = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else None)
         dist.all_reduce(probe)
         census["all_reduce_of_ones"] = float(probe.item())
+        assert census["all_reduce_of_ones"] == world
+        if backend == "nccl":  # an N-GPU line must come from N distinct GPUs
+            assert census["distinct_gpus"] == world, f"{world} ranks on {census['distinct_gpus']} distinct GPU(s): {census['ranks']}"
 
     import mpopt_amd as M
     from mpopt_amd import mp

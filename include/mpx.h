@@ -244,8 +244,11 @@ int mpx_get_tile_weights(const mpx_ctx* ctx, int64_t* weights);
  * outside the limits of the scheme.  Arrays of n_tiles entries; host-only contexts answer too (the plan is host arithmetic). */
 int mpx_get_tile_spans(const mpx_ctx* ctx, int32_t* span_first, int32_t* span_len, int32_t* n_foreign);
 /* Device buffer holding the per-tile partial sums of the last mpx_eval_device call
- * ([batch][n_tiles][width] doubles; entries of tiles outside the tile range are untouched).  Ranks
- * sum this buffer (and their disjoint output slices) before the MPX_BOUNDARY_ONLY pass. */
+ * ([batch][n_tiles][width] doubles; entries of tiles outside the tile range are untouched -- except that the hess_l pass of a
+ * MIXED-DEGREE grid writes the slots of its own node-ordered tiles, phase tile_first + k for its k-th tile of the phase: a tile
+ * range maps proportionally onto them, so a rank's slots there need not lie inside its [tile_begin, tile_end), and the slots past a
+ * phase's last node-ordered tile are nobody's).  Ranks exchange the slots they own (mpx_shard_table, kind 2) before the
+ * MPX_BOUNDARY_ONLY pass. */
 int mpx_get_partials(mpx_ctx* ctx, int64_t batch, double** device_ptr, int64_t* count);
 
 /* Segment-sharded evaluation over `world` ranks (one process per GPU; the collective itself is the caller's: RCCL through

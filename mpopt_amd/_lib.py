@@ -68,13 +68,25 @@ def _build_lock(path):
             fcntl.flock(fh, fcntl.LOCK_UN)
 
 
+def _flags_stamp():
+    """The extra flags the library on disk was built with (diagnostics builds: MPX_LIB_HIPCC_FLAGS); '' for a plain build."""
+    try:
+        with open(LIB_PATH + ".flags") as f:
+            return f.read()
+    except OSError:
+        return ""
+
+
 def build_library(force=False, verbose=False):
     """hipcc -> mpopt_amd/libmpx.so (host runtime + generic kernels, gfx950).  Objects and the library are written under
-    private temporary names and moved into place atomically; a file lock serialises concurrent builders."""
-    if not force and not _stale(LIB_PATH, _sources()):
+    private temporary names and moved into place atomically; a file lock serialises concurrent builders.  The flags of
+    MPX_LIB_HIPCC_FLAGS are part of the staleness check: a diagnostics build neither poisons later plain runs nor is silently
+    skipped."""
+    want = os.environ.get("MPX_LIB_HIPCC_FLAGS", "")
+    if not force and not _stale(LIB_PATH, _sources()) and _flags_stamp() == want:
         return LIB_PATH
     with _build_lock(os.path.join(PKG, ".build.lock")):
-        if not force and not _stale(LIB_PATH, _sources()):
+        if not force and not _stale(LIB_PATH, _sources()) and _flags_stamp() == want:
             return LIB_PATH  # another process built it while we waited
         with tempfile.TemporaryDirectory(dir=PKG, prefix=".build_") as tmp:
             return _build_library_in(tmp, verbose)
@@ -104,6 +116,12 @@ def _build_library_in(tmp, verbose):
         if r.returncode:
             raise MpxError("building libmpx failed: " + " ".join(cmd) + "\n" + r.stderr[:6000])
     os.replace(out, LIB_PATH)
+    stamp = LIB_PATH + ".flags"
+    if extra:
+        with open(stamp, "w") as f:
+            f.write(os.environ.get("MPX_LIB_HIPCC_FLAGS", ""))
+    elif os.path.exists(stamp):
+        os.remove(stamp)
     return LIB_PATH
 
 

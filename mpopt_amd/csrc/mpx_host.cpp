@@ -747,6 +747,22 @@ __global__ __launch_bounds__(MPX_PREFIX_THREADS) void mpx_prefix_kernel(const do
   prefix_scan_block([&](int s) { return a[s]; }, wcum + (int64_t)blockIdx.x * S, S, threadIdx.x, wave_tot);
 }
 
+// (a re-allocation loses the prefix sums the buffer held)
+inline int reserve_wcum(mpx_ctx* c, size_t n) {
+  const double* before = c->wcum.p;
+  const int rc = reserve(c, c->wcum, n);
+  if (c->wcum.p != before) c->wcum_phases = 0;
+  return rc;
+}
+inline uint32_t all_phases(const mpx_ctx* c) { return c->n_phases >= 32 ? ~0u : ((1u << c->n_phases) - 1u); }
+// exclusive prefix sums of n_w width vectors at device address p into c->wcum (all phases), with the bookkeeping MPX_WIDTHS_UNCHANGED relies on
+int launch_prefix(mpx_ctx* c, const double* p, int64_t n_w, int p_per_point) {
+  hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(MPX_PREFIX_THREADS), 0, c->stream, p, c->wcum.p, c->S);
+  HIPCHK(c, hipGetLastError());
+  c->wcum_p = p, c->wcum_batch = n_w, c->wcum_ppp = p_per_point ? 1 : 0, c->wcum_phases = all_phases(c);
+  return MPX_OK;
+}
+
 int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size_t size, unsigned lds_bytes = 0) {
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   HIPCHK(c, hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, lds_bytes, c->stream, nullptr, cfg));
@@ -804,12 +820,10 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
   const bool light = !(sig & 8);
   const char* env = getenv("MPX_BPB");  // tuning / test override (read per call: tools switch it inside one process)
   if (env && atoi(env) > 0 && mode != MPX_MODE_HESS) return {atoi(env), nullptr, nullptr};
-  // (the hess_l node kernels take one evaluation point per workgroup as a compile-time fact, mpx_kernels.h: MPX_HESS_ONE_POINT;
-  // MPX_BPB_HESS=n only for code objects built with -DMPX_HESS_ONE_POINT=0)
-  if (mode == MPX_MODE_HESS) {
-    const char* eh = getenv("MPX_BPB_HESS");
-    return {eh && atoi(eh) > 0 ? atoi(eh) : 1, nullptr, nullptr};
-  }
+  // (the hess_l node kernels take one evaluation point per workgroup as a compile-time fact, mpx_kernels.h: MPX_HESS_ONE_POINT --
+  // a host-side override could only leave points unevaluated, so there is none; a code object built with -DMPX_HESS_ONE_POINT=0
+  // runs its batch loop over one point per workgroup as well)
+  if (mode == MPX_MODE_HESS) return {1, nullptr, nullptr};
   const int64_t work = B * (c->tile_end - c->tile_begin);
   static const bool no_tune = getenv("MPX_NO_TUNE") != nullptr;
   if (no_tune || work < 8192 || !key || c->shard_world > 1) return {1, nullptr, nullptr};
@@ -1180,7 +1194,7 @@ extern "C" int mpx_get_comp_weights(const mpx_ctx* c, double* w) {
 
 extern "C" int mpx_geometry_reset(mpx_ctx* c) {
   if (!c) return MPX_ERR_INVALID;
-  for (auto& t : c->tune) t.stage = 0, t.uses = 0;
+  for (auto& t : c->tune) t.stage = -2, t.uses = 0;  // (re-allocated arrays: two unmeasured passes first, like a new entry)
   return MPX_OK;
 }
 
@@ -1463,10 +1477,9 @@ extern "C" int mpx_resid_eval_device(mpx_ctx* c, mpx_resid_plan* P, int64_t batc
   HIPCHK(c, hipSetDevice(c->device));
   const int64_t n_w = p_per_point ? batch : 1;
   int rc;
-  if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
+  if ((rc = reserve_wcum(c, (size_t)(n_w * c->n_p)))) return rc;
   c->wcum_valid = false;
-  hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(MPX_PREFIX_THREADS), 0, c->stream, p, c->wcum.p, c->S);
-  HIPCHK(c, hipGetLastError());
+  if ((rc = launch_prefix(c, p, n_w, p_per_point))) return rc;
   const PhaseStruct& Ph = c->ph[P->phase];
   for (auto& B : P->buckets) {
     MpxResidArgs A{};
@@ -2105,7 +2118,11 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
     c->ea_lds_allowed = 150 * 1024;
   }
   if (fast) {
-    if ((rc = reserve(c, c->wcum, (size_t)(batch * c->n_p)))) return rc;
+    const size_t wcap = c->wcum.cap;
+    if ((rc = reserve_wcum(c, (size_t)(batch * c->n_p)))) return rc;
+    // the prefix sums of this phase's new widths are left in wcum: they describe p_out (per point, this batch)
+    if (wcap != c->wcum.cap || c->wcum_p != p_out || c->wcum_batch != batch || c->wcum_ppp != 1) c->wcum_phases = 0;
+    c->wcum_p = p_out, c->wcum_batch = batch, c->wcum_ppp = 1, c->wcum_phases |= 1u << phase;
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
     const unsigned grid = (unsigned)std::min<int64_t>(batch, n_cu);  // persistent: a workgroup owns its compute unit's LDS
@@ -2113,6 +2130,7 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
     hipLaunchKernelGGL(mpx_equal_area_fast_kernel, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream, resid, (int)n_pts, p_in, p_out,
                        (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, damping, c->wcum.p, (int64_t)c->n_p, (int)batch, chunk, magic, pad, (int)pos_off, c->nx, phase * c->S, dbg);
   } else {
+    if (c->wcum_p == p_out) c->wcum_phases &= ~(1u << phase);  // the generic kernel changes the widths and leaves no prefix sums
     hipLaunchKernelGGL(mpx_equal_area_kernel, dim3((unsigned)batch), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
                        (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, (int)batch);
   }
@@ -2204,12 +2222,11 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
   if (c->kind == 1) return mpx_asm_eval_device(c, mask, batch, z, lam_g, sigma, f, g, grad_f, jac_val, hess_val);
   const int64_t n_w = p_per_point ? batch : 1;
   int rc;
-  if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p)))) return rc;
+  if ((rc = reserve_wcum(c, (size_t)(n_w * c->n_p)))) return rc;
   if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
-  if (!skip_prefix) {
-    hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(MPX_PREFIX_THREADS), 0, c->stream, p, c->wcum.p, c->S);
-    HIPCHK(c, hipGetLastError());
-  }
+  // MPX_WIDTHS_UNCHANGED (or the host path's "same p"): only if the buffer really holds the prefix sums of THIS p for every phase
+  if (skip_prefix && !(c->wcum_p == p && c->wcum_batch == n_w && c->wcum_ppp == (p_per_point ? 1 : 0) && c->wcum_phases == all_phases(c))) skip_prefix = false;
+  if (!skip_prefix && (rc = launch_prefix(c, p, n_w, p_per_point))) return rc;
   MpxIO io{};
   io.z = z;
   io.z_stride = c->n_z;
@@ -2296,7 +2313,7 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   if ((mask & MPX_HESS) && (!lam_g || !sigma || !hess_val)) return fail(c, MPX_ERR_INVALID, "mpx_eval: HESS needs lam_g, sigma, hess_val");
   if (((mask & MPX_F) && !f) || ((mask & MPX_G) && !g) || ((mask & MPX_GRAD) && !grad_f) || ((mask & MPX_JAC) && !jac_val))
     return fail(c, MPX_ERR_INVALID, "mpx_eval: a requested output array is NULL");
-  if ((rc = reserve(c, c->st_p, npv)) || (rc = reserve(c, c->wcum, npv))) return rc;
+  if ((rc = reserve(c, c->st_p, npv)) || (rc = reserve_wcum(c, npv))) return rc;
   const bool same_p = npv == 0 || c->wcum_valid && cap_p == c->st_p.cap && cap_w == c->wcum.cap && c->last_p.size() == npv &&
                       memcmp(c->last_p.data(), p, npv * 8) == 0;
   if (!same_p) {
@@ -2459,12 +2476,11 @@ extern "C" int mpx_eval_grad_gamma_device(mpx_ctx* c, int64_t batch, const doubl
     if (!B.fn_gradl) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_eval_grad_gamma: the code object has no nlp_grad kernels (generated by an older mpopt_amd)");
   const int64_t n_w = p_per_point ? batch : 1, nt = (int64_t)c->tiles.size();
   int rc;
-  if ((rc = reserve(c, c->wcum, (size_t)(n_w * c->n_p))) || (rc = reserve(c, c->partial, (size_t)(batch * nt * c->nred))) ||
+  if ((rc = reserve_wcum(c, (size_t)(n_w * c->n_p))) || (rc = reserve(c, c->partial, (size_t)(batch * nt * c->nred))) ||
       (rc = reserve(c, c->gl_pnode, (size_t)(batch * c->n_phases * c->N * 2))) ||
       (rc = reserve(c, c->gl_halo, (size_t)(batch * c->n_phases * c->S * (c->nx + c->nu)))))
     return rc;
-  hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(MPX_PREFIX_THREADS), 0, c->stream, p, c->wcum.p, c->S);
-  HIPCHK(c, hipGetLastError());
+  if ((rc = launch_prefix(c, p, n_w, p_per_point))) return rc;
   for (auto& B : c->buckets) {
     const PhaseStruct& P = c->ph[B.phase];
     const DegTable& t = c->degs[B.dt];

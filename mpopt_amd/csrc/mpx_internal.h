@@ -166,6 +166,14 @@ struct mpx_ctx {
   // upload and the prefix-sum launch are skipped while p is unchanged)
   std::vector<double> last_p;
   bool wcum_valid = false;
+  // what the device buffer `wcum` holds: the exclusive prefix sums of the width vectors at device address wcum_p (wcum_batch
+  // vectors, shared or per point) for the phases in wcum_phases.  Written by every prefix launch (all phases) and by the fast
+  // equal-area kernel (the phase it updated); MPX_WIDTHS_UNCHANGED is honoured only when it describes the call's own p -- otherwise
+  // the prefix kernel is launched after all (a generic equal-area update, a larger grid, another array: never stale sums)
+  const double* wcum_p = nullptr;
+  int64_t wcum_batch = 0;
+  int wcum_ppp = 0;
+  uint32_t wcum_phases = 0;
   // launch-geometry selection for large batches (run_mode): evaluation points per workgroup, measured once per output placement
   struct GeomTune {
     const void* key = nullptr;  // dominant output array of the pass

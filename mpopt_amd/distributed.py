@@ -105,6 +105,7 @@ class SegmentShardedEvaluator:
     MODES = ("allgather", "root", "owner")
 
     def __init__(self, oracle, rank=None, world=None, group=None, mode="allgather", root=0):
+        """``root``: the rank WITHIN ``group`` (not a global rank) that holds the result in mode "root"."""
         import torch.distributed as dist
 
         if mode not in self.MODES:
@@ -162,9 +163,10 @@ class SegmentShardedEvaluator:
             hr = recv.cpu() if recv is not None else None
         else:
             hs, hr = send, recv
-        if self.mode == "root":
+        if self.mode == "root":  # ``root`` is a rank of the GROUP; dist.gather's dst is a global rank
             parts = list(hr.view(self.world, -1).unbind(0)) if self.rank == self.root else None
-            dist.gather(hs, parts, dst=self.root, group=self.group)
+            dst = dist.get_global_rank(self.group, self.root) if self.group is not None else self.root
+            dist.gather(hs, parts, dst=dst, group=self.group)
         else:
             dist.all_gather_into_tensor(hr, hs, group=self.group)
         if host and recv is not None:

@@ -72,8 +72,15 @@ def _worker(rank, world, port, q):
         # every tile-produced value is owned exactly once; what nobody owns belongs to the boundary pass (terminal / linking entries)
         jr, jc = (o.jac_pattern() if mask != MPX_HESS else o.hess_pattern())
         assert owned[0].max() == 1 and owned[2].max() == 1
-        # (hess_l on a mixed-degree grid runs over node-ordered tiles: fewer of them than bucket tiles, the spare slots are nobody's)
-        assert owned[2].min() == 1 or mask == MPX_HESS
+        # (hess_l on a MIXED-DEGREE grid runs over node-ordered tiles: fewer of them than bucket tiles, and exactly the spare partial
+        # slots at the end of every phase's block are nobody's; everywhere else every slot is owned)
+        if mask == MPX_HESS and len(set(int(d) for d in o.poly_orders)) > 1:
+            nred, tpp, nht = sizes[2] // o.n_tiles, o.n_tiles // o.ocp.n_phases, -(-o.n_nodes // 256)
+            spare = np.concatenate([np.arange((ph * tpp + nht) * nred, (ph + 1) * tpp * nred) for ph in range(o.ocp.n_phases)])
+            for b_ in range(B):
+                assert np.array_equal(np.flatnonzero(owned[2].reshape(B, -1)[b_] == 0), spare)
+        else:
+            assert owned[2].min() == 1
         if 1 in sizes and sizes[1]:
             stride1 = int(tab[tab[:, 1] == 1][0, 4])
             assert owned[1].reshape(B, -1)[:, :stride1].min() == 1

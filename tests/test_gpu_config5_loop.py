@@ -4,6 +4,8 @@ Dirichlet(1), then five outer iterations of the h-adaptive loop with everything 
     equal-area width update, damped (mpx_equal_area_widths_device; mpopt.py:2636-2659, 2587-2590).
 Every iteration is checked: residuals against the numpy oracle on a sample of segments, hess_l against the C oracle (all
 entries), the new widths against the reference's rule (numpy restatement pinned by tests/golden/hadaptive.npz) at 1e-10."""
+import os
+
 import numpy as np
 import pytest
 
@@ -137,6 +139,26 @@ def test_mid_point_residuals_fused_into_the_hess_pass(case):
         assert torch.equal(Ha, Hb) and torch.equal(Ra, Rb) and not torch.equal(Ha, H0)
         p2h = p2.cpu().numpy()
         assert np.abs(p2h.sum(axis=1) - 1).max() < 1e-9 and p2h.min() > 0
+        # ... and the flag is never trusted blindly: the GENERIC equal-area kernel (larger grids; MPX_EA_GENERIC=1) leaves no prefix
+        # sums behind, neither does an update into another array -- the library then launches the prefix kernel after all instead of
+        # evaluating with the sums of older widths (round-3 advisor finding)
+        os.environ["MPX_EA_GENERIC"] = "1"
+        try:
+            p3 = torch.empty_like(p)
+            o.equal_area_widths_device(0, B, N - 1, Rb, p2, p3, damping=0.4, p_in_per_point=1)
+        finally:
+            del os.environ["MPX_EA_GENERIC"]
+        Hc, Hd = torch.empty_like(H0), torch.empty_like(H0)
+        o.set_mid_resid_output(None)
+        o.eval_device(MPX_HESS | MPX_WIDTHS_UNCHANGED, B, Z, p3, 1, lam, sig, None, None, None, None, Hc)
+        o.eval_device(MPX_HESS, B, Z, p3, 1, lam, sig, None, None, None, None, Hd)
+        o.sync()
+        assert torch.equal(Hc, Hd) and not torch.equal(Hc, Hb)
+        p4 = p3.clone()  # same widths at another address: the sums on the device describe p3, not p4
+        o.equal_area_widths_device(0, B, N - 1, Rb, p2, p3, damping=0.4, p_in_per_point=1)  # fast kernel: prefix sums of p3
+        o.eval_device(MPX_HESS | MPX_WIDTHS_UNCHANGED, B, Z, p4, 1, lam, sig, None, None, None, None, Hc)
+        o.sync()
+        assert torch.equal(Hc, Hd)
     o.set_mid_resid_output(None)
     with pytest.raises(M.MpxError):
         o.eval_device(MPX_HESS | MPX_MID_RESID, B, Z, p, 1, lam, sig, None, None, None, None, H1)
