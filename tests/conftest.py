@@ -29,3 +29,26 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Worst PER-ENTRY relative error of every entry class the parity tests compared (helpers.assert_entries), so that the figures
+    land in the test log also when the tests pass and output is captured (north_star: 1e-10 relative for FP64 residuals/derivatives)."""
+    try:
+        from helpers import ENTRY_LOG
+    except Exception:
+        return
+    if not ENTRY_LOG:
+        return
+    groups = {}
+    for what, n, worst, floor in ENTRY_LOG:
+        case, _, cls = what.partition(" ")
+        g = groups.setdefault(cls or case, [0, 0, -1.0, ""])
+        g[0] += 1
+        g[1] += n
+        if worst > g[2]:
+            g[2], g[3] = worst, case
+    tr = terminalreporter
+    tr.write_sep("-", "per-entry parity: worst |a-b| / max(|b|, class floor) by entry class (tolerance 1e-10)")
+    for cls, (cnt, n, worst, case) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
+        tr.write_line(f"  {worst:9.2e}  {cls}  ({cnt} comparisons, {n} entries; worst in {case})")

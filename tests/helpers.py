@@ -71,6 +71,9 @@ def entry_errors(a, b, floor=None):
     return np.abs(a - b) / np.maximum(np.abs(b), floor), floor
 
 
+ENTRY_LOG = []  # (what, n, worst, floor) of every assert_entries call: tests/conftest.py prints the per-class summary at the end of the run
+
+
 def assert_entries(a, b, tol=1e-10, floor=None, what="", report=True):
     """Every entry within ``tol`` relative (north_star: "within 1e-10 relative for FP64 residuals/derivatives"), see entry_errors.
     Prints the worst per-entry relative error of the class so that it lands in the test log (-s / GPUTEST)."""
@@ -78,11 +81,68 @@ def assert_entries(a, b, tol=1e-10, floor=None, what="", report=True):
     worst = float(e.max()) if e.size else 0.0
     if report:
         print(f"[entries] {what}: n={e.size} worst per-entry rel err {worst:.2e} (floor {np.max(fl):.2e})")
+        ENTRY_LOG.append((what, int(e.size), worst, float(np.max(fl))))
     if not worst <= tol:  # (also catches NaN)
         k = int(np.nanargmax(e)) if not np.isnan(e).all() else 0
         raise AssertionError(f"{what}: entry {np.unravel_index(k, e.shape)}: {np.asarray(a).ravel()[k]!r} vs {np.asarray(b).ravel()[k]!r}, "
                              f"rel err {worst:.3e} > {tol:.1e} (floor {np.max(fl):.3e})")
     return worst
+
+
+def align_coo(rows, cols, rrows, rcols, rvals, what=""):
+    """Reference triplets aligned onto the pattern (rows, cols): array of len(rows) with the reference value of every entry (0
+    where the reference has none -- our explicit structural zeros); every reference entry must exist in the pattern."""
+    pos = {(int(r), int(c)): k for k, (r, c) in enumerate(zip(rows.tolist(), cols.tolist()))}
+    assert len(pos) == len(rows), f"{what}: duplicate entries in the pattern"
+    out = np.zeros(len(rows))
+    for r, c, v in zip(np.asarray(rrows).tolist(), np.asarray(rcols).tolist(), np.asarray(rvals).tolist()):
+        assert (r, c) in pos, f"{what}: reference entry {(r, c)} missing from the pattern"
+        out[pos[(r, c)]] += v
+    return out
+
+
+def border_columns(o):
+    """Indices of the (t0, tf, a) variables of every phase in z (the dense border of jac_g / hess_l, mpopt.py:537-543)."""
+    nzp = o.n_z // o.ocp.n_phases
+    k = (o.ocp.nx + o.ocp.nu) * o.n_nodes
+    return np.concatenate([np.arange(ph * nzp + k, ph * nzp + k + 2 + o.ocp.na) for ph in range(o.ocp.n_phases)])
+
+
+def assert_by_class(a, b, classes, tol=1e-10, what="", floors=None):
+    """Per-entry parity of aligned value arrays, one floor per ENTRY CLASS (north_star: 1e-10 relative for FP64 derivatives):
+    ``classes`` maps a class name to a boolean mask; every entry must belong to exactly one class.  Floor of a class = the median
+    magnitude of its non-zero reference entries unless ``floors[name]`` says otherwise.  Returns {class: worst per-entry rel err}."""
+    a, b = np.asarray(a, float).ravel(), np.asarray(b, float).ravel()
+    cover = np.zeros(a.size, int)
+    worst = {}
+    for name, m in classes.items():
+        m = np.asarray(m, bool).ravel()
+        cover += m
+        if m.any():
+            worst[name] = assert_entries(a[m], b[m], tol, floor=(floors or {}).get(name), what=f"{what} [{name}]")
+    assert (cover == 1).all(), f"{what}: classes do not partition the entries"
+    return worst
+
+
+def jac_classes(o, rows, cols, vals_ref, vals_ref_other):
+    """Entry classes of jac_g in a given (rows, cols) order: 'constant' = copies of differentiation / interpolation table entries
+    and the +-1 of linking rows (identical at two different evaluation points of the ORACLE), 'border' = the (t0, tf, a) columns,
+    'variable' = everything else the kernels compute from (z, p)."""
+    border = np.isin(cols, border_columns(o))
+    const = (np.asarray(vals_ref) == np.asarray(vals_ref_other)) & ~border
+    return {"constant (D / interpolation copies)": const, "border columns (t0, tf, a)": border, "variable node entries": ~const & ~border}
+
+
+def hess_classes(o, rows, cols):
+    bc = border_columns(o)
+    rb, cb = np.isin(rows, bc), np.isin(cols, bc)
+    return {"node bands": ~rb & ~cb, "border (node x (t0, tf, a))": rb ^ cb, "corner ((t0, tf, a) x (t0, tf, a))": rb & cb}
+
+
+def grad_classes(o):
+    m = np.zeros(o.n_z, bool)
+    m[border_columns(o)] = True
+    return {"node entries": ~m, "(t0, tf, a) entries (sums over all nodes)": m}
 
 
 def emulate_shard_exchange(tables, rank_len, world, batch, arrays_by_rank, all_gather):

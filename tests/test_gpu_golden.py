@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 import problems
-from helpers import assert_coo_close, build_case, load_golden, rel_err
+from helpers import (align_coo, assert_by_class, assert_coo_close, build_case, grad_classes, hess_classes, jac_classes, load_golden,
+                     rel_err)
 
 TOL = 1e-10
 pytestmark = pytest.mark.gpu
@@ -25,6 +26,16 @@ def test_golden_point(name):
     hr, hc = o.hess_pattern()
     assert (hr <= hc).all()
     assert_coo_close(hr, hc, r["hess_l"], G["hess_row"], G["hess_col"], G["hess_val"], TOL, "hess_l")
+    # ... and PER ENTRY, one floor per entry class (helpers.py): which Jacobian entries are grid constants is read off the numpy
+    # oracle (pinned to these goldens at 1e-12, tests/test_oracle.py) evaluated at a second point
+    from oracle.mpopt_oracle import OracleNLP
+
+    O = OracleNLP(ocp, *problems.GOLDEN_CASES[name][1:])
+    ja = align_coo(jr, jc, G["jac_row"], G["jac_col"], G["jac_val"], "jac_g")
+    J2 = O.jac_g(G["z0"], G["p_equal"]).toarray()
+    assert_by_class(r["jac_g"], ja, jac_classes(o, jr, jc, ja, J2[jr, jc]), TOL, f"{name} jac_g")
+    assert_by_class(r["hess_l"], align_coo(hr, hc, G["hess_row"], G["hess_col"], G["hess_val"], "hess_l"), hess_classes(o, hr, hc), TOL, f"{name} hess_l")
+    assert_by_class(r["grad_f"], G["grad_f"], grad_classes(o), TOL, f"{name} grad_f")
 
 
 @pytest.mark.parametrize("name", list(problems.GOLDEN_CASES))

@@ -9,7 +9,7 @@ import scipy.sparse as sp
 import mpopt_amd as M
 from mpopt_amd import mp
 import problems
-from helpers import rel_err
+from helpers import assert_by_class, assert_entries, grad_classes, hess_classes, jac_classes, rel_err
 from oracle.mpopt_oracle import OracleNLP
 from oracle.c_oracle import COracle
 
@@ -129,23 +129,37 @@ def test_full_size_against_c_oracle_and_properties(name):
     jr, jc = o.jac_pattern()
     hr, hc = o.hess_pattern()
     assert (hr <= hc).all() and len(set(zip(hr.tolist(), hc.tolist()))) == o.nnz_hess
+    # PER-ENTRY parity, one floor per entry class (north_star: "within 1e-10 relative for FP64 residuals/derivatives"): the
+    # oracle's values are aligned onto the GPU's pattern (its extra entries are explicit zeros), classes from helpers.py
+    cs = [C.eval(Z[b], p) for b in range(B)]
+    Jal = []
     for b in range(B):
-        c = C.eval(Z[b], p)
+        Jc = sp.coo_matrix((cs[b]["jac_val"], (cs[b]["jac_row"], cs[b]["jac_col"])), shape=(o.n_g, o.n_z)).tocsr()
+        Jal.append(np.asarray(Jc[jr, jc]).ravel())
+        assert np.count_nonzero(Jal[-1]) == np.count_nonzero(Jc.data)  # nothing of the oracle lies outside the GPU's pattern
+    nzp = o.n_z // ocp.n_phases
+    Xcols = np.zeros(o.n_z, bool)  # the state columns of every phase: a row with a CONSTANT entry there is a defect row (D block)
+    for ph in range(ocp.n_phases):
+        Xcols[ph * nzp:ph * nzp + ocp.nx * o.n_nodes] = True
+    for b in range(B):
+        c = cs[b]
         assert rel_err(r["f"][b], c["f"]) < TOL
-        assert rel_err(r["g"][b], c["g"]) < TOL
-        assert rel_err(r["grad_f"][b], c["grad_f"]) < TOL
-        J = sp.coo_matrix((r["jac_g"][b], (jr, jc)), shape=(o.n_g, o.n_z)).tocsr()
-        Jc = sp.coo_matrix((c["jac_val"], (c["jac_row"], c["jac_col"])), shape=(o.n_g, o.n_z)).tocsr()
-        d = (J - Jc)
-        assert (abs(d).max() if d.nnz else 0.0) < TOL * max(1.0, abs(Jc).max())
+        jcl = jac_classes(o, jr, jc, Jal[b], Jal[(b + 2) % B])
+        assert_by_class(r["jac_g"][b], Jal[b], jcl, TOL, f"{name}[{b}] jac_g")
+        # g: a defect row is a DIFFERENCE of (degree + 1) products D[k][j] X[j] and h Sx dyn -- its floor is the size of those terms
+        # (typical |D entry| x typical |X|), not the size of the residual that is left; the other rows are plain values
+        zx = np.abs(Z[b][Z[b] != 0])
+        term = float(np.median(np.abs(Jal[b][jcl["constant (D / interpolation copies)"]])) * np.median(zx))
+        isF = np.zeros(o.n_g, bool)
+        isF[np.unique(jr[jcl["constant (D / interpolation copies)"] & Xcols[jc]])] = True
+        assert_by_class(r["g"][b], c["g"], {"defect rows (D.X - h Sx dyn)": isF, "other rows": ~isF}, TOL, f"{name}[{b}] g",
+                        floors={"defect rows (D.X - h Sx dyn)": term})
+        assert_by_class(r["grad_f"][b], c["grad_f"], grad_classes(o), TOL, f"{name}[{b}] grad_f")
         # hess_l against the C oracle's hand-derived second derivatives (upper triangle, duplicates summed): every tile,
         # the multi-tile partial sums of the (t0, tf, a) corner and the terminal entries at full size
-        Hg = sp.coo_matrix((r["hess_l"][b], (hr, hc)), shape=(o.n_z, o.n_z)).tocsr()
         Hc = C.hess_matrix(Z[b], p, sig, lam)
-        dh = Hg - Hc
-        assert (abs(dh).max() if dh.nnz else 0.0) < TOL * max(1.0, abs(Hc).max())
-        pat_c = set(zip(*Hc.nonzero()))
-        assert pat_c <= set(zip(hr.tolist(), hc.tolist()))  # the oracle's structural entries all exist in the GPU pattern
+        assert set(zip(*Hc.nonzero())) <= set(zip(hr.tolist(), hc.tolist()))  # the oracle's structural entries all exist in the GPU pattern
+        assert_by_class(r["hess_l"][b], np.asarray(Hc[hr, hc]).ravel(), hess_classes(o, hr, hc), TOL, f"{name}[{b}] hess_l")
     # size-independent derivative properties (central differences of the GPU's own f, g)
     rng = np.random.default_rng(5)
     v = rng.standard_normal(o.n_z)
