@@ -274,6 +274,9 @@ def main():
     ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config3-hess", "config2-hess", "adaptive-fgj", "config3-shard", "config4-shard", "config5-loop"],
                     help="default: the metric's configuration (BASELINE configs[1], f+g+grad_f+jac_g).  The others are "
                          "secondary reports (configs[4]: nlp_hess_l on hypersensitive 4000x3; configs[2]: mixed-degree grid)")
+    ap.add_argument("--oracles", default="f,g,grad_f,jac_g",
+                    help="first-order workloads: which outputs the timed pass writes (a line search calls nlp_f / nlp_g alone); the default is "
+                         "the metric's fused bundle.  Algorithmic bytes follow the selection: 8 (n_z + n_p + [1] + [n_g] + [n_z] + [nnz_jac])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary MPX_JAC_VARIABLE_ONLY measurement (it launches the same kernel with less work, "
@@ -405,6 +408,12 @@ def main():
     gr = torch.empty(B, o.n_z, dtype=torch.float64, device=dev)
     jv = torch.empty(B, o.nnz_jac, dtype=torch.float64, device=dev)
     mask = MPX_F | MPX_G | MPX_GRAD | MPX_JAC
+    sel = [w for w in args.oracles.split(",") if w]
+    partial_sel = sorted(sel) != ["f", "g", "grad_f", "jac_g"]
+    if partial_sel:
+        assert not hess_mode and not shard and not adaptive and set(sel) <= {"f", "g", "grad_f", "jac_g"}, "--oracles applies to the first-order workloads"
+        mask = sum({"f": MPX_F, "g": MPX_G, "grad_f": MPX_GRAD, "jac_g": MPX_JAC}[w] for w in set(sel))
+        args.no_extras = True
     if hess_mode:
         from mpopt_amd._lib import MPX_HESS
 
@@ -456,7 +465,8 @@ def main():
         elif hess_mode:
             o.eval_device(mask, B, Z, p, 0, lam, sig, None, None, None, None, hv)
         else:
-            o.eval_device(mask, B, Z, p, 0, None, None, f, g, gr, jv, None)
+            o.eval_device(mask, B, Z, p, 0, None, None, f if mask & MPX_F else None, g if mask & MPX_G else None, gr if mask & MPX_GRAD else None,
+                          jv if mask & MPX_JAC else None, None)
 
     t_ramp = time.perf_counter()
     if shard:  # collectives inside the step: every rank must issue the same number of them (no time-based loop)
@@ -525,11 +535,15 @@ def main():
         extra["placement_sweep_node_kernel_us"] = [round(v, 1) for v in sweep]
 
     # sanity: the timed outputs are real (finite, and f matches a host recomputation of one point)
-    assert torch.isfinite(jv[0]).all() and (hess_mode or torch.isfinite(g[-1]).all())
+    if not partial_sel:
+        assert torch.isfinite(jv[0]).all() and (hess_mode or torch.isfinite(g[-1]).all())
 
     if rank == 0:
         kernel_s = node_ms / 1e3 / K  # all node-kernel launches of one step (one event bracket per pass, mpx_profile)
         bytes_eval = o.bytes_hess if hess_mode else o.bytes_fgj
+        if partial_sel:
+            bytes_eval = 8 * (o.n_z + o.n_p + (1 if mask & MPX_F else 0) + (o.n_g if mask & MPX_G else 0) + (o.n_z if mask & MPX_GRAD else 0) +
+                              (o.nnz_jac if mask & MPX_JAC else 0))
         if loop5:  # one step = 5 outer iterations of (residuals, hess_l, width update); the roofline object covers the whole loop
             n_pts = plan.n_pts
             bytes_eval = 5 * (o.bytes_hess + 8 * (o.n_z + 2 * o.n_p + n_pts * ocp.nx) + 8 * (n_pts * ocp.nx + 2 * o.n_p))
@@ -537,7 +551,7 @@ def main():
         achieved = B * bytes_eval / kernel_s / 1e9
         sweep_us = extra.get("placement_sweep_node_kernel_us")
         out = {
-            "metric": "NLP grad_f+jac_g evals/sec, 1000-seg LGR" if args.workload == "config2-fgj" else f"NLP evals/sec ({args.workload})",
+            "metric": "NLP grad_f+jac_g evals/sec, 1000-seg LGR" if args.workload == "config2-fgj" and not partial_sel else f"NLP evals/sec ({args.workload}{', outputs ' + '+'.join(sel) if partial_sel else ''})",
             "value": (1 if shard else world) * B * K * (5 if loop5 else 1) / elapsed,
             "unit": "point-iterations/s (one = residuals at the mid-points + nlp_hess_l + equal-area width update)" if loop5 else "evals/s",
             "n_gpus": world,
@@ -550,7 +564,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{label}; {'h-adaptive loop, widths ~ Dirichlet(1), 5 outer iterations per step (SURVEY 8(d)), ' if loop5 else ''}"
-                                   f"{'nlp_hess_l' if hess_mode else 'f+g+grad_f+jac_g'}, "
+                                   f"{'nlp_hess_l' if hess_mode else '+'.join(sel)}, "
                                    f"{B} evaluation points per GPU per step, inputs resident in HBM",
                        "n_z": o.n_z, "n_g": o.n_g, "nnz_jac": o.nnz_jac, "batch_per_gpu": B,
                        "parallelism": (f"segments of every evaluation sharded over {world} rank(s), one all-gather of the owned runs per "
@@ -563,7 +577,7 @@ def main():
                          "kernel": ("whole loop: mpx_node_hess_0_3 (with the mid-point residuals, MPX_MID_RESID) + mpx_boundary_hess + mpx_equal_area_kernel (wall time of the step)" if loop5
                                     else ("mpx_pts_jac + mpx_gather_kernel (MPX_NO_FUSE)" if os.environ.get("MPX_NO_FUSE") else "mpx_asm_fgj (fused point + gather pass)") if adaptive
                                     else "mpx_node_hessn_* (node-ordered tiles of the mixed-degree grid)" if hess_mode and isinstance(P, (list, tuple)) and len(set(P)) > 1
-                                    else f"mpx_node_{'hess' if hess_mode else 'fgj'}_0_*"),
+                                    else f"mpx_node_{'hess' if hess_mode else 'fgj' if mask & (MPX_GRAD | MPX_JAC) else 'fg'}_0_*"),
                          "kernel_us": kernel_s * 1e6,
                          "bytes_per_eval": bytes_eval, "evals_per_launch": B,
                          "algorithmic_bytes_per_launch": B * bytes_eval},
@@ -607,7 +621,7 @@ def main():
                 out["roofline"]["frac_by_traffic"] = tb / kernel_s / 1e9 / HBM_PEAK_GBS
                 out["roofline"]["traffic_source"] = (os.path.relpath(tfp, ROOT) + " (" + str(tr.get("kernel", "the timed kernels")) +
                                                      "; rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; 2 x FETCH + WRITE)")
-        if world == 1 and not args.no_cpu_baseline and args.workload == "config2-fgj":
+        if world == 1 and not args.no_cpu_baseline and args.workload == "config2-fgj" and not partial_sel:
             from oracle.c_oracle import COracle
 
             C = COracle(["moon_lander"], S, P, "LGR")

@@ -280,7 +280,10 @@ class ProblemProgram:
 
     def source(self):
         nph = len(self.phases)
-        parts = ["// generated by mpopt_amd.codegen -- do not edit", "#include <hip/hip_runtime.h>",
+        # (fp contract(off), here and in mpx_kernels.h: a product and a sum are fused only where the source says fma().  The node
+        # functions are inlined into several kernels -- node_body, light_body, resid_body, gradl_body --, and with the compiler's
+        # default every one of them made its own fusing choices: the same g came out with different last bits from different passes)
+        parts = ["// generated by mpopt_amd.codegen -- do not edit", "#include <hip/hip_runtime.h>", "#pragma clang fp contract(off)",
                  f"#define MPX_NPH {nph}", "namespace mpxgen {", "template <int PH> struct Phase;"]
         parts += [p.source(self.flags[k]) for k, p in enumerate(self.phases)]
         parts.append("}  // namespace mpxgen")
@@ -293,6 +296,8 @@ class ProblemProgram:
         for ph in range(nph):
             for d in self.degrees:
                 parts.append(f"MPX_INSTANTIATE_GRADL({ph}, {d})")
+                if 12 < d <= 31:  # light passes of the high-degree buckets on the matrix cores (mpx_kernels.h: light_body)
+                    parts.append(f"MPX_INSTANTIATE_LIGHT({ph}, {d})")
         parts.append("MPX_INSTANTIATE_BOUNDARY()")
         return "\n".join(parts) + "\n"
 

@@ -6,6 +6,7 @@
 
 #define MPX_TILE 256           // nodes (= lanes) per workgroup tile: 4 wavefronts of 64
 #define MPX_MAX_PHASES 8
+#define MPX_LIGHT_WAVES 8       // wavefronts per workgroup of the light-pass kernels (mpx_light_*: one segment x 16 points per wavefront)
 
 // kernel modes
 #define MPX_MODE_FG 0    // f, g
@@ -90,6 +91,17 @@ struct MpxNodeArgs {
   const int64_t* abs_fstage;
   const int32_t* abs_fn;
   int32_t abs_cap, pad2_;
+};
+
+// Light passes of a high-degree bucket on the matrix cores (mpx_light_*, mpx_kernels.h: light_body): the bucket's whole segments
+// (n_segs of them; bucket-local node first_node + sg * degree is point 1 of segment sg), per-point sums per segment in segsum
+// [B][n_segs][nred of the pass] (mpx_light_combine_kernel folds them into the tiles' partial-sum slots).
+struct MpxLightArgs {
+  MpxNodeArgs node;
+  double* segsum;
+  const double* wdeg;  // [degree + 1] quadrature weights of the bucket's degree
+  int32_t n_segs, first_node;
+  long long* dbg;  // MPX_LIGHT_DEBUG=1 (code objects built with -DMPX_LIGHT_STAMPS): phase stamps of one wavefront, else NULL
 };
 
 // Mixed-degree grids, hess_l pass: the node Hessian does not depend on the polynomial degree (no D.X contraction), so its tiles

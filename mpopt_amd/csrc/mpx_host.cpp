@@ -619,6 +619,11 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     char name[96];
     snprintf(name, sizeof name, "mpx_node_gradl_%d_%d", B.phase, B.deg);
     if (hipModuleGetFunction(&B.fn_gradl, c->module, name) != hipSuccess) B.fn_gradl = nullptr, (void)hipGetLastError();
+    static const char* lm[2] = {"fg", "fgq"};
+    for (int m = 0; m < 2 && B.deg > 12 && B.deg <= 31; ++m) {  // light passes of the high-degree buckets (mpx_kernels.h: light_body)
+      snprintf(name, sizeof name, "mpx_light_%s_%d_%d", lm[m], B.phase, B.deg);
+      if (hipModuleGetFunction(&B.fn_light[m], c->module, name) != hipSuccess) B.fn_light[m] = nullptr, (void)hipGetLastError();
+    }
   }
   if (hipModuleGetFunction(&c->fn_gradl_fin, c->module, "mpx_gradl_finish") != hipSuccess) c->fn_gradl_fin = nullptr, (void)hipGetLastError();
   int rc;
@@ -638,7 +643,7 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     if ((rc = upload(c, &t.d_D, t.D))) return rc;
     if ((rc = upload(c, &t.d_Cmid, t.Cmid))) return rc;
     if ((rc = upload(c, &t.d_tk, t.tk))) return rc;
-    if ((rc = upload(c, &t.d_Dmid, t.Dmid)) || (rc = upload(c, &t.d_tkm, t.tkm))) return rc;
+    if ((rc = upload(c, &t.d_Dmid, t.Dmid)) || (rc = upload(c, &t.d_tkm, t.tkm)) || (rc = upload(c, &t.d_w, t.w))) return rc;
   }
   for (auto& B : c->buckets) {
     if ((rc = upload(c, &B.d_node_i, B.node_i))) return rc;
@@ -799,6 +804,23 @@ __global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restric
     if (k < nb) out[(int64_t)k * stride] = v[k];
 }
 
+// Light passes (mpx_light_*): per-point sums arrive per segment; the tile's slot of the partial-sum buffer is the sum of its
+// segments IN ORDER (what the boundary kernel then adds up tile by tile).  One thread per (evaluation point, tile, quantity).
+__global__ __launch_bounds__(256) void mpx_light_combine_kernel(const double* __restrict__ segsum, int n_segs, int nred_pass, const MpxTile* __restrict__ tiles,
+                                                                int tile_first, int n_tiles, int first_node, int deg, double* __restrict__ partial,
+                                                                int n_tiles_total, int nred, int64_t B) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * n_tiles * nred_pass) return;
+  const int r = (int)(e % nred_pass), tl = (int)((e / nred_pass) % n_tiles);
+  const int64_t b = e / ((int64_t)nred_pass * n_tiles);
+  const MpxTile T = tiles[tile_first + tl];
+  const int sg0 = (T.m0 - first_node) / deg, cnt = T.n / deg;
+  const double* __restrict__ src = segsum + (b * n_segs + sg0) * nred_pass + r;
+  double v = 0;
+  for (int k = 0; k < cnt; ++k) v += src[(int64_t)k * nred_pass];
+  partial[(b * n_tiles_total + T.tile_id) * nred + r] = v;
+}
+
 // Evaluation points per workgroup.
 //  * Round 1 picked 4-8 for large batches (best case of the software-pipelined loop).  Round 2 measured both over physical
 //    placements of the output buffers on five boxes (tools/placement_ab.py, profiles/r2_headline): with 5 points per workgroup the
@@ -902,7 +924,13 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   if (shard && !owner && want_g && io.B > 65535) return fail(c, MPX_ERR_UNSUPPORTED, "segment-sharded evaluation: batch must be <= 65535");
   // (owner-resident sharding, MPX_OWNER_RESIDENT: nothing but the tile partials is exchanged, so the node kernels store their
   // g / grad_f rows directly, like a plain tile sub-range)
-  const bool packed = want_g && io.B <= 65535 &&
+  // Light passes (no Jacobian values) of high-degree buckets run on the matrix cores (light_body) with direct stores; the other
+  // buckets of such a pass store directly too (no staging block, no row spans).  Any batch size: which kernel evaluates a pass
+  // never depends on the batch, so results do not either.  MPX_NO_LIGHT=1: the node kernels (A/B runs).
+  bool light = false;
+  if (mode != MPX_MODE_HESS && !io.jac && !shard && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_LIGHT") && getenv("MPX_LIGHT"))  /* (work in progress: opt-in) */
+    for (auto& B : c->buckets) light = light || B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0] != nullptr;
+  const bool packed = want_g && io.B <= 65535 && !light &&
                       ((shard && !owner) || (c->g_packed && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_PACKED_G")));
   if (packed) {
     int rc = reserve(c, c->gtmp, (size_t)(io.B * c->gtmp_n));
@@ -1014,6 +1042,40 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       A.abs_fpos = c->d_abs_fpos, A.abs_fstage = c->d_abs_fstage, A.abs_fn = c->d_abs_fn, A.abs_cap = B.abs_cap;
       lds = (unsigned)B.abs_cap * (unsigned)B.abs_slots * 8u;
     }
+    hipFunction_t fl = light ? B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0] : nullptr;
+    if (fl) {  // whole-segment tiles on the matrix cores; the node-0 mini tile stays with node_body below
+      const int64_t l0 = lo + (c->tiles[lo].node0 ? 1 : 0);
+      if (hi > l0) {
+        const int first_node = c->tiles[l0].m0, nred_pass = mode == MPX_MODE_FGJ ? 3 + c->na : 1;
+        const int n_segs = (int)(((int64_t)B.node_i.size() - first_node) / B.deg);
+        int rc = reserve(c, c->light_seg, (size_t)(io.B * n_segs * nred_pass));
+        if (rc) return rc;
+        MpxLightArgs L{};
+        L.node = A, L.node.regular = 0, L.node.tile_first = (int32_t)l0, L.node.tile_count = (int32_t)(hi - l0);
+        L.segsum = c->light_seg.p, L.wdeg = t.d_w, L.n_segs = n_segs, L.first_node = first_node;
+        // persistent wavefronts: one workgroup per compute unit, every wavefront walks the (segment, 16 points) items (light_body)
+        static int n_cu = 0;
+        if (!n_cu && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) n_cu = 256;
+        const int64_t items = (int64_t)((n_segs + 15) / 16) * io.B;
+        const unsigned wgs = (unsigned)std::min<int64_t>((items + MPX_LIGHT_WAVES - 1) / MPX_LIGHT_WAVES, n_cu);
+        static long long* ldbg = nullptr;
+        if (!ldbg && getenv("MPX_LIGHT_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
+        L.dbg = ldbg;
+        if ((rc = launch(c, fl, dim3(wgs, 1, 1), dim3(64 * MPX_LIGHT_WAVES, 1, 1), &L, sizeof L))) return rc;
+        if (c->profile) ++c->prof_launches;
+        if (ldbg) {
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          fprintf(stderr, "light kernel (deg %d) phases of one item (us): loads %.2f  matrix core %.2f  node functions + stores %.2f\n", B.deg, (ldbg[1] - ldbg[0]) / 100.0,
+                  (ldbg[2] - ldbg[1]) / 100.0, (ldbg[3] - ldbg[2]) / 100.0);
+        }
+        const int64_t ne = io.B * (hi - l0) * nred_pass;
+        hipLaunchKernelGGL(mpx_light_combine_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, c->light_seg.p, n_segs, nred_pass, c->d_tiles,
+                           (int)l0, (int)(hi - l0), first_node, B.deg, io.partial, io.n_tiles_total, io.nred, (int64_t)io.B);
+        HIPCHK(c, hipGetLastError());
+      }
+      if (l0 == lo) continue;
+      hi = l0, A.tile_count = 1, A.regular = 0;
+    }
     for (int64_t bf = 0; bf < (int64_t)gy * io.b_per_block; bf += (int64_t)65535 * io.b_per_block) {
       A.io.b_first = (int32_t)bf;
       const int gys = (int)std::min<int64_t>(65535, gy - bf / io.b_per_block);
@@ -1119,7 +1181,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     auto fr = [](void* p) {
       if (p) (void)hipFree(p);
     };
-    for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk), fr(t.d_Dmid), fr(t.d_tkm);
+    for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk), fr(t.d_Dmid), fr(t.d_tkm), fr(t.d_w);
     for (auto& B : c->buckets) fr(B.d_node_i), fr(B.d_node_sk);
     fr(c->d_htiles), fr(c->d_node_seg), fr(c->d_node_tk);
     fr(c->d_tiles), fr(c->d_Wnode), fr(c->d_seg_start), fr(c->d_lin_ptr), fr(c->d_lin_idx), fr(c->d_lin_row), fr(c->d_lin_coef);
@@ -1127,7 +1189,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
     fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
-    fr(c->gl_halo.p), fr(c->gl_pnode.p), fr(c->st_ggx.p), fr(c->st_ggp.p), fr(c->gl_grad.p), fr(c->gl_jac.p);
+    fr(c->light_seg.p), fr(c->gl_halo.p), fr(c->gl_pnode.p), fr(c->st_ggx.p), fr(c->st_ggp.p), fr(c->gl_grad.p), fr(c->gl_jac.p);
     fr(c->d_lt_ptr), fr(c->d_lt_col), fr(c->d_lt_row), fr(c->d_lt_coef), fr(c->d_colind_j), fr(c->d_jrow);
     fr(c->d_gmap), fr(c->d_qmap), fr(c->d_abs_fpos), fr(c->d_abs_fstage), fr(c->d_abs_fn), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);

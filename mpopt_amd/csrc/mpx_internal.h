@@ -35,7 +35,7 @@ struct PhaseStruct {
 struct DegTable {
   int deg = 0;
   std::vector<double> roots, D, Cmid, w, tk, Dmid, tkm;
-  double *d_D = nullptr, *d_Cmid = nullptr, *d_tk = nullptr, *d_Dmid = nullptr, *d_tkm = nullptr;
+  double *d_D = nullptr, *d_Cmid = nullptr, *d_tk = nullptr, *d_Dmid = nullptr, *d_tkm = nullptr, *d_w = nullptr;
 };
 
 struct Bucket {
@@ -47,6 +47,7 @@ struct Bucket {
   int32_t *d_node_i = nullptr, *d_node_sk = nullptr;
   hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
   hipFunction_t fn_gradl = nullptr;  // mpx_node_gradl_<phase>_<deg> (nlp_grad)
+  hipFunction_t fn_light[2] = {nullptr, nullptr};  // mpx_light_fg / _fgq _<phase>_<deg>: light passes on the matrix cores (12 < deg <= 31)
 };
 
 template <class T>
@@ -102,6 +103,7 @@ struct mpx_ctx {
   // and the generic J^T lam route (assembled contexts; MPX_GRADL_GENERIC=1): scratch grad_f / jac_val + compressed-column tables
   hipFunction_t fn_gradl_fin = nullptr;
   DevBuf<double> gl_halo, gl_pnode, st_ggx, st_ggp, gl_grad, gl_jac;
+  DevBuf<double> light_seg;  // per-segment sums of the light passes (MpxLightArgs::segsum), all light buckets of a pass one after the other
   int64_t *d_lt_ptr = nullptr, *d_lt_col = nullptr, *d_lt_row = nullptr, *d_colind_j = nullptr;
   double* d_lt_coef = nullptr;
   int32_t* d_jrow = nullptr;

@@ -28,6 +28,11 @@
 
 #include "mpx_device.h"
 
+// A product and a sum are fused only where the source says fma(): the same expression (node time, node functions, residuals) is
+// evaluated by several kernels of this file, whose results are promised to be bit-identical (light and heavy passes, fused and
+// separate residual passes, sharded and unsharded evaluations); left to itself the compiler fuses differently per inlining context.
+#pragma clang fp contract(off)
+
 #ifndef MPX_TABLES_IN_LDS_ABOVE
 #define MPX_TABLES_IN_LDS_ABOVE 12  // degrees above this keep the D / mid-point tables in LDS
 #endif
@@ -683,6 +688,230 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Light passes of the high-degree buckets (degrees MPX_TABLES_IN_LDS_ABOVE < P <= 31): f, g and grad_f WITHOUT the Jacobian values --
+// what a line search calls (nlp_f / nlp_g alone), little HBM traffic per node.  In node_body such a pass is bound by the LDS pipe,
+// not by HBM: every lane re-reads its row of D and the segment's X from LDS for each of the 3 (P + 1) products of a node, 186
+// ds_read_b64 per lane and point at degree 30 -- counters of mpx_node_fg_0_30 on config 3 (profiles/r4_c3_fg): LDS busy 67 %, VALU busy
+// 9 %, 318 us for 0.5 GB.  This is the case north_star reserves MFMA for ("only if the D.X defect contraction proves dense enough"):
+//   * one WAVEFRONT = one segment x 16 evaluation points.  D.X_a, D.U_c, C_mid.U_c are (P+1)x(P+1) by (P+1)x16 products on the matrix
+//     cores (v_mfma_f64_16x16x4_f64): A operand = the table (the lane's entries stay in registers for the life of the workgroup),
+//     B operand = one state / control of the segment's nodes for 16 points, loaded STRAIGHT from global memory -- no LDS, no barrier
+//     in the contraction.  C/D layout (row = (lane >> 4) + 4 reg, col = lane & 15; tools/mfma_f64_probe.hip): lane (n, q) ends up with
+//     the rows k = q + 4 e of point n -- exactly the nodes whose X / U it supplied as B operand (k = 4 ks + q), so the node functions
+//     are evaluated in place on the same registers.
+//   * The matrix core accumulates the four products of an instruction in order, fused (probe: 256 / 256 results bit-equal to the
+//     sequential fma chain), and K runs over the nodes in order: g is BIT-IDENTICAL to node_body's (tested).  The padding column
+//     (node P + 1) multiplies a zero of the table.
+//   * Stores go straight to the rows of g / grad_f (16 points x 32-byte sectors per instruction; for these passes direct stores beat
+//     the staging + row-span scheme of the heavy passes: 351 against 367 us on config 3, tools/r3_single_oracle_bpb.py).
+//   * A workgroup = the segments of ONE tile of the bucket (its waves take them in turn) x 16 points; the per-point sums (f, and for
+//     the grad_f pass d/dt0, d/dtf, d/dA) are reduced lane -> the four lane groups of a point -> the tile's segments in order, into the
+//     tile's slot of the partial-sum buffer: fixed order, independent of the batch (the boundary kernel is unchanged).  f of a light
+//     pass and f of a heavy pass (node_body's shuffle tree) round differently in the last bit; g and grad_f do not.
+// The node-0 mini tile of a bucket and every other bucket of the pass go through node_body with direct stores.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef double mpx_d4 __attribute__((ext_vector_type(4)));
+
+template <int PH, int P, int MODE>
+__device__ __forceinline__ void light_body(const MpxLightArgs& L) {
+  using G = mpxgen::Phase<PH>;
+  const MpxNodeArgs& A = L.node;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
+  constexpr int P1 = P + 1, MT = (P1 + 15) / 16, KS = 4 * MT;
+  static_assert(MT <= 2, "light_body: degrees up to 31");
+  constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : G::NRED;
+  const int t = threadIdx.x, wave = t >> 6, l = t & 63, n = l & 15, q = l >> 4;
+  const int N = A.N;
+  const MpxIO& io = A.io;
+  // A operands: lane l supplies row (l & 15) of an M tile and column (l >> 4) of a K step
+  double AD[MT][KS], AC[MT][KS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 16 * mt + n, j = 4 * ks + q;
+      const bool in = k <= P && j <= P;
+      AD[mt][ks] = in ? A.Dmat[(in ? k : 0) * P1 + (in ? j : 0)] : 0.0;
+      AC[mt][ks] = (G::MIDU && in && k >= 1) ? A.Cmid[((in && k >= 1) ? k - 1 : 0) * P1 + (in ? j : 0)] : 0.0;
+    }
+  // (the quadrature weight of point k >= 1 of a segment is w_k of its degree: the composite vector repeats the table, mpopt.py:4060-4062)
+  double tkv[KS], wtab[KS];
+#pragma unroll
+  for (int e = 0; e < KS; ++e) tkv[e] = A.tk[q + 4 * e <= P ? q + 4 * e : P], wtab[e] = L.wdeg[q + 4 * e <= P ? q + 4 * e : P];
+  const bool want_g = io.g != nullptr;
+  // PERSISTENT, INDEPENDENT wavefronts: the grid is one workgroup of MPX_LIGHT_WAVES wavefronts per compute unit (242 VGPRs each: they
+  // fill its register file), and every wavefront walks the (segment, 16 points) items with the stride of all wavefronts of the grid --
+  // consecutive wavefronts take consecutive segments of the same points.  No barrier anywhere: the two wavefronts of a SIMD drift
+  // apart, one waits for its loads while the other feeds the matrix core.  (Launched one workgroup per (tile, 16 points), a compute
+  // unit drained completely between two workgroups and reloaded the tables each time: wavefronts lived 2.6 us and the unit held 1.8
+  // of them on average -- SQ_WAVE_CYCLES / SQ_BUSY_CYCLES, profiles/r4_c3_fg.)  Per-point sums leave per SEGMENT (L.segsum);
+  // mpx_light_combine_kernel adds the segments of every tile in order into the tile's slot of the partial-sum buffer.
+  // The 16 columns of a wavefront's products are 16 CONSECUTIVE SEGMENTS of the bucket at ONE evaluation point: everything the
+  // wavefront reads and writes lies in a few KB of each row of z / g.  (First version: 16 evaluation points of one segment -- every
+  // load fetched 16 chunks 0.6 MB apart, no two in the same DRAM row: 7 us per item in the loads alone, tools/r4_light_stamps.py.)
+  const int n_grp = (L.n_segs + 15) / 16;
+  const int64_t total = (int64_t)n_grp * (io.B - io.b_first), stride = (int64_t)gridDim.x * MPX_LIGHT_WAVES;
+  int64_t item = (int64_t)blockIdx.x * MPX_LIGHT_WAVES + wave;
+  // One item's inputs of this lane.  The loop is software pipelined: the loads of the NEXT item are issued between the last matrix
+  // instruction and the stores of the current one (the B operands' registers are free by then), so a wavefront always has loads in
+  // flight -- before, every wavefront of the chip sat in its load phase at the same time (6-8 of the 14 us of an item,
+  // tools/r4_light_stamps.py) and the memory system idled during the other phases.
+  struct In {
+    double zX[NX][KS], zU[NU > 0 ? NU : 1][KS];
+    double t0v, tfv, ws, wc;
+    Vec<NA> As;
+    int st, sgi, b;
+  };
+  auto load_item = [&](int64_t it, In& I) {
+    int sg = (int)(it % n_grp) * 16 + n;
+    I.sgi = sg;
+    sg = sg < L.n_segs ? sg : L.n_segs - 1;  // (lanes past the last segment shadow it; they store nothing)
+    I.b = io.b_first + (int)(it / n_grp);
+    const int m0 = L.first_node + sg * P;
+    I.st = A.node_i[m0] - 1;                 // the segment's point 0 in the phase
+    const int s = A.node_sk[m0] >> 8;
+    const double* __restrict__ zb = io.z + (int64_t)I.b * io.z_stride + A.z_off;
+    const double* __restrict__ zt = zb + (int64_t)(NX + NU) * N;
+    I.t0v = zt[0], I.tfv = zt[1];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) I.As[c] = zt[2 + c];
+    const int64_t woff = (int64_t)I.b * io.w_stride + A.seg_off + s;
+    I.ws = io.w[woff], I.wc = io.wcum[woff];
+#pragma unroll
+    for (int e = 0; e < KS; ++e) {
+      const int j = q + 4 * e <= P ? q + 4 * e : P;  // (the padding node P + 1 meets a zero of the table)
+#pragma unroll
+      for (int a = 0; a < NX; ++a) I.zX[a][e] = (zb + (int64_t)a * N)[I.st + j];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) I.zU[c][e] = (zb + (int64_t)(NX + c) * N)[I.st + j];
+    }
+  };
+#ifdef MPX_LIGHT_STAMPS  // phase stamps of one wavefront's third item (wall_clock64: 100 MHz), forced waits at the phase ends
+  int it_ = 0;
+#define MPX_LSTAMP(k) if (L.dbg && blockIdx.x == 1 && wave == 1 && it_ == 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (l == 0) L.dbg[k] = wall_clock64(); }
+#else
+#define MPX_LSTAMP(k)
+#endif
+  In I;
+  if (item < total) load_item(item, I);
+  for (; item < total; item += stride) {
+    MPX_LSTAMP(0)
+    const int st = I.st, sgi = I.sgi, b = I.b;
+    const bool bok = sgi < L.n_segs;  // this lane's column is a real segment
+    const double kap = I.ws * A.inv_dtau;
+    // (1) node functions of the lane's nodes: everything that needs the inputs
+    Vec<NRED> red;
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) red[r] = 0.0;
+    double fxs[NX][KS], ccs[NC > 0 ? NC : 1][KS];
+#pragma unroll
+    for (int e = 0; e < KS; ++e) {
+      const int j = q + 4 * e;
+      const bool valid = bok && j >= 1 && j <= P;  // (point 0 of a segment belongs to the previous one; node 0 of the phase to node_body)
+      const double th = I.wc + I.ws * tkv[e];
+      Vec<NX> Xs, fx;
+      Vec<NU> Us;
+      Vec<NC> cc;
+#pragma unroll
+      for (int a = 0; a < NX; ++a) Xs[a] = I.zX[a][e];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) Us[c] = I.zU[c][e];
+      if constexpr (MODE == MPX_MODE_FG) {
+        double qW;
+        G::fg(Xs, Us, I.t0v, I.tfv, I.As, kap, th, wtab[e], fx, cc, qW);
+        if (valid) red[0] += qW;
+      } else {
+        Vec<NX> dd;
+        Vec<G::NJV> jv;
+        Vec<NX + NU> gn;
+        Vec<NRED> gr;
+        G::fgj(Xs, Us, I.t0v, I.tfv, I.As, kap, th, wtab[e], fx, cc, dd, jv, gn, gr);
+        if (valid) {
+#pragma unroll
+          for (int r = 0; r < NRED; ++r) red[r] += gr[r];
+          if (io.grad) {
+            double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
+#pragma unroll
+            for (int a = 0; a < NX + NU; ++a) qb[(int64_t)a * N + st + j] = gn[a];
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < NX; ++a) fxs[a][e] = fx[a];
+#pragma unroll
+      for (int jj = 0; jj < NC; ++jj) ccs[jj][e] = cc[jj];
+    }
+    MPX_LSTAMP(1)
+    // (2) the contractions on the matrix core
+    mpx_d4 aX[NX][MT], aDU[NU > 0 ? NU : 1][MT], aCU[NU > 0 ? NU : 1][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int a = 0; a < NX; ++a) aX[a][mt] = mpx_d4{0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < NU; ++c) aDU[c][mt] = mpx_d4{0, 0, 0, 0}, aCU[c][mt] = mpx_d4{0, 0, 0, 0};
+    }
+    if (want_g) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int a = 0; a < NX; ++a) aX[a][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(AD[mt][ks], I.zX[a][ks], aX[a][mt], 0, 0, 0);
+          if constexpr (G::DIFF_U) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) aDU[c][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(AD[mt][ks], I.zU[c][ks], aDU[c][mt], 0, 0, 0);
+          }
+          if constexpr (G::MIDU) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) aCU[c][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(AC[mt][ks], I.zU[c][ks], aCU[c][mt], 0, 0, 0);
+          }
+        }
+    }
+    // (3) the next item's loads, into the registers the B operands just left
+    __builtin_amdgcn_sched_barrier(0);
+    if (item + stride < total) load_item(item + stride, I);
+    __builtin_amdgcn_sched_barrier(0);
+    MPX_LSTAMP(2)
+    // (4) stores
+    if (want_g && bok) {
+      double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
+#pragma unroll
+      for (int e = 0; e < KS; ++e) {
+        const int j = q + 4 * e, i = st + j;
+        if (j >= 1 && j <= P) {
+#pragma unroll
+          for (int a = 0; a < NX; ++a) gb[A.g_off_F + (int64_t)a * N + i] = aX[a][e / 4][e % 4] - fxs[a][e];
+#pragma unroll
+          for (int jj = 0; jj < NC; ++jj) gb[A.g_off_C + (int64_t)jj * N + i] = ccs[jj][e];
+          if constexpr (G::DIFF_U) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) gb[A.g_off_DU + (int64_t)c * N + i] = aDU[c][e / 4][e % 4];
+          }
+          if constexpr (G::MIDU) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) gb[A.g_off_mU + (int64_t)c * (N - 1) + (i - 1)] = aCU[c][e / 4][e % 4];
+          }
+        }
+      }
+    }
+    // the point's sums over this segment: the lane's nodes in order, then the four lane groups of the segment
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) {
+      double v = red[r];
+      v += __shfl_down(v, 32, 64);
+      v += __shfl_down(v, 16, 64);
+      if (l < 16 && bok) L.segsum[((int64_t)b * L.n_segs + sgi) * NRED + r] = v;  // (16 consecutive segments of the point)
+    }
+    MPX_LSTAMP(3)
+#ifdef MPX_LIGHT_STAMPS
+    ++it_;
+#endif
+  }
+#undef MPX_LSTAMP
+}
+
 // ---------------------------------------------------------------------------------------------
 // hess_l node pass over node-ordered tiles (mixed-degree grids, MpxHessNodeArgs): lane <-> node i0 + l.  Same arithmetic as the
 // MODE_HESS branch of node_body (G::hess, slot layout of scatter_slots, fixed-order tile sums), without anything that depends
@@ -1294,6 +1523,14 @@ __device__ __forceinline__ void gradl_finish_body(const MpxGradlFinArgs& A) {
 #define MPX_INSTANTIATE_HESS_BY_NODE(PH)                                                                    \
   extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_hessn_##PH(const MpxHessNodeArgs A) {  \
     mpxk::hess_by_node_body<PH>(A);                                                                         \
+  }
+
+#define MPX_INSTANTIATE_LIGHT(PH, P)                                                                                          \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES) void mpx_light_fg_##PH##_##P(const MpxLightArgs A) {          \
+    mpxk::light_body<PH, P, MPX_MODE_FG>(A);                                                                                  \
+  }                                                                                                                           \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES) void mpx_light_fgq_##PH##_##P(const MpxLightArgs A) {         \
+    mpxk::light_body<PH, P, MPX_MODE_FGJ>(A);                                                                                 \
   }
 
 #define MPX_INSTANTIATE_GRADL(PH, P)                                                                        \

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Kernel stats + PMC traffic (separate FETCH_SIZE / WRITE_SIZE passes) of the dominant node kernel of any bench workload.
-# usage: tools/profile_workload.sh <name> <workload> <kernel-name-prefix>      -> gpurun_out/<name>/
+# usage: tools/profile_workload.sh <name> <workload> <kernel-name-prefix> [extra bench.py arguments]      -> gpurun_out/<name>/
 set -u
-name=$1; wl=$2; kern=$3
+name=$1; wl=$2; kern=$3; shift 3; xa="$*"
 out=gpurun_out/$name; mkdir -p $out; export TMPDIR=/tmp
-python bench.py --workload $wl --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $out/bench_line.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- python bench.py --workload $wl --no-cpu-baseline --no-extras > $out/bench_under_rocprof.log 2>&1
+python bench.py --workload $wl --no-cpu-baseline --no-extras $xa 2>/dev/null | tail -1 > $out/bench_line.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- python bench.py --workload $wl --no-cpu-baseline --no-extras $xa > $out/bench_under_rocprof.log 2>&1
 cp $(find $out/trace -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv; rm -rf $out/trace
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -o run -- python bench.py --workload $wl --no-cpu-baseline --no-extras --steps 5 --warmup 1 --ramp-seconds 0.2 > $out/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -o run -- python bench.py --workload $wl --no-cpu-baseline --no-extras $xa --steps 5 --warmup 1 --ramp-seconds 0.2 > $out/pmc_$c.log 2>&1
   f=$(find $out/pmc_$c -name '*counter_collection.csv' | head -1)
   grep -E "Counter_Name|$kern" "$f" | head -60 > $out/pmc_$(echo $c | tr A-Z a-z).csv; rm -rf $out/pmc_$c
 done
