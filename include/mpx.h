@@ -243,6 +243,15 @@ int mpx_get_tile_weights(const mpx_ctx* ctx, int64_t* weights);
  * for the unpack pass) and the number of nodes of other tiles inside that span.  All zero on single-degree grids and on grids
  * outside the limits of the scheme.  Arrays of n_tiles entries; host-only contexts answer too (the plan is host arithmetic). */
 int mpx_get_tile_spans(const mpx_ctx* ctx, int32_t* span_first, int32_t* span_len, int32_t* n_foreign);
+/* Light passes (evaluations WITHOUT the Jacobian values: f, g, grad_f -- what a line search calls) of grids with exactly one high
+ * degree (12 < P <= 31) and otherwise degrees <= 12 run through dedicated kernels (mpx_light_*): the D.X / D.U / C_mid.U contractions
+ * of the high degree on the matrix cores (v_mfma_f64_16x16x4_f64), one wavefront per group of up to 16 high-degree segments plus the
+ * low-degree segments between them, span-coalesced I/O.  g and the node entries of grad_f are bit-identical to the node kernels'; f
+ * and the (t0, tf, a) entries of grad_f (sums over all nodes) are summed in another fixed order and may differ in the last place
+ * from the heavy passes'.  Which kernels run never depends on the batch size.  This query reports the plan: degree = 0 when the grid
+ * has none (structure only: works without a device).  MPX_NO_LIGHT=1 (environment, read per call) switches the light kernels off. */
+int mpx_get_light_plan(const mpx_ctx* ctx, int32_t* degree, int64_t* n_groups, int64_t* max_span_nodes, int64_t* n_low_degree_nodes);
+
 /* Device buffer holding the per-tile partial sums of the last mpx_eval_device call
  * ([batch][n_tiles][width] doubles; entries of tiles outside the tile range are untouched -- except that the hess_l pass of a
  * MIXED-DEGREE grid writes the slots of its own node-ordered tiles, phase tile_first + k for its k-th tile of the phase: a tile

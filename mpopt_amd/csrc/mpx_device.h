@@ -6,7 +6,7 @@
 
 #define MPX_TILE 256           // nodes (= lanes) per workgroup tile: 4 wavefronts of 64
 #define MPX_MAX_PHASES 8
-#define MPX_LIGHT_WAVES 8       // wavefronts per workgroup of the light-pass kernels (mpx_light_*: one segment x 16 points per wavefront)
+#define MPX_LIGHT_WAVES 4       // wavefronts per workgroup of the light-pass kernels (mpx_light_*): two workgroups per compute unit
 
 // kernel modes
 #define MPX_MODE_FG 0    // f, g
@@ -93,15 +93,36 @@ struct MpxNodeArgs {
   int32_t abs_cap, pad2_;
 };
 
-// Light passes of a high-degree bucket on the matrix cores (mpx_light_*, mpx_kernels.h: light_body): the bucket's whole segments
-// (n_segs of them; bucket-local node first_node + sg * degree is point 1 of segment sg), per-point sums per segment in segsum
-// [B][n_segs][nred of the pass] (mpx_light_combine_kernel folds them into the tiles' partial-sum slots).
+// Light passes (f, g, grad_f without the Jacobian values) of a phase whose grid has ONE high degree (12 < P <= 31, contractions on the
+// matrix cores) and otherwise low degrees (<= 12), mpx_kernels.h: light_body.  A wavefront works on a GROUP: up to 16 consecutive
+// segments of the high degree plus every low-degree segment between them -- one contiguous span of the phase's nodes, read and
+// written with fully coalesced accesses through an LDS buffer.
+#define MPX_LIGHT_MAXDEG 8  // distinct degrees of a grid with a light plan
+#define MPX_LIGHT_CHUNKS 10 // a group's span: at most 64 * MPX_LIGHT_CHUNKS nodes (one load per lane, chunk and row, all in flight together)
+struct MpxLightGroup {
+  int32_t lo_r, len_r;      // nodes read: [lo_r, lo_r + len_r) (the owned span and the node before it)
+  int32_t lo_w, len_w;      // nodes owned (rows written): [lo_w, lo_w + len_w)
+  int32_t seg_first, n_light;  // the group's high-degree segments: bucket-local indices seg_first .. seg_first + n_light - 1
+  int32_t f_first, f_count; // its foreign nodes: entries of MpxLightArgs::foreign
+};
+struct MpxLightForeign {    // one node of a low-degree segment inside a group's span
+  int32_t pos, pos0;        // the node and point 0 of its segment, relative to lo_r
+  int32_t dk;               // (index of the degree table << 8) | point k
+  int32_t s;                // segment
+  double tk, w;             // (tau_k - tau0) / (tau1 - tau0) and the quadrature weight of the node (no dependent table loads in the kernel)
+};
 struct MpxLightArgs {
-  MpxNodeArgs node;
-  double* segsum;
-  const double* wdeg;  // [degree + 1] quadrature weights of the bucket's degree
-  int32_t n_segs, first_node;
-  long long* dbg;  // MPX_LIGHT_DEBUG=1 (code objects built with -DMPX_LIGHT_STAMPS): phase stamps of one wavefront, else NULL
+  MpxNodeArgs node;         // io, table of the high degree (Dmat, Cmid, tk), offsets; node_i / node_sk of the high-degree bucket
+  const MpxLightGroup* groups;
+  const MpxLightForeign* foreign;
+  const double* wdeg;       // [P + 1] quadrature weights of the high degree
+  const double* ftab;       // differentiation and mid-point tables of the low degrees, concatenated (copied to LDS by every workgroup)
+  int32_t ftab_n;           // doubles in ftab
+  int32_t fD_off[MPX_LIGHT_MAXDEG], fC_off[MPX_LIGHT_MAXDEG];  // offsets in ftab, by degree-table index
+  int32_t fdeg[MPX_LIGHT_MAXDEG];
+  int32_t n_groups, first_node;  // first_node: bucket-local node of point 1 of the bucket's first whole segment (0 or 1)
+  int32_t span_cap, slot_first;  // LDS doubles per row and wavefront; first partial-sum slot of the phase (group g writes slot_first + g)
+  long long* dbg;           // MPX_LIGHT_DEBUG=1 (code objects built with -DMPX_LIGHT_STAMPS): phase stamps of one wavefront, else NULL
 };
 
 // Mixed-degree grids, hess_l pass: the node Hessian does not depend on the polynomial degree (no D.X contraction), so its tiles

@@ -252,6 +252,64 @@ int build_layout(mpx_ctx* c) {
   c->tile_begin = 0;
   c->tile_end = (int64_t)c->tiles.size();
 
+  // ---- light plan (mpx_light_*): one high degree on the matrix cores, the low-degree segments in between by lanes --------------
+  {
+    mpx_ctx::LightPlan& L = c->lplan;
+    L = mpx_ctx::LightPlan();
+    int n_high = 0, dL = 0;
+    bool low_ok = c->degs.size() <= MPX_LIGHT_MAXDEG;
+    for (auto& t : c->degs) {
+      if (t.deg > 12 && t.deg <= 31) ++n_high, dL = t.deg;
+      else if (t.deg > 12) low_ok = false;
+    }
+    if (n_high == 1 && low_ok) {
+      std::vector<int> segsL;
+      for (int s = 0; s < S; ++s)
+        if (c->orders[s] == dL) segsL.push_back(s);
+      const int nL = (int)segsL.size(), nin = nx + nu;
+      L.fD_off.assign(c->degs.size(), -1), L.fC_off.assign(c->degs.size(), -1);
+      for (size_t k = 0; k < c->degs.size(); ++k) {
+        if (c->degs[k].deg == dL) continue;
+        L.fD_off[k] = (int32_t)L.ftab.size(), L.ftab.insert(L.ftab.end(), c->degs[k].D.begin(), c->degs[k].D.end());
+        L.fC_off[k] = (int32_t)L.ftab.size(), L.ftab.insert(L.ftab.end(), c->degs[k].Cmid.begin(), c->degs[k].Cmid.end());
+      }
+      // LDS of a workgroup: span rows of its wavefronts + the low-degree tables + 9 KB of static tables, under the 64 KB a launch gets
+      // by default (two workgroups per compute unit)
+      const int cap_limit = std::min(64 * MPX_LIGHT_CHUNKS, (int)((int64_t)(53248 - 8 * (int64_t)L.ftab.size()) / (8 * MPX_LIGHT_WAVES * nin)));  // the span rows of a workgroup's wavefronts in 52 KB of LDS (+ 9 KB of tables: under the 64 KB a launch gets by default, two workgroups per compute unit)
+      L.deg = dL, L.dt = deg_index(c, dL), L.first_node = segsL[0] == 0 ? 1 : 0, L.ok = true;
+      for (int i = 0; i < nL && L.ok;) {
+        int cnt = std::min(16, nL - i);
+        for (; cnt > 0; --cnt) {  // as many segments as the span buffer and the foreign-node slots (2 turns of 64 lanes) hold
+          const int64_t lo_w = i == 0 ? 0 : (int64_t)c->seg_start[segsL[i]] + 1, hi = i + cnt < nL ? (int64_t)c->seg_start[segsL[i + cnt]] + 1 : N;
+          const int64_t lo_r = std::max<int64_t>(lo_w - 1, 0);
+          int64_t nf = 0;
+          for (int s = (i == 0 ? 0 : segsL[i]); s < S && c->seg_start[s] + 1 < hi; ++s)
+            if (c->orders[s] != dL) nf += c->orders[s] + (s == 0 ? 1 : 0);
+          if (hi - lo_r <= cap_limit && nf <= 128) break;
+        }
+        if (cnt == 0) { L.ok = false; break; }
+        MpxLightGroup Gp{};
+        const int64_t lo_w = i == 0 ? 0 : (int64_t)c->seg_start[segsL[i]] + 1, hi = i + cnt < nL ? (int64_t)c->seg_start[segsL[i + cnt]] + 1 : N;
+        Gp.lo_w = (int32_t)lo_w, Gp.len_w = (int32_t)(hi - lo_w), Gp.lo_r = (int32_t)std::max<int64_t>(lo_w - 1, 0), Gp.len_r = (int32_t)(hi - Gp.lo_r);
+        Gp.seg_first = i, Gp.n_light = cnt, Gp.f_first = (int32_t)L.foreign.size();
+        for (int s = (i == 0 ? 0 : segsL[i]); s < S && c->seg_start[s] + 1 < hi; ++s) {
+          if (c->orders[s] == dL) continue;
+          for (int k = (s == 0 ? 0 : 1); k <= c->orders[s]; ++k)
+            L.foreign.push_back(MpxLightForeign{c->seg_start[s] + k - Gp.lo_r, c->seg_start[s] - Gp.lo_r, (deg_index(c, c->orders[s]) << 8) | k, s,
+                                                c->degs[deg_index(c, c->orders[s])].tk[k], c->compW[c->seg_start[s] + k]});
+        }
+        Gp.f_count = (int32_t)L.foreign.size() - Gp.f_first;
+        L.span_cap = std::max(L.span_cap, (int)Gp.len_r);
+        L.groups.push_back(Gp);
+        i += cnt;
+      }
+      L.span_cap += L.span_cap & 1;
+      // (a group's sums go to the partial-sum slot tile_first + group of its phase)
+      for (int p = 0; p < c->n_phases && L.ok; ++p) L.ok = (int)L.groups.size() <= c->ph[p].tile_count;
+    }
+    if (!L.ok) L.groups.clear(), L.foreign.clear(), L.ftab.clear();
+  }
+
   // ---- packed g / grad_f staging (see MpxIO::gtmp): used by mixed-degree phases and by segment-sharded evaluations ----
   {
     std::vector<int> per_phase(c->n_phases, 0);
@@ -627,6 +685,7 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   }
   if (hipModuleGetFunction(&c->fn_gradl_fin, c->module, "mpx_gradl_finish") != hipSuccess) c->fn_gradl_fin = nullptr, (void)hipGetLastError();
   int rc;
+  if (c->lplan.ok && ((rc = upload(c, &c->d_lgroups, c->lplan.groups)) || (rc = upload(c, &c->d_lforeign, c->lplan.foreign)) || (rc = upload(c, &c->d_lftab, c->lplan.ftab)))) return rc;
   if ((rc = upload(c, &c->d_lt_ptr, c->lt_ptr)) || (rc = upload(c, &c->d_lt_col, c->lt_col)) || (rc = upload(c, &c->d_lt_row, c->lt_row)) ||
       (rc = upload(c, &c->d_lt_coef, c->lt_coef)))
     return rc;
@@ -804,23 +863,6 @@ __global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restric
     if (k < nb) out[(int64_t)k * stride] = v[k];
 }
 
-// Light passes (mpx_light_*): per-point sums arrive per segment; the tile's slot of the partial-sum buffer is the sum of its
-// segments IN ORDER (what the boundary kernel then adds up tile by tile).  One thread per (evaluation point, tile, quantity).
-__global__ __launch_bounds__(256) void mpx_light_combine_kernel(const double* __restrict__ segsum, int n_segs, int nred_pass, const MpxTile* __restrict__ tiles,
-                                                                int tile_first, int n_tiles, int first_node, int deg, double* __restrict__ partial,
-                                                                int n_tiles_total, int nred, int64_t B) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= B * n_tiles * nred_pass) return;
-  const int r = (int)(e % nred_pass), tl = (int)((e / nred_pass) % n_tiles);
-  const int64_t b = e / ((int64_t)nred_pass * n_tiles);
-  const MpxTile T = tiles[tile_first + tl];
-  const int sg0 = (T.m0 - first_node) / deg, cnt = T.n / deg;
-  const double* __restrict__ src = segsum + (b * n_segs + sg0) * nred_pass + r;
-  double v = 0;
-  for (int k = 0; k < cnt; ++k) v += src[(int64_t)k * nred_pass];
-  partial[(b * n_tiles_total + T.tile_id) * nred + r] = v;
-}
-
 // Evaluation points per workgroup.
 //  * Round 1 picked 4-8 for large batches (best case of the software-pipelined loop).  Round 2 measured both over physical
 //    placements of the output buffers on five boxes (tools/placement_ab.py, profiles/r2_headline): with 5 points per workgroup the
@@ -927,9 +969,10 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   // Light passes (no Jacobian values) of high-degree buckets run on the matrix cores (light_body) with direct stores; the other
   // buckets of such a pass store directly too (no staging block, no row spans).  Any batch size: which kernel evaluates a pass
   // never depends on the batch, so results do not either.  MPX_NO_LIGHT=1: the node kernels (A/B runs).
-  bool light = false;
-  if (mode != MPX_MODE_HESS && !io.jac && !shard && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_LIGHT") && getenv("MPX_LIGHT"))  /* (work in progress: opt-in) */
-    for (auto& B : c->buckets) light = light || B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0] != nullptr;
+  bool light = c->lplan.ok && mode != MPX_MODE_HESS && !io.jac && !shard && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() &&
+               !getenv("MPX_NO_LIGHT");
+  for (auto& B : c->buckets)
+    if (light && B.deg == c->lplan.deg && !B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0]) light = false;
   const bool packed = want_g && io.B <= 65535 && !light &&
                       ((shard && !owner) || (c->g_packed && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_PACKED_G")));
   if (packed) {
@@ -948,7 +991,42 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   // absorbing buckets (see build_layout) go last: their tiles read what the other buckets staged
   const bool absorb = packed && !shard && c->absorb;
   const bool by_node = mode == MPX_MODE_HESS && c->hess_by_node;
-  if (by_node && nodes) {  // mixed-degree grid: one launch per phase over node-ordered tiles
+  if (light) {  // every phase: one launch of persistent wavefronts over the (group, evaluation point) items (light_body)
+    HIPCHK(c, hipMemsetAsync(io.partial, 0, (size_t)io.B * io.n_tiles_total * io.nred * 8, c->stream));  // (slots without a group stay zero)
+    static int n_cu = 0;
+    if (!n_cu && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) n_cu = 256;
+    for (auto& B : c->buckets) {
+      if (B.deg != c->lplan.deg) continue;
+      const PhaseStruct& P = c->ph[B.phase];
+      const DegTable& t = c->degs[B.dt];
+      MpxLightArgs L{};
+      MpxNodeArgs& A = L.node;
+      A.io = io, A.tiles = c->d_tiles, A.node_i = B.d_node_i, A.node_sk = B.d_node_sk;
+      A.Dmat = t.d_D, A.Cmid = t.d_Cmid, A.tk = t.d_tk, A.Dmid = t.d_Dmid, A.tkm = t.d_tkm, A.phase = B.phase, A.Wnode = c->d_Wnode;
+      A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
+      A.z_off = P.z_off, A.g_off_F = P.g_off_F, A.g_off_C = P.g_off_C, A.g_off_DU = P.g_off_DU, A.g_off_mU = P.g_off_mU;
+      A.N = (int32_t)c->N, A.seg_off = B.phase * c->S;
+      L.groups = c->d_lgroups, L.foreign = c->d_lforeign, L.wdeg = t.d_w;
+      for (size_t k = 0; k < c->degs.size(); ++k) L.fD_off[k] = c->lplan.fD_off[k], L.fC_off[k] = c->lplan.fC_off[k], L.fdeg[k] = c->degs[k].deg;
+      L.ftab = c->d_lftab, L.ftab_n = (int32_t)c->lplan.ftab.size();
+      L.n_groups = (int32_t)c->lplan.groups.size(), L.first_node = c->lplan.first_node, L.span_cap = c->lplan.span_cap, L.slot_first = P.tile_first;
+      static long long* ldbg = nullptr;
+      if (!ldbg && getenv("MPX_LIGHT_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
+      L.dbg = ldbg;
+      const int64_t items = (int64_t)L.n_groups * io.B;
+      const unsigned wgs = (unsigned)std::min<int64_t>((items + MPX_LIGHT_WAVES - 1) / MPX_LIGHT_WAVES, 2 * (int64_t)n_cu);
+      const unsigned lds = (unsigned)((MPX_LIGHT_WAVES * (c->nx + c->nu) * c->lplan.span_cap + c->lplan.ftab.size()) * 8);
+      int rc = launch(c, B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0], dim3(wgs, 1, 1), dim3(64 * MPX_LIGHT_WAVES, 1, 1), &L, sizeof L, lds);
+      if (rc) return rc;
+      if (c->profile) ++c->prof_launches;
+      if (ldbg) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        fprintf(stderr, "light kernel (deg %d) phases of one item (us): span loads %.2f  matrix core + node functions %.2f  outputs %.2f\n", B.deg, (ldbg[1] - ldbg[0]) / 100.0,
+                (ldbg[2] - ldbg[1]) / 100.0, (ldbg[3] - ldbg[2]) / 100.0);
+      }
+    }
+  }
+  if (by_node && nodes && !light) {  // mixed-degree grid: one launch per phase over node-ordered tiles
     for (int p = 0; p < c->n_phases; ++p) {
       int64_t lo = c->ph_htile_first[p], hi = lo + c->ph_htile_count[p];
       if (shard) {  // the rank's share of every phase's tiles (same fractions in every phase)
@@ -978,7 +1056,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       }
     }
   }
-  for (int pass = 0; pass < 2 && !by_node; ++pass)
+  for (int pass = 0; pass < 2 && !by_node && !light; ++pass)
   for (auto& B : c->buckets) {
     const bool absorber = absorb && B.abs_cap > 0;
     int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);
@@ -1041,40 +1119,6 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
     if (absorber && pass == 1) {
       A.abs_fpos = c->d_abs_fpos, A.abs_fstage = c->d_abs_fstage, A.abs_fn = c->d_abs_fn, A.abs_cap = B.abs_cap;
       lds = (unsigned)B.abs_cap * (unsigned)B.abs_slots * 8u;
-    }
-    hipFunction_t fl = light ? B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0] : nullptr;
-    if (fl) {  // whole-segment tiles on the matrix cores; the node-0 mini tile stays with node_body below
-      const int64_t l0 = lo + (c->tiles[lo].node0 ? 1 : 0);
-      if (hi > l0) {
-        const int first_node = c->tiles[l0].m0, nred_pass = mode == MPX_MODE_FGJ ? 3 + c->na : 1;
-        const int n_segs = (int)(((int64_t)B.node_i.size() - first_node) / B.deg);
-        int rc = reserve(c, c->light_seg, (size_t)(io.B * n_segs * nred_pass));
-        if (rc) return rc;
-        MpxLightArgs L{};
-        L.node = A, L.node.regular = 0, L.node.tile_first = (int32_t)l0, L.node.tile_count = (int32_t)(hi - l0);
-        L.segsum = c->light_seg.p, L.wdeg = t.d_w, L.n_segs = n_segs, L.first_node = first_node;
-        // persistent wavefronts: one workgroup per compute unit, every wavefront walks the (segment, 16 points) items (light_body)
-        static int n_cu = 0;
-        if (!n_cu && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) n_cu = 256;
-        const int64_t items = (int64_t)((n_segs + 15) / 16) * io.B;
-        const unsigned wgs = (unsigned)std::min<int64_t>((items + MPX_LIGHT_WAVES - 1) / MPX_LIGHT_WAVES, n_cu);
-        static long long* ldbg = nullptr;
-        if (!ldbg && getenv("MPX_LIGHT_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
-        L.dbg = ldbg;
-        if ((rc = launch(c, fl, dim3(wgs, 1, 1), dim3(64 * MPX_LIGHT_WAVES, 1, 1), &L, sizeof L))) return rc;
-        if (c->profile) ++c->prof_launches;
-        if (ldbg) {
-          HIPCHK(c, hipStreamSynchronize(c->stream));
-          fprintf(stderr, "light kernel (deg %d) phases of one item (us): loads %.2f  matrix core %.2f  node functions + stores %.2f\n", B.deg, (ldbg[1] - ldbg[0]) / 100.0,
-                  (ldbg[2] - ldbg[1]) / 100.0, (ldbg[3] - ldbg[2]) / 100.0);
-        }
-        const int64_t ne = io.B * (hi - l0) * nred_pass;
-        hipLaunchKernelGGL(mpx_light_combine_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, c->light_seg.p, n_segs, nred_pass, c->d_tiles,
-                           (int)l0, (int)(hi - l0), first_node, B.deg, io.partial, io.n_tiles_total, io.nred, (int64_t)io.B);
-        HIPCHK(c, hipGetLastError());
-      }
-      if (l0 == lo) continue;
-      hi = l0, A.tile_count = 1, A.regular = 0;
     }
     for (int64_t bf = 0; bf < (int64_t)gy * io.b_per_block; bf += (int64_t)65535 * io.b_per_block) {
       A.io.b_first = (int32_t)bf;
@@ -1189,7 +1233,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
     fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
-    fr(c->light_seg.p), fr(c->gl_halo.p), fr(c->gl_pnode.p), fr(c->st_ggx.p), fr(c->st_ggp.p), fr(c->gl_grad.p), fr(c->gl_jac.p);
+    fr(c->d_lgroups), fr(c->d_lforeign), fr(c->d_lftab), fr(c->gl_halo.p), fr(c->gl_pnode.p), fr(c->st_ggx.p), fr(c->st_ggp.p), fr(c->gl_grad.p), fr(c->gl_jac.p);
     fr(c->d_lt_ptr), fr(c->d_lt_col), fr(c->d_lt_row), fr(c->d_lt_coef), fr(c->d_colind_j), fr(c->d_jrow);
     fr(c->d_gmap), fr(c->d_qmap), fr(c->d_abs_fpos), fr(c->d_abs_fstage), fr(c->d_abs_fn), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
@@ -1309,6 +1353,16 @@ extern "C" int mpx_get_tile_spans(const mpx_ctx* c, int32_t* first, int32_t* len
   if (!c || !first || !len || !n_foreign) return MPX_ERR_INVALID;
   if (c->kind != 0) return MPX_ERR_UNSUPPORTED;
   for (size_t t = 0; t < c->tiles.size(); ++t) first[t] = c->tiles[t].span_lo, len[t] = c->tiles[t].span_len, n_foreign[t] = c->tiles[t].f_count;
+  return MPX_OK;
+}
+
+extern "C" int mpx_get_light_plan(const mpx_ctx* c, int32_t* degree, int64_t* n_groups, int64_t* max_span_nodes, int64_t* n_low_degree_nodes) {
+  if (!c) return MPX_ERR_INVALID;
+  const bool ok = c->kind == 0 && c->lplan.ok;
+  if (degree) *degree = ok ? c->lplan.deg : 0;
+  if (n_groups) *n_groups = ok ? (int64_t)c->lplan.groups.size() : 0;
+  if (max_span_nodes) *max_span_nodes = ok ? c->lplan.span_cap : 0;
+  if (n_low_degree_nodes) *n_low_degree_nodes = ok ? (int64_t)c->lplan.foreign.size() : 0;
   return MPX_OK;
 }
 

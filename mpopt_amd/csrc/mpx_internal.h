@@ -103,7 +103,19 @@ struct mpx_ctx {
   // and the generic J^T lam route (assembled contexts; MPX_GRADL_GENERIC=1): scratch grad_f / jac_val + compressed-column tables
   hipFunction_t fn_gradl_fin = nullptr;
   DevBuf<double> gl_halo, gl_pnode, st_ggx, st_ggp, gl_grad, gl_jac;
-  DevBuf<double> light_seg;  // per-segment sums of the light passes (MpxLightArgs::segsum), all light buckets of a pass one after the other
+  // light passes on the matrix cores (mpx_light_*, mpx_kernels.h: light_body): grids with ONE high degree (12 < P <= 31) and otherwise
+  // degrees <= 12.  Groups of up to 16 high-degree segments + the low-degree segments between them (the same for every phase)
+  struct LightPlan {
+    bool ok = false;
+    int deg = 0, dt = -1, first_node = 0, span_cap = 0;
+    std::vector<MpxLightGroup> groups;
+    std::vector<MpxLightForeign> foreign;
+    std::vector<double> ftab;               // D and C_mid of the low degrees, concatenated
+    std::vector<int32_t> fD_off, fC_off;    // by degree-table index (-1: the high degree)
+  } lplan;
+  MpxLightGroup* d_lgroups = nullptr;
+  MpxLightForeign* d_lforeign = nullptr;
+  double* d_lftab = nullptr;
   int64_t *d_lt_ptr = nullptr, *d_lt_col = nullptr, *d_lt_row = nullptr, *d_colind_j = nullptr;
   double* d_lt_coef = nullptr;
   int32_t* d_jrow = nullptr;

@@ -689,27 +689,31 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Light passes of the high-degree buckets (degrees MPX_TABLES_IN_LDS_ABOVE < P <= 31): f, g and grad_f WITHOUT the Jacobian values --
-// what a line search calls (nlp_f / nlp_g alone), little HBM traffic per node.  In node_body such a pass is bound by the LDS pipe,
-// not by HBM: every lane re-reads its row of D and the segment's X from LDS for each of the 3 (P + 1) products of a node, 186
-// ds_read_b64 per lane and point at degree 30 -- counters of mpx_node_fg_0_30 on config 3 (profiles/r4_c3_fg): LDS busy 67 %, VALU busy
-// 9 %, 318 us for 0.5 GB.  This is the case north_star reserves MFMA for ("only if the D.X defect contraction proves dense enough"):
-//   * one WAVEFRONT = one segment x 16 evaluation points.  D.X_a, D.U_c, C_mid.U_c are (P+1)x(P+1) by (P+1)x16 products on the matrix
-//     cores (v_mfma_f64_16x16x4_f64): A operand = the table (the lane's entries stay in registers for the life of the workgroup),
-//     B operand = one state / control of the segment's nodes for 16 points, loaded STRAIGHT from global memory -- no LDS, no barrier
-//     in the contraction.  C/D layout (row = (lane >> 4) + 4 reg, col = lane & 15; tools/mfma_f64_probe.hip): lane (n, q) ends up with
-//     the rows k = q + 4 e of point n -- exactly the nodes whose X / U it supplied as B operand (k = 4 ks + q), so the node functions
-//     are evaluated in place on the same registers.
+// Light passes -- f, g and grad_f WITHOUT the Jacobian values, what a line search calls (nlp_f / nlp_g alone) -- of grids with a high
+// degree (MPX_TABLES_IN_LDS_ABOVE < P <= 31).  In node_body such a pass is bound by the LDS pipe, not by HBM: every lane re-reads its
+// row of D and the segment's X from LDS for each of the 3 (P + 1) products of a node, 186 ds_read_b64 per lane and point at degree 30
+// -- counters of mpx_node_fg_0_30 on config 3 (profiles/r4_c3_fg): LDS busy 67 %, VALU busy 9 %, 318 us for 0.5 GB.  This is the case
+// north_star reserves MFMA for ("only if the D.X defect contraction proves dense enough"):
+//   * a WAVEFRONT works on a group: up to 16 consecutive segments of the high degree at one evaluation point, plus the low-degree
+//     segments between them (config 3: [3, 30, 3] ...) -- ONE contiguous span of the phase's nodes.  The span's X / U rows enter LDS
+//     with fully coalesced loads (512 B per instruction), the rows of g / grad_f leave the same way: no partial lines, no staging
+//     block, no second bucket launch (the heavy passes need row spans + a staging round trip for that).
+//   * D.X_a, D.U_c, C_mid.U_c of the 16 segments are (P+1)x(P+1) by (P+1)x16 products on the matrix cores (v_mfma_f64_16x16x4_f64): A
+//     operand = the table (the lane's entries stay in registers for the life of the wavefront), B operand column n = segment n.
+//     C/D layout (row = (lane >> 4) + 4 reg, col = lane & 15; tools/mfma_f64_probe.hip): lane (n, q) ends up with the rows
+//     k = q + 4 e of segment n -- exactly the nodes whose X / U it supplied as B operand (k = 4 ks + q), so the node functions are
+//     evaluated in place on the same registers.
 //   * The matrix core accumulates the four products of an instruction in order, fused (probe: 256 / 256 results bit-equal to the
 //     sequential fma chain), and K runs over the nodes in order: g is BIT-IDENTICAL to node_body's (tested).  The padding column
 //     (node P + 1) multiplies a zero of the table.
-//   * Stores go straight to the rows of g / grad_f (16 points x 32-byte sectors per instruction; for these passes direct stores beat
-//     the staging + row-span scheme of the heavy passes: 351 against 367 us on config 3, tools/r3_single_oracle_bpb.py).
-//   * A workgroup = the segments of ONE tile of the bucket (its waves take them in turn) x 16 points; the per-point sums (f, and for
-//     the grad_f pass d/dt0, d/dtf, d/dA) are reduced lane -> the four lane groups of a point -> the tile's segments in order, into the
-//     tile's slot of the partial-sum buffer: fixed order, independent of the batch (the boundary kernel is unchanged).  f of a light
-//     pass and f of a heavy pass (node_body's shuffle tree) round differently in the last bit; g and grad_f do not.
-// The node-0 mini tile of a bucket and every other bucket of the pass go through node_body with direct stores.
+//   * The low-degree nodes of the span: one lane each, the same fma chains as node_body over the span in LDS.
+//   * Wavefronts are persistent and independent (no barrier): each walks the (group, point) items with the stride of the grid.  The
+//     per-point sums (f; for the grad_f pass d/dt0, d/dtf, d/dA) of a group go to the partial-sum slot slot_first + group -- lane,
+//     lane groups, segments, low-degree nodes, in that order: fixed, independent of the batch; the boundary kernel is unchanged.
+//     f of a light pass and f of a heavy pass (node_body's tiles) round differently in the last bit; g and the node entries of
+//     grad_f do not.
+// History of the design (profiles/r4_c3_fg/README.md): 16 evaluation points as the 16 columns, loads straight from global memory:
+// every access a 32-byte granule, the memory system delivered 3 TB/s at most and the low-degree bucket's own launch cost 86 us.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef double mpx_d4 __attribute__((ext_vector_type(4)));
 
@@ -718,14 +722,25 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
   using G = mpxgen::Phase<PH>;
   const MpxNodeArgs& A = L.node;
   constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
+  constexpr int NIN = NX + NU;
   constexpr int P1 = P + 1, MT = (P1 + 15) / 16, KS = 4 * MT;
   static_assert(MT <= 2, "light_body: degrees up to 31");
   constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : G::NRED;
+  // rows of g a node writes: defect, path, DU, mU (the mid-point row before node i is row i - 1 of its block)
+  constexpr int R_C = NX, R_DU = NX + NC, R_MU = R_DU + (G::DIFF_U ? NU : 0), NG = R_MU + (G::MIDU ? NU : 0);
+  extern __shared__ double sBuf[];  // [wavefront][NIN][span_cap]: the span's inputs, then (in turns of NIN rows) its outputs; the low-degree tables
   const int t = threadIdx.x, wave = t >> 6, l = t & 63, n = l & 15, q = l >> 4;
-  const int N = A.N;
+  const int N = A.N, cap = L.span_cap;
+  double* __restrict__ sW = sBuf + (size_t)wave * NIN * cap;
+  const double* __restrict__ sTab = sBuf + (size_t)MPX_LIGHT_WAVES * NIN * cap;
+  for (int e = t; e < L.ftab_n; e += 64 * MPX_LIGHT_WAVES) sBuf[(size_t)MPX_LIGHT_WAVES * NIN * cap + e] = L.ftab[e];
   const MpxIO& io = A.io;
-  // A operands: lane l supplies row (l & 15) of an M tile and column (l >> 4) of a K step
-  double AD[MT][KS], AC[MT][KS];
+  // A operands: lane l supplies row (l & 15) of an M tile and column (l >> 4) of a K step.  The differentiation table stays in
+  // registers; the mid-point table (one chain per control) and the per-point constants are read from LDS where they are used --
+  // with everything in registers a wavefront needed 336 of them and a compute unit held four wavefronts.
+  double AD[MT][KS];
+  __shared__ double sAC[MT][KS][64];
+  __shared__ double sTk[4 * KS], sWt[4 * KS];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -733,116 +748,83 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
       const int k = 16 * mt + n, j = 4 * ks + q;
       const bool in = k <= P && j <= P;
       AD[mt][ks] = in ? A.Dmat[(in ? k : 0) * P1 + (in ? j : 0)] : 0.0;
-      AC[mt][ks] = (G::MIDU && in && k >= 1) ? A.Cmid[((in && k >= 1) ? k - 1 : 0) * P1 + (in ? j : 0)] : 0.0;
+      if (wave == 0) sAC[mt][ks][l] = (G::MIDU && in && k >= 1) ? A.Cmid[((in && k >= 1) ? k - 1 : 0) * P1 + (in ? j : 0)] : 0.0;
     }
-  // (the quadrature weight of point k >= 1 of a segment is w_k of its degree: the composite vector repeats the table, mpopt.py:4060-4062)
-  double tkv[KS], wtab[KS];
-#pragma unroll
-  for (int e = 0; e < KS; ++e) tkv[e] = A.tk[q + 4 * e <= P ? q + 4 * e : P], wtab[e] = L.wdeg[q + 4 * e <= P ? q + 4 * e : P];
-  const bool want_g = io.g != nullptr;
-  // PERSISTENT, INDEPENDENT wavefronts: the grid is one workgroup of MPX_LIGHT_WAVES wavefronts per compute unit (242 VGPRs each: they
-  // fill its register file), and every wavefront walks the (segment, 16 points) items with the stride of all wavefronts of the grid --
-  // consecutive wavefronts take consecutive segments of the same points.  No barrier anywhere: the two wavefronts of a SIMD drift
-  // apart, one waits for its loads while the other feeds the matrix core.  (Launched one workgroup per (tile, 16 points), a compute
-  // unit drained completely between two workgroups and reloaded the tables each time: wavefronts lived 2.6 us and the unit held 1.8
-  // of them on average -- SQ_WAVE_CYCLES / SQ_BUSY_CYCLES, profiles/r4_c3_fg.)  Per-point sums leave per SEGMENT (L.segsum);
-  // mpx_light_combine_kernel adds the segments of every tile in order into the tile's slot of the partial-sum buffer.
-  // The 16 columns of a wavefront's products are 16 CONSECUTIVE SEGMENTS of the bucket at ONE evaluation point: everything the
-  // wavefront reads and writes lies in a few KB of each row of z / g.  (First version: 16 evaluation points of one segment -- every
-  // load fetched 16 chunks 0.6 MB apart, no two in the same DRAM row: 7 us per item in the loads alone, tools/r4_light_stamps.py.)
-  const int n_grp = (L.n_segs + 15) / 16;
-  const int64_t total = (int64_t)n_grp * (io.B - io.b_first), stride = (int64_t)gridDim.x * MPX_LIGHT_WAVES;
-  int64_t item = (int64_t)blockIdx.x * MPX_LIGHT_WAVES + wave;
-  // One item's inputs of this lane.  The loop is software pipelined: the loads of the NEXT item are issued between the last matrix
-  // instruction and the stores of the current one (the B operands' registers are free by then), so a wavefront always has loads in
-  // flight -- before, every wavefront of the chip sat in its load phase at the same time (6-8 of the 14 us of an item,
-  // tools/r4_light_stamps.py) and the memory system idled during the other phases.
-  struct In {
-    double zX[NX][KS], zU[NU > 0 ? NU : 1][KS];
-    double t0v, tfv, ws, wc;
-    Vec<NA> As;
-    int st, sgi, b;
-  };
-  auto load_item = [&](int64_t it, In& I) {
-    int sg = (int)(it % n_grp) * 16 + n;
-    I.sgi = sg;
-    sg = sg < L.n_segs ? sg : L.n_segs - 1;  // (lanes past the last segment shadow it; they store nothing)
-    I.b = io.b_first + (int)(it / n_grp);
-    const int m0 = L.first_node + sg * P;
-    I.st = A.node_i[m0] - 1;                 // the segment's point 0 in the phase
-    const int s = A.node_sk[m0] >> 8;
-    const double* __restrict__ zb = io.z + (int64_t)I.b * io.z_stride + A.z_off;
-    const double* __restrict__ zt = zb + (int64_t)(NX + NU) * N;
-    I.t0v = zt[0], I.tfv = zt[1];
-#pragma unroll
-    for (int c = 0; c < NA; ++c) I.As[c] = zt[2 + c];
-    const int64_t woff = (int64_t)I.b * io.w_stride + A.seg_off + s;
-    I.ws = io.w[woff], I.wc = io.wcum[woff];
-#pragma unroll
-    for (int e = 0; e < KS; ++e) {
-      const int j = q + 4 * e <= P ? q + 4 * e : P;  // (the padding node P + 1 meets a zero of the table)
-#pragma unroll
-      for (int a = 0; a < NX; ++a) I.zX[a][e] = (zb + (int64_t)a * N)[I.st + j];
-#pragma unroll
-      for (int c = 0; c < NU; ++c) I.zU[c][e] = (zb + (int64_t)(NX + c) * N)[I.st + j];
-    }
-  };
+  // (the quadrature weight of point k of a segment is w_k of its degree: the composite vector repeats the table, mpopt.py:4060-4062)
+  if (t < 4 * KS) sTk[t] = A.tk[t <= P ? t : P], sWt[t] = L.wdeg[t <= P ? t : P];
+  __syncthreads();  // (the only barrier of the kernel: the tables are in place)
+  const bool want_g = io.g != nullptr, want_q = MODE == MPX_MODE_FGJ && io.grad != nullptr;
+  const int64_t total = (int64_t)L.n_groups * (io.B - io.b_first), stride = (int64_t)gridDim.x * MPX_LIGHT_WAVES;
+  auto lds_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };  // (one wavefront: LDS operations complete in order)
 #ifdef MPX_LIGHT_STAMPS  // phase stamps of one wavefront's third item (wall_clock64: 100 MHz), forced waits at the phase ends
   int it_ = 0;
 #define MPX_LSTAMP(k) if (L.dbg && blockIdx.x == 1 && wave == 1 && it_ == 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (l == 0) L.dbg[k] = wall_clock64(); }
 #else
 #define MPX_LSTAMP(k)
 #endif
-  In I;
-  if (item < total) load_item(item, I);
-  for (; item < total; item += stride) {
+  // Every wavefront of the chip starts at the same time and the phases of an item take the same time everywhere: left alone, all of
+  // them sit in the load phase together, then in the matrix phase, then in the store phase (stamps: 7 + 6.5 + 3.5 us per item), and
+  // the memory system idles two thirds of the time.  Half of the wavefronts start half an item late.
+#ifndef MPX_LIGHT_STAGGER
+#define MPX_LIGHT_STAGGER 0
+#endif
+  if (wave & 1)
+    for (int k = 0; k < MPX_LIGHT_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+  for (int64_t item = (int64_t)blockIdx.x * MPX_LIGHT_WAVES + wave; item < total; item += stride) {
     MPX_LSTAMP(0)
-    const int st = I.st, sgi = I.sgi, b = I.b;
-    const bool bok = sgi < L.n_segs;  // this lane's column is a real segment
-    const double kap = I.ws * A.inv_dtau;
-    // (1) node functions of the lane's nodes: everything that needs the inputs
-    Vec<NRED> red;
+    const int gi = (int)(item % L.n_groups), b = io.b_first + (int)(item / L.n_groups);
+    const MpxLightGroup Gp = L.groups[gi];
+    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + A.z_off;
+    const double* __restrict__ zt = zb + (int64_t)NIN * N;
+    const double t0v = zt[0], tfv = zt[1];
+    Vec<NA> As;
 #pragma unroll
-    for (int r = 0; r < NRED; ++r) red[r] = 0.0;
-    double fxs[NX][KS], ccs[NC > 0 ? NC : 1][KS];
+    for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
+    constexpr int FMAX = 2;  // turns of 64 low-degree nodes a lane can hold (the host keeps f_count <= 64 * FMAX)
+    // descriptors first: the loads that depend on them (widths of the segments) are then in flight together with the span's
+    MpxLightForeign Fd[FMAX];
 #pragma unroll
-    for (int e = 0; e < KS; ++e) {
-      const int j = q + 4 * e;
-      const bool valid = bok && j >= 1 && j <= P;  // (point 0 of a segment belongs to the previous one; node 0 of the phase to node_body)
-      const double th = I.wc + I.ws * tkv[e];
-      Vec<NX> Xs, fx;
-      Vec<NU> Us;
-      Vec<NC> cc;
+    for (int u = 0; u < FMAX; ++u) Fd[u] = L.foreign[Gp.f_first + (64 * u + l < Gp.f_count ? 64 * u + l : 0)];
+    const bool col = n < Gp.n_light;  // the lane's high-degree segment (column n of the products)
+    const int m0 = L.first_node + (Gp.seg_first + (col ? n : 0)) * P;
+    const int st = A.node_i[m0] - 1, s = A.node_sk[m0] >> 8;  // point 0 of the segment in the phase; the segment
+    const int64_t woff = (int64_t)b * io.w_stride + A.seg_off;
+    // (1) the span's rows of X / U: coalesced loads, into LDS
+    lds_sync();  // (the previous item's output reads of this buffer are done)
+    {  // (ALL loads of the span are issued before the first LDS write: one round trip to memory per item, not one per batch)
+      constexpr int CH = MPX_LIGHT_CHUNKS;  // 64-node chunks a span can have (the host caps the span at 64 * CH nodes)
+      double v[NIN][CH];
 #pragma unroll
-      for (int a = 0; a < NX; ++a) Xs[a] = I.zX[a][e];
+      for (int u = 0; u < CH; ++u) {
+        const int idx = 64 * u + l;
 #pragma unroll
-      for (int c = 0; c < NU; ++c) Us[c] = I.zU[c][e];
-      if constexpr (MODE == MPX_MODE_FG) {
-        double qW;
-        G::fg(Xs, Us, I.t0v, I.tfv, I.As, kap, th, wtab[e], fx, cc, qW);
-        if (valid) red[0] += qW;
-      } else {
-        Vec<NX> dd;
-        Vec<G::NJV> jv;
-        Vec<NX + NU> gn;
-        Vec<NRED> gr;
-        G::fgj(Xs, Us, I.t0v, I.tfv, I.As, kap, th, wtab[e], fx, cc, dd, jv, gn, gr);
-        if (valid) {
-#pragma unroll
-          for (int r = 0; r < NRED; ++r) red[r] += gr[r];
-          if (io.grad) {
-            double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
-#pragma unroll
-            for (int a = 0; a < NX + NU; ++a) qb[(int64_t)a * N + st + j] = gn[a];
-          }
-        }
+        for (int a = 0; a < NIN; ++a) v[a][u] = idx < Gp.len_r ? (zb + (int64_t)a * N)[Gp.lo_r + idx] : 0.0;
       }
 #pragma unroll
-      for (int a = 0; a < NX; ++a) fxs[a][e] = fx[a];
+      for (int u = 0; u < CH; ++u) {
+        const int idx = 64 * u + l;
+        if (idx < Gp.len_r) {
 #pragma unroll
-      for (int jj = 0; jj < NC; ++jj) ccs[jj][e] = cc[jj];
+          for (int a = 0; a < NIN; ++a) sW[a * cap + idx] = v[a][u];
+        }
+      }
     }
+    const int sp = st - Gp.lo_r;  // point 0 of the lane's segment in the span
+    const double ws = io.w[woff + s], wc = io.wcum[woff + s];
+    double wsf[FMAX], wcf[FMAX];
+#pragma unroll
+    for (int u = 0; u < FMAX; ++u) wsf[u] = io.w[woff + Fd[u].s], wcf[u] = io.wcum[woff + Fd[u].s];
+    lds_sync();
     MPX_LSTAMP(1)
+    double zX[NX][KS], zU[NU > 0 ? NU : 1][KS];
+#pragma unroll
+    for (int e = 0; e < KS; ++e) {
+      const int j = q + 4 * e <= P ? q + 4 * e : P;  // (the padding node P + 1 meets a zero of the table)
+#pragma unroll
+      for (int a = 0; a < NX; ++a) zX[a][e] = sW[a * cap + sp + j];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) zU[c][e] = sW[(NX + c) * cap + sp + j];
+    }
     // (2) the contractions on the matrix core
     mpx_d4 aX[NX][MT], aDU[NU > 0 ? NU : 1][MT], aCU[NU > 0 ? NU : 1][MT];
 #pragma unroll
@@ -852,57 +834,208 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
 #pragma unroll
       for (int c = 0; c < NU; ++c) aDU[c][mt] = mpx_d4{0, 0, 0, 0}, aCU[c][mt] = mpx_d4{0, 0, 0, 0};
     }
+#ifdef MPX_ABL_LIGHT_NO_MFMA  // ablation: no matrix instructions
+    if (false) {
+#else
     if (want_g) {
+#endif
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-          for (int a = 0; a < NX; ++a) aX[a][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(AD[mt][ks], I.zX[a][ks], aX[a][mt], 0, 0, 0);
+          for (int a = 0; a < NX; ++a) aX[a][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(AD[mt][ks], zX[a][ks], aX[a][mt], 0, 0, 0);
           if constexpr (G::DIFF_U) {
 #pragma unroll
-            for (int c = 0; c < NU; ++c) aDU[c][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(AD[mt][ks], I.zU[c][ks], aDU[c][mt], 0, 0, 0);
+            for (int c = 0; c < NU; ++c) aDU[c][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(AD[mt][ks], zU[c][ks], aDU[c][mt], 0, 0, 0);
           }
           if constexpr (G::MIDU) {
 #pragma unroll
-            for (int c = 0; c < NU; ++c) aCU[c][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(AC[mt][ks], I.zU[c][ks], aCU[c][mt], 0, 0, 0);
+            for (int c = 0; c < NU; ++c) aCU[c][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(sAC[mt][ks][l], zU[c][ks], aCU[c][mt], 0, 0, 0);
           }
         }
     }
-    // (3) the next item's loads, into the registers the B operands just left
-    __builtin_amdgcn_sched_barrier(0);
-    if (item + stride < total) load_item(item + stride, I);
-    __builtin_amdgcn_sched_barrier(0);
-    MPX_LSTAMP(2)
-    // (4) stores
-    if (want_g && bok) {
-      double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
+    // (3) the low-degree nodes of the span, one lane each (in turns of 64): node_body's fma chains over the span in LDS
+    double fval[FMAX][NG > 0 ? NG : 1], fgrd[FMAX][MODE == MPX_MODE_FGJ ? NIN : 1];
+    int fpos[FMAX];
+    Vec<NRED> fred;
 #pragma unroll
-      for (int e = 0; e < KS; ++e) {
-        const int j = q + 4 * e, i = st + j;
-        if (j >= 1 && j <= P) {
+    for (int r = 0; r < NRED; ++r) fred[r] = 0.0;
 #pragma unroll
-          for (int a = 0; a < NX; ++a) gb[A.g_off_F + (int64_t)a * N + i] = aX[a][e / 4][e % 4] - fxs[a][e];
+    for (int u = 0; u < FMAX; ++u) {
+      fpos[u] = -1;
+      const int fi = 64 * u + l;
+#ifdef MPX_ABL_LIGHT_NO_FOREIGN  // ablation: the low-degree nodes are skipped
+      if (false) {
+#else
+      if (fi < Gp.f_count) {
+#endif
+        const MpxLightForeign F = Fd[u];
+        const int di = F.dk >> 8, k = F.dk & 255, pf = L.fdeg[di], p1f = pf + 1;
+        const double* __restrict__ Dr = sTab + L.fD_off[di] + k * p1f;
+        const double* __restrict__ Cr = sTab + L.fC_off[di] + (k >= 1 ? k - 1 : 0) * p1f;
+        fpos[u] = F.pos;
+        Vec<NX> Xs, fx;
+        Vec<NU> Us;
+        Vec<NC> cc;
 #pragma unroll
-          for (int jj = 0; jj < NC; ++jj) gb[A.g_off_C + (int64_t)jj * N + i] = ccs[jj][e];
+        for (int a = 0; a < NX; ++a) Xs[a] = sW[a * cap + F.pos];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) Us[c] = sW[(NX + c) * cap + F.pos];
+        const double kapf = wsf[u] * A.inv_dtau, thf = wcf[u] + wsf[u] * F.tk;
+        Vec<NRED> gr;
+        if constexpr (MODE == MPX_MODE_FG) {
+          G::fg(Xs, Us, t0v, tfv, As, kapf, thf, F.w, fx, cc, gr[0]);
+        } else {
+          Vec<NX> dd;
+          Vec<G::NJV> jv;
+          Vec<NIN> gn;
+          G::fgj(Xs, Us, t0v, tfv, As, kapf, thf, F.w, fx, cc, dd, jv, gn, gr);
+#pragma unroll
+          for (int a = 0; a < NIN; ++a) fgrd[u][a] = gn[a];
+        }
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) fred[r] += gr[r];
+        if (want_g) {
+#pragma unroll
+          for (int a = 0; a < NX; ++a) {
+            double acc = 0;
+            for (int j = 0; j < p1f; ++j) acc = fma(Dr[j], sW[a * cap + F.pos0 + j], acc);
+            fval[u][a] = acc - fx[a];
+          }
+#pragma unroll
+          for (int jj = 0; jj < NC; ++jj) fval[u][R_C + jj] = cc[jj];
           if constexpr (G::DIFF_U) {
 #pragma unroll
-            for (int c = 0; c < NU; ++c) gb[A.g_off_DU + (int64_t)c * N + i] = aDU[c][e / 4][e % 4];
+            for (int c = 0; c < NU; ++c) {
+              double acc = 0;
+              for (int j = 0; j < p1f; ++j) acc = fma(Dr[j], sW[(NX + c) * cap + F.pos0 + j], acc);
+              fval[u][R_DU + c] = acc;
+            }
           }
           if constexpr (G::MIDU) {
 #pragma unroll
-            for (int c = 0; c < NU; ++c) gb[A.g_off_mU + (int64_t)c * (N - 1) + (i - 1)] = aCU[c][e / 4][e % 4];
+            for (int c = 0; c < NU; ++c) {
+              double acc = 0;
+              if (k >= 1)
+                for (int j = 0; j < p1f; ++j) acc = fma(Cr[j], sW[(NX + c) * cap + F.pos0 + j], acc);
+              fval[u][R_MU + c] = acc;
+            }
           }
         }
       }
     }
-    // the point's sums over this segment: the lane's nodes in order, then the four lane groups of the segment
+    // (4) node functions of the lane's high-degree nodes
+    const double kap = ws * A.inv_dtau;
+    Vec<NRED> red;
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) red[r] = 0.0;
+    double fxs[KS][NX], ccs[KS][NC > 0 ? NC : 1], ogrd[KS][MODE == MPX_MODE_FGJ ? NIN : 1];
+#pragma unroll
+    for (int e = 0; e < KS; ++e) {
+      const int j = q + 4 * e;
+      const bool valid = col && j <= P && (j >= 1 || s == 0);  // (point 0 of a segment belongs to the previous one -- except node 0 of the phase)
+      const double th = wc + ws * sTk[j];
+      Vec<NX> Xs, fx;
+      Vec<NU> Us;
+      Vec<NC> cc;
+#pragma unroll
+      for (int a = 0; a < NX; ++a) Xs[a] = zX[a][e];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) Us[c] = zU[c][e];
+      Vec<NRED> gr;
+      if constexpr (MODE == MPX_MODE_FG) {
+        G::fg(Xs, Us, t0v, tfv, As, kap, th, sWt[j], fx, cc, gr[0]);
+      } else {
+        Vec<NX> dd;
+        Vec<G::NJV> jv;
+        Vec<NIN> gn;
+        G::fgj(Xs, Us, t0v, tfv, As, kap, th, sWt[j], fx, cc, dd, jv, gn, gr);
+#pragma unroll
+        for (int a = 0; a < NIN; ++a) ogrd[e][a] = gn[a];
+      }
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) red[r] += gr[r];
+      }
+#pragma unroll
+      for (int a = 0; a < NX; ++a) fxs[e][a] = fx[a];
+#pragma unroll
+      for (int jj = 0; jj < NC; ++jj) ccs[e][jj] = cc[jj];
+    }
+    // (value of row r of g at the lane's e-th node: compile-time indices after unrolling)
+    auto oval = [&](int e, int r) -> double {
+      if (r < R_C) return aX[r < NX ? r : 0][e / 4][e % 4] - fxs[e][r < NX ? r : 0];
+      if (r < R_DU) return ccs[e][NC > 0 ? r - R_C : 0];
+      if (r < R_MU) return aDU[NU > 0 ? r - R_DU : 0][e / 4][e % 4];
+      return aCU[NU > 0 ? r - R_MU : 0][e / 4][e % 4];
+    };
+    MPX_LSTAMP(2)
+    // (5) outputs: NIN rows at a time through the LDS buffer (every input read is done), coalesced stores of the owned span.
+    // Row r of the span buffer holds positions relative to lo_r; a mid-point row holds the row of node i at position i - 1.
+    const int w0 = Gp.lo_w - Gp.lo_r;  // first owned position
+    auto put_rows = [&](auto value_light, auto value_foreign, int r0, int nr, auto row_ptr, auto shift) {
+      lds_sync();
+#pragma unroll
+      for (int e = 0; e < KS; ++e) {
+        const int j = q + 4 * e;
+        if (col && j <= P && (j >= 1 || s == 0)) {
+#pragma unroll
+          for (int r = 0; r < NIN; ++r)
+            if (r < nr && sp + j - shift(r0 + r) >= 0) sW[r * cap + sp + j - shift(r0 + r)] = value_light(e, r0 + r);  // (node 0 has no mid-point row)
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < FMAX; ++u)
+        if (fpos[u] >= 0) {
+#pragma unroll
+          for (int r = 0; r < NIN; ++r)
+            if (r < nr && fpos[u] - shift(r0 + r) >= 0) sW[r * cap + fpos[u] - shift(r0 + r)] = value_foreign(u, r0 + r);
+        }
+      lds_sync();
+#pragma unroll
+      for (int r = 0; r < NIN; ++r)
+        if (r < nr) {
+          double* __restrict__ dst = row_ptr(r0 + r);  // address of the row's entry of node lo_r (the shift is in the positions)
+          const int sh = shift(r0 + r);
+          // owned positions [w0, w0 + len_w); a shifted row has no entry for node 0 of the phase
+          const int p_lo = w0 - sh < 0 ? 0 : w0 - sh, p_hi = w0 + Gp.len_w - sh;
+          for (int idx = p_lo + l; idx < p_hi; idx += 64) dst[idx] = sW[r * cap + idx];
+        }
+    };
+    if (want_g) {
+      double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
+      for (int r0 = 0; r0 < NG; r0 += NIN) {
+        put_rows([&](int e, int r) { return oval(e, r); }, [&](int u, int r) { return fval[u][r]; }, r0, NG - r0 < NIN ? NG - r0 : NIN,
+                 [&](int r) -> double* {
+                   if (r < R_C) return gb + A.g_off_F + (int64_t)r * N + Gp.lo_r;
+                   if (r < R_DU) return gb + A.g_off_C + (int64_t)(r - R_C) * N + Gp.lo_r;
+                   if (r < R_MU) return gb + A.g_off_DU + (int64_t)(r - R_DU) * N + Gp.lo_r;
+                   return gb + A.g_off_mU + (int64_t)(r - R_MU) * (N - 1) + Gp.lo_r;
+                 },
+                 [&](int r) { return r >= R_MU ? 1 : 0; });
+      }
+    }
+    if constexpr (MODE == MPX_MODE_FGJ) {
+      if (want_q) {
+        double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
+        put_rows([&](int e, int r) { return ogrd[e][r]; }, [&](int u, int r) { return fgrd[u][r]; }, 0, NIN,
+                 [&](int r) -> double* { return qb + (int64_t)r * N + Gp.lo_r; }, [&](int) { return 0; });
+      }
+    }
+    // (6) the point's sums over this group: the lane's nodes in order, the four lane groups of a segment, the segments (fixed
+    // tree), then the low-degree nodes (wave tree)
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
       double v = red[r];
       v += __shfl_down(v, 32, 64);
       v += __shfl_down(v, 16, 64);
-      if (l < 16 && bok) L.segsum[((int64_t)b * L.n_segs + sgi) * NRED + r] = v;  // (16 consecutive segments of the point)
+      v += __shfl_down(v, 8, 64);
+      v += __shfl_down(v, 4, 64);
+      v += __shfl_down(v, 2, 64);
+      v += __shfl_down(v, 1, 64);
+      const double fs = wave_sum(fred[r]);
+      if (l == 0) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + gi) * io.nred + r] = v + fs;
     }
     MPX_LSTAMP(3)
 #ifdef MPX_LIGHT_STAMPS
@@ -1526,10 +1659,10 @@ __device__ __forceinline__ void gradl_finish_body(const MpxGradlFinArgs& A) {
   }
 
 #define MPX_INSTANTIATE_LIGHT(PH, P)                                                                                          \
-  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES) void mpx_light_fg_##PH##_##P(const MpxLightArgs A) {          \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_light_fg_##PH##_##P(const MpxLightArgs A) {          \
     mpxk::light_body<PH, P, MPX_MODE_FG>(A);                                                                                  \
   }                                                                                                                           \
-  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES) void mpx_light_fgq_##PH##_##P(const MpxLightArgs A) {         \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_light_fgq_##PH##_##P(const MpxLightArgs A) {         \
     mpxk::light_body<PH, P, MPX_MODE_FGJ>(A);                                                                                 \
   }
 

@@ -441,6 +441,12 @@ class NlpFunctions:
         _lib.check(self._L.mpx_get_tile_spans(self._ctx, *[v.ctypes.data_as(_lib.c_int32_p) for v in a]), self._ctx)
         return tuple(a)
 
+    def light_plan(self):
+        """(degree, n_groups, max_span_nodes, n_low_degree_nodes) of the light-pass plan (mpx_get_light_plan); degree 0: none."""
+        d, g, sp, nf = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._L.mpx_get_light_plan(self._ctx, ctypes.byref(d), ctypes.byref(g), ctypes.byref(sp), ctypes.byref(nf)), self._ctx)
+        return d.value, g.value, sp.value, nf.value
+
     def partials(self, batch):
         """(device pointer, element count) of the per-tile partial-sum buffer for ``batch`` points."""
         ptr, cnt = ctypes.c_void_p(), ctypes.c_int64()

@@ -1,0 +1,104 @@
+"""Light passes (f, g, grad_f without the Jacobian values) of grids with a high degree: the mpx_light_* kernels (contractions on the
+matrix cores, span-coalesced I/O; mpx_kernels.h: light_body) against the node kernels they replace for these passes
+(MPX_NO_LIGHT=1): g and the node entries of grad_f bit for bit, f and the (t0, tf, a) entries of grad_f to rounding; against the
+numpy oracle; batch-split invariance.  What nlp_g / nlp_f compute: reference mpopt.py:227-232, 455."""
+import os
+
+import numpy as np
+import pytest
+
+import mpopt_amd as M
+from mpopt_amd import mp
+import problems
+from helpers import assert_entries, border_columns
+
+mixed = lambda S: [30 if s % 3 == 1 else 3 for s in range(S)]
+CASES = {
+    "config3_pattern_48": (problems.van_der_pol, 48, mixed(48), "CGL"),          # 16 high-degree segments: one full group
+    "config3_pattern_100": (problems.van_der_pol, 100, mixed(100), "CGL"),       # 33 of them: ragged last group
+    "high_first_and_last": (problems.van_der_pol, 9, [30, 3, 3, 30, 5, 30, 3, 2, 30], "LGL"),  # node 0 on the matrix core; ragged degrees
+    "dae_vdp_9x17": (problems.dae_vdp, 9, 17, "LGL"),                            # regular grid, path row, parameter: 4 rows of g per node
+    "dae_vdp_40x13": (problems.dae_vdp, 40, 13, "LGR"),                          # lowest degree of the scheme, several groups
+    "vdp_3x31": (problems.van_der_pol, 3, 31, "CGL"),                            # highest degree: both M tiles full
+    "kitchen_sink_mixed": (problems.kitchen_sink, 12, [20, 3, 20, 5] * 3, "LGR"),  # two phases, DU rows, time dependence, parameters
+    "time_dependent_mixed": (problems.time_dependent, 30, [3, 16, 4] * 10, "CGL"),
+}
+NO_PLAN = {
+    "two_high_degrees": (problems.van_der_pol, 8, [20, 16] * 4, "CGL"),
+    "low_degrees_only": (problems.van_der_pol, 8, [3, 5] * 4, "CGL"),
+    "degree_above_31": (problems.van_der_pol, 3, [40, 3, 3], "CGL"),
+}
+
+
+def build(case):
+    builder, S, po, scheme = case
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    return ocp, mpo, mpo.create_nlp()[0]["oracle"]
+
+
+@pytest.mark.parametrize("name", list(CASES) + list(NO_PLAN))
+def test_light_plan_structure(name):
+    """The plan is host arithmetic: it exists exactly for grids with one degree in 13..31 and otherwise degrees <= 12."""
+    builder, S, po, scheme = (CASES.get(name) or NO_PLAN[name])
+    ocp = builder(mp, M.math)
+    orders = [po] * S if isinstance(po, int) else list(po)
+    o = M.NlpFunctions(ocp, S, orders, scheme, with_device=False)
+    deg, n_groups, span, n_low = o.light_plan()
+    if name in NO_PLAN:
+        assert (deg, n_groups) == (0, 0)
+    else:
+        high = [d for d in orders if d > 12]
+        assert deg == high[0] and n_groups >= -(-len(high) // 16) and span <= 640
+        assert n_low == sum(d for d in orders if d <= 12) + (1 if orders[0] <= 12 else 0)
+    o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+def test_light_kernels_against_node_kernels_and_oracle(name):
+    from oracle.mpopt_oracle import OracleNLP
+
+    ocp, mpo, o = build(CASES[name])
+    assert o.light_plan()[0] > 12
+    rng = np.random.default_rng(3)
+    node = np.ones(o.n_z, bool)
+    node[border_columns(o)] = False
+    z0 = mpo.initialize_solution()
+    for B in (1, 16, 37):
+        Z = z0[None, :] * (1 + 0.02 * rng.uniform(-1, 1, (B, o.n_z))) + 0.02 * rng.uniform(-1, 1, (B, o.n_z))
+        w = rng.uniform(0.5, 1.5, (ocp.n_phases, o.n_segments))
+        p = (w / w.sum(1, keepdims=True)).ravel()
+        masks = (["f", "g"], ["g"], ["f"], ["f", "grad_f"], ["f", "g", "grad_f"], ["grad_f"])
+        light = [o.eval(m, Z, p) for m in masks]
+        os.environ["MPX_NO_LIGHT"] = "1"
+        try:
+            heavy = [o.eval(m, Z, p) for m in masks]
+        finally:
+            del os.environ["MPX_NO_LIGHT"]
+        for m, a, b in zip(masks, light, heavy):
+            if "g" in m:
+                assert np.array_equal(a["g"], b["g"]), (name, B, m)
+            if "grad_f" in m:
+                assert np.array_equal(a["grad_f"][:, node], b["grad_f"][:, node]), (name, B, m)
+                assert_entries(a["grad_f"][:, ~node], b["grad_f"][:, ~node], 1e-12, what=f"{name} B={B} grad_f (t0, tf, a) entries, light vs node kernels")
+            if "f" in m:
+                assert np.abs(a["f"] - b["f"]).max() <= 1e-13 * max(1.0, np.abs(b["f"]).max()), (name, B, m)
+                assert np.array_equal(a["f"], light[0]["f"]), (name, B, m)  # every light pass sums f in the same order
+        # batch-split invariance of the light passes: a batch equals its single evaluations bit for bit
+        for b_ in (0, B - 1):
+            r1 = o.eval(["f", "g", "grad_f"], Z[b_], p)
+            assert r1["f"] == light[4]["f"][b_] and np.array_equal(r1["g"], light[4]["g"][b_]) and np.array_equal(r1["grad_f"], light[4]["grad_f"][b_])
+        # per-point widths
+        P2 = np.stack([np.roll(p.reshape(ocp.n_phases, -1), b_, axis=1).ravel() for b_ in range(B)])
+        lp = o.eval(["f", "g"], Z, P2)
+        r1 = o.eval(["f", "g"], Z[B - 1], P2[B - 1])
+        assert r1["f"] == lp["f"][B - 1] and np.array_equal(r1["g"], lp["g"][B - 1])
+    builder, S, po, scheme = CASES[name]
+    O = OracleNLP(ocp, S, po, scheme)
+    r = o.eval(["f", "g", "grad_f"], Z[0], p)
+    assert abs(r["f"] - O.f(Z[0], p)) <= 1e-10 * max(1.0, abs(O.f(Z[0], p)))
+    go = O.g(Z[0], p)
+    assert np.abs(r["g"] - go).max() <= 1e-10 * max(1.0, np.abs(go).max())
+    assert_entries(r["grad_f"], O.grad_f(Z[0], p), 1e-10, what=f"{name} grad_f (light) vs numpy oracle")
+    o.close()

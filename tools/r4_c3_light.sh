@@ -1,10 +1,11 @@
 #!/bin/bash
 # Round 4: the light passes of config 3 (nlp_g / nlp_f / nlp_grad_f alone, what a line search calls): kernel stats + PMC traffic
-# of mpx_node_fg_0_30 / mpx_node_fgj_0_30, and the MPX_BPB sweep.        -> gpurun_out/r4_c3_fg/
+# of the dominant kernel and the MPX_BPB sweep.   usage: tools/r4_c3_light.sh <tag> <kernel prefix>   -> gpurun_out/r4_c3_fg/<tag>_*
 set -u
 cd "$(dirname "$0")/.."
+tag=${1:-after}; kern=${2:-mpx_light}
 for o in g f grad_f; do
-  bash tools/profile_workload.sh r4_c3_fg/$o config3-fgj mpx_node_fg --oracles $o
+  bash tools/profile_workload.sh r4_c3_fg/${tag}_$o config3-fgj $kern --oracles $o
 done
-CASE=1 ONLY=f,g,grad_f,f+g python tools/r3_single_oracle_bpb.py > gpurun_out/r4_c3_fg/bpb_sweep.txt 2>&1
-tail -5 gpurun_out/r4_c3_fg/bpb_sweep.txt
+CASE=1 ONLY=f,g,grad_f,f+g python tools/r3_single_oracle_bpb.py > gpurun_out/r4_c3_fg/${tag}_bpb_sweep.txt 2>&1
+tail -5 gpurun_out/r4_c3_fg/${tag}_bpb_sweep.txt

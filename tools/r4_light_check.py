@@ -4,7 +4,7 @@ import numpy as np, torch
 import mpopt_amd as M
 from mpopt_amd import mp
 import problems
-for case in (problems.BENCH_CASES[1], (problems.kitchen_sink, 12, [20, 3, 16, 5] * 3, "LGR"), (problems.dae_vdp, 9, 17, "LGL")):
+for case in (problems.BENCH_CASES[1], (problems.kitchen_sink, 12, [20, 3, 20, 5] * 3, "LGR"), (problems.dae_vdp, 9, 17, "LGL")):
     builder, S, P, scheme = case
     mpo = mp.mpopt(builder(mp, M.math), S, P, scheme)
     o = mpo.create_nlp()[0]["oracle"]
@@ -19,6 +19,14 @@ for case in (problems.BENCH_CASES[1], (problems.kitchen_sink, 12, [20, 3, 16, 5]
             res[tag] = (o.eval(["f", "g"], Z, p), o.eval(["g"], Z, p), o.eval(["f", "grad_f"], Z, p), o.eval(["f", "g", "grad_f"], Z, p), o.eval(["f"], Z, p))
         os.environ.pop("MPX_NO_LIGHT", None)
         a, b = res["light"], res["node"]
+        nzp = o.n_z // mpo._ocp.n_phases
+        node = np.ones(o.n_z, bool)
+        for ph in range(mpo._ocp.n_phases):  # the (t0, tf, a) entries of grad_f are sums over all nodes: they round like f
+            node[ph * nzp + (mpo._ocp.nx + mpo._ocp.nu) * o.n_nodes:(ph + 1) * nzp] = False
+        for r_ in (a, b):
+            for d in r_:
+                if "grad_f" in d:
+                    d["grad_f"] = d["grad_f"][..., node]
         print(builder.__name__, "B", B, "g bit-equal", np.array_equal(a[0]["g"], b[0]["g"]), np.array_equal(a[1]["g"], b[1]["g"]), np.array_equal(a[3]["g"], b[3]["g"]),
               "grad_f bit-equal", np.array_equal(a[2]["grad_f"], b[2]["grad_f"]), np.array_equal(a[3]["grad_f"], b[3]["grad_f"]),
               "f rel diff", float(np.abs(a[0]["f"] - b[0]["f"]).max() / np.abs(b[0]["f"]).max()), float(np.abs(a[2]["f"] - b[2]["f"]).max()), float(np.abs(a[4]["f"] - b[4]["f"]).max()),
