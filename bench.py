@@ -577,6 +577,7 @@ def main():
                          "kernel": ("whole loop: mpx_node_hess_0_3 (with the mid-point residuals, MPX_MID_RESID) + mpx_boundary_hess + mpx_equal_area_kernel (wall time of the step)" if loop5
                                     else ("mpx_pts_jac + mpx_gather_kernel (MPX_NO_FUSE)" if os.environ.get("MPX_NO_FUSE") else "mpx_asm_fgj (fused point + gather pass)") if adaptive
                                     else "mpx_node_hessn_* (node-ordered tiles of the mixed-degree grid)" if hess_mode and isinstance(P, (list, tuple)) and len(set(P)) > 1
+                                    else f"mpx_light_{'fgq' if mask & MPX_GRAD else 'fg'}_0_{o.light_plan()[0]} (matrix cores)" if partial_sel and not mask & MPX_JAC and o.light_plan()[0] and not os.environ.get("MPX_NO_LIGHT")
                                     else f"mpx_node_{'hess' if hess_mode else 'fgj' if mask & (MPX_GRAD | MPX_JAC) else 'fg'}_0_*"),
                          "kernel_us": kernel_s * 1e6,
                          "bytes_per_eval": bytes_eval, "evals_per_launch": B,
@@ -586,6 +587,15 @@ def main():
             out["roofline"]["note"] = ("SURVEY 8(d) byte model: it charges all n_g multipliers although the kernel reads only those of rows with second "
                                        "derivatives, and a working set this small is partly Infinity-Cache resident -- a fraction near or above 1 is "
                                        "not an HBM-roofline statement (no PMC traffic for this workload)")
+        # what the numbers are pinned to: never read the CPU ratio as "vs CasADi", nor the parity as "vs CasADi's AD"
+        gold = sorted(fn for fn in os.listdir(os.path.join(ROOT, "tests", "golden")) if fn.endswith(".npz"))
+        out["parity"] = {"goldens": f"{len(gold)} files under tests/golden/ (outputs of the imported reference: tables from CollocationRoots / Collocation, "
+                                    "NLP vectors incl. grad_gamma_x / grad_gamma_p from mpopt.create_nlp())",
+                         "generator": "tests/golden/make_golden.py over tests/golden/casadi_shim.py (sympy stand-in for CasADi, which is absent): CasADi's own AD / "
+                                      "evaluation order is unpinned",
+                         "degree>10 tables": "mpmath (50 digits): the reference's 'numerical' back-end is 4e-9 off at degree 20 and 4e-4 at degree 30",
+                         "tolerance": "1e-10 per entry, one floor per entry class (tests/helpers.py: assert_by_class); indices exact",
+                         "full_size_checker": "oracle/mpopt_oracle.c (hand-derived derivatives) on configs 2-5 incl. nlp_grad"}
         out["outputs"] = ("NlpFunctions.alloc_outputs: the fastest of up to six candidate allocations by measured node-kernel time, one-time set-up "
                           "(candidates, us per pass: %s); value_placement_median / frac_placement_* are plain torch.empty allocations" % placed["node_us_per_pass"]
                           if placed else "plain torch.empty allocations")
@@ -661,7 +671,11 @@ def main():
             out["cpu_baseline"] = {"value": cpu_med, "unit": "evals/s", "cores": 1, "kind": "port", "p10": cpu_p10, "p90": cpu_p90, "repeats": n_rep,
                                    "sample": f"{ns} of the same evaluation points x {inner} passes per repeat, {n_rep} repeats (median; p10 / p90 beside it), "
                                              f"oracle/mpopt_oracle.c (gcc -O2, scalar, values only), {tt:.1f} s",
-                                   "host_cpus": os.cpu_count()}
+                                   "host_cpus": os.cpu_count(),
+                                   "vs_casadi_published": "the port is NOT CasADi: at moon lander 10x6 it takes 2.0 us per f+g+grad_f+jac_g against the 64.5 us CasADi's "
+                                                          "recorded nlp_f + nlp_g + nlp_grad_f + nlp_jac_g sum to (docs/source/notebooks/moon_lander.ipynb:203-210; "
+                                                          "profiles/r3_report.md anchor row), i.e. about 30x faster per evaluation -- the GPU / port ratio "
+                                                          "understates GPU / CasADi by that factor"}
             out["casadi"] = casadi_probe(S, P, Zh[:ns], ph, g[0].cpu().numpy())
     # Secondary measurement on N > 1 lines (RCCL on the path).  It runs AFTER the headline is final and under a
     # watchdog: whatever happens in it -- an exception, a collective that never returns -- rank 0 still prints its ONE line.

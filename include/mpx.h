@@ -243,6 +243,11 @@ int mpx_get_tile_weights(const mpx_ctx* ctx, int64_t* weights);
  * for the unpack pass) and the number of nodes of other tiles inside that span.  All zero on single-degree grids and on grids
  * outside the limits of the scheme.  Arrays of n_tiles entries; host-only contexts answer too (the plan is host arithmetic). */
 int mpx_get_tile_spans(const mpx_ctx* ctx, int32_t* span_first, int32_t* span_len, int32_t* n_foreign);
+/* Decisions of the layout planner that are not errors but worth knowing, one per line ("" when there are none): e.g. a
+ * mixed-degree grid whose row spans exceed the LDS of a compute unit (150 KB per workgroup incl. the kernel's own tiles) or whose
+ * tiles would have to fetch more than 256 nodes of other buckets keeps the staging block + unpack pass for g / grad_f of the heavy
+ * passes.  The string belongs to the context. */
+const char* mpx_get_notes(const mpx_ctx* ctx);
 /* Light passes (evaluations WITHOUT the Jacobian values: f, g, grad_f -- what a line search calls) of grids with exactly one high
  * degree (12 < P <= 31) and otherwise degrees <= 12 run through dedicated kernels (mpx_light_*): the D.X / D.U / C_mid.U contractions
  * of the high degree on the matrix cores (v_mfma_f64_16x16x4_f64), one wavefront per group of up to 16 high-degree segments plus the

@@ -383,14 +383,23 @@ int build_layout(mpx_ctx* c) {
           }
         T.f_count = (int32_t)c->abs_fpos.size() - T.f_first;
         cap = std::max(cap, (int)T.span_len);
-        if (T.f_count > MPX_TILE) c->absorb = false;
+        if (T.f_count > MPX_TILE) {
+          if (c->absorb) c->notes += "mixed-degree grid: a tile of the largest bucket would have to fetch " + std::to_string(T.f_count) + " nodes of other buckets (limit " +
+                                     std::to_string(MPX_TILE) + "): g / grad_f of the heavy passes go through the staging block and the unpack pass instead of row spans\n";
+          c->absorb = false;
+        }
       }
       cap += cap & 1;
-      {  // static LDS of the bucket's node kernel (same arithmetic as build_tables) + the span rows: inside the 64 KB a launch
-         // gets without raising the function's dynamic shared memory limit
+      {  // static LDS of the bucket's node kernel (same arithmetic as build_tables) + the span rows: up to 150 of the 160 KB of a
+         // compute unit (past the 64 KB a launch gets by default load_device raises the kernels' dynamic shared memory limit)
         const int64_t P1 = B.deg + 1, segs = MPX_TILE / B.deg;
         const int64_t lds_static = 8 * ((B.deg > 12 ? P1 * P1 + (int64_t)B.deg * P1 : 0) + 2 * (int64_t)(nx + nu) * segs * P1) + 8 * 2 * 4 * 64;
-        if ((int64_t)cap * nsg * 8 > 32768 || lds_static + (int64_t)cap * nsg * 8 > 65536) c->absorb = false;
+        if (lds_static + (int64_t)cap * nsg * 8 > 150 * 1024) {
+          if (c->absorb) c->notes += "mixed-degree grid: the row spans of the largest bucket need " + std::to_string((lds_static + (int64_t)cap * nsg * 8) / 1024) +
+                                     " KB of LDS per workgroup (limit 150): g / grad_f of the heavy passes go through the staging block and the unpack pass instead\n";
+          c->absorb = false;
+        }
+        B.abs_lds_static = lds_static;
       }
       B.abs_cap = cap, B.abs_slots = nsg;
     }
@@ -671,6 +680,18 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     snprintf(name, sizeof name, "mpx_boundary_%s", modes[m]);
     hipError_t e = hipModuleGetFunction(&c->fn_bound[m], c->module, name);
     if (e != hipSuccess) return fail(c, MPX_ERR_INVALID, "code object lacks kernel %s", name);
+  }
+  // row spans of more than the default 64 KB of LDS per workgroup: raise the dynamic shared memory limit of the absorbing kernels
+  for (auto& B : c->buckets) {
+    const int64_t dyn = (int64_t)B.abs_cap * B.abs_slots * 8;
+    if (!c->absorb || B.abs_cap <= 0 || B.abs_lds_static + dyn <= 65536) continue;
+    for (int m = 0; m < 2; ++m)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(B.fn[m]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+        (void)hipGetLastError();
+        c->notes += "mixed-degree grid: the runtime refused " + std::to_string(dyn / 1024) + " KB of dynamic LDS for the row spans: unpack pass instead\n";
+        c->absorb = false;
+        break;
+      }
   }
   // nlp_grad kernels (code objects generated before they existed lack them: mpx_eval_grad_gamma then says so)
   for (auto& B : c->buckets) {
@@ -1355,6 +1376,8 @@ extern "C" int mpx_get_tile_spans(const mpx_ctx* c, int32_t* first, int32_t* len
   for (size_t t = 0; t < c->tiles.size(); ++t) first[t] = c->tiles[t].span_lo, len[t] = c->tiles[t].span_len, n_foreign[t] = c->tiles[t].f_count;
   return MPX_OK;
 }
+
+extern "C" const char* mpx_get_notes(const mpx_ctx* c) { return c ? c->notes.c_str() : ""; }
 
 extern "C" int mpx_get_light_plan(const mpx_ctx* c, int32_t* degree, int64_t* n_groups, int64_t* max_span_nodes, int64_t* n_low_degree_nodes) {
   if (!c) return MPX_ERR_INVALID;

@@ -44,6 +44,7 @@ struct Bucket {
   int tile_first = 0, tile_count = 0;  // global tile ids
   int abs_cap = 0;                     // > 0: absorbing bucket (MpxNodeArgs::abs_cap), row capacity of its LDS span buffer
   int abs_slots = 0;                   // row slots of that buffer (g rows + grad_f rows per node)
+  int64_t abs_lds_static = 0;          // static LDS of the bucket's node kernel (the span rows come on top as dynamic LDS)
   int32_t *d_node_i = nullptr, *d_node_sk = nullptr;
   hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
   hipFunction_t fn_gradl = nullptr;  // mpx_node_gradl_<phase>_<deg> (nlp_grad)
@@ -66,6 +67,7 @@ struct mpx_ctx {
   int kind = 0;
   mpx_asm_state* assembled = nullptr;
   std::string err;
+  std::string notes;  // decisions worth knowing that are not errors (mpx_get_notes): fallbacks of the layout planner
   // problem
   int n_phases = 0, nx = 0, nu = 0, na = 0, S = 0, scheme = 0, device = 0;
   double tau0 = -1, tau1 = 1;

@@ -441,6 +441,11 @@ class NlpFunctions:
         _lib.check(self._L.mpx_get_tile_spans(self._ctx, *[v.ctypes.data_as(_lib.c_int32_p) for v in a]), self._ctx)
         return tuple(a)
 
+    def notes(self):
+        """Planner decisions worth knowing (mpx_get_notes), a list of lines."""
+        t = self._L.mpx_get_notes(self._ctx)
+        return [ln for ln in (t.decode() if t else "").splitlines() if ln]
+
     def light_plan(self):
         """(degree, n_groups, max_span_nodes, n_low_degree_nodes) of the light-pass plan (mpx_get_light_plan); degree 0: none."""
         d, g, sp, nf = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
