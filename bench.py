@@ -619,14 +619,19 @@ def main():
                 if os.path.exists(p_):
                     return p_, json.load(open(p_))
             return None, None
-        tsrc = {"config2-fgj": (("r3_final/headline", "r2_headline"), 4096), "config3-fgj": (("r3_final/c3_fgj", "r2_c3_spans"), 512),
-                "config3-hess": (("r3_final/c3_hess",), 2048), "config5-hess": (("r2_config5_hess",), 4096), "config2-hess": (("r2_config2_hess",), 4096),
-                "adaptive-fgj": (("r3_final/adaptive", "r3_adaptive2"), 4096)}.get(args.workload)
+        tsrc = {"config2-fgj": (("r4_final/headline", "r3_final/headline", "r2_headline"), 4096), "config3-fgj": (("r4_final/c3_fgj", "r3_final/c3_fgj", "r2_c3_spans"), 512),
+                "config3-hess": (("r4_final/c3_hess", "r3_final/c3_hess"), 2048), "config5-hess": (("r2_config5_hess",), 4096), "config2-hess": (("r2_config2_hess",), 4096),
+                "adaptive-fgj": (("r4_final/adaptive", "r3_final/adaptive", "r3_adaptive2"), 4096),
+                "config5-loop": (("r4_final/config5_loop", "r3_final/config5_loop"), 512)}.get(args.workload)
+        if partial_sel:
+            tsrc = {"config3-fgj": ((f"r4_c3_fg/after_{'_'.join(w for w in ('f', 'g', 'grad_f') if w in sel)}",), 512)}.get(args.workload) if not mask & MPX_JAC else None
         if tsrc and B == tsrc[1]:
             tfp, tr = _first(*tsrc[0])
             wl = tr.get("workload") if tr else None
-            if tr and (not isinstance(wl, dict) or wl == {"segments": S, "degree": P, "batch": B}):
+            if tr and (not isinstance(wl, dict) or wl == {"segments": S, "degree": P, "batch": B}) and (not partial_sel or wl == "config3-fgj"):
                 tb = tr.get("bytes_per_launch", tr.get("bytes_per_pass"))
+                if tb is None and "bytes_per_outer_iteration" in tr:  # the config-5 loop: one step = 5 outer iterations
+                    tb = 5 * tr["bytes_per_outer_iteration"]
                 out["roofline"]["traffic"] = tb
                 out["roofline"]["frac_by_traffic"] = tb / kernel_s / 1e9 / HBM_PEAK_GBS
                 out["roofline"]["traffic_source"] = (os.path.relpath(tfp, ROOT) + " (" + str(tr.get("kernel", "the timed kernels")) +

@@ -281,7 +281,7 @@ def test_numpy_functions_on_traced_symbols():
 def test_mixed_degree_row_span_plan(monkeypatch):
     """Mixed-degree grids: the tiles of the bucket with the most nodes cut the phase's nodes into contiguous spans and store
     the g / grad_f rows of their span themselves (mpx_get_tile_spans); single-degree grids and grids outside the limits of the
-    scheme (a tile would have to fetch more than 256 foreign nodes, or hold more than 32 KB of rows in LDS) keep none."""
+    scheme (a tile would have to fetch more than 256 foreign nodes, or need more than 150 KB of LDS per workgroup) keep none."""
     def spans(builder, S, po, scheme):
         ocp = builder(mp, M.math)
         mpo = mp.mpopt(ocp, S, po, scheme)
@@ -305,9 +305,10 @@ def test_mixed_degree_row_span_plan(monkeypatch):
     # halves of different degree: one tile would fetch > 256 foreign nodes -> the unpack pass stays
     o, lo, ln, nf, N = spans(problems.van_der_pol, 400, [3] * 200 + [6] * 200, "LGL")
     assert not ln.any()
-    # 7 states + 3 controls: the node kernel's own state/control tile leaves no room for the span rows within 64 KB of LDS
+    # 7 states + 3 controls: the node kernel's own state/control tile + the span rows exceed the 64 KB a launch gets by default -- since
+    # round 4 the dynamic LDS limit of the kernels is raised (up to 150 KB per workgroup) instead of falling back to the unpack pass
     o, lo, ln, nf, N = spans(problems.staged_ascent, 30, [3, 4, 3] * 10, "LGR")
-    assert not ln.any()
+    assert ln.any() and o.notes() == []
     monkeypatch.setenv("MPX_NO_ABSORB", "1")
     o, lo, ln, nf, N = spans(problems.van_der_pol, 48, [30 if s % 3 == 1 else 3 for s in range(48)], "CGL")
     assert not ln.any()

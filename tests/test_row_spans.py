@@ -27,12 +27,15 @@ def test_two_halves_grid_falls_back_and_says_so():
 
 
 @pytest.mark.gpu
-def test_row_spans_beyond_64_kb_of_lds():
+@pytest.mark.parametrize("case", ["kitchen_sink", "staged_ascent"])
+def test_row_spans_beyond_64_kb_of_lds(case):
     """Kitchen sink (3 states, 2 controls, path rows, DU rows: 14 row slots per node) on config 3's degree pattern: span rows +
     the degree-30 kernel's own LDS exceed the 64 KB a launch gets by default -- the library raises the kernels' dynamic shared
     memory limit instead of falling back.  Bit-identical to the unpack path."""
-    ocp = problems.kitchen_sink(mp, M.math)
-    S, po = 48, mixed(48)
+    if case == "kitchen_sink":
+        ocp, S, po = problems.kitchen_sink(mp, M.math), 48, mixed(48)
+    else:  # 7 states + 3 controls (examples/Multi-phase launch-vehicle family): the grid tests/test_host.py plans on the host
+        ocp, S, po = problems.staged_ascent(mp, M.math), 30, [3, 4, 3] * 10
     mpo = mp.mpopt(ocp, S, po, "LGR")
     o = mpo.create_nlp()[0]["oracle"]
     assert o.tile_spans()[1].any() and o.notes() == []
