@@ -299,7 +299,28 @@ class ProblemProgram:
                 if 12 < d <= 31:  # light passes of the high-degree buckets on the matrix cores (mpx_kernels.h: light_body)
                     parts.append(f"MPX_INSTANTIATE_LIGHT({ph}, {d})")
         parts.append("MPX_INSTANTIATE_BOUNDARY()")
+        parts += self._resident_source()
         return "\n".join(parts) + "\n"
+
+    def _resident_source(self):
+        """The resident kernel of single evaluations (mpx_kernels.h: resident_loop): one workgroup per tile stays on the device and
+        is fed through mapped host memory.  Generated only for single-degree grids of low degree whose node kernels (first-order
+        and hess_l variant of every phase, inlined into ONE kernel) fit the LDS of a workgroup."""
+        if len(self.degrees) != 1 or self.degrees[0] > 12:
+            return []
+        d = self.degrees[0]
+        slots = (256 // d) * (d + 1)
+        lds = sum(2 * (2 * (p.nx + p.nu) * slots * 8 + 2 * 4 * max(3 + p.na, len(p.hc), 1) * 8) for p in self.phases)
+        if lds > 56 * 1024:
+            return []
+        out = ['extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_resident(const MpxResidentArgs R) {',
+               "  mpxk::resident_loop(R,", "    [&](const MpxNodeArgs& A, int mode, int bx) {"]
+        for ph in range(len(self.phases)):
+            out.append(f"      {'if' if ph == 0 else 'else if'} (A.phase == {ph}) {{ if (mode == MPX_MODE_HESS) mpxk::node_body<{ph}, {d}, MPX_MODE_HESS>(A, bx); "
+                       f"else mpxk::node_body<{ph}, {d}, MPX_MODE_FGJ>(A, bx); }}")
+        out += ["    },", "    [&](const MpxBoundArgs& G, int mode) { if (mode == MPX_MODE_HESS) mpxk::boundary_body<MPX_MODE_HESS>(G, 0); else mpxk::boundary_body<MPX_MODE_FGJ>(G, 0); });",
+                "}"]
+        return out
 
     def key(self, extra=""):
         return hashlib.sha256((self.source() + extra).encode()).hexdigest()[:24]

@@ -70,7 +70,7 @@ struct MpxNodeArgs {
   const double* tk;        // (tau_k - tau0)/(tau1 - tau0), k = 0..P
   const double* Dmid;      // P x (P+1): first derivative of the Lagrange basis at the mid-points (MPX_MID_RESID)
   const double* tkm;       // ((tau_{k-1} + tau_k)/2 - tau0)/(tau1 - tau0), k = 1..P at index k - 1
-  int32_t phase, pad3_;
+  int32_t phase, deg;      // (deg: the bucket's polynomial degree -- the resident kernel dispatches on (phase, deg))
   const double* Wnode;     // composite quadrature weight per node of this phase
   double inv_dtau;         // 1/(tau1 - tau0)
   int64_t z_off;           // offset of the phase's block in z / grad_f
@@ -243,6 +243,43 @@ struct MpxResidArgs {
 };
 
 #define MPX_ACCUM_BIT (1LL << 62)
+
+// ---- resident kernel (single evaluations, the regime an NLP solver drives) ------------------------------------------------
+// One workgroup per tile stays on the device and is fed through a mailbox in page-locked host memory: no kernel launch, no
+// stream synchronisation per evaluation.  Workgroup 0 polls `seq`; a new value is a request: it copies `mode`, `ccs` and `io` to
+// device memory and publishes the number there for the other workgroups; node pass (every workgroup its tile) -> grid barrier ->
+// boundary pass (workgroup 0) -> [grid barrier -> compressed-column permutation of the values, all workgroups] -> grid barrier ->
+// `done = seq`.  The kernel leaves by itself when idle for idle_ticks or older than life_ticks (wall_clock64, 100 MHz): it first
+// clears `alive`, then looks at `seq` once more (the host writes `seq` BEFORE it reads `alive`), and sets `exited` as its last act.
+#define MPX_RES_SLOTS 8      // argument sets the device remembers: an NLP solver repeats a handful of (function, arrays) combinations
+struct MpxResRequest {
+  int32_t mode, ccs;         // MPX_MODE_*; ccs: bit 0 jac_val, bit 1 hess_val leave in compressed-column order
+  MpxIO io;                  // B = 1; with ccs the value pointer of io is the native-order scratch and ccs_out the caller's array
+  double* ccs_out;
+};
+struct MpxMailbox {
+  // host -> device, ONE word polled over PCIe: (request number << 8) | (argument slot << 1) | (1: the slot's content is new, read it
+  // from `slots`).  In the steady state of a solve a request costs the device nothing but this read.
+  unsigned long long seq;
+  unsigned long long done;   // device -> host: request number of the last completed request
+  unsigned int alive, exited, stop, pad_;
+  MpxResRequest slots[MPX_RES_SLOTS];
+};
+struct MpxResidentArgs {
+  MpxMailbox* box;                  // device alias of the mailbox
+  const MpxNodeArgs* buckets;       // static part of every bucket's arguments (io comes with the request)
+  const int32_t* tile_bucket;       // [n_tiles]
+  const MpxBoundArgs* bound;
+  MpxResRequest* dev_slots;         // device copies of the argument slots
+  unsigned long long* dev_seq;      // the request word, republished in device memory for the workgroups other than 0
+  unsigned long long* sync_count;   // grid barrier: arrivals since the kernel started
+  const int64_t* perm_j;            // compressed-column permutations (NULL until first needed)
+  const int64_t* perm_h;
+  int64_t nnz_j, nnz_h;
+  unsigned long long start_seq;     // the last request served before this launch
+  long long idle_ticks, life_ticks;
+  int32_t n_tiles, pad_;
+};
 
 // Segment sharding: one contiguous run of values a rank owns.  kind 0: jac_val / hess_val of the caller, 1: packed g / grad_f
 // staging, 2: per-tile partial sums.  The run of evaluation point b starts at  src_off + b * stride  in its array and at

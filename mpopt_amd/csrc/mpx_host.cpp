@@ -664,6 +664,9 @@ int build_layout(mpx_ctx* c) {
   return MPX_OK;
 }
 
+MpxNodeArgs node_args_static(const mpx_ctx* c, const Bucket& B, bool absorber);
+MpxBoundArgs bound_args_static(const mpx_ctx* c);
+
 int load_device(mpx_ctx* c, const mpx_problem* prob) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipModuleLoadData(&c->module, prob->code_object));
@@ -744,6 +747,34 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   c->has_device = true;
+  // resident kernel of single evaluations (generated for single-degree grids of low degree, codegen.py): one workgroup per tile, all
+  // of them on the device at once (two fit a compute unit)
+  {
+    mpx_ctx::Resident& R = c->res;
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    if (hipModuleGetFunction(&R.fn, c->module, "mpx_resident") != hipSuccess) R.fn = nullptr, (void)hipGetLastError();
+    if (R.fn && !c->g_packed && (int64_t)c->tiles.size() <= n_cu) {
+      std::vector<MpxNodeArgs> ba;
+      std::vector<int32_t> tb(c->tiles.size(), 0);
+      for (size_t k = 0; k < c->buckets.size(); ++k) {
+        ba.push_back(node_args_static(c, c->buckets[k], false));
+        for (int t = c->buckets[k].tile_first; t < c->buckets[k].tile_first + c->buckets[k].tile_count; ++t) tb[t] = (int32_t)k;
+      }
+      std::vector<MpxBoundArgs> bo(1, bound_args_static(c));
+      std::vector<MpxResRequest> rq(MPX_RES_SLOTS);
+      std::vector<unsigned long long> sc(1, 0);
+      memset(rq.data(), 0, sizeof(MpxResRequest) * MPX_RES_SLOTS);
+      if ((rc = upload(c, &R.d_buckets, ba)) || (rc = upload(c, &R.d_tile_bucket, tb)) || (rc = upload(c, &R.d_bound, bo)) || (rc = upload(c, &R.d_slots, rq)) ||
+          (rc = upload(c, &R.d_sync, sc)) || (rc = upload(c, &R.d_seq, sc)))
+        return rc;
+      HIPCHK(c, hipHostMalloc((void**)&R.box, sizeof(MpxMailbox), hipHostMallocMapped));
+      HIPCHK(c, hipHostGetDevicePointer((void**)&R.box_dev, R.box, 0));
+      memset(R.box, 0, sizeof(MpxMailbox));
+      HIPCHK(c, hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+      R.ok = true;
+    }
+  }
   return MPX_OK;
 }
 
@@ -969,6 +1000,87 @@ GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig
   return {T->best, nullptr, nullptr};
 }
 
+// Arguments of a bucket's node kernels that do not depend on the call (io, the tile sub-range and the absorbing lists come on top).
+MpxNodeArgs node_args_static(const mpx_ctx* c, const Bucket& B, bool absorber) {
+  const PhaseStruct& P = c->ph[B.phase];
+  const DegTable& t = c->degs[B.dt];
+  MpxNodeArgs A{};
+  A.tiles = c->d_tiles;
+  A.node_i = B.d_node_i;
+  A.node_sk = B.d_node_sk;
+  A.Dmat = t.d_D;
+  A.Cmid = t.d_Cmid;
+  A.tk = t.d_tk;
+  A.Dmid = t.d_Dmid;
+  A.tkm = t.d_tkm;
+  A.phase = B.phase;
+  A.deg = B.deg;
+  A.Wnode = c->d_Wnode;
+  A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
+  A.z_off = P.z_off;
+  A.g_off_F = P.g_off_F;
+  A.g_off_C = P.g_off_C;
+  A.g_off_DU = P.g_off_DU;
+  A.g_off_mU = P.g_off_mU;
+  A.N = (int32_t)c->N;
+  A.seg_off = B.phase * c->S;
+  A.tile_first = B.tile_first;
+  A.tile_count = B.tile_count;
+  // regular bucket (every segment of the phase has this degree, tiles = [node 0][full ...][last]): descriptors by arithmetic
+  {
+    const int nt = B.tile_count;
+    bool reg = (int64_t)B.node_i.size() == c->N && nt >= 2 && c->tiles[B.tile_first].node0 && !absorber;
+    const int lanes = reg ? c->tiles[B.tile_first + 1].n : 0;
+    for (int t = 1; reg && t < nt; ++t) {
+      const MpxTile& T = c->tiles[B.tile_first + t];
+      const MpxTile& F = c->tiles[B.tile_first + 1];
+      reg = T.m0 == 1 + (t - 1) * lanes && !T.node0 && T.n == T.n_own && (t == nt - 1 ? T.n <= lanes : T.n == lanes) && lanes % B.deg == 0;
+      if (reg && t < nt - 1 && t > 1)  // full tiles: equal blocks at equal strides
+        reg = T.jac_base - F.jac_base == (int64_t)(t - 1) * c->tile_jac_size[B.tile_first + 1] &&
+              T.hess_base - F.hess_base == (int64_t)(t - 1) * c->tile_hess_size[B.tile_first + 1] &&
+              T.g_base - F.g_base == (int64_t)(t - 1) * c->tile_g_size[B.tile_first + 1];
+    }
+    A.regular = reg ? 1 : 0;
+    if (reg) {
+      const int idx[3] = {B.tile_first, B.tile_first + 1, B.tile_first + nt - 1};
+      for (int w = 0; w < 3; ++w) {
+        A.reg_jac_base[w] = c->tiles[idx[w]].jac_base, A.reg_hess_base[w] = c->tiles[idx[w]].hess_base, A.reg_g_base[w] = c->tiles[idx[w]].g_base;
+      }
+      A.reg_first_tile = B.tile_first, A.reg_last = nt - 1, A.reg_lanes = lanes, A.reg_last_lanes = c->tiles[idx[2]].n;
+      A.reg_jac_size = c->tile_jac_size[B.tile_first + 1], A.reg_hess_size = c->tile_hess_size[B.tile_first + 1], A.reg_g_size = c->tile_g_size[B.tile_first + 1];
+    }
+  }
+  return A;
+}
+
+// ... and of the boundary kernels
+MpxBoundArgs bound_args_static(const mpx_ctx* c) {
+  MpxBoundArgs G{};
+  for (int p = 0; p < c->n_phases; ++p) {
+    const PhaseStruct& P = c->ph[p];
+    G.ph[p].z_off = P.z_off;
+    G.ph[p].N = (int32_t)c->N;
+    G.ph[p].tile_first = P.tile_first;
+    G.ph[p].tile_count = P.tile_count;
+    G.ph[p].tile_count_h = c->hess_by_node ? c->ph_htile_count[p] : P.tile_count;
+    G.ph[p].g_off_TC = P.g_off_TC;
+    G.ph[p].jac_TC = P.jac_TC;
+    G.mg_off[p] = c->mg_off[p];
+    G.hc_off[p] = c->hc_off[p];
+    G.th_off[p] = c->th_off[p];
+  }
+  G.mg_dst = c->d_mg_dst;
+  G.hc_dst = c->d_hc_dst;
+  G.th_dst = c->d_th_dst;
+  G.lin_ptr = c->d_lin_ptr;
+  G.lin_idx = c->d_lin_idx;
+  G.lin_coef = c->d_lin_coef;
+  G.lin_row = c->d_lin_row;
+  G.lin_jac = c->lin_jac;
+  G.n_lin = (int32_t)c->lin_row.size();
+  return G;
+}
+
 int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool owner = false) {
   MpxIO io = io0;
   // (the array that identifies the pass for the geometry measurement: its largest output)
@@ -1090,52 +1202,10 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
     if (hi <= lo || !nodes) continue;
     const PhaseStruct& P = c->ph[B.phase];
     const DegTable& t = c->degs[B.dt];
-    MpxNodeArgs A{};
+    MpxNodeArgs A = node_args_static(c, B, absorber);
     A.io = io;
-    A.tiles = c->d_tiles;
-    A.node_i = B.d_node_i;
-    A.node_sk = B.d_node_sk;
-    A.Dmat = t.d_D;
-    A.Cmid = t.d_Cmid;
-    A.tk = t.d_tk;
-    A.Dmid = t.d_Dmid;
-    A.tkm = t.d_tkm;
-    A.phase = B.phase;
-    A.Wnode = c->d_Wnode;
-    A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
-    A.z_off = P.z_off;
-    A.g_off_F = P.g_off_F;
-    A.g_off_C = P.g_off_C;
-    A.g_off_DU = P.g_off_DU;
-    A.g_off_mU = P.g_off_mU;
-    A.N = (int32_t)c->N;
-    A.seg_off = B.phase * c->S;
     A.tile_first = (int32_t)lo;
     A.tile_count = (int32_t)(hi - lo);
-    // regular bucket (every segment of the phase has this degree, tiles = [node 0][full ...][last]): descriptors by arithmetic
-    {
-      const int nt = B.tile_count;
-      bool reg = (int64_t)B.node_i.size() == c->N && nt >= 2 && c->tiles[B.tile_first].node0 && !absorber;
-      const int lanes = reg ? c->tiles[B.tile_first + 1].n : 0;
-      for (int t = 1; reg && t < nt; ++t) {
-        const MpxTile& T = c->tiles[B.tile_first + t];
-        const MpxTile& F = c->tiles[B.tile_first + 1];
-        reg = T.m0 == 1 + (t - 1) * lanes && !T.node0 && T.n == T.n_own && (t == nt - 1 ? T.n <= lanes : T.n == lanes) && lanes % B.deg == 0;
-        if (reg && t < nt - 1 && t > 1)  // full tiles: equal blocks at equal strides
-          reg = T.jac_base - F.jac_base == (int64_t)(t - 1) * c->tile_jac_size[B.tile_first + 1] &&
-                T.hess_base - F.hess_base == (int64_t)(t - 1) * c->tile_hess_size[B.tile_first + 1] &&
-                T.g_base - F.g_base == (int64_t)(t - 1) * c->tile_g_size[B.tile_first + 1];
-      }
-      A.regular = reg ? 1 : 0;
-      if (reg) {
-        const int idx[3] = {B.tile_first, B.tile_first + 1, B.tile_first + nt - 1};
-        for (int w = 0; w < 3; ++w) {
-          A.reg_jac_base[w] = c->tiles[idx[w]].jac_base, A.reg_hess_base[w] = c->tiles[idx[w]].hess_base, A.reg_g_base[w] = c->tiles[idx[w]].g_base;
-        }
-        A.reg_first_tile = B.tile_first, A.reg_last = nt - 1, A.reg_lanes = lanes, A.reg_last_lanes = c->tiles[idx[2]].n;
-        A.reg_jac_size = c->tile_jac_size[B.tile_first + 1], A.reg_hess_size = c->tile_hess_size[B.tile_first + 1], A.reg_g_size = c->tile_g_size[B.tile_first + 1];
-      }
-    }
     unsigned lds = 0;
     if (absorber && pass == 1) {
       A.abs_fpos = c->d_abs_fpos, A.abs_fstage = c->d_abs_fstage, A.abs_fn = c->d_abs_fn, A.abs_cap = B.abs_cap;
@@ -1161,30 +1231,8 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
     if (rc) return rc;
   }
   if (shard ? nodes : !c->run_boundary) return MPX_OK;  // sharded: node pass and boundary pass are separate calls
-  MpxBoundArgs G{};
+  MpxBoundArgs G = bound_args_static(c);
   G.io = io;
-  for (int p = 0; p < c->n_phases; ++p) {
-    const PhaseStruct& P = c->ph[p];
-    G.ph[p].z_off = P.z_off;
-    G.ph[p].N = (int32_t)c->N;
-    G.ph[p].tile_first = P.tile_first;
-    G.ph[p].tile_count = P.tile_count;
-    G.ph[p].tile_count_h = c->hess_by_node ? c->ph_htile_count[p] : P.tile_count;
-    G.ph[p].g_off_TC = P.g_off_TC;
-    G.ph[p].jac_TC = P.jac_TC;
-    G.mg_off[p] = c->mg_off[p];
-    G.hc_off[p] = c->hc_off[p];
-    G.th_off[p] = c->th_off[p];
-  }
-  G.mg_dst = c->d_mg_dst;
-  G.hc_dst = c->d_hc_dst;
-  G.th_dst = c->d_th_dst;
-  G.lin_ptr = c->d_lin_ptr;
-  G.lin_idx = c->d_lin_idx;
-  G.lin_coef = c->d_lin_coef;
-  G.lin_row = c->d_lin_row;
-  G.lin_jac = c->lin_jac;
-  G.n_lin = (int32_t)c->lin_row.size();
   return launch(c, c->fn_bound[mode], dim3((unsigned)io.B, 1, 1), dim3(256, 1, 1), &G, sizeof G);
 }
 
@@ -1243,6 +1291,13 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
   if (c->has_device || c->module) {
     (void)hipSetDevice(c->device);
     mpx_asm_release(c);
+    if (c->res.box) {  // the resident kernel leaves when asked (or by itself: idle / lifetime limits)
+      __atomic_store_n(&c->res.box->stop, 1u, __ATOMIC_SEQ_CST);
+      if (c->res.stream) (void)hipStreamSynchronize(c->res.stream), (void)hipStreamDestroy(c->res.stream);
+      (void)hipHostFree(c->res.box);
+      for (void* q : {(void*)c->res.d_buckets, (void*)c->res.d_tile_bucket, (void*)c->res.d_bound, (void*)c->res.d_slots, (void*)c->res.d_seq, (void*)c->res.d_sync})
+        if (q) (void)hipFree(q);
+    }
     auto fr = [](void* p) {
       if (p) (void)hipFree(p);
     };
@@ -2346,27 +2401,10 @@ static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const
   return MPX_OK;
 }
 
-static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
-                       const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix) {
-  if (!c) return MPX_ERR_INVALID;
-  if (!c->has_device)
-    return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
-  if (batch < 1 || batch > (1 << 30) || !z || (!p && c->n_p > 0)) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
-  if ((mask & MPX_HESS) && (!lam_g || !sigma || !hess_val)) return fail(c, MPX_ERR_INVALID, "mpx_eval: HESS needs lam_g, sigma, hess_val");
-  if ((mask & MPX_F) && !f) return fail(c, MPX_ERR_INVALID, "mpx_eval: f is NULL");
-  if ((mask & MPX_G) && !g) return fail(c, MPX_ERR_INVALID, "mpx_eval: g is NULL");
-  if ((mask & MPX_GRAD) && !grad_f) return fail(c, MPX_ERR_INVALID, "mpx_eval: grad_f is NULL");
-  if ((mask & MPX_JAC) && !jac_val) return fail(c, MPX_ERR_INVALID, "mpx_eval: jac_val is NULL");
-  HIPCHK(c, hipSetDevice(c->device));
-  if (c->kind == 1) return mpx_asm_eval_device(c, mask, batch, z, lam_g, sigma, f, g, grad_f, jac_val, hess_val);
-  const int64_t n_w = p_per_point ? batch : 1;
-  int rc;
-  if ((rc = reserve_wcum(c, (size_t)(n_w * c->n_p)))) return rc;
-  if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
-  // MPX_WIDTHS_UNCHANGED (or the host path's "same p"): only if the buffer really holds the prefix sums of THIS p for every phase
-  if (skip_prefix && !(c->wcum_p == p && c->wcum_batch == n_w && c->wcum_ppp == (p_per_point ? 1 : 0) && c->wcum_phases == all_phases(c))) skip_prefix = false;
-  if (!skip_prefix && (rc = launch_prefix(c, p, n_w, p_per_point))) return rc;
-  MpxIO io{};
+// The batched I/O view of one evaluation call (what every kernel of the call sees).
+static int make_io(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g, const double* sigma,
+                   double* f, double* g, double* grad_f, double* jac_val, double* hess_val, MpxIO& io) {
+  io = MpxIO{};
   io.z = z;
   io.z_stride = c->n_z;
   io.w = p;
@@ -2398,6 +2436,31 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
   io.n_tiles_total = (int32_t)c->tiles.size();
   io.nred = c->nred;
   io.B = (int32_t)batch;
+  return MPX_OK;
+}
+
+static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
+                       const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix) {
+  if (!c) return MPX_ERR_INVALID;
+  if (!c->has_device)
+    return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
+  if (batch < 1 || batch > (1 << 30) || !z || (!p && c->n_p > 0)) return fail(c, MPX_ERR_INVALID, "mpx_eval: batch/z/p invalid");
+  if ((mask & MPX_HESS) && (!lam_g || !sigma || !hess_val)) return fail(c, MPX_ERR_INVALID, "mpx_eval: HESS needs lam_g, sigma, hess_val");
+  if ((mask & MPX_F) && !f) return fail(c, MPX_ERR_INVALID, "mpx_eval: f is NULL");
+  if ((mask & MPX_G) && !g) return fail(c, MPX_ERR_INVALID, "mpx_eval: g is NULL");
+  if ((mask & MPX_GRAD) && !grad_f) return fail(c, MPX_ERR_INVALID, "mpx_eval: grad_f is NULL");
+  if ((mask & MPX_JAC) && !jac_val) return fail(c, MPX_ERR_INVALID, "mpx_eval: jac_val is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->kind == 1) return mpx_asm_eval_device(c, mask, batch, z, lam_g, sigma, f, g, grad_f, jac_val, hess_val);
+  const int64_t n_w = p_per_point ? batch : 1;
+  int rc;
+  if ((rc = reserve_wcum(c, (size_t)(n_w * c->n_p)))) return rc;
+  if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
+  // MPX_WIDTHS_UNCHANGED (or the host path's "same p"): only if the buffer really holds the prefix sums of THIS p for every phase
+  if (skip_prefix && !(c->wcum_p == p && c->wcum_batch == n_w && c->wcum_ppp == (p_per_point ? 1 : 0) && c->wcum_phases == all_phases(c))) skip_prefix = false;
+  if (!skip_prefix && (rc = launch_prefix(c, p, n_w, p_per_point))) return rc;
+  MpxIO io{};
+  if ((rc = make_io(c, mask, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val, io))) return rc;
   const bool nodes = !(mask & MPX_BOUNDARY_ONLY), owner = (mask & MPX_OWNER_RESIDENT) != 0;
   if (!nodes && !c->run_boundary && c->shard_world <= 1) return fail(c, MPX_ERR_INVALID, "MPX_BOUNDARY_ONLY with the boundary pass disabled");
   if (mask & (MPX_GRAD | MPX_JAC)) {
@@ -2430,6 +2493,125 @@ static int wait_flag(mpx_ctx* c) {
       break;
     }
   }
+  return MPX_OK;
+}
+
+// ---- resident kernel: launch, request, completion (mpx_kernels.h: resident_loop) ---------------------------------------------------
+static int res_launch(mpx_ctx* c) {
+  mpx_ctx::Resident& R = c->res;
+  HIPCHK(c, hipStreamSynchronize(R.stream));  // (an earlier instance has left)
+  int rc;
+  if ((rc = upload_ccs_perm(c, MPX_JAC, &c->d_perm_j)) || (rc = upload_ccs_perm(c, MPX_HESS, &c->d_perm_h))) return rc;
+  const unsigned long long zero = 0;
+  HIPCHK(c, hipMemcpy(R.d_seq, &R.word, sizeof R.word, hipMemcpyHostToDevice));  // nothing pending for the workgroups that poll the device copy
+  HIPCHK(c, hipMemcpy(R.d_sync, &zero, sizeof zero, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(R.d_slots, R.slot, sizeof R.slot, hipMemcpyHostToDevice));  // (the slots the host believes the device to hold)
+  R.box->seq = R.word, R.box->done = R.seq, R.box->exited = 0, R.box->stop = 0;
+  __atomic_store_n(&R.box->alive, 1u, __ATOMIC_SEQ_CST);
+  static const double idle_ms = getenv("MPX_RESIDENT_IDLE_MS") ? atof(getenv("MPX_RESIDENT_IDLE_MS")) : 20.0;
+  MpxResidentArgs A{};
+  A.box = R.box_dev, A.buckets = R.d_buckets, A.tile_bucket = R.d_tile_bucket, A.bound = R.d_bound, A.dev_slots = R.d_slots, A.dev_seq = R.d_seq, A.sync_count = R.d_sync;
+  A.perm_j = c->d_perm_j, A.perm_h = c->d_perm_h, A.nnz_j = c->nnz_j, A.nnz_h = c->nnz_h;
+  A.start_seq = R.word, A.idle_ticks = (long long)(idle_ms * 1e5), A.life_ticks = 200000000LL /* 2 s of the 100 MHz clock */, A.n_tiles = (int32_t)c->tiles.size();
+  size_t size = sizeof A;
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  HIPCHK(c, hipModuleLaunchKernel(R.fn, (unsigned)c->tiles.size(), 1, 1, MPX_TILE, 1, 1, 0, R.stream, nullptr, cfg));
+  R.launched = true;
+  ++R.n_launches;
+  return MPX_OK;
+}
+
+// One pass (mode) of a single evaluation through the resident kernel; blocks until the results are in the caller's arrays.
+static int res_request(mpx_ctx* c, int mode, int ccs, const MpxIO& io, double* ccs_out) {
+  mpx_ctx::Resident& R = c->res;
+  int rc;
+  if (!R.launched && (rc = res_launch(c))) return rc;
+  // the argument slot: one the device already holds (an NLP solver passes the same work-vector slices to the same function on every
+  // call), else the next one round robin, flagged as new
+  MpxResRequest rq;
+  memset(&rq, 0, sizeof rq);
+  rq.mode = mode, rq.ccs = ccs, rq.io = io, rq.ccs_out = ccs_out;
+  int sl = -1;
+  for (int k = 0; k < R.n_slots && sl < 0; ++k)
+    if (memcmp(&R.slot[k], &rq, sizeof rq) == 0) sl = k;
+  unsigned long long fresh = 0;
+  if (sl < 0) {
+    sl = R.next_slot, R.next_slot = (R.next_slot + 1) % MPX_RES_SLOTS, R.n_slots = std::max(R.n_slots, sl + 1);
+    R.slot[sl] = rq, R.box->slots[sl] = rq, fresh = 1;
+  }
+  const unsigned long long q = ++R.seq, word = (q << 8) | ((unsigned long long)sl << 1) | fresh;
+  R.word = word;
+  __atomic_store_n(&R.box->seq, word, __ATOMIC_SEQ_CST);
+  ++R.n_requests;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spins = 1;; ++spins) {
+    if (__atomic_load_n(&R.box->done, __ATOMIC_ACQUIRE) == q) {
+      static const bool dbg = getenv("MPX_RES_DEBUG") != nullptr;  // with a code object built with -DMPX_RES_STAMPS
+      if (dbg) {
+        static double acc[6] = {0, 0, 0, 0, 0, 0};
+        static int n = 0;
+        const long long* st = reinterpret_cast<const long long*>(&R.box->slots[MPX_RES_SLOTS - 1]);
+        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        for (int k = 0; k < 5; ++k) acc[k] += (st[k + 1] - st[k]) / 100.0;
+        acc[5] += host_us;
+        if (++n == 500) {
+          fprintf(stderr, "resident request (mode %d, us): args %.2f  node pass %.2f  barrier %.2f  boundary %.2f  last barrier (system fence) %.2f | device total %.2f, host round trip %.2f\n", mode,
+                  acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, (acc[0] + acc[1] + acc[2] + acc[3] + acc[4]) / n, acc[5] / n);
+          for (double& a : acc) a = 0;
+          n = 0;
+        }
+      }
+      return MPX_OK;
+    }
+    if ((spins & 0x3ff) == 0) {
+      if (!__atomic_load_n(&R.box->alive, __ATOMIC_SEQ_CST)) {
+        // the kernel is leaving (idle / lifetime limit): it looks at seq once more after clearing `alive` -- either it serves this
+        // request after all, or it sets `exited` and a new instance takes it
+        while (__atomic_load_n(&R.box->done, __ATOMIC_ACQUIRE) != q && !__atomic_load_n(&R.box->exited, __ATOMIC_SEQ_CST) &&
+               std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) {}
+        if (__atomic_load_n(&R.box->done, __ATOMIC_ACQUIRE) == q) return MPX_OK;
+        if (!__atomic_load_n(&R.box->exited, __ATOMIC_SEQ_CST)) break;
+        R.word = 0, --R.seq;  // (the new instance starts from "nothing seen", holding every slot the host knows, this request's included)
+        rc = res_launch(c);
+        R.seq = q, R.word = word;
+        if (rc) return rc;
+        __atomic_store_n(&R.box->seq, word, __ATOMIC_SEQ_CST);
+      } else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+        break;
+      }
+    }
+  }
+  __atomic_store_n(&R.box->stop, 1u, __ATOMIC_SEQ_CST);
+  R.ok = false;  // never again on this context
+  return fail(c, MPX_ERR_HIP, "resident kernel: no completion of request %llu within 5 s", q);
+}
+
+// A single evaluation through the resident kernel (zero-copy arrays already resolved to their device aliases).
+static int res_eval(mpx_ctx* c, int mask, const double* z, const double* p, const double* lam_g, const double* sigma, double* f, double* g, double* grad_f,
+                    double* jac_val, double* hess_val, bool same_p) {
+  int rc;
+  if ((rc = reserve_wcum(c, (size_t)c->n_p)) || (rc = reserve(c, c->partial, (size_t)((int64_t)c->tiles.size() * c->nred)))) return rc;
+  if (!(same_p && c->wcum_p == p && c->wcum_batch == 1 && c->wcum_ppp == 0 && c->wcum_phases == all_phases(c))) {
+    if ((rc = launch_prefix(c, p, 1, 0))) return rc;  // (the widths changed: rare -- an NLP solver keeps p for a whole solve)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  const bool ccs = (mask & MPX_CCS_ORDER) != 0;
+  double *tj = jac_val, *th = hess_val;
+  if (ccs && (mask & MPX_JAC) && c->nnz_j) {
+    if ((rc = reserve(c, c->ccs_j, (size_t)c->nnz_j))) return rc;
+    tj = c->ccs_j.p;
+  }
+  if (ccs && (mask & MPX_HESS) && c->nnz_h) {
+    if ((rc = reserve(c, c->ccs_h, (size_t)c->nnz_h))) return rc;
+    th = c->ccs_h.p;
+  }
+  MpxIO io{};
+  if ((rc = make_io(c, mask & ~MPX_CCS_ORDER, 1, z, p, 0, lam_g, sigma, f, g, grad_f, tj, th, io))) return rc;
+  io.b_per_block = 1;
+  if (mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC))
+    if ((rc = res_request(c, MPX_MODE_FGJ, tj != jac_val ? 1 : 0, io, jac_val))) return rc;
+  if (mask & MPX_HESS)
+    if ((rc = res_request(c, MPX_MODE_HESS, th != hess_val ? 2 : 0, io, hess_val))) return rc;
   return MPX_OK;
 }
 
@@ -2499,6 +2681,20 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
       static int n_acc = 0;
       auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
       const double t1 = lat_dbg ? now() : 0;
+      // single evaluations through the resident kernel (no launch, no stream synchronisation) -- OPT-IN (MPX_RESIDENT=1): measured on
+      // MI355X it is not faster than the launched kernels (moon lander 20x3: 43.5 against 44.1 us per IPOPT iteration, 1000x5: 127
+      // against 101 us; profiles/r4_resident): what the device saves in launches it spends polling and fencing over PCIe
+      const bool res_on = getenv("MPX_RESIDENT") != nullptr;  // (read per call: tests switch it inside one process)
+      const bool resident = res_on && c->res.ok && B == 1 && c->kind == 0 && !(mask & ~(MPX_F | MPX_G | MPX_GRAD | MPX_JAC | MPX_HESS | MPX_CCS_ORDER)) &&
+                            c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_RESIDENT");
+      if (resident) {
+        rc = res_eval(c, mask, (const double*)zd, c->st_p.p, (const double*)ld, c->h_scratch_dev + B, c->h_scratch_dev, (double*)gd, (double*)qd, (double*)jd,
+                      (double*)hd, same_p);
+        c->wcum_valid = rc == MPX_OK;
+        if (rc) return rc;
+        if (mask & MPX_F) memcpy(f, c->h_scratch, B * 8);
+        return MPX_OK;
+      }
       rc = eval_core(c, mask, batch, (const double*)zd, c->st_p.p, p_per_point, (const double*)ld, c->h_scratch_dev + B, c->h_scratch_dev, (double*)gd,
                      (double*)qd, (double*)jd, (double*)hd, same_p);
       if (rc) {

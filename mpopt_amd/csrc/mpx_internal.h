@@ -190,6 +190,22 @@ struct mpx_ctx {
   int64_t wcum_batch = 0;
   int wcum_ppp = 0;
   uint32_t wcum_phases = 0;
+  // resident kernel of single evaluations (mpx_kernels.h: resident_loop; MpxMailbox / MpxResidentArgs in mpx_device.h)
+  struct Resident {
+    hipFunction_t fn = nullptr;
+    hipStream_t stream = nullptr;
+    MpxMailbox *box = nullptr, *box_dev = nullptr;  // page-locked, GPU-visible
+    MpxNodeArgs* d_buckets = nullptr;
+    int32_t* d_tile_bucket = nullptr;
+    MpxBoundArgs* d_bound = nullptr;
+    MpxResRequest* d_slots = nullptr;
+    unsigned long long *d_seq = nullptr, *d_sync = nullptr;
+    unsigned long long seq = 0, word = 0;  // number of the last request; the word it was sent as
+    MpxResRequest slot[MPX_RES_SLOTS];     // host copies of the argument slots (what the device holds)
+    int n_slots = 0, next_slot = 0;
+    bool ok = false, launched = false;
+    long long n_launches = 0, n_requests = 0;
+  } res;
   // launch-geometry selection for large batches (run_mode): evaluation points per workgroup, measured once per output placement
   struct GeomTune {
     const void* key = nullptr;  // dominant output array of the pass

@@ -176,7 +176,7 @@ __device__ __forceinline__ void stream_regs(SlotStream<VEC>& S, F reg_val) {  //
 }
 
 template <int PH, int P, int MODE>
-__device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
+__device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx = -1) {  // res_bx >= 0: called by the resident kernel for tile res_bx of the bucket
   using G = mpxgen::Phase<PH>;
   constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
   constexpr int P1 = P + 1;
@@ -199,12 +199,12 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A) {
   // every XCD at a different phase of its range: +-0.
   // (MPX_MAP_NATURAL restores blockIdx.x = tile, blockIdx.y = chunk for A/B runs.)
 #if defined(MPX_MAP_NATURAL)
-  const unsigned bx_ = blockIdx.x, by_ = blockIdx.y;
+  const unsigned bx_ = res_bx >= 0 ? (unsigned)res_bx : blockIdx.x, by_ = res_bx >= 0 ? 0u : blockIdx.y;
 #else
   const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x, tot_ = gridDim.x * gridDim.y;
   const unsigned xcd_ = lin_ % 8, q_ = tot_ / 8, r_ = tot_ % 8;  // XCD j owns q_ + (j < r_) items
   const unsigned item_ = xcd_ * q_ + (xcd_ < r_ ? xcd_ : r_) + lin_ / 8;  // bijection [0, tot) -> [0, tot)
-  const unsigned bx_ = item_ % gridDim.x, by_ = item_ / gridDim.x;
+  const unsigned bx_ = res_bx >= 0 ? (unsigned)res_bx : item_ % gridDim.x, by_ = res_bx >= 0 ? 0u : item_ / gridDim.x;
 #endif
 #ifdef MPX_NO_REGULAR
   const bool regular = false;
@@ -1352,9 +1352,9 @@ struct PhaseLoop<-1, MODE> {
 };
 
 template <int MODE>
-__device__ __forceinline__ void boundary_body(const MpxBoundArgs& A) {
+__device__ __forceinline__ void boundary_body(const MpxBoundArgs& A, const int res_b = -1) {  // res_b >= 0: called by the resident kernel
   __shared__ double red[MAXRED];
-  const int b = blockIdx.x, l = threadIdx.x;
+  const int b = res_b >= 0 ? res_b : (int)blockIdx.x, l = threadIdx.x;
   const MpxIO& io = A.io;
   double facc = 0;
   PhaseLoop<MPX_NPH - 1, MODE>::run(A, b, l, red, facc);
@@ -1628,6 +1628,126 @@ __device__ __forceinline__ void gradl_finish_body(const MpxGradlFinArgs& A) {
       for (int64_t e = A.lt_ptr[c]; e < A.lt_ptr[c + 1]; ++e) s = fma(lb[A.lt_row[e]], A.lt_coef[e], s);
       gb[A.lt_col[c]] += s;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Resident kernel (MpxResidentArgs, mpx_device.h): single evaluations without a launch.  `dispatch(A, mode, bx)` runs the node pass
+// of tile bx of the bucket A describes (generated: a chain of node_body<PH, P, MODE> instantiations), `bound(G, mode)` the
+// boundary pass.  All n_tiles workgroups are resident at once (the host launches only then).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool SYSTEM>
+__device__ __forceinline__ void res_grid_sync(const MpxResidentArgs& R, unsigned long long& epoch) {
+  if (SYSTEM) __threadfence_system();  // (the last barrier of a request: outputs may live in mapped host memory)
+  else __threadfence();
+  __syncthreads();
+  ++epoch;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(R.sync_count, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = epoch * (unsigned long long)R.n_tiles;
+    while (__hip_atomic_load(R.sync_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+  }
+  __syncthreads();
+}
+
+template <class Dispatch, class Bound>
+__device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch dispatch, Bound bound) {
+  __shared__ unsigned long long s_seq;
+  const int t = blockIdx.x;
+  constexpr unsigned long long EXIT = ~0ull;
+  unsigned long long seen = R.start_seq, epoch = 0;  // (request WORDS: number << 8 | slot << 1 | new)
+  // the static arguments of this workgroup's bucket and of the boundary pass: fetched ONCE (a per-request copy of the 0.7 KB cost
+  // 6.3 of the 20 us of a request, tools/r4_resident_stamps.py); the request's io comes through LDS
+  MpxNodeArgs A = R.buckets[R.tile_bucket[t]];
+  __shared__ MpxResRequest sQ;
+  const long long t_start = wall_clock64();
+  long long t_idle = t_start;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      unsigned long long q = seen;
+      if (t == 0) {
+        for (;;) {
+          q = __hip_atomic_load(&R.box->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (q != seen) break;
+          const long long now = wall_clock64();
+          if (now - t_idle > R.idle_ticks || now - t_start > R.life_ticks ||
+              __hip_atomic_load(&R.box->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+            // leave: tell the host first, then look once more (the host writes seq before it reads alive)
+            __hip_atomic_store(&R.box->alive, 0u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            q = __hip_atomic_load(&R.box->seq, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (q == seen) q = EXIT;
+            else __hip_atomic_store(&R.box->alive, 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);  // (a request came in after all: stay)
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (q != EXIT && (q & 1)) {  // new content of the slot: fetch it from the mailbox once
+          const int sl = (int)((q >> 1) & 127);
+          R.dev_slots[sl] = R.box->slots[sl];
+          __threadfence();
+        }
+        __hip_atomic_store(R.dev_seq, q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        while ((q = __hip_atomic_load(R.dev_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == seen) __builtin_amdgcn_s_sleep(1);
+      }
+      s_seq = q;
+    }
+    __syncthreads();
+    const unsigned long long q = s_seq;
+    __syncthreads();
+    if (q == EXIT) break;
+    seen = q;
+#ifdef MPX_RES_STAMPS  // phase stamps of workgroup 0 (wall_clock64, 100 MHz) into the mailbox's last slot (diagnostics builds)
+#define MPX_RSTAMP(k) if (t == 0 && threadIdx.x == 0) reinterpret_cast<long long*>(&R.box->slots[MPX_RES_SLOTS - 1])[k] = wall_clock64();
+#else
+#define MPX_RSTAMP(k)
+#endif
+    MPX_RSTAMP(0)
+    {
+      const int* __restrict__ src = reinterpret_cast<const int*>(&R.dev_slots[(q >> 1) & 127]);
+      int* dst = reinterpret_cast<int*>(&sQ);
+      for (int e = threadIdx.x; e < (int)(sizeof(MpxResRequest) / 4); e += blockDim.x) dst[e] = src[e];
+    }
+    __syncthreads();
+    const MpxResRequest& Q = sQ;
+    const int mode = Q.mode, ccs = Q.ccs;
+    A.io = Q.io;
+    MPX_RSTAMP(1)
+    dispatch(A, mode, t - A.tile_first);
+    MPX_RSTAMP(2)
+    res_grid_sync<false>(R, epoch);
+    MPX_RSTAMP(3)
+    if (t == 0) {
+      __shared__ MpxBoundArgs sGb;
+      {
+        const int* __restrict__ src = reinterpret_cast<const int*>(R.bound);
+        int* dst = reinterpret_cast<int*>(&sGb);
+        for (int e = threadIdx.x; e < (int)(sizeof(MpxBoundArgs) / 4); e += blockDim.x) dst[e] = src[e];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) sGb.io = A.io;
+      __syncthreads();
+      bound(sGb, mode);
+    }
+    MPX_RSTAMP(4)
+    if (ccs) {  // values in compressed-column order: out[k] = native[perm[k]], every workgroup a slice (coalesced writes)
+      res_grid_sync<false>(R, epoch);
+      const bool hs = mode == MPX_MODE_HESS;
+      const double* __restrict__ src = hs ? A.io.hess : A.io.jac;
+      const int64_t* __restrict__ perm = hs ? R.perm_h : R.perm_j;
+      const int64_t nnz = hs ? R.nnz_h : R.nnz_j;
+      double* __restrict__ dst = Q.ccs_out;
+      for (int64_t k = (int64_t)t * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)R.n_tiles * blockDim.x) dst[k] = src[perm[k]];
+    }
+    res_grid_sync<true>(R, epoch);
+    MPX_RSTAMP(5)
+    if (t == 0 && threadIdx.x == 0) __hip_atomic_store(&R.box->done, q >> 8, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    t_idle = wall_clock64();
+  }
+  if (t == 0 && threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(&R.box->exited, 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 }  // namespace mpxk
