@@ -298,6 +298,8 @@ class ProblemProgram:
                 parts.append(f"MPX_INSTANTIATE_GRADL({ph}, {d})")
                 if 12 < d <= 31:  # light passes of the high-degree buckets on the matrix cores (mpx_kernels.h: light_body)
                     parts.append(f"MPX_INSTANTIATE_LIGHT({ph}, {d})")
+                if d <= 12 and len(self.degrees) == 1:  # ... and of single-degree grids of low degree (light_low_body)
+                    parts.append(f"MPX_INSTANTIATE_LIGHT_LOW({ph}, {d})")
         parts.append("MPX_INSTANTIATE_BOUNDARY()")
         parts += self._resident_source()
         return "\n".join(parts) + "\n"

@@ -308,6 +308,15 @@ int build_layout(mpx_ctx* c) {
       for (int p = 0; p < c->n_phases && L.ok; ++p) L.ok = (int)L.groups.size() <= c->ph[p].tile_count;
     }
     if (!L.ok) L.groups.clear(), L.foreign.clear(), L.ftab.clear();
+    // single-degree grids of low degree (mpx_lightlow_*, light_low_body): spans of `own` nodes, the kernel's compile-time geometry
+    if (!L.ok && c->degs.size() == 1 && c->degs[0].deg <= 12) {
+      const int P = c->degs[0].deg, cap0 = 53248 / (8 * MPX_LIGHT_WAVES * (nx + nu));
+      const int chl = std::min(8, std::max(1, (cap0 - 2 * P - 8) / 64));
+      L.low = true, L.deg = P, L.dt = 0, L.own = 64 * chl, L.span_cap = (L.own + 2 * P + 8 + 1) & ~1;
+      L.n_low_groups = (int)((N + L.own - 1) / L.own);
+      L.ok = chl >= 2;  // (rows of more than ~24 inputs leave one chunk per span: the node kernels do as well)
+      for (int p = 0; p < c->n_phases && L.ok; ++p) L.ok = L.n_low_groups <= c->ph[p].tile_count;
+    }
   }
 
   // ---- packed g / grad_f staging (see MpxIO::gtmp): used by mixed-degree phases and by segment-sharded evaluations ----
@@ -702,8 +711,8 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     snprintf(name, sizeof name, "mpx_node_gradl_%d_%d", B.phase, B.deg);
     if (hipModuleGetFunction(&B.fn_gradl, c->module, name) != hipSuccess) B.fn_gradl = nullptr, (void)hipGetLastError();
     static const char* lm[2] = {"fg", "fgq"};
-    for (int m = 0; m < 2 && B.deg > 12 && B.deg <= 31; ++m) {  // light passes of the high-degree buckets (mpx_kernels.h: light_body)
-      snprintf(name, sizeof name, "mpx_light_%s_%d_%d", lm[m], B.phase, B.deg);
+    for (int m = 0; m < 2 && ((B.deg > 12 && B.deg <= 31) || c->lplan.low); ++m) {  // light passes (mpx_kernels.h: light_body / light_low_body)
+      snprintf(name, sizeof name, "mpx_light%s_%s_%d_%d", c->lplan.low ? "low" : "", lm[m], B.phase, B.deg);
       if (hipModuleGetFunction(&B.fn_light[m], c->module, name) != hipSuccess) B.fn_light[m] = nullptr, (void)hipGetLastError();
     }
   }
@@ -1140,15 +1149,15 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       A.z_off = P.z_off, A.g_off_F = P.g_off_F, A.g_off_C = P.g_off_C, A.g_off_DU = P.g_off_DU, A.g_off_mU = P.g_off_mU;
       A.N = (int32_t)c->N, A.seg_off = B.phase * c->S;
       L.groups = c->d_lgroups, L.foreign = c->d_lforeign, L.wdeg = t.d_w;
-      for (size_t k = 0; k < c->degs.size(); ++k) L.fD_off[k] = c->lplan.fD_off[k], L.fC_off[k] = c->lplan.fC_off[k], L.fdeg[k] = c->degs[k].deg;
+      for (size_t k = 0; k < c->degs.size() && !c->lplan.low; ++k) L.fD_off[k] = c->lplan.fD_off[k], L.fC_off[k] = c->lplan.fC_off[k], L.fdeg[k] = c->degs[k].deg;
       L.ftab = c->d_lftab, L.ftab_n = (int32_t)c->lplan.ftab.size();
-      L.n_groups = (int32_t)c->lplan.groups.size(), L.first_node = c->lplan.first_node, L.span_cap = c->lplan.span_cap, L.slot_first = P.tile_first;
+      L.n_groups = c->lplan.low ? c->lplan.n_low_groups : (int32_t)c->lplan.groups.size(), L.first_node = c->lplan.first_node, L.span_cap = c->lplan.span_cap, L.slot_first = P.tile_first;
       static long long* ldbg = nullptr;
       if (!ldbg && getenv("MPX_LIGHT_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
       L.dbg = ldbg;
       const int64_t items = (int64_t)L.n_groups * io.B;
       const unsigned wgs = (unsigned)std::min<int64_t>((items + MPX_LIGHT_WAVES - 1) / MPX_LIGHT_WAVES, 2 * (int64_t)n_cu);
-      const unsigned lds = (unsigned)((MPX_LIGHT_WAVES * (c->nx + c->nu) * c->lplan.span_cap + c->lplan.ftab.size()) * 8);
+      const unsigned lds = c->lplan.low ? 0u : (unsigned)((MPX_LIGHT_WAVES * (c->nx + c->nu) * c->lplan.span_cap + c->lplan.ftab.size()) * 8);
       int rc = launch(c, B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0], dim3(wgs, 1, 1), dim3(64 * MPX_LIGHT_WAVES, 1, 1), &L, sizeof L, lds);
       if (rc) return rc;
       if (c->profile) ++c->prof_launches;
@@ -1438,7 +1447,7 @@ extern "C" int mpx_get_light_plan(const mpx_ctx* c, int32_t* degree, int64_t* n_
   if (!c) return MPX_ERR_INVALID;
   const bool ok = c->kind == 0 && c->lplan.ok;
   if (degree) *degree = ok ? c->lplan.deg : 0;
-  if (n_groups) *n_groups = ok ? (int64_t)c->lplan.groups.size() : 0;
+  if (n_groups) *n_groups = ok ? (c->lplan.low ? (int64_t)c->lplan.n_low_groups : (int64_t)c->lplan.groups.size()) : 0;
   if (max_span_nodes) *max_span_nodes = ok ? c->lplan.span_cap : 0;
   if (n_low_degree_nodes) *n_low_degree_nodes = ok ? (int64_t)c->lplan.foreign.size() : 0;
   return MPX_OK;

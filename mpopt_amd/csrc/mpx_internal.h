@@ -108,8 +108,8 @@ struct mpx_ctx {
   // light passes on the matrix cores (mpx_light_*, mpx_kernels.h: light_body): grids with ONE high degree (12 < P <= 31) and otherwise
   // degrees <= 12.  Groups of up to 16 high-degree segments + the low-degree segments between them (the same for every phase)
   struct LightPlan {
-    bool ok = false;
-    int deg = 0, dt = -1, first_node = 0, span_cap = 0;
+    bool ok = false, low = false;           // low: single-degree grid of degree <= 12 (light_low_body: spans of `own` nodes)
+    int deg = 0, dt = -1, first_node = 0, span_cap = 0, own = 0, n_low_groups = 0;
     std::vector<MpxLightGroup> groups;
     std::vector<MpxLightForeign> foreign;
     std::vector<double> ftab;               // D and C_mid of the low degrees, concatenated

@@ -1045,6 +1045,213 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
 #undef MPX_LSTAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Light passes of SINGLE-DEGREE grids of low degree (P <= 12; BASELINE configs 1, 2, 4, 5): the same persistent, span-coalesced
+// scheme as light_body without the matrix cores -- a wavefront takes a span of 64 * CHL consecutive nodes of one evaluation point
+// (plus the few nodes that complete its first and last segment), stages the span's X / U rows in LDS with coalesced loads, evaluates
+// its nodes lane by lane (64 at a time) with node_body's fma chains over LDS, and stores the rows of g / grad_f coalesced through
+// LDS.  node_body's light passes were bound by the lifetime of a workgroup, not by HBM (0.38 - 0.53 of peak at config 2 even with
+// 16 evaluation points per workgroup: barrier per point, tile descriptors, 250-node tiles); here nothing but one table barrier at
+// kernel start.  g and the node entries of grad_f: bit-identical to node_body's.  Sums: lane (its nodes in order), wavefront tree,
+// one partial-sum slot per span.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PH, int P, int MODE>
+__device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
+  using G = mpxgen::Phase<PH>;
+  const MpxNodeArgs& A = L.node;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
+  constexpr int NIN = NX + NU, P1 = P + 1;
+  constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : G::NRED;
+  constexpr int R_C = NX, R_DU = NX + NC, R_MU = R_DU + (G::DIFF_U ? NU : 0), NG = R_MU + (G::MIDU ? NU : 0);
+  // span geometry, compile time: rows of CAP doubles per wavefront in 52 KB of LDS per workgroup; CHL chunks of 64 owned nodes
+  constexpr int CAP0 = 53248 / (8 * MPX_LIGHT_WAVES * NIN);
+  constexpr int CHL = (CAP0 - 2 * P - 8) / 64 > 8 ? 8 : ((CAP0 - 2 * P - 8) / 64 < 1 ? 1 : (CAP0 - 2 * P - 8) / 64);
+  constexpr int OWN = 64 * CHL, CH = CHL + 1, CAP = (OWN + 2 * P + 8 + 1) & ~1;
+  static_assert(MPX_LIGHT_WAVES * NIN * CAP * 8 <= 56 * 1024, "light_low_body: span rows do not fit LDS");
+  __shared__ double sBufL[MPX_LIGHT_WAVES][NIN][CAP];
+  __shared__ double sD[P1 * P1], sC[P * P1], sTk[P1], sWt[P1];
+  const int t = threadIdx.x, wave = t >> 6, l = t & 63;
+  const int N = A.N;
+  double(*sW)[CAP] = sBufL[wave];
+  const MpxIO& io = A.io;
+  for (int e = t; e < P1 * P1; e += 64 * MPX_LIGHT_WAVES) sD[e] = A.Dmat[e];
+  for (int e = t; e < P * P1; e += 64 * MPX_LIGHT_WAVES) sC[e] = A.Cmid[e];
+  if (t < P1) sTk[t] = A.tk[t], sWt[t] = L.wdeg[t];
+  __syncthreads();  // (the only barrier of the kernel)
+  const bool want_g = io.g != nullptr, want_q = MODE == MPX_MODE_FGJ && io.grad != nullptr;
+  const int n_groups = (N + OWN - 1) / OWN;
+  const int64_t total = (int64_t)n_groups * (io.B - io.b_first), stride = (int64_t)gridDim.x * MPX_LIGHT_WAVES;
+  auto lds_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+#ifdef MPX_LIGHT_STAMPS
+  int it_ = 0;
+#define MPX_LSTAMP(k) if (L.dbg && blockIdx.x == 1 && wave == 1 && it_ == 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (l == 0) L.dbg[k] = wall_clock64(); }
+#else
+#define MPX_LSTAMP(k)
+#endif
+  for (int64_t item = (int64_t)blockIdx.x * MPX_LIGHT_WAVES + wave; item < total; item += stride) {
+    MPX_LSTAMP(0)
+    const int gi = (int)(item % n_groups), b = io.b_first + (int)(item / n_groups);
+    const int lo_w = gi * OWN, len_w = N - lo_w < OWN ? N - lo_w : OWN;
+    const int lo_r = lo_w == 0 ? 0 : ((lo_w - 1) / P) * P;                 // point 0 of the first owned node's segment
+    const int i_last = lo_w + len_w - 1;
+    const int hi_r = i_last == 0 ? 1 : ((i_last - 1) / P + 1) * P + 1;    // one past the last node of the last owned node's segment
+    const int len_r = hi_r - lo_r;
+    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + A.z_off;
+    const double* __restrict__ zt = zb + (int64_t)NIN * N;
+    const double t0v = zt[0], tfv = zt[1];
+    Vec<NA> As;
+#pragma unroll
+    for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
+    const int64_t woff = (int64_t)b * io.w_stride + A.seg_off;
+    // the lane's nodes and the widths of their segments (loads in flight together with the span's)
+    int sg[CHL], kk[CHL];
+    double wsv[CHL], wcv[CHL];
+#pragma unroll
+    for (int u = 0; u < CHL; ++u) {
+      const int i = lo_w + 64 * u + l < N ? lo_w + 64 * u + l : N - 1;
+      sg[u] = i == 0 ? 0 : (i - 1) / P, kk[u] = i == 0 ? 0 : (i - 1) % P + 1;
+      wsv[u] = io.w[woff + sg[u]], wcv[u] = io.wcum[woff + sg[u]];
+    }
+    lds_sync();  // (the previous item's output reads of this buffer are done)
+    {
+      double v[NIN][CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int idx = 64 * u + l;
+#pragma unroll
+        for (int a = 0; a < NIN; ++a) v[a][u] = idx < len_r ? (zb + (int64_t)a * N)[lo_r + idx] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int idx = 64 * u + l;
+        if (idx < len_r) {
+#pragma unroll
+          for (int a = 0; a < NIN; ++a) sW[a][idx] = v[a][u];
+        }
+      }
+    }
+    lds_sync();
+    MPX_LSTAMP(1)
+    Vec<NRED> red;
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) red[r] = 0.0;
+    double oval[CHL][NG > 0 ? NG : 1], ogrd[CHL][MODE == MPX_MODE_FGJ ? NIN : 1];
+#pragma unroll
+    for (int u = 0; u < CHL; ++u) {
+      const int i = lo_w + 64 * u + l;
+      const bool valid = 64 * u + l < len_w;
+      const int k = kk[u], pos = (valid ? i : N - 1) - lo_r, pos0 = sg[u] * P - lo_r;  // the node and point 0 of its segment in the span
+      Vec<NX> Xs, fx;
+      Vec<NU> Us;
+      Vec<NC> cc;
+#pragma unroll
+      for (int a = 0; a < NX; ++a) Xs[a] = sW[a][pos];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) Us[c] = sW[NX + c][pos];
+      const double kap = wsv[u] * A.inv_dtau, th = wcv[u] + wsv[u] * sTk[k];
+      Vec<NRED> gr;
+      if constexpr (MODE == MPX_MODE_FG) {
+        G::fg(Xs, Us, t0v, tfv, As, kap, th, sWt[k], fx, cc, gr[0]);
+      } else {
+        Vec<NX> dd;
+        Vec<G::NJV> jv;
+        Vec<NIN> gn;
+        G::fgj(Xs, Us, t0v, tfv, As, kap, th, sWt[k], fx, cc, dd, jv, gn, gr);
+#pragma unroll
+        for (int a = 0; a < NIN; ++a) ogrd[u][a] = gn[a];
+      }
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) red[r] += gr[r];
+      }
+      if (want_g) {
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+          double acc = 0;
+#pragma unroll
+          for (int j = 0; j < P1; ++j) acc = fma(sD[k * P1 + j], sW[a][pos0 + j], acc);
+          oval[u][a] = acc - fx[a];
+        }
+#pragma unroll
+        for (int jj = 0; jj < NC; ++jj) oval[u][R_C + jj] = cc[jj];
+        if constexpr (G::DIFF_U) {
+#pragma unroll
+          for (int c = 0; c < NU; ++c) {
+            double acc = 0;
+#pragma unroll
+            for (int j = 0; j < P1; ++j) acc = fma(sD[k * P1 + j], sW[NX + c][pos0 + j], acc);
+            oval[u][R_DU + c] = acc;
+          }
+        }
+        if constexpr (G::MIDU) {
+#pragma unroll
+          for (int c = 0; c < NU; ++c) {
+            double acc = 0;
+            if (k >= 1) {
+#pragma unroll
+              for (int j = 0; j < P1; ++j) acc = fma(sC[(k - 1) * P1 + j], sW[NX + c][pos0 + j], acc);
+            }
+            oval[u][R_MU + c] = acc;
+          }
+        }
+      }
+    }
+    MPX_LSTAMP(2)
+    // outputs: NIN rows at a time through the LDS buffer (every input read is done), coalesced stores of the owned span
+    const int w0 = lo_w - lo_r;
+    auto put_rows = [&](auto value, int r0, int nr, auto row_ptr, auto shift) {
+      lds_sync();
+#pragma unroll
+      for (int u = 0; u < CHL; ++u) {
+        const int pos = w0 + 64 * u + l;
+        if (64 * u + l < len_w) {
+#pragma unroll
+          for (int r = 0; r < NIN; ++r)
+            if (r < nr && pos - shift(r0 + r) >= 0) sW[r][pos - shift(r0 + r)] = value(u, r0 + r);  // (node 0 has no mid-point row)
+        }
+      }
+      lds_sync();
+#pragma unroll
+      for (int r = 0; r < NIN; ++r)
+        if (r < nr) {
+          double* __restrict__ dst = row_ptr(r0 + r);
+          const int sh = shift(r0 + r);
+          const int p_lo = w0 - sh < 0 ? 0 : w0 - sh, p_hi = w0 + len_w - sh;
+          for (int idx = p_lo + l; idx < p_hi; idx += 64) dst[idx] = sW[r][idx];
+        }
+    };
+    if (want_g) {
+      double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
+      for (int r0 = 0; r0 < NG; r0 += NIN) {
+        put_rows([&](int u, int r) { return oval[u][r]; }, r0, NG - r0 < NIN ? NG - r0 : NIN,
+                 [&](int r) -> double* {
+                   if (r < R_C) return gb + A.g_off_F + (int64_t)r * N + lo_r;
+                   if (r < R_DU) return gb + A.g_off_C + (int64_t)(r - R_C) * N + lo_r;
+                   if (r < R_MU) return gb + A.g_off_DU + (int64_t)(r - R_DU) * N + lo_r;
+                   return gb + A.g_off_mU + (int64_t)(r - R_MU) * (N - 1) + lo_r;
+                 },
+                 [&](int r) { return r >= R_MU ? 1 : 0; });
+      }
+    }
+    if constexpr (MODE == MPX_MODE_FGJ) {
+      if (want_q) {
+        double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
+        put_rows([&](int u, int r) { return ogrd[u][r]; }, 0, NIN, [&](int r) -> double* { return qb + (int64_t)r * N + lo_r; }, [&](int) { return 0; });
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) {
+      const double v = wave_sum(red[r]);
+      if (l == 0) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + gi) * io.nred + r] = v;
+    }
+    MPX_LSTAMP(3)
+#ifdef MPX_LIGHT_STAMPS
+    ++it_;
+#endif
+  }
+#undef MPX_LSTAMP
+}
+
 // ---------------------------------------------------------------------------------------------
 // hess_l node pass over node-ordered tiles (mixed-degree grids, MpxHessNodeArgs): lane <-> node i0 + l.  Same arithmetic as the
 // MODE_HESS branch of node_body (G::hess, slot layout of scatter_slots, fixed-order tile sums), without anything that depends
@@ -1784,6 +1991,14 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
   }                                                                                                                           \
   extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_light_fgq_##PH##_##P(const MpxLightArgs A) {         \
     mpxk::light_body<PH, P, MPX_MODE_FGJ>(A);                                                                                 \
+  }
+
+#define MPX_INSTANTIATE_LIGHT_LOW(PH, P)                                                                                      \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_lightlow_fg_##PH##_##P(const MpxLightArgs A) {    \
+    mpxk::light_low_body<PH, P, MPX_MODE_FG>(A);                                                                              \
+  }                                                                                                                           \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_lightlow_fgq_##PH##_##P(const MpxLightArgs A) {   \
+    mpxk::light_low_body<PH, P, MPX_MODE_FGJ>(A);                                                                             \
   }
 
 #define MPX_INSTANTIATE_GRADL(PH, P)                                                                        \
