@@ -1156,7 +1156,9 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       if (!ldbg && getenv("MPX_LIGHT_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
       L.dbg = ldbg;
       const int64_t items = (int64_t)L.n_groups * io.B;
-      const unsigned wgs = (unsigned)std::min<int64_t>((items + MPX_LIGHT_WAVES - 1) / MPX_LIGHT_WAVES, 2 * (int64_t)n_cu);
+      int per_cu = 2;  // resident workgroups per compute unit (the kernels' launch bounds)
+      if (const char* e = getenv("MPX_LIGHT_PER_CU")) per_cu = std::max(1, atoi(e));
+      const unsigned wgs = (unsigned)std::min<int64_t>((items + MPX_LIGHT_WAVES - 1) / MPX_LIGHT_WAVES, per_cu * (int64_t)n_cu);
       const unsigned lds = c->lplan.low ? 0u : (unsigned)((MPX_LIGHT_WAVES * (c->nx + c->nu) * c->lplan.span_cap + c->lplan.ftab.size()) * 8);
       int rc = launch(c, B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0], dim3(wgs, 1, 1), dim3(64 * MPX_LIGHT_WAVES, 1, 1), &L, sizeof L, lds);
       if (rc) return rc;

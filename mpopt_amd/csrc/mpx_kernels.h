@@ -1048,12 +1048,16 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Light passes of SINGLE-DEGREE grids of low degree (P <= 12; BASELINE configs 1, 2, 4, 5): the same persistent, span-coalesced
 // scheme as light_body without the matrix cores -- a wavefront takes a span of 64 * CHL consecutive nodes of one evaluation point
-// (plus the few nodes that complete its first and last segment), stages the span's X / U rows in LDS with coalesced loads, evaluates
-// its nodes lane by lane (64 at a time) with node_body's fma chains over LDS, and stores the rows of g / grad_f coalesced through
-// LDS.  node_body's light passes were bound by the lifetime of a workgroup, not by HBM (0.38 - 0.53 of peak at config 2 even with
-// 16 evaluation points per workgroup: barrier per point, tile descriptors, 250-node tiles); here nothing but one table barrier at
-// kernel start.  g and the node entries of grad_f: bit-identical to node_body's.  Sums: lane (its nodes in order), wavefront tree,
-// one partial-sum slot per span.
+// (plus the few nodes that complete its first and last segment), stages the span's X / U rows in LDS (16-byte loads, all of them in
+// flight before the first LDS write), evaluates its nodes lane by lane (64 at a time) with node_body's fma chains over LDS, and
+// stores every row of g / grad_f straight from the registers: the lanes of a chunk hold consecutive nodes, so a row leaves as one
+// 512-byte store per chunk.  node_body's light passes were bound by the lifetime of a workgroup, not by HBM (0.38 - 0.53 of peak at
+// config 2 even with 16 evaluation points per workgroup: barrier per point, tile descriptors, 250-node tiles); here nothing but
+// one table barrier at kernel start.  Measured at config 2, B = 4096 (profiles/r4_lightlow): nlp_f 80.5 us (6.5 TB/s, 0.81 of
+// peak), nlp_g 182.6 us (0.70), nlp_f + nlp_grad_f 181.2 us (0.70).  What did NOT help: LDS-DMA double buffering of 256-node spans
+// (98 / 216 us), staging the outputs through LDS for 16-byte stores (83 / 197), three workgroups per compute unit (91 / 197).
+// g and the node entries of grad_f: bit-identical to node_body's.  Sums: lane (its nodes in order), wavefront tree, one
+// partial-sum slot per span.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int PH, int P, int MODE>
 __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
@@ -1066,7 +1070,8 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
   // span geometry, compile time: rows of CAP doubles per wavefront in 52 KB of LDS per workgroup; CHL chunks of 64 owned nodes
   constexpr int CAP0 = 53248 / (8 * MPX_LIGHT_WAVES * NIN);
   constexpr int CHL = (CAP0 - 2 * P - 8) / 64 > 8 ? 8 : ((CAP0 - 2 * P - 8) / 64 < 1 ? 1 : (CAP0 - 2 * P - 8) / 64);
-  constexpr int OWN = 64 * CHL, CH = CHL + 1, CAP = (OWN + 2 * P + 8 + 1) & ~1;
+  constexpr int OWN = 64 * CHL, CAP = (OWN + 2 * P + 8 + 1) & ~1;
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
   static_assert(MPX_LIGHT_WAVES * NIN * CAP * 8 <= 56 * 1024, "light_low_body: span rows do not fit LDS");
   __shared__ double sBufL[MPX_LIGHT_WAVES][NIN][CAP];
   __shared__ double sD[P1 * P1], sC[P * P1], sTk[P1], sWt[P1];
@@ -1113,20 +1118,25 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
       wsv[u] = io.w[woff + sg[u]], wcv[u] = io.wcum[woff + sg[u]];
     }
     lds_sync();  // (the previous item's output reads of this buffer are done)
-    {
-      double v[NIN][CH];
+    {  // 16 bytes per lane (rows are 8-byte aligned: N is odd as often as not), every load of the span in flight before the first LDS write
+      constexpr int CH2 = (CAP + 127) / 128;
+      d2u v[NIN][CH2];
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int idx = 64 * u + l;
+      for (int u = 0; u < CH2; ++u) {
+        const int idx = 128 * u + 2 * l;
 #pragma unroll
-        for (int a = 0; a < NIN; ++a) v[a][u] = idx < len_r ? (zb + (int64_t)a * N)[lo_r + idx] : 0.0;
+        for (int a = 0; a < NIN; ++a) {
+          const double* __restrict__ src = zb + (int64_t)a * N + lo_r + idx;
+          if (idx + 1 < len_r) v[a][u] = *(const d2u*)src;
+          else v[a][u] = d2u{idx < len_r ? src[0] : 0.0, 0.0};
+        }
       }
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int idx = 64 * u + l;
+      for (int u = 0; u < CH2; ++u) {
+        const int idx = 128 * u + 2 * l;
         if (idx < len_r) {
 #pragma unroll
-          for (int a = 0; a < NIN; ++a) sW[a][idx] = v[a][u];
+          for (int a = 0; a < NIN; ++a) sW[a][idx] = v[a][u].x, sW[a][idx + 1] = v[a][u].y;
         }
       }
     }
@@ -1135,7 +1145,10 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
     Vec<NRED> red;
 #pragma unroll
     for (int r = 0; r < NRED; ++r) red[r] = 0.0;
-    double oval[CHL][NG > 0 ? NG : 1], ogrd[CHL][MODE == MPX_MODE_FGJ ? NIN : 1];
+    // The lanes of a chunk hold CONSECUTIVE nodes, so every row of g / grad_f leaves as one 512-byte store per chunk straight from
+    // the registers (no staging; the mid-point rows are the same run shifted by one node)
+    double* __restrict__ gb = want_g ? io.g + (int64_t)b * io.g_stride : nullptr;
+    double* __restrict__ qb = want_q ? io.grad + (int64_t)b * io.grad_stride + A.z_off : nullptr;
 #pragma unroll
     for (int u = 0; u < CHL; ++u) {
       const int i = lo_w + 64 * u + l;
@@ -1157,30 +1170,31 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
         Vec<G::NJV> jv;
         Vec<NIN> gn;
         G::fgj(Xs, Us, t0v, tfv, As, kap, th, sWt[k], fx, cc, dd, jv, gn, gr);
+        if (want_q && valid) {
 #pragma unroll
-        for (int a = 0; a < NIN; ++a) ogrd[u][a] = gn[a];
+          for (int a = 0; a < NIN; ++a) qb[(int64_t)a * N + i] = gn[a];
+        }
       }
       if (valid) {
 #pragma unroll
         for (int r = 0; r < NRED; ++r) red[r] += gr[r];
       }
       if (want_g) {
+        double dx[NX > 0 ? NX : 1], du[NU > 0 ? NU : 1], mu[NU > 0 ? NU : 1];
 #pragma unroll
         for (int a = 0; a < NX; ++a) {
           double acc = 0;
 #pragma unroll
           for (int j = 0; j < P1; ++j) acc = fma(sD[k * P1 + j], sW[a][pos0 + j], acc);
-          oval[u][a] = acc - fx[a];
+          dx[a] = acc - fx[a];
         }
-#pragma unroll
-        for (int jj = 0; jj < NC; ++jj) oval[u][R_C + jj] = cc[jj];
         if constexpr (G::DIFF_U) {
 #pragma unroll
           for (int c = 0; c < NU; ++c) {
             double acc = 0;
 #pragma unroll
             for (int j = 0; j < P1; ++j) acc = fma(sD[k * P1 + j], sW[NX + c][pos0 + j], acc);
-            oval[u][R_DU + c] = acc;
+            du[c] = acc;
           }
         }
         if constexpr (G::MIDU) {
@@ -1191,54 +1205,28 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
 #pragma unroll
               for (int j = 0; j < P1; ++j) acc = fma(sC[(k - 1) * P1 + j], sW[NX + c][pos0 + j], acc);
             }
-            oval[u][R_MU + c] = acc;
+            mu[c] = acc;
+          }
+        }
+        if (valid) {
+#pragma unroll
+          for (int a = 0; a < NX; ++a) gb[A.g_off_F + (int64_t)a * N + i] = dx[a];
+#pragma unroll
+          for (int jj = 0; jj < NC; ++jj) gb[A.g_off_C + (int64_t)jj * N + i] = cc[jj];
+          if constexpr (G::DIFF_U) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) gb[A.g_off_DU + (int64_t)c * N + i] = du[c];
+          }
+          if constexpr (G::MIDU) {
+            if (k >= 1) {  // (node 0 has no mid-point row)
+#pragma unroll
+              for (int c = 0; c < NU; ++c) gb[A.g_off_mU + (int64_t)c * (N - 1) + i - 1] = mu[c];
+            }
           }
         }
       }
     }
     MPX_LSTAMP(2)
-    // outputs: NIN rows at a time through the LDS buffer (every input read is done), coalesced stores of the owned span
-    const int w0 = lo_w - lo_r;
-    auto put_rows = [&](auto value, int r0, int nr, auto row_ptr, auto shift) {
-      lds_sync();
-#pragma unroll
-      for (int u = 0; u < CHL; ++u) {
-        const int pos = w0 + 64 * u + l;
-        if (64 * u + l < len_w) {
-#pragma unroll
-          for (int r = 0; r < NIN; ++r)
-            if (r < nr && pos - shift(r0 + r) >= 0) sW[r][pos - shift(r0 + r)] = value(u, r0 + r);  // (node 0 has no mid-point row)
-        }
-      }
-      lds_sync();
-#pragma unroll
-      for (int r = 0; r < NIN; ++r)
-        if (r < nr) {
-          double* __restrict__ dst = row_ptr(r0 + r);
-          const int sh = shift(r0 + r);
-          const int p_lo = w0 - sh < 0 ? 0 : w0 - sh, p_hi = w0 + len_w - sh;
-          for (int idx = p_lo + l; idx < p_hi; idx += 64) dst[idx] = sW[r][idx];
-        }
-    };
-    if (want_g) {
-      double* __restrict__ gb = io.g + (int64_t)b * io.g_stride;
-      for (int r0 = 0; r0 < NG; r0 += NIN) {
-        put_rows([&](int u, int r) { return oval[u][r]; }, r0, NG - r0 < NIN ? NG - r0 : NIN,
-                 [&](int r) -> double* {
-                   if (r < R_C) return gb + A.g_off_F + (int64_t)r * N + lo_r;
-                   if (r < R_DU) return gb + A.g_off_C + (int64_t)(r - R_C) * N + lo_r;
-                   if (r < R_MU) return gb + A.g_off_DU + (int64_t)(r - R_DU) * N + lo_r;
-                   return gb + A.g_off_mU + (int64_t)(r - R_MU) * (N - 1) + lo_r;
-                 },
-                 [&](int r) { return r >= R_MU ? 1 : 0; });
-      }
-    }
-    if constexpr (MODE == MPX_MODE_FGJ) {
-      if (want_q) {
-        double* __restrict__ qb = io.grad + (int64_t)b * io.grad_stride + A.z_off;
-        put_rows([&](int u, int r) { return ogrd[u][r]; }, 0, NIN, [&](int r) -> double* { return qb + (int64_t)r * N + lo_r; }, [&](int) { return 0; });
-      }
-    }
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
       const double v = wave_sum(red[r]);
@@ -1993,11 +1981,13 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
     mpxk::light_body<PH, P, MPX_MODE_FGJ>(A);                                                                                 \
   }
 
+// (two workgroups per compute unit: three measured 8 - 13 % slower at config 2, one 45 % -- profiles/r4_lightlow/README.md)
+#define MPX_LOW_WPS(PH) 2
 #define MPX_INSTANTIATE_LIGHT_LOW(PH, P)                                                                                      \
-  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_lightlow_fg_##PH##_##P(const MpxLightArgs A) {    \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(PH)) void mpx_lightlow_fg_##PH##_##P(const MpxLightArgs A) {    \
     mpxk::light_low_body<PH, P, MPX_MODE_FG>(A);                                                                              \
   }                                                                                                                           \
-  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_lightlow_fgq_##PH##_##P(const MpxLightArgs A) {   \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(PH)) void mpx_lightlow_fgq_##PH##_##P(const MpxLightArgs A) {   \
     mpxk::light_low_body<PH, P, MPX_MODE_FGJ>(A);                                                                             \
   }
 
