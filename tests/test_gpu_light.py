@@ -28,6 +28,17 @@ NO_PLAN = {
     "low_degrees_only": (problems.van_der_pol, 8, [3, 5] * 4, "CGL"),
     "degree_above_31": (problems.van_der_pol, 3, [40, 3, 3], "CGL"),
 }
+# single-degree grids of degree <= 12: the mpx_lightlow_* kernels (spans of 64 * CHL consecutive nodes per wavefront)
+LOW_CASES = {
+    "moon_lander_20x3": (problems.moon_lander, 20, 3, "LGR"),                     # one short span
+    "moon_lander_300x5": (problems.moon_lander, 300, 5, "LGR"),                   # three spans, segments straddle the span ends
+    "schwartz_2x200x3": (problems.two_phase_schwartz, 200, 3, "LGL"),             # two phases
+    "kitchen_sink_40x5": (problems.kitchen_sink, 40, 5, "LGR"),                   # five inputs per node: shorter spans; DU rows, parameters
+    "dae_vdp_37x12": (problems.dae_vdp, 37, 12, "CGL"),                           # highest degree of the family
+    "time_dependent_400x3": (problems.time_dependent, 400, 3, "LGR"),
+    "hyper_sensitive_700x1": (problems.hyper_sensitive, 700, 1, "LGR"),           # degree 1: every node its own segment
+    "van_der_pol_513x2": (problems.van_der_pol, 513, 2, "CGL"),                   # N = 1027: the last span holds three nodes
+}
 
 
 def build(case):
@@ -35,6 +46,21 @@ def build(case):
     ocp = builder(mp, M.math)
     mpo = mp.mpopt(ocp, S, po, scheme)
     return ocp, mpo, mpo.create_nlp()[0]["oracle"]
+
+
+@pytest.mark.parametrize("name", list(LOW_CASES))
+def test_low_degree_plan_structure(name):
+    """Single-degree grids of degree <= 12: spans of 64 * CHL nodes (CHL from the LDS budget of the span rows), one partial-sum
+    slot per span -- never more spans than tiles in a phase."""
+    builder, S, po, scheme = LOW_CASES[name]
+    ocp = builder(mp, M.math)
+    o = M.NlpFunctions(ocp, S, [po] * S, scheme, with_device=False)
+    deg, n_groups, span, n_low = o.light_plan()
+    nin = ocp.nx + ocp.nu
+    chl = min(8, max(1, (53248 // (32 * nin) - 2 * po - 8) // 64))
+    assert deg == po and n_low == 0 and span == (64 * chl + 2 * po + 8 + 1) // 2 * 2
+    assert n_groups == -(-o.n_nodes // (64 * chl))
+    o.close()
 
 
 @pytest.mark.parametrize("name", list(CASES) + list(NO_PLAN))
@@ -55,12 +81,13 @@ def test_light_plan_structure(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", list(CASES) + list(LOW_CASES))
 def test_light_kernels_against_node_kernels_and_oracle(name):
     from oracle.mpopt_oracle import OracleNLP
 
-    ocp, mpo, o = build(CASES[name])
-    assert o.light_plan()[0] > 12
+    case = CASES.get(name) or LOW_CASES[name]
+    ocp, mpo, o = build(case)
+    assert (o.light_plan()[0] > 12) == (name in CASES) and o.light_plan()[1] > 0
     rng = np.random.default_rng(3)
     node = np.ones(o.n_z, bool)
     node[border_columns(o)] = False
@@ -94,7 +121,7 @@ def test_light_kernels_against_node_kernels_and_oracle(name):
         lp = o.eval(["f", "g"], Z, P2)
         r1 = o.eval(["f", "g"], Z[B - 1], P2[B - 1])
         assert r1["f"] == lp["f"][B - 1] and np.array_equal(r1["g"], lp["g"][B - 1])
-    builder, S, po, scheme = CASES[name]
+    builder, S, po, scheme = case
     O = OracleNLP(ocp, S, po, scheme)
     r = o.eval(["f", "g", "grad_f"], Z[0], p)
     assert abs(r["f"] - O.f(Z[0], p)) <= 1e-10 * max(1.0, abs(O.f(Z[0], p)))
