@@ -214,7 +214,11 @@ class AssembledNlpFunctions(NlpFunctions):
             terms_m = np.concatenate([cf[ptr[r]:ptr[r + 1]] for r in rows_m]) if len(rows_m) else np.zeros(0)  # ELL table of the multi-term rows
             vals = np.concatenate([first, np.zeros(1 if (nt == 0).any() else 0), terms_m])
             sizes["NDICT_" + tag] = len(np.unique(vals.view(np.int64))) if len(vals) else 0
-        self.source = self._source(funcs, sizes)
+        # per set: function id and the running term offsets of its local variables / multipliers -- compile-time constants of the
+        # fused kernels (mpx_assembly_fused.h, mpxgen::SetT; the host computes the same offsets from loc_nterm / mu_nterm)
+        self._set_consts = [(self.functions.index(s.fn), np.concatenate([[0], np.cumsum(np.asarray(e[0][0], np.int64))]).tolist(),
+                             np.concatenate([[0], np.cumsum(np.asarray(e[1][0], np.int64))]).tolist()) for s, e in zip(self.sets, self._ell)]
+        self.source = self._source(funcs, sizes, self._set_consts)
         if with_device is None:
             with_device = _lib.gpu_available()
         self.code_object = None
@@ -224,7 +228,7 @@ class AssembledNlpFunctions(NlpFunctions):
 
     # -- generated source ---------------------------------------------------------------------------
     @staticmethod
-    def _source(funcs, sizes):
+    def _source(funcs, sizes, set_consts=()):
         parts = ["// generated by mpopt_amd.assembly -- do not edit", "#include <hip/hip_runtime.h>", "namespace mpxgen {",
                  "template <int FID> struct Pt;"]
         parts += [f.source(k) for k, f in enumerate(funcs)]
@@ -237,6 +241,14 @@ class AssembledNlpFunctions(NlpFunctions):
         # fused persistent kernels for batches (mpx_assembly_fused.h): the sizes of this problem are compile-time constants there
         # (row loops unroll, a lane's share of the row table lives in registers)
         parts += [f"#define MPX_FUSE_{k} {int(v)}" for k, v in sizes.items()]
+        if 0 < len(set_consts) <= 16:
+            arr = lambda v: "{" + ", ".join(str(int(x)) for x in v) + "}"
+            parts += ["namespace mpxgen {", "template <int SET> struct SetT;"]
+            for k, (fid, lt, mt) in enumerate(set_consts):
+                parts.append(f"template <> struct SetT<{k}> {{\n  static constexpr int FID = {fid};\n"
+                             f"  __host__ __device__ static constexpr int lt(int v) {{ constexpr int a[] = {arr(lt)}; return a[v]; }}\n"
+                             f"  __host__ __device__ static constexpr int mt(int r) {{ constexpr int a[] = {arr(mt)}; return a[r]; }}\n}};")
+            parts += ["}  // namespace mpxgen", f"#define MPX_FUSE_SETS {len(set_consts)}"]
         parts += ['#include "mpx_assembly_fused.h"', f"MPX_INSTANTIATE_FUSED({len(funcs)})"]
         return "\n".join(parts) + "\n"
 

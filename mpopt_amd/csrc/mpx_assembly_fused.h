@@ -123,10 +123,26 @@ struct RowRegsPacked {
   }
 };
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int, I>) ... f(integral_constant<int, N - 1>)
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+#ifndef MPX_FUSE_SET_MAX_ENTRIES
+#define MPX_FUSE_SET_MAX_ENTRIES 96  // table entries of a point (32-bit codes) a lane may hold at once (mpxgen::SetT path)
+#endif
+
 // point functions of one 64-point block for the U evaluation points of a chunk: a term's table entry (position, coefficient) is
 // read once and applied to all of them (per evaluation point the terms are added in the stored order, as in the two-pass point
 // kernels); local variables from z in LDS, results to raw in LDS
-template <int FID, int MODE, int U, int VN, int RAWN>
+// SET >= 0 (round 4): the term counts of the set's local variables and multipliers are compile-time constants of the generated
+// source (mpxgen::SetT<SET>::lt / mt -- the running offsets the host computes from the same tables), so EVERY table entry of the
+// point is requested in one round trip and the sums are straight-line code; with run-time counts the loop of each variable was its
+// own dependent round trip (ten in a row for a moon-lander mid-point: 4.5 of the 5 us of a point task).
+template <int FID, int MODE, int U, int VN, int RAWN, int SET = -1>
 __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __restrict__ ltoff, const int* __restrict__ mtoff, const ::MpxFusedArgs& A, int blk, int lane,
                                             double (*V)[VN], int b0, int nu, const double* __restrict__ CH, const double* __restrict__ ldict,
                                             const double* __restrict__ mdict) {
@@ -154,7 +170,37 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
   // single-term variables -- states, controls, t0, tf, the segment's width -- instead of one each: the unrolled loop over v with a
   // run-time term loop inside would not let the compiler overlap them), the remaining terms of the long ones follow in groups of
   // MPX_FUSE_LOC_G.  Same terms, same order, same fma chains.
-  if constexpr (NLD > 0) {
+  constexpr bool SETC = []() {
+    if constexpr (SET >= 0 && NLD > 0) return mpxgen::SetT<(SET >= 0 ? SET : 0)>::lt(NLOC) <= MPX_FUSE_SET_MAX_ENTRIES;
+    else return false;
+  }();
+  if constexpr (SETC) {
+    using ST = mpxgen::SetT<(SET >= 0 ? SET : 0)>;
+    constexpr int NE = ST::lt(NLOC);
+    uint32_t e[NE > 0 ? NE : 1];
+#pragma unroll
+    for (int t = 0; t < NE; ++t) e[t] = S.loc_pack[(int64_t)t * n + p];
+    static_for<0, NLOC>([&](auto vc) {
+      constexpr int v = decltype(vc)::value, ta = ST::lt(v), tb = ST::lt(v + 1);
+      double acc[U];
+      if (MPX_FUSE_CHAINS && v == S.chain_v) {
+        const int slot = S.chain_pos[p];
+#pragma unroll
+        for (int u = 0; u < U; ++u) loc[u][v] = CH[u * MPX_FUSE_CHAIN_MAX + slot];
+        return;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = 0.0;
+      static_for<ta, tb>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const double cq = ldict[e[t] >> 16];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = fma(cq, V[u][RAWN + (int)(e[t] & 0xffffu)], acc[u]);  // (first term: fma(c, v, 0.0) as in the two-pass kernels)
+      });
+#pragma unroll
+      for (int u = 0; u < U; ++u) loc[u][v] = acc[u];
+    });
+  } else if constexpr (NLD > 0) {
     // packed tables: the first entry of every variable in one round trip (one register each), the rest in groups of MPX_FUSE_LOC_GP
     uint32_t e0[NLOC > 0 ? NLOC : 1];
 #pragma unroll
@@ -236,6 +282,46 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
 #endif
   if constexpr (MODE == MPX_MODE_HESS) {
     double mu[U][NOUT > 0 ? NOUT : 1];
+    constexpr bool SETM = []() {
+      if constexpr (SET >= 0) return mpxgen::SetT<(SET >= 0 ? SET : 0)>::mt(NOUT) <= 16;
+      else return false;
+    }();
+    if constexpr (SETM) {  // every multiplier entry in one round trip, every multiplier in the next, then straight-line sums
+      using ST = mpxgen::SetT<(SET >= 0 ? SET : 0)>;
+      constexpr int NM = ST::mt(NOUT);
+      int ix[NM > 0 ? NM : 1];
+      double cf[NM > 0 ? NM : 1], lm[U][NM > 0 ? NM : 1];
+#pragma unroll
+      for (int t = 0; t < NM; ++t) {
+        const int64_t tt = (int64_t)t * n + p;
+        if constexpr (NMD > 0) {
+          const uint32_t e = S.mu_pack[tt];
+          ix[t] = (int)(e & 0xffffu), cf[t] = mdict[e >> 16];
+        } else {
+          ix[t] = S.mu_idx[tt], cf[t] = S.mu_coef[tt];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NM; ++t)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int b = b0 + (u < nu ? u : 0);
+          lm[u][t] = ix[t] == A.n_g ? A.sigma[b] : A.lam[(int64_t)b * A.lam_stride + ix[t]];
+        }
+      static_for<0, NOUT>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        double acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = 0;
+        static_for<ST::mt(r), ST::mt(r + 1)>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc[u] = fma(cf[t], lm[u][t], acc[u]);
+        });
+#pragma unroll
+        for (int u = 0; u < U; ++u) mu[u][r] = acc[u];
+      });
+    } else
 #pragma unroll
     for (int r = 0; r < NOUT; ++r) {
       double acc[U];
@@ -322,6 +408,24 @@ struct FusedDispatch<MODE, -1, U, VN, RAWN> {
   __device__ static __forceinline__ void run(const MpxPtSet&, const int*, const int*, const ::MpxFusedArgs&, int, int, double (*)[VN], int, int, const double*, const double*,
                                              const double*) {}
 };
+
+#ifdef MPX_FUSE_SETS  // dispatch on the set index: term counts of the set are compile-time constants (mpxgen::SetT<SET>)
+template <int MODE, int SET, int U, int VN, int RAWN>
+struct FusedDispatchSet {
+  __device__ static __forceinline__ void run(int k, const MpxPtSet& S, const int* lt, const int* mt, const ::MpxFusedArgs& A, int blk, int lane, double (*V)[VN], int b0, int nu,
+                                             const double* CH, const double* ld, const double* md) {
+    if (k == SET)
+      fused_point<mpxgen::SetT<SET>::FID, MODE, U, VN, RAWN, SET>(S, lt, mt, A, blk, lane, V, b0, nu, CH, ld, md);
+    else
+      FusedDispatchSet<MODE, SET - 1, U, VN, RAWN>::run(k, S, lt, mt, A, blk, lane, V, b0, nu, CH, ld, md);
+  }
+};
+template <int MODE, int U, int VN, int RAWN>
+struct FusedDispatchSet<MODE, -1, U, VN, RAWN> {
+  __device__ static __forceinline__ void run(int, const MpxPtSet&, const int*, const int*, const ::MpxFusedArgs&, int, int, double (*)[VN], int, int, const double*, const double*,
+                                             const double*) {}
+};
+#endif
 
 // MODE_FG / MODE_FGJ: arrays f (1 row), g (NG), grad_f (NZ), jac_val (NNZJ); MODE_HESS: hess_val (NNZH).
 // MT: ELL width of the multi-term rows (rows with 2 .. MT terms); RL x TL: long rows per wavefront x 64-term rounds
@@ -474,7 +578,11 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       if (u >= nu) continue;
       int k = 0;
       while (k + 1 < A.n_sets && bx >= sS[k + 1].block_first) ++k;
+#if defined(MPX_FUSE_SETS) && !defined(MPX_FUSE_NO_SET_CONSTS)
+      FusedDispatchSet<MODE, MPX_FUSE_SETS - 1, 1, VN, RAWN>::run(k, sS[k], sLt[k], sMt[k], A, bx - sS[k].block_first, lane, &V[u], b0 + u, 1, &CH[it_ & 1][u][0], sLDict, sMDict);
+#else
       FusedDispatch<MODE, NF - 1, 1, VN, RAWN>::run(sS[k], sLt[k], sMt[k], A, bx - sS[k].block_first, lane, &V[u], b0 + u, 1, &CH[it_ & 1][u][0], sLDict, sMDict);
+#endif
     }
     // table entries of this lane's multi-term rows: loads issued before the barrier, used after the single-term rows
     MPX_FUSE_STAMP(2);
