@@ -77,6 +77,18 @@
 
 namespace mpxk {
 
+#ifndef MPX_FUSE_PAIR_ROWS
+#define MPX_FUSE_PAIR_ROWS 0  // (measured 6 % slower at moon lander 20x5, tools/r4_adaptive_ab.py: 60.2 against 56.8 us)
+#endif
+typedef double mpx_d2u __attribute__((ext_vector_type(2), aligned(8)));
+// Row <-> (register k, lane l).  Paired (MPX_FUSE_PAIR_ROWS=1): registers 2j, 2j + 1 of lane l hold the ADJACENT rows 2 (j NT + l), + 1, so that the
+// two values leave as one 16-byte store (a wavefront's store instruction then writes a 1 KB run); an odd last register holds row
+// (K - 1) NT + l.  Unpaired (default): row k NT + l.
+template <int K, int NT>
+__device__ __forceinline__ int fused_row_of(int k, int l) {
+  if (MPX_FUSE_PAIR_ROWS && k < (K & ~1)) return (k >> 1) * 2 * NT + 2 * l + (k & 1);
+  return k * NT + l;
+}
 template <int NA, int NT>
 struct RowRegs {  // first terms of the rows k * NT + lane, k < K, of one output array; idx < 0: not a single-term row of this lane
   static constexpr int K = (NA + NT - 1) / NT;
@@ -85,7 +97,7 @@ struct RowRegs {  // first terms of the rows k * NT + lane, k < K, of one output
   __device__ __forceinline__ void load(const ::MpxFusedArgs& A, int base, int l) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const int r = k * NT + l;
+      const int r = fused_row_of<K, NT>(k, l);
       const bool ok = r < NA && A.r_nt[base + (r < NA ? r : 0)] <= 1;
       idx[k] = ok ? A.r_idx[base + r] : -1;
       coef[k] = ok ? A.r_coef[base + r] : 0.0;
@@ -97,7 +109,7 @@ struct RowRegs {  // first terms of the rows k * NT + lane, k < K, of one output
     if (!out) return;
 #pragma unroll
     for (int k = 0; k < K; ++k)
-      if (idx[k] >= 0) out[k * NT + l] = fma(coef[k], V[idx[k]], 0.0);
+      if (idx[k] >= 0) out[fused_row_of<K, NT>(k, l)] = fma(coef[k], V[idx[k]], 0.0);
   }
 };
 
@@ -111,15 +123,25 @@ struct RowRegsPacked {
   __device__ __forceinline__ void load(const ::MpxFusedArgs& A, int base, int l) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const int r = k * NT + l;
+      const int r = fused_row_of<K, NT>(k, l);
       pk[k] = r < NA ? A.r_pack[base + r] : 0xffffffffu;
     }
   }
   __device__ __forceinline__ void store(const double* __restrict__ V, const double* __restrict__ dict, double* __restrict__ out, int l) const {
     if (!out) return;
+    constexpr int KP = MPX_FUSE_PAIR_ROWS ? (K & ~1) : 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-      if (pk[k] != 0xffffffffu) out[k * NT + l] = fma(dict[pk[k] >> 16], V[pk[k] & 0xffffu], 0.0);
+    for (int k = 0; k < KP; k += 2) {
+      const bool ha = pk[k] != 0xffffffffu, hb = pk[k + 1] != 0xffffffffu;
+      const double a = ha ? fma(dict[pk[k] >> 16], V[pk[k] & 0xffffu], 0.0) : 0.0, b = hb ? fma(dict[pk[k + 1] >> 16], V[pk[k + 1] & 0xffffu], 0.0) : 0.0;
+      double* __restrict__ o = out + fused_row_of<K, NT>(k, l);
+      if (ha && hb) *(mpx_d2u*)o = mpx_d2u{a, b};
+      else if (ha) o[0] = a;
+      else if (hb) o[1] = b;
+    }
+#pragma unroll
+    for (int k = KP; k < K; ++k)
+      if (pk[k] != 0xffffffffu) out[fused_row_of<K, NT>(k, l)] = fma(dict[pk[k] >> 16], V[pk[k] & 0xffffu], 0.0);
   }
 };
 
@@ -551,10 +573,16 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 #pragma unroll
   for (int q = 0; q < MAXT; ++q) my_t[q] = q < n_my ? A.task_list[tq0 + q] : 0;
   const int n_chunks = (A.B + U - 1) / U;
-  if ((int)blockIdx.x < n_chunks) z_load(blockIdx.x), chains_of(blockIdx.x, 0);
+#ifndef MPX_FUSE_XCD_BLOCKED
+#define MPX_FUSE_XCD_BLOCKED 1
+#endif
+  // XCD-blocked walk (as node_body): workgroup i runs on XCD i % 8; the workgroups of one XCD take CONSECUTIVE chunks of every round,
+  // so each L2 streams a contiguous eighth of the round's outputs instead of every eighth chunk
+  const int first_chunk = (MPX_FUSE_XCD_BLOCKED && gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+  if (first_chunk < n_chunks) z_load(first_chunk), chains_of(first_chunk, 0);
   int it_ = 0;
 #define MPX_FUSE_STAMP(k) do { if (A.dbg && blockIdx.x == 1 && l == 0 && it_ == 2) A.dbg[k] = wall_clock64(); } while (0)
-  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x, ++it_) {
+  for (int c = first_chunk; c < n_chunks; c += gridDim.x, ++it_) {
     const int b0 = c * U, nu = (A.B - b0 < U) ? A.B - b0 : U;
     MPX_FUSE_STAMP(0);
 #ifdef MPX_FUSE_PT_STAMPS
@@ -567,7 +595,12 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     }
     __syncthreads();
     MPX_FUSE_STAMP(1);
-    if (c + (int)gridDim.x < n_chunks) z_load(c + gridDim.x), chains_of(c + gridDim.x, (it_ + 1) & 1);  // in flight during this chunk's work
+#ifndef MPX_FUSE_Z_LATE
+#define MPX_FUSE_Z_LATE 0
+#endif
+    // (the next chunk's z, in flight during this chunk's work.  Requesting it BEHIND the point tasks instead -- a wavefront's loads
+    // return in order, the table entries of the point tasks are L2 hits -- measured 4 % slower in process, tools/r4_adaptive_ab.py)
+    if (!MPX_FUSE_Z_LATE && c + (int)gridDim.x < n_chunks) z_load(c + gridDim.x), chains_of(c + gridDim.x, (it_ + 1) & 1);
     // ---- point functions: wavefront <-> (64-point block, evaluation point) ----
     // wavefront <-> its scheduled (64-point block, evaluation point) tasks
     for (int q = 0; q < n_my; ++q) {
@@ -584,6 +617,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       FusedDispatch<MODE, NF - 1, 1, VN, RAWN>::run(sS[k], sLt[k], sMt[k], A, bx - sS[k].block_first, lane, &V[u], b0 + u, 1, &CH[it_ & 1][u][0], sLDict, sMDict);
 #endif
     }
+    if (MPX_FUSE_Z_LATE && c + (int)gridDim.x < n_chunks) z_load(c + gridDim.x), chains_of(c + gridDim.x, (it_ + 1) & 1);
     // table entries of this lane's multi-term rows: loads issued before the barrier, used after the single-term rows
     MPX_FUSE_STAMP(2);
     __syncthreads();
@@ -634,6 +668,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
         R3.store(Vu, A.out[3] ? A.out[3] + b * A.out_stride[3] : nullptr, l);
       }
     }
+    MPX_FUSE_STAMP(4);
     // ---- rows with 2 .. MT terms: one lane per row, ELL table [t][row] (the MT loads of a row are independent), added in stored order ----
 #if MPX_FUSE_MULTI_EARLY
 #pragma unroll
