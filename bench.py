@@ -267,7 +267,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a timed region of >= 0.2 s at the default workload)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="evaluation points per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="evaluation points per GPU per step (default 4096; 512 for config 3 first-order and the config-5 loop, 16 for the shard workloads)")
     ap.add_argument("--segments", type=int, default=1000)
     ap.add_argument("--degree", type=int, default=5)
     ap.add_argument("--plain-outputs", action="store_true", help="time plain torch.empty output arrays instead of NlpFunctions.alloc_outputs")
@@ -362,7 +362,8 @@ def main():
     from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC
     import problems
 
-    S, P, B, K, W = args.segments, args.degree, args.batch, args.steps, args.warmup
+    batch_given = args.batch is not None
+    S, P, B, K, W = args.segments, args.degree, args.batch if batch_given else 4096, args.steps, args.warmup
     hess_mode = args.workload.endswith("hess")
     shard = args.workload.endswith("-shard")
     scheme, builder, label = "LGR", problems.moon_lander, f"moon-lander OCP, n_segments={S}, poly_orders={P}, LGR (BASELINE configs[1])"
@@ -372,15 +373,15 @@ def main():
         label = "hypersensitive OCP, n_segments=4000, poly_orders=3, LGR (BASELINE configs[4])"
     elif args.workload in ("config3-fgj", "config3-shard", "config3-hess"):
         builder, S, P, scheme = problems.BENCH_CASES[1]
-        B = min(B, 2048 if hess_mode else 512)
+        B = B if batch_given else min(B, 2048 if hess_mode else 512)
         label = "Van der Pol OCP, n_segments=2000, poly_orders=[3,30,3]*, CGL (BASELINE configs[2])"
     elif args.workload == "config4-shard":
         builder, S, P, scheme = problems.BENCH_CASES[2]
         label = "two-phase Schwartz OCP, 500 segments per phase, poly_orders=3, LGL (BASELINE configs[3])"
     if shard:  # every rank evaluates the SAME points, each its share of the segments
-        B = min(B, 16) if args.batch == 4096 else B
+        B = B if batch_given else min(B, 16)
     if loop5:  # SURVEY 8(d) config-5 protocol: widths ~ Dirichlet(1), 5 outer iterations, device resident, one context
-        B = min(B, 512) if args.batch == 4096 else B
+        B = B if batch_given else min(B, 512)
         hess_mode = True
     adaptive = args.workload == "adaptive-fgj"
     if adaptive:  # widths as decision variables, assembled context (point kernels + gather)
