@@ -265,7 +265,8 @@ int mpx_get_light_plan(const mpx_ctx* ctx, int32_t* degree, int64_t* n_groups, i
  * ([batch][n_tiles][width] doubles; entries of tiles outside the tile range are untouched -- except that the hess_l pass of a
  * MIXED-DEGREE grid writes the slots of its own node-ordered tiles, phase tile_first + k for its k-th tile of the phase: a tile
  * range maps proportionally onto them, so a rank's slots there need not lie inside its [tile_begin, tile_end), and the slots past a
- * phase's last node-ordered tile are nobody's).  Ranks exchange the slots they own (mpx_shard_table, kind 2) before the
+ * phase's last node-ordered tile are nobody's; a LIGHT pass, see mpx_get_light_plan, writes one slot per group / span, phase
+ * tile_first + index, its boundary pass sums exactly those, and the phase's other slots keep whatever they held).  Ranks exchange the slots they own (mpx_shard_table, kind 2) before the
  * MPX_BOUNDARY_ONLY pass. */
 int mpx_get_partials(mpx_ctx* ctx, int64_t batch, double** device_ptr, int64_t* count);
 

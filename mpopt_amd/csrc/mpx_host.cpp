@@ -1134,7 +1134,8 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   const bool absorb = packed && !shard && c->absorb;
   const bool by_node = mode == MPX_MODE_HESS && c->hess_by_node;
   if (light) {  // every phase: one launch of persistent wavefronts over the (group, evaluation point) items (light_body)
-    HIPCHK(c, hipMemsetAsync(io.partial, 0, (size_t)io.B * io.n_tiles_total * io.nred * 8, c->stream));  // (slots without a group stay zero)
+    // (every group / span writes its partial-sum slot, phase tile_first + index; the boundary pass of a light evaluation sums
+    // exactly those -- see below --, so the other slots need no clearing)
     static int n_cu = 0;
     if (!n_cu && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) n_cu = 256;
     for (auto& B : c->buckets) {
@@ -1244,6 +1245,8 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   if (shard ? nodes : !c->run_boundary) return MPX_OK;  // sharded: node pass and boundary pass are separate calls
   MpxBoundArgs G = bound_args_static(c);
   G.io = io;
+  if (light)  // the slots the light kernels wrote: one per group / span, in front of the phase's tile slots
+    for (int p = 0; p < c->n_phases; ++p) G.ph[p].tile_count = c->lplan.low ? c->lplan.n_low_groups : (int32_t)c->lplan.groups.size();
   return launch(c, c->fn_bound[mode], dim3((unsigned)io.B, 1, 1), dim3(256, 1, 1), &G, sizeof G);
 }
 

@@ -717,6 +717,18 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
 // ---------------------------------------------------------------------------------------------------------------------
 typedef double mpx_d4 __attribute__((ext_vector_type(4)));
 
+#ifndef MPX_LIGHT_XCD_BLOCKED
+#define MPX_LIGHT_XCD_BLOCKED 0
+#endif
+// Workgroup i of a launch runs on XCD i % 8: with MPX_LIGHT_XCD_BLOCKED=1 the workgroups of one XCD take CONSECUTIVE items of every
+// round of the persistent loop (each L2 streams a contiguous eighth of the round's rows instead of every eighth group of items), as
+// node_body's XCD-blocked walk does for the tiles.  Measured in process (tools/r4_light_ab.py): 1.5 % slower at config 2 (g: 208.5
+// against 205.1 us), 3 - 5 % slower at config 3 -- off.
+__device__ __forceinline__ unsigned light_block_xcd() {
+  if (MPX_LIGHT_XCD_BLOCKED && gridDim.x % 8 == 0) return (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+  return blockIdx.x;
+}
+
 template <int PH, int P, int MODE>
 __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
   using G = mpxgen::Phase<PH>;
@@ -770,7 +782,7 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
 #endif
   if (wave & 1)
     for (int k = 0; k < MPX_LIGHT_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-  for (int64_t item = (int64_t)blockIdx.x * MPX_LIGHT_WAVES + wave; item < total; item += stride) {
+  for (int64_t item = (int64_t)light_block_xcd() * MPX_LIGHT_WAVES + wave; item < total; item += stride) {
     MPX_LSTAMP(0)
     const int gi = (int)(item % L.n_groups), b = io.b_first + (int)(item / L.n_groups);
     const MpxLightGroup Gp = L.groups[gi];
@@ -792,20 +804,29 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
     // (1) the span's rows of X / U: coalesced loads, into LDS
     lds_sync();  // (the previous item's output reads of this buffer are done)
     {  // (ALL loads of the span are issued before the first LDS write: one round trip to memory per item, not one per batch)
-      constexpr int CH = MPX_LIGHT_CHUNKS;  // 64-node chunks a span can have (the host caps the span at 64 * CH nodes)
-      double v[NIN][CH];
+      // (16 bytes per lane; rows are only 8-byte aligned -- N is odd as often as not --, an odd row length ends with an 8-byte load)
+      constexpr int CH2 = (MPX_LIGHT_CHUNKS + 1) / 2;  // 128-node chunks a span can have (the host caps the span at 64 * MPX_LIGHT_CHUNKS nodes)
+      typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+      d2u v[NIN][CH2];
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int idx = 64 * u + l;
+      for (int u = 0; u < CH2; ++u) {
+        const int idx = 128 * u + 2 * l;
 #pragma unroll
-        for (int a = 0; a < NIN; ++a) v[a][u] = idx < Gp.len_r ? (zb + (int64_t)a * N)[Gp.lo_r + idx] : 0.0;
+        for (int a = 0; a < NIN; ++a) {
+          const double* __restrict__ src = zb + (int64_t)a * N + Gp.lo_r + idx;
+          if (idx + 1 < Gp.len_r) v[a][u] = *(const d2u*)src;
+          else v[a][u] = d2u{idx < Gp.len_r ? src[0] : 0.0, 0.0};
+        }
       }
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int idx = 64 * u + l;
+      for (int u = 0; u < CH2; ++u) {
+        const int idx = 128 * u + 2 * l;
         if (idx < Gp.len_r) {
 #pragma unroll
-          for (int a = 0; a < NIN; ++a) sW[a * cap + idx] = v[a][u];
+          for (int a = 0; a < NIN; ++a) {
+            sW[a * cap + idx] = v[a][u].x;
+            if (idx + 1 < Gp.len_r) sW[a * cap + idx + 1] = v[a][u].y;
+          }
         }
       }
     }
@@ -1093,7 +1114,7 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
 #else
 #define MPX_LSTAMP(k)
 #endif
-  for (int64_t item = (int64_t)blockIdx.x * MPX_LIGHT_WAVES + wave; item < total; item += stride) {
+  for (int64_t item = (int64_t)light_block_xcd() * MPX_LIGHT_WAVES + wave; item < total; item += stride) {
     MPX_LSTAMP(0)
     const int gi = (int)(item % n_groups), b = io.b_first + (int)(item / n_groups);
     const int lo_w = gi * OWN, len_w = N - lo_w < OWN ? N - lo_w : OWN;
