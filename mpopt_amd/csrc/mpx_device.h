@@ -98,7 +98,10 @@ struct MpxNodeArgs {
 // segments of the high degree plus every low-degree segment between them -- one contiguous span of the phase's nodes, read and
 // written with fully coalesced accesses through an LDS buffer.
 #define MPX_LIGHT_MAXDEG 8  // distinct degrees of a grid with a light plan
-#define MPX_LIGHT_CHUNKS 10 // a group's span: at most 64 * MPX_LIGHT_CHUNKS nodes (one load per lane, chunk and row, all in flight together)
+#define MPX_LIGHT_CHUNKS 10
+#ifndef MPX_LOW_MAX_CHUNKS
+#define MPX_LOW_MAX_CHUNKS 12  // 64-node chunks of a span of the low-degree light kernels (light_low_body; the host's plan uses the same cap)
+#endif // a group's span: at most 64 * MPX_LIGHT_CHUNKS nodes (one load per lane, chunk and row, all in flight together)
 struct MpxLightGroup {
   int32_t lo_r, len_r;      // nodes read: [lo_r, lo_r + len_r) (the owned span and the node before it)
   int32_t lo_w, len_w;      // nodes owned (rows written): [lo_w, lo_w + len_w)

@@ -311,7 +311,9 @@ int build_layout(mpx_ctx* c) {
     // single-degree grids of low degree (mpx_lightlow_*, light_low_body): spans of `own` nodes, the kernel's compile-time geometry
     if (!L.ok && c->degs.size() == 1 && c->degs[0].deg <= 12) {
       const int P = c->degs[0].deg, cap0 = 53248 / (8 * MPX_LIGHT_WAVES * (nx + nu));
-      const int chl = std::min(8, std::max(1, (cap0 - 2 * P - 8) / 64));
+      int max_chl = MPX_LOW_MAX_CHUNKS;
+      if (const char* e = getenv("MPX_LOW_MAX_CHUNKS")) max_chl = std::max(1, atoi(e));  // (A/B builds: kernels compiled with -DMPX_LOW_MAX_CHUNKS=n)
+      const int chl = std::min(max_chl, std::max(1, (cap0 - 2 * P - 8) / 64));
       L.low = true, L.deg = P, L.dt = 0, L.own = 64 * chl, L.span_cap = (L.own + 2 * P + 8 + 1) & ~1;
       L.n_low_groups = (int)((N + L.own - 1) / L.own);
       L.ok = chl >= 2;  // (rows of more than ~24 inputs leave one chunk per span: the node kernels do as well)

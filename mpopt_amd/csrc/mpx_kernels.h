@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
   constexpr int R_C = NX, R_DU = NX + NC, R_MU = R_DU + (G::DIFF_U ? NU : 0), NG = R_MU + (G::MIDU ? NU : 0);
   // span geometry, compile time: rows of CAP doubles per wavefront in 52 KB of LDS per workgroup; CHL chunks of 64 owned nodes
   constexpr int CAP0 = 53248 / (8 * MPX_LIGHT_WAVES * NIN);
-  constexpr int CHL = (CAP0 - 2 * P - 8) / 64 > 8 ? 8 : ((CAP0 - 2 * P - 8) / 64 < 1 ? 1 : (CAP0 - 2 * P - 8) / 64);
+  constexpr int CHL = (CAP0 - 2 * P - 8) / 64 > MPX_LOW_MAX_CHUNKS ? MPX_LOW_MAX_CHUNKS : ((CAP0 - 2 * P - 8) / 64 < 1 ? 1 : (CAP0 - 2 * P - 8) / 64);
   constexpr int OWN = 64 * CHL, CAP = (OWN + 2 * P + 8 + 1) & ~1;
   typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
   static_assert(MPX_LIGHT_WAVES * NIN * CAP * 8 <= 56 * 1024, "light_low_body: span rows do not fit LDS");

@@ -57,7 +57,7 @@ def test_low_degree_plan_structure(name):
     o = M.NlpFunctions(ocp, S, [po] * S, scheme, with_device=False)
     deg, n_groups, span, n_low = o.light_plan()
     nin = ocp.nx + ocp.nu
-    chl = min(8, max(1, (53248 // (32 * nin) - 2 * po - 8) // 64))
+    chl = min(12, max(1, (53248 // (32 * nin) - 2 * po - 8) // 64))
     assert deg == po and n_low == 0 and span == (64 * chl + 2 * po + 8 + 1) // 2 * 2
     assert n_groups == -(-o.n_nodes // (64 * chl))
     o.close()
