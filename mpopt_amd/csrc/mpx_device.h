@@ -173,6 +173,7 @@ struct MpxBoundArgs {
   const int64_t* lin_row;  // g row of each linear row
   int64_t lin_jac;         // first Jacobian value of the linear rows
   int32_t n_lin;
+  int32_t part_group;      // > 1: partial-sum slots are added in groups of this many (short-span light passes, light_low_body)
 };
 
 // nlp_grad (the sixth oracle of ca.nlpsol, mpopt.py:757): gradient of gamma = sigma * f + lam_g^T g w.r.t. x and w.r.t. the

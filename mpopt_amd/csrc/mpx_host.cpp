@@ -316,8 +316,8 @@ int build_layout(mpx_ctx* c) {
       const int chl = std::min(max_chl, std::max(1, (cap0 - 2 * P - 8) / 64));
       L.low = true, L.deg = P, L.dt = 0, L.own = 64 * chl, L.span_cap = (L.own + 2 * P + 8 + 1) & ~1;
       L.n_low_groups = (int)((N + L.own - 1) / L.own);
+      L.n_low_chunks = (int)((N + 63) / 64);  // partial-sum slots of a phase in a light pass: one per 64-node chunk
       L.ok = chl >= 2;  // (rows of more than ~24 inputs leave one chunk per span: the node kernels do as well)
-      for (int p = 0; p < c->n_phases && L.ok; ++p) L.ok = L.n_low_groups <= c->ph[p].tile_count;
     }
   }
 
@@ -716,6 +716,8 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     for (int m = 0; m < 2 && ((B.deg > 12 && B.deg <= 31) || c->lplan.low); ++m) {  // light passes (mpx_kernels.h: light_body / light_low_body)
       snprintf(name, sizeof name, "mpx_light%s_%s_%d_%d", c->lplan.low ? "low" : "", lm[m], B.phase, B.deg);
       if (hipModuleGetFunction(&B.fn_light[m], c->module, name) != hipSuccess) B.fn_light[m] = nullptr, (void)hipGetLastError();
+      snprintf(name, sizeof name, "mpx_lightlows_%s_%d_%d", lm[m], B.phase, B.deg);  // one chunk per wavefront: small batches
+      if (!c->lplan.low || hipModuleGetFunction(&B.fn_light_small[m], c->module, name) != hipSuccess) B.fn_light_small[m] = nullptr, (void)hipGetLastError();
     }
   }
   if (hipModuleGetFunction(&c->fn_gradl_fin, c->module, "mpx_gradl_finish") != hipSuccess) c->fn_gradl_fin = nullptr, (void)hipGetLastError();
@@ -1116,7 +1118,10 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   bool light = c->lplan.ok && mode != MPX_MODE_HESS && !io.jac && !shard && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() &&
                !getenv("MPX_NO_LIGHT");
   for (auto& B : c->buckets)
-    if (light && B.deg == c->lplan.deg && !B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0]) light = false;
+    if (light && B.deg == c->lplan.deg && (!B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0] || (c->lplan.low && !B.fn_light_small[mode == MPX_MODE_FGJ ? 1 : 0]))) light = false;
+  if (light && c->lplan.low) io.n_tiles_total = c->n_phases * c->lplan.n_low_chunks;  // (partial-sum slots of a light pass: [phase][64-node chunk])
+  // low-degree plan: fewer long spans than a wavefront per SIMD of the device -> one 64-node chunk per wavefront (same sums)
+  const bool light_small = light && c->lplan.low && (int64_t)c->lplan.n_low_groups * io.B < 1024 && !getenv("MPX_LIGHT_LONG_SPANS");
   const bool packed = want_g && io.B <= 65535 && !light &&
                       ((shard && !owner) || (c->g_packed && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_PACKED_G")));
   if (packed) {
@@ -1155,6 +1160,11 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       for (size_t k = 0; k < c->degs.size() && !c->lplan.low; ++k) L.fD_off[k] = c->lplan.fD_off[k], L.fC_off[k] = c->lplan.fC_off[k], L.fdeg[k] = c->degs[k].deg;
       L.ftab = c->d_lftab, L.ftab_n = (int32_t)c->lplan.ftab.size();
       L.n_groups = c->lplan.low ? c->lplan.n_low_groups : (int32_t)c->lplan.groups.size(), L.first_node = c->lplan.first_node, L.span_cap = c->lplan.span_cap, L.slot_first = P.tile_first;
+      // low-degree plan: fewer long spans than half the wavefront slots of the device -> one 64-node chunk per wavefront (same sums:
+      // the partial-sum slots are per chunk for both span lengths)
+      const bool small = light_small;
+      if (c->lplan.low) L.slot_first = B.phase * c->lplan.n_low_chunks;
+      if (small) L.n_groups = c->lplan.n_low_chunks;
       static long long* ldbg = nullptr;
       if (!ldbg && getenv("MPX_LIGHT_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
       L.dbg = ldbg;
@@ -1163,7 +1173,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       if (const char* e = getenv("MPX_LIGHT_PER_CU")) per_cu = std::max(1, atoi(e));
       const unsigned wgs = (unsigned)std::min<int64_t>((items + MPX_LIGHT_WAVES - 1) / MPX_LIGHT_WAVES, per_cu * (int64_t)n_cu);
       const unsigned lds = c->lplan.low ? 0u : (unsigned)((MPX_LIGHT_WAVES * (c->nx + c->nu) * c->lplan.span_cap + c->lplan.ftab.size()) * 8);
-      int rc = launch(c, B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0], dim3(wgs, 1, 1), dim3(64 * MPX_LIGHT_WAVES, 1, 1), &L, sizeof L, lds);
+      int rc = launch(c, (small ? B.fn_light_small : B.fn_light)[mode == MPX_MODE_FGJ ? 1 : 0], dim3(wgs, 1, 1), dim3(64 * MPX_LIGHT_WAVES, 1, 1), &L, sizeof L, lds);
       if (rc) return rc;
       if (c->profile) ++c->prof_launches;
       if (ldbg) {
@@ -1247,8 +1257,12 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   if (shard ? nodes : !c->run_boundary) return MPX_OK;  // sharded: node pass and boundary pass are separate calls
   MpxBoundArgs G = bound_args_static(c);
   G.io = io;
-  if (light)  // the slots the light kernels wrote: one per group / span, in front of the phase's tile slots
-    for (int p = 0; p < c->n_phases; ++p) G.ph[p].tile_count = c->lplan.low ? c->lplan.n_low_groups : (int32_t)c->lplan.groups.size();
+  G.part_group = light_small ? c->lplan.own / 64 : 1;
+  if (light)  // the slots the light kernels wrote: one per group in front of the phase's tile slots, or [phase][64-node chunk]
+    for (int p = 0; p < c->n_phases; ++p) {
+      if (c->lplan.low) G.ph[p].tile_first = p * c->lplan.n_low_chunks, G.ph[p].tile_count = light_small ? c->lplan.n_low_chunks : c->lplan.n_low_groups;
+      else G.ph[p].tile_count = (int32_t)c->lplan.groups.size();
+    }
   return launch(c, c->fn_bound[mode], dim3((unsigned)io.B, 1, 1), dim3(256, 1, 1), &G, sizeof G);
 }
 
@@ -1464,7 +1478,7 @@ extern "C" int mpx_get_partials(mpx_ctx* c, int64_t batch, double** ptr, int64_t
   if (!c || !ptr || !count || batch < 1) return MPX_ERR_INVALID;
   if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "context has no device code");
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred));
+  int rc = reserve(c, c->partial, (size_t)(batch * partial_slots(c) * c->nred));
   if (rc) return rc;
   *ptr = c->partial.p;
   *count = batch * (int64_t)c->tiles.size() * c->nred;
@@ -1968,7 +1982,7 @@ static int shard_copy(mpx_ctx* c, int mask, int64_t batch, double* vals, double*
   const int part_only = (mask & MPX_OWNER_RESIDENT) ? 1 : 0;
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
-  if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
+  if ((rc = reserve(c, c->partial, (size_t)(batch * partial_slots(c) * c->nred)))) return rc;
   double* gt = nullptr;
   if (!part_only && ps == 0 && (mask & (MPX_G | MPX_GRAD))) {
     if ((rc = reserve(c, c->gtmp, (size_t)(batch * c->gtmp_n)))) return rc;
@@ -2471,7 +2485,7 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
   const int64_t n_w = p_per_point ? batch : 1;
   int rc;
   if ((rc = reserve_wcum(c, (size_t)(n_w * c->n_p)))) return rc;
-  if ((rc = reserve(c, c->partial, (size_t)(batch * (int64_t)c->tiles.size() * c->nred)))) return rc;
+  if ((rc = reserve(c, c->partial, (size_t)(batch * partial_slots(c) * c->nred)))) return rc;
   // MPX_WIDTHS_UNCHANGED (or the host path's "same p"): only if the buffer really holds the prefix sums of THIS p for every phase
   if (skip_prefix && !(c->wcum_p == p && c->wcum_batch == n_w && c->wcum_ppp == (p_per_point ? 1 : 0) && c->wcum_phases == all_phases(c))) skip_prefix = false;
   if (!skip_prefix && (rc = launch_prefix(c, p, n_w, p_per_point))) return rc;
@@ -2606,7 +2620,7 @@ static int res_request(mpx_ctx* c, int mode, int ccs, const MpxIO& io, double* c
 static int res_eval(mpx_ctx* c, int mask, const double* z, const double* p, const double* lam_g, const double* sigma, double* f, double* g, double* grad_f,
                     double* jac_val, double* hess_val, bool same_p) {
   int rc;
-  if ((rc = reserve_wcum(c, (size_t)c->n_p)) || (rc = reserve(c, c->partial, (size_t)((int64_t)c->tiles.size() * c->nred)))) return rc;
+  if ((rc = reserve_wcum(c, (size_t)c->n_p)) || (rc = reserve(c, c->partial, (size_t)(partial_slots(c) * c->nred)))) return rc;
   if (!(same_p && c->wcum_p == p && c->wcum_batch == 1 && c->wcum_ppp == 0 && c->wcum_phases == all_phases(c))) {
     if ((rc = launch_prefix(c, p, 1, 0))) return rc;  // (the widths changed: rare -- an NLP solver keeps p for a whole solve)
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2702,7 +2716,10 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
       // against 101 us; profiles/r4_resident): what the device saves in launches it spends polling and fencing over PCIe
       const bool res_on = getenv("MPX_RESIDENT") != nullptr;  // (read per call: tests switch it inside one process)
       const bool resident = res_on && c->res.ok && B == 1 && c->kind == 0 && !(mask & ~(MPX_F | MPX_G | MPX_GRAD | MPX_JAC | MPX_HESS | MPX_CCS_ORDER)) &&
-                            c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_RESIDENT");
+                            c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_RESIDENT") &&
+                            // (passes the span kernels take -- no Jacobian / Hessian values, light plan -- stay with them: their f is
+                            // summed per 64-node chunk, the resident kernel's per tile)
+                            !(c->lplan.ok && !(mask & (MPX_JAC | MPX_HESS)) && !getenv("MPX_NO_LIGHT"));
       if (resident) {
         rc = res_eval(c, mask, (const double*)zd, c->st_p.p, (const double*)ld, c->h_scratch_dev + B, c->h_scratch_dev, (double*)gd, (double*)qd, (double*)jd,
                       (double*)hd, same_p);

@@ -48,7 +48,7 @@ struct Bucket {
   int32_t *d_node_i = nullptr, *d_node_sk = nullptr;
   hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
   hipFunction_t fn_gradl = nullptr;  // mpx_node_gradl_<phase>_<deg> (nlp_grad)
-  hipFunction_t fn_light[2] = {nullptr, nullptr};  // mpx_light_fg / _fgq _<phase>_<deg>: light passes on the matrix cores (12 < deg <= 31)
+  hipFunction_t fn_light[2], fn_light_small[2] = {nullptr, nullptr};  // mpx_light_fg / _fgq _<phase>_<deg>: light passes on the matrix cores (12 < deg <= 31)
 };
 
 template <class T>
@@ -109,7 +109,7 @@ struct mpx_ctx {
   // degrees <= 12.  Groups of up to 16 high-degree segments + the low-degree segments between them (the same for every phase)
   struct LightPlan {
     bool ok = false, low = false;           // low: single-degree grid of degree <= 12 (light_low_body: spans of `own` nodes)
-    int deg = 0, dt = -1, first_node = 0, span_cap = 0, own = 0, n_low_groups = 0;
+    int deg = 0, dt = -1, first_node = 0, span_cap = 0, own = 0, n_low_groups = 0, n_low_chunks = 0;
     std::vector<MpxLightGroup> groups;
     std::vector<MpxLightForeign> foreign;
     std::vector<double> ftab;               // D and C_mid of the low degrees, concatenated
@@ -246,6 +246,13 @@ inline int fail(mpx_ctx* c, int code, const char* fmt, ...) {
     if (e_ != hipSuccess)                                                                        \
       return fail(ctx, MPX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+// Doubles-per-point of the partial-sum buffer, in slots: the tiles, or -- light passes of single-degree low-degree grids -- one slot per
+// 64-node chunk of every phase (mpx_kernels.h: light_low_body), whichever is more
+inline int64_t partial_slots(const mpx_ctx* c) {
+  const int64_t low = c->lplan.ok && c->lplan.low ? (int64_t)c->n_phases * c->lplan.n_low_chunks : 0;
+  return std::max<int64_t>((int64_t)c->tiles.size(), low);
+}
 
 template <class T>
 inline int upload(mpx_ctx* c, T** dst, const std::vector<T>& v) {

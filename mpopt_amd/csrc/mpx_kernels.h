@@ -53,6 +53,26 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // lane 0 holds the total; fixed tree => deterministic
 }
 
+// The same total in EVERY lane, on the DPP path (no LDS round trips: __shfl_down is two ds_bpermute per step and double): inclusive
+// scan by row shifts and row broadcasts, then lane 63.  A fixed tree of its own (not wave_sum's): used where a sum is taken per
+// 64-node chunk inside a loop (light_low_body), eight to twelve times per item.
+__device__ __forceinline__ double wave_total_dpp(double x) {
+  auto dpp0 = [](double v, auto ctrl, auto row_mask) {
+    constexpr int C = decltype(ctrl)::value, R = decltype(row_mask)::value;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), C, R, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), C, R, 0xf, false);
+    return __hiloint2double(hi, lo);
+  };
+  using std::integral_constant;
+  x += dpp0(x, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});  // row_shr:1
+  x += dpp0(x, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});  // row_shr:2
+  x += dpp0(x, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});  // row_shr:4
+  x += dpp0(x, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});  // row_shr:8
+  x += dpp0(x, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
+  x += dpp0(x, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+
 typedef double mpx_d2 __attribute__((ext_vector_type(2)));
 
 // Scatter NS per-lane values into a tile block.  Layout of a block (n lanes, NS slots), chosen so
@@ -1077,10 +1097,12 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
 // one table barrier at kernel start.  Measured at config 2, B = 4096 (profiles/r4_lightlow): nlp_f 80.5 us (6.5 TB/s, 0.81 of
 // peak), nlp_g 182.6 us (0.70), nlp_f + nlp_grad_f 181.2 us (0.70).  What did NOT help: LDS-DMA double buffering of 256-node spans
 // (98 / 216 us), staging the outputs through LDS for 16-byte stores (83 / 197), three workgroups per compute unit (91 / 197).
-// g and the node entries of grad_f: bit-identical to node_body's.  Sums: lane (its nodes in order), wavefront tree, one
-// partial-sum slot per span.
+// g and the node entries of grad_f: bit-identical to node_body's.  Sums: wavefront total per 64-node chunk, the chunks of a long span
+// added in order, the spans added by the boundary pass in order -- and the same grouping when every chunk is its own span, so that
+// SMALL batches can run the same arithmetic with one chunk per wavefront (SMALL = true: a single evaluation keeps 79 wavefronts busy at config 2 instead of 10; with the long
+// spans a single nlp_f + nlp_g + nlp_grad_f pass took 33 instead of 22 us) and still give the bits of a large batch.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int PH, int P, int MODE>
+template <int PH, int P, int MODE, bool SMALL>
 __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
   using G = mpxgen::Phase<PH>;
   const MpxNodeArgs& A = L.node;
@@ -1090,7 +1112,7 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
   constexpr int R_C = NX, R_DU = NX + NC, R_MU = R_DU + (G::DIFF_U ? NU : 0), NG = R_MU + (G::MIDU ? NU : 0);
   // span geometry, compile time: rows of CAP doubles per wavefront in 52 KB of LDS per workgroup; CHL chunks of 64 owned nodes
   constexpr int CAP0 = 53248 / (8 * MPX_LIGHT_WAVES * NIN);
-  constexpr int CHL = (CAP0 - 2 * P - 8) / 64 > MPX_LOW_MAX_CHUNKS ? MPX_LOW_MAX_CHUNKS : ((CAP0 - 2 * P - 8) / 64 < 1 ? 1 : (CAP0 - 2 * P - 8) / 64);
+  constexpr int CHL = SMALL ? 1 : ((CAP0 - 2 * P - 8) / 64 > MPX_LOW_MAX_CHUNKS ? MPX_LOW_MAX_CHUNKS : ((CAP0 - 2 * P - 8) / 64 < 1 ? 1 : (CAP0 - 2 * P - 8) / 64));
   constexpr int OWN = 64 * CHL, CAP = (OWN + 2 * P + 8 + 1) & ~1;
   typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
   static_assert(MPX_LIGHT_WAVES * NIN * CAP * 8 <= 56 * 1024, "light_low_body: span rows do not fit LDS");
@@ -1163,9 +1185,12 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
     }
     lds_sync();
     MPX_LSTAMP(1)
-    Vec<NRED> red;
+    // Sums: wavefront total of every 64-node chunk (fixed tree); the long spans add their chunks' totals in chunk order into one
+    // partial-sum slot per span, the one-chunk spans write a slot per chunk and the boundary pass adds them in the same groups
+    // (MpxBoundArgs::part_group): both give the same bits.
+    Vec<NRED> tot;
 #pragma unroll
-    for (int r = 0; r < NRED; ++r) red[r] = 0.0;
+    for (int r = 0; r < NRED; ++r) tot[r] = 0.0;
     // The lanes of a chunk hold CONSECUTIVE nodes, so every row of g / grad_f leaves as one 512-byte store per chunk straight from
     // the registers (no staging; the mid-point rows are the same run shifted by one node)
     double* __restrict__ gb = want_g ? io.g + (int64_t)b * io.g_stride : nullptr;
@@ -1196,9 +1221,18 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
           for (int a = 0; a < NIN; ++a) qb[(int64_t)a * N + i] = gn[a];
         }
       }
-      if (valid) {
+      // sums: one partial-sum slot per CHUNK of 64 nodes (chunk index in the phase), wavefront tree over the chunk's nodes -- the
+      // same slots and the same additions for every span length, so the short-span and the long-span kernels agree bit for bit
+      if (64 * u < len_w) {
 #pragma unroll
-        for (int r = 0; r < NRED; ++r) red[r] += gr[r];
+        for (int r = 0; r < NRED; ++r) {
+          const double v = wave_total_dpp(valid ? gr[r] : 0.0);
+          if constexpr (SMALL) {
+            if (l == 0) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + (lo_w >> 6)) * io.nred + r] = v;
+          } else {
+            tot[r] = u == 0 ? 0.0 + v : tot[r] + v;
+          }
+        }
       }
       if (want_g) {
         double dx[NX > 0 ? NX : 1], du[NU > 0 ? NU : 1], mu[NU > 0 ? NU : 1];
@@ -1248,10 +1282,11 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
       }
     }
     MPX_LSTAMP(2)
+    if constexpr (!SMALL) {
+      if (l == 0) {
 #pragma unroll
-    for (int r = 0; r < NRED; ++r) {
-      const double v = wave_sum(red[r]);
-      if (l == 0) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + gi) * io.nred + r] = v;
+        for (int r = 0; r < NRED; ++r) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + gi) * io.nred + r] = tot[r];
+      }
     }
     MPX_LSTAMP(3)
 #ifdef MPX_LIGHT_STAMPS
@@ -1486,13 +1521,46 @@ __device__ __forceinline__ void boundary_phase(const MpxBoundArgs& A, int b, int
     const int nred = io.nred, total = (MODE == MPX_MODE_HESS ? P.tile_count_h : P.tile_count) * nred;
     const int per = (256 / nred) * nred;  // whole tiles per chunk
     double s = 0;
-    for (int c0 = 0; c0 < total; c0 += per) {
-      const int cnt = total - c0 < per ? total - c0 : per;
-      if (l < cnt) sPart[l] = pp[c0 + l];
+    // > 1: the slots are added in GROUPS of glen -- a short-span light pass (light_low_body): the sum of a group is what a long span
+    // writes into its one slot, so both passes give the same bits.  The groups are independent: lane (group, column) adds its glen
+    // slots, then the NRED summing lanes add the group sums in order (8 + 24 dependent additions instead of 188 at config 5).
+    const int glen = A.part_group;
+    const int n_grp = glen > 1 ? (total / nred + glen - 1) / glen : 0;
+    if (glen > 1 && glen <= MPX_LOW_MAX_CHUNKS && n_grp * nred <= 256) {
+      if (l < n_grp * nred) {
+        const int g = l / nred, r = l - g * nred, cnt = total / nred - g * glen < glen ? total / nred - g * glen : glen;
+        double v[MPX_LOW_MAX_CHUNKS];
+#pragma unroll
+        for (int c = 0; c < MPX_LOW_MAX_CHUNKS; ++c) v[c] = c < cnt ? pp[(g * glen + c) * nred + r] : 0.0;  // (all loads in flight together)
+        double tg = 0;
+#pragma unroll
+        for (int c = 0; c < MPX_LOW_MAX_CHUNKS; ++c)
+          if (c < cnt) tg += v[c];
+        sPart[l] = tg;
+      }
       __syncthreads();
       if (l < NRED)
-        for (int e = l; e < cnt; e += nred) s += sPart[e];
-      __syncthreads();
+        for (int g = 0; g < n_grp; ++g) s += sPart[g * nred + l];
+    } else {
+      double tg = 0;
+      int in_group = 0;
+      for (int c0 = 0; c0 < total; c0 += per) {
+        const int cnt = total - c0 < per ? total - c0 : per;
+        if (l < cnt) sPart[l] = pp[c0 + l];
+        __syncthreads();
+        if (l < NRED) {
+          if (glen > 1) {
+            for (int e = l; e < cnt; e += nred) {
+              tg += sPart[e];
+              if (++in_group == glen) s += tg, tg = 0, in_group = 0;
+            }
+          } else {
+            for (int e = l; e < cnt; e += nred) s += sPart[e];
+          }
+        }
+        __syncthreads();
+      }
+      if (in_group) s += tg;
     }
     if (l < NRED) red[l] = s;
   }
@@ -2006,10 +2074,16 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
 #define MPX_LOW_WPS(PH) 2
 #define MPX_INSTANTIATE_LIGHT_LOW(PH, P)                                                                                      \
   extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(PH)) void mpx_lightlow_fg_##PH##_##P(const MpxLightArgs A) {    \
-    mpxk::light_low_body<PH, P, MPX_MODE_FG>(A);                                                                              \
+    mpxk::light_low_body<PH, P, MPX_MODE_FG, false>(A);                                                                       \
   }                                                                                                                           \
   extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(PH)) void mpx_lightlow_fgq_##PH##_##P(const MpxLightArgs A) {   \
-    mpxk::light_low_body<PH, P, MPX_MODE_FGJ>(A);                                                                             \
+    mpxk::light_low_body<PH, P, MPX_MODE_FGJ, false>(A);                                                                      \
+  }                                                                                                                           \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(PH)) void mpx_lightlows_fg_##PH##_##P(const MpxLightArgs A) {   \
+    mpxk::light_low_body<PH, P, MPX_MODE_FG, true>(A);                                                                        \
+  }                                                                                                                           \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(PH)) void mpx_lightlows_fgq_##PH##_##P(const MpxLightArgs A) {  \
+    mpxk::light_low_body<PH, P, MPX_MODE_FGJ, true>(A);                                                                       \
   }
 
 #define MPX_INSTANTIATE_GRADL(PH, P)                                                                        \

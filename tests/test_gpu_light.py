@@ -129,3 +129,30 @@ def test_light_kernels_against_node_kernels_and_oracle(name):
     assert np.abs(r["g"] - go).max() <= 1e-10 * max(1.0, np.abs(go).max())
     assert_entries(r["grad_f"], O.grad_f(Z[0], p), 1e-10, what=f"{name} grad_f (light) vs numpy oracle")
     o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(LOW_CASES))
+def test_short_and_long_spans_give_the_same_bits(name, monkeypatch):
+    """Small batches run one 64-node chunk per wavefront (mpx_lightlows_*), large ones spans of up to 12 chunks (mpx_lightlow_*); the
+    partial-sum slots are per chunk in both, so f and the (t0, tf, a) entries of grad_f -- the sums -- agree bit for bit: a single
+    evaluation with the long spans forced (MPX_LIGHT_LONG_SPANS=1), and a point inside a batch large enough to take them by itself."""
+    ocp, mpo, o = build(LOW_CASES[name])
+    rng = np.random.default_rng(9)
+    n_groups = o.light_plan()[1]
+    B = -(-1100 // n_groups)  # (4 * 256 compute units / n_groups is where the library switches)
+    z0 = mpo.initialize_solution()
+    Z = z0[None, :] * (1 + 0.02 * rng.uniform(-1, 1, (B, o.n_z))) + 0.02 * rng.uniform(-1, 1, (B, o.n_z))
+    w = rng.uniform(0.5, 1.5, (ocp.n_phases, o.n_segments))
+    p = (w / w.sum(1, keepdims=True)).ravel()
+    for mask in (["f"], ["f", "g"], ["f", "grad_f"], ["f", "g", "grad_f"]):
+        big = o.eval(mask, Z, p)
+        for b_ in (0, B // 2, B - 1):
+            one = o.eval(mask, Z[b_], p)
+            monkeypatch.setenv("MPX_LIGHT_LONG_SPANS", "1")
+            forced = o.eval(mask, Z[b_], p)
+            monkeypatch.delenv("MPX_LIGHT_LONG_SPANS")
+            for k in mask:
+                assert np.array_equal(np.asarray(one[k]), np.asarray(big[k][b_])), (name, mask, k, b_)
+                assert np.array_equal(np.asarray(one[k]), np.asarray(forced[k])), (name, mask, k, b_, "forced long spans")
+    o.close()
