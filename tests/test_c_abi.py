@@ -203,8 +203,10 @@ def test_nlpsol_like_caller_runs_ipopt_call_sequence_on_the_gpu(name, tmp_path):
     refj = o.eval(["jac_g"], Z, p, ccs_order=True)
     refh = o.eval(["hess_l"], Z, p, lam_g=lam, sigma=sig, ccs_order=True)
     small = o.nnz_jac * 8 <= 65536
-    if small:  # the fused pass includes the Jacobian: same kernel launch as this mask
+    if small:  # the fused pass includes the Jacobian: same kernel launch as this mask (a HEAVY pass: its f is summed per tile, a light
+        # pass's per 64-node chunk -- the same value to rounding; which pass serves nlp_f is the same-iterate cache's choice)
         refj = o.eval(["f", "g", "grad_f", "jac_g"], Z, p, ccs_order=True)
+        ref = refj
     for k in range(K):
         f, g, gr, jv, hv = vals[k, 0], vals[k, 1:1 + o.n_g], vals[k, 1 + o.n_g:1 + o.n_g + o.n_z], vals[k, 1 + o.n_g + o.n_z:per - o.nnz_hess], vals[k, per - o.nnz_hess:]
         assert f == ref["f"][k] and np.array_equal(g, ref["g"][k]) and np.array_equal(gr, ref["grad_f"][k]), k

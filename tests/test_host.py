@@ -237,6 +237,14 @@ def test_assembled_context_structure_without_gpu():
         assert (np.diff(jc[perm]) >= 0).all()  # perm sorts the source-major stored order into compressed-column order
         with pytest.raises(M.MpxError):
             orc.eval(["f"], G["z"], None)
+        # the term offsets of every point set that the generated source holds as compile-time constants (mpxgen::SetT, fused kernels)
+        # are the running sums of the ELL term counts the host receives
+        assert f"#define MPX_FUSE_SETS {len(orc.sets)}" in orc.source
+        for k, (s_, e) in enumerate(zip(orc.sets, orc._ell)):
+            fid, lt, mt = orc._set_consts[k]
+            assert fid == orc.functions.index(s_.fn) and lt[0] == 0 and mt[0] == 0
+            assert np.array_equal(np.diff(lt), np.asarray(e[0][0])) and np.array_equal(np.diff(mt), np.asarray(e[1][0]))
+            assert f"template <> struct SetT<{k}>" in orc.source and "{" + ", ".join(str(int(x)) for x in lt) + "}" in orc.source
         orc.close()
 
 
