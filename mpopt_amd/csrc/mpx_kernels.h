@@ -47,7 +47,12 @@ struct Vec {
   __device__ __forceinline__ operator double*() { return v; }
 };
 
+__device__ __forceinline__ double wave_total_dpp(double x);
+#ifndef MPX_WAVE_SUM_DPP
+#define MPX_WAVE_SUM_DPP 0
+#endif
 __device__ __forceinline__ double wave_sum(double v) {
+  if (MPX_WAVE_SUM_DPP) return wave_total_dpp(v);  // (A/B: another fixed tree, no LDS round trips)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;  // lane 0 holds the total; fixed tree => deterministic

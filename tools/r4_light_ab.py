@@ -22,9 +22,13 @@ Z = torch.tensor(mpo.initialize_solution()[None, :] * (1 + 0.01 * rng.uniform(-1
 p = torch.tensor(np.full(o.n_p, 1.0 / S), device=dev)
 f = torch.empty(B, dtype=torch.float64, device=dev); g = torch.empty(B, o.n_g, dtype=torch.float64, device=dev); q = torch.empty(B, o.n_z, dtype=torch.float64, device=dev)
 print(builder.__name__, S, "B", B, "plan", o.light_plan())
-for name, mask in (("f", 1), ("g", 2), ("f+grad_f", 5)):
-    args = (mask, B, Z, p, 0, None, None, f if mask & 1 else None, g if mask & 2 else None, q if mask & 4 else None, None, None)
-    byt = 8 * B * (o.n_z + (o.n_g if mask & 2 else 0) + (o.n_z if mask & 4 else 0))
+lam = torch.tensor(rng.standard_normal((B, o.n_g)), device=dev); sig = torch.ones(B, dtype=torch.float64, device=dev)
+heavy = os.environ.get("HEAVY")  # HEAVY=1: the passes with the Jacobian / Hessian values instead of the light ones
+jv = torch.empty(B, o.nnz_jac, dtype=torch.float64, device=dev) if heavy else None
+hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev) if heavy else None
+for name, mask in ((("f+g+grad_f+jac_g", 15), ("hess_l", 16)) if heavy else (("f", 1), ("g", 2), ("f+grad_f", 5))):
+    args = (mask, B, Z, p, 0, lam, sig, f if mask & 1 else None, g if mask & 2 else None, q if mask & 4 else None, jv if mask & 8 else None, hv if mask & 16 else None)
+    byt = 8 * B * (o.n_z + (o.n_g if mask & 2 else 0) + (o.n_z if mask & 4 else 0) + (o.nnz_jac if mask & 8 else 0) + (o.n_g + o.nnz_hess if mask & 16 else 0))
     res, outs = [[] for _ in ctx], []
     for rnd in range(6):
         for k, (_, ok) in enumerate(ctx):
@@ -32,7 +36,7 @@ for name, mask in (("f", 1), ("g", 2), ("f+grad_f", 5)):
             ok.sync(); ok.timer_start()
             for _ in range(30): ok.eval_device(*args)
             res[k].append(ok.timer_stop() / 30 * 1e3)
-            if rnd == 0: outs.append((g.clone(), q.clone(), f.clone()))
+            if rnd == 0: outs.append((g.clone(), q.clone(), f.clone()) + ((jv.clone(), hv.clone()) if heavy else ()))
     for k, fl in enumerate(flags):
         same = all(torch.equal(a, b) for a, b in zip(outs[k], outs[0]))
         med = sorted(res[k])[len(res[k]) // 2]
