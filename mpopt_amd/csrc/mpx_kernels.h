@@ -47,20 +47,8 @@ struct Vec {
   __device__ __forceinline__ operator double*() { return v; }
 };
 
-__device__ __forceinline__ double wave_total_dpp(double x);
-#ifndef MPX_WAVE_SUM_DPP
-#define MPX_WAVE_SUM_DPP 0
-#endif
-__device__ __forceinline__ double wave_sum(double v) {
-  if (MPX_WAVE_SUM_DPP) return wave_total_dpp(v);  // (A/B: another fixed tree, no LDS round trips)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;  // lane 0 holds the total; fixed tree => deterministic
-}
-
-// The same total in EVERY lane, on the DPP path (no LDS round trips: __shfl_down is two ds_bpermute per step and double): inclusive
-// scan by row shifts and row broadcasts, then lane 63.  A fixed tree of its own (not wave_sum's): used where a sum is taken per
-// 64-node chunk inside a loop (light_low_body), eight to twelve times per item.
+// The wavefront's total in EVERY lane, on the DPP path (no LDS round trips): inclusive scan by row shifts and row broadcasts, then
+// lane 63.  A fixed tree.
 __device__ __forceinline__ double wave_total_dpp(double x) {
   auto dpp0 = [](double v, auto ctrl, auto row_mask) {
     constexpr int C = decltype(ctrl)::value, R = decltype(row_mask)::value;
@@ -76,6 +64,19 @@ __device__ __forceinline__ double wave_total_dpp(double x) {
   x += dpp0(x, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
   x += dpp0(x, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+#ifndef MPX_WAVE_SUM_DPP
+#define MPX_WAVE_SUM_DPP 1
+#endif
+// Sum over the wavefront, lane 0 (at least) holds the total; a fixed tree => deterministic.  On the DPP path since round 4
+// (wave_total_dpp above): the __shfl_down tree is two ds_bpermute per step and double, twelve dependent LDS round trips per sum --
+// config 2 f+g+grad_f+jac_g 1021 -> 1003 us per 4096 points, config 5 142 -> 138 us per 512 in process (tools/r4_light_ab.py HEAVY=1;
+// -DMPX_WAVE_SUM_DPP=0 restores the old tree, whose sums differ in the last place).
+__device__ __forceinline__ double wave_sum(double v) {
+  if (MPX_WAVE_SUM_DPP) return wave_total_dpp(v);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
 }
 
 typedef double mpx_d2 __attribute__((ext_vector_type(2)));
@@ -1069,17 +1070,11 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
                  [&](int r) -> double* { return qb + (int64_t)r * N + Gp.lo_r; }, [&](int) { return 0; });
       }
     }
-    // (6) the point's sums over this group: the lane's nodes in order, the four lane groups of a segment, the segments (fixed
-    // tree), then the low-degree nodes (wave tree)
+    // (6) the point's sums over this group: the lane's nodes in order, then the wavefront's fixed tree (wave_sum) over the lanes of
+    // the high-degree nodes and over those of the low-degree nodes
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
-      double v = red[r];
-      v += __shfl_down(v, 32, 64);
-      v += __shfl_down(v, 16, 64);
-      v += __shfl_down(v, 8, 64);
-      v += __shfl_down(v, 4, 64);
-      v += __shfl_down(v, 2, 64);
-      v += __shfl_down(v, 1, 64);
+      const double v = wave_sum(red[r]);
       const double fs = wave_sum(fred[r]);
       if (l == 0) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + gi) * io.nred + r] = v + fs;
     }
