@@ -255,7 +255,9 @@ const char* mpx_get_notes(const mpx_ctx* ctx);
  * and the (t0, tf, a) entries of grad_f (sums over all nodes) are summed in another fixed order and may differ in the last place
  * from the heavy passes'.  Which kernels run never depends on the batch size.  Single-degree grids of degree <= 12 have the
  * same scheme without the matrix cores (mpx_lightlow_*): spans of 64 * CHL consecutive nodes per wavefront (CHL <= 12 from the LDS
- * budget of the span rows), rows of g / grad_f stored straight from the registers.  This query reports the plan: degree = 0 when
+ * budget of the span rows), rows of g / grad_f stored straight from the registers; their sums are defined per 64-node chunk (chunks of
+ * a span in order, spans in order), and batches of fewer than 1024 spans run one chunk per wavefront with the same additions, so a
+ * result never depends on the batch size it was computed in (MPX_LIGHT_LONG_SPANS=1: long spans always).  This query reports the plan: degree = 0 when
  * the grid has none, else the high degree (n_groups = groups of <= 16 high-degree segments, n_low_degree_nodes = nodes evaluated by
  * lanes) or the single low degree (n_groups = spans per phase, max_span_nodes = LDS row length, n_low_degree_nodes = 0); structure
  * only: works without a device.  MPX_NO_LIGHT=1 (environment, read per call) switches the light kernels off. */
