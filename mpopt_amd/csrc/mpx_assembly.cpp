@@ -116,8 +116,7 @@ __global__ __launch_bounds__(256) void mpx_gather_kernel(const MpxGatherArgs A) 
       const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride;
       double s = 0;
       for (int64_t e = e0 + lane; e < e1; e += 64) s = fma(A.coef[e], gather_value(A.src[e], rb, zb), s);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+      s = mpx_wave_total(s);
       if (lane == 0) out[(int64_t)b * stride + local] = s;
     }
     return;

@@ -756,8 +756,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 #pragma unroll
             for (int t = 0; t < TL; ++t)
               if (lidx[r][t] >= 0) s = fma(lcf[r][t], V[u][lidx[r][t]], s);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+            s = mpx_wave_total(s);
             if (lane == 0) {
               double* op = out_of(row, b0 + u);
               if (op) *op = s;
@@ -772,8 +771,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
         for (int u = 0; u < nu; ++u) {
           double s = 0;
           for (int64_t e = e0 + lane; e < e1; e += 64) s = fma(A.coef[e], V[u][A.idx[e]], s);
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+          s = mpx_wave_total(s);
           if (lane == 0) {
             double* op = out_of(row, b0 + u);
             if (op) *op = s;
@@ -786,8 +784,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
         const int64_t e0 = A.ptr[row], e1 = A.ptr[row + 1];
         double s = 0;
         for (int64_t e = e0 + lane; e < e1; e += 64) s = fma(A.coef[e], V[u][A.idx[e]], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        s = mpx_wave_total(s);
         if (lane == 0) {
           double* op = out_of(row, b0 + u);
           if (op) *op = s;

@@ -401,4 +401,31 @@ struct MpxFusedArgs {
   const double* m_dict;
   int32_t n_ldict, n_mdict;
 };
+
+#if defined(__HIPCC__)
+// Wavefront total of a double in every lane, on the DPP path (inclusive scan by row shifts and row broadcasts, then lane 63): a
+// fixed tree without LDS round trips -- the long rows of assembled contexts (one wavefront per row: mpx_gather_kernel and the fused
+// kernels use the SAME tree so that both paths stay bit-identical) were reduced by a __shfl_down tree, twelve ds_bpermute per sum.
+#ifndef MPX_ASM_SUM_DPP
+#define MPX_ASM_SUM_DPP 1
+#endif
+#define MPX_DPP_STEP_(x, CTRL, ROWS)                                                                         \
+  x += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWS, 0xf, false),         \
+                        __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWS, 0xf, false))
+__device__ __forceinline__ double mpx_wave_total(double x) {
+#if MPX_ASM_SUM_DPP
+  MPX_DPP_STEP_(x, 0x111, 0xf);  // row_shr:1
+  MPX_DPP_STEP_(x, 0x112, 0xf);  // row_shr:2
+  MPX_DPP_STEP_(x, 0x114, 0xf);  // row_shr:4
+  MPX_DPP_STEP_(x, 0x118, 0xf);  // row_shr:8
+  MPX_DPP_STEP_(x, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  MPX_DPP_STEP_(x, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+#else
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  return __shfl(x, 0, 64);
+#endif
+}
+#endif
+
 #endif
