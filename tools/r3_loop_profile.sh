@@ -41,7 +41,8 @@ PY
 MPX_LIB_HIPCC_FLAGS=-DMPX_EA_STAMPS python -c "
 from mpopt_amd import _lib
 _lib.build_library(force=True)"
-MPX_EA_DEBUG=1 timeout 300 python bench.py $W --steps 3 --warmup 1 2>&1 | grep -A1 "equal_area phases" | tail -4 > $out/phase_stamps.txt; cat $out/phase_stamps.txt
+# (the same flags on the run: the library is rebuilt whenever MPX_LIB_HIPCC_FLAGS changes)
+MPX_LIB_HIPCC_FLAGS=-DMPX_EA_STAMPS MPX_EA_DEBUG=1 timeout 300 python bench.py $W --steps 3 --warmup 1 2>&1 | grep -A1 "equal_area phases" | tail -4 > $out/phase_stamps.txt; cat $out/phase_stamps.txt
 python -c "
 from mpopt_amd import _lib
 _lib.build_library(force=True)"
