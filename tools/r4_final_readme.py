@@ -1,0 +1,78 @@
+"""profiles/r4_final/README.md from the files tools/r4_evidence.sh left there.  python tools/r4_final_readme.py"""
+import csv, json, os
+R = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r4_final") + "/"
+bl = lambda f: json.load(open(R + f))
+rows = []
+for f, label in (("bench_line_default.json", "headline: config 2 f+g+grad_f+jac_g, B=4096 (this box)"),
+                 ("earlier_run_fast_box/bench_line_default.json", "same, an earlier run of the round on another box"),
+                 ("bench_line_config2-hess.json", "config 2 hess_l"), ("bench_line_config3-fgj.json", "config 3 f+g+grad_f+jac_g (B=512)"),
+                 ("bench_line_config3-hess.json", "config 3 hess_l"), ("bench_line_config5-hess.json", "config 5 hess_l"),
+                 ("bench_line_config5-loop.json", "config-5 loop, B=512"), ("bench_line_config5-loop_B2048.json", "config-5 loop, B=2048"),
+                 ("bench_line_config5-loop_B4096.json", "config-5 loop, B=4096"), ("bench_line_adaptive-fgj.json", "mpopt_adaptive 20x5 f+g+grad_f+jac_g, B=4096"),
+                 ("bench_line_2ranks_gloo_self_launched.json", "python bench.py --gpus 2 (self-launched, gloo, two ranks on ONE GPU)")):
+    if not os.path.exists(R + f):
+        continue
+    d = bl(f); r = d["roofline"]
+    ratio = ("%.3f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])) if r.get("traffic") else "—"
+    rows.append(f"| {label} | {d['value']:.4g} {d['unit'].split(' (')[0]} | {d['ms_per_step'] * 1000:.1f} | {r['frac']:.3f} | {ratio} | `{f}` |")
+light = []
+for d_, label in (("c2_light_f", "config 2 nlp_f"), ("c2_light_g", "config 2 nlp_g"), ("c2_light_f_grad_f", "config 2 nlp_f + nlp_grad_f"),
+                  ("c3_light_f", "config 3 nlp_f (B=512)"), ("c3_light_g", "config 3 nlp_g"), ("c3_light_f_grad_f", "config 3 nlp_f + nlp_grad_f")):
+    t = json.load(open(R + d_ + "/traffic.json")); b = json.load(open(R + d_ + "/bench_line.json")); ks = list(csv.DictReader(open(R + d_ + "/kernel_stats.csv")))[0]
+    kus = float(ks["AverageNs"]) / 1000
+    light.append(f"| {label} | `{ks['Name']}` {kus:.1f} | {b['ms_per_step'] * 1000:.1f} | {t['algorithmic_bytes_per_launch'] / kus / 1e6 / 8:.3f} | {b['roofline']['frac']:.3f} | {t['traffic_over_algorithmic']:.3f} | `{d_}/` |")
+ii = bl("bench_line_default.json")
+ab = open(R + "adaptive_ab.txt").read().strip() if os.path.exists(R + "adaptive_ab.txt") else ""
+txt = f"""# r4_final — round-4 evidence (`tools/r4_evidence.sh`, one GPU call; MI355X, ROCm 7.2)
+
+Every directory: `bench_line.json` (the bench line of the workload), `kernel_stats.csv` (`rocprofv3 --kernel-trace --stats` of the same
+command), `pmc_fetch_size.csv` / `pmc_write_size.csv` (separate `rocprofv3 --pmc` passes), `traffic.json` (2 × FETCH_SIZE + WRITE_SIZE per
+launch against the algorithmic bytes, corrections per MI355X_MICROARCH.md).  `gpu_tests_full_suite.log`: `pytest tests -m gpu` of the
+tree at the end of the round (236 passed) with the per-entry parity summary by entry class.  (This file: `tools/r4_final_readme.py`.)
+
+| workload | value | µs per step | roofline.frac (of 8 TB/s) | PMC traffic / algorithmic | file |
+|---|---|---|---|---|---|
+""" + "\n".join(rows) + """
+
+The headline varies by box and by where the driver places the output arrays (DESIGN §5: 0.68–0.80 this round, same kernels on
+different boxes; `earlier_run_fast_box/` keeps a line and the profile of the fast kind).
+
+## Light passes (no Jacobian values: what a line search calls)
+
+| pass | dominant kernel, µs | whole pass µs (prefix + kernel + boundary) | frac, kernel alone | frac, whole pass | traffic / algorithmic | dir |
+|---|---|---|---|---|---|---|
+""" + "\n".join(light) + f"""
+
+Round 3 (node kernels): config 2 nlp_f / nlp_g / f+grad_f 157 / 232 / 260 µs per pass; config 3 124 / 380 / 266 µs.
+`lightlow_check.txt`: the span kernels against the node kernels (`MPX_NO_LIGHT=1`) on seven grids — g and the node entries of grad_f bit
+for bit — and the pass times of both at B = 4096 for configs 2, 4, 5.
+
+## Assembled contexts (`mpopt_adaptive`)
+
+`adaptive/` (bench line, PMC traffic, kernel stats) and `adaptive_ab.txt` = in-process A/B of this round's switches on the same arrays
+(`tools/r4_adaptive_ab.py`):
+
+```
+{ab}
+```
+
+## Config-5 loop
+
+`config5_loop/` (kernel stats, per-kernel PMC traffic of one outer iteration, bench lines of the three call sequences, phase stamps of
+the equal-area kernel); lines at B = 2048 / 4096 beside the default B = 512: the three kernel boundaries of an iteration are per launch
+(DESIGN §9).
+
+## Single evaluations (`bench_line_default.json` → `ipopt_iter*`)
+
+config 2: {ii['ipopt_iter']['us_per_iter']:.1f} µs per IPOPT iteration (CPU port {ii['ipopt_iter']['cpu_port_us_per_iter']:.0f}), per call {ii['ipopt_iter']['per_call_us']};
+config 0: {ii['ipopt_iter_config0']['us_per_iter']:.1f} µs; config 4: {ii['ipopt_iter_config4']['us_per_iter']:.1f} µs.
+
+## Every oracle x config x batch size
+
+`../r4_report.md` (`tools/report.py`, one box): per-oracle wall time per call for B = 1 ... 4096 on device pointers, B = 1 through host
+pointers, all six configurations.  Against `../r3_report.md`: the light oracles are faster at EVERY batch size (config 2 nlp_f: 15.3 → 13.3
+µs at B = 64, 29.2 → 22.9 at 512, 173.6 → 103.1 at 4096; config 5 nlp_grad_f 515 → 366 at 4096), the heavy ones within box spread.
+`../r4_soak.md`: 46 grids through the light-kernel soak (`tools/r4_light_soak.py`), no mismatch.
+"""
+open(R + "README.md", "w").write(txt)
+print(txt[:1500])
