@@ -2021,6 +2021,12 @@ namespace {
 #define MPX_EA_THREADS 1024
 #define MPX_EA_PF 12  // residual samples a lane can prefetch for the next evaluation point (n <= 12 * 1024)
 #define MPX_EA_WR 4   // new segment boundaries per lane in the fast kernel (S <= 4 * 1024)
+#ifndef MPX_EA_SLICES
+#define MPX_EA_SLICES 4  // 1 ... 4: slices the prefetch of the next point is requested in (fast kernel, scalar residuals)
+#endif
+#ifndef MPX_EA_COND_PREFETCH
+#define MPX_EA_COND_PREFETCH 0  // 1: the guarded prefetch of round 3 (A/B: MPX_LIB_HIPCC_FLAGS=-DMPX_EA_COND_PREFETCH=1)
+#endif
 // Generic kernel: vector residuals, sample lists of any length (cumulative areas in LDS when they fit, else in HBM scratch), any
 // number of phases.  One workgroup per evaluation point.
 __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const double* __restrict__ resid, int64_t n, int nx, const double* __restrict__ p_in,
@@ -2125,6 +2131,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const do
 //  * the exclusive prefix sums of the new widths -- what mpx_prefix_kernel would compute from p_out, same additions in the same
 //    order (prefix_scan_block) -- are left in `wcum`, so that the next evaluation needs no prefix launch (MPX_WIDTHS_UNCHANGED).
 // Same rule, same searches (first j with cum[j] >= target) as the generic kernel; the cumulative sums associate differently.
+template <bool SCALAR>
 __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(const double* __restrict__ resid, int n, const double* __restrict__ p_in,
                                                                   double* __restrict__ p_out, int64_t p_stride_in, int64_t p_stride_out, int S,
                                                                   double damping, double* __restrict__ wcum, int64_t wcum_stride, int B, int chunk,
@@ -2146,12 +2153,18 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
   int* __restrict__ jmap = reinterpret_cast<int*>(pos);  // [WR * NT] first-target marks: live between the area scan and the boundaries
   __shared__ int wave_j[NT / 64];
   double pf[PF];
-  auto fetch = [&](int b, int l) {  // (indices clamped, not predicated: the loads of one point are issued back to back)
+  // The prefetch must reach its use without a control-flow merge in between: with `if (next point exists) fetch(...)`, a run-time
+  // `nx == 1` and a guard per load the fetched values met the old ones in phi nodes, the register allocator resolved those with
+  // copies right behind the loads, and a copy reads its source -- s_waitcnt vmcnt(0) two instructions after the last load was
+  // issued: the whole fetch was exposed at every point of a batch (16.8 us per point against 9.8 us of phases).  So: SCALAR is a
+  // template parameter, every lane issues all PF loads (indices clamped to the last sample: the surplus ones of a short sample
+  // list hit one line), and the last point of a workgroup fetches itself again.
+  auto fetch = [&](int b, int l, int k0 = 0, int k1 = PF) {  // (k0, k1: literals at the call sites)
     const double* __restrict__ r = resid + (int64_t)b * n * nx;
-    if (nx == 1) {
+    if constexpr (SCALAR) {
 #pragma unroll
       for (int k = 0; k < PF; ++k)
-        if (k * NT < n) pf[k] = r[min(k * NT + l, m)];
+        if (k >= k0 && k < k1 && (!MPX_EA_COND_PREFETCH || k * NT < n)) pf[k] = r[min(k * NT + l, m)];
     } else {  // vector residuals: the 2-norm of a sample, accumulated like the generic kernel's (fma over the components, then sqrt)
 #pragma unroll
       for (int k = 0; k < PF; ++k)
@@ -2163,7 +2176,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
         }
     }
   };
-  if ((int)blockIdx.x < B) fetch(blockIdx.x, threadIdx.x);
+  fetch(min((int)blockIdx.x, B - 1), threadIdx.x);  // (the host launches at most B workgroups)
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     // (the lane id is opaque per point: everything derived from it is recomputed here with a few integer operations instead of
     // being hoisted out of the loop into registers the 128-VGPR budget of a 1024-lane workgroup does not have)
@@ -2175,7 +2188,14 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
       if (k * NT < n) cum[phys(k * NT + l)] = fabs(pf[k]);  // (slots past sample m are never read: the host sized the rows for them)
     reinterpret_cast<int4*>(jmap)[l] = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);  // (the boundaries of the previous point are spent)
     __syncthreads();
-    if (b + (int)gridDim.x < B) fetch(b + gridDim.x, l);  // in flight during the scan and the search of this point
+    // Scalar residuals: the next point's samples are requested in MPX_EA_SLICES slices, one behind each of the first phases.  All
+    // workgroups of the launch pass through the same phase at the same time: requested at once, the 25 MB of a round of 256 points
+    // met an idle memory system, filled the compute units' request queues and held every wavefront at its load instructions until
+    // HBM had delivered (stamps at B = 2048: the phase behind the fetch 2.2 -> 5.5 us).
+    constexpr int SL = SCALAR && !MPX_EA_COND_PREFETCH ? MPX_EA_SLICES : 1, PS = (PF + SL - 1) / SL;
+    const int b_next = min(b + (int)gridDim.x, B - 1);
+    if constexpr (SCALAR && !MPX_EA_COND_PREFETCH) fetch(b_next, l, 0, PS);  // in flight during the scan and the search of this point
+    else if (b + (int)gridDim.x < B) fetch(b + gridDim.x, l);
     double pin[WR];  // the lane's old widths: requested now, used after the search
     {
       const double* __restrict__ pi_ = p_in + (int64_t)b * p_stride_in + seg_off;
@@ -2205,6 +2225,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
     const double inc = wave_scan_inclusive(tot);
     if ((l & 63) == 63) wave_tot[l >> 6] = inc;
     __syncthreads();  // (also: every lane has read its `first`)
+    if constexpr (SL > 1) fetch(b_next, l, PS, 2 * PS);
     double off = wave_shift_up_1(inc);
     double total = 0;
 #pragma unroll
@@ -2224,6 +2245,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
     if (l == 0) cum[0] = 0.0;
     if (cnt > 0 && i0 + cnt == m) cum[cnt < chunk ? row + cnt : last] = 1.0;  // (the reference divides by the last entry: exactly 1 there)
     __syncthreads();
+    if constexpr (SL > 2) fetch(b_next, l, 2 * PS, 3 * PS);
     MPX_EA_STAMP(3);
     // New boundaries without a search.  kc(j) = number of targets T_s = (s + 1) / S not above cum[j] is a product and a floor
     // (an fma and a division settle the rare products within rounding of an integer); sample j is the first one at or above T_s
@@ -2255,6 +2277,7 @@ __global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(con
     }
     MPX_EA_STAMP(7);
     __syncthreads();
+    if constexpr (SL > 3) fetch(b_next, l, 3 * PS, PF);
     MPX_EA_STAMP(8);
     int jj[WR];
     {
@@ -2337,7 +2360,8 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
   long long*& dbg = c->ea_dbg;  // per context: freed in mpx_destroy
   if (!dbg && getenv("MPX_EA_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&dbg, 128, hipHostMallocMapped));
   if (lds > 48 * 1024 && lds > c->ea_lds_allowed) {  // the attribute is per device: remembered per context, not per process
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_fast_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_fast_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     c->ea_lds_allowed = 150 * 1024;
   }
@@ -2351,8 +2375,10 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
     const unsigned grid = (unsigned)std::min<int64_t>(batch, n_cu);  // persistent: a workgroup owns its compute unit's LDS
     const unsigned magic = (unsigned)((((uint64_t)1 << 32) + chunk - 1) / chunk);  // i / chunk = umulhi(i, magic) for i < 2^32 / chunk
-    hipLaunchKernelGGL(mpx_equal_area_fast_kernel, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream, resid, (int)n_pts, p_in, p_out,
-                       (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, damping, c->wcum.p, (int64_t)c->n_p, (int)batch, chunk, magic, pad, (int)pos_off, c->nx, phase * c->S, dbg);
+    // (scalar residuals -- one state -- have their own instantiation: the prefetch of the next point must not pass a run-time branch)
+    hipLaunchKernelGGL(c->nx == 1 ? mpx_equal_area_fast_kernel<true> : mpx_equal_area_fast_kernel<false>, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream,
+                       resid, (int)n_pts, p_in, p_out, (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, damping, c->wcum.p, (int64_t)c->n_p,
+                       (int)batch, chunk, magic, pad, (int)pos_off, c->nx, phase * c->S, dbg);
   } else {
     if (c->wcum_p == p_out) c->wcum_phases &= ~(1u << phase);  // the generic kernel changes the widths and leaves no prefix sums
     hipLaunchKernelGGL(mpx_equal_area_kernel, dim3((unsigned)batch), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
