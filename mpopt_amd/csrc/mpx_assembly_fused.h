@@ -600,7 +600,9 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 #endif
     // (the next chunk's z, in flight during this chunk's work.  Requesting it BEHIND the point tasks instead -- a wavefront's loads
     // return in order, the table entries of the point tasks are L2 hits -- measured 4 % slower in process, tools/r4_adaptive_ab.py)
+#ifndef MPX_ABL_FUSE_NO_ZNEXT  // ablation (wrong results): every chunk of a workgroup works on the z of its first chunk -- what the z fetch costs
     if (!MPX_FUSE_Z_LATE && c + (int)gridDim.x < n_chunks) z_load(c + gridDim.x), chains_of(c + gridDim.x, (it_ + 1) & 1);
+#endif
     // ---- point functions: wavefront <-> (64-point block, evaluation point) ----
     // wavefront <-> its scheduled (64-point block, evaluation point) tasks
     for (int q = 0; q < n_my; ++q) {
