@@ -746,6 +746,9 @@ typedef double mpx_d4 __attribute__((ext_vector_type(4)));
 #ifndef MPX_LIGHT_XCD_BLOCKED
 #define MPX_LIGHT_XCD_BLOCKED 0
 #endif
+#ifndef MPX_LIGHT_DESC_LDS
+#define MPX_LIGHT_DESC_LDS 1
+#endif
 // Workgroup i of a launch runs on XCD i % 8: with MPX_LIGHT_XCD_BLOCKED=1 the workgroups of one XCD take CONSECUTIVE items of every
 // round of the persistent loop (each L2 streams a contiguous eighth of the round's rows instead of every eighth group of items), as
 // node_body's XCD-blocked walk does for the tiles.  Measured in process (tools/r4_light_ab.py): 1.5 % slower at config 2 (g: 208.5
@@ -790,6 +793,13 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
     }
   // (the quadrature weight of point k of a segment is w_k of its degree: the composite vector repeats the table, mpopt.py:4060-4062)
   if (t < 4 * KS) sTk[t] = A.tk[t <= P ? t : P], sWt[t] = L.wdeg[t <= P ? t : P];
+  // (degree and table offsets of the low-degree buckets, indexed by a lane-dependent value: out of the kernel arguments that was a
+  // dependent round trip to memory -- global_load_dword, s_waitcnt vmcnt -- in front of every turn of low-degree nodes; from LDS
+  // config 3 nlp_g 162.6 -> 154.1 us in process, -DMPX_LIGHT_DESC_LDS=0 restores it.  Measured with it and not kept
+  // (profiles/r4_light_chains): the segment widths requested before the wait for the span (+-0), the low-degree contractions four
+  // terms at a time (spills: f + grad_f 138 -> 159 us), the row stores four LDS reads at a time (+1 %).)
+  __shared__ int sFdeg[MPX_LIGHT_MAXDEG], sFD[MPX_LIGHT_MAXDEG], sFC[MPX_LIGHT_MAXDEG];
+  if (t < MPX_LIGHT_MAXDEG) sFdeg[t] = L.fdeg[t], sFD[t] = L.fD_off[t], sFC[t] = L.fC_off[t];
   __syncthreads();  // (the only barrier of the kernel: the tables are in place)
   const bool want_g = io.g != nullptr, want_q = MODE == MPX_MODE_FGJ && io.grad != nullptr;
   const int64_t total = (int64_t)L.n_groups * (io.B - io.b_first), stride = (int64_t)gridDim.x * MPX_LIGHT_WAVES;
@@ -918,9 +928,15 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
       if (fi < Gp.f_count) {
 #endif
         const MpxLightForeign F = Fd[u];
+#if MPX_LIGHT_DESC_LDS
+        const int di = F.dk >> 8, k = F.dk & 255, pf = sFdeg[di], p1f = pf + 1;
+        const double* __restrict__ Dr = sTab + sFD[di] + k * p1f;
+        const double* __restrict__ Cr = sTab + sFC[di] + (k >= 1 ? k - 1 : 0) * p1f;
+#else
         const int di = F.dk >> 8, k = F.dk & 255, pf = L.fdeg[di], p1f = pf + 1;
         const double* __restrict__ Dr = sTab + L.fD_off[di] + k * p1f;
         const double* __restrict__ Cr = sTab + L.fC_off[di] + (k >= 1 ? k - 1 : 0) * p1f;
+#endif
         fpos[u] = F.pos;
         Vec<NX> Xs, fx;
         Vec<NU> Us;
