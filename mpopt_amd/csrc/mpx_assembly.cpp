@@ -87,11 +87,30 @@ __device__ __forceinline__ double gather_value(int32_t k, const double* __restri
 }
 
 __device__ __forceinline__ double* gather_out(const MpxGatherArgs& A, int64_t row, int64_t& local, int64_t& stride) {
+  // The segment tables are part of the kernel arguments, i.e. scalar registers as long as every index is a constant.  Indexed by the
+  // lane's running `sg` (a search loop) they were fetched from the argument block in memory instead: up to three dependent round
+  // trips in front of the first useful load of a kernel whose whole life is a few microseconds (single evaluations).  The begins are
+  // non-decreasing, so the last segment that starts at or before the row is the one the search stopped at.
+#ifdef MPX_GATHER_OUT_SEARCH  // (the search of rounds 1 - 4: A/B with MPX_LIB_HIPCC_FLAGS=-DMPX_GATHER_OUT_SEARCH)
   int sg = 0;
   while (sg + 1 < A.n_seg && row >= A.seg_begin[sg + 1]) ++sg;
   local = row - A.seg_begin[sg];
   stride = A.seg_stride[sg];
   return A.seg_out[sg];
+#endif
+  static_assert(sizeof(A.seg_out) / sizeof(A.seg_out[0]) == 4, "gather_out: four output segments");
+  int64_t beg = A.seg_begin[0];
+  double* out = A.seg_out[0];
+  stride = A.seg_stride[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const bool in = k < A.n_seg && row >= A.seg_begin[k];
+    beg = in ? A.seg_begin[k] : beg;
+    stride = in ? A.seg_stride[k] : stride;
+    out = in ? A.seg_out[k] : out;
+  }
+  local = row - beg;
+  return out;
 }
 
 template <int UN>

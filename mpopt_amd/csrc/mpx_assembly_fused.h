@@ -71,6 +71,9 @@
 #ifndef MPX_FUSE_MID_WAVE
 #define MPX_FUSE_MID_WAVE 0
 #endif
+#ifndef MPX_FUSE_OUT_INDEXED
+#define MPX_FUSE_OUT_INDEXED 0
+#endif
 #ifndef MPX_FUSE_NT
 #define MPX_FUSE_NT 512  // lanes per workgroup
 #endif
@@ -510,10 +513,24 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       mnt_[q] = m < A.n_multi ? A.r_nt[mrow_[q]] : 0;
     }
   }
+  // (the four bases and strides from LDS: lgkmcnt, not vmcnt)
+  __shared__ double* sOb[4];
+  __shared__ int64_t sOs[4];
+  if (l < 4) sOb[l] = A.out[l], sOs[l] = A.out_stride[l];  // (visible behind the first barrier of the chunk loop)
+  // (constant indices into the argument block only: A.out[a] with the lane's own `a` is not a scalar register but a load from the
+  // argument block in memory -- and the wait for it, s_waitcnt vmcnt(0) in front of the row's store, also waited for every store
+  // the wavefront had issued before: the multi-term and long rows drained the burst of single-term rows one row at a time)
   auto out_of = [&](int row, int64_t b) -> double* {
+#if MPX_FUSE_OUT_INDEXED  // (the form of rounds 3 / 4, A/B)
     int a = 0, loc = row;
     if (loc >= N0) { loc -= N0, a = 1; if (loc >= N1) { loc -= N1, a = 2; if (loc >= N2) { loc -= N2, a = 3; } } }
     return A.out[a] ? A.out[a] + b * A.out_stride[a] + loc : nullptr;
+#else
+    int a = 0, loc = row;
+    if (loc >= N0) { loc -= N0, a = 1; if (loc >= N1) { loc -= N1, a = 2; if (loc >= N2) { loc -= N2, a = 3; } } }
+    double* base = sOb[a];
+    return base ? base + b * sOs[a] + loc : nullptr;
+#endif
   };
   // long rows of this wavefront (rows wave, wave + NW, ...): lane j holds terms j, j + 64, ... of each
   int lidx[RL > 0 ? RL : 1][TL > 0 ? TL : 1];
