@@ -1596,6 +1596,11 @@ def solve(ocp, n_segments=1, poly_orders=9, scheme="LGR", plot=True, solve_dict=
     return (mpo, post)
 
 
+def get_segment_boundaries():
+    """Placeholder of the reference's module surface (mpopt.py:4311-4313: a function with an empty body)."""
+    return None
+
+
 def __getattr__(name):
     """``mp.plt`` like the reference module (mpopt.py:25), imported on first use."""
     if name == "plt":

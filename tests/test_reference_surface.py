@@ -187,8 +187,10 @@ def test_module_surface_used_by_the_reference_examples():
     import matplotlib
     matplotlib.use("Agg")
     assert mp.plt.__name__ == "matplotlib.pyplot"
-    for name in ("OCP", "mpopt", "mpopt_h_adaptive", "mpopt_adaptive", "post_process", "solve", "Collocation", "CollocationRoots"):
+    for name in ("OCP", "mpopt", "mpopt_h_adaptive", "mpopt_adaptive", "mpopt_ph_adaptive", "post_process", "solve", "Collocation",
+                 "CollocationRoots", "get_segment_boundaries"):
         assert hasattr(mp, name), name
+    assert mp.get_segment_boundaries() is None  # (mpopt.py:4311-4313: an empty function)
     mpo = mp.mpopt(problems.moon_lander(mp, M.math), 3, 3)
     nlp, bounds = mpo.create_nlp()
     assert mpo.Z.shape[0] == len(bounds["lbx"]) and mpo.G.shape[0] == len(bounds["lbg"])
