@@ -65,6 +65,35 @@ __device__ __forceinline__ double wave_total_dpp(double x) {
   x += dpp0(x, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
+// M wavefront totals at once, each by the tree of wave_total_dpp (the same bits), step by step across the M values: one total is a
+// chain of six dependent DPP moves and additions with their wait states, M of them written one after the other between other work
+// ran as M chains in a row (twelve per item in light_low_body: 37 of 187 us of a config-5 nlp_f pass).
+template <int M>
+__device__ __forceinline__ void wave_total_dpp_n(double (&x)[M]) {
+  auto dpp0 = [](double v, auto ctrl, auto row_mask) {
+    constexpr int C = decltype(ctrl)::value, R = decltype(row_mask)::value;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), C, R, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), C, R, 0xf, false);
+    return __hiloint2double(hi, lo);
+  };
+  using std::integral_constant;
+  auto step = [&](auto ctrl, auto row_mask) {
+    double d[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) d[m] = dpp0(x[m], ctrl, row_mask);
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] += d[m];
+  };
+  step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});  // row_shr:1
+  step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});  // row_shr:2
+  step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});  // row_shr:4
+  step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});  // row_shr:8
+  step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
+  step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+    x[m] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x[m]), 63), __builtin_amdgcn_readlane(__double2loint(x[m]), 63));
+}
 #ifndef MPX_WAVE_SUM_DPP
 #define MPX_WAVE_SUM_DPP 1
 #endif
@@ -746,6 +775,12 @@ typedef double mpx_d4 __attribute__((ext_vector_type(4)));
 #ifndef MPX_LIGHT_XCD_BLOCKED
 #define MPX_LIGHT_XCD_BLOCKED 0
 #endif
+#ifndef MPX_LOW_TOTALS_GROUPED
+#define MPX_LOW_TOTALS_GROUPED 1  // 0: one wave_total_dpp per chunk where the chunk is worked on (the form of most of round 4, A/B)
+#endif
+#ifndef MPX_LOW_TOTALS_GROUP
+#define MPX_LOW_TOTALS_GROUP 12
+#endif
 #ifndef MPX_LIGHT_DESC_LDS
 #define MPX_LIGHT_DESC_LDS 1
 #endif
@@ -1207,6 +1242,13 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
     Vec<NRED> tot;
 #pragma unroll
     for (int r = 0; r < NRED; ++r) tot[r] = 0.0;
+    // chunks whose wavefront totals are formed together: all of the span's in the passes without gradients (one sum per chunk);
+    // with the three and more sums per chunk of the gradient passes the grouped form measured 2 % slower (registers), so those keep
+    // one wave_total_dpp per chunk and sum.  In process, B = 4096 (tools/r4_light_ab.py, -DMPX_LOW_TOTALS_GROUPED=0 against the
+    // default): nlp_f config 5 181.8 -> 168.5 us, config 4 72.2 -> 67.3, config 2 97.4 -> 93.9; nlp_g unchanged; bit-identical.
+    constexpr bool GROUPED = MPX_LOW_TOTALS_GROUPED && !SMALL && MODE == MPX_MODE_FG;
+    constexpr int CG = !GROUPED ? 1 : (CHL < MPX_LOW_TOTALS_GROUP ? CHL : MPX_LOW_TOTALS_GROUP);
+    double gk[CG][NRED];
     // The lanes of a chunk hold CONSECUTIVE nodes, so every row of g / grad_f leaves as one 512-byte store per chunk straight from
     // the registers (no staging; the mid-point rows are the same run shifted by one node)
     double* __restrict__ gb = want_g ? io.g + (int64_t)b * io.g_stride : nullptr;
@@ -1239,14 +1281,32 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
       }
       // sums: one partial-sum slot per CHUNK of 64 nodes (chunk index in the phase), wavefront tree over the chunk's nodes -- the
       // same slots and the same additions for every span length, so the short-span and the long-span kernels agree bit for bit
-      if (64 * u < len_w) {
+      if constexpr (SMALL || !GROUPED) {
+        if (64 * u < len_w) {
 #pragma unroll
-        for (int r = 0; r < NRED; ++r) {
-          const double v = wave_total_dpp(valid ? gr[r] : 0.0);
-          if constexpr (SMALL) {
-            if (l == 0) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + (lo_w >> 6)) * io.nred + r] = v;
-          } else {
-            tot[r] = u == 0 ? 0.0 + v : tot[r] + v;
+          for (int r = 0; r < NRED; ++r) {
+            const double v = wave_total_dpp(valid ? gr[r] : 0.0);
+            if constexpr (SMALL) {
+              if (l == 0) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + (lo_w >> 6)) * io.nred + r] = v;
+            } else {
+              tot[r] = u == 0 ? 0.0 + v : tot[r] + v;
+            }
+          }
+        }
+      } else {  // the totals of CG chunks together (wave_total_dpp_n), added to the span's sums in chunk order as before
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) gk[u % CG][r] = valid ? gr[r] : 0.0;
+        if (u % CG == CG - 1 || u == CHL - 1) {
+          const int u0 = u - u % CG;
+#pragma unroll
+          for (int r = 0; r < NRED; ++r) {
+            double x[CG];
+#pragma unroll
+            for (int m = 0; m < CG; ++m) x[m] = m <= u % CG ? gk[m][r] : 0.0;
+            wave_total_dpp_n<CG>(x);
+#pragma unroll
+            for (int m = 0; m < CG; ++m)
+              if (m <= u % CG && 64 * (u0 + m) < len_w) tot[r] = u0 + m == 0 ? 0.0 + x[m] : tot[r] + x[m];
           }
         }
       }
