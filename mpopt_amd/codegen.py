@@ -75,6 +75,9 @@ class PhaseProgram:
         self.nc = len(self.c)
         L = tr.wrap(ocp.get_running_costs(phase)(x, u, t, a_))
         self.qW = W * (h * L)
+        # does anything of a node depend on the node TIME (t = t0 + (tf - t0) th)?  If no phase does, the prefix sums of the segment
+        # widths (th's only input besides the width itself) are never used, and libmpx skips the kernel that forms them
+        self.time_dependent = any(e.depends_on({"th"}) for e in self.fx + self.c + [self.qW])
         self.node_vars = ([(COL_X, a, Xs[a]) for a in range(nx)] + [(COL_U, b, Us[b]) for b in range(nu)]
                           + [(COL_T0, 0, t0v), (COL_TF, 0, tfv)] + [(COL_A, c, As[c]) for c in range(na)])
         nv = self.node_vars
@@ -301,6 +304,9 @@ class ProblemProgram:
                 if d <= 12 and len(self.degrees) == 1:  # ... and of single-degree grids of low degree (light_low_body)
                     parts.append(f"MPX_INSTANTIATE_LIGHT_LOW({ph}, {d})")
         parts.append("MPX_INSTANTIATE_BOUNDARY()")
+        # (read by libmpx at load: 0 = no node function of any phase uses the node time, the widths' prefix sums are not needed)
+        parts.append('extern "C" __device__ __attribute__((used)) const int mpx_time_dependent = '
+                     f"{1 if any(p.time_dependent for p in self.phases) else 0};")
         parts += self._resident_source()
         return "\n".join(parts) + "\n"
 

@@ -91,6 +91,7 @@ struct mpx_ctx {
   std::vector<double> lt_coef;
   // device
   bool has_device = false;
+  bool time_dep = true;  // some node function uses the node time (mpx_time_dependent of the code object; true when the symbol is absent): else no prefix sums of the widths
   hipModule_t module = nullptr;
   hipFunction_t fn_bound[3] = {nullptr, nullptr, nullptr};
   hipStream_t stream = nullptr;

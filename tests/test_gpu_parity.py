@@ -200,6 +200,43 @@ def test_launch_geometry_does_not_change_results(monkeypatch):
     assert len(digests) == 1
 
 
+@pytest.mark.gpu
+def test_time_invariant_problems_skip_the_prefix_pass_with_identical_results():
+    """A problem none of whose node functions uses t never reads the prefix sums of the widths: mpx_eval_device leaves the prefix
+    kernel out.  Forcing it (MPX_ALWAYS_PREFIX=1, read when the context is created) must give the same bits, for widths that differ
+    per evaluation point and across calls; the time-dependent problems of the other tests keep the pass."""
+    import subprocess, sys, os
+
+    code = (
+        "import sys,os,hashlib;sys.path.insert(0,os.getcwd());sys.path.insert(0,'tests');import numpy as np,torch\n"
+        "import mpopt_amd as M;from mpopt_amd import mp;import problems\n"
+        "h=hashlib.sha256()\n"
+        "for b,S,P,sch in ((problems.moon_lander,60,5,'LGR'),(problems.two_phase_schwartz,30,3,'LGL'),(problems.van_der_pol,12,[3,20,3]*4,'CGL')):\n"
+        "    mpo=mp.mpopt(b(mp,M.math),S,P,sch);o=mpo.create_nlp()[0]['oracle'];B=9;rng=np.random.default_rng(5)\n"
+        "    assert 'mpx_time_dependent = 0;' in o.source\n"
+        "    dev=torch.device('cuda',0);Z=torch.tensor(mpo.initialize_solution()[None,:]+0.05*rng.standard_normal((B,o.n_z)),device=dev)\n"
+        "    lam=torch.tensor(rng.standard_normal((B,o.n_g)),device=dev);sig=torch.ones(B,dtype=torch.float64,device=dev)\n"
+        "    for rep in range(2):\n"
+        "        p=torch.tensor(rng.dirichlet(np.ones(S),(B,o.n_p//S)).reshape(B,o.n_p),device=dev)\n"
+        "        f=torch.empty(B,dtype=torch.float64,device=dev);g=torch.empty(B,o.n_g,dtype=torch.float64,device=dev);q=torch.empty(B,o.n_z,dtype=torch.float64,device=dev)\n"
+        "        jv=torch.empty(B,o.nnz_jac,dtype=torch.float64,device=dev);hv=torch.empty(B,o.nnz_hess,dtype=torch.float64,device=dev)\n"
+        "        o.eval_device(15,B,Z,p,1,None,None,f,g,q,jv);o.eval_device(16,B,Z,p,1,lam,sig,None,None,None,None,hv);o.eval_device(3,B,Z,p,1,None,None,f,g);o.sync()\n"
+        "        for a in (f,g,q,jv,hv): h.update(a.cpu().numpy().tobytes())\n"
+        "    o.close()\n"
+        "print(h.hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = set()
+    for force in ("", "1"):
+        env = dict(os.environ)
+        env.pop("MPX_ALWAYS_PREFIX", None)
+        if force:
+            env["MPX_ALWAYS_PREFIX"] = "1"
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.add(out.stdout.strip().splitlines()[-1])
+    assert len(digests) == 1
+
+
 ABSORB_CASES = {
     "vdp_3_30_3_x16": (problems.van_der_pol, 48, mixed(48), "CGL"),            # config 3's pattern, two absorbing tiles
     "vdp_3_30_3_x100": (problems.van_der_pol, 300, mixed(300), "CGL"),         # 13 absorbing tiles

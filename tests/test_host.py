@@ -158,6 +158,16 @@ def test_generated_source_is_deterministic_and_cached():
     assert path1 == path2 and co1 == co2 and (co1[:4] == b"\x7fELF" or co1.startswith(b"__CLANG_OFFLOAD_BUNDLE__"))
 
 
+@pytest.mark.parametrize("name,expected", [("moon_lander", 0), ("hyper_sensitive", 0), ("van_der_pol", 0), ("two_phase_schwartz", 0),
+                                           ("time_dependent", 1), ("kitchen_sink", 1)])
+def test_generated_source_says_whether_a_node_function_uses_time(name, expected):
+    """``mpx_time_dependent`` of the code object: libmpx forms the prefix sums of the segment widths (the node times' only other input)
+    only for problems whose dynamics / path constraints / running costs use t (mpopt.py:192-198 is where t comes from)."""
+    o = M.NlpFunctions(getattr(problems, name)(mp, M.math), 4, [3] * 4, "LGR", with_device=False)
+    m = re.search(r"mpx_time_dependent = (\d);", o.source)
+    assert m and int(m.group(1)) == expected
+
+
 CASADI_FUNCS = {"nlp_f": (2, 1), "nlp_g": (2, 1), "nlp_grad_f": (2, 2), "nlp_jac_g": (2, 2), "nlp_hess_l": (4, 1)}
 
 
