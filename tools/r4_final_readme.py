@@ -21,6 +21,9 @@ for d_, label in (("c2_light_f", "config 2 nlp_f"), ("c2_light_g", "config 2 nlp
     t = json.load(open(R + d_ + "/traffic.json")); b = json.load(open(R + d_ + "/bench_line.json")); ks = list(csv.DictReader(open(R + d_ + "/kernel_stats.csv")))[0]
     kus = float(ks["AverageNs"]) / 1000
     light.append(f"| {label} | `{ks['Name']}` {kus:.1f} | {b['ms_per_step'] * 1000:.1f} | {t['algorithmic_bytes_per_launch'] / kus / 1e6 / 8:.3f} | {b['roofline']['frac']:.3f} | {t['traffic_over_algorithmic']:.3f} | `{d_}/` |")
+import re as _re
+_m = _re.search(r"(\d+) passed", open(R + "gpu_tests_full_suite.log").read())
+n_passed = _m.group(1) if _m else "?"
 ii = bl("bench_line_default.json")
 ab = open(R + "adaptive_ab.txt").read().strip() if os.path.exists(R + "adaptive_ab.txt") else ""
 txt = f"""# r4_final — round-4 evidence (`tools/r4_evidence.sh`, one GPU call; MI355X, ROCm 7.2)
@@ -28,7 +31,7 @@ txt = f"""# r4_final — round-4 evidence (`tools/r4_evidence.sh`, one GPU call;
 Every directory: `bench_line.json` (the bench line of the workload), `kernel_stats.csv` (`rocprofv3 --kernel-trace --stats` of the same
 command), `pmc_fetch_size.csv` / `pmc_write_size.csv` (separate `rocprofv3 --pmc` passes), `traffic.json` (2 × FETCH_SIZE + WRITE_SIZE per
 launch against the algorithmic bytes, corrections per MI355X_MICROARCH.md).  `gpu_tests_full_suite.log`: `pytest tests -m gpu` of the
-tree at the end of the round (236 passed) with the per-entry parity summary by entry class.  (This file: `tools/r4_final_readme.py`.)
+tree at the end of the round ({n_passed} passed) with the per-entry parity summary by entry class.  (This file: `tools/r4_final_readme.py`.)
 
 | workload | value | µs per step | roofline.frac (of 8 TB/s) | PMC traffic / algorithmic | file |
 |---|---|---|---|---|---|
