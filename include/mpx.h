@@ -73,7 +73,9 @@ extern "C" {
                              MPX_JAC_VARIABLE_ONLY / MPX_BOUNDARY_ONLY. */
 #define MPX_WIDTHS_UNCHANGED 256 /* mpx_eval_device only: `p`, p_per_point and batch are those of the previous device-pointer call
                                     of this context (mpx_eval_device or mpx_resid_eval_device) and the memory behind `p` has not
-                                    changed since: the prefix sums kept on the device are reused.  The caller's assertion. */
+                                    changed since: the prefix sums kept on the device are reused.  The caller's assertion.
+                                    (Contexts of problems none of whose node functions uses the time t never form these sums --
+                                    the node time is their only consumer -- and ignore the flag.) */
 #define MPX_MID_RESID 1024 /* mpx_eval_device, with MPX_HESS: the node kernels of the hess_l pass also evaluate the dynamics residuals
                               D_mid.X - h_s Sx dyn(I_mid.X, I_mid.U, t_mid, a) at the mid-points between consecutive nodes of every
                               segment -- what mpx_resid_eval_device(resid) gives for the plan whose targets are those mid-points
