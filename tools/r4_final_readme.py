@@ -42,7 +42,7 @@ different boxes; `earlier_run_fast_box/` keeps a line and the profile of the fas
 
 ## Light passes (no Jacobian values: what a line search calls)
 
-| pass | dominant kernel, µs | whole pass µs (prefix + kernel + boundary) | frac, kernel alone | frac, whole pass | traffic / algorithmic | dir |
+| pass | dominant kernel, µs | whole pass µs (kernel + boundary; + the prefix kernel where a problem uses time) | frac, kernel alone | frac, whole pass | traffic / algorithmic | dir |
 |---|---|---|---|---|---|---|
 """ + "\n".join(light) + f"""
 
