@@ -299,13 +299,18 @@ extern "C" int nlp_jac_g(const double** arg, double** res, long long*, double*, 
   return mpx_eval(C.ctx, (want_g ? MPX_G : 0) | MPX_JAC | MPX_CCS_ORDER, 1, in(arg, 0, C.zx), in(arg, 1, C.zp), 0, 0, 0, 0, want_g ? res[0] : 0, 0, jv, 0) ? 1 : 0;
 }
 
-// ---- nlp_hess_l : (x, p, lam_f, lam_g) -> (hess_gamma_x_x, upper triangle) -----------------------
+// ---- nlp_hess_l : (x, p, lam_f, lam_g) -> (triu_hess_gamma_x_x) ------------------------------------
+// Names: CasADi 3.6.0 (the reference's pin, requirements.txt:4) asks an external oracle for each function BY NAME and then checks
+// every input / output name against its request string with ':' replaced by '_' (External::factory).  IpoptInterface requests
+// {"x","p","lam:f","lam:g"} -> {"triu:hess:gamma:x:x"}, so the one output must be called triu_hess_gamma_x_x -- like grad_f_x,
+// jac_g_x, lam_f, lam_g, grad_gamma_x, grad_gamma_p elsewhere in this file.  tests/c_abi/nlpsol_like.c holds the request table and
+// computes the expected names by that rule.
 MPX_COMMON(nlp_hess_l, 4, 1)
 extern "C" const char* nlp_hess_l_name_in(long long i) {
   static const char* n[] = {"x", "p", "lam_f", "lam_g"};
   return i >= 0 && i < 4 ? n[i] : 0;
 }
-extern "C" const char* nlp_hess_l_name_out(long long i) { return i == 0 ? "hess_gamma_x_x" : 0; }
+extern "C" const char* nlp_hess_l_name_out(long long i) { return i == 0 ? "triu_hess_gamma_x_x" : 0; }
 extern "C" const long long* nlp_hess_l_sparsity_in(long long i) {
   return i == 0 ? C.sp_x.data() : (i == 1 ? C.sp_p.data() : (i == 2 ? C.sp_one.data() : (i == 3 ? C.sp_g.data() : 0)));
 }

@@ -137,11 +137,41 @@ int main(int argc, char** argv) {
 #define NFN 7
 #define I_NLP 5
 #define I_GRAD 6
-  static const char* NAMES[NFN] = {"nlp_f", "nlp_g", "nlp_grad_f", "nlp_jac_g", "nlp_hess_l", "nlp", "nlp_grad"};
-  static const cint NIN[NFN] = {2, 2, 2, 2, 4, 2, 4}, NOUT[NFN] = {1, 1, 2, 2, 1, 2, 4};
-  static const char* IN_NAMES[4] = {"x", "p", "lam_f", "lam_g"};
-  static const char* OUT_NAMES[NFN][4] = {{"f", 0, 0, 0}, {"g", 0, 0, 0}, {"f", "grad_f_x", 0, 0}, {"g", "jac_g_x", 0, 0}, {"hess_gamma_x_x", 0, 0, 0},
-                                         {"f", "g", 0, 0}, {"f", "g", "grad_gamma_x", "grad_gamma_p"}};
+  /* ONE table: the seven requests exactly as CasADi 3.6.0 (the reference's pin, requirements.txt:4) states them --
+   *   Nlpsol::init:         oracle "nlp"; create_function("nlp_grad", {"x","p","lam:f","lam:g"}, {"f","g","grad:gamma:x","grad:gamma:p"}, {{"gamma",{"f","g"}}})
+   *   IpoptInterface::init: create_function("nlp_f", {"x","p"}, {"f"}), ("nlp_g", {"x","p"}, {"g"}), ("nlp_grad_f", {"x","p"}, {"f","grad:f:x"}),
+   *                         ("nlp_jac_g", {"x","p"}, {"g","jac:g:x"}), ("nlp_hess_l", {"x","p","lam:f","lam:g"}, {"triu:hess:gamma:x:x"}, {{"gamma",{"f","g"}}})
+   * For an external oracle External::factory looks the function up BY NAME in the library and then checks every input / output
+   * name against the request string with ':' replaced by '_' ("Inconsistent input name. Expected: ..."); the expected symbol
+   * names below are COMPUTED by that rule from the request strings, never written out. */
+  typedef struct { const char* name; const char* in[4]; const char* out[4]; } request_t;
+  static const request_t REQ[NFN] = {
+      {"nlp_f", {"x", "p", 0, 0}, {"f", 0, 0, 0}},
+      {"nlp_g", {"x", "p", 0, 0}, {"g", 0, 0, 0}},
+      {"nlp_grad_f", {"x", "p", 0, 0}, {"f", "grad:f:x", 0, 0}},
+      {"nlp_jac_g", {"x", "p", 0, 0}, {"g", "jac:g:x", 0, 0}},
+      {"nlp_hess_l", {"x", "p", "lam:f", "lam:g"}, {"triu:hess:gamma:x:x", 0, 0, 0}},
+      {"nlp", {"x", "p", 0, 0}, {"f", "g", 0, 0}},
+      {"nlp_grad", {"x", "p", "lam:f", "lam:g"}, {"f", "g", "grad:gamma:x", "grad:gamma:p"}}};
+  const char* NAMES[NFN];
+  cint NIN[NFN], NOUT[NFN];
+  char IN_NAMES[NFN][4][40], OUT_NAMES[NFN][4][40];
+  for (int k = 0; k < NFN; ++k) {
+    NAMES[k] = REQ[k].name;
+    NIN[k] = NOUT[k] = 0;
+    for (int i = 0; i < 4; ++i) {
+      const char* src[2] = {REQ[k].in[i], REQ[k].out[i]};
+      char* dst[2] = {IN_NAMES[k][i], OUT_NAMES[k][i]};
+      for (int d = 0; d < 2; ++d) {
+        dst[d][0] = 0;
+        if (!src[d]) continue;
+        size_t n = strlen(src[d]);
+        if (n >= sizeof IN_NAMES[0][0]) return 64;
+        for (size_t c = 0; c <= n; ++c) dst[d][c] = src[d][c] == ':' ? '_' : src[d][c];
+        ++*(d ? &NOUT[k] : &NIN[k]);
+      }
+    }
+  }
   static const int ORDER[NFN] = {I_NLP, 0, 1, 2, 3, 4, I_GRAD};
   fn_t F[NFN];
   cint max_arg = 0, max_res = 0, max_iw = 0, max_w = 0;
@@ -163,9 +193,11 @@ int main(int argc, char** argv) {
       DIE(4, "%s: optional memory-object symbols are not all there", NAMES[k]);
     if (f->n_in() != NIN[k] || f->n_out() != NOUT[k]) DIE(4, "%s: n_in / n_out", NAMES[k]);
     for (cint i = 0; i < NIN[k]; ++i)
-      if (!f->name_in(i) || strcmp(f->name_in(i), IN_NAMES[i])) DIE(4, "%s: name_in(%lld)", NAMES[k], i);
+      if (!f->name_in(i) || strcmp(f->name_in(i), IN_NAMES[k][i]))
+        DIE(4, "%s: Inconsistent input name. Expected: %s, got: %s", NAMES[k], IN_NAMES[k][i], f->name_in(i) ? f->name_in(i) : "(null)");
     for (cint i = 0; i < NOUT[k]; ++i)
-      if (!f->name_out(i) || strcmp(f->name_out(i), OUT_NAMES[k][i])) DIE(4, "%s: name_out(%lld)", NAMES[k], i);
+      if (!f->name_out(i) || strcmp(f->name_out(i), OUT_NAMES[k][i]))
+        DIE(4, "%s: Inconsistent output name. Expected: %s, got: %s", NAMES[k], OUT_NAMES[k][i], f->name_out(i) ? f->name_out(i) : "(null)");
     if (f->name_in(NIN[k]) || f->name_out(NOUT[k]) || f->sp_in(NIN[k]) || f->sp_out(NOUT[k])) DIE(4, "%s: out-of-range index must give NULL", NAMES[k]);
     if (f->work(&f->sz_arg, &f->sz_res, &f->sz_iw, &f->sz_w)) DIE(4, "%s_work failed", NAMES[k]);
     if (f->sz_arg < NIN[k] || f->sz_res < NOUT[k]) DIE(4, "%s_work: sz_arg / sz_res smaller than n_in / n_out", NAMES[k]);
