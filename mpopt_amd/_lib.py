@@ -72,7 +72,7 @@ def _flags_stamp():
     """The extra flags the library on disk was built with (diagnostics builds: MPX_LIB_HIPCC_FLAGS); '' for a plain build."""
     try:
         with open(LIB_PATH + ".flags") as f:
-            return f.read()
+            return " ".join(f.read().split())
     except OSError:
         return ""
 
@@ -82,7 +82,7 @@ def build_library(force=False, verbose=False):
     private temporary names and moved into place atomically; a file lock serialises concurrent builders.  The flags of
     MPX_LIB_HIPCC_FLAGS are part of the staleness check: a diagnostics build neither poisons later plain runs nor is silently
     skipped."""
-    want = os.environ.get("MPX_LIB_HIPCC_FLAGS", "")
+    want = " ".join(os.environ.get("MPX_LIB_HIPCC_FLAGS", "").split())  # normalised like the stamp (a whitespace-only value = no flags)
     if not force and not _stale(LIB_PATH, _sources()) and _flags_stamp() == want:
         return LIB_PATH
     with _build_lock(os.path.join(PKG, ".build.lock")):
@@ -119,7 +119,7 @@ def _build_library_in(tmp, verbose):
     stamp = LIB_PATH + ".flags"
     if extra:
         with open(stamp, "w") as f:
-            f.write(os.environ.get("MPX_LIB_HIPCC_FLAGS", ""))
+            f.write(" ".join(extra))
     elif os.path.exists(stamp):
         os.remove(stamp)
     return LIB_PATH

@@ -301,7 +301,7 @@ class ProblemProgram:
                 parts.append(f"MPX_INSTANTIATE_GRADL({ph}, {d})")
                 if 12 < d <= 31:  # light passes of the high-degree buckets on the matrix cores (mpx_kernels.h: light_body)
                     parts.append(f"MPX_INSTANTIATE_LIGHT({ph}, {d})")
-                if d <= 12 and len(self.degrees) == 1:  # ... and of single-degree grids of low degree (light_low_body)
+                if d <= 12 and len(self.degrees) == 1 and self.light_low_chunks(d) >= 2:  # ... and of single-degree grids of low degree (light_low_body)
                     parts.append(f"MPX_INSTANTIATE_LIGHT_LOW({ph}, {d})")
         parts.append("MPX_INSTANTIATE_BOUNDARY()")
         # (read by libmpx at load: 0 = no node function of any phase uses the node time, the widths' prefix sums are not needed)
@@ -309,6 +309,16 @@ class ProblemProgram:
                      f"{1 if any(p.time_dependent for p in self.phases) else 0};")
         parts += self._resident_source()
         return "\n".join(parts) + "\n"
+
+    def light_low_chunks(self, d):
+        """64-node chunks per span of the low-degree light kernels, exactly as light_low_body (mpx_kernels.h: CAP0 / CHL) and the
+        host's plan (mpx_host.cpp: lplan, `ok = chl >= 2`) compute them: the X / U rows of MPX_LIGHT_WAVES = 4 wavefronts share 52 KB
+        of LDS.  Problems with many states + controls (nx + nu > ~11 at degree 3) get fewer than two chunks: the host would not use
+        the kernels, and from ~24 inputs on their span rows do not fit the LDS of a workgroup at all (static_assert in the kernel) --
+        so they are not instantiated (the node kernels serve the light passes of such problems, as before round 4)."""
+        nin = self.phases[0].nx + self.phases[0].nu
+        cap0 = 53248 // (8 * 4 * max(nin, 1))
+        return max(1, (cap0 - 2 * d - 8) // 64)
 
     def _resident_source(self):
         """The resident kernel of single evaluations (mpx_kernels.h: resident_loop): one workgroup per tile stays on the device and

@@ -1123,8 +1123,11 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   // Light passes (no Jacobian values) of high-degree buckets run on the matrix cores (light_body) with direct stores; the other
   // buckets of such a pass store directly too (no staging block, no row spans).  Any batch size: which kernel evaluates a pass
   // never depends on the batch, so results do not either.  MPX_NO_LIGHT=1: the node kernels (A/B runs).
-  bool light = c->lplan.ok && mode != MPX_MODE_HESS && !io.jac && !shard && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() &&
-               !getenv("MPX_NO_LIGHT");
+  // (and only when the boundary pass follows in THIS call: the light kernels write their partial sums in their own slot layout --
+  // one slot per group / span or [phase][64-node chunk] --, which a later MPX_BOUNDARY_ONLY call and mpx_get_partials, both laid
+  // out per tile, would misread; mpx_set_tile_range(0, n_tiles, run_boundary = 0) therefore keeps the node kernels)
+  bool light = c->lplan.ok && mode != MPX_MODE_HESS && !io.jac && !shard && nodes && c->run_boundary && c->tile_begin == 0 &&
+               c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_LIGHT");
   for (auto& B : c->buckets)
     if (light && B.deg == c->lplan.deg && (!B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0] || (c->lplan.low && !B.fn_light_small[mode == MPX_MODE_FGJ ? 1 : 0]))) light = false;
   if (light && c->lplan.low) io.n_tiles_total = c->n_phases * c->lplan.n_low_chunks;  // (partial-sum slots of a light pass: [phase][64-node chunk])
@@ -2379,7 +2382,11 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
     if ((rc = reserve_wcum(c, (size_t)(batch * c->n_p)))) return rc;
     // the prefix sums of this phase's new widths are left in wcum: they describe p_out (per point, this batch)
     if (wcap != c->wcum.cap || c->wcum_p != p_out || c->wcum_batch != batch || c->wcum_ppp != 1) c->wcum_phases = 0;
-    c->wcum_p = p_out, c->wcum_batch = batch, c->wcum_ppp = 1, c->wcum_phases |= 1u << phase;
+    // (the kernel writes the prefix sums only for time-dependent problems -- want_prefix below; otherwise the phase's bit is CLEARED:
+    // the bookkeeping must never say the buffer holds sums it does not hold)
+    c->wcum_p = p_out, c->wcum_batch = batch, c->wcum_ppp = 1;
+    if (c->time_dep) c->wcum_phases |= 1u << phase;
+    else c->wcum_phases &= ~(1u << phase);
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
     const unsigned grid = (unsigned)std::min<int64_t>(batch, n_cu);  // persistent: a workgroup owns its compute unit's LDS
@@ -2937,7 +2944,8 @@ extern "C" int mpx_eval_grad_gamma(mpx_ctx* c, int64_t batch, const double* z, c
   if (!c) return MPX_ERR_INVALID;
   if (!c->has_device)
     return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval_grad_gamma: context was created without a gfx950 code object; there is no CPU fallback");
-  if (batch < 1 || !z || (!p && c->n_p > 0) || !lam_g || !sigma) return fail(c, MPX_ERR_INVALID, "mpx_eval_grad_gamma: batch/z/p/lam_g/sigma invalid");
+  if (batch < 1 || batch > (1 << 30) || !z || (!p && c->n_p > 0) || !lam_g || !sigma)  // (bounded BEFORE the size products and reserves below)
+    return fail(c, MPX_ERR_INVALID, "mpx_eval_grad_gamma: batch/z/p/lam_g/sigma invalid");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t B = (size_t)batch, npv = (size_t)(p_per_point ? batch : 1) * c->n_p;
   int rc;

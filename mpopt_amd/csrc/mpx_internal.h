@@ -48,7 +48,7 @@ struct Bucket {
   int32_t *d_node_i = nullptr, *d_node_sk = nullptr;
   hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
   hipFunction_t fn_gradl = nullptr;  // mpx_node_gradl_<phase>_<deg> (nlp_grad)
-  hipFunction_t fn_light[2], fn_light_small[2] = {nullptr, nullptr};  // mpx_light_fg / _fgq _<phase>_<deg>: light passes on the matrix cores (12 < deg <= 31)
+  hipFunction_t fn_light[2] = {nullptr, nullptr}, fn_light_small[2] = {nullptr, nullptr};  // mpx_light_fg / _fgq _<phase>_<deg>: light passes on the matrix cores (12 < deg <= 31)
 };
 
 template <class T>

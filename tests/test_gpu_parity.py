@@ -178,6 +178,72 @@ def test_full_size_against_c_oracle_and_properties(name):
     assert np.abs(H @ v - dL).max() < 2e-5 * max(1.0, np.abs(dL).max())
 
 
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_light_passes_against_c_oracle_and_node_kernels(name, monkeypatch):
+    """The kernels a line search calls -- nlp_f, nlp_g, nlp_grad_f WITHOUT the Jacobian values are served by the span kernels
+    (mpx_lightlow_* on single-degree grids, mpx_light_* on the matrix cores for the [3, 30, 3] grids) -- at every BASELINE size: at
+    1000 x 5, 2000 mixed, 2 x 500 x 3 and 4000 x 3 the span plan has many groups with segments that straddle span ends.  For every FULL case, batch
+    sizes 1 / 3 / 37 and the four masks a solver uses: per-entry against the C oracle with the entry classes and floors of the
+    fused test above, AND against the same call through the node kernels (MPX_NO_LIGHT=1): g and the node entries of grad_f bit for
+    bit, f and the (t0, tf, a) sums (another fixed order) to rounding.  The plan is asserted so the test cannot fall back silently.
+    What is computed: mpopt.py:227-232 (defects), 455 (objective)."""
+    from helpers import border_columns
+
+    (builder, S, po, scheme), cnames, st, midu = FULL[name]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    assert o.light_plan()[1] > 0, "no light plan: the masks below would run the node kernels"
+    C = COracle(cnames, S, po, scheme, scale_x=ocp.scale_x, scale_u=ocp.scale_u, scale_a=ocp.scale_a if ocp.na else None, scale_t=st, midu=midu)
+    z, p, lam, sig = random_point(o, mpo, None, 29, S, ocp.n_phases)
+    rng = np.random.default_rng(41)
+    node = np.ones(o.n_z, bool)
+    node[border_columns(o)] = False
+    jr, jc = o.jac_pattern()
+    masks = (["f"], ["g"], ["f", "grad_f"], ["f", "g", "grad_f"])
+    for B in (1, 3, 37):
+        Z = z[None, :] * (1 + 0.01 * rng.uniform(-1, 1, (B, o.n_z))) + 0.01 * rng.uniform(-1, 1, (B, o.n_z))
+        Z[0] = z
+        light = [o.eval(m, Z, p) for m in masks]
+        monkeypatch.setenv("MPX_NO_LIGHT", "1")
+        heavy = [o.eval(m, Z, p) for m in masks]
+        monkeypatch.delenv("MPX_NO_LIGHT")
+        for m, a, h in zip(masks, light, heavy):
+            if "g" in m:
+                assert np.array_equal(a["g"], h["g"]), (name, B, m)
+            if "grad_f" in m:
+                assert np.array_equal(a["grad_f"][:, node], h["grad_f"][:, node]), (name, B, m)
+                assert_entries(a["grad_f"][:, ~node], h["grad_f"][:, ~node], 1e-12, what=f"{name} B={B} light vs node kernels: grad_f [(t0, tf, a) sums]", report=False)
+            if "f" in m:
+                assert np.abs(a["f"] - h["f"]).max() <= 1e-13 * max(1.0, np.abs(h["f"]).max()), (name, B, m)
+                assert np.array_equal(a["f"], light[0]["f"]), (name, B, m)  # every light pass sums f in the same order
+        # per-entry against the C oracle (the same entry classes / floors as the fused test above): point 0 of the small batches,
+        # the middle and the last point of the large one
+        for b in ((18, 36) if B == 37 else (0,)):
+            c, c2 = C.eval(Z[b], p), C.eval(Z[b] * 1.01, p)
+            Jal, Jal2 = (np.asarray(sp.coo_matrix((q["jac_val"], (q["jac_row"], q["jac_col"])), shape=(o.n_g, o.n_z)).tocsr()[jr, jc]).ravel() for q in (c, c2))
+            jcl = jac_classes(o, jr, jc, Jal, Jal2)
+            nzp = o.n_z // ocp.n_phases
+            Xcols = np.zeros(o.n_z, bool)
+            for ph in range(ocp.n_phases):
+                Xcols[ph * nzp:ph * nzp + ocp.nx * o.n_nodes] = True
+            zx = np.abs(Z[b][Z[b] != 0])
+            term = float(np.median(np.abs(Jal[jcl["constant (D / interpolation copies)"]])) * np.median(zx))
+            isF = np.zeros(o.n_g, bool)
+            isF[np.unique(jr[jcl["constant (D / interpolation copies)"] & Xcols[jc]])] = True
+            for m, a in zip(masks, light):
+                # (the per-entry summary of the session groups by what follows the first space: one line per configuration, array and class)
+                tag = f"light:{'+'.join(m)}:B={B}[{b}] {name} light passes:"
+                if "f" in m:
+                    assert rel_err(a["f"][b], c["f"]) < TOL, tag
+                if "g" in m:
+                    assert_by_class(a["g"][b], c["g"], {"defect rows (D.X - h Sx dyn)": isF, "other rows": ~isF}, TOL, tag + " g",
+                                    floors={"defect rows (D.X - h Sx dyn)": term})
+                if "grad_f" in m:
+                    assert_by_class(a["grad_f"][b], c["grad_f"], grad_classes(o), TOL, tag + " grad_f")
+    o.close()
+
+
 def test_launch_geometry_does_not_change_results(monkeypatch):
     """Fixed-order reductions: any batch split (b_per_block) gives bit-identical outputs."""
     import subprocess, sys, os, json
@@ -428,6 +494,48 @@ def test_segment_sharding_is_bit_identical(case, world):
     assert np.array_equal(f.cpu().numpy(), ref["f"])
     for k in total:
         assert np.array_equal(total[k].cpu().numpy(), ref[k]), k
+
+
+@pytest.mark.parametrize("case", ["moon_lander_60x5", "vdp_mixed_3_30_3", "kitchen_sink_40"])
+def test_tile_range_with_one_rank_and_a_light_mask(case, monkeypatch):
+    """The world = 1 case of the tile-range flow with a mask WITHOUT the Jacobian values (f, g, grad_f): the node pass of
+    mpx_set_tile_range(0, n_tiles, run_boundary = 0) must leave its partial sums in the per-tile layout that the later
+    MPX_BOUNDARY_ONLY call (and mpx_get_partials) reads -- i.e. it must not take the light kernels, whose slots are laid out per
+    span / 64-node chunk (round-4 advisor finding: silently wrong f and (t0, tf, a) entries of grad_f).  Bit-identical to the same
+    mask through the node kernels in one call, and equal to rounding to the light pass."""
+    import torch
+    from mpopt_amd._lib import MPX_BOUNDARY_ONLY
+
+    builder, S, po, scheme = REDUCED[case]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(12)
+    B = 3
+    Zh = mpo.initialize_solution()[None, :] + 0.05 * rng.standard_normal((B, o.n_z))
+    ph = np.full(o.n_p, 1.0 / S)
+    light = o.eval(["f", "g", "grad_f"], Zh, ph)
+    monkeypatch.setenv("MPX_NO_LIGHT", "1")
+    ref = o.eval(["f", "g", "grad_f"], Zh, ph)
+    monkeypatch.delenv("MPX_NO_LIGHT")
+    t = lambda a: torch.tensor(a, device=dev)
+    Z, p = t(Zh), t(ph)
+    f = torch.full((B,), -7.0, dtype=torch.float64, device=dev)
+    g = torch.zeros((B, o.n_g), dtype=torch.float64, device=dev)
+    q = torch.zeros((B, o.n_z), dtype=torch.float64, device=dev)
+    o.set_tile_range(0, o.n_tiles, run_boundary=False)
+    o.eval_device(7, B, Z, p, 0, None, None, f, g, q, None, None)
+    o.sync()
+    ptr, cnt = o.partials(B)  # (count = batch * n_tiles * nred: the per-tile layout)
+    assert cnt == B * o.n_tiles * (cnt // (B * o.n_tiles))
+    o.set_tile_range(0, o.n_tiles, run_boundary=True)
+    o.eval_device(7 | MPX_BOUNDARY_ONLY, B, Z, p, 0, None, None, f, g, q, None, None)
+    o.sync()
+    assert np.array_equal(f.cpu().numpy(), ref["f"]) and np.array_equal(g.cpu().numpy(), ref["g"]) and np.array_equal(q.cpu().numpy(), ref["grad_f"])
+    assert np.array_equal(g.cpu().numpy(), light["g"])
+    assert np.abs(f.cpu().numpy() - light["f"]).max() <= 1e-13 * np.abs(light["f"]).max()
+    assert np.abs(q.cpu().numpy() - light["grad_f"]).max() <= 1e-12 * max(1.0, np.abs(light["grad_f"]).max())
 
 
 def test_edge_cases_default_ocp_and_extreme_grids():

@@ -158,6 +158,25 @@ def test_generated_source_is_deterministic_and_cached():
     assert path1 == path2 and co1 == co2 and (co1[:4] == b"\x7fELF" or co1.startswith(b"__CLANG_OFFLOAD_BUNDLE__"))
 
 
+@pytest.mark.parametrize("nx,nu,expect_low", [(20, 6, False), (14, 6, False), (8, 3, True), (2, 1, True)])
+def test_wide_problems_compile_and_get_low_degree_light_kernels_only_when_they_fit(nx, nu, expect_low):
+    """Round-4 advisor finding: MPX_INSTANTIATE_LIGHT_LOW was emitted for every single-degree grid of degree <= 12, and
+    light_low_body's span rows (4 wavefronts x (nx + nu) rows) do not fit the LDS of a workgroup from ~24 inputs on -- the code
+    object of OCP(n_states=20, n_controls=6) no longer compiled, create_nlp on a GPU raised.  The generator now instantiates them
+    only where the host's plan would use them (>= 2 chunks per span, the same arithmetic as mpx_host.cpp / mpx_kernels.h), and every
+    width compiles (hipcc cross-compiles gfx950 without a GPU)."""
+    ocp = mp.OCP(n_states=nx, n_controls=nu)
+    ocp.dynamics[0] = lambda x, u, t: [u[i % nu] - 0.1 * x[i] * x[(i + 1) % nx] for i in range(nx)]
+    ocp.running_costs[0] = lambda x, u, t: sum(x[i] * x[i] for i in range(nx)) + sum(u[i] * u[i] for i in range(nu))
+    ocp.validate()
+    o = M.NlpFunctions(ocp, 3, [3] * 3, "LGR", with_device=False)
+    assert ("MPX_INSTANTIATE_LIGHT_LOW(0, 3)" in o.source) == expect_low
+    assert (o.light_plan()[1] > 0) == expect_low  # the host's plan and the generator agree
+    co, path = _lib.compile_kernels(o.source)
+    assert co[:4] == b"\x7fELF" or co.startswith(b"__CLANG_OFFLOAD_BUNDLE__")
+    o.close()
+
+
 @pytest.mark.parametrize("name,expected", [("moon_lander", 0), ("hyper_sensitive", 0), ("van_der_pol", 0), ("two_phase_schwartz", 0),
                                            ("time_dependent", 1), ("kitchen_sink", 1)])
 def test_generated_source_says_whether_a_node_function_uses_time(name, expected):
