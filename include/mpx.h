@@ -290,7 +290,8 @@ int mpx_get_partials(mpx_ctx* ctx, int64_t batch, double** device_ptr, int64_t* 
  * rows of mpx_shard_table, tile_cuts[world + 1] = the tile ranges.  mpx_shard_table: out[n_entries][6] = (rank, kind, offset,
  * length, stride, packed_offset) of every owned run; kind 0 = jac_val / hess_val, 1 = staging block, 2 = tile partials; the
  * run of evaluation point b starts at offset + b * stride in its array and at packed_offset * batch + b * length in the
- * rank's exchange buffer (structure only: works without a device).
+ * rank's exchange buffer (structure only: works without a device).  With MPX_OWNER_RESIDENT in `mask` the packed_offset of a kind-2
+ * run is its offset in the partials-only exchange buffer of that mode (the other kinds do not travel there).
  *
  * Three ways to finish a sharded evaluation (mpopt_amd/distributed.py drives them):
  *   all-gather        steps 1-5 above: every rank ends with the complete result.

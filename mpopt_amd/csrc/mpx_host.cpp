@@ -1939,7 +1939,8 @@ extern "C" int mpx_shard_table(const mpx_ctx* c, int mask, int64_t* out) {
   if (!c || !out || c->shard_cuts.empty()) return MPX_ERR_INVALID;
   const int ps = (mask & MPX_HESS) ? 1 : 0;
   for (auto& e : c->shard_ent[ps]) {
-    *out++ = e.rank, *out++ = e.kind, *out++ = e.src_off, *out++ = e.len, *out++ = e.stride, *out++ = e.dst_off;
+    // (with MPX_OWNER_RESIDENT in the mask the last column of a partial-sum run is its offset in the partials-only exchange buffer)
+    *out++ = e.rank, *out++ = e.kind, *out++ = e.src_off, *out++ = e.len, *out++ = e.stride, *out++ = ((mask & MPX_OWNER_RESIDENT) && e.kind == 2) ? e.part_off : e.dst_off;
   }
   return MPX_OK;
 }

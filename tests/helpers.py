@@ -163,3 +163,125 @@ def emulate_shard_exchange(tables, rank_len, world, batch, arrays_by_rank, all_g
         if r != me:
             for b in range(batch):
                 arrays_by_rank[int(kind)][off + b * stride: off + b * stride + ln] = recv[r * n + dst * batch + b * ln: r * n + dst * batch + (b + 1) * ln]
+
+
+class HostShardOracle:
+    """TEST INFRASTRUCTURE (CPU tests of ``SegmentShardedEvaluator`` at world sizes no test box has the GPUs for): stands in for the
+    DEVICE calls of ``NlpFunctions`` -- eval_device / shard_pack / shard_unpack / sync -- over host torch tensors, driven by the REAL
+    shard tables and ownership runs of a structure-only libmpx context (``struct``).  The "node kernels" copy what this rank owns
+    out of seeded truth arrays (identical on every rank) and leave everything else NaN; pack / unpack restate mpx_shard_copy_kernel
+    (mpx_host.cpp) from ``mpx_shard_table``; the "boundary pass" sums the tile partials of every point in slot order into f -- NaN
+    unless every rank's slots arrived.  The product path never sees this class."""
+
+    def __init__(self, struct, batch, seed=0):
+        import torch
+        from mpopt_amd._lib import MPX_HESS, MPX_JAC
+
+        self.s, self.B, self.torch = struct, int(batch), torch
+        self.rank = 0
+        rng = np.random.default_rng(seed)
+        o = struct
+        self.nnz = {0: o.nnz_jac, 1: o.nnz_hess}
+        self.truth = {"g": rng.standard_normal((batch, o.n_g)), "grad_f": rng.standard_normal((batch, o.n_z)),
+                      "jac_g": rng.standard_normal((batch, o.nnz_jac)), "hess_l": rng.standard_normal((batch, o.nnz_hess))}
+        self._rng = rng
+        self.staging = self.partial = None
+        self.calls = []
+
+    # ---- structure: straight from libmpx -------------------------------------------------------------------------------------
+    def shard_setup(self, world, rank):
+        self.s.shard_setup(world, rank)
+        self.world, self.rank = int(world), int(rank)
+
+    def shard_info(self, mask):
+        return self.s.shard_info(mask)
+
+    def shard_owned(self, which, rank):
+        return self.s.shard_owned(which, rank)
+
+    def sync(self):
+        pass
+
+    def set_stream(self, stream):
+        raise AssertionError("host tensors: no stream to set")
+
+    def _tab(self, mask):
+        return self.s.shard_table(mask)
+
+    def _strides(self, mask):
+        from mpopt_amd._lib import MPX_OWNER_RESIDENT
+
+        tab = self.s.shard_table(mask & ~MPX_OWNER_RESIDENT)
+        st = {}
+        for k in (1, 2):
+            rows = tab[tab[:, 1] == k]
+            st[k] = int(rows[0, 4]) if len(rows) else 0
+        return st
+
+    def _truth_kind(self, mask, kind):
+        """Seeded truth of the staging block / the tile partials of this pass (the same stream on every rank)."""
+        st = self._strides(mask)[kind]
+        r = np.random.default_rng(1000 + 10 * kind + (1 if self._hess(mask) else 0))
+        return r.standard_normal((self.B, st))
+
+    @staticmethod
+    def _hess(mask):
+        from mpopt_amd._lib import MPX_HESS
+
+        return bool(mask & MPX_HESS)
+
+    # ---- the device calls ---------------------------------------------------------------------------------------------------
+    def eval_device(self, mask, batch, z, p, ppp=0, lam_g=None, sigma=None, f=None, g=None, grad_f=None, jac_val=None, hess_val=None):
+        from mpopt_amd._lib import MPX_BOUNDARY_ONLY, MPX_G, MPX_GRAD, MPX_OWNER_RESIDENT
+
+        torch = self.torch
+        assert batch == self.B
+        hess, owner = self._hess(mask), bool(mask & MPX_OWNER_RESIDENT)
+        vals = hess_val if hess else jac_val
+        self.calls.append(("boundary" if mask & MPX_BOUNDARY_ONLY else "nodes", hess, owner))
+        if mask & MPX_BOUNDARY_ONLY:
+            if f is not None and not hess:  # fixed-order sum of every tile's slots: NaN unless all of them arrived
+                f.copy_(self.partial.sum(dim=1))
+            return
+        tab = self._tab(mask & ~MPX_OWNER_RESIDENT)
+        st = self._strides(mask)
+        self.staging = torch.full((self.B, max(st[1], 1)), float("nan"), dtype=torch.float64)
+        self.partial = torch.full((self.B, max(st[2], 1)), float("nan"), dtype=torch.float64)
+        truth = {0: torch.tensor(self.truth["hess_l" if hess else "jac_g"]), 1: torch.tensor(self._truth_kind(mask, 1)) if st[1] else None,
+                 2: torch.tensor(self._truth_kind(mask, 2))}
+        dst = {0: vals, 1: self.staging, 2: self.partial}
+        for rr, kind, off, ln, stride, _ in tab.tolist():
+            if rr != self.rank or dst[kind] is None or (owner and kind == 1):
+                continue
+            dst[kind].view(self.B, -1)[:, off:off + ln] = truth[kind][:, off:off + ln]
+        if owner:  # owner-resident: the node kernels store their own g / grad_f rows directly
+            for name, arr in (("g", g), ("grad_f", grad_f)):
+                if arr is not None and not hess:
+                    for off, ln in self.shard_owned(name, self.rank).tolist():
+                        arr[:, off:off + ln] = torch.tensor(self.truth[name][:, off:off + ln])
+
+    def _copy(self, mask, vals, buf, unpack):
+        from mpopt_amd._lib import MPX_OWNER_RESIDENT
+
+        owner = bool(mask & MPX_OWNER_RESIDENT)
+        rank_len, _ = self.s.shard_info(mask)
+        n = max(rank_len * self.B, 2)
+        src = {0: vals, 1: self.staging, 2: self.partial}
+        for rr, kind, off, ln, stride, dst in self._tab(mask).tolist():
+            if (rr == self.rank) == bool(unpack) or (owner and kind != 2) or src[kind] is None:
+                continue
+            a = src[kind].view(self.B, -1)
+            assert kind == 0 or a.shape[1] == stride or a.shape[1] == 1
+            base = (rr * n if unpack else 0) + dst * self.B
+            for b in range(self.B):
+                if unpack:
+                    a[b, off:off + ln] = buf[base + b * ln: base + (b + 1) * ln]
+                else:
+                    buf[base + b * ln: base + (b + 1) * ln] = a[b, off:off + ln]
+
+    def shard_pack(self, mask, batch, vals, send):
+        send.fill_(float("nan"))
+        self._copy(mask, vals, send, 0)
+
+    def shard_unpack(self, mask, batch, recv, vals):
+        self._copy(mask, vals, recv, 1)

@@ -30,6 +30,16 @@ def test_gpus_2_spawns_two_ranks_and_rank0_prints_one_line():
     assert out == {"launch_check": True, "n_gpus": 2, "backend": "gloo", "all_reduce_of_ones": 2.0}
 
 
+@pytest.mark.parametrize("n", [4, 8])
+def test_gpus_4_and_8_launch_over_gloo(n):
+    """The driver's round-end scaling run is `--gpus 1, 2, 4, 8`: the self-launch, the rendezvous and one real all-reduce with 4
+    and 8 ranks (gloo, no GPU) -- the widest launch the bench will see on an 8-GPU node."""
+    r, lines = run_bench(["--gpus", str(n), "--launch-check"], {"MPX_DIST_BACKEND": "gloo"}, 600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0]) == {"launch_check": True, "n_gpus": n, "backend": "gloo", "all_reduce_of_ones": float(n)}
+
+
 def test_gpus_1_stays_a_single_process():
     r, lines = run_bench(["--gpus", "1", "--launch-check"], {}, 120)
     assert r.returncode == 0, r.stderr[-2000:]

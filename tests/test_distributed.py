@@ -130,6 +130,93 @@ def test_two_rank_gloo():
     assert got == [(0, "ok"), (1, "ok")]
 
 
+def _evaluator_worker(rank, world, port, q):
+    """SegmentShardedEvaluator itself -- mode logic, buffer sizes, the collective of every mode, group-relative root -- at world sizes
+    4 and 8 over gloo, with the device calls of the oracle replaced by a host stand-in that is driven by libmpx's REAL shard tables
+    (tests/helpers.py: HostShardOracle).  Every owned run must arrive bit-exactly where the mode promises it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import mpopt_amd as M
+    from mpopt_amd import mp, distributed as D
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC, MPX_HESS
+    from helpers import HostShardOracle
+    import problems
+
+    r, w, _ = D.init_from_env(backend="gloo")
+    B = 2
+    cases = [(problems.van_der_pol, 48, [30 if s % 3 == 1 else 3 for s in range(48)], "CGL"),   # config 3's degree pattern: hess_l by node-ordered tiles
+             (problems.two_phase_schwartz, 200, [3] * 200, "LGL")]                              # config 4's shape: two phases
+    FGJ = MPX_F | MPX_G | MPX_GRAD | MPX_JAC
+    for builder, S, po, scheme in cases:
+        struct = M.NlpFunctions(builder(mp, M.math), S, po, scheme, with_device=False)
+        for mode in D.SegmentShardedEvaluator.MODES:
+            root = w - 1 if mode == "root" else 0  # (a root other than rank 0)
+            ho = HostShardOracle(struct, B, seed=5)
+            ev = D.SegmentShardedEvaluator(ho, mode=mode, root=root)
+            assert (ev.rank, ev.world, ev.backend) == (r, w, "gloo")
+            nan = lambda *s_: torch.full(s_, float("nan"), dtype=torch.float64)
+            z, p = torch.zeros(B, struct.n_z, dtype=torch.float64), torch.zeros(struct.n_p, dtype=torch.float64)
+            f, g, gq, jv, hv = nan(B), nan(B, struct.n_g), nan(B, struct.n_z), nan(B, struct.nnz_jac), nan(B, struct.nnz_hess)
+            ev.eval(FGJ | MPX_HESS, B, z, p, None, None, f, g, gq, jv, hv)
+            assert [c[0] for c in ho.calls] == (["nodes", "boundary"] * 2 if (mode != "root" or r == root) else ["nodes"] * 2), ho.calls
+            complete = mode == "allgather" or (mode == "root" and r == root)
+            for name, arr, mask in (("jac_g", jv, FGJ), ("hess_l", hv, MPX_HESS)):
+                truth = torch.tensor(ho.truth[name])
+                own_any = torch.zeros(arr.shape[1], dtype=torch.bool)
+                own_me = torch.zeros(arr.shape[1], dtype=torch.bool)
+                for rr in range(w):
+                    for off, ln in struct.shard_owned(name, rr).tolist():
+                        own_any[off:off + ln] = True
+                        if rr == r:
+                            own_me[off:off + ln] = True
+                have = own_any if complete else own_me
+                assert torch.equal(arr[:, have], truth[:, have]) and arr[:, ~have].isnan().all(), (mode, name, r)
+            if mode == "owner":  # the rank's own node rows of g / grad_f, stored directly
+                for name, arr in (("g", g), ("grad_f", gq)):
+                    m = torch.zeros(arr.shape[1], dtype=torch.bool)
+                    for off, ln in struct.shard_owned(name, r).tolist():
+                        m[off:off + ln] = True
+                    assert torch.equal(arr[:, m], torch.tensor(ho.truth[name])[:, m]) and arr[:, ~m].isnan().all()
+            # the tile partials of the LAST pass (hess_l) and f of the first: complete wherever the boundary pass ran
+            if mode != "root" or r == root:
+                assert not f.isnan().any()
+                fs = [torch.empty_like(f) for _ in range(w)] if mode != "root" else None
+                if fs is not None:
+                    dist.all_gather(fs, f)
+                    assert all(torch.equal(fs[0], x) for x in fs)  # same slots, same order, same bits on every rank
+                    assert torch.equal(f, torch.tensor(ho._truth_kind(FGJ, 2)).sum(dim=1))
+            else:
+                assert f.isnan().all()
+            sent, recvd = ev.exchange_doubles(FGJ, B)
+            n_full, _ = struct.shard_info(FGJ)
+            if mode == "owner":
+                assert sent < max(n_full * B, 2)  # partials only
+            else:
+                assert sent == max(n_full * B, 2) and recvd == (w * sent if complete else 0)
+            ev.close()
+            dist.barrier()
+        struct.close()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_segment_sharded_evaluator_modes_over_gloo(world):
+    port = _free_port()
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_evaluator_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(420)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(r, "ok") for r in range(world)]
+
+
 def test_partition_tiles_properties():
     from mpopt_amd.distributed import partition_tiles, shard_range
 
