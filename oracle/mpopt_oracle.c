@@ -30,6 +30,21 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* LONG-DOUBLE ACCUMULATION MODE (-DORC_LONG_DOUBLE, built as liborc_ld.so by oracle/c_oracle.py): the SAME source with every
+ * `double` -- arguments, tables, intermediates, sums -- an x87 80-bit long double (64-bit significand: 11 more bits than the
+ * kernels and than this file's normal build).  Inputs are the same binary64 numbers converted exactly, so its results are the
+ * formulas of this file evaluated (almost) without rounding.  The parity tests use it as the ARBITER: where a GPU value and
+ * the double build of this oracle differ by a few 1e-11 in a cancelling entry, |gpu - ld| and |c - ld| say whose rounding it is
+ * (tests/test_gpu_parity.py).  Literals such as 0.3 stay the binary64 constants of the double build (same problem). */
+#ifdef ORC_LONG_DOUBLE
+#define double long double
+#define cos cosl
+#define sin sinl
+#define exp expl
+#define fabs fabsl
+#define sqrt sqrtl
+#endif
+
 #define MAXV 16 /* nx + nu + 1 + na */
 #define MAXP 64 /* max degree + 1 */
 
@@ -509,6 +524,18 @@ int orc_set_table(orc* o, int deg, const double* D, const double* w, const doubl
       return 0;
     }
   return -1;
+}
+
+/* The tables of one degree as this oracle holds them (the long-double build is given the double build's tables, so that both
+ * evaluate the same problem). */
+int orc_get_table(const orc* o, int deg, double* D, double* w, double* Cmid) {
+  const deg_table* T = tab(o, deg);
+  if (!T) return -1;
+  int n = deg + 1;
+  memcpy(D, T->D, n * n * sizeof(double));
+  memcpy(w, T->w, n * sizeof(double));
+  memcpy(Cmid, T->Cmid, deg * n * sizeof(double));
+  return 0;
 }
 
 void orc_destroy(orc* o) {
