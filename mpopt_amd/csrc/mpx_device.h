@@ -93,6 +93,23 @@ struct MpxNodeArgs {
   int32_t abs_cap, pad2_;
 };
 
+// All phases of a single-degree grid in ONE launch (mpx_node_<mode>_all_<deg>; round 5): the phases of an OCP share one grid
+// (mpopt.py:70-75), so their buckets have the same degree and differ only in offsets and in the generated node functions.  A
+// launch per phase pays a prologue, a tail and a kernel boundary each (config 4: two phases of 7 tiles) -- here the workgroups
+// of all phases are ONE grid: item -> (tile of the launch, evaluation point), XCD-blocked over the whole grid; tile t belongs to
+// the phase with tile_cum[ph] <= t < tile_cum[ph + 1] and is tile t - tile_cum[ph] of that phase's range.  The kernel-side
+// array has the code object's phase count (MPX_NPH, generated source); the host passes the first n_ph entries.
+#ifdef MPX_NPH
+#define MPX_NPH_ARGS MPX_NPH
+#else
+#define MPX_NPH_ARGS MPX_MAX_PHASES
+#endif
+struct MpxNodeMultiArgs {
+  int32_t tile_cum[MPX_MAX_PHASES + 1];
+  int32_t n_ph;
+  MpxNodeArgs a[MPX_NPH_ARGS];
+};
+
 // Light passes (f, g, grad_f without the Jacobian values) of a phase whose grid has ONE high degree (12 < P <= 31, contractions on the
 // matrix cores) and otherwise low degrees (<= 12), mpx_kernels.h: light_body.  A wavefront works on a GROUP: up to 16 consecutive
 // segments of the high degree plus every low-degree segment between them -- one contiguous span of the phase's nodes, read and
@@ -126,6 +143,18 @@ struct MpxLightArgs {
   int32_t n_groups, first_node;  // first_node: bucket-local node of point 1 of the bucket's first whole segment (0 or 1)
   int32_t span_cap, slot_first;  // LDS doubles per row and wavefront; first partial-sum slot of the phase (group g writes slot_first + g)
   long long* dbg;           // MPX_LIGHT_DEBUG=1 (code objects built with -DMPX_LIGHT_STAMPS): phase stamps of one wavefront, else NULL
+};
+
+// ... and the low-degree span kernels of all phases in one launch (mpx_lightlow*_all_<deg>): item -> (span, phase, evaluation point);
+// what differs between the phases of a grid is the offsets below (and the generated functions).  `base` carries phase 0.
+struct MpxLightPhase {
+  int64_t z_off, g_off_F, g_off_C, g_off_DU, g_off_mU;
+  int32_t seg_off, slot_first;
+};
+struct MpxLightMultiArgs {
+  MpxLightArgs base;
+  int32_t n_ph, pad_;
+  MpxLightPhase ph[MPX_NPH_ARGS];
 };
 
 // Mixed-degree grids, hess_l pass: the node Hessian does not depend on the polynomial degree (no D.X contraction), so its tiles

@@ -275,6 +275,7 @@ FULL_EXTRA_CASES = [
     (dae_vdp, 2000, [30 if s % 3 == 1 else 3 for s in range(2000)], "CGL"),
     (time_dependent, 4000, 3, "LGR"),
     (time_dependent, 2000, [30 if s % 3 == 1 else 3 for s in range(2000)], "CGL"),
+    (time_dependent, 8000, 3, "LGR"),  # stress: twice config 5's nodes
 ]
 
 

@@ -96,6 +96,33 @@ def test_c_oracle_matches_reference(name):
     assert np.array_equal(g1, r["g"]) and np.array_equal(v1, r["jac_val"])
 
 
+@pytest.mark.parametrize("name", list(C_CASES))
+def test_c_oracle_long_double_build_is_pinned_to_the_same_goldens(name):
+    """The arbiter of the full-size parity tests (oracle/mpopt_oracle.c built with -DORC_LONG_DOUBLE: the same source, every double an
+    80-bit long double, the binary64 build's tables): pinned to the reference's goldens like the binary64 build, equal to it to
+    1e-13 on these small grids, and its COO patterns are the same arrays."""
+    names, st, midu = C_CASES[name]
+    _, S, po, scheme = problems.GOLDEN_CASES[name]
+    G = load_golden(name)
+    C, L = COracle(names, S, po, scheme, scale_t=st, midu=midu), COracle(names, S, po, scheme, scale_t=st, midu=midu, long_double=True)
+    a, b = C.eval(G["z"], G["p"]), L.eval(G["z"], G["p"])
+    assert np.array_equal(a["jac_row"], b["jac_row"]) and np.array_equal(a["jac_col"], b["jac_col"])
+    for k in ("f", "g", "grad_f", "jac_val"):
+        assert rel_err(a[k], b[k]) < 1e-13, k
+    assert rel_err(b["f"], G["f"]) < TOL and rel_err(b["g"], G["g"]) < TOL and rel_err(b["grad_f"], G["grad_f"]) < TOL
+    J, Jr = np.zeros((C.n_g, C.n_z)), np.zeros((C.n_g, C.n_z))
+    J[b["jac_row"], b["jac_col"]] = b["jac_val"]
+    Jr[G["jac_row"], G["jac_col"]] = G["jac_val"]
+    assert rel_err(J, Jr) < TOL
+    ha, hb = C.hess(G["z"], G["p"], float(G["sigma"]), G["lam"]), L.hess(G["z"], G["p"], float(G["sigma"]), G["lam"])
+    assert np.array_equal(ha["hess_row"], hb["hess_row"]) and np.array_equal(ha["hess_col"], hb["hess_col"]) and rel_err(ha["hess_val"], hb["hess_val"]) < 1e-13
+    Hr = np.zeros((C.n_z, C.n_z))
+    Hr[G["hess_row"], G["hess_col"]] = G["hess_val"]
+    assert rel_err(L.hess_matrix(G["z"], G["p"], float(G["sigma"]), G["lam"]).toarray(), Hr) < TOL
+    for x, y, g_ in zip(C.grad_gamma(G["z"], G["p"], float(G["sigma"]), G["lam"]), L.grad_gamma(G["z"], G["p"], float(G["sigma"]), G["lam"]), (G["grad_gamma_x"], G["grad_gamma_p"])):
+        assert rel_err(x, y) < 1e-13 and rel_err(y, g_) < TOL
+
+
 @pytest.mark.parametrize("S,po,scheme", [(5, 3, "LGR"), (3, [2, 4, 3], "CGL"), (1, [5], "LGL")])
 def test_c_oracle_time_dependent_problem_matches_numpy_oracle(S, po, scheme):
     """The synthetic time-dependent problem of the C oracle (hand-written first and second derivatives incl. every d/dt term,
