@@ -303,6 +303,11 @@ class ProblemProgram:
                     parts.append(f"MPX_INSTANTIATE_LIGHT({ph}, {d})")
                 if d <= 12 and len(self.degrees) == 1 and self.light_low_chunks(d) >= 2:  # ... and of single-degree grids of low degree (light_low_body)
                     parts.append(f"MPX_INSTANTIATE_LIGHT_LOW({ph}, {d})")
+        if nph > 1 and len(self.degrees) == 1:  # all phases of a single-degree grid in ONE launch (mpx_kernels.h: node_all, light_low_all)
+            d = self.degrees[0]
+            parts.append(f"MPX_INSTANTIATE_NODE_ALL({d})")
+            if d <= 12 and self.light_low_chunks(d) >= 2:
+                parts.append(f"MPX_INSTANTIATE_LIGHT_LOW_ALL({d})")
         parts.append("MPX_INSTANTIATE_BOUNDARY()")
         # (read by libmpx at load: 0 = no node function of any phase uses the node time, the widths' prefix sums are not needed)
         parts.append('extern "C" __device__ __attribute__((used)) const int mpx_time_dependent = '

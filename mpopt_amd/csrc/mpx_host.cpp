@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -703,6 +704,20 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     hipError_t e = hipModuleGetFunction(&c->fn_bound[m], c->module, name);
     if (e != hipSuccess) return fail(c, MPX_ERR_INVALID, "code object lacks kernel %s", name);
   }
+  if (c->n_phases > 1 && c->degs.size() == 1) {  // all phases in one launch (optional kernels)
+    static const char* lm[2] = {"fg", "fgq"};
+    char name[96];
+    for (int m = 0; m < 3; ++m) {
+      snprintf(name, sizeof name, "mpx_node_%s_all_%d", modes[m], c->degs[0].deg);
+      if (hipModuleGetFunction(&c->fn_node_all[m], c->module, name) != hipSuccess) c->fn_node_all[m] = nullptr, (void)hipGetLastError();
+    }
+    for (int m = 0; m < 2 && c->lplan.low; ++m) {
+      snprintf(name, sizeof name, "mpx_lightlow_%s_all_%d", lm[m], c->degs[0].deg);
+      if (hipModuleGetFunction(&c->fn_lightlow_all[m], c->module, name) != hipSuccess) c->fn_lightlow_all[m] = nullptr, (void)hipGetLastError();
+      snprintf(name, sizeof name, "mpx_lightlows_%s_all_%d", lm[m], c->degs[0].deg);
+      if (hipModuleGetFunction(&c->fn_lightlows_all[m], c->module, name) != hipSuccess) c->fn_lightlows_all[m] = nullptr, (void)hipGetLastError();
+    }
+  }
   // row spans of more than the default 64 KB of LDS per workgroup: raise the dynamic shared memory limit of the absorbing kernels
   for (auto& B : c->buckets) {
     const int64_t dyn = (int64_t)B.abs_cap * B.abs_slots * 8;
@@ -1156,6 +1171,11 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
     // exactly those -- see below --, so the other slots need no clearing)
     static int n_cu = 0;
     if (!n_cu && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) n_cu = 256;
+    // one launch for all phases where the code object has the kernels (single-degree grid, n_phases > 1); MPX_NO_PHASE_MERGE=1: A/B
+    const int lmode = mode == MPX_MODE_FGJ ? 1 : 0;
+    const bool merged_light = c->lplan.low && c->n_phases > 1 && (light_small ? c->fn_lightlows_all : c->fn_lightlow_all)[lmode] != nullptr &&
+                              (int)c->buckets.size() == c->n_phases && !getenv("MPX_NO_PHASE_MERGE");
+    MpxLightMultiArgs LM{};
     for (auto& B : c->buckets) {
       if (B.deg != c->lplan.deg) continue;
       const PhaseStruct& P = c->ph[B.phase];
@@ -1179,9 +1199,21 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       static long long* ldbg = nullptr;
       if (!ldbg && getenv("MPX_LIGHT_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
       L.dbg = ldbg;
-      const int64_t items = (int64_t)L.n_groups * io.B;
       int per_cu = 2;  // resident workgroups per compute unit (the kernels' launch bounds)
       if (const char* e = getenv("MPX_LIGHT_PER_CU")) per_cu = std::max(1, atoi(e));
+      if (merged_light) {  // collect the phases; the launch follows the last one
+        if (B.phase == 0) LM.base = L;
+        LM.ph[B.phase] = MpxLightPhase{A.z_off, A.g_off_F, A.g_off_C, A.g_off_DU, A.g_off_mU, A.seg_off, L.slot_first};
+        if (++LM.n_ph < c->n_phases) continue;
+        const int64_t items = (int64_t)L.n_groups * c->n_phases * io.B;
+        const unsigned wgs = (unsigned)std::min<int64_t>((items + MPX_LIGHT_WAVES - 1) / MPX_LIGHT_WAVES, per_cu * (int64_t)n_cu);
+        int rc = launch(c, (small ? c->fn_lightlows_all : c->fn_lightlow_all)[lmode], dim3(wgs, 1, 1), dim3(64 * MPX_LIGHT_WAVES, 1, 1), &LM,
+                        offsetof(MpxLightMultiArgs, ph) + (size_t)c->n_phases * sizeof(MpxLightPhase));
+        if (rc) return rc;
+        if (c->profile) ++c->prof_launches;
+        continue;
+      }
+      const int64_t items = (int64_t)L.n_groups * io.B;
       const unsigned wgs = (unsigned)std::min<int64_t>((items + MPX_LIGHT_WAVES - 1) / MPX_LIGHT_WAVES, per_cu * (int64_t)n_cu);
       const unsigned lds = c->lplan.low ? 0u : (unsigned)((MPX_LIGHT_WAVES * (c->nx + c->nu) * c->lplan.span_cap + c->lplan.ftab.size()) * 8);
       int rc = launch(c, (small ? B.fn_light_small : B.fn_light)[mode == MPX_MODE_FGJ ? 1 : 0], dim3(wgs, 1, 1), dim3(64 * MPX_LIGHT_WAVES, 1, 1), &L, sizeof L, lds);
@@ -1224,7 +1256,40 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       }
     }
   }
-  for (int pass = 0; pass < 2 && !by_node && !light; ++pass)
+  // All phases of a single-degree grid in ONE launch (mpx_kernels.h: node_all): the x dimension of the grid holds the tiles of the
+  // phases' ranges one after the other.  MPX_NO_PHASE_MERGE=1 (read per call): one launch per phase, the same bits (tested).
+  bool merged_nodes = false;
+  if (!by_node && !light && nodes && c->fn_node_all[mode] && c->n_phases > 1 && (int)c->buckets.size() == c->n_phases && !absorb &&
+      !getenv("MPX_NO_PHASE_MERGE")) {
+    MpxNodeMultiArgs M{};
+    int64_t total = 0;
+    for (auto& B : c->buckets) {
+      const int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);
+      MpxNodeArgs& A = M.a[B.phase];
+      A = node_args_static(c, B, false);
+      A.io = io;
+      A.tile_first = (int32_t)std::min(lo, hi);
+      A.tile_count = (int32_t)std::max<int64_t>(hi - lo, 0);
+    }
+    bool in_order = true;  // (buckets in phase order: tile_cum below relies on it)
+    for (int p = 0; p < c->n_phases; ++p) in_order = in_order && c->buckets[p].phase == p;
+    for (int p = 0; p < c->n_phases; ++p) M.tile_cum[p] = (int32_t)total, total += M.a[p].tile_count;
+    for (int p = c->n_phases; p <= MPX_MAX_PHASES; ++p) M.tile_cum[p] = (int32_t)total;
+    M.n_ph = c->n_phases;
+    if (in_order && total > 0) {
+      merged_nodes = true;
+      for (int64_t bf = 0; bf < (int64_t)gy * io.b_per_block; bf += (int64_t)65535 * io.b_per_block) {
+        for (int p = 0; p < c->n_phases; ++p) M.a[p].io.b_first = (int32_t)bf;
+        const int gys = (int)std::min<int64_t>(65535, gy - bf / io.b_per_block);
+        int rc = launch(c, c->fn_node_all[mode], dim3((unsigned)total, gys, 1), dim3(MPX_TILE, 1, 1), &M, offsetof(MpxNodeMultiArgs, a) + (size_t)c->n_phases * sizeof(MpxNodeArgs));
+        if (rc) return rc;
+        if (c->profile) ++c->prof_launches;
+      }
+    } else if (in_order) {
+      merged_nodes = true;  // nothing to run in this tile range
+    }
+  }
+  for (int pass = 0; pass < 2 && !by_node && !light && !merged_nodes; ++pass)
   for (auto& B : c->buckets) {
     const bool absorber = absorb && B.abs_cap > 0;
     int64_t lo = std::max<int64_t>(B.tile_first, c->tile_begin), hi = std::min<int64_t>(B.tile_first + B.tile_count, c->tile_end);

@@ -94,6 +94,10 @@ struct mpx_ctx {
   bool time_dep = true;  // some node function uses the node time (mpx_time_dependent of the code object; true when the symbol is absent): else no prefix sums of the widths
   hipModule_t module = nullptr;
   hipFunction_t fn_bound[3] = {nullptr, nullptr, nullptr};
+  // all phases of a single-degree grid in one launch (n_phases > 1; mpx_node_<mode>_all_<deg>, mpx_lightlow[s]_<fg|fgq>_all_<deg>);
+  // nullptr: the code object has none (one degree per phase only, or generated before round 5) -- one launch per phase then
+  hipFunction_t fn_node_all[3] = {nullptr, nullptr, nullptr};
+  hipFunction_t fn_lightlow_all[2] = {nullptr, nullptr}, fn_lightlows_all[2] = {nullptr, nullptr};
   hipStream_t stream = nullptr;
   MpxTile* d_tiles = nullptr;
   double* d_Wnode = nullptr;

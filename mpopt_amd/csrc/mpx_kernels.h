@@ -230,8 +230,19 @@ __device__ __forceinline__ void stream_regs(SlotStream<VEC>& S, F reg_val) {  //
   }
 }
 
+// Static LDS keyed by size and tag ONLY: node_body<PH, ...> of different phases (or modes) inlined into one kernel -- the all-phases
+// kernels below, the resident kernel -- get the SAME block instead of one per instantiation (the phases of an OCP have the same
+// nx / nu, mpopt.py:3407-3409, so their blocks have the same size; a workgroup runs one phase).
+template <int N_DOUBLES, int TAG>
+__device__ __forceinline__ double* mpx_lds() {
+  __shared__ double blk[N_DOUBLES > 0 ? N_DOUBLES : 1];
+  return blk;
+}
+
 template <int PH, int P, int MODE>
-__device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx = -1) {  // res_bx >= 0: called by the resident kernel for tile res_bx of the bucket
+__device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx = -1, const int item_bx = -1, const unsigned item_by = 0) {
+  // res_bx >= 0: called by the resident kernel for tile res_bx of the bucket;  item_bx >= 0: called by the all-phases kernel
+  // (node_all below) with the workgroup's tile of THIS phase's range and its chunk of evaluation points already worked out
   using G = mpxgen::Phase<PH>;
   constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
   constexpr int P1 = P + 1;
@@ -243,8 +254,9 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
   // control-slope rows, interpolation blocks of the mid-point rows
   constexpr int NS_MAIN = NX * P1 + G::NJV + (G::DIFF_U ? NU * P1 : 0);
   constexpr int NS_MID = G::MIDU ? NU * P1 : 0;
-  __shared__ double sXU[2][NX + NU][SLOTS];
-  __shared__ double sRed[2][MPX_TILE / 64][NRED1];
+  double(*sXU)[NX + NU][SLOTS] = reinterpret_cast<double(*)[NX + NU][SLOTS]>(mpx_lds<2 * (NX + NU) * SLOTS, 0>());  // [2][NX + NU][SLOTS]
+  constexpr int NRED_LDS = 12;  // (one block for every mode and phase: NRED differs between them, the block does not)
+  double(*sRed)[MPX_TILE / 64][NRED1] = reinterpret_cast<double(*)[MPX_TILE / 64][NRED1]>(mpx_lds<2 * (MPX_TILE / 64) * (NRED1 > NRED_LDS ? NRED1 : NRED_LDS), 1>());
   extern __shared__ double sAbs[];  // absorbing tiles: [row slot][abs_cap] g / grad_f values of the tile's node span
 
   // Workgroup -> (tile, batch chunk).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin;
@@ -254,12 +266,13 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
   // every XCD at a different phase of its range: +-0.
   // (MPX_MAP_NATURAL restores blockIdx.x = tile, blockIdx.y = chunk for A/B runs.)
 #if defined(MPX_MAP_NATURAL)
-  const unsigned bx_ = res_bx >= 0 ? (unsigned)res_bx : blockIdx.x, by_ = res_bx >= 0 ? 0u : blockIdx.y;
+  const unsigned bx_ = item_bx >= 0 ? (unsigned)item_bx : res_bx >= 0 ? (unsigned)res_bx : blockIdx.x, by_ = item_bx >= 0 ? item_by : res_bx >= 0 ? 0u : blockIdx.y;
 #else
   const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x, tot_ = gridDim.x * gridDim.y;
   const unsigned xcd_ = lin_ % 8, q_ = tot_ / 8, r_ = tot_ % 8;  // XCD j owns q_ + (j < r_) items
   const unsigned item_ = xcd_ * q_ + (xcd_ < r_ ? xcd_ : r_) + lin_ / 8;  // bijection [0, tot) -> [0, tot)
-  const unsigned bx_ = res_bx >= 0 ? (unsigned)res_bx : item_ % gridDim.x, by_ = res_bx >= 0 ? 0u : item_ / gridDim.x;
+  const unsigned bx_ = item_bx >= 0 ? (unsigned)item_bx : res_bx >= 0 ? (unsigned)res_bx : item_ % gridDim.x;
+  const unsigned by_ = item_bx >= 0 ? item_by : res_bx >= 0 ? 0u : item_ / gridDim.x;
 #endif
 #ifdef MPX_NO_REGULAR
   const bool regular = false;
@@ -315,8 +328,8 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
   // banks, equal points broadcast.
   constexpr bool TAB_LDS = (P > MPX_TABLES_IN_LDS_ABOVE);
   constexpr int NREG = TAB_LDS ? 1 : P1;
-  __shared__ double sD[TAB_LDS ? P1 * P1 : 1];
-  __shared__ double sC[TAB_LDS ? P * P1 : 1];
+  double* const sD = mpx_lds<(TAB_LDS ? P1 * P1 : 1), 2>();
+  double* const sC = mpx_lds<(TAB_LDS ? P * P1 : 1), 3>();
   double Drow_[NREG], Crow_[NREG], Dmrow_[NREG];
   const int drow = k * P1, crow = (k >= 1 ? k - 1 : 0) * P1;
   // MPX_MID_RESID (hess_l pass only, degrees with the tables in registers): residual of the dynamics at the mid-point before node k
@@ -743,6 +756,34 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
   }
 }
 
+// All phases of a single-degree grid in one launch (MpxNodeMultiArgs): the grid's x dimension holds the tiles of every phase one
+// after the other, the XCD-blocked item walk runs over the WHOLE grid (so an XCD still streams one contiguous share of the
+// outputs), and a workgroup dispatches on the phase its tile belongs to -- uniform per workgroup; the node functions of the
+// phases are different generated code, the register budget of the kernel is the largest of them.  Bit-identical to the
+// per-phase launches (same node_body, same tile, same slots).
+template <int P, int MODE, int PH = 0>
+__device__ __forceinline__ void node_all_dispatch(const MpxNodeMultiArgs& M, const int ph, const int bx, const unsigned by) {
+  if constexpr (PH < MPX_NPH) {
+    if (ph == PH) node_body<PH, P, MODE>(M.a[PH], -1, bx, by);
+    else node_all_dispatch<P, MODE, PH + 1>(M, ph, bx, by);
+  }
+}
+template <int P, int MODE>
+__device__ __forceinline__ void node_all(const MpxNodeMultiArgs& M) {
+#if defined(MPX_MAP_NATURAL)
+  const unsigned gt = blockIdx.x, by = blockIdx.y;
+#else
+  const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x, tot_ = gridDim.x * gridDim.y;
+  const unsigned xcd_ = lin_ % 8, q_ = tot_ / 8, r_ = tot_ % 8;
+  const unsigned item_ = xcd_ * q_ + (xcd_ < r_ ? xcd_ : r_) + lin_ / 8;
+  const unsigned gt = item_ % gridDim.x, by = item_ / gridDim.x;
+#endif
+  int ph = 0;
+#pragma unroll
+  for (int q = 1; q < MPX_NPH; ++q) ph += (q < M.n_ph && (int)gt >= M.tile_cum[q]) ? 1 : 0;
+  node_all_dispatch<P, MODE>(M, ph, (int)gt - M.tile_cum[ph], by);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Light passes -- f, g and grad_f WITHOUT the Jacobian values, what a line search calls (nlp_f / nlp_g alone) -- of grids with a high
 // degree (MPX_TABLES_IN_LDS_ABOVE < P <= 31).  In node_body such a pass is bound by the LDS pipe, not by HBM: every lane re-reads its
@@ -1153,14 +1194,24 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
 // SMALL batches can run the same arithmetic with one chunk per wavefront (SMALL = true: a single evaluation keeps 79 wavefronts busy at config 2 instead of 10; with the long
 // spans a single nlp_f + nlp_g + nlp_grad_f pass took 33 instead of 22 us) and still give the bits of a large batch.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int PH, int P, int MODE, bool SMALL>
-__device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
-  using G = mpxgen::Phase<PH>;
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for_n(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_n<N, I + 1>(f);
+  }
+}
+
+// One implementation for the per-phase kernels (PH0 = the phase, NPHK = 1) and the all-phases kernels (PH0 = 0, NPHK = MPX_NPH;
+// round 5): there an item is (span, phase, evaluation point) -- the phases of a grid share its nodes and tables and differ in the
+// offsets of MpxLightPhase and in the generated functions; a wavefront dispatches on the phase of its item.  One launch, one
+// table prologue and one tail for all phases (config 4: 8 items per wavefront instead of two launches of 4).
+template <int P, int MODE, bool SMALL, int PH0, int NPHK>
+__device__ __forceinline__ void light_low_run(const MpxLightArgs& L, const MpxLightPhase* __restrict__ phases) {
+  using G0 = mpxgen::Phase<PH0>;
   const MpxNodeArgs& A = L.node;
-  constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC;
+  constexpr int NX = G0::NX, NU = G0::NU, NA = G0::NA;
   constexpr int NIN = NX + NU, P1 = P + 1;
-  constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : G::NRED;
-  constexpr int R_C = NX, R_DU = NX + NC, R_MU = R_DU + (G::DIFF_U ? NU : 0), NG = R_MU + (G::MIDU ? NU : 0);
   // span geometry, compile time: rows of CAP doubles per wavefront in 52 KB of LDS per workgroup; CHL chunks of 64 owned nodes
   constexpr int CAP0 = 53248 / (8 * MPX_LIGHT_WAVES * NIN);
   constexpr int CHL = SMALL ? 1 : ((CAP0 - 2 * P - 8) / 64 > MPX_LOW_MAX_CHUNKS ? MPX_LOW_MAX_CHUNKS : ((CAP0 - 2 * P - 8) / 64 < 1 ? 1 : (CAP0 - 2 * P - 8) / 64));
@@ -1179,7 +1230,7 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
   __syncthreads();  // (the only barrier of the kernel)
   const bool want_g = io.g != nullptr, want_q = MODE == MPX_MODE_FGJ && io.grad != nullptr;
   const int n_groups = (N + OWN - 1) / OWN;
-  const int64_t total = (int64_t)n_groups * (io.B - io.b_first), stride = (int64_t)gridDim.x * MPX_LIGHT_WAVES;
+  const int64_t total = (int64_t)n_groups * NPHK * (io.B - io.b_first), stride = (int64_t)gridDim.x * MPX_LIGHT_WAVES;
   auto lds_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 #ifdef MPX_LIGHT_STAMPS
   int it_ = 0;
@@ -1187,21 +1238,25 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
 #else
 #define MPX_LSTAMP(k)
 #endif
-  for (int64_t item = (int64_t)light_block_xcd() * MPX_LIGHT_WAVES + wave; item < total; item += stride) {
+  // one item: span gi of phase PHc::value (offsets Q) at evaluation point b
+  auto run_item = [&](auto PHc, const MpxLightPhase& Q, const int gi, const int b) {
+    using G = mpxgen::Phase<decltype(PHc)::value>;
+    static_assert(G::NX == NX && G::NU == NU && G::NA == NA, "the phases of an OCP have the same numbers of states, controls and parameters");
+    constexpr int NC = G::NC;
+    constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : G::NRED;
     MPX_LSTAMP(0)
-    const int gi = (int)(item % n_groups), b = io.b_first + (int)(item / n_groups);
     const int lo_w = gi * OWN, len_w = N - lo_w < OWN ? N - lo_w : OWN;
     const int lo_r = lo_w == 0 ? 0 : ((lo_w - 1) / P) * P;                 // point 0 of the first owned node's segment
     const int i_last = lo_w + len_w - 1;
     const int hi_r = i_last == 0 ? 1 : ((i_last - 1) / P + 1) * P + 1;    // one past the last node of the last owned node's segment
     const int len_r = hi_r - lo_r;
-    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + A.z_off;
+    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + Q.z_off;
     const double* __restrict__ zt = zb + (int64_t)NIN * N;
     const double t0v = zt[0], tfv = zt[1];
     Vec<NA> As;
 #pragma unroll
     for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
-    const int64_t woff = (int64_t)b * io.w_stride + A.seg_off;
+    const int64_t woff = (int64_t)b * io.w_stride + Q.seg_off;
     // the lane's nodes and the widths of their segments (loads in flight together with the span's)
     int sg[CHL], kk[CHL];
     double wsv[CHL], wcv[CHL];
@@ -1252,7 +1307,7 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
     // The lanes of a chunk hold CONSECUTIVE nodes, so every row of g / grad_f leaves as one 512-byte store per chunk straight from
     // the registers (no staging; the mid-point rows are the same run shifted by one node)
     double* __restrict__ gb = want_g ? io.g + (int64_t)b * io.g_stride : nullptr;
-    double* __restrict__ qb = want_q ? io.grad + (int64_t)b * io.grad_stride + A.z_off : nullptr;
+    double* __restrict__ qb = want_q ? io.grad + (int64_t)b * io.grad_stride + Q.z_off : nullptr;
 #pragma unroll
     for (int u = 0; u < CHL; ++u) {
       const int i = lo_w + 64 * u + l;
@@ -1287,7 +1342,7 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
           for (int r = 0; r < NRED; ++r) {
             const double v = wave_total_dpp(valid ? gr[r] : 0.0);
             if constexpr (SMALL) {
-              if (l == 0) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + (lo_w >> 6)) * io.nred + r] = v;
+              if (l == 0) io.partial[((int64_t)b * io.n_tiles_total + Q.slot_first + (lo_w >> 6)) * io.nred + r] = v;
             } else {
               tot[r] = u == 0 ? 0.0 + v : tot[r] + v;
             }
@@ -1341,17 +1396,17 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
         }
         if (valid) {
 #pragma unroll
-          for (int a = 0; a < NX; ++a) gb[A.g_off_F + (int64_t)a * N + i] = dx[a];
+          for (int a = 0; a < NX; ++a) gb[Q.g_off_F + (int64_t)a * N + i] = dx[a];
 #pragma unroll
-          for (int jj = 0; jj < NC; ++jj) gb[A.g_off_C + (int64_t)jj * N + i] = cc[jj];
+          for (int jj = 0; jj < NC; ++jj) gb[Q.g_off_C + (int64_t)jj * N + i] = cc[jj];
           if constexpr (G::DIFF_U) {
 #pragma unroll
-            for (int c = 0; c < NU; ++c) gb[A.g_off_DU + (int64_t)c * N + i] = du[c];
+            for (int c = 0; c < NU; ++c) gb[Q.g_off_DU + (int64_t)c * N + i] = du[c];
           }
           if constexpr (G::MIDU) {
             if (k >= 1) {  // (node 0 has no mid-point row)
 #pragma unroll
-              for (int c = 0; c < NU; ++c) gb[A.g_off_mU + (int64_t)c * (N - 1) + i - 1] = mu[c];
+              for (int c = 0; c < NU; ++c) gb[Q.g_off_mU + (int64_t)c * (N - 1) + i - 1] = mu[c];
             }
           }
         }
@@ -1361,15 +1416,38 @@ __device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
     if constexpr (!SMALL) {
       if (l == 0) {
 #pragma unroll
-        for (int r = 0; r < NRED; ++r) io.partial[((int64_t)b * io.n_tiles_total + L.slot_first + gi) * io.nred + r] = tot[r];
+        for (int r = 0; r < NRED; ++r) io.partial[((int64_t)b * io.n_tiles_total + Q.slot_first + gi) * io.nred + r] = tot[r];
       }
     }
     MPX_LSTAMP(3)
 #ifdef MPX_LIGHT_STAMPS
     ++it_;
 #endif
+  };
+  for (int64_t item = (int64_t)light_block_xcd() * MPX_LIGHT_WAVES + wave; item < total; item += stride) {
+    const int gi = (int)(item % n_groups);
+    if constexpr (NPHK == 1) {
+      run_item(std::integral_constant<int, PH0>{}, phases[0], gi, io.b_first + (int)(item / n_groups));
+    } else {  // (the phases of one evaluation point next to each other: its z is read once through the caches)
+      const int64_t rest = item / n_groups;
+      const int ph = (int)(rest % NPHK), b = io.b_first + (int)(rest / NPHK);
+      static_for_n<NPHK>([&](auto K) {
+        if (ph == decltype(K)::value) run_item(std::integral_constant<int, PH0 + decltype(K)::value>{}, phases[decltype(K)::value], gi, b);
+      });
+    }
   }
 #undef MPX_LSTAMP
+}
+
+template <int PH, int P, int MODE, bool SMALL>
+__device__ __forceinline__ void light_low_body(const MpxLightArgs& L) {
+  const MpxNodeArgs& A = L.node;
+  const MpxLightPhase Q{A.z_off, A.g_off_F, A.g_off_C, A.g_off_DU, A.g_off_mU, A.seg_off, L.slot_first};
+  light_low_run<P, MODE, SMALL, PH, 1>(L, &Q);
+}
+template <int P, int MODE, bool SMALL>
+__device__ __forceinline__ void light_low_all(const MpxLightMultiArgs& M) {
+  light_low_run<P, MODE, SMALL, 0, MPX_NPH>(M.base, M.ph);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2160,6 +2238,31 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
   }                                                                                                                           \
   extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(PH)) void mpx_lightlows_fgq_##PH##_##P(const MpxLightArgs A) {  \
     mpxk::light_low_body<PH, P, MPX_MODE_FGJ, true>(A);                                                                       \
+  }
+
+// all phases of a single-degree grid in one launch (generated for OCPs with more than one phase; MpxNodeMultiArgs / MpxLightMultiArgs)
+#define MPX_INSTANTIATE_NODE_ALL(P)                                                                                            \
+  extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_fg_all_##P(const MpxNodeMultiArgs M) {        \
+    mpxk::node_all<P, MPX_MODE_FG>(M);                                                                                         \
+  }                                                                                                                            \
+  extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_WAVES_FOR(P)) void mpx_node_fgj_all_##P(const MpxNodeMultiArgs M) {    \
+    mpxk::node_all<P, MPX_MODE_FGJ>(M);                                                                                        \
+  }                                                                                                                            \
+  extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_hess_all_##P(const MpxNodeMultiArgs M) {      \
+    mpxk::node_all<P, MPX_MODE_HESS>(M);                                                                                       \
+  }
+#define MPX_INSTANTIATE_LIGHT_LOW_ALL(P)                                                                                       \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(0)) void mpx_lightlow_fg_all_##P(const MpxLightMultiArgs M) {   \
+    mpxk::light_low_all<P, MPX_MODE_FG, false>(M);                                                                             \
+  }                                                                                                                            \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(0)) void mpx_lightlow_fgq_all_##P(const MpxLightMultiArgs M) {  \
+    mpxk::light_low_all<P, MPX_MODE_FGJ, false>(M);                                                                            \
+  }                                                                                                                            \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(0)) void mpx_lightlows_fg_all_##P(const MpxLightMultiArgs M) {  \
+    mpxk::light_low_all<P, MPX_MODE_FG, true>(M);                                                                              \
+  }                                                                                                                            \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LOW_WPS(0)) void mpx_lightlows_fgq_all_##P(const MpxLightMultiArgs M) { \
+    mpxk::light_low_all<P, MPX_MODE_FGJ, true>(M);                                                                             \
   }
 
 #define MPX_INSTANTIATE_GRADL(PH, P)                                                                        \

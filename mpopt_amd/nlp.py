@@ -309,7 +309,7 @@ class NlpFunctions:
                                                 _ptr(grad_gamma_x), _ptr(grad_gamma_p))
         _lib.check(rc, self._ctx)
 
-    def alloc_outputs(self, mask, batch, z, p, p_per_point=0, lam_g=None, sigma=None, tries=6):
+    def alloc_outputs(self, mask, batch, z, p, p_per_point=0, lam_g=None, sigma=None, tries=16, target_us=None):
         """Output arrays for ``eval_device(mask, batch, ...)`` -- torch tensors f [batch], g [batch, n_g], grad_f [batch, n_z],
         jac_val [batch, nnz_jac], hess_val [batch, nnz_hess] for the outputs ``mask`` names, ``None`` for the others -- placed by
         MEASUREMENT: the node kernels stream into several GB of output per pass, and how fast the HBM controllers drain those
@@ -319,7 +319,12 @@ class NlpFunctions:
         sets are allocated (all held until the end: a freed slow placement would be handed out again), each is timed with the real
         inputs, the search stops early once a candidate is 8 % faster than the slowest seen (placements come in two states), the
         fastest is returned and the rest is freed.  A one-time cost of a few passes per candidate at set-up; results do not depend on it.
-        Returns ``(outputs, report)``; report = node-kernel microseconds per pass of every candidate, and the index kept."""
+        ``target_us`` (round 5): the node-kernel time per pass the caller knows a well-placed set reaches (e.g. the algorithmic bytes of
+        the pass over 0.95 of the measured HBM copy rate for the metric's kernel): the search then stops at the first candidate within
+        3 % of it and otherwise keeps drawing up to ``tries`` (default 16 since round 5: with one fast placement in six -- the driver's
+        round-4 box -- six draws missed it every third time).  Without a target the relative rule alone decides.
+        Returns ``(outputs, report)``; report = node-kernel microseconds per pass of every candidate, the index kept, ``tries_used``,
+        ``stopped_by`` ("target", "relative", "tries", "memory")."""
         import torch
 
         from ._lib import MPX_F, MPX_G, MPX_GRAD, MPX_HESS, MPX_JAC
@@ -329,8 +334,10 @@ class NlpFunctions:
                   (MPX_HESS, (batch, self.nnz_hess)))
         cands, times = [], []
         need = 8 * sum(int(np.prod(sh)) for bit, sh in shapes if mask & bit)
+        stopped = "tries"
         for _ in range(max(1, int(tries))):
             if cands and torch.cuda.mem_get_info(dev)[0] < 1.25 * need:
+                stopped = "memory"
                 break  # (the candidates are all held until the end: never search the device out of memory)
             outs = [torch.empty(sh, dtype=torch.float64, device=dev) if mask & bit else None for bit, sh in shapes]
             for _ in range(8):  # (the first six passes into new arrays are the library's own geometry measurement, include/mpx.h)
@@ -343,13 +350,19 @@ class NlpFunctions:
             self.profile(False)
             cands.append(outs)
             times.append(ms * 1e3 / 6.0)  # node kernels of one pass (all degree buckets)
-            if len(times) > 1 and times[-1] <= 0.92 * max(times):
+            if target_us is not None:
+                if times[-1] <= 1.03 * target_us:
+                    stopped = "target"
+                    break
+            elif len(times) > 1 and times[-1] <= 0.92 * max(times):
+                stopped = "relative"
                 break
         best = min(range(len(times)), key=times.__getitem__)
         keep = cands[best]
         del cands, outs
         torch.cuda.empty_cache()
-        return keep, {"node_us_per_pass": [round(t, 1) for t in times], "kept": best}
+        return keep, {"node_us_per_pass": [round(t, 1) for t in times], "kept": best, "tries_used": len(times), "stopped_by": stopped,
+                      "target_us": None if target_us is None else round(float(target_us), 1)}
 
     def geometry_reset(self):
         """Void the launch-geometry measurements (call after re-allocating output arrays; include/mpx.h)."""

@@ -460,8 +460,14 @@ def test_device_pointer_api_matches_host_api():
     o.sync()
     for k, v in zip(("f", "g", "grad_f", "jac_g"), outs):
         assert np.array_equal(v.cpu().numpy(), ref[k]), k
+    assert rep["tries_used"] == len(rep["node_us_per_pass"]) and rep["stopped_by"] in ("relative", "tries", "memory") and rep["target_us"] is None
     outs, rep = o.alloc_outputs(16, B, Z, p, 0, lam, sig, tries=2)
     assert outs[:4] == [None] * 4 and np.array_equal(outs[4].cpu().numpy(), ref["hess_l"])
+    # with a target: an unreachable one draws every candidate, a generous one stops at the first
+    outs, rep = o.alloc_outputs(1 | 2 | 4 | 8, B, Z, p, 0, None, None, tries=4, target_us=1e-3)
+    assert rep["tries_used"] == 4 and rep["stopped_by"] == "tries" and rep["target_us"] == 0.0
+    outs, rep = o.alloc_outputs(1 | 2 | 4 | 8, B, Z, p, 0, None, None, tries=4, target_us=1e9)
+    assert rep["tries_used"] == 1 and rep["stopped_by"] == "target" and rep["kept"] == 0
 
 
 @pytest.mark.parametrize("case,world", [("kitchen_sink_40", 3), ("vdp_mixed_3_30_3", 2), ("moon_lander_60x5", 4)])
@@ -555,6 +561,59 @@ def test_tile_range_with_one_rank_and_a_light_mask(case, monkeypatch):
     assert np.array_equal(g.cpu().numpy(), light["g"])
     assert np.abs(f.cpu().numpy() - light["f"]).max() <= 1e-13 * np.abs(light["f"]).max()
     assert np.abs(q.cpu().numpy() - light["grad_f"]).max() <= 1e-12 * max(1.0, np.abs(light["grad_f"]).max())
+
+
+@pytest.mark.parametrize("case", ["config4_full", "schwartz_30x3", "generic_two_phase_70x4", "kitchen_sink_40x5"])
+def test_all_phases_in_one_launch_equal_one_launch_per_phase(case, monkeypatch):
+    """Round 5: on single-degree grids with several phases the node kernels (f/g/grad_f/jac_g, hess_l) and the low-degree span
+    kernels of ALL phases run as one launch (mpx_node_<mode>_all_<deg>, mpx_lightlow[s]_*_all_<deg>; the phase loop of
+    mpopt.py:600-627 as a grid dimension).  Same tiles, same slots, same arithmetic: every output of every mask equals the
+    per-phase launches (MPX_NO_PHASE_MERGE=1) bit for bit -- single evaluations (short spans), a ragged batch, a batch large enough
+    for the long spans, per-point widths -- and the launch count of a pass drops by n_phases - 1."""
+    import torch
+
+    builder, S, po, scheme = {"config4_full": problems.BENCH_CASES[2], "kitchen_sink_40x5": (problems.kitchen_sink, 40, 5, "LGR")}.get(case) or REDUCED[case]
+    ocp = builder(mp, M.math)
+    assert ocp.n_phases > 1
+    mpo = mp.mpopt(ocp, S, po, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    assert "MPX_INSTANTIATE_NODE_ALL" in o.source and "MPX_INSTANTIATE_LIGHT_LOW_ALL" in o.source
+    rng = np.random.default_rng(77)
+    z0 = mpo.initialize_solution()
+    masks = (["f", "g", "grad_f", "jac_g"], ["hess_l"], ["f"], ["g"], ["f", "grad_f"], ["f", "g", "grad_f"], ["g", "jac_g"], ["f", "g", "grad_f", "jac_g", "hess_l"])
+    n_groups = o.light_plan()[1]
+    for B in (1, 5, -(-1100 // max(n_groups * ocp.n_phases, 1)) + 3):
+        Z = z0[None, :] * (1 + 0.02 * rng.uniform(-1, 1, (B, o.n_z))) + 0.02 * rng.uniform(-1, 1, (B, o.n_z))
+        w = rng.uniform(0.5, 1.5, (B, ocp.n_phases, o.n_segments))
+        P2 = (w / w.sum(2, keepdims=True)).reshape(B, -1)
+        lam, sig = rng.standard_normal((B, o.n_g)), rng.uniform(0.5, 1.5, B)
+        for p in (P2[0], P2):
+            merged = [o.eval(m, Z, p, lam_g=lam, sigma=sig) for m in masks]
+            monkeypatch.setenv("MPX_NO_PHASE_MERGE", "1")
+            split = [o.eval(m, Z, p, lam_g=lam, sigma=sig) for m in masks]
+            monkeypatch.delenv("MPX_NO_PHASE_MERGE")
+            for m, a, b in zip(masks, merged, split):
+                for k in m:
+                    assert np.array_equal(a[k], b[k]), (case, B, m, k)
+    # launches per pass (profile counters of the context): one node launch instead of n_phases
+    dev = torch.device("cuda", 0)
+    Zt, pt = torch.tensor(Z, device=dev), torch.tensor(P2[0], device=dev)
+    f, g = torch.empty(B, dtype=torch.float64, device=dev), torch.empty(B, o.n_g, dtype=torch.float64, device=dev)
+    jv = torch.empty(B, o.nnz_jac, dtype=torch.float64, device=dev)
+    counts = []
+    o.profile(True)
+    for split_ in (False, True):
+        if split_:
+            monkeypatch.setenv("MPX_NO_PHASE_MERGE", "1")
+        o.profile_read()
+        o.eval_device(1 | 2 | 8, B, Zt, pt, 0, None, None, f, g, None, jv, None)
+        o.eval_device(1 | 2, B, Zt, pt, 0, None, None, f, g, None, None, None)
+        o.sync()
+        counts.append(o.profile_read()[1])
+    o.profile(False)
+    monkeypatch.delenv("MPX_NO_PHASE_MERGE")
+    assert counts[1] - counts[0] == 2 * (ocp.n_phases - 1), counts
+    o.close()
 
 
 def test_edge_cases_default_ocp_and_extreme_grids():
