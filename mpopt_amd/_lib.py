@@ -38,6 +38,12 @@ class MpxError(RuntimeError):
     pass
 
 
+class MpxSchemeError(MpxError, ValueError):
+    """A collocation scheme that cannot be transcribed (LG: p nodes where the composite builders need p + 1).  Also a ValueError: the
+    reference fails with one at the same point -- ``mpopt(ocp, S, p, "LG")`` constructs, ``create_nlp()`` raises ValueError from
+    get_composite_differentiation_matrix (mpopt.py:99 -> 4032-4038), for every grid and both D_MATRIX_METHODs."""
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if cand and os.path.exists(cand):

@@ -300,7 +300,8 @@ class ProblemProgram:
             for d in self.degrees:
                 parts.append(f"MPX_INSTANTIATE_GRADL({ph}, {d})")
                 if 12 < d <= 31:  # light passes of the high-degree buckets on the matrix cores (mpx_kernels.h: light_body)
-                    parts.append(f"MPX_INSTANTIATE_LIGHT({ph}, {d})")
+                    low = [q for q in self.degrees if q != d]  # (the one low degree as a compile-time constant, light_body)
+                    parts.append(f"MPX_INSTANTIATE_LIGHT_PF({ph}, {d}, {low[0] if len(low) == 1 and low[0] <= 12 else 0})")
                 if d <= 12 and len(self.degrees) == 1 and self.light_low_chunks(d) >= 2:  # ... and of single-degree grids of low degree (light_low_body)
                     parts.append(f"MPX_INSTANTIATE_LIGHT_LOW({ph}, {d})")
         if nph > 1 and len(self.degrees) == 1:  # all phases of a single-degree grid in ONE launch (mpx_kernels.h: node_all, light_low_all)

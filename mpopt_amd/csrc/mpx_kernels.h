@@ -829,12 +829,40 @@ typedef double mpx_d4 __attribute__((ext_vector_type(4)));
 // round of the persistent loop (each L2 streams a contiguous eighth of the round's rows instead of every eighth group of items), as
 // node_body's XCD-blocked walk does for the tiles.  Measured in process (tools/r4_light_ab.py): 1.5 % slower at config 2 (g: 208.5
 // against 205.1 us), 3 - 5 % slower at config 3 -- off.
+// The wavefront index through readfirstlane (round 5): the compiler then knows that the item of a wavefront -- group, evaluation point,
+// every base address derived from them -- is uniform: scalar registers and scalar loads (the group descriptor) instead of per-lane
+// 64-bit address pairs in VGPRs.  -DMPX_LIGHT_SCALAR_WAVE=0: the per-lane form of round 4 (A/B).
+#ifndef MPX_LIGHT_SCALAR_WAVE
+#define MPX_LIGHT_SCALAR_WAVE 1
+#endif
+#if MPX_LIGHT_SCALAR_WAVE
+#define MPX_LIGHT_UNIFORM_WAVE(w) __builtin_amdgcn_readfirstlane(w)
+#else
+#define MPX_LIGHT_UNIFORM_WAVE(w) (w)
+#endif
 __device__ __forceinline__ unsigned light_block_xcd() {
   if (MPX_LIGHT_XCD_BLOCKED && gridDim.x % 8 == 0) return (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
   return blockIdx.x;
 }
 
-template <int PH, int P, int MODE>
+// PF (round 5): the ONE low degree of the grid when there is exactly one (config 3: [3, 30, 3] -> 3), else 0.  With it the low-degree
+// nodes' contractions are straight-line code -- table rows and span values requested together, fma chains unrolled -- where the
+// run-time degree made every term a dependent LDS round trip inside a loop (4 terms x 3 chains x 2 turns: 16 of 151 us, r4_light_chains).
+#ifndef MPX_LIGHT_STATIC_LOW
+#define MPX_LIGHT_STATIC_LOW 1
+#endif
+// Measured with it, in process on config 3 at B = 512 (tools/r4_light_ab.py, profiles/r5_c3_light/ab.txt; nlp_g / nlp_f / f + grad_f,
+// us per whole pass; round-4 form 150.2 / 64.5 / 134.6): the static low degree 142.8 / 64.5 / 135.2 (kept); rows leaving the span buffer
+// 16 bytes per lane +-0.5 % (MPX_LIGHT_ROWS16, off); whole 128-node chunks loaded under a UNIFORM branch without per-lane bounds
+// 187 / 80 / 167 -- the branch splits the loads of a span over basic blocks and the compiler waits for each block's loads before the
+// next: the one property this kernel lives on is that ALL loads of an item are in flight together (MPX_LIGHT_FAST_LOAD, off).
+#ifndef MPX_LIGHT_ROWS16
+#define MPX_LIGHT_ROWS16 0  // 1: rows of g / grad_f leave the span buffer 16 bytes per lane (1 KB per wavefront store) instead of 8
+#endif
+#ifndef MPX_LIGHT_FAST_LOAD
+#define MPX_LIGHT_FAST_LOAD 0  // 1: whole 128-node chunks of a span are loaded without per-lane bounds (uniform branch) -- 25 % SLOWER
+#endif
+template <int PH, int P, int MODE, int PF = 0>
 __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
   using G = mpxgen::Phase<PH>;
   const MpxNodeArgs& A = L.node;
@@ -846,7 +874,7 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
   // rows of g a node writes: defect, path, DU, mU (the mid-point row before node i is row i - 1 of its block)
   constexpr int R_C = NX, R_DU = NX + NC, R_MU = R_DU + (G::DIFF_U ? NU : 0), NG = R_MU + (G::MIDU ? NU : 0);
   extern __shared__ double sBuf[];  // [wavefront][NIN][span_cap]: the span's inputs, then (in turns of NIN rows) its outputs; the low-degree tables
-  const int t = threadIdx.x, wave = t >> 6, l = t & 63, n = l & 15, q = l >> 4;
+  const int t = threadIdx.x, wave = MPX_LIGHT_UNIFORM_WAVE(t >> 6), l = t & 63, n = l & 15, q = l >> 4;
   const int N = A.N, cap = L.span_cap;
   double* __restrict__ sW = sBuf + (size_t)wave * NIN * cap;
   const double* __restrict__ sTab = sBuf + (size_t)MPX_LIGHT_WAVES * NIN * cap;
@@ -920,20 +948,29 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
       constexpr int CH2 = (MPX_LIGHT_CHUNKS + 1) / 2;  // 128-node chunks a span can have (the host caps the span at 64 * MPX_LIGHT_CHUNKS nodes)
       typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
       d2u v[NIN][CH2];
+      const int len_r_u = MPX_LIGHT_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(Gp.len_r) : Gp.len_r;
 #pragma unroll
       for (int u = 0; u < CH2; ++u) {
         const int idx = 128 * u + 2 * l;
+        if (MPX_LIGHT_FAST_LOAD && MPX_LIGHT_SCALAR_WAVE && 128 * (u + 1) <= len_r_u) {  // (uniform: a whole chunk)
 #pragma unroll
-        for (int a = 0; a < NIN; ++a) {
-          const double* __restrict__ src = zb + (int64_t)a * N + Gp.lo_r + idx;
-          if (idx + 1 < Gp.len_r) v[a][u] = *(const d2u*)src;
-          else v[a][u] = d2u{idx < Gp.len_r ? src[0] : 0.0, 0.0};
+          for (int a = 0; a < NIN; ++a) v[a][u] = *(const d2u*)(zb + (int64_t)a * N + Gp.lo_r + idx);
+        } else {
+#pragma unroll
+          for (int a = 0; a < NIN; ++a) {
+            const double* __restrict__ src = zb + (int64_t)a * N + Gp.lo_r + idx;
+            if (idx + 1 < Gp.len_r) v[a][u] = *(const d2u*)src;
+            else v[a][u] = d2u{idx < Gp.len_r ? src[0] : 0.0, 0.0};
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < CH2; ++u) {
         const int idx = 128 * u + 2 * l;
-        if (idx < Gp.len_r) {
+        if (MPX_LIGHT_FAST_LOAD && MPX_LIGHT_SCALAR_WAVE && 128 * (u + 1) <= len_r_u) {
+#pragma unroll
+          for (int a = 0; a < NIN; ++a) *(d2u*)&sW[a * cap + idx] = v[a][u];  // (cap is even, idx is even: 16-byte aligned in LDS)
+        } else if (idx < Gp.len_r) {
 #pragma unroll
           for (int a = 0; a < NIN; ++a) {
             sW[a * cap + idx] = v[a][u].x;
@@ -1004,10 +1041,12 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
       if (fi < Gp.f_count) {
 #endif
         const MpxLightForeign F = Fd[u];
+        constexpr bool SLOW = PF > 0 && MPX_LIGHT_STATIC_LOW;
 #if MPX_LIGHT_DESC_LDS
-        const int di = F.dk >> 8, k = F.dk & 255, pf = sFdeg[di], p1f = pf + 1;
-        const double* __restrict__ Dr = sTab + sFD[di] + k * p1f;
-        const double* __restrict__ Cr = sTab + sFC[di] + (k >= 1 ? k - 1 : 0) * p1f;
+        // (one low degree, compile time: its two tables are the whole of sTab -- D at 0, C_mid behind it, mpx_host.cpp: lplan.ftab)
+        const int di = F.dk >> 8, k = F.dk & 255, pf = SLOW ? PF : sFdeg[di], p1f = pf + 1;
+        const double* __restrict__ Dr = sTab + (SLOW ? 0 : sFD[di]) + k * p1f;
+        const double* __restrict__ Cr = sTab + (SLOW ? (PF + 1) * (PF + 1) : sFC[di]) + (k >= 1 ? k - 1 : 0) * p1f;
 #else
         const int di = F.dk >> 8, k = F.dk & 255, pf = L.fdeg[di], p1f = pf + 1;
         const double* __restrict__ Dr = sTab + L.fD_off[di] + k * p1f;
@@ -1035,6 +1074,47 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
         }
 #pragma unroll
         for (int r = 0; r < NRED; ++r) fred[r] += gr[r];
+        if constexpr (SLOW) {
+          if (want_g) {  // the same fma chains, same order; every operand requested before the first is used
+            constexpr int PF1 = PF + 1;
+            double dr[PF1], cr[PF1], xv[NIN][PF1];
+#pragma unroll
+            for (int j = 0; j < PF1; ++j) {
+              dr[j] = Dr[j];
+              if constexpr (G::MIDU) cr[j] = Cr[j];
+#pragma unroll
+              for (int a = 0; a < NIN; ++a)
+                if (a < NX || G::DIFF_U || G::MIDU) xv[a][j] = sW[a * cap + F.pos0 + j];
+            }
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+              double acc = 0;
+#pragma unroll
+              for (int j = 0; j < PF1; ++j) acc = fma(dr[j], xv[a][j], acc);
+              fval[u][a] = acc - fx[a];
+            }
+#pragma unroll
+            for (int jj = 0; jj < NC; ++jj) fval[u][R_C + jj] = cc[jj];
+            if constexpr (G::DIFF_U) {
+#pragma unroll
+              for (int c = 0; c < NU; ++c) {
+                double acc = 0;
+#pragma unroll
+                for (int j = 0; j < PF1; ++j) acc = fma(dr[j], xv[NX + c][j], acc);
+                fval[u][R_DU + c] = acc;
+              }
+            }
+            if constexpr (G::MIDU) {
+#pragma unroll
+              for (int c = 0; c < NU; ++c) {
+                double acc = 0;
+#pragma unroll
+                for (int j = 0; j < PF1; ++j) acc = fma(cr[j], xv[NX + c][j], acc);
+                fval[u][R_MU + c] = k >= 1 ? acc : 0.0;
+              }
+            }
+          }
+        } else
         if (want_g) {
 #pragma unroll
           for (int a = 0; a < NX; ++a) {
@@ -1139,7 +1219,15 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
           const int sh = shift(r0 + r);
           // owned positions [w0, w0 + len_w); a shifted row has no entry for node 0 of the phase
           const int p_lo = w0 - sh < 0 ? 0 : w0 - sh, p_hi = w0 + Gp.len_w - sh;
-          for (int idx = p_lo + l; idx < p_hi; idx += 64) dst[idx] = sW[r * cap + idx];
+          if constexpr (MPX_LIGHT_ROWS16) {  // pairs (even positions: 16-byte aligned in LDS; 8-byte aligned in memory), ragged ends singly
+            typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+            const int e_lo = (p_lo + 1) & ~1, e_hi = p_hi & ~1;
+            if (l == 0 && p_lo < e_lo && p_lo < p_hi) dst[p_lo] = sW[r * cap + p_lo];
+            if (l == 1 && e_hi < p_hi && e_hi >= e_lo) dst[e_hi] = sW[r * cap + e_hi];
+            for (int idx = e_lo + 2 * l; idx < e_hi; idx += 128) *(d2u*)(dst + idx) = *(const d2u*)&sW[r * cap + idx];
+          } else {
+            for (int idx = p_lo + l; idx < p_hi; idx += 64) dst[idx] = sW[r * cap + idx];
+          }
         }
     };
     if (want_g) {
@@ -1220,7 +1308,7 @@ __device__ __forceinline__ void light_low_run(const MpxLightArgs& L, const MpxLi
   static_assert(MPX_LIGHT_WAVES * NIN * CAP * 8 <= 56 * 1024, "light_low_body: span rows do not fit LDS");
   __shared__ double sBufL[MPX_LIGHT_WAVES][NIN][CAP];
   __shared__ double sD[P1 * P1], sC[P * P1], sTk[P1], sWt[P1];
-  const int t = threadIdx.x, wave = t >> 6, l = t & 63;
+  const int t = threadIdx.x, wave = MPX_LIGHT_UNIFORM_WAVE(t >> 6), l = t & 63;
   const int N = A.N;
   double(*sW)[CAP] = sBufL[wave];
   const MpxIO& io = A.io;
@@ -2216,12 +2304,14 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
     mpxk::hess_by_node_body<PH>(A);                                                                         \
   }
 
-#define MPX_INSTANTIATE_LIGHT(PH, P)                                                                                          \
+#define MPX_INSTANTIATE_LIGHT(PH, P) MPX_INSTANTIATE_LIGHT_PF(PH, P, 0)
+// (PF: the grid's one low degree, 0 if it has none or several -- light_body)
+#define MPX_INSTANTIATE_LIGHT_PF(PH, P, PF)                                                                                   \
   extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_light_fg_##PH##_##P(const MpxLightArgs A) {          \
-    mpxk::light_body<PH, P, MPX_MODE_FG>(A);                                                                                  \
+    mpxk::light_body<PH, P, MPX_MODE_FG, PF>(A);                                                                              \
   }                                                                                                                           \
   extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_light_fgq_##PH##_##P(const MpxLightArgs A) {         \
-    mpxk::light_body<PH, P, MPX_MODE_FGJ>(A);                                                                                 \
+    mpxk::light_body<PH, P, MPX_MODE_FGJ, PF>(A);                                                                             \
   }
 
 // (two workgroups per compute unit: three measured 8 - 13 % slower at config 2, one 45 % -- profiles/r4_lightlow/README.md)

@@ -103,7 +103,8 @@ class NlpFunctions:
         if len(self.poly_orders) != self.n_segments:
             raise ValueError("poly_orders must have one entry per segment")
         if scheme not in _lib.SCHEMES or scheme == "LG":
-            raise MpxError(f"scheme {scheme!r} is not usable for transcription (needs degree+1 nodes; LGR, LGL, CGL)")
+            raise _lib.MpxSchemeError(f"scheme {scheme!r} is not usable for transcription (needs degree+1 nodes; LGR, LGL, CGL) -- the reference "
+                                      "raises ValueError here as well: cannot reshape array of size p^2 into shape (p+1, p+1), mpopt.py:4032-4038")
         self.scheme = scheme
         if midu_rows is None:
             midu_rows = [bool(ocp.midu[ph]) and bool((np.asarray(ocp.lbu[ph]) > -np.inf).any()

@@ -164,3 +164,19 @@ def test_unknown_scheme_and_lg_quirks():
     assert len(mp.CollocationRoots("LG")._taus_fn(4)) == 4
     with pytest.raises(M.MpxError):
         M.NlpFunctions(mp.OCP(), 1, [3], "LG", with_device=False)
+
+
+@pytest.mark.parametrize("S,po", [(3, 3), (1, [4]), (2, [2, 5])])
+def test_lg_scheme_fails_where_and_how_the_reference_fails(S, po):
+    """SURVEY row a4, closed as "matches the reference's failure": with scheme "LG" the reference CONSTRUCTS the optimizer and raises
+    ValueError from create_nlp (compute_numerical_approximation -> get_composite_differentiation_matrix, mpopt.py:99 -> 4032-4038:
+    "cannot reshape array of size p^2 into shape (p+1, p+1)") -- for every grid and both D_MATRIX_METHODs, checked against the
+    imported reference in the build container.  Same here: the constructor succeeds, the node sets are served
+    (p nodes), create_nlp raises an error that IS a ValueError (and an MpxError)."""
+    import problems
+
+    mpo = mp.mpopt(problems.moon_lander(mp, M.math), S, po, "LG")
+    assert len(mp.CollocationRoots("LG")._taus_fn(5)) == 5
+    with pytest.raises(ValueError) as e:
+        mpo.create_nlp()
+    assert isinstance(e.value, M.MpxError) and "LG" in str(e.value)

@@ -13,7 +13,6 @@ mpo = mp.mpopt(builder(mp, M.math), S, P, scheme)
 o = mpo.create_nlp()[0]["oracle"]
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
-sz = o.sizes() if hasattr(o, "sizes") else None
 for B in [int(b) for b in os.environ.get("B", "4096,512,1").split(",")]:
     Z = torch.tensor(mpo.initialize_solution()[None, :] * (1 + 0.01 * rng.uniform(-1, 1, (B, o.n_z))), device=dev)
     p = torch.tensor(np.full(o.n_p, 1.0 / S), device=dev)
