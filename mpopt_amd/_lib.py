@@ -52,7 +52,8 @@ def hipcc():
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("mpx_host.cpp", "mpx_assembly.cpp", "mpx_colloc.cpp", "mpx_casadi.cpp", "mpx_device.h", "mpx_internal.h")] + [os.path.join(INCLUDE, "mpx.h")]
+    return [os.path.join(CSRC, f) for f in ("mpx_host.cpp", "mpx_shard.cpp", "mpx_equal_area.cpp", "mpx_assembly.cpp", "mpx_colloc.cpp", "mpx_casadi.cpp", "mpx_device.h",
+                                            "mpx_internal.h", "mpx_scan.h", "mpx_assembly_kernels.h")] + [os.path.join(INCLUDE, "mpx.h")]
 
 
 def _stale(target, deps):
@@ -104,6 +105,7 @@ def _build_library_in(tmp, verbose):
     hobj = os.path.join(tmp, "mpx_host.o")
     cobj = os.path.join(tmp, "mpx_casadi.o")
     aobj = os.path.join(tmp, "mpx_assembly.o")
+    sobj, eobj = os.path.join(tmp, "mpx_shard.o"), os.path.join(tmp, "mpx_equal_area.o")
     out = os.path.join(tmp, "libmpx.so")
     extra = os.environ.get("MPX_LIB_HIPCC_FLAGS", "").split()  # diagnostics builds (-DMPX_EA_STAMPS ...)
     cmds = [
@@ -113,7 +115,11 @@ def _build_library_in(tmp, verbose):
          os.path.join(CSRC, "mpx_host.cpp"), "-o", hobj] + extra,
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
          os.path.join(CSRC, "mpx_assembly.cpp"), "-o", aobj] + extra,
-        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, aobj, obj, cobj, "-o", out],
+        [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
+         os.path.join(CSRC, "mpx_shard.cpp"), "-o", sobj] + extra,
+        [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
+         os.path.join(CSRC, "mpx_equal_area.cpp"), "-o", eobj] + extra,
+        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, aobj, sobj, eobj, obj, cobj, "-o", out],
     ]
     for cmd in cmds:
         r = subprocess.run(cmd, capture_output=True, text=True)

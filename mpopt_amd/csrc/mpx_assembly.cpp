@@ -48,6 +48,7 @@ struct DevFused {
   uint32_t* m_pack = nullptr;  // ELL table of the multi-term rows packed the same way, same dictionary
   uint32_t* c_pack = nullptr;  // ... and compact, row after row (MpxFusedArgs::c_pack / c_ptr): what a workgroup keeps in LDS
   int32_t* c_ptr = nullptr;
+  int32_t* m_wmax = nullptr;   // longest row of every block of 64 multi-term rows (ordered by term count)
   int32_t c_total = 0;
   unsigned lds_dyn = 0;        // dynamic LDS bytes of the launch when the compact table rides in LDS (0: the ELL table from memory)
   uint32_t* r_pack = nullptr;  // single-term rows packed (MpxFusedArgs::r_pack); n_dict = 0: not representable (an index or the dictionary past 16 bits)
@@ -241,6 +242,11 @@ int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, in
     if (nt > mt) longr.push_back((int32_t)r);  // (mt = the pass's long-row threshold, DevGather::long_threshold)
     else if (nt >= 2) multi.push_back((int32_t)r);
   }
+  // (longest first, ties in row order: the 64 rows a wavefront takes together are then about equally long -- MpxFusedArgs::m_wmax;
+  // which lane sums a row changes, the row's terms, their order and its fma chain do not)
+  std::stable_sort(multi.begin(), multi.end(), [&](int32_t x, int32_t y) { return r_nt[(size_t)x] > r_nt[(size_t)y]; });
+  std::vector<int32_t> wmax((multi.size() + 63) / 64, 0);
+  for (size_t m = 0; m < multi.size(); ++m) wmax[m / 64] = std::max(wmax[m / 64], r_nt[(size_t)multi[m]]);
   f.n_multi = (int32_t)multi.size(), f.n_mid = (int32_t)mid.size(), f.n_long = (int32_t)longr.size();
   // ELL copy of the multi-term rows: [t][row], padded with (the 1.0 slot, 0) -- padding terms are never added (t < nt)
   std::vector<int32_t> m_idx((size_t)std::max<int64_t>((int64_t)mt * f.n_multi, 1), (int32_t)(raw_n + n_z));
@@ -280,7 +286,7 @@ int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, in
   }
   f.c_total = (int32_t)c_pack.size();
   int rc;
-  if ((rc = upload(c, &f.c_pack, c_pack)) || (rc = upload(c, &f.c_ptr, c_ptr))) return rc;
+  if ((rc = upload(c, &f.c_pack, c_pack)) || (rc = upload(c, &f.c_ptr, c_ptr)) || (rc = upload(c, &f.m_wmax, wmax))) return rc;
   if ((rc = upload(c, &f.r_pack, r_pack)) || (rc = upload(c, &f.r_dict, r_dict)) || (rc = upload(c, &f.m_pack, m_pack))) return rc;
   if ((rc = upload(c, &f.r_idx, r_idx)) || (rc = upload(c, &f.r_nt, r_nt)) || (rc = upload(c, &f.r_coef, r_coef)) || (rc = upload(c, &f.idx, idx)) ||
       (rc = upload(c, &f.multi, multi)) || (rc = upload(c, &f.mid, mid)) || (rc = upload(c, &f.longr, longr)) || (rc = upload(c, &f.m_idx, m_idx)) ||
@@ -311,7 +317,7 @@ void mpx_asm_release(mpx_ctx* c) {
   };
   for (auto& s : a->sets) fr(s.loc_toff), fr(s.loc_idx), fr(s.mu_toff), fr(s.mu_idx), fr(s.loc_coef), fr(s.cst), fr(s.mu_coef);
   for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef), fr(g->long_rows);
-  for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef), fr(f->r_pack), fr(f->r_dict), fr(f->m_pack), fr(f->c_pack), fr(f->c_ptr);
+  for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef), fr(f->r_pack), fr(f->r_dict), fr(f->m_pack), fr(f->c_pack), fr(f->c_ptr), fr(f->m_wmax);
   fr(a->d_ch_ptr), fr(a->d_ch_idx), fr(a->d_ch_slot), fr(a->d_ch_coef);
   for (auto q : a->d_chain_pos) fr(q);
   for (auto q : a->d_loc_pack) fr(q);
@@ -673,6 +679,7 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
   A.multi_rows = f.multi, A.m_idx = f.m_idx, A.m_coef = f.m_coef, A.mid_rows = f.mid, A.long_rows = f.longr;
   A.n_multi = f.n_multi, A.n_mid = f.n_mid, A.n_long = f.n_long;
   A.c_pack = f.c_pack, A.c_ptr = f.c_ptr, A.c_total = f.c_total, A.multi_lds = f.lds_dyn ? 1 : 0;
+  A.m_wmax = f.m_wmax;
   A.task_ptr = a->d_task_ptr[mode == MPX_MODE_HESS ? 1 : 0], A.task_list = a->d_task_list[mode == MPX_MODE_HESS ? 1 : 0];
   A.ch_ptr = a->d_ch_ptr, A.ch_idx = a->d_ch_idx, A.ch_coef = a->d_ch_coef, A.ch_slot = a->d_ch_slot, A.n_chains = a->n_chains;
   for (int k = 0; k < 4; ++k) A.out[k] = out[k], A.out_stride[k] = stride[k];

@@ -77,6 +77,9 @@
 #ifndef MPX_FUSE_NT
 #define MPX_FUSE_NT 512  // lanes per workgroup
 #endif
+#ifndef MPX_FUSE_WMAX
+#define MPX_FUSE_WMAX 1  // multi-term rows: loop bound = the longest row of the wavefront's block (0: the pass-wide ELL width, round 4)
+#endif
 
 namespace mpxk {
 
@@ -775,28 +778,46 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       } else {
         row = A.multi_rows[m], nt = A.r_nt[row];
       }
-      int ix[MT > 0 ? MT : 1];
-      double cf[MT > 0 ? MT : 1];
-      if constexpr (NDICT > 0) {
+      // The multi-term rows are ordered by term count (host: upload_fused), so the 64 rows of a wavefront's round are about equally
+      // long: the table loads and the fma slots run to the LONGEST row of the block (MpxFusedArgs::m_wmax, a scalar load) instead of the
+      // pass-wide ELL width -- 35 % of the term slots of the moon-lander hess_l pass were padding (5908 terms in 824 rows of width 11),
+      // and this pass is bound by instruction issue (profiles/r5_adaptive_hess).  One straight-line variant per bound (the loads of a
+      // round stay in ONE basic block, all in flight together); every row keeps its terms, their order and its fma chain.
+      auto rows_body = [&](auto WMc) {
+        constexpr int WM = decltype(WMc)::value;
+        int ix[WM > 0 ? WM : 1];
+        double cf[WM > 0 ? WM : 1];
+        if constexpr (NDICT > 0) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const uint32_t e = A.m_pack[(int64_t)t * A.n_multi + m];
-          ix[t] = (int)(e & 0xffffu), cf[t] = sDict[e >> 16];
+          for (int t = 0; t < WM; ++t) {
+            const uint32_t e = A.m_pack[(int64_t)t * A.n_multi + m];
+            ix[t] = (int)(e & 0xffffu), cf[t] = sDict[e >> 16];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < WM; ++t) ix[t] = A.m_idx[(int64_t)t * A.n_multi + m], cf[t] = A.m_coef[(int64_t)t * A.n_multi + m];
         }
-      } else {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) ix[t] = A.m_idx[(int64_t)t * A.n_multi + m], cf[t] = A.m_coef[(int64_t)t * A.n_multi + m];
-      }
+        for (int u = 0; u < U; ++u) {
+          if (u >= nu) break;
+          double s = 0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (u >= nu) break;
-        double s = 0;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-          if (t < nt) s = fma(cf[t], V[u][ix[t]], s);
-        double* o = out_of(row, b0 + u);
-        if (o) *o = s;
-      }
+          for (int t = 0; t < WM; ++t)
+            if (t < nt) s = fma(cf[t], V[u][ix[t]], s);
+          double* o = out_of(row, b0 + u);
+          if (o) *o = s;
+        }
+      };
+#if MPX_FUSE_WMAX
+      const int wm = A.m_wmax ? A.m_wmax[r_ * NW + wave] : MT;  // (wave is uniform: a scalar load)
+      bool done_ = false;
+      static_for<2, MT>([&](auto K) {
+        if (!done_ && wm <= decltype(K)::value) rows_body(K), done_ = true;
+      });
+      if (!done_) rows_body(std::integral_constant<int, MT>{});
+#else
+      rows_body(std::integral_constant<int, MT>{});
+#endif
     }
     MPX_FUSE_STAMP(5);
     MPX_FUSE_STAMP(6);

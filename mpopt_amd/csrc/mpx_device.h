@@ -433,6 +433,8 @@ struct MpxFusedArgs {
   const uint32_t* c_pack;
   const int32_t* c_ptr;    // [n_multi + 1]
   int32_t c_total, pad4_;
+  // multi-term rows are ordered by term count, longest first; m_wmax[k] = term count of the longest of rows 64 k .. 64 k + 63
+  const int32_t* m_wmax;
   const double* l_dict;    // dictionaries of MpxPtSet::loc_pack / mu_pack (all sets of the context)
   const double* m_dict;
   int32_t n_ldict, n_mdict;

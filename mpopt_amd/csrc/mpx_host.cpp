@@ -9,6 +9,7 @@
 //   node ownership                  mpopt.py:189-195, 208   (shared node belongs to the earlier
 //                                                            segment; later segments drop w_0)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -26,6 +27,7 @@
 #include "mpx_device.h"
 
 #include "mpx_internal.h"
+#include "mpx_scan.h"
 
 using namespace mpxi;
 
@@ -814,99 +816,13 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   return MPX_OK;
 }
 
-// exclusive prefix sums of the segment widths (the reference's running t_seg0, mpopt.py:192): one workgroup per
-// (width vector, phase).  Each of the sixteen wavefronts owns a contiguous share and walks it 64 elements at a time with
-// coalesced loads: first the quarter totals (so that every wavefront knows its starting offset), then the scan proper --
-// shuffle scan inside the 64 elements, running carry across them.  Fixed order: results do not depend on anything else.
-// (the scan itself is a device function: mpx_equal_area_kernel runs it on the widths it has just produced, with the same
-// additions in the same order, so that the prefix sums it leaves behind are the ones this kernel would compute)
-// Wavefront scans on the DPP path (row shifts inside the 16-lane rows, then the row broadcasts 15 / 31): six v_mov_dpp pairs + six
-// additions, no LDS crossbar (__shfl_up costs two ds_bpermute per level and their latency six times in a row: the scans of the
-// equal-area kernel spent most of their time there, profiles/r3_config5_loop).  Lanes without a source add +0.0.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_or_zero(double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_scan_inclusive(double x) {
-  x += dpp_or_zero<0x111, 0xf>(x);  // row_shr:1
-  x += dpp_or_zero<0x112, 0xf>(x);  // row_shr:2
-  x += dpp_or_zero<0x114, 0xf>(x);  // row_shr:4
-  x += dpp_or_zero<0x118, 0xf>(x);  // row_shr:8
-  x += dpp_or_zero<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
-  x += dpp_or_zero<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
-  return x;
-}
-__device__ __forceinline__ int wave_max_scan_inclusive(int x) {  // x >= 0; lanes without a source contribute 0
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
-  return x;
-}
-__device__ __forceinline__ double wave_shift_up_1(double x) { return dpp_or_zero<0x138, 0xf>(x); }  // wave_shr:1 (lane 0: +0.0)
-__device__ __forceinline__ double wave_last(double x) {  // lane 63's value, in every lane
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
-}
-#define MPX_PREFIX_THREADS 1024
-template <class Load>  // a(s): the s-th width (global memory in mpx_prefix_kernel, LDS in mpx_equal_area_kernel)
-__device__ __forceinline__ void prefix_scan_block(Load a, double* __restrict__ o, int S, int tid, double* wave_tot) {
-  constexpr int NWV = MPX_PREFIX_THREADS / 64;
-  const bool active = true;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int quarter = ((S + NWV - 1) / NWV + 63) / 64 * 64;  // a wavefront's share: a multiple of 64, every step is one aligned run
-  const int q0 = wave * quarter, q1 = active ? min(S, q0 + quarter) : 0;
-  double tot = 0;
-  for (int s0 = q0 + lane; s0 < q1; s0 += 64 * 8) {  // eight loads in flight, added in index order
-    double v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = s0 + k * 64 < q1 ? a(s0 + k * 64) : 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (s0 + k * 64 < q1) tot += v[k];
-  }
-  tot = wave_last(wave_scan_inclusive(tot));
-  if (active && lane == 0) wave_tot[wave] = tot;
-  __syncthreads();
-  double carry = 0;
-  if (active)
-    for (int q = 0; q < wave; ++q) carry += wave_tot[q];
-  // eight 64-element steps at a time: their loads are in flight together, the scan itself (same additions, same order as one
-  // step at a time) runs on registers
-  for (int s0 = q0; s0 < q1; s0 += 64 * 8) {
-    double v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int s = s0 + k * 64 + lane;
-      v[k] = s < q1 ? a(s) : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int s = s0 + k * 64 + lane;
-      const double inc = wave_scan_inclusive(v[k]);
-      if (s < q1) o[s] = carry + wave_shift_up_1(inc);
-      carry += wave_last(inc);
-    }
-  }
-}
-
+// (wavefront / workgroup scans of the widths: mpx_scan.h, shared with mpx_equal_area.cpp)
 __global__ __launch_bounds__(MPX_PREFIX_THREADS) void mpx_prefix_kernel(const double* __restrict__ w, double* __restrict__ wcum, int S) {
   __shared__ double wave_tot[MPX_PREFIX_THREADS / 64];
   const double* __restrict__ a = w + (int64_t)blockIdx.x * S;
   prefix_scan_block([&](int s) { return a[s]; }, wcum + (int64_t)blockIdx.x * S, S, threadIdx.x, wave_tot);
 }
 
-// (a re-allocation loses the prefix sums the buffer held)
-inline int reserve_wcum(mpx_ctx* c, size_t n) {
-  const double* before = c->wcum.p;
-  const int rc = reserve(c, c->wcum, n);
-  if (c->wcum.p != before) c->wcum_phases = 0;
-  return rc;
-}
-inline uint32_t all_phases(const mpx_ctx* c) { return c->n_phases >= 32 ? ~0u : ((1u << c->n_phases) - 1u); }
 // exclusive prefix sums of n_w width vectors at device address p into c->wcum (all phases), with the bookkeeping MPX_WIDTHS_UNCHANGED relies on
 int launch_prefix(mpx_ctx* c, const double* p, int64_t n_w, int p_per_point) {
   hipLaunchKernelGGL(mpx_prefix_kernel, dim3((unsigned)(n_w * c->n_phases)), dim3(MPX_PREFIX_THREADS), 0, c->stream, p, c->wcum.p, c->S);
@@ -915,8 +831,13 @@ int launch_prefix(mpx_ctx* c, const double* p, int64_t n_w, int p_per_point) {
   return MPX_OK;
 }
 
-int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size_t size, unsigned lds_bytes = 0) {
+int launch(mpx_ctx* c, hipFunction_t fn, dim3 grid, dim3 block, void* args, size_t size, unsigned lds_bytes = 0, bool any_order = false) {
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  if (any_order) {  // (experiment, MPX_BOUNDARY_ANYORDER: no barrier against the previous kernel of the stream; sizes in work-items)
+    HIPCHK(c, hipExtModuleLaunchKernel(fn, grid.x * block.x, grid.y * block.y, grid.z * block.z, block.x, block.y, block.z, lds_bytes, c->stream, nullptr, cfg, nullptr, nullptr,
+                                       1u /* hipExtAnyOrderLaunch */));
+    return MPX_OK;
+  }
   HIPCHK(c, hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, lds_bytes, c->stream, nullptr, cfg));
   return MPX_OK;
 }
@@ -1339,7 +1260,10 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       if (c->lplan.low) G.ph[p].tile_first = p * c->lplan.n_low_chunks, G.ph[p].tile_count = light_small ? c->lplan.n_low_chunks : c->lplan.n_low_groups;
       else G.ph[p].tile_count = (int32_t)c->lplan.groups.size();
     }
-  return launch(c, c->fn_bound[mode], dim3((unsigned)io.B, 1, 1), dim3(256, 1, 1), &G, sizeof G);
+  // (MPX_BOUNDARY_ANYORDER=1, read per call, MPX_BOUNDARY_ONLY calls only: an experiment of round 5 -- the boundary pass of the config-5
+  // loop launched without a barrier against the equal-area kernel in front of it, profiles/r5_loop/)
+  const bool any_order = !nodes && getenv("MPX_BOUNDARY_ANYORDER") != nullptr;
+  return launch(c, c->fn_bound[mode], dim3((unsigned)io.B, 1, 1), dim3(256, 1, 1), &G, sizeof G, 0, any_order);
 }
 
 }  // namespace
@@ -1841,644 +1765,6 @@ extern "C" int mpx_resid_eval(mpx_ctx* c, mpx_resid_plan* P, int64_t batch, cons
 }
 
 
-// ---- segment sharding -------------------------------------------------------------------------------
-// Ranks evaluate disjoint contiguous tile ranges; what a rank owns afterwards is a handful of contiguous runs: the value
-// blocks of its tiles (jac_val or hess_val), its run of the packed g / grad_f staging block and its per-tile partial sums.
-// mpx_shard_pack copies the runs into one exchange buffer, the caller all-gathers the buffers (RCCL over xGMI),
-// mpx_shard_unpack scatters the other ranks' runs into place, and the MPX_BOUNDARY_ONLY pass finishes the evaluation.
-namespace {
-
-// (partials_only: the owner-resident exchange -- a rank's buffer holds nothing but its tile partials, at offset 0)
-__global__ __launch_bounds__(256) void mpx_shard_copy_kernel(const MpxShardEnt* __restrict__ ents, int64_t B, int64_t rank_len, int my_rank,
-                                                             int unpack, int partials_only, double* vals, double* gtmp, double* partial, double* buf) {
-  const MpxShardEnt E = ents[blockIdx.y];
-  if (unpack ? E.rank == my_rank : E.rank != my_rank) return;
-  if (partials_only && E.kind != 2) return;
-  double* __restrict__ base = E.kind == 0 ? vals : (E.kind == 1 ? gtmp : partial);
-  if (!base) return;
-  double* __restrict__ pk = buf + (unpack ? (int64_t)E.rank * rank_len * B : 0) + (partials_only ? E.part_off : E.dst_off) * B;
-  const int64_t n = B * E.len;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = e / E.len, i = e - b * E.len;
-    double* __restrict__ at = base + E.src_off + b * E.stride + i;
-    if (unpack)
-      *at = pk[e];
-    else
-      pk[e] = *at;
-  }
-}
-
-// greedy prefix split of the tiles by weight (Jacobian block size): contiguous ranges, possibly empty
-std::vector<int64_t> shard_cuts(const std::vector<int64_t>& w, int world) {
-  const int64_t n = (int64_t)w.size();
-  std::vector<double> cum(n + 1, 0.0);
-  for (int64_t t = 0; t < n; ++t) cum[t + 1] = cum[t] + (double)std::max<int64_t>(w[t], 1);
-  std::vector<int64_t> cuts(1, 0);
-  for (int r = 1; r < world; ++r) {
-    const double target = cum[n] * r / world;
-    int64_t k = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
-    if (k > 0 && std::abs(cum[k - 1] - target) <= std::abs(cum[std::min(k, n)] - target)) --k;
-    cuts.push_back(std::max(cuts.back(), std::min(k, n)));
-  }
-  cuts.push_back(n);
-  return cuts;
-}
-
-// value runs of the node-ordered hess_l tiles rank r owns (merged where adjacent)
-void hess_node_runs(const mpx_ctx* c, int r, std::vector<std::pair<int64_t, int64_t>>& runs) {
-  runs.clear();
-  for (int p = 0; p < c->n_phases; ++p) {
-    const int64_t cnt = c->ph_htile_count[p], a0 = c->shard_cuts_h[r] * cnt / c->shard_cuts_h.back(), a1 = c->shard_cuts_h[r + 1] * cnt / c->shard_cuts_h.back();
-    for (int64_t h = c->ph_htile_first[p] + a0; h < c->ph_htile_first[p] + a1; ++h)
-      runs.push_back({c->htiles[(size_t)h].hess_base, (int64_t)c->ph[p].hn.size() * c->htiles[(size_t)h].n});
-  }
-  std::sort(runs.begin(), runs.end());
-  size_t o = 0;
-  for (size_t k = 0; k < runs.size(); ++k) {
-    if (runs[k].second <= 0) continue;
-    if (o > 0 && runs[o - 1].first + runs[o - 1].second == runs[k].first)
-      runs[o - 1].second += runs[k].second;
-    else
-      runs[o++] = runs[k];
-  }
-  runs.resize(o);
-}
-
-void shard_runs(const std::vector<MpxTile>& tiles, const std::vector<int64_t>& size, bool hess, int64_t tb, int64_t te,
-                std::vector<std::pair<int64_t, int64_t>>& runs) {
-  runs.clear();
-  for (int64_t t = tb; t < te; ++t)
-    if (size[t] > 0) runs.push_back({hess ? tiles[t].hess_base : tiles[t].jac_base, size[t]});
-  std::sort(runs.begin(), runs.end());
-  size_t o = 0;
-  for (size_t k = 0; k < runs.size(); ++k) {
-    if (o > 0 && runs[o - 1].first + runs[o - 1].second == runs[k].first)
-      runs[o - 1].second += runs[k].second;
-    else
-      runs[o++] = runs[k];
-  }
-  runs.resize(o);
-}
-
-}  // namespace
-
-extern "C" int mpx_shard_setup(mpx_ctx* c, int world, int rank) {
-  if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, MPX_ERR_INVALID, "mpx_shard_setup: bad world / rank");
-  if (c->kind != 0) return fail(c, MPX_ERR_UNSUPPORTED, "assembled contexts have no tiles to shard");
-  const int64_t nt = (int64_t)c->tiles.size();
-  c->shard_world = world;
-  c->shard_rank = rank;
-  for (int ps = 0; ps < 2; ++ps) {
-    c->shard_ent[ps].clear();
-    c->shard_ent_first[ps].assign(1, 0);
-    c->shard_len[ps] = 0;
-    if (c->d_shard_ent[ps]) (void)hipFree(c->d_shard_ent[ps]);
-    c->d_shard_ent[ps] = nullptr;
-  }
-  if (world == 1) {
-    c->shard_cuts = {0, nt};
-    c->tile_begin = 0, c->tile_end = nt, c->run_boundary = 1;
-    return MPX_OK;
-  }
-  c->shard_cuts = shard_cuts(c->tile_jac_size, world);
-  if (c->hess_by_node) {  // hess_l pass: ranks split the node-ordered tiles of every phase in the same proportions
-    const int64_t cnt = c->ph_htile_count.empty() ? 0 : c->ph_htile_count[0];
-    c->shard_cuts_h.assign(1, 0);
-    for (int r = 1; r <= world; ++r) c->shard_cuts_h.push_back(cnt * r / world);
-  }
-  c->tile_begin = c->shard_cuts[rank];
-  c->tile_end = c->shard_cuts[rank + 1];
-  c->run_boundary = 0;
-  std::vector<std::pair<int64_t, int64_t>> runs;
-  c->shard_len_part = 0;  // owner-resident exchange: the tile partials only (max over ranks and passes)
-  for (int ps = 0; ps < 2; ++ps) {
-    for (int r = 0; r < world; ++r) {
-      const int64_t tb = c->shard_cuts[r], te = c->shard_cuts[r + 1];
-      int64_t pos = 0, ppos = 0;
-      auto add = [&](int kind, int64_t off, int64_t len, int64_t stride) {
-        if (len <= 0) return;
-        c->shard_ent[ps].push_back(MpxShardEnt{off, len, stride, pos, kind, r, kind == 2 ? ppos : 0});
-        pos += len;
-        if (kind == 2) ppos += len, c->shard_len_part = std::max(c->shard_len_part, ppos);
-      };
-      if (ps == 1 && c->hess_by_node) {
-        hess_node_runs(c, r, runs);
-        for (auto& q : runs) add(0, q.first, q.second, c->nnz_h);
-        for (int p = 0; p < c->n_phases; ++p) {  // the partial sums of its tiles: one run of tile slots per phase
-          const int64_t cnt = c->ph_htile_count[p], a0 = c->shard_cuts_h[r] * cnt / c->shard_cuts_h.back(), a1 = c->shard_cuts_h[r + 1] * cnt / c->shard_cuts_h.back();
-          add(2, (c->ph[p].tile_first + a0) * c->nred, (a1 - a0) * c->nred, nt * c->nred);
-        }
-        c->shard_len[ps] = std::max(c->shard_len[ps], pos);
-        c->shard_ent_first[ps].push_back((int32_t)c->shard_ent[ps].size());
-        continue;
-      }
-      shard_runs(c->tiles, ps ? c->tile_hess_size : c->tile_jac_size, ps == 1, tb, te, runs);
-      for (auto& q : runs) add(0, q.first, q.second, ps ? c->nnz_h : c->nnz_j);
-      if (ps == 0 && te > tb) add(1, c->tiles[tb].g_base, c->tiles[te - 1].g_base + c->tile_g_size[te - 1] - c->tiles[tb].g_base, c->gtmp_n);
-      add(2, tb * c->nred, (te - tb) * c->nred, nt * c->nred);
-      c->shard_len[ps] = std::max(c->shard_len[ps], pos);
-      c->shard_ent_first[ps].push_back((int32_t)c->shard_ent[ps].size());
-    }
-    c->shard_len[ps] += c->shard_len[ps] & 1;  // keep every rank's slot 16-byte aligned
-    c->shard_len_part += c->shard_len_part & 1;
-
-    if (c->has_device) {
-      HIPCHK(c, hipSetDevice(c->device));
-      int rc = upload(c, &c->d_shard_ent[ps], c->shard_ent[ps]);
-      if (rc) return rc;
-    }
-  }
-  return MPX_OK;
-}
-
-extern "C" int mpx_shard_info(const mpx_ctx* c, int mask, int64_t* rank_len, int64_t* n_entries, int64_t* tile_cuts) {
-  if (!c || c->shard_cuts.empty()) return MPX_ERR_INVALID;
-  const int ps = (mask & MPX_HESS) ? 1 : 0;
-  if (rank_len) *rank_len = (mask & MPX_OWNER_RESIDENT) ? c->shard_len_part : c->shard_len[ps];
-  if (n_entries) *n_entries = (int64_t)c->shard_ent[ps].size();
-  if (tile_cuts) memcpy(tile_cuts, c->shard_cuts.data(), c->shard_cuts.size() * sizeof(int64_t));
-  return MPX_OK;
-}
-
-extern "C" int mpx_shard_table(const mpx_ctx* c, int mask, int64_t* out) {
-  if (!c || !out || c->shard_cuts.empty()) return MPX_ERR_INVALID;
-  const int ps = (mask & MPX_HESS) ? 1 : 0;
-  for (auto& e : c->shard_ent[ps]) {
-    // (with MPX_OWNER_RESIDENT in the mask the last column of a partial-sum run is its offset in the partials-only exchange buffer)
-    *out++ = e.rank, *out++ = e.kind, *out++ = e.src_off, *out++ = e.len, *out++ = e.stride, *out++ = ((mask & MPX_OWNER_RESIDENT) && e.kind == 2) ? e.part_off : e.dst_off;
-  }
-  return MPX_OK;
-}
-
-// Runs of `which` (MPX_G / MPX_GRAD / MPX_JAC / MPX_HESS) owned by `rank` in the owner-resident protocol.
-extern "C" int mpx_shard_owned(const mpx_ctx* c, int which, int rank, int64_t* n_runs, int64_t* runs) {
-  if (!c || !n_runs || c->shard_cuts.empty() || rank < 0 || rank + 1 >= (int)c->shard_cuts.size()) return MPX_ERR_INVALID;
-  if (c->kind != 0) return MPX_ERR_UNSUPPORTED;
-  const int64_t tb = c->shard_cuts[rank], te = c->shard_cuts[rank + 1];
-  std::vector<std::pair<int64_t, int64_t>> out;
-  if (which == MPX_HESS && c->hess_by_node) {
-    hess_node_runs(c, rank, out);
-  } else if (which == MPX_JAC || which == MPX_HESS) {
-    shard_runs(c->tiles, which == MPX_HESS ? c->tile_hess_size : c->tile_jac_size, which == MPX_HESS, tb, te, out);
-  } else if (which == MPX_G || which == MPX_GRAD) {
-    // the packed staging map of build_layout knows which tile holds every node row: rows whose staged position falls into the
-    // staging run of the rank's tiles belong to the rank
-    std::vector<int64_t> rows;
-    if (te > tb) {
-      const int64_t lo = c->tiles[tb].g_base, hi = c->tiles[te - 1].g_base + c->tile_g_size[te - 1];
-      const std::vector<int64_t>& map = which == MPX_G ? c->gmap : c->qmap;
-      for (int64_t r = 0; r < (int64_t)map.size(); ++r)
-        if (map[r] >= lo && map[r] < hi) rows.push_back(r);
-    }
-    for (int64_t r : rows) {
-      if (!out.empty() && out.back().first + out.back().second == r)
-        ++out.back().second;
-      else
-        out.push_back({r, 1});
-    }
-  } else {
-    return MPX_ERR_INVALID;
-  }
-  *n_runs = (int64_t)out.size();
-  if (runs)
-    for (auto& q : out) *runs++ = q.first, *runs++ = q.second;
-  return MPX_OK;
-}
-
-extern "C" int mpx_device_pci_bus_id(int device, char* out, int len) {
-  if (!out || len < 16) return MPX_ERR_INVALID;
-  out[0] = 0;
-  return hipDeviceGetPCIBusId(out, len, device) == hipSuccess ? MPX_OK : MPX_ERR_HIP;
-}
-
-static int shard_copy(mpx_ctx* c, int mask, int64_t batch, double* vals, double* buf, int unpack) {
-  if (!c || !buf || batch < 1) return MPX_ERR_INVALID;
-  if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "mpx_shard_pack/unpack: context has no device code; there is no CPU fallback");
-  if (c->shard_world <= 1) return fail(c, MPX_ERR_INVALID, "mpx_shard_pack/unpack without mpx_shard_setup(world > 1)");
-  const int ps = (mask & MPX_HESS) ? 1 : 0;
-  const int part_only = (mask & MPX_OWNER_RESIDENT) ? 1 : 0;
-  HIPCHK(c, hipSetDevice(c->device));
-  int rc;
-  if ((rc = reserve(c, c->partial, (size_t)(batch * partial_slots(c) * c->nred)))) return rc;
-  double* gt = nullptr;
-  if (!part_only && ps == 0 && (mask & (MPX_G | MPX_GRAD))) {
-    if ((rc = reserve(c, c->gtmp, (size_t)(batch * c->gtmp_n)))) return rc;
-    gt = c->gtmp.p;
-  }
-  const int32_t first = unpack ? 0 : c->shard_ent_first[ps][c->shard_rank];
-  const int32_t count = unpack ? (int32_t)c->shard_ent[ps].size() : c->shard_ent_first[ps][c->shard_rank + 1] - first;
-  if (count <= 0) return MPX_OK;
-  int64_t longest = 1;
-  for (int32_t k = first; k < first + count; ++k)
-    if (!part_only || c->shard_ent[ps][k].kind == 2) longest = std::max(longest, c->shard_ent[ps][k].len * batch);
-  const unsigned gx = (unsigned)std::min<int64_t>((longest + 255) / 256, 2048);
-  hipLaunchKernelGGL(mpx_shard_copy_kernel, dim3(gx, (unsigned)count), dim3(256), 0, c->stream, c->d_shard_ent[ps] + first, batch,
-                     part_only ? c->shard_len_part : c->shard_len[ps], c->shard_rank, unpack, part_only,
-                     ((mask & (MPX_JAC | MPX_HESS)) && !part_only ? vals : nullptr), gt, c->partial.p, buf);
-  HIPCHK(c, hipGetLastError());
-  return MPX_OK;
-}
-
-extern "C" int mpx_shard_pack(mpx_ctx* c, int mask, int64_t batch, const double* vals, double* send) {
-  return shard_copy(c, mask, batch, const_cast<double*>(vals), send, 0);
-}
-
-extern "C" int mpx_shard_unpack(mpx_ctx* c, int mask, int64_t batch, const double* recv, double* vals) {
-  return shard_copy(c, mask, batch, vals, const_cast<double*>(recv), 1);
-}
-
-
-// ---- h-adaptive width update on the device ---------------------------------------------------
-// Equal-area rule of the reference (mpopt_h_adaptive.get_roots_wrt_equal_area, mpopt.py:2636-2659, fed with the per-point
-// 2-norms of the dynamics residuals, mpopt.py:2620-2633) and its damped update (mpopt.py:2587-2590), batched: one workgroup
-// per evaluation point, fixed-order block scan of the trapezoid areas, one binary search per new segment boundary.
-namespace {
-// (1024 lanes per workgroup: the cumulative areas of one evaluation point fill most of a compute unit's LDS, so a workgroup is
-// alone on its CU and its own 16 wavefronts are all there is to hide load and LDS latency: 4 wavefronts measured 2.3x slower)
-#define MPX_EA_THREADS 1024
-#define MPX_EA_PF 12  // residual samples a lane can prefetch for the next evaluation point (n <= 12 * 1024)
-#define MPX_EA_WR 4   // new segment boundaries per lane in the fast kernel (S <= 4 * 1024)
-#ifndef MPX_EA_SLICES
-#define MPX_EA_SLICES 4  // 1 ... 4: slices the prefetch of the next point is requested in (fast kernel, scalar residuals)
-#endif
-#ifndef MPX_EA_COND_PREFETCH
-#define MPX_EA_COND_PREFETCH 0  // 1: the guarded prefetch of round 3 (A/B: MPX_LIB_HIPCC_FLAGS=-DMPX_EA_COND_PREFETCH=1)
-#endif
-// Generic kernel: vector residuals, sample lists of any length (cumulative areas in LDS when they fit, else in HBM scratch), any
-// number of phases.  One workgroup per evaluation point.
-__global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_kernel(const double* __restrict__ resid, int64_t n, int nx, const double* __restrict__ p_in,
-                                                             double* __restrict__ p_out, int64_t p_stride_in, int64_t p_stride_out, int S, int seg_off,
-                                                             double damping, double* __restrict__ cum_all, int cum_in_lds, int B) {
-  extern __shared__ double s_dyn[];  // cum_in_lds: [n] cumulative areas, then [S + 1] boundaries; else only the boundaries
-  constexpr int NT = MPX_EA_THREADS;
-  __shared__ double wave_tot[NT / 64];
-  __shared__ double total;
-  const int l = threadIdx.x;
-  const int64_t pos_off = cum_in_lds ? n : 0;
-  double* __restrict__ pos = s_dyn + pos_off;
-  const int64_t m = n - 1, chunk = (m + NT - 1) / NT;  // m trapezoids; lane l owns the trapezoids [i0, i1)
-  const int64_t i0 = l * chunk < m ? l * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const double* __restrict__ r = resid + (int64_t)b * n * nx;
-    double* __restrict__ cum = cum_in_lds ? s_dyn : cum_all + (int64_t)b * n;  // cum[i] = area of the first i trapezoids
-    auto norm2 = [&](int64_t i) {
-      if (nx == 1) return fabs(r[i]);
-      double q = 0;
-      for (int a = 0; a < nx; ++a) q = fma(r[i * nx + a], r[i * nx + a], q);
-      return sqrt(q);
-    };
-    if (cum_in_lds) {  // the residual norms enter LDS with coalesced loads; the scan below turns them into cumulative areas in place
-      for (int64_t i = l; i < n; i += 8 * NT) {
-        double v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = i + k * NT < n ? norm2(i + k * NT) : 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (i + k * NT < n) cum[i + k * NT] = v[k];
-      }
-      __syncthreads();
-    }
-    auto sample = [&](int64_t i) { return cum_in_lds ? cum[i] : norm2(i); };
-    const double first = i0 < i1 ? sample(i0) : 0.0;  // (read before the in-place pass of the neighbouring lane overwrites it)
-    double tot = 0, prev = first;
-    for (int64_t i = i0; i < i1; ++i) {
-      const double nxt = sample(i + 1);
-      tot += 0.5 * (prev + nxt);
-      prev = nxt;
-    }
-    const double inc = wave_scan_inclusive(tot);
-    if ((l & 63) == 63) wave_tot[l >> 6] = inc;
-    __syncthreads();
-    double off = wave_shift_up_1(inc);
-    for (int q = 0; q < (l >> 6); ++q) off += wave_tot[q];
-    if (l == NT - 1) total = off + tot;
-    __syncthreads();
-    const double inv = 1.0 / total;
-    if (l == 0) cum[0] = 0.0;  // (lane 0 holds sample 0 in `first`)
-    prev = first;
-    for (int64_t i = i0; i < i1; ++i) {
-      const double nxt = sample(i + 1);  // position i + 1 is overwritten two lines down, by this lane only
-      off += 0.5 * (prev + nxt);
-      prev = nxt;
-      cum[i + 1] = i + 1 == m ? 1.0 : off * inv;  // (the reference divides by the last entry: exactly 1 there)
-    }
-    __syncthreads();
-    if (l == 0) pos[0] = 0.0;
-    // lane l owns a contiguous run of boundaries: one binary search for the first, then a forward walk (targets are monotone)
-    const int per = (S + NT - 1) / NT, s0 = l * per < S ? l * per : S, s1 = s0 + per < S ? s0 + per : S;
-    int64_t j = 1;
-    for (int s = s0; s < s1; ++s) {
-      const double target = (double)(s + 1) / (double)S;
-      if (s == s0) {
-        int64_t lo = 0, hi = m;  // first j with cum[j] >= target
-        while (lo < hi) {
-          const int64_t mid = (lo + hi) >> 1;
-          if (cum[mid] >= target) hi = mid; else lo = mid + 1;
-        }
-        j = lo < 1 ? 1 : lo;
-      } else {
-        while (j < m && cum[j] < target) ++j;
-      }
-      pos[s + 1] = ((double)(j - 1) + (target - cum[j - 1]) / (cum[j] - cum[j - 1])) / (double)m;
-    }
-    __syncthreads();
-    const double* __restrict__ pi = p_in + (int64_t)b * p_stride_in + seg_off;
-    double* __restrict__ po = p_out + (int64_t)b * p_stride_out + seg_off;
-    for (int s = l; s < S; s += 8 * NT) {
-      double v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = s + k * NT < S ? pi[s + k * NT] : 0.0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (s + k * NT < S) po[s + k * NT] = damping * (pos[s + k * NT + 1] - pos[s + k * NT]) + (1.0 - damping) * v[k];
-    }
-    __syncthreads();  // LDS is rewritten by the next point
-  }
-}
-
-// Fast kernel: n <= 12 * 1024 samples, S <= 4 * 1024 segments per phase (the config-5 protocol and everything of its size; scalar or
-// vector residuals -- the 2-norms are formed while the next point is fetched --, one call per phase).
-//  * persistent: one workgroup per compute unit; the NEXT point's samples are fetched into registers (coalesced) before the current
-//    point is scanned and searched, so the load phase disappears behind the rest;
-//  * the samples live in LDS in rows of `chunk` (= the trapezoids of one lane) padded to an odd number of doubles: a lane reads its
-//    row into registers and writes the cumulative areas back over it without bank conflicts (the unpadded layout of the generic
-//    kernel serialises every access four-fold at chunk = 12), one pass over LDS instead of two;
-//  * every new boundary is found by its own branch-free binary search, the lane's four searches interleaved (targets l, l + 1024,
-//    ...): the walk of the generic kernel is as long as the flattest stretch of the residual curve -- the slowest lane set the pace;
-//  * the exclusive prefix sums of the new widths -- what mpx_prefix_kernel would compute from p_out, same additions in the same
-//    order (prefix_scan_block) -- are left in `wcum`, so that the next evaluation needs no prefix launch (MPX_WIDTHS_UNCHANGED).
-// Same rule, same searches (first j with cum[j] >= target) as the generic kernel; the cumulative sums associate differently.
-template <bool SCALAR>
-__global__ __launch_bounds__(MPX_EA_THREADS) void mpx_equal_area_fast_kernel(const double* __restrict__ resid, int n, const double* __restrict__ p_in,
-                                                                  double* __restrict__ p_out, int64_t p_stride_in, int64_t p_stride_out, int S,
-                                                                  double damping, double* __restrict__ wcum, int64_t wcum_stride, int B, int chunk,
-                                                                  unsigned magic, int pad, int pos_off, int nx, int seg_off, int want_prefix, long long* dbg) {
-#ifdef MPX_EA_STAMPS  // phase stamps of the second point of workgroup 0 (-DMPX_EA_STAMPS + MPX_EA_DEBUG=1)
-#define MPX_EA_STAMP(k) if (dbg && threadIdx.x == 0 && blockIdx.x == 0 && b == (int)gridDim.x * ((B - 1) / (int)gridDim.x > 0 ? 1 : 0)) dbg[k] = wall_clock64()
-#else
-#define MPX_EA_STAMP(k)
-#endif
-  extern __shared__ double s_dyn[];  // padded samples / cumulative areas, then [S + 1] boundaries at pos_off
-  constexpr int NT = MPX_EA_THREADS, PF = MPX_EA_PF, WR = MPX_EA_WR;
-  __shared__ double wave_tot[NT / 64];
-  __shared__ double pre_tot[MPX_PREFIX_THREADS / 64];
-  const int m = n - 1;
-  const double inv_m = 1.0 / (double)m;
-  auto phys = [&](int i) { return i + (pad ? (int)__umulhi((unsigned)i, magic) : 0); };  // i + i / chunk (exact for i < 2^32 / chunk)
-  double* __restrict__ cum = s_dyn;
-  double* __restrict__ pos = s_dyn + pos_off;
-  int* __restrict__ jmap = reinterpret_cast<int*>(pos);  // [WR * NT] first-target marks: live between the area scan and the boundaries
-  __shared__ int wave_j[NT / 64];
-  double pf[PF];
-  // The prefetch must reach its use without a control-flow merge in between: with `if (next point exists) fetch(...)`, a run-time
-  // `nx == 1` and a guard per load the fetched values met the old ones in phi nodes, the register allocator resolved those with
-  // copies right behind the loads, and a copy reads its source -- s_waitcnt vmcnt(0) two instructions after the last load was
-  // issued: the whole fetch was exposed at every point of a batch (16.8 us per point against 9.8 us of phases).  So: SCALAR is a
-  // template parameter, every lane issues all PF loads (indices clamped to the last sample: the surplus ones of a short sample
-  // list hit one line), and the last point of a workgroup fetches itself again.
-  auto fetch = [&](int b, int l, int k0 = 0, int k1 = PF) {  // (k0, k1: literals at the call sites)
-    const double* __restrict__ r = resid + (int64_t)b * n * nx;
-    if constexpr (SCALAR) {
-#pragma unroll
-      for (int k = 0; k < PF; ++k)
-        if (k >= k0 && k < k1 && (!MPX_EA_COND_PREFETCH || k * NT < n)) pf[k] = r[min(k * NT + l, m)];
-    } else {  // vector residuals: the 2-norm of a sample, accumulated like the generic kernel's (fma over the components, then sqrt)
-#pragma unroll
-      for (int k = 0; k < PF; ++k)
-        if (k * NT < n) {
-          const double* __restrict__ ri = r + (int64_t)min(k * NT + l, m) * nx;
-          double q = 0;
-          for (int a = 0; a < nx; ++a) q = fma(ri[a], ri[a], q);
-          pf[k] = sqrt(q);
-        }
-    }
-  };
-  fetch(min((int)blockIdx.x, B - 1), threadIdx.x);  // (the host launches at most B workgroups)
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    // (the lane id is opaque per point: everything derived from it is recomputed here with a few integer operations instead of
-    // being hoisted out of the loop into registers the 128-VGPR budget of a 1024-lane workgroup does not have)
-    int l = threadIdx.x;
-    asm volatile("" : "+v"(l));
-    MPX_EA_STAMP(0);
-#pragma unroll
-    for (int k = 0; k < PF; ++k)
-      if (k * NT < n) cum[phys(k * NT + l)] = fabs(pf[k]);  // (slots past sample m are never read: the host sized the rows for them)
-    reinterpret_cast<int4*>(jmap)[l] = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);  // (the boundaries of the previous point are spent)
-    __syncthreads();
-    // Scalar residuals: the next point's samples are requested in MPX_EA_SLICES slices, one behind each of the first phases.  All
-    // workgroups of the launch pass through the same phase at the same time: requested at once, the 25 MB of a round of 256 points
-    // met an idle memory system, filled the compute units' request queues and held every wavefront at its load instructions until
-    // HBM had delivered (stamps at B = 2048: the phase behind the fetch 2.2 -> 5.5 us).
-    constexpr int SL = SCALAR && !MPX_EA_COND_PREFETCH ? MPX_EA_SLICES : 1, PS = (PF + SL - 1) / SL;
-    const int b_next = min(b + (int)gridDim.x, B - 1);
-    if constexpr (SCALAR && !MPX_EA_COND_PREFETCH) fetch(b_next, l, 0, PS);  // in flight during the scan and the search of this point
-    else if (b + (int)gridDim.x < B) fetch(b + gridDim.x, l);
-    double pin[WR];  // the lane's old widths: requested now, used after the search
-    {
-      const double* __restrict__ pi_ = p_in + (int64_t)b * p_stride_in + seg_off;
-#pragma unroll
-      for (int k = 0; k < WR; ++k) pin[k] = pi_[min(l + k * NT, S - 1)];
-    }
-    MPX_EA_STAMP(1);
-    // lane l owns the trapezoids [i0, i0 + cnt) = its row of the padded layout; its samples i0 ... i0 + cnt are read twice (row sums,
-    // then cumulative areas written back over them); the last one is the next lane's first -- the first slot of the next row,
-    // overwritten by THIS lane only, so the next lane keeps its copy (`first`)
-    const int i0 = l * chunk < m ? l * chunk : m, cnt = (i0 + chunk < m ? i0 + chunk : m) - i0;
-    const int row = cnt > 0 ? i0 + (pad ? l : 0) : 0;  // phys(i0); lanes without trapezoids read row 0 and use nothing of it
-    const int last = row + chunk + pad;                // slot of sample i0 + chunk
-    // (the row is fetched whole, then used: thirteen LDS reads in flight instead of a read, a wait and an addition thirteen times;
-    // slots past the row's end repeat `last` and are masked by t < cnt)
-    double a[PF + 1];
-    auto load_row = [&]() {
-      a[0] = cum[row];
-#pragma unroll
-      for (int t = 0; t < PF; ++t) a[t + 1] = cum[t + 1 < chunk ? row + t + 1 : last];
-    };
-    load_row();
-    const double first = a[0];
-    double tot = 0;
-#pragma unroll
-    for (int t = 0; t < PF; ++t) tot += t < cnt ? 0.5 * (a[t] + a[t + 1]) : 0.0;
-    const double inc = wave_scan_inclusive(tot);
-    if ((l & 63) == 63) wave_tot[l >> 6] = inc;
-    __syncthreads();  // (also: every lane has read its `first`)
-    if constexpr (SL > 1) fetch(b_next, l, PS, 2 * PS);
-    double off = wave_shift_up_1(inc);
-    double total = 0;
-#pragma unroll
-    for (int q = 0; q < NT / 64; ++q) {
-      if (q == (l >> 6)) off += total;
-      total += wave_tot[q];
-    }
-    MPX_EA_STAMP(2);
-    const double inv = 1.0 / total;
-    load_row();
-    a[0] = first;
-#pragma unroll
-    for (int t = 0; t < PF; ++t) {
-      off += 0.5 * (a[t] + a[t + 1]);
-      if (t < cnt) cum[t + 1 < chunk ? row + t + 1 : last] = off * inv;
-    }
-    if (l == 0) cum[0] = 0.0;
-    if (cnt > 0 && i0 + cnt == m) cum[cnt < chunk ? row + cnt : last] = 1.0;  // (the reference divides by the last entry: exactly 1 there)
-    __syncthreads();
-    if constexpr (SL > 2) fetch(b_next, l, 2 * PS, 3 * PS);
-    MPX_EA_STAMP(3);
-    // New boundaries without a search.  kc(j) = number of targets T_s = (s + 1) / S not above cum[j] is a product and a floor
-    // (an fma and a division settle the rare products within rounding of an integer); sample j is the first one at or above T_s
-    // exactly for s in [kc(j - 1), kc(j)), so every lane marks, for its own samples, the FIRST such target (jmap, aliased on the
-    // boundaries, cleared above) and a running maximum over the targets -- four per lane, a DPP scan per wavefront, sixteen
-    // wavefront totals -- fills in the rest.  (14 dependent, divergent LDS probes per target, conflicts included, were 6 of the
-    // 13.6 us of a point: profiles/r3_config5_loop.)  Same answer as the generic kernel's searches: first j with
-    // cum[j] >= fl((s + 1) / S), j >= 1.
-    {
-      const double Sd = (double)S;
-      auto not_above = [&](double c) {  // #{s in [0, S): fl((s + 1) / S) <= c}, c in [0, 1]
-        const double x = c * Sd, xf = floor(x), d = x - xf;
-        int q = (int)xf;
-        if (d == 0.0 || d > 1.0 - 2e-12) {  // (rare: the rounded product is an integer, or within rounding below the next one)
-          if (fma(c, Sd, -xf) < 0.0) --q;   // the product was rounded up to an integer: q = floor(c S) exactly now
-          // s + 1 <= q: (s + 1) / S <= c before rounding, hence after.  s + 1 = q + 1 is above c, but the quotient may round down to it
-          if (q < S && (double)(q + 1) / Sd <= c) ++q;
-        }
-        return q < S ? q : S;
-      };
-      load_row();
-      int kprev = not_above(a[0]);
-#pragma unroll
-      for (int t = 0; t < PF; ++t) {
-        const int kc = not_above(a[t + 1]);
-        if (t < cnt && kc > kprev) atomicMin(&jmap[kprev], i0 + t + 1);
-        kprev = kc;
-      }
-    }
-    MPX_EA_STAMP(7);
-    __syncthreads();
-    if constexpr (SL > 3) fetch(b_next, l, 3 * PS, PF);
-    MPX_EA_STAMP(8);
-    int jj[WR];
-    {
-      const int4 mk = reinterpret_cast<const int4*>(jmap)[l];  // the marks of targets 4 l ... 4 l + 3 (0x7fffffff: none)
-      jj[0] = mk.x, jj[1] = mk.y, jj[2] = mk.z, jj[3] = mk.w;
-      static_assert(WR == 4, "one 16-byte read per lane");
-#pragma unroll
-      for (int k = 0; k < WR; ++k) jj[k] = jj[k] == 0x7fffffff ? 0 : jj[k];
-#pragma unroll
-      for (int k = 1; k < WR; ++k) jj[k] = max(jj[k], jj[k - 1]);
-      const int inc_j = wave_max_scan_inclusive(jj[WR - 1]);
-      if ((l & 63) == 63) wave_j[l >> 6] = inc_j;
-      int before = __builtin_amdgcn_update_dpp(0, inc_j, 0x138, 0xf, 0xf, false);  // wave_shr:1
-      __syncthreads();  // (also: every lane has read its marks; the boundaries may overwrite them)
-#pragma unroll
-      for (int q = 0; q < NT / 64; ++q)
-        if (q < (l >> 6)) before = max(before, wave_j[q]);
-#pragma unroll
-      for (int k = 0; k < WR; ++k) jj[k] = max(jj[k], before);
-    }
-    MPX_EA_STAMP(9);
-#pragma unroll
-    for (int k = 0; k < WR; ++k) {
-      const int s = WR * l + k;
-      const int j = jj[k] < 1 ? 1 : jj[k];
-      const double target = (double)(WR * (int)threadIdx.x + k + 1) / (double)S;  // (of the lane, not of the point: hoisted)
-      const double c0 = cum[phys(j - 1)], c1 = cum[phys(j)];
-      if (s < S) pos[s + 1] = ((double)(j - 1) + (target - c0) / (c1 - c0)) * inv_m;
-    }
-    if (l == 0) pos[0] = 0.0;
-    __syncthreads();
-    MPX_EA_STAMP(4);
-    double* __restrict__ po = p_out + (int64_t)b * p_stride_out + seg_off;
-    // the new widths also replace the boundaries in LDS (registers first: a lane's pos[s + 1] is its neighbour's pos[s]), then
-    // the workgroup scans them exactly as mpx_prefix_kernel scans p_out (MPX_PREFIX_THREADS == MPX_EA_THREADS)
-    double wn[WR];
-#pragma unroll
-    for (int k = 0; k < WR; ++k) {
-      const int s = min(l + k * NT, S - 1);
-      wn[k] = damping * (pos[s + 1] - pos[s]) + (1.0 - damping) * pin[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < WR; ++k) {
-      const int s = l + k * NT;
-      if (s < S) pos[s] = wn[k], po[s] = wn[k];
-    }
-    __syncthreads();
-    MPX_EA_STAMP(5);
-    // (only for problems with a node function that uses the node time: nothing else reads the prefix sums -- 1.8 of 11.5 us per point)
-    if (want_prefix) prefix_scan_block([&](int s) { return pos[s]; }, wcum + (int64_t)b * wcum_stride + seg_off, S, l, pre_tot);
-    MPX_EA_STAMP(6);
-    __syncthreads();  // LDS is rewritten by the next point
-  }
-#undef MPX_EA_STAMP
-}
-}  // namespace
-
-extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch, int64_t n_pts, const double* resid, const double* p_in,
-                                            int p_in_per_point, double* p_out, double damping) {
-  if (!c || !resid || !p_in || !p_out || batch < 1 || n_pts < 2) return fail(c, MPX_ERR_INVALID, "mpx_equal_area_widths_device: bad arguments");
-  if (c->kind != 0 || phase < 0 || phase >= c->n_phases) return fail(c, MPX_ERR_INVALID, "mpx_equal_area_widths_device: phase out of range");
-  if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "mpx_equal_area_widths_device: context has no device code; there is no CPU fallback");
-  HIPCHK(c, hipSetDevice(c->device));
-  // cumulative areas in LDS when they fit next to the S + 1 boundaries (150 of the 160 KB of a compute unit), else in HBM scratch
-  const size_t lds_all = (size_t)(n_pts + c->S + 1) * 8, lds_pos = (size_t)(c->S + 1) * 8;
-  const int in_lds = lds_all <= 150 * 1024;
-  if (lds_pos > 150 * 1024) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_equal_area_widths_device: more than 19199 segments per phase");
-  // the fast kernel (it leaves the prefix sums of the phase's new widths for the next evaluation; MPX_WIDTHS_UNCHANGED is the caller's
-  // word that every phase has been updated): rows of `chunk` samples padded to an odd stride
-  const int chunk = (int)((n_pts - 1 + MPX_EA_THREADS - 1) / MPX_EA_THREADS), pad = chunk % 2 == 0;
-  // (rows for every staged slot: the lanes stage ceil(n / 1024) * 1024 samples, the ones past the last sample are never read)
-  const int64_t staged = (n_pts + MPX_EA_THREADS - 1) / MPX_EA_THREADS * MPX_EA_THREADS;
-  const int64_t pos_off = (staged + (pad ? staged / chunk : 0) + 2) & ~(int64_t)1;
-  const size_t lds_fast = (size_t)(pos_off + std::max<int64_t>(c->S + 1, MPX_EA_WR * MPX_EA_THREADS / 2)) * 8;  // (boundaries, or the marks they alias)
-  const bool fast = n_pts <= (int64_t)MPX_EA_PF * MPX_EA_THREADS && c->S <= MPX_EA_WR * MPX_EA_THREADS &&
-                    lds_fast <= 150 * 1024 && !getenv("MPX_EA_GENERIC");
-  int rc;
-  if (!fast && !in_lds && (rc = reserve(c, c->ea_scratch, (size_t)(batch * n_pts)))) return rc;
-  const size_t lds = fast ? lds_fast : in_lds ? lds_all : lds_pos;
-  long long*& dbg = c->ea_dbg;  // per context: freed in mpx_destroy
-  if (!dbg && getenv("MPX_EA_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&dbg, 128, hipHostMallocMapped));
-  if (lds > 48 * 1024 && lds > c->ea_lds_allowed) {  // the attribute is per device: remembered per context, not per process
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_fast_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_fast_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    c->ea_lds_allowed = 150 * 1024;
-  }
-  if (fast) {
-    const size_t wcap = c->wcum.cap;
-    if ((rc = reserve_wcum(c, (size_t)(batch * c->n_p)))) return rc;
-    // the prefix sums of this phase's new widths are left in wcum: they describe p_out (per point, this batch)
-    if (wcap != c->wcum.cap || c->wcum_p != p_out || c->wcum_batch != batch || c->wcum_ppp != 1) c->wcum_phases = 0;
-    // (the kernel writes the prefix sums only for time-dependent problems -- want_prefix below; otherwise the phase's bit is CLEARED:
-    // the bookkeeping must never say the buffer holds sums it does not hold)
-    c->wcum_p = p_out, c->wcum_batch = batch, c->wcum_ppp = 1;
-    if (c->time_dep) c->wcum_phases |= 1u << phase;
-    else c->wcum_phases &= ~(1u << phase);
-    int n_cu = 256;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-    const unsigned grid = (unsigned)std::min<int64_t>(batch, n_cu);  // persistent: a workgroup owns its compute unit's LDS
-    const unsigned magic = (unsigned)((((uint64_t)1 << 32) + chunk - 1) / chunk);  // i / chunk = umulhi(i, magic) for i < 2^32 / chunk
-    // (scalar residuals -- one state -- have their own instantiation: the prefetch of the next point must not pass a run-time branch)
-    hipLaunchKernelGGL(c->nx == 1 ? mpx_equal_area_fast_kernel<true> : mpx_equal_area_fast_kernel<false>, dim3(grid), dim3(MPX_EA_THREADS), lds, c->stream,
-                       resid, (int)n_pts, p_in, p_out, (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, damping, c->wcum.p, (int64_t)c->n_p,
-                       (int)batch, chunk, magic, pad, (int)pos_off, c->nx, phase * c->S, c->time_dep ? 1 : 0, dbg);
-  } else {
-    if (c->wcum_p == p_out) c->wcum_phases &= ~(1u << phase);  // the generic kernel changes the widths and leaves no prefix sums
-    hipLaunchKernelGGL(mpx_equal_area_kernel, dim3((unsigned)batch), dim3(MPX_EA_THREADS), lds, c->stream, resid, n_pts, c->nx, p_in, p_out,
-                       (int64_t)(p_in_per_point ? c->n_p : 0), (int64_t)c->n_p, c->S, phase * c->S, damping, c->ea_scratch.p, in_lds, (int)batch);
-  }
-  HIPCHK(c, hipGetLastError());
-  // the context's prefix sums now belong to p_out: a following mpx_eval_device(... | MPX_WIDTHS_UNCHANGED, p = p_out, per point,
-  // same batch) may use them (the caller's assertion, as always with that flag)
-  c->wcum_valid = false;
-  if (dbg) {  // MPX_EA_DEBUG: phase stamps of the last workgroup (wall_clock64, 100 MHz)
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    fprintf(stderr, "equal_area phases (us): stage %.2f  row sums %.2f  cumulative areas %.2f  search %.2f  widths %.2f  prefix %.2f\n", (dbg[1] - dbg[0]) / 100.0,
-            (dbg[2] - dbg[1]) / 100.0, (dbg[3] - dbg[2]) / 100.0, (dbg[4] - dbg[3]) / 100.0, (dbg[5] - dbg[4]) / 100.0, (dbg[6] - dbg[5]) / 100.0);
-    fprintf(stderr, "  search = marks %.2f  barrier %.2f  running maximum %.2f  boundaries %.2f\n", (dbg[7] - dbg[3]) / 100.0, (dbg[8] - dbg[7]) / 100.0,
-            (dbg[9] - dbg[8]) / 100.0, (dbg[4] - dbg[9]) / 100.0);
-  }
-  return MPX_OK;
-}
 
 static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
                      const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix);

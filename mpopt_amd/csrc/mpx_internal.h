@@ -302,6 +302,15 @@ inline int prof_end(mpx_ctx* c, hipEvent_t end_event) {
   if (end_event) HIPCHK(c, hipEventRecord(end_event, c->stream));
   return MPX_OK;
 }
+// (a re-allocation loses the prefix sums the buffer held)
+inline int reserve_wcum(mpx_ctx* c, size_t n) {
+  const double* before = c->wcum.p;
+  const int rc = reserve(c, c->wcum, n);
+  if (c->wcum.p != before) c->wcum_phases = 0;
+  return rc;
+}
+inline uint32_t all_phases(const mpx_ctx* c) { return c->n_phases >= 32 ? ~0u : ((1u << c->n_phases) - 1u); }
+
 }  // namespace mpxi
 
 // mpx_assembly.cpp

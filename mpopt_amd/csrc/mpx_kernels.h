@@ -1745,8 +1745,52 @@ __device__ __forceinline__ void resid_body(const MpxResidArgs& A) {
 // ---------------------------------------------------------------------------------------------
 constexpr int MAXRED = 64;
 
+// What a phase of the boundary pass reads from memory, requested for EVERY phase before the first of them is waited for (round 5):
+// the phase's first 256 partial-sum values (one per lane) and, on lane 0, the inputs of its terminal functions.  The pass is one
+// short workgroup per evaluation point and nothing but a chain of dependent round trips -- partial sums, barrier, terminal inputs,
+// per phase, one phase after the other: four in a row at config 4 (11 us of a 141 us nlp_g pass at B = 4096, and a quarter of a
+// single evaluation); now one.  Same values, same additions, same order.
+#ifndef MPX_BOUND_PREFETCH
+#define MPX_BOUND_PREFETCH 1
+#endif
+template <int PH>
+struct BoundPhaseIn {
+  using G = mpxgen::Phase<PH>;
+  Vec<G::NX> XF, X0;
+  Vec<G::NA> As;
+  double t0v, tfv, pv;
+};
+template <int PH>
+struct BoundIn : BoundIn<PH - 1> {
+  BoundPhaseIn<PH> me;
+};
+template <>
+struct BoundIn<-1> {};
+
 template <int PH, int MODE>
-__device__ __forceinline__ void boundary_phase(const MpxBoundArgs& A, int b, int l, double* red, double& facc) {
+__device__ __forceinline__ void boundary_phase_load(const MpxBoundArgs& A, int b, int l, BoundPhaseIn<PH>& I) {
+  using G = mpxgen::Phase<PH>;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA;
+  const MpxIO& io = A.io;
+  const MpxPhaseInfo& P = A.ph[PH];
+  const double* __restrict__ pp = io.partial + ((int64_t)b * io.n_tiles_total + P.tile_first) * io.nred;
+  const int nred = io.nred, total = (MODE == MPX_MODE_HESS ? P.tile_count_h : P.tile_count) * nred;
+  const int per = (256 / nred) * nred;
+  I.pv = l < (total < per ? total : per) ? pp[l] : 0.0;
+  if (l == 0) {
+    const int N = P.N;
+    const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + P.z_off;
+#pragma unroll
+    for (int a = 0; a < NX; ++a) I.XF[a] = zb[(int64_t)a * N + N - 1], I.X0[a] = zb[(int64_t)a * N];
+    const double* zt = zb + (int64_t)(NX + NU) * N;
+    I.t0v = zt[0], I.tfv = zt[1];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) I.As[c] = zt[2 + c];
+  }
+}
+
+template <int PH, int MODE>
+__device__ __forceinline__ void boundary_phase(const MpxBoundArgs& A, int b, int l, double* red, double& facc, const BoundPhaseIn<PH>* pre = nullptr) {
   using G = mpxgen::Phase<PH>;
   constexpr int NX = G::NX, NU = G::NU, NA = G::NA;
   constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : (MODE == MPX_MODE_FGJ ? G::NRED : G::NHC);
@@ -1788,7 +1832,7 @@ __device__ __forceinline__ void boundary_phase(const MpxBoundArgs& A, int b, int
       int in_group = 0;
       for (int c0 = 0; c0 < total; c0 += per) {
         const int cnt = total - c0 < per ? total - c0 : per;
-        if (l < cnt) sPart[l] = pp[c0 + l];
+        if (l < cnt) sPart[l] = (pre && c0 == 0) ? pre->pv : pp[c0 + l];
         __syncthreads();
         if (l < NRED) {
           if (glen > 1) {
@@ -1812,15 +1856,20 @@ __device__ __forceinline__ void boundary_phase(const MpxBoundArgs& A, int b, int
     const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride + P.z_off;
     Vec<NX> XF, X0;
     Vec<NA> As;
+    double t0v, tfv;
+    if (pre) {
+      XF = pre->XF, X0 = pre->X0, As = pre->As, t0v = pre->t0v, tfv = pre->tfv;
+    } else {
 #pragma unroll
-    for (int a = 0; a < NX; ++a) {
-      XF[a] = zb[(int64_t)a * N + N - 1];
-      X0[a] = zb[(int64_t)a * N];
+      for (int a = 0; a < NX; ++a) {
+        XF[a] = zb[(int64_t)a * N + N - 1];
+        X0[a] = zb[(int64_t)a * N];
+      }
+      const double* zt = zb + (int64_t)(NX + NU) * N;
+      t0v = zt[0], tfv = zt[1];
+#pragma unroll
+      for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
     }
-    const double* zt = zb + (int64_t)(NX + NU) * N;
-    const double t0v = zt[0], tfv = zt[1];
-#pragma unroll
-    for (int c = 0; c < NA; ++c) As[c] = zt[2 + c];
     double M = 0;
     Vec<G::NTC> tc;
     if constexpr (MODE == MPX_MODE_FG) {
@@ -1871,10 +1920,20 @@ struct PhaseLoop {
     PhaseLoop<PH - 1, MODE>::run(A, b, l, red, facc);
     boundary_phase<PH, MODE>(A, b, l, red, facc);
   }
+  __device__ static __forceinline__ void load(const MpxBoundArgs& A, int b, int l, BoundIn<PH>& I) {
+    PhaseLoop<PH - 1, MODE>::load(A, b, l, I);
+    boundary_phase_load<PH, MODE>(A, b, l, I.me);
+  }
+  __device__ static __forceinline__ void run_pre(const MpxBoundArgs& A, int b, int l, double* red, double& facc, const BoundIn<PH>& I) {
+    PhaseLoop<PH - 1, MODE>::run_pre(A, b, l, red, facc, I);
+    boundary_phase<PH, MODE>(A, b, l, red, facc, &I.me);
+  }
 };
 template <int MODE>
 struct PhaseLoop<-1, MODE> {
   __device__ static __forceinline__ void run(const MpxBoundArgs&, int, int, double*, double&) {}
+  __device__ static __forceinline__ void load(const MpxBoundArgs&, int, int, BoundIn<-1>&) {}
+  __device__ static __forceinline__ void run_pre(const MpxBoundArgs&, int, int, double*, double&, const BoundIn<-1>&) {}
 };
 
 template <int MODE>
@@ -1883,7 +1942,13 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A, const int r
   const int b = res_b >= 0 ? res_b : (int)blockIdx.x, l = threadIdx.x;
   const MpxIO& io = A.io;
   double facc = 0;
-  PhaseLoop<MPX_NPH - 1, MODE>::run(A, b, l, red, facc);
+  if constexpr (MPX_BOUND_PREFETCH && MPX_NPH <= 4) {  // (registers: ~12 per phase on lane 0's wavefront)
+    BoundIn<MPX_NPH - 1> I;
+    PhaseLoop<MPX_NPH - 1, MODE>::load(A, b, l, I);
+    PhaseLoop<MPX_NPH - 1, MODE>::run_pre(A, b, l, red, facc, I);
+  } else {
+    PhaseLoop<MPX_NPH - 1, MODE>::run(A, b, l, red, facc);
+  }
   if constexpr (MODE != MPX_MODE_HESS) {
     const double* __restrict__ zb = io.z + (int64_t)b * io.z_stride;
     for (int r = l; r < A.n_lin; r += blockDim.x) {
