@@ -597,8 +597,8 @@ def main():
         }
         if hess_mode and not loop5:
             out["roofline"]["note"] = ("SURVEY 8(d) byte model: it charges all n_g multipliers although the kernel reads only those of rows with second "
-                                       "derivatives, and a working set this small is partly Infinity-Cache resident -- a fraction near or above 1 is "
-                                       "not an HBM-roofline statement (no PMC traffic for this workload)")
+                                       "derivatives, and a working set this small is partly Infinity-Cache resident -- read `frac` together with "
+                                       "`frac_by_traffic` (PMC bytes actually moved over this run's kernel time) where the line carries it")
         # what the numbers are pinned to: never read the CPU ratio as "vs CasADi", nor the parity as "vs CasADi's AD"
         gold = sorted(fn for fn in os.listdir(os.path.join(ROOT, "tests", "golden")) if fn.endswith(".npz"))
         out["parity"] = {"goldens": f"{len(gold)} files under tests/golden/ (outputs of the imported reference: tables from CollocationRoots / Collocation, "
@@ -636,16 +636,26 @@ def main():
                 if os.path.exists(p_):
                     return p_, json.load(open(p_))
             return None, None
-        tsrc = {"config2-fgj": (("r4_final/headline", "r3_final/headline", "r2_headline"), 4096), "config3-fgj": (("r4_final/c3_fgj", "r3_final/c3_fgj", "r2_c3_spans"), 512),
-                "config3-hess": (("r4_final/c3_hess", "r3_final/c3_hess"), 2048), "config5-hess": (("r2_config5_hess",), 4096), "config2-hess": (("r2_config2_hess",), 4096),
-                "adaptive-fgj": (("r4_final/adaptive", "r3_final/adaptive", "r3_adaptive2"), 4096),
-                "config5-loop": (("r4_final/config5_loop", "r3_final/config5_loop"), 512)}.get(args.workload)
-        if partial_sel:
-            tsrc = {"config3-fgj": ((f"r4_c3_fg/after_{'_'.join(w for w in ('f', 'g', 'grad_f') if w in sel)}",), 512)}.get(args.workload) if not mask & MPX_JAC else None
+        # (newest round first; every secondary workload has a PMC pass since round 5: tools/r5_evidence.sh -> profiles/r5_final/)
+        cfgn = args.workload[6] if args.workload.startswith("config") else ""
+        tsrc = {"config2-fgj": (("r5_final/headline", "r4_final/headline", "r3_final/headline", "r2_headline"), 4096),
+                "config3-fgj": (("r5_final/c3_fgj", "r4_final/c3_fgj", "r3_final/c3_fgj", "r2_c3_spans"), 512),
+                "config3-hess": (("r5_final/c3_hess", "r4_final/c3_hess", "r3_final/c3_hess"), 2048),
+                "config5-hess": (("r5_final/c5_hess", "r2_config5_hess"), 4096), "config2-hess": (("r5_final/c2_hess", "r2_config2_hess"), 4096),
+                "config4-fgj": (("r5_final/c4_fgj",), 4096), "config4-hess": (("r5_final/c4_hess",), 4096), "config5-fgj": (("r5_final/c5_fgj",), 4096),
+                "adaptive-fgj": (("r5_final/adaptive_fgj", "r4_final/adaptive", "r3_final/adaptive", "r3_adaptive2"), 4096),
+                "adaptive-hess": (("r5_final/adaptive_hess",), 4096),
+                "config5-loop": (("r5_final/config5_loop", "r4_final/config5_loop", "r3_final/config5_loop"), 512)}.get(args.workload)
+        if partial_sel:  # the light passes (no Jacobian values): one PMC pass per configuration and selection
+            seln = "_".join(w for w in ("f", "g", "grad_f") if w in sel)
+            tsrc = None
+            if not mask & MPX_JAC and cfgn in "2345" and cfgn:
+                tsrc = ((f"r5_final/c{cfgn}_light_{seln}",) + ((f"r4_c3_fg/after_{seln}",) if cfgn == "3" else ()) + ((f"r4_final/c2_light_{seln}",) if cfgn == "2" else ()),
+                        512 if cfgn == "3" else 4096)
         if tsrc and B == tsrc[1]:
             tfp, tr = _first(*tsrc[0])
             wl = tr.get("workload") if tr else None
-            if tr and (not isinstance(wl, dict) or wl == {"segments": S, "degree": P, "batch": B}) and (not partial_sel or wl == "config3-fgj"):
+            if tr and (not isinstance(wl, dict) or wl == {"segments": S, "degree": P, "batch": B}) and (not partial_sel or wl == args.workload):
                 tb = tr.get("bytes_per_launch", tr.get("bytes_per_pass"))
                 if tb is None and "bytes_per_outer_iteration" in tr:  # the config-5 loop: one step = 5 outer iterations
                     tb = 5 * tr["bytes_per_outer_iteration"]

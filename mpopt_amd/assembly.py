@@ -214,8 +214,6 @@ class AssembledNlpFunctions(NlpFunctions):
             terms_m = np.concatenate([cf[ptr[r]:ptr[r + 1]] for r in rows_m]) if len(rows_m) else np.zeros(0)  # ELL table of the multi-term rows
             vals = np.concatenate([first, np.zeros(1 if (nt == 0).any() else 0), terms_m])
             sizes["NDICT_" + tag] = len(np.unique(vals.view(np.int64))) if len(vals) else 0
-            # all terms of the multi-term rows: the compact table a workgroup of the fused kernels keeps in LDS (MpxFusedArgs::c_pack)
-            sizes["CTOT_" + tag] = int(len(terms_m))
         # per set: function id and the running term offsets of its local variables / multipliers -- compile-time constants of the
         # fused kernels (mpx_assembly_fused.h, mpxgen::SetT; the host computes the same offsets from loc_nterm / mu_nterm)
         self._set_consts = [(self.functions.index(s.fn), np.concatenate([[0], np.cumsum(np.asarray(e[0][0], np.int64))]).tolist(),

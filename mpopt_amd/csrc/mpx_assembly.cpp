@@ -46,11 +46,6 @@ struct DevFused {
   double *r_coef = nullptr, *m_coef = nullptr;
   int32_t n_multi = 0, n_mid = 0, n_long = 0;
   uint32_t* m_pack = nullptr;  // ELL table of the multi-term rows packed the same way, same dictionary
-  uint32_t* c_pack = nullptr;  // ... and compact, row after row (MpxFusedArgs::c_pack / c_ptr): what a workgroup keeps in LDS
-  int32_t* c_ptr = nullptr;
-  int32_t* m_wmax = nullptr;   // longest row of every block of 64 multi-term rows (ordered by term count)
-  int32_t c_total = 0;
-  unsigned lds_dyn = 0;        // dynamic LDS bytes of the launch when the compact table rides in LDS (0: the ELL table from memory)
   uint32_t* r_pack = nullptr;  // single-term rows packed (MpxFusedArgs::r_pack); n_dict = 0: not representable (an index or the dictionary past 16 bits)
   double* r_dict = nullptr;
   int32_t n_dict = 0;
@@ -242,11 +237,6 @@ int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, in
     if (nt > mt) longr.push_back((int32_t)r);  // (mt = the pass's long-row threshold, DevGather::long_threshold)
     else if (nt >= 2) multi.push_back((int32_t)r);
   }
-  // (longest first, ties in row order: the 64 rows a wavefront takes together are then about equally long -- MpxFusedArgs::m_wmax;
-  // which lane sums a row changes, the row's terms, their order and its fma chain do not)
-  std::stable_sort(multi.begin(), multi.end(), [&](int32_t x, int32_t y) { return r_nt[(size_t)x] > r_nt[(size_t)y]; });
-  std::vector<int32_t> wmax((multi.size() + 63) / 64, 0);
-  for (size_t m = 0; m < multi.size(); ++m) wmax[m / 64] = std::max(wmax[m / 64], r_nt[(size_t)multi[m]]);
   f.n_multi = (int32_t)multi.size(), f.n_mid = (int32_t)mid.size(), f.n_long = (int32_t)longr.size();
   // ELL copy of the multi-term rows: [t][row], padded with (the 1.0 slot, 0) -- padding terms are never added (t < nt)
   std::vector<int32_t> m_idx((size_t)std::max<int64_t>((int64_t)mt * f.n_multi, 1), (int32_t)(raw_n + n_z));
@@ -278,15 +268,7 @@ int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, in
         m_pack[(size_t)(t * f.n_multi + m)] = (uint32_t)idx[(size_t)e] | (code(g.coef[e]) << 16);
     f.n_dict = ok ? (int32_t)r_dict.size() : 0;
   }
-  std::vector<uint32_t> c_pack;
-  std::vector<int32_t> c_ptr(1, 0);
-  for (int32_t m = 0; m < f.n_multi; ++m) {
-    for (int64_t e = g.ptr[multi[m]], t = 0; e < g.ptr[multi[m] + 1]; ++e, ++t) c_pack.push_back(m_pack[(size_t)(t * f.n_multi + m)]);
-    c_ptr.push_back((int32_t)c_pack.size());
-  }
-  f.c_total = (int32_t)c_pack.size();
   int rc;
-  if ((rc = upload(c, &f.c_pack, c_pack)) || (rc = upload(c, &f.c_ptr, c_ptr)) || (rc = upload(c, &f.m_wmax, wmax))) return rc;
   if ((rc = upload(c, &f.r_pack, r_pack)) || (rc = upload(c, &f.r_dict, r_dict)) || (rc = upload(c, &f.m_pack, m_pack))) return rc;
   if ((rc = upload(c, &f.r_idx, r_idx)) || (rc = upload(c, &f.r_nt, r_nt)) || (rc = upload(c, &f.r_coef, r_coef)) || (rc = upload(c, &f.idx, idx)) ||
       (rc = upload(c, &f.multi, multi)) || (rc = upload(c, &f.mid, mid)) || (rc = upload(c, &f.longr, longr)) || (rc = upload(c, &f.m_idx, m_idx)) ||
@@ -317,7 +299,7 @@ void mpx_asm_release(mpx_ctx* c) {
   };
   for (auto& s : a->sets) fr(s.loc_toff), fr(s.loc_idx), fr(s.mu_toff), fr(s.mu_idx), fr(s.loc_coef), fr(s.cst), fr(s.mu_coef);
   for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef), fr(g->long_rows);
-  for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef), fr(f->r_pack), fr(f->r_dict), fr(f->m_pack), fr(f->c_pack), fr(f->c_ptr), fr(f->m_wmax);
+  for (DevFused* f : {&a->ffgj, &a->fhess}) fr(f->r_idx), fr(f->r_nt), fr(f->idx), fr(f->multi), fr(f->mid), fr(f->longr), fr(f->m_idx), fr(f->r_coef), fr(f->m_coef), fr(f->r_pack), fr(f->r_dict), fr(f->m_pack);
   fr(a->d_ch_ptr), fr(a->d_ch_idx), fr(a->d_ch_slot), fr(a->d_ch_coef);
   for (auto q : a->d_chain_pos) fr(q);
   for (auto q : a->d_loc_pack) fr(q);
@@ -509,10 +491,10 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
   {  // fused persistent kernels (mpx_assembly_fused.h): present in code objects generated since round 3
     hipDeviceptr_t sym = nullptr;
     size_t bytes = 0;
-    int info[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // ([9], [10]: round 5; code objects generated before have nine entries)
+    int info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     static const char* fname[3] = {"mpx_asm_fg", "mpx_asm_fgj", "mpx_asm_hes"};
-    const bool have_info = hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_fuse_info") == hipSuccess && (bytes == 9 * sizeof(int) || bytes == sizeof info) &&
-                           hipMemcpyDtoH(info, sym, bytes) == hipSuccess && info[0] >= 64 && info[0] <= 1024;
+    const bool have_info = hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_fuse_info") == hipSuccess && bytes == sizeof info &&
+                           hipMemcpyDtoH(info, sym, sizeof info) == hipSuccess && info[0] >= 64 && info[0] <= 1024;
     // rows with more terms than the pass's ELL width are summed by a wavefront (lane-strided partial sums + shuffle tree) in BOTH
     // the two-pass gather kernel and the fused kernel -- one definition of every sum, so the two paths agree bit for bit
     const int thr_fgj = have_info && info[3] >= 2 ? info[3] : MPX_GATHER_LONG, thr_hes = have_info && info[4] >= 2 ? info[4] : MPX_GATHER_LONG;
@@ -572,28 +554,6 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
           int per_cu = 1;
           if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, a->fn_fused[m], a->fuse_nt, 0) != hipSuccess || per_cu < 1) per_cu = 1;
           a->fuse_wg[m] = n_cu * per_cu;
-        }
-        // The compact table of the multi-term rows in LDS: a compile-time decision of the code object (mpx_fuse_info[9], [10] = the
-        // dynamic LDS its kernels expect; MPX_HIPCC_FLAGS=-DMPX_FUSE_MULTI_LDS=0 builds them without).  The host's table must have
-        // exactly that size, else the code object was generated for other tables: no fused kernels then.
-        for (int ps = 0; ps < 2; ++ps) {
-          DevFused& F = ps ? a->fhess : a->ffgj;
-          const unsigned want = (unsigned)info[9 + ps];
-          if (!want) continue;
-          const unsigned have = (unsigned)(((size_t)F.c_total + 2 * (size_t)F.n_multi + 2) * 4);
-          if (have != want || F.n_dict <= 0) {
-            c->notes += "assembled context: the code object expects " + std::to_string(want) + " B of LDS for the multi-term rows, the tables need " + std::to_string(have) + ": two-pass kernels\n";
-            a->fuse_u[ps] = 0;
-            continue;
-          }
-          F.lds_dyn = want;
-          for (int m = ps ? 2 : 0; m < (ps ? 3 : 2); ++m) {
-            int per_cu = 1;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(a->fn_fused[m]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, a->fn_fused[m], a->fuse_nt, want) != hipSuccess || per_cu < 1) per_cu = 1;
-            a->fuse_wg[m] = n_cu * per_cu;
-          }
-          (void)hipGetLastError();
         }
       }
     }
@@ -678,8 +638,6 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
   A.l_dict = a->d_l_dict, A.m_dict = a->d_m_dict, A.n_ldict = a->n_ldict, A.n_mdict = a->n_mdict;
   A.multi_rows = f.multi, A.m_idx = f.m_idx, A.m_coef = f.m_coef, A.mid_rows = f.mid, A.long_rows = f.longr;
   A.n_multi = f.n_multi, A.n_mid = f.n_mid, A.n_long = f.n_long;
-  A.c_pack = f.c_pack, A.c_ptr = f.c_ptr, A.c_total = f.c_total, A.multi_lds = f.lds_dyn ? 1 : 0;
-  A.m_wmax = f.m_wmax;
   A.task_ptr = a->d_task_ptr[mode == MPX_MODE_HESS ? 1 : 0], A.task_list = a->d_task_list[mode == MPX_MODE_HESS ? 1 : 0];
   A.ch_ptr = a->d_ch_ptr, A.ch_idx = a->d_ch_idx, A.ch_coef = a->d_ch_coef, A.ch_slot = a->d_ch_slot, A.n_chains = a->n_chains;
   for (int k = 0; k < 4; ++k) A.out[k] = out[k], A.out_stride[k] = stride[k];
@@ -692,7 +650,7 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
   A.dbg = dbg_on ? a->dbg : nullptr;
   size_t sz = sizeof(A);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIPCHK(c, hipModuleLaunchKernel(a->fn_fused[mode], grid, 1, 1, (unsigned)a->fuse_nt, 1, 1, f.lds_dyn, c->stream, nullptr, cfg));
+  HIPCHK(c, hipModuleLaunchKernel(a->fn_fused[mode], grid, 1, 1, (unsigned)a->fuse_nt, 1, 1, 0, c->stream, nullptr, cfg));
   if (dbg_on) {  // phase stamps of workgroup 1, third chunk (us): z->LDS, points, barrier, single rows, multi rows, mid rows, long rows, barrier
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const long long* d = a->dbg;

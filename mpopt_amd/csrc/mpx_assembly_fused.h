@@ -77,9 +77,6 @@
 #ifndef MPX_FUSE_NT
 #define MPX_FUSE_NT 512  // lanes per workgroup
 #endif
-#ifndef MPX_FUSE_WMAX
-#define MPX_FUSE_WMAX 1  // multi-term rows: loop bound = the longest row of the wavefront's block (0: the pass-wide ELL width, round 4)
-#endif
 
 namespace mpxk {
 
@@ -458,7 +455,7 @@ struct FusedDispatchSet<MODE, -1, U, VN, RAWN> {
 // MODE_FG / MODE_FGJ: arrays f (1 row), g (NG), grad_f (NZ), jac_val (NNZJ); MODE_HESS: hess_val (NNZH).
 // MT: ELL width of the multi-term rows (rows with 2 .. MT terms); RL x TL: long rows per wavefront x 64-term rounds
 // per long row when their table fits the register budget (RL == 0: read from global memory per chunk).
-template <int MODE, int NF, int NT, int U, int RAWN, int NZ, int N0, int N1, int N2, int N3, int MT, int RM, int RL, int TL, int NDICT, bool MLDS = false>
+template <int MODE, int NF, int NT, int U, int RAWN, int NZ, int N0, int N1, int N2, int N3, int MT, int RM, int RL, int TL, int NDICT>
 __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
   constexpr int VN = RAWN + NZ + 1;  // [raw | z | 1.0]
   __shared__ double V[U][VN];
@@ -495,22 +492,6 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
   __shared__ double sDict[NDICT > 0 ? NDICT : 1];  // coefficient dictionary of the packed single-term rows
   if constexpr (NDICT > 0) {
     for (int e = l; e < NDICT; e += NT) sDict[e] = e < A.n_dict ? A.r_dict[e] : 0.0;
-    __syncthreads();
-  }
-  // Compact table of the multi-term rows in LDS for the life of the workgroup (MpxFusedArgs::multi_lds, dynamic LDS: [c_total]
-  // entries | [n_multi + 1] offsets | [n_multi] rows).  Round 5: the stamps of mpx_asm_hes (profiles/r5_adaptive_hess) put the
-  // multi-term phase at 2.8 of 5.5 us per chunk -- EVERY row of hess_l is one, and per chunk a lane walked row -> term count -> table
-  // entries through memory (two dependent round trips per round of 512 rows).
-  // MLDS is a compile-time decision of the generated source (MPX_FUSE_MLDS_OK below: packed tables, and the workgroup's LDS stays
-  // within half a compute unit); the host reads the expected dynamic LDS from mpx_fuse_info and refuses the kernel otherwise.
-  extern __shared__ uint32_t sDynM[];
-  const uint32_t* __restrict__ sEnt = sDynM;
-  const int* __restrict__ sPtr = reinterpret_cast<const int*>(sDynM) + A.c_total;
-  const int* __restrict__ sRowM = sPtr + A.n_multi + 1;
-  if constexpr (MLDS) {
-    for (int e = l; e < A.c_total; e += NT) sDynM[e] = A.c_pack[e];
-    for (int e = l; e <= A.n_multi; e += NT) sDynM[A.c_total + e] = (uint32_t)A.c_ptr[e];
-    for (int e = l; e < A.n_multi; e += NT) sDynM[A.c_total + A.n_multi + 1 + e] = (uint32_t)A.multi_rows[e];
     __syncthreads();
   }
   std::conditional_t<(NDICT > 0), RowRegsPacked<N0, NT>, RowRegs<N0, NT>> R0;
@@ -680,16 +661,14 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     // store queue to drain -- the multi-term phase was 5 us of a 15 us chunk) and used after it.
     constexpr bool PE = NDICT > 0 && MROW && MPX_FUSE_PACKED_EARLY && !MPX_FUSE_MULTI_EARLY;
     uint32_t epk[PE ? RM : 1][PE ? (MT > 0 ? MT : 1) : 1];
-    if constexpr (PE && !MLDS) {
-      {
-        int le = l;
-        asm volatile("" : "+v"(le));  // (opaque per chunk: the table addresses are recomputed, not hoisted into registers)
+    if constexpr (PE) {
+      int le = l;
+      asm volatile("" : "+v"(le));  // (opaque per chunk: the table addresses are recomputed, not hoisted into registers)
 #pragma unroll
-        for (int r = 0; r < RM; ++r) {
-          const int m = r * NT + le, mm = m < A.n_multi ? m : 0;
+      for (int r = 0; r < RM; ++r) {
+        const int m = r * NT + le, mm = m < A.n_multi ? m : 0;
 #pragma unroll
-          for (int t = 0; t < MT; ++t) epk[r][t] = A.m_pack[(int64_t)t * A.n_multi + mm];
-        }
+        for (int t = 0; t < MT; ++t) epk[r][t] = A.m_pack[(int64_t)t * A.n_multi + mm];
       }
     }
     // ---- rows with one term: registers -> LDS read -> store ----
@@ -728,26 +707,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     }
     for (int m = A.n_multi; m < A.n_multi; m += NT) {
 #else
-    if constexpr (MLDS) {  // table entries, term counts and row numbers from LDS: same terms, same order, same fma chains
-      if constexpr (NDICT > 0) {
-        for (int m = l; m < A.n_multi; m += NT) {
-          const int e0 = sPtr[m], nt = sPtr[m + 1] - e0, row = sRowM[m];
-          uint32_t e[MT > 0 ? MT : 1];
-#pragma unroll
-          for (int t = 0; t < MT; ++t) e[t] = sEnt[e0 + (t < nt ? t : 0)];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (u >= nu) break;
-            double sm = 0;
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-              if (t < nt) sm = fma(sDict[e[t] >> 16], V[u][e[t] & 0xffffu], sm);
-            double* o = out_of(row, b0 + u);
-            if (o) *o = sm;
-          }
-        }
-      }
-    } else if constexpr (PE) {
+    if constexpr (PE) {
 #pragma unroll
       for (int r = 0; r < RM; ++r)
         if (mnt_[r] > 0) {
@@ -765,7 +725,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
     }
     int lm = l;
     asm volatile("" : "+v"(lm));  // (opaque per chunk: else the 2 MT table addresses of every round are hoisted out of the chunk loop -- registers)
-    for (int m = (PE || MLDS) ? A.n_multi : lm, r_ = 0; m < A.n_multi; m += NT, ++r_) {
+    for (int m = PE ? A.n_multi : lm, r_ = 0; m < A.n_multi; m += NT, ++r_) {
 #endif
       // (row and term count of the lane's r_-th multi-term row: registers for the life of the workgroup where the row count is a
       // compile-time constant -- two dependent loads per round less)
@@ -778,46 +738,28 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
       } else {
         row = A.multi_rows[m], nt = A.r_nt[row];
       }
-      // The multi-term rows are ordered by term count (host: upload_fused), so the 64 rows of a wavefront's round are about equally
-      // long: the table loads and the fma slots run to the LONGEST row of the block (MpxFusedArgs::m_wmax, a scalar load) instead of the
-      // pass-wide ELL width -- 35 % of the term slots of the moon-lander hess_l pass were padding (5908 terms in 824 rows of width 11),
-      // and this pass is bound by instruction issue (profiles/r5_adaptive_hess).  One straight-line variant per bound (the loads of a
-      // round stay in ONE basic block, all in flight together); every row keeps its terms, their order and its fma chain.
-      auto rows_body = [&](auto WMc) {
-        constexpr int WM = decltype(WMc)::value;
-        int ix[WM > 0 ? WM : 1];
-        double cf[WM > 0 ? WM : 1];
-        if constexpr (NDICT > 0) {
+      int ix[MT > 0 ? MT : 1];
+      double cf[MT > 0 ? MT : 1];
+      if constexpr (NDICT > 0) {
 #pragma unroll
-          for (int t = 0; t < WM; ++t) {
-            const uint32_t e = A.m_pack[(int64_t)t * A.n_multi + m];
-            ix[t] = (int)(e & 0xffffu), cf[t] = sDict[e >> 16];
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < WM; ++t) ix[t] = A.m_idx[(int64_t)t * A.n_multi + m], cf[t] = A.m_coef[(int64_t)t * A.n_multi + m];
+        for (int t = 0; t < MT; ++t) {
+          const uint32_t e = A.m_pack[(int64_t)t * A.n_multi + m];
+          ix[t] = (int)(e & 0xffffu), cf[t] = sDict[e >> 16];
         }
+      } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (u >= nu) break;
-          double s = 0;
+        for (int t = 0; t < MT; ++t) ix[t] = A.m_idx[(int64_t)t * A.n_multi + m], cf[t] = A.m_coef[(int64_t)t * A.n_multi + m];
+      }
 #pragma unroll
-          for (int t = 0; t < WM; ++t)
-            if (t < nt) s = fma(cf[t], V[u][ix[t]], s);
-          double* o = out_of(row, b0 + u);
-          if (o) *o = s;
-        }
-      };
-#if MPX_FUSE_WMAX
-      const int wm = A.m_wmax ? A.m_wmax[r_ * NW + wave] : MT;  // (wave is uniform: a scalar load)
-      bool done_ = false;
-      static_for<2, MT>([&](auto K) {
-        if (!done_ && wm <= decltype(K)::value) rows_body(K), done_ = true;
-      });
-      if (!done_) rows_body(std::integral_constant<int, MT>{});
-#else
-      rows_body(std::integral_constant<int, MT>{});
-#endif
+      for (int u = 0; u < U; ++u) {
+        if (u >= nu) break;
+        double s = 0;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          if (t < nt) s = fma(cf[t], V[u][ix[t]], s);
+        double* o = out_of(row, b0 + u);
+        if (o) *o = s;
+      }
     }
     MPX_FUSE_STAMP(5);
     MPX_FUSE_STAMP(6);
@@ -893,15 +835,12 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 #define MPX_FUSE_MAX_ROWS_PER_LANE 48
 #endif
 #define MPX_FUSE_CEIL(n) (((n) + MPX_FUSE_NT - 1) / MPX_FUSE_NT)
-#ifndef MPX_FUSE_MAX_U_HES  // (the Hessian pass writes little per point: more points per chunk spread its point tasks better over the wavefronts)
-#define MPX_FUSE_MAX_U_HES MPX_FUSE_MAX_U
-#endif
-#define MPX_FUSE_U_FOR(RAWN, ROWS, MAXU) ((ROWS) > MPX_FUSE_MAX_ROWS_PER_LANE ? 0 : ((int)(MPX_FUSE_LDS_BYTES / (8 * ((RAWN) + MPX_FUSE_NZ + 1))) > (MAXU) ? (MAXU) : (int)(MPX_FUSE_LDS_BYTES / (8 * ((RAWN) + MPX_FUSE_NZ + 1)))))
+#define MPX_FUSE_U_FOR(RAWN, ROWS) ((ROWS) > MPX_FUSE_MAX_ROWS_PER_LANE ? 0 : ((int)(MPX_FUSE_LDS_BYTES / (8 * ((RAWN) + MPX_FUSE_NZ + 1))) > MPX_FUSE_MAX_U ? MPX_FUSE_MAX_U : (int)(MPX_FUSE_LDS_BYTES / (8 * ((RAWN) + MPX_FUSE_NZ + 1)))))
 #ifndef MPX_FUSE_U_FGJ
-#define MPX_FUSE_U_FGJ MPX_FUSE_U_FOR(MPX_FUSE_RAW_N, 1 + MPX_FUSE_CEIL(MPX_FUSE_NG) + MPX_FUSE_CEIL(MPX_FUSE_NZ) + MPX_FUSE_CEIL(MPX_FUSE_NNZJ), MPX_FUSE_MAX_U)
+#define MPX_FUSE_U_FGJ MPX_FUSE_U_FOR(MPX_FUSE_RAW_N, 1 + MPX_FUSE_CEIL(MPX_FUSE_NG) + MPX_FUSE_CEIL(MPX_FUSE_NZ) + MPX_FUSE_CEIL(MPX_FUSE_NNZJ))
 #endif
 #ifndef MPX_FUSE_U_HES
-#define MPX_FUSE_U_HES MPX_FUSE_U_FOR(MPX_FUSE_RAWH_N, MPX_FUSE_CEIL(MPX_FUSE_NNZH), MPX_FUSE_MAX_U_HES)
+#define MPX_FUSE_U_HES MPX_FUSE_U_FOR(MPX_FUSE_RAWH_N, MPX_FUSE_CEIL(MPX_FUSE_NNZH))
 #endif
 
 // Long-row tables in registers when a wavefront's share is at most 16 (position, coefficient) pairs per lane.
@@ -924,54 +863,28 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 #endif
 #define MPX_FUSE_PACK(N) ((N) > 0 && (N) <= MPX_FUSE_DICT_MAX ? (N) : 0)
 
-// Compact table of the multi-term rows in LDS (fused_body: MLDS): packed tables, and static (V, the three dictionaries, ~8.5 KB of set
-// descriptors) + dynamic LDS of the workgroup within 78 KB so that two workgroups still share a compute unit (160 KB).  MPX_FUSE_CTOT_* = all terms of the pass's multi-term rows
-// (generated source).  OFF by default -- a negative result of round 5 (profiles/r5_adaptive_hess/README.md): built because the
-// stamps put the multi-term phase of mpx_asm_hes at 2.8 of 5.5 us per chunk, and measured SLOWER in process (hess_l 31.8 -> 34.9 us,
-// first-order pass 57.1 -> 59.1 us, bit-identical): the counters say these kernels are bound by instruction ISSUE (every wavefront
-// 23 % active, four per SIMD: 91 % of the issue slots), not by the table's round trips, and the LDS copy adds three LDS reads per
-// row to an instruction stream that was the limit already.  -DMPX_FUSE_MULTI_LDS=1 builds it (the host follows mpx_fuse_info).
-#ifndef MPX_FUSE_MULTI_LDS
-#define MPX_FUSE_MULTI_LDS 0
-#endif
-#ifndef MPX_FUSE_CTOT_FGJ
-#define MPX_FUSE_CTOT_FGJ 0
-#endif
-#ifndef MPX_FUSE_CTOT_HES
-#define MPX_FUSE_CTOT_HES 0
-#endif
-#define MPX_FUSE_MLDS_BYTES(CTOT, NMULTI) (((CTOT) + 2 * (NMULTI) + 2) * 4)
-#define MPX_FUSE_MLDS_OK(U, RAWN, CTOT, NMULTI, NDICT)                                                              \
-  (MPX_FUSE_MULTI_LDS && MPX_FUSE_PACK(NDICT) > 0 && (CTOT) > 0 && (U) > 0 &&                                      \
-   (U) * ((RAWN) + MPX_FUSE_NZ + 1) * 8 + 8704 + 8 * (MPX_FUSE_NLD + MPX_FUSE_NMD + MPX_FUSE_PACK(NDICT)) + MPX_FUSE_MLDS_BYTES(CTOT, NMULTI) <= 78 * 1024)
-#define MPX_FUSE_MLDS_FGJ MPX_FUSE_MLDS_OK(MPX_FUSE_U_FGJ, MPX_FUSE_RAW_N, MPX_FUSE_CTOT_FGJ, MPX_FUSE_NMULTI_FGJ, MPX_FUSE_NDICT_FGJ)
-#define MPX_FUSE_MLDS_HES MPX_FUSE_MLDS_OK(MPX_FUSE_U_HES, MPX_FUSE_RAWH_N, MPX_FUSE_CTOT_HES, MPX_FUSE_NMULTI_HES, MPX_FUSE_NDICT_HES)
-
 // mpx_fuse_info = {lanes per workgroup, U of the first-order kernels, U of the Hessian kernel, ELL width of the multi-term rows
 // of the first-order pass, of the Hessian pass, dictionary capacity of the packed single-term rows of the two passes (0: unpacked)}
 // (U == 0: that kernel does not exist: one evaluation point does not fit the budgets); the host reads it from the code object.
-// [9], [10] (round 5): dynamic LDS bytes the first-order / Hessian kernels expect for the compact multi-row table (0: none).
 #define MPX_INSTANTIATE_FUSED(NF)                                                                                              \
-  extern "C" __device__ __attribute__((used)) const int mpx_fuse_info[11] = {MPX_FUSE_NT, MPX_FUSE_U_FGJ, MPX_FUSE_U_HES,      \
+  extern "C" __device__ __attribute__((used)) const int mpx_fuse_info[9] = {MPX_FUSE_NT, MPX_FUSE_U_FGJ, MPX_FUSE_U_HES,       \
                                                                               MPX_FUSE_MT_FGJ, MPX_FUSE_MT_HES,                \
-                                                                              MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_HES), MPX_FUSE_NLD, MPX_FUSE_NMD, \
-                                                                              MPX_FUSE_MLDS_FGJ ? MPX_FUSE_MLDS_BYTES(MPX_FUSE_CTOT_FGJ, MPX_FUSE_NMULTI_FGJ) : 0, \
-                                                                              MPX_FUSE_MLDS_HES ? MPX_FUSE_MLDS_BYTES(MPX_FUSE_CTOT_HES, MPX_FUSE_NMULTI_HES) : 0}; \
+                                                                              MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_HES), MPX_FUSE_NLD, MPX_FUSE_NMD}; \
   extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_fg(const MpxFusedArgs A) {                                \
     if constexpr (MPX_FUSE_U_FGJ > 0)                                                                                          \
       mpxk::fused_body<MPX_MODE_FG, NF, MPX_FUSE_NT, (MPX_FUSE_U_FGJ > 0 ? MPX_FUSE_U_FGJ : 1), MPX_FUSE_RAW_N, MPX_FUSE_NZ, 1, \
                        MPX_FUSE_NG, MPX_FUSE_NZ, MPX_FUSE_NNZJ, MPX_FUSE_MT_FGJ, MPX_FUSE_CEIL(MPX_FUSE_NMULTI_FGJ), MPX_FUSE_RL_OK(MPX_FUSE_NLONG_FGJ, MPX_FUSE_LT_FGJ), \
-                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ), MPX_FUSE_MLDS_FGJ>(A);                 \
+                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ)>(A);                                    \
   }                                                                                                                            \
   extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_fgj(const MpxFusedArgs A) {                               \
     if constexpr (MPX_FUSE_U_FGJ > 0)                                                                                          \
       mpxk::fused_body<MPX_MODE_FGJ, NF, MPX_FUSE_NT, (MPX_FUSE_U_FGJ > 0 ? MPX_FUSE_U_FGJ : 1), MPX_FUSE_RAW_N, MPX_FUSE_NZ, 1, \
                        MPX_FUSE_NG, MPX_FUSE_NZ, MPX_FUSE_NNZJ, MPX_FUSE_MT_FGJ, MPX_FUSE_CEIL(MPX_FUSE_NMULTI_FGJ), MPX_FUSE_RL_OK(MPX_FUSE_NLONG_FGJ, MPX_FUSE_LT_FGJ), \
-                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ), MPX_FUSE_MLDS_FGJ>(A);                 \
+                       MPX_FUSE_TL(MPX_FUSE_LT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ)>(A);                                    \
   }                                                                                                                            \
   extern "C" __global__ __launch_bounds__(MPX_FUSE_NT, MPX_FUSE_MIN_WAVES) void mpx_asm_hes(const MpxFusedArgs A) {                               \
     if constexpr (MPX_FUSE_U_HES > 0)                                                                                          \
       mpxk::fused_body<MPX_MODE_HESS, NF, MPX_FUSE_NT, (MPX_FUSE_U_HES > 0 ? MPX_FUSE_U_HES : 1), MPX_FUSE_RAWH_N, MPX_FUSE_NZ, \
                        MPX_FUSE_NNZH, 0, 0, 0, MPX_FUSE_MT_HES, MPX_FUSE_CEIL(MPX_FUSE_NMULTI_HES), MPX_FUSE_RL_OK(MPX_FUSE_NLONG_HES, MPX_FUSE_LT_HES),          \
-                       MPX_FUSE_TL(MPX_FUSE_LT_HES), MPX_FUSE_PACK(MPX_FUSE_NDICT_HES), MPX_FUSE_MLDS_HES>(A);                 \
+                       MPX_FUSE_TL(MPX_FUSE_LT_HES), MPX_FUSE_PACK(MPX_FUSE_NDICT_HES)>(A);                                    \
   }

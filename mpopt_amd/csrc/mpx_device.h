@@ -404,8 +404,7 @@ struct MpxFusedArgs {
   const double* m_coef;
   const int32_t* mid_rows;    // rows with MT + 1 .. MPX_GATHER_LONG terms
   const int32_t* long_rows;   // rows with more
-  int32_t n_multi, n_mid, n_long;
-  int32_t multi_lds;          // != 0: the launch carries dynamic LDS for the compact table of the multi-term rows (c_pack / c_ptr below)
+  int32_t n_multi, n_mid, n_long, pad_;
   double* out[4];
   int64_t out_stride[4];
   long long* dbg;  // MPX_FUSE_DEBUG: phase stamps of one workgroup (wall_clock64, 100 MHz), else NULL
@@ -427,14 +426,6 @@ struct MpxFusedArgs {
   const double* r_dict;
   int32_t n_dict, pad3_;
   const uint32_t* m_pack;  // [t][n_multi] ELL table of the multi-term rows, packed with the same dictionary
-  // the same terms row after row (round 5): entries c_ptr[m] .. c_ptr[m + 1] of c_pack are the terms of multi-term row m in stored
-  // order.  Small enough (config "moon lander 20x5 adaptive": 824 rows of hess_l, ~2500 terms = 10 KB against 36 KB padded) for a
-  // workgroup to keep in LDS for its life: the rows phase of a chunk then reads no table from memory at all
-  const uint32_t* c_pack;
-  const int32_t* c_ptr;    // [n_multi + 1]
-  int32_t c_total, pad4_;
-  // multi-term rows are ordered by term count, longest first; m_wmax[k] = term count of the longest of rows 64 k .. 64 k + 63
-  const int32_t* m_wmax;
   const double* l_dict;    // dictionaries of MpxPtSet::loc_pack / mu_pack (all sets of the context)
   const double* m_dict;
   int32_t n_ldict, n_mdict;

@@ -10,5 +10,5 @@ for fl in "" "-DMPX_FUSE_PT_STAMPS=1"; do
   MPX_HIPCC_FLAGS="$fl" MPX_FUSE_DEBUG=1 MPX_FUSE_PT_STAMPS=1 timeout 300 python bench.py --workload adaptive-hess --no-cpu-baseline --no-extras --steps 3 --warmup 1 --ramp-seconds 0.1 2>&1 | grep -A1 "fused mode 2" | tail -4 >> $out/stamps.txt
 done
 bash tools/r5_counters.sh $out/counters mpx_asm_hes --workload adaptive-hess > $out/counters.log 2>&1
-timeout 900 python tools/r4_adaptive_ab.py "" "-DMPX_FUSE_MROW_HES=1" "-DMPX_FUSE_MAX_U_HES=3" "-DMPX_FUSE_MAX_U_HES=3 -DMPX_FUSE_MROW_HES=1" "-DMPX_FUSE_MIN_WAVES=2 -DMPX_FUSE_MROW_HES=1" ${EXTRA_AB:-} 2>&1 | grep "^hess\|^fgj" > $out/ab.txt
+timeout 900 python tools/r4_adaptive_ab.py "" "-DMPX_FUSE_MROW_HES=1" "-DMPX_FUSE_MIN_WAVES=2 -DMPX_FUSE_MROW_HES=1" ${EXTRA_AB:-} 2>&1 | grep "^hess\|^fgj" > $out/ab.txt
 cat $out/stamps.txt $out/ab.txt
