@@ -197,7 +197,11 @@ int mpx_eval(mpx_ctx* ctx, int what_mask, int64_t batch, const double* z, const 
              const double* lam_g, const double* sigma, double* f, double* g, double* grad_f, double* jac_val,
              double* hess_val);
 /* Device-pointer variant: same arguments, all pointers are device pointers, asynchronous on the
- * context's stream, nothing is copied.  This is the throughput path (inputs resident in HBM). */
+ * context's stream, nothing is copied.  This is the throughput path (inputs resident in HBM).
+ * Launches per pass: one node launch per (phase, degree) bucket + the boundary pass (+ the prefix sums of the widths for problems
+ * whose functions use time); on single-degree grids with several phases ALL phases share one node launch (the reference's phase
+ * loop, mpopt.py:600-627, as a dimension of the grid; same results bit for bit -- MPX_NO_PHASE_MERGE=1 in the environment, read per
+ * call, restores one launch per phase). */
 int mpx_eval_device(mpx_ctx* ctx, int what_mask, int64_t batch, const double* z, const double* p, int p_per_point,
                     const double* lam_g, const double* sigma, double* f, double* g, double* grad_f,
                     double* jac_val, double* hess_val);

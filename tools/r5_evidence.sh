@@ -27,5 +27,7 @@ done
 timeout 900 bash tools/r3_loop_profile.sh r5_final/config5_loop > $o/config5_loop.log 2>&1
 for b in 2048 4096; do timeout 300 python bench.py --workload config5-loop --no-cpu-baseline --no-extras --batch $b 2>/dev/null | tail -1 > $o/bench_line_config5-loop_B$b.json; done
 MPX_DIST_BACKEND=gloo timeout 500 python bench.py --gpus 2 --steps 20 --warmup 5 --batch 1024 2>/dev/null | tail -1 > $o/bench_line_2ranks_gloo_self_launched.json
-find $o -name '*.log' -size +200k -delete
+( time timeout 900 python bench.py > $o/bench_line_default.json 2> $o/bench_default.err ) 2> $o/bench_default_time.txt
+timeout 1200 python -m pytest tests -m gpu -x -q > $o/gpu_tests_full_suite.log 2>&1
+find $o -name '*.log' -size +200k ! -name 'gpu_tests_full_suite.log' -delete
 ls $o | head -80
