@@ -191,7 +191,7 @@ class AssembledNlpFunctions(NlpFunctions):
             v = np.concatenate([np.ascontiguousarray(a, dtype=np.float64).ravel() for a in arrs]) if arrs else np.zeros(0)
             return len(np.unique(v.view(np.int64))) if len(v) else 0
 
-        sizes["NDICT_LOC"] = _ndistinct([e[0][2] for e in self._ell]) if self.n_z_ + 1 < 8192 else 0  # (byte offsets in 16 bits, libmpx: lok)
+        sizes["NDICT_LOC"] = _ndistinct([e[0][2] for e in self._ell]) if self.n_z_ + 1 < 65536 else 0
         sizes["NDICT_MU"] = _ndistinct([e[1][2] for e in self._ell]) if self.n_g_ + 1 < 65536 else 0
         for tag, (ptr, _, _) in (("FGJ", self.fgj), ("HES", self.hess)):  # shape of the multi-term and long rows of each pass
             nt = np.diff(ptr)

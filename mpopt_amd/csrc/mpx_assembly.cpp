@@ -54,7 +54,6 @@ struct DevFused {
 struct mpx_asm_state {
   DevFused ffgj, fhess;
   hipFunction_t fn_fused[3] = {nullptr, nullptr, nullptr};
-  uint32_t pack_scale = 1;              // 8: the packed table entries carry byte offsets (code objects since round 5: mpx_fuse_byte_offsets), 1: indices
   int fuse_nt = 0, fuse_u[2] = {0, 0};  // lanes per workgroup; evaluation points per workgroup pass (first order, Hessian); 0: no kernel
   int fuse_wg[3] = {0, 0, 0};           // resident workgroups per launch (compute units x occupancy)
   long long* dbg = nullptr;             // MPX_FUSE_DEBUG
@@ -224,7 +223,7 @@ int upload_gather(mpx_ctx* c, DevGather& d, const mpx_gather& g, int64_t raw_n, 
   return upload_n(c, &d.coef, g.coef, (size_t)d.nnz);
 }
 
-int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, int64_t n_z, int mt, uint32_t sc) {
+int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, int64_t n_z, int mt) {
   const int64_t nnz = g.n_rows ? g.ptr[g.n_rows] : 0;
   std::vector<int32_t> r_idx((size_t)std::max<int64_t>(g.n_rows, 1), 0), r_nt((size_t)std::max<int64_t>(g.n_rows, 1), 0), idx((size_t)std::max<int64_t>(nnz, 1), 0), multi, mid, longr;
   std::vector<double> r_coef((size_t)std::max<int64_t>(g.n_rows, 1), 0.0);
@@ -250,23 +249,23 @@ int upload_fused(mpx_ctx* c, DevFused& f, const mpx_gather& g, int64_t raw_n, in
   std::vector<double> r_dict;
   {
     std::map<uint64_t, uint32_t> code_of;
-    bool ok = (raw_n + n_z + 1) * sc < 65536;  // (sc = 8: byte offsets in 16 bits -- position * 8 and code * 8, mpx_assembly_fused.h: fuse_at; 1: indices)
+    bool ok = raw_n + n_z + 1 <= 65536;
     auto code = [&](double v) -> uint32_t {
       uint64_t bits;
       memcpy(&bits, &v, 8);
       auto it = code_of.find(bits);
       if (it == code_of.end()) {
-        ok = ok && (r_dict.size() + 1) * sc < 65536;
+        ok = ok && r_dict.size() < 65535;
         it = code_of.emplace(bits, (uint32_t)r_dict.size()).first;
         r_dict.push_back(v);
       }
       return it->second;
     };
     for (int64_t r = 0; r < g.n_rows && ok; ++r)
-      if (r_nt[(size_t)r] <= 1) r_pack[(size_t)r] = ((uint32_t)r_idx[(size_t)r] * sc) | ((code(r_coef[(size_t)r]) * sc) << 16);
+      if (r_nt[(size_t)r] <= 1) r_pack[(size_t)r] = (uint32_t)r_idx[(size_t)r] | (code(r_coef[(size_t)r]) << 16);
     for (int32_t m = 0; m < f.n_multi && ok; ++m)
       for (int64_t e = g.ptr[multi[m]], t = 0; e < g.ptr[multi[m] + 1]; ++e, ++t)
-        m_pack[(size_t)(t * f.n_multi + m)] = ((uint32_t)idx[(size_t)e] * sc) | ((code(g.coef[e]) * sc) << 16);
+        m_pack[(size_t)(t * f.n_multi + m)] = (uint32_t)idx[(size_t)e] | (code(g.coef[e]) << 16);
     f.n_dict = ok ? (int32_t)r_dict.size() : 0;
   }
   int rc;
@@ -379,27 +378,16 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
     a->raw_n += (int64_t)d.n * (d.n_out + d.n_jac);
     a->rawh_n += (int64_t)d.n * d.n_hess;
   }
-  {  // what the code object's fused kernels expect in the packed tables: byte offsets (round 5) or indices
-    hipDeviceptr_t sym = nullptr;
-    size_t bytes = 0;
-    int v = 0;
-    if (c->module && hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_fuse_byte_offsets") == hipSuccess && bytes == sizeof(int) &&
-        hipMemcpyDtoH(&v, sym, sizeof(int)) == hipSuccess && v == 1)
-      a->pack_scale = 8;
-    (void)hipGetLastError();
-  }
   {  // packed copies of the local-variable and multiplier tables of every set (index | code << 16) with context-wide dictionaries
     std::vector<double> ldict, mdict;
     std::map<uint64_t, uint32_t> lcode, mcode;
-    const uint32_t sc = a->pack_scale;
-    // (local variables: z index * sc | code * sc << 16; multipliers: index | code * sc << 16 -- their low half addresses lam_g in memory)
-    bool lok = (D->n_z + 1) * (int64_t)sc < 65536, mok = D->n_g + 1 < 65536;
-    auto code = [sc](std::map<uint64_t, uint32_t>& m, std::vector<double>& dict, double v, bool& ok) -> uint32_t {
+    bool lok = D->n_z + 1 < 65536, mok = D->n_g + 1 < 65536;
+    auto code = [](std::map<uint64_t, uint32_t>& m, std::vector<double>& dict, double v, bool& ok) -> uint32_t {
       uint64_t bits;
       memcpy(&bits, &v, 8);
       auto it = m.find(bits);
       if (it == m.end()) {
-        ok = ok && (dict.size() + 1) * sc < 65536;
+        ok = ok && dict.size() < 65535;
         it = m.emplace(bits, (uint32_t)dict.size()).first;
         dict.push_back(v);
       }
@@ -412,8 +400,8 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
       for (int v = 0; v < S.n_loc; ++v) lt += S.loc_nterm[v];
       for (int r = 0; r < S.n_out; ++r) mt_ += S.mu_nterm[r];
       std::vector<uint32_t> lp((size_t)std::max<int64_t>(lt * S.n_points, 1), 0u), mp((size_t)std::max<int64_t>(mt_ * S.n_points, 1), 0u);
-      for (int64_t e = 0; e < lt * S.n_points; ++e) lp[(size_t)e] = ((uint32_t)S.loc_idx[e] * sc) | ((code(lcode, ldict, S.loc_coef[e], lok) * sc) << 16);
-      for (int64_t e = 0; e < mt_ * S.n_points; ++e) mp[(size_t)e] = (uint32_t)S.mu_idx[e] | ((code(mcode, mdict, S.mu_coef[e], mok) * sc) << 16);
+      for (int64_t e = 0; e < lt * S.n_points; ++e) lp[(size_t)e] = (uint32_t)S.loc_idx[e] | (code(lcode, ldict, S.loc_coef[e], lok) << 16);
+      for (int64_t e = 0; e < mt_ * S.n_points; ++e) mp[(size_t)e] = (uint32_t)S.mu_idx[e] | (code(mcode, mdict, S.mu_coef[e], mok) << 16);
       if ((rc = upload(c, &a->d_loc_pack[k], lp)) || (rc = upload(c, &a->d_mu_pack[k], mp))) return bail(rc);
       hs[k].loc_pack = a->d_loc_pack[k], hs[k].mu_pack = a->d_mu_pack[k];
     }
@@ -519,7 +507,7 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
       for (auto& d : a->sets) ok = ok && d.n_loc < 48 && d.n_out < 48;  // (LDS copies of the offset arrays in the fused kernels)
       ok = ok && a->sets.size() <= 16;
       if (ok && (info[1] > 0 || info[2] > 0)) {
-        if ((rc = upload_fused(c, a->ffgj, D->fgj, a->raw_n, D->n_z, thr_fgj, a->pack_scale)) || (rc = upload_fused(c, a->fhess, D->hess, a->rawh_n, D->n_z, thr_hes, a->pack_scale))) return bail(rc);
+        if ((rc = upload_fused(c, a->ffgj, D->fgj, a->raw_n, D->n_z, thr_fgj)) || (rc = upload_fused(c, a->fhess, D->hess, a->rawh_n, D->n_z, thr_hes))) return bail(rc);
         if ((info[7] > 0 && (a->n_ldict < 1 || a->n_ldict > info[7])) || (info[8] > 0 && (a->n_mdict < 1 || a->n_mdict > info[8])))
           return bail(fail(c, MPX_ERR_INVALID, "fused kernels: dictionaries of the packed local-variable / multiplier tables (%d / %d entries) do not fit the compiled capacity (%d / %d)",
                            a->n_ldict, a->n_mdict, info[7], info[8]));

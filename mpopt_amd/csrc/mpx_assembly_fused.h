@@ -84,20 +84,6 @@ namespace mpxk {
 #define MPX_FUSE_PAIR_ROWS 0  // (measured 6 % slower at moon lander 20x5, tools/r4_adaptive_ab.py: 60.2 against 56.8 us)
 #endif
 typedef double mpx_d2u __attribute__((ext_vector_type(2), aligned(8)));
-// Packed table entries carry BYTE offsets (round 5): position * 8 in the low half, dictionary code * 8 in the high half, so that a
-// term is decoded with one v_and and one v_lshrrev and read through the immediate offset of ds_read_b64 -- two shifts per term less
-// in kernels that are bound by instruction issue (profiles/r5_adaptive_hess).  (The multiplier tables keep their low half an index:
-// it addresses lam_g in global memory.)
-#ifndef MPX_FUSE_BYTE_OFFSETS
-#define MPX_FUSE_BYTE_OFFSETS 1  // 0: indices in the packed entries (round 4; A/B -- libmpx packs what the code object's mpx_fuse_byte_offsets says)
-#endif
-__device__ __forceinline__ double fuse_at(const double* __restrict__ base, uint32_t off) {
-#if MPX_FUSE_BYTE_OFFSETS
-  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off);
-#else
-  return base[off];
-#endif
-}
 // Row <-> (register k, lane l).  Paired (MPX_FUSE_PAIR_ROWS=1): registers 2j, 2j + 1 of lane l hold the ADJACENT rows 2 (j NT + l), + 1, so that the
 // two values leave as one 16-byte store (a wavefront's store instruction then writes a 1 KB run); an odd last register holds row
 // (K - 1) NT + l.  Unpaired (default): row k NT + l.
@@ -150,7 +136,7 @@ struct RowRegsPacked {
 #pragma unroll
     for (int k = 0; k < KP; k += 2) {
       const bool ha = pk[k] != 0xffffffffu, hb = pk[k + 1] != 0xffffffffu;
-      const double a = ha ? fma(fuse_at(dict, pk[k] >> 16), fuse_at(V, pk[k] & 0xffffu), 0.0) : 0.0, b = hb ? fma(fuse_at(dict, pk[k + 1] >> 16), fuse_at(V, pk[k + 1] & 0xffffu), 0.0) : 0.0;
+      const double a = ha ? fma(dict[pk[k] >> 16], V[pk[k] & 0xffffu], 0.0) : 0.0, b = hb ? fma(dict[pk[k + 1] >> 16], V[pk[k + 1] & 0xffffu], 0.0) : 0.0;
       double* __restrict__ o = out + fused_row_of<K, NT>(k, l);
       if (ha && hb) *(mpx_d2u*)o = mpx_d2u{a, b};
       else if (ha) o[0] = a;
@@ -158,7 +144,7 @@ struct RowRegsPacked {
     }
 #pragma unroll
     for (int k = KP; k < K; ++k)
-      if (pk[k] != 0xffffffffu) out[fused_row_of<K, NT>(k, l)] = fma(fuse_at(dict, pk[k] >> 16), fuse_at(V, pk[k] & 0xffffu), 0.0);
+      if (pk[k] != 0xffffffffu) out[fused_row_of<K, NT>(k, l)] = fma(dict[pk[k] >> 16], V[pk[k] & 0xffffu], 0.0);
   }
 };
 
@@ -232,9 +218,9 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
       for (int u = 0; u < U; ++u) acc[u] = 0.0;
       static_for<ta, tb>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        const double cq = fuse_at(ldict, e[t] >> 16);
+        const double cq = ldict[e[t] >> 16];
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = fma(cq, fuse_at(&V[u][RAWN], e[t] & 0xffffu), acc[u]);  // (first term: fma(c, v, 0.0) as in the two-pass kernels)
+        for (int u = 0; u < U; ++u) acc[u] = fma(cq, V[u][RAWN + (int)(e[t] & 0xffffu)], acc[u]);  // (first term: fma(c, v, 0.0) as in the two-pass kernels)
       });
 #pragma unroll
       for (int u = 0; u < U; ++u) loc[u][v] = acc[u];
@@ -258,9 +244,9 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
       }
       const int t1 = ltoff[v + 1];
       {
-        const double c0 = fuse_at(ldict, e0[v] >> 16);
+        const double c0 = ldict[e0[v] >> 16];
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = ltoff[v] < t1 ? fma(c0, fuse_at(&V[u][RAWN], e0[v] & 0xffffu), 0.0) : 0.0;
+        for (int u = 0; u < U; ++u) acc[u] = ltoff[v] < t1 ? fma(c0, V[u][RAWN + (int)(e0[v] & 0xffffu)], 0.0) : 0.0;
       }
       for (int t = ltoff[v] + 1; t < t1; t += MPX_FUSE_LOC_GP) {
         uint32_t pe[MPX_FUSE_LOC_GP];
@@ -269,9 +255,9 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
 #pragma unroll
         for (int q = 0; q < MPX_FUSE_LOC_GP; ++q)
           if (t + q < t1) {
-            const double cq = fuse_at(ldict, pe[q] >> 16);
+            const double cq = ldict[pe[q] >> 16];
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] = fma(cq, fuse_at(&V[u][RAWN], pe[q] & 0xffffu), acc[u]);
+            for (int u = 0; u < U; ++u) acc[u] = fma(cq, V[u][RAWN + (int)(pe[q] & 0xffffu)], acc[u]);
           }
       }
 #pragma unroll
@@ -335,7 +321,7 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
         const int64_t tt = (int64_t)t * n + p;
         if constexpr (NMD > 0) {
           const uint32_t e = S.mu_pack[tt];
-          ix[t] = (int)(e & 0xffffu), cf[t] = fuse_at(mdict, e >> 16);
+          ix[t] = (int)(e & 0xffffu), cf[t] = mdict[e >> 16];
         } else {
           ix[t] = S.mu_idx[tt], cf[t] = S.mu_coef[tt];
         }
@@ -375,7 +361,7 @@ __device__ __forceinline__ void fused_point(const MpxPtSet& S, const int* __rest
           const int64_t tt = (int64_t)(t + q < mtoff[r + 1] ? t + q : mtoff[r + 1] - 1) * n + p;
           if constexpr (NMD > 0) {
             const uint32_t e = S.mu_pack[tt];
-            ix[q] = (int)(e & 0xffffu), cf[q] = fuse_at(mdict, e >> 16);
+            ix[q] = (int)(e & 0xffffu), cf[q] = mdict[e >> 16];
           } else {
             ix[q] = S.mu_idx[tt], cf[q] = S.mu_coef[tt];
           }
@@ -731,7 +717,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
             double sm = 0;
 #pragma unroll
             for (int t = 0; t < MT; ++t)
-              if (t < mnt_[r]) sm = fma(fuse_at(sDict, epk[r][t] >> 16), fuse_at(V[u], epk[r][t] & 0xffffu), sm);
+              if (t < mnt_[r]) sm = fma(sDict[epk[r][t] >> 16], V[u][epk[r][t] & 0xffffu], sm);
             double* o = out_of(mrow_[r], b0 + u);
             if (o) *o = sm;
           }
@@ -758,7 +744,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           const uint32_t e = A.m_pack[(int64_t)t * A.n_multi + m];
-          ix[t] = (int)(e & 0xffffu), cf[t] = fuse_at(sDict, e >> 16);  // (ix: a byte offset into V here)
+          ix[t] = (int)(e & 0xffffu), cf[t] = sDict[e >> 16];
         }
       } else {
 #pragma unroll
@@ -770,7 +756,7 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
         double s = 0;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
-          if (t < nt) s = fma(cf[t], NDICT > 0 ? fuse_at(V[u], (uint32_t)ix[t]) : V[u][ix[t]], s);
+          if (t < nt) s = fma(cf[t], V[u][ix[t]], s);
         double* o = out_of(row, b0 + u);
         if (o) *o = s;
       }
@@ -881,7 +867,6 @@ __device__ __forceinline__ void fused_body(const ::MpxFusedArgs& A) {
 // of the first-order pass, of the Hessian pass, dictionary capacity of the packed single-term rows of the two passes (0: unpacked)}
 // (U == 0: that kernel does not exist: one evaluation point does not fit the budgets); the host reads it from the code object.
 #define MPX_INSTANTIATE_FUSED(NF)                                                                                              \
-  extern "C" __device__ __attribute__((used)) const int mpx_fuse_byte_offsets = MPX_FUSE_BYTE_OFFSETS;                         \
   extern "C" __device__ __attribute__((used)) const int mpx_fuse_info[9] = {MPX_FUSE_NT, MPX_FUSE_U_FGJ, MPX_FUSE_U_HES,       \
                                                                               MPX_FUSE_MT_FGJ, MPX_FUSE_MT_HES,                \
                                                                               MPX_FUSE_PACK(MPX_FUSE_NDICT_FGJ), MPX_FUSE_PACK(MPX_FUSE_NDICT_HES), MPX_FUSE_NLD, MPX_FUSE_NMD}; \
