@@ -271,7 +271,7 @@ def compile_kernels(source, verbose=False):
     Cached on disk under mpopt_amd/_jit_cache keyed by the full text of everything compiled."""
     h = hashlib.sha256()
     h.update(source.encode())
-    for dep in ("mpx_kernels.h", "mpx_assembly_kernels.h", "mpx_assembly_fused.h", "mpx_device.h"):
+    for dep in ("mpx_kernels.h", "mpx_assembly_kernels.h", "mpx_assembly_fused.h", "mpx_assembly_lanes.h", "mpx_device.h"):
         with open(os.path.join(CSRC, dep), "rb") as f:
             h.update(f.read())
     h.update(os.environ.get("MPX_HIPCC_FLAGS", "").encode())

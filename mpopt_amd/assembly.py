@@ -218,7 +218,17 @@ class AssembledNlpFunctions(NlpFunctions):
         # fused kernels (mpx_assembly_fused.h, mpxgen::SetT; the host computes the same offsets from loc_nterm / mu_nterm)
         self._set_consts = [(self.functions.index(s.fn), np.concatenate([[0], np.cumsum(np.asarray(e[0][0], np.int64))]).tolist(),
                              np.concatenate([[0], np.cumsum(np.asarray(e[1][0], np.int64))]).tolist()) for s, e in zip(self.sets, self._ell)]
-        self.source = self._source(funcs, sizes, self._set_consts)
+        # batches of hess_l: lane <-> evaluation point, the tables as straight-line code (assembly_lanes.py; no plan: no useful grouping
+        # of the point tasks, the fused kernels keep the pass).  With a plan the entries of hess_l are ordered group by group.  Same
+        # long-row threshold as libmpx (mpx_assembly.cpp: thr_hes).  MPX_NO_LANES_CODE=1: contexts without it (A/B, tests).
+        from . import assembly_lanes
+        import os
+        self.lanes_plan = None if os.environ.get("MPX_NO_LANES_CODE") else assembly_lanes.plan_hess(self)
+        lanes_src = None
+        if self.lanes_plan is not None:
+            assembly_lanes.group_major(self, self.lanes_plan)
+            lanes_src = assembly_lanes.hess_source(self, sizes["MT_HES"] if sizes["MT_HES"] >= 2 else 24, self.lanes_plan)
+        self.source = self._source(funcs, sizes, self._set_consts, extra=lanes_src)
         if with_device is None:
             with_device = _lib.gpu_available()
         self.code_object = None
@@ -228,7 +238,7 @@ class AssembledNlpFunctions(NlpFunctions):
 
     # -- generated source ---------------------------------------------------------------------------
     @staticmethod
-    def _source(funcs, sizes, set_consts=()):
+    def _source(funcs, sizes, set_consts=(), extra=None):
         parts = ["// generated by mpopt_amd.assembly -- do not edit", "#include <hip/hip_runtime.h>", "namespace mpxgen {",
                  "template <int FID> struct Pt;"]
         parts += [f.source(k) for k, f in enumerate(funcs)]
@@ -250,6 +260,8 @@ class AssembledNlpFunctions(NlpFunctions):
                              f"  __host__ __device__ static constexpr int mt(int r) {{ constexpr int a[] = {arr(mt)}; return a[r]; }}\n}};")
             parts += ["}  // namespace mpxgen", f"#define MPX_FUSE_SETS {len(set_consts)}"]
         parts += ['#include "mpx_assembly_fused.h"', f"MPX_INSTANTIATE_FUSED({len(funcs)})"]
+        if extra:
+            parts.append(extra)
         return "\n".join(parts) + "\n"
 
     # -- expansion of the chain rule into gather rows -------------------------------------------------

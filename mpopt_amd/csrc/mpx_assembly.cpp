@@ -54,6 +54,8 @@ struct DevFused {
 struct mpx_asm_state {
   DevFused ffgj, fhess;
   hipFunction_t fn_fused[3] = {nullptr, nullptr, nullptr};
+  hipFunction_t fn_lanes = nullptr;  // mpx_asml_hes (mpx_assembly_lanes.h): hess_l of batches, lane <-> evaluation point; NULL: not in the code object
+  int lanes_groups = 0;
   int fuse_nt = 0, fuse_u[2] = {0, 0};  // lanes per workgroup; evaluation points per workgroup pass (first order, Hessian); 0: no kernel
   int fuse_wg[3] = {0, 0, 0};           // resident workgroups per launch (compute units x occupancy)
   long long* dbg = nullptr;             // MPX_FUSE_DEBUG
@@ -558,6 +560,14 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
       }
     }
     (void)hipGetLastError();
+    {  // the lane-per-point Hessian kernel (generated when the point tasks fall into groups: mpopt_amd/assembly_lanes.py)
+      int li[3] = {0, 0, 0};
+      hipFunction_t fl = nullptr;
+      if (hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_asml_info") == hipSuccess && bytes == sizeof li && hipMemcpyDtoH(li, sym, sizeof li) == hipSuccess &&
+          li[0] >= 1 && li[2] == (int)D->nnz_hess && hipModuleGetFunction(&fl, c->module, "mpx_asml_hes") == hipSuccess)
+        a->fn_lanes = fl, a->lanes_groups = li[0];
+    }
+    (void)hipGetLastError();
   }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "hipEventCreate failed"));
   c->has_device = true;
@@ -664,6 +674,28 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
   return MPX_OK;
 }
 
+// Lane-per-evaluation-point Hessian kernel (mpx_assembly_lanes.h): whole blocks of 64 evaluation points, one wavefront per
+// (group of point tasks, block); the groups of a block sit on one XCD.  Bit-identical to the other two paths, so the host picks by
+// batch size; MPX_NO_LANES=1 / MPX_LANES_MIN_BATCH=n (read per call) switch.
+static bool use_lanes(const mpx_asm_state* a, int64_t batch) {
+  if (!a->fn_lanes || getenv("MPX_NO_LANES")) return false;
+  const char* mb = getenv("MPX_LANES_MIN_BATCH");
+  return batch >= std::max<int64_t>(mb ? atoll(mb) : 512, 64);
+}
+
+static int launch_lanes(mpx_ctx* c, int64_t batch, const double* z, const double* lam, const double* sigma, double* hess_val) {
+  const int64_t n_blocks = (batch + 63) / 64;  // (the last block of a ragged batch starts at batch - 64)
+  mpx_asm_state* a = c->assembled;
+  MpxLaneArgs A{};
+  A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma, A.out = hess_val, A.out_stride = c->nnz_h;
+  A.B = (int32_t)batch, A.n_blocks = (int32_t)n_blocks;
+  const unsigned grid = (unsigned)(8 * (int64_t)a->lanes_groups * ((n_blocks + 7) / 8));
+  size_t sz = sizeof(A);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIPCHK(c, hipModuleLaunchKernel(a->fn_lanes, grid, 1, 1, 64, 1, 1, 0, c->stream, nullptr, cfg));
+  return MPX_OK;
+}
+
 // Evaluation points per pass.  The raw point values are written by the point kernels and read back by the gather pass; while a
 // pass's raw values + outputs fit the 256 MB Infinity Cache of an MI355X the read-back does not go to HBM.  Measured
 // (tools/adaptive_batch_sweep.py, moon lander 20x5): f+g+grad_f+jac_g peaks at 2048 points (179 MB per pass: 31 M evals/s) and
@@ -715,27 +747,30 @@ int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, co
     if ((rc = prof_end(c, pe))) return rc;
     if (c->profile) ++c->prof_launches;
   }
-  if ((mask & MPX_HESS) && use_fused(a, MPX_MODE_HESS, batch)) {
-    hipEvent_t pe = nullptr;
+  if (mask & MPX_HESS) {
+    hipEvent_t pe = nullptr;  // (mpx_profile: one bracket per evaluation, counted as one launch)
     if ((rc = prof_begin(c, &pe))) return rc;
-    double* outp[4] = {hess_val, nullptr, nullptr, nullptr};
-    const int64_t stride[4] = {c->nnz_h, 0, 0, 0};
-    if ((rc = launch_fused(c, MPX_MODE_HESS, batch, z, lam_g, sigma, outp, stride))) return rc;
-    if ((rc = prof_end(c, pe))) return rc;
-    if (c->profile) ++c->prof_launches;
-  } else if (mask & MPX_HESS) {
-    const int64_t per = points_per_pass(batch, a->rawh_n + c->n_z + c->n_g + 1 + c->nnz_h);
-    if ((rc = reserve(c, a->raw, (size_t)(per * a->rawh_n)))) return rc;
-    hipEvent_t pe = nullptr;
-    if ((rc = prof_begin(c, &pe))) return rc;
-    for (int64_t b0 = 0; b0 < batch; b0 += per) {
-      const int64_t nb = std::min(per, batch - b0);
-      const double* zb = z + b0 * c->n_z;
-      if ((rc = launch_points(c, MPX_MODE_HESS, nb, zb, lam_g + b0 * c->n_g, sigma + b0))) return rc;
-      const int64_t begin[1] = {0};
-      double* outp[1] = {hess_val + b0 * c->nnz_h};
-      const int64_t stride[1] = {c->nnz_h};
-      if ((rc = launch_gather(c, a->hess, nb, zb, a->rawh_n, 1, begin, outp, stride))) return rc;
+    int64_t done = 0;
+    if (use_lanes(a, batch)) {
+      if ((rc = launch_lanes(c, batch, z, lam_g, sigma, hess_val))) return rc;
+      done = batch;
+    }
+    if (done < batch && use_fused(a, MPX_MODE_HESS, batch - done)) {
+      double* outp[4] = {hess_val + done * c->nnz_h, nullptr, nullptr, nullptr};
+      const int64_t stride[4] = {c->nnz_h, 0, 0, 0};
+      if ((rc = launch_fused(c, MPX_MODE_HESS, batch - done, z + done * c->n_z, lam_g + done * c->n_g, sigma + done, outp, stride))) return rc;
+    } else if (done < batch) {
+      const int64_t per = points_per_pass(batch - done, a->rawh_n + c->n_z + c->n_g + 1 + c->nnz_h);
+      if ((rc = reserve(c, a->raw, (size_t)(per * a->rawh_n)))) return rc;
+      for (int64_t b0 = done; b0 < batch; b0 += per) {
+        const int64_t nb = std::min(per, batch - b0);
+        const double* zb = z + b0 * c->n_z;
+        if ((rc = launch_points(c, MPX_MODE_HESS, nb, zb, lam_g + b0 * c->n_g, sigma + b0))) return rc;
+        const int64_t begin[1] = {0};
+        double* outp[1] = {hess_val + b0 * c->nnz_h};
+        const int64_t stride[1] = {c->nnz_h};
+        if ((rc = launch_gather(c, a->hess, nb, zb, a->rawh_n, 1, begin, outp, stride))) return rc;
+      }
     }
     if ((rc = prof_end(c, pe))) return rc;
     if (c->profile) ++c->prof_launches;

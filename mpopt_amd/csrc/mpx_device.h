@@ -431,6 +431,19 @@ struct MpxFusedArgs {
   int32_t n_ldict, n_mdict;
 };
 
+// Arguments of the lane-per-evaluation-point Hessian kernel of assembled contexts (mpx_assembly_lanes.h, generated by
+// mpopt_amd/assembly_lanes.py): every table of the pass is in the instruction stream of the code object, the call carries the arrays.
+struct MpxLaneArgs {
+  const double* z;
+  int64_t z_stride;
+  const double* lam;
+  int64_t lam_stride;
+  const double* sigma;
+  double* out;  // hess_val
+  int64_t out_stride;
+  int32_t B, n_blocks;  // evaluation points; 64-point blocks
+};
+
 #if defined(__HIPCC__)
 // Wavefront total of a double in every lane, on the DPP path (inclusive scan by row shifts and row broadcasts, then lane 63): a
 // fixed tree without LDS round trips -- the long rows of assembled contexts (one wavefront per row: mpx_gather_kernel and the fused

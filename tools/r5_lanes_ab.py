@@ -1,0 +1,49 @@
+"""hess_l of an assembled context, three ways in ONE process on the same arrays (the host reads the switches per call): the
+lane-per-evaluation-point kernel (mpx_asml_hes, round 5), the fused kernel (mpx_asm_hes, MPX_NO_LANES=1), the two-pass kernels
+(MPX_NO_LANES=1 MPX_NO_FUSE=1).  Bit-equality of all three, median / min time per pass, fraction of the 8 TB/s peak by algorithmic bytes.
+python tools/r5_lanes_ab.py [problem=moon_lander S=20 P=5] ; B="512 1024 4096 4133 16384"; FLAGS="-DX=1;-DY=2": more contexts whose code
+objects are built with these MPX_HIPCC_FLAGS (lanes kernel only), e.g. the ablations -DMPX_LANE_ABL=1|2|4."""
+import os, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np, torch
+import mpopt_amd as M
+from mpopt_amd import mp
+import problems
+name = sys.argv[1] if len(sys.argv) > 1 else "moon_lander"
+S, P = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (20, 5)
+mpo = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
+o = mpo.create_nlp()[0]["oracle"]
+pl = o.lanes_plan
+print(f"{name} {S}x{P}: n_z {o.n_z} n_g {o.n_g} nnz_hess {o.nnz_hess}; lanes plan: " + ("none" if pl is None else f"{len(pl.groups)} groups, {pl.n_tasks} tasks + {pl.halo_tasks} halo, tile rows {pl.ne_max}"))
+dev = torch.device("cuda", 0)
+VARIANTS = [("lanes", {}, o), ("fused", {"MPX_NO_LANES": "1"}, o), ("two-pass", {"MPX_NO_LANES": "1", "MPX_NO_FUSE": "1"}, o)]
+keep = []
+for fl in [x for x in os.environ.get("FLAGS", "").split(";") if x]:
+    os.environ["MPX_HIPCC_FLAGS"] = fl
+    m2 = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
+    keep.append(m2)
+    VARIANTS.append(("lanes " + fl, {}, m2.create_nlp()[0]["oracle"]))
+os.environ.pop("MPX_HIPCC_FLAGS", None)
+for B in [int(b) for b in os.environ.get("B", "512 1024 4096 4133 16384").split()]:
+    rng = np.random.default_rng(B)
+    Z = torch.tensor(mpo.initialize_solution()[None, :] * (1 + 0.02 * rng.uniform(-1, 1, (B, o.n_z))), device=dev)
+    lam = torch.tensor(rng.standard_normal((B, o.n_g)), device=dev)
+    sig = torch.tensor(rng.uniform(0.5, 1.5, B), device=dev)
+    hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
+    alg = 8 * (o.n_z + o.n_g + 1 + o.nnz_hess)
+    res, outs = {v[0]: [] for v in VARIANTS}, {}
+    for rnd in range(5):
+        for v, env, oc in VARIANTS:
+            for k in ("MPX_NO_LANES", "MPX_NO_FUSE"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            hv.fill_(float("nan"))
+            for _ in range(3): oc.eval_device(16, B, Z, None, 0, lam, sig, None, None, None, None, hv)
+            oc.sync(); oc.timer_start()
+            for _ in range(20): oc.eval_device(16, B, Z, None, 0, lam, sig, None, None, None, None, hv)
+            res[v].append(oc.timer_stop() / 20 * 1e3)
+            if rnd == 0: outs[v] = hv.clone()
+    for v, _, _ in VARIANTS:
+        same = torch.equal(outs[v], outs["two-pass"]) and not torch.isnan(outs[v]).any().item()
+        med = sorted(res[v])[len(res[v]) // 2]
+        print(f"B {B:6d} {v:28s} median {med:8.2f} us  min {min(res[v]):8.2f}  frac(median) {alg * B / med / 1e3 / 8e3:.3f}  bit-equal to two-pass: {same}")
