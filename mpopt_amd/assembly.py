@@ -236,6 +236,13 @@ class AssembledNlpFunctions(NlpFunctions):
             self.code_object, self.code_object_path = _lib.compile_kernels(self.source, verbose=verbose)
         self._create(device)
 
+    def batched_plan(self):
+        """(lanes per workgroup of the fused kernels, groups of the lane-per-point hess_l kernel) the context's code object carries
+        (mpx_get_assembled_plan); 0: that kernel is absent."""
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.check(self._L.mpx_get_assembled_plan(self._ctx, ctypes.byref(a), ctypes.byref(b)), self._ctx)
+        return a.value, b.value
+
     # -- generated source ---------------------------------------------------------------------------
     @staticmethod
     def _source(funcs, sizes, set_consts=(), extra=None):

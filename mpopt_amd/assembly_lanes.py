@@ -63,7 +63,7 @@ def _pieces(runs):
     out = []
     for a, n, e in runs:
         while n:
-            k = n.bit_length() - 1
+            k = min(n.bit_length() - 1, 6)  # (at most 64 columns: one evaluation point per instruction)
             out.append((a, k, e))
             a, n, e = a + (1 << k), n - (1 << k), e + (1 << k)
     return out
@@ -185,16 +185,22 @@ def plan_hess(o, min_tasks=8, max_tasks=40, max_raw=260, max_tile=300):
             raw += len(used[(k, p)])
         g["zcols"], g["lcols"], g["raw"] = sorted(zc), sorted(lc), raw
         if len(g["tasks"]) > max_tasks or raw > max_raw or len(zc) + len(lc) > max_tile or len(g["rows"]) > max_tile:
+            if os.environ.get("MPX_LANES_VERBOSE"):
+                print(f"assembly_lanes: no plan -- a group of {len(g['tasks'])} tasks, {raw} raw values, {len(zc) + len(lc)} columns, {len(g['rows'])} rows")
             return None
     return HessLanePlan(groups, n_t, n_rows)
 
 
 def _chain(terms, acc):
-    """Statements of  acc = fma(c_t, v_t, acc)  over ``terms`` = [(coef, value expression)] from acc = 0, in order."""
+    """Statements of  acc = fma(c_t, v_t, acc)  over ``terms`` = [(coef, value expression)] from acc = 0, in order.
+    ``__builtin_fma``, not ``fma``: HIP's fma() is an OCML function whose llvm.fma call carries the ``contract`` flag whatever the
+    pragma in scope says; with a LITERAL coefficient 1.0 the optimiser rewrites it into an fadd that inherits the flag and then
+    fuses it with a product inside the (contract-off) point function -- one rounding less than the two-pass kernels, seen on
+    hyper-sensitive 40x4 as last-bit differences in the (t0 | tf, width) entries.  The builtin takes its flags from the pragma."""
     if not terms:
         return [f"{acc} = 0.0;"]
-    out = [f"{acc} = fma({_cfloat(terms[0][0])}, {terms[0][1]}, 0.0);"]
-    out += [f"{acc} = fma({_cfloat(c)}, {v}, {acc});" for c, v in terms[1:]]
+    out = [f"{acc} = __builtin_fma({_cfloat(terms[0][0])}, {terms[0][1]}, 0.0);"]
+    out += [f"{acc} = __builtin_fma({_cfloat(c)}, {v}, {acc});" for c, v in terms[1:]]
     return out
 
 

@@ -712,6 +712,14 @@ static int64_t points_per_pass(int64_t batch, int64_t doubles_per_point) {
   return ((batch + n_pass - 1) / n_pass + 3) / 4 * 4;
 }
 
+extern "C" int mpx_get_assembled_plan(const mpx_ctx* c, int32_t* fused_lanes, int32_t* hess_lane_groups) {
+  if (!c || c->kind != 1) return MPX_ERR_INVALID;
+  const mpx_asm_state* a = c->has_device ? c->assembled : nullptr;  // (a context without a device has no kernels)
+  if (fused_lanes) *fused_lanes = a ? a->fuse_nt : 0;
+  if (hess_lane_groups) *hess_lane_groups = a && a->fn_lanes ? a->lanes_groups : 0;
+  return MPX_OK;
+}
+
 // Device-pointer evaluation of an assembled context (called from eval_core in mpx_host.cpp after the
 // argument checks).  All pointers are device pointers.
 int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* lam_g, const double* sigma, double* f, double* g,

@@ -41,10 +41,17 @@ struct LaneIO {
   template <int SRC, int START, int K, int E0>
   __device__ __forceinline__ void ld() {
     constexpr int PPI = 64 >> K, STRIDE = SRC == 0 ? MPX_LANE_ZS : MPX_LANE_LS;
-    const int lo = (lane >> K) * STRIDE + (lane & ((1 << K) - 1));
-    const double* __restrict__ src = SRC == 0 ? zb : lb;
+    // (byte offsets in 32 bits: uniform base in scalar registers + one VGPR offset per access, no 64-bit address arithmetic per lane)
+    const unsigned lo = 8u * (unsigned)((lane >> K) * STRIDE + (lane & ((1 << K) - 1)));
+    const char* __restrict__ src = (const char*)(SRC == 0 ? zb : lb);
 #pragma unroll
-    for (int i = 0; i < (1 << K); ++i) v[E0 + i] = src[lo + (i * PPI * STRIDE + START)];
+    for (int i = 0; i < (1 << K); ++i) {
+      // (one 32-bit add per access, pinned: left alone the compiler widens  base + lane offset  to 64 bits once and then adds every
+      // constant to that with a carry chain, two vector instructions per access)
+      unsigned off = lo + 8u * (unsigned)(i * PPI * STRIDE + START);
+      asm volatile("" : "+v"(off));
+      v[E0 + i] = *(const double*)(src + off);
+    }
   }
   template <int SRC, int START, int K, int E0>
   __device__ __forceinline__ void put() {
@@ -56,10 +63,18 @@ struct LaneIO {
   template <int START, int K, int E0>
   __device__ __forceinline__ void st() {
     constexpr int PPI = 64 >> K;
-    const int lo = (lane >> K) * MPX_LANE_OS + (lane & ((1 << K) - 1));
+    const unsigned lo = 8u * (unsigned)((lane >> K) * MPX_LANE_OS + (lane & ((1 << K) - 1)));
     const int lt = (lane & ((1 << K) - 1)) * MPX_LANE_LDW + (lane >> K);
+    char* __restrict__ dst = (char*)ob;
+    double w[1 << K];  // (all of the piece's tile reads first: the pinned offsets below keep the order they are written in)
 #pragma unroll
-    for (int i = 0; i < (1 << K); ++i) ob[lo + (i * PPI * MPX_LANE_OS + START)] = T[lt + (E0 * MPX_LANE_LDW + i * PPI)];
+    for (int i = 0; i < (1 << K); ++i) w[i] = T[lt + (E0 * MPX_LANE_LDW + i * PPI)];
+#pragma unroll
+    for (int i = 0; i < (1 << K); ++i) {
+      unsigned off = lo + 8u * (unsigned)(i * PPI * MPX_LANE_OS + START);
+      asm volatile("" : "+v"(off));
+      *(double*)(dst + off) = w[i];
+    }
   }
 };
 

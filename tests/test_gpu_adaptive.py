@@ -325,3 +325,78 @@ def test_fused_kernels_without_the_packed_tables(flags, monkeypatch):
     monkeypatch.setenv("MPX_HIPCC_FLAGS", flags)
     test_fused_kernels_equal_the_two_pass_kernels_bitwise("kitchen_sink_6x4", monkeypatch)
     test_fused_kernels_equal_the_two_pass_kernels_bitwise("moon_lander_20x5", monkeypatch)
+
+
+LANE_CASES = {
+    "moon_lander_20x5": (problems.moon_lander, 20, 5, "LGR"),          # the bench workload (adaptive-hess)
+    "hyper_sensitive_40x4": (problems.hyper_sensitive, 40, 4, "LGL"),  # nonlinear dynamics: (x, x) entries, long rows
+    "generic_two_phase_6x4": (problems.generic_two_phase, 6, 4, "LGR"),
+    "moon_lander_8x9": (problems.moon_lander, 8, 9, "LGR"),            # 18 tasks + halo per group
+    "van_der_pol_mixed": (problems.van_der_pol, 9, [2, 4, 3] * 3, "CGL"),
+    "hyper_sensitive_4x3": (problems.hyper_sensitive, 4, 3, "LGL"),    # small enough for the symbolic CPU oracle
+    "van_der_pol_3_mixed": (problems.van_der_pol, 3, [2, 4, 3], "CGL"),
+}
+
+
+@pytest.mark.parametrize("name", list(LANE_CASES))
+def test_lane_per_point_hessian_equals_the_other_kernels_bitwise(name, monkeypatch):
+    """Round 5: hess_l of a batch with one LANE per evaluation point and the tables of the pass as generated straight-line code
+    (mpx_asml_hes, mpopt_amd/assembly_lanes.py), the entries of hess_l ordered group by group.  Same fma chains in the same order
+    as the point + gather kernels (MPX_NO_LANES=1 MPX_NO_FUSE=1) and the fused kernel (MPX_NO_LANES=1): every bit equal, for
+    batches of exactly one block, ragged ones (the last block starts at B - 64) and several hundred blocks; and against the CPU
+    oracle through the (permuted) pattern.  Reference: the Hessian CasADi derives at mpopt.py:3206 for mpopt.py:3034-3174."""
+    import torch
+    from mpopt_amd._lib import MPX_HESS
+
+    builder, S, po, scheme = LANE_CASES[name]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt_adaptive(ocp, S, po, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    assert o.lanes_plan is not None and o.batched_plan()[1] == len(o.lanes_plan.groups) > 0, "the lane kernel is missing from the code object"
+    first = 0
+    for g in o.lanes_plan.groups:  # group-major order of the entries
+        assert g["rows"] == list(range(first, first + len(g["rows"])))
+        first += len(g["rows"])
+    assert first == o.nnz_hess
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("MPX_LANES_MIN_BATCH", "64")
+    for B in (64, 65, 127, 640, 4096 + 37):
+        rng = np.random.default_rng(B)
+        Zh = mpo.initialize_solution()[None, :] * (1 + 0.05 * rng.uniform(-1, 1, (B, o.n_z))) + 0.02 * rng.uniform(-1, 1, (B, o.n_z))
+        lamh, sigh = rng.standard_normal((B, o.n_g)), rng.uniform(0.5, 1.5, B)
+        Z, lam, sig = torch.tensor(Zh, device=dev), torch.tensor(lamh, device=dev), torch.tensor(sigh, device=dev)
+
+        def run():
+            hv = torch.full((B, o.nnz_hess), float("nan"), dtype=torch.float64, device=dev)
+            o.eval_device(MPX_HESS, B, Z, None, 0, lam, sig, None, None, None, None, hv)
+            o.sync()
+            return hv
+
+        got = run()
+        monkeypatch.setenv("MPX_NO_LANES", "1")
+        fused = run()  # (the fused kernel from 256 points on, else the two-pass kernels)
+        monkeypatch.setenv("MPX_NO_FUSE", "1")
+        two = run()
+        monkeypatch.delenv("MPX_NO_FUSE")
+        monkeypatch.delenv("MPX_NO_LANES")
+        assert not bool(torch.isnan(got).any())
+        assert torch.equal(got, two) and torch.equal(fused, two), (name, B, float((got - two).abs().max()))
+        if B == 65 and name in ("hyper_sensitive_4x3", "van_der_pol_3_mixed"):  # and the values themselves, against the CPU oracle
+            from oracle.mpopt_oracle import OracleAdaptiveNLP
+
+            O = OracleAdaptiveNLP(ocp, S, po, scheme)
+            r, c = o.hess_pattern()
+            for b in (0, 64):
+                H = np.zeros((o.n_z, o.n_z))
+                H[r, c] = got[b].cpu().numpy()
+                assert rel_err(H + np.triu(H, 1).T, O.hess_l(Zh[b], None, sigh[b], lamh[b])) < TOL, (name, b)
+    o.close()
+
+
+def test_contexts_without_groups_keep_the_fused_kernel():
+    """Time-dependent dynamics couple every node with every earlier width: no grouping of the point tasks, no lane kernel in the code
+    object -- the pass stays with the fused kernel and MPX_NO_LANES changes nothing."""
+    mpo = mp.mpopt_adaptive(problems.kitchen_sink(mp, M.math), 6, 4, "LGR")
+    o = mpo.create_nlp()[0]["oracle"]
+    assert o.lanes_plan is None and o.batched_plan()[1] == 0 and o.batched_plan()[0] > 0
+    o.close()

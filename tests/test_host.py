@@ -349,3 +349,63 @@ def test_mixed_degree_row_span_plan(monkeypatch):
     monkeypatch.setenv("MPX_NO_ABSORB", "1")
     o, lo, ln, nf, N = spans(problems.van_der_pol, 48, [30 if s % 3 == 1 else 3 for s in range(48)], "CGL")
     assert not ln.any()
+
+
+@pytest.mark.parametrize("builder,S,P,scheme,expect", [
+    (problems.moon_lander, 20, 5, "LGR", True), (problems.hyper_sensitive, 12, 4, "LGL", True), (problems.generic_two_phase, 6, 4, "LGR", True),
+    (problems.kitchen_sink, 6, 4, "LGR", False), (problems.moon_lander, 3, 2, "LGR", False)])
+def test_lane_plan_of_assembled_hessians(builder, S, P, scheme, expect):
+    """mpopt_amd/assembly_lanes.py: the point tasks of an mpopt_adaptive transcription fall into groups (a collocation segment each)
+    unless every row couples everything (time-dependent dynamics) or the problem is tiny.  Structure of a plan: every entry of
+    hess_l in exactly one group, group by group in the pattern's order; every raw value a row reads belongs to a task of ITS group
+    (own or halo); the group's columns of z / lam_g cover what its tasks read for those entries; the generated source has one
+    LaneGrp per group and the pattern is still the same SET of (row, col) pairs as without the plan."""
+    import os
+
+    from mpopt_amd import assembly_lanes
+
+    assert assembly_lanes._pieces([(10, 5, 0), (40, 138, 5)]) == [(10, 2, 0), (14, 0, 4), (40, 6, 5), (104, 6, 69), (168, 3, 133), (176, 1, 141)]  # <= 64 columns a piece
+    mpo = mp.mpopt_adaptive(builder(mp, M.math), S, P, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    pl = o.lanes_plan
+    assert (pl is not None) == expect
+    os.environ["MPX_NO_LANES_CODE"] = "1"
+    try:
+        o2 = mp.mpopt_adaptive(builder(mp, M.math), S, P, scheme).create_nlp()[0]["oracle"]
+    finally:
+        del os.environ["MPX_NO_LANES_CODE"]
+    assert o2.lanes_plan is None and "mpx_asml" not in o2.source
+    key = lambda r, c: sorted(zip(np.asarray(r).tolist(), np.asarray(c).tolist()))
+    assert key(*o.hess_pattern()) == key(*o2.hess_pattern()) and key(*o.jac_pattern()) == key(*o2.jac_pattern())
+    if pl is None:
+        assert "mpx_asml" not in o.source
+        return
+    ptr, src, _ = o.hess
+    slot_task = {}
+    for k, s in enumerate(o.sets):
+        for q in range(s.fn.n_hess):
+            for p in range(s.n):
+                slot_task[o.rawh_off[k] + q * s.n + p] = (k, p, q)
+    first = 0
+    for gi, g in enumerate(pl.groups):
+        assert g["rows"] == list(range(first, first + len(g["rows"]))) and len(g["rows"]) > 0
+        first += len(g["rows"])
+        tasks = set(g["tasks"])
+        for r in g["rows"]:
+            for e in range(ptr[r], ptr[r + 1]):
+                k, p, q = slot_task[int(src[e])]
+                assert (k, p) in tasks
+                lv, mv = g["use"][(k, p)]
+                dl, dm = assembly_lanes._hess_deps(o.sets[k].fn)[q]
+                assert dl <= lv and dm <= mv
+        zc = set(g["zcols"])
+        for (k, p), (lv, _) in g["use"].items():
+            s = o.sets[k]
+            for v in lv:
+                lo, hi = s.L.indptr[p * s.fn.n_loc + v], s.L.indptr[p * s.fn.n_loc + v + 1]
+                assert {int(c) for c, d in zip(s.L.indices[lo:hi], s.L.data[lo:hi]) if d != 0} <= zc
+        assert f"struct LaneGrp<{gi}>" in o.source
+    assert first == o.nnz_hess and f"#define MPX_LANE_GROUPS {len(pl.groups)}" in o.source and "MPX_INSTANTIATE_LANES_HESS" in o.source
+    # the same transcription evaluated through both orders of the pattern gives the same Hessian matrix (CPU contexts cannot
+    # evaluate; the -m gpu tests do) -- here: the CCS permutations of both contexts address the same matrix positions
+    assert sorted(zip(*o.hess_pattern())) == sorted(zip(*o2.hess_pattern()))

@@ -47,3 +47,21 @@ for B in [int(b) for b in os.environ.get("B", "512 1024 4096 4133 16384").split(
         same = torch.equal(outs[v], outs["two-pass"]) and not torch.isnan(outs[v]).any().item()
         med = sorted(res[v])[len(res[v]) // 2]
         print(f"B {B:6d} {v:28s} median {med:8.2f} us  min {min(res[v]):8.2f}  frac(median) {alg * B / med / 1e3 / 8e3:.3f}  bit-equal to two-pass: {same}")
+if os.environ.get("ORDER_AB"):  # single evaluations (two-pass kernels) with the entries of hess_l group-major (lanes plan) and source-major (no plan)
+    os.environ["MPX_NO_LANES_CODE"] = "1"
+    m2 = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
+    o2 = m2.create_nlp()[0]["oracle"]
+    del os.environ["MPX_NO_LANES_CODE"]
+    rng = np.random.default_rng(1)
+    for B in (1, 16, 128):
+        Z = torch.tensor(mpo.initialize_solution()[None, :] * (1 + 0.02 * rng.uniform(-1, 1, (B, o.n_z))), device=dev)
+        lam, sig = torch.tensor(rng.standard_normal((B, o.n_g)), device=dev), torch.ones(B, dtype=torch.float64, device=dev)
+        hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
+        res = {"group-major": [], "source-major": []}
+        for rnd in range(5):
+            for tag, oc in (("group-major", o), ("source-major", o2)):
+                for _ in range(10): oc.eval_device(16, B, Z, None, 0, lam, sig, None, None, None, None, hv)
+                oc.sync(); oc.timer_start()
+                for _ in range(200): oc.eval_device(16, B, Z, None, 0, lam, sig, None, None, None, None, hv)
+                res[tag].append(oc.timer_stop() / 200 * 1e3)
+        print(f"two-pass hess_l, B = {B:4d}: " + ", ".join(f"{t} {sorted(v)[2]:.2f} us" for t, v in res.items()))
