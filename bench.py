@@ -587,7 +587,8 @@ def main():
                          "frac_vs_measured_peak": achieved / HBM_MEASURED_GBS if not (shard and world > 1) else None,
                          "measured_peak": HBM_MEASURED_GBS,
                          "kernel": ("whole loop: mpx_node_hess_0_3 (with the mid-point residuals, MPX_MID_RESID) + mpx_boundary_hess + mpx_equal_area_kernel (wall time of the step)" if loop5
-                                    else ("mpx_pts_* + mpx_gather_kernel (MPX_NO_FUSE)" if os.environ.get("MPX_NO_FUSE") else f"mpx_asm_{'hes' if hess_mode else 'fgj'} (fused point + gather pass)") if adaptive
+                                    else ("mpx_asml_hes (lane per evaluation point, the tables of the pass as generated code)" if hess_mode and o.batched_plan()[1] and not os.environ.get("MPX_NO_LANES") and B >= 512
+                                          else "mpx_pts_* + mpx_gather_kernel (MPX_NO_FUSE)" if os.environ.get("MPX_NO_FUSE") else f"mpx_asm_{'hes' if hess_mode else 'fgj'} (fused point + gather pass)") if adaptive
                                     else "mpx_node_hessn_* (node-ordered tiles of the mixed-degree grid)" if hess_mode and isinstance(P, (list, tuple)) and len(set(P)) > 1
                                     else f"mpx_light_{'fgq' if mask & MPX_GRAD else 'fg'}_0_{o.light_plan()[0]} (matrix cores)" if partial_sel and not mask & MPX_JAC and o.light_plan()[0] and not os.environ.get("MPX_NO_LIGHT")
                                     else f"mpx_node_{'hess' if hess_mode else 'fgj' if mask & (MPX_GRAD | MPX_JAC) else 'fg'}_0_*"),
@@ -644,7 +645,7 @@ def main():
                 "config5-hess": (("r5_final/c5_hess", "r2_config5_hess"), 4096), "config2-hess": (("r5_final/c2_hess", "r2_config2_hess"), 4096),
                 "config4-fgj": (("r5_final/c4_fgj",), 4096), "config4-hess": (("r5_final/c4_hess",), 4096), "config5-fgj": (("r5_final/c5_fgj",), 4096),
                 "adaptive-fgj": (("r5_final/adaptive_fgj", "r4_final/adaptive", "r3_final/adaptive", "r3_adaptive2"), 4096),
-                "adaptive-hess": (("r5_final/adaptive_hess",), 4096),
+                "adaptive-hess": (("r5_lanes/adaptive_hess",) if not os.environ.get("MPX_NO_LANES") else ("r5_final/adaptive_hess",), 4096),
                 "config5-loop": (("r5_final/config5_loop", "r4_final/config5_loop", "r3_final/config5_loop"), 512)}.get(args.workload)
         if partial_sel:  # the light passes (no Jacobian values): one PMC pass per configuration and selection
             seln = "_".join(w for w in ("f", "g", "grad_f") if w in sel)
