@@ -218,16 +218,26 @@ class AssembledNlpFunctions(NlpFunctions):
         # fused kernels (mpx_assembly_fused.h, mpxgen::SetT; the host computes the same offsets from loc_nterm / mu_nterm)
         self._set_consts = [(self.functions.index(s.fn), np.concatenate([[0], np.cumsum(np.asarray(e[0][0], np.int64))]).tolist(),
                              np.concatenate([[0], np.cumsum(np.asarray(e[1][0], np.int64))]).tolist()) for s, e in zip(self.sets, self._ell)]
-        # batches of hess_l: lane <-> evaluation point, the tables as straight-line code (assembly_lanes.py; no plan: no useful grouping
-        # of the point tasks, the fused kernels keep the pass).  With a plan the entries of hess_l are ordered group by group.  Same
-        # long-row threshold as libmpx (mpx_assembly.cpp: thr_hes).  MPX_NO_LANES_CODE=1: contexts without it (A/B, tests).
+        # batches: lane <-> evaluation point, the tables as straight-line code (assembly_lanes.py; no plan: no useful grouping of the
+        # point tasks, the fused kernels keep that pass).  With a plan the entries of hess_l / jac_g are ordered group by group.  Same
+        # long-row thresholds as libmpx (mpx_assembly.cpp: thr_hes, thr_fgj).  MPX_NO_LANES_CODE=1: contexts without it (A/B, tests).
         from . import assembly_lanes
         import os
-        self.lanes_plan = None if os.environ.get("MPX_NO_LANES_CODE") else assembly_lanes.plan_hess(self)
+        self.lanes_plan = self.lanes_plan_fgj = None
         lanes_src = None
-        if self.lanes_plan is not None:
-            assembly_lanes.group_major(self, self.lanes_plan)
-            lanes_src = assembly_lanes.hess_source(self, sizes["MT_HES"] if sizes["MT_HES"] >= 2 else 24, self.lanes_plan)
+        if not os.environ.get("MPX_NO_LANES_CODE"):
+            self.lanes_plan = assembly_lanes.plan_pass(self, "hes")
+            # (the first-order pass this way is an opt-in, MPX_LANES_FGJ=1: bit-identical, but the pass is 96 % output and the fused kernel
+            # already runs at the write-stream ceiling -- 100 against 58 us at moon lander 20x5, profiles/r5_lanes)
+            self.lanes_plan_fgj = assembly_lanes.plan_pass(self, "fgj") if os.environ.get("MPX_LANES_FGJ", "0") == "1" else None
+            parts = []
+            for plan, tag in ((self.lanes_plan, "HES"), (self.lanes_plan_fgj, "FGJ")):
+                if plan is not None:
+                    assembly_lanes.group_major(self, plan)
+                    mt = sizes["MT_" + tag]
+                    parts.append(assembly_lanes.pass_source(self, mt if mt >= 2 else 24, plan))
+            if parts:
+                lanes_src = "\n".join([assembly_lanes.common_source(self)] + parts)
         self.source = self._source(funcs, sizes, self._set_consts, extra=lanes_src)
         if with_device is None:
             with_device = _lib.gpu_available()
@@ -237,11 +247,11 @@ class AssembledNlpFunctions(NlpFunctions):
         self._create(device)
 
     def batched_plan(self):
-        """(lanes per workgroup of the fused kernels, groups of the lane-per-point hess_l kernel) the context's code object carries
-        (mpx_get_assembled_plan); 0: that kernel is absent."""
-        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
-        _lib.check(self._L.mpx_get_assembled_plan(self._ctx, ctypes.byref(a), ctypes.byref(b)), self._ctx)
-        return a.value, b.value
+        """(lanes per workgroup of the fused kernels, groups of the lane-per-point hess_l kernel, groups of the lane-per-point first-order
+        kernel) the context's code object carries (mpx_get_assembled_plan); 0: that kernel is absent."""
+        a, b, d = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.check(self._L.mpx_get_assembled_plan(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(d)), self._ctx)
+        return a.value, b.value, d.value
 
     # -- generated source ---------------------------------------------------------------------------
     @staticmethod

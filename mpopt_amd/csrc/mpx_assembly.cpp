@@ -54,8 +54,13 @@ struct DevFused {
 struct mpx_asm_state {
   DevFused ffgj, fhess;
   hipFunction_t fn_fused[3] = {nullptr, nullptr, nullptr};
-  hipFunction_t fn_lanes = nullptr;  // mpx_asml_hes (mpx_assembly_lanes.h): hess_l of batches, lane <-> evaluation point; NULL: not in the code object
-  int lanes_groups = 0;
+  // lane-per-evaluation-point kernels (mpx_assembly_lanes.h), pass 0: hess_l (mpx_asml_hes), pass 1: f, g, grad_f, jac_g (mpx_asml_fgj);
+  // fn NULL: not in the code object.  *_global: the second kernel of a pass with global rows (n_global > 0), n_sid scratch slots per block.
+  struct Lanes {
+    hipFunction_t fn = nullptr, fn_global = nullptr;
+    int groups = 0, n_global = 0, n_sid = 0;
+  } lanes[2];
+  DevBuf<double> lane_scratch;
   int fuse_nt = 0, fuse_u[2] = {0, 0};  // lanes per workgroup; evaluation points per workgroup pass (first order, Hessian); 0: no kernel
   int fuse_wg[3] = {0, 0, 0};           // resident workgroups per launch (compute units x occupancy)
   long long* dbg = nullptr;             // MPX_FUSE_DEBUG
@@ -560,12 +565,16 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
       }
     }
     (void)hipGetLastError();
-    {  // the lane-per-point Hessian kernel (generated when the point tasks fall into groups: mpopt_amd/assembly_lanes.py)
-      int li[3] = {0, 0, 0};
-      hipFunction_t fl = nullptr;
-      if (hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_asml_info") == hipSuccess && bytes == sizeof li && hipMemcpyDtoH(li, sym, sizeof li) == hipSuccess &&
-          li[0] >= 1 && li[2] == (int)D->nnz_hess && hipModuleGetFunction(&fl, c->module, "mpx_asml_hes") == hipSuccess)
-        a->fn_lanes = fl, a->lanes_groups = li[0];
+    for (int ps = 0; ps < 2; ++ps) {  // the lane-per-point kernels (generated when the point tasks fall into groups: mpopt_amd/assembly_lanes.py)
+      static const char* iname[2] = {"mpx_asml_hes_info", "mpx_asml_fgj_info"};
+      static const char* kname2[2] = {"mpx_asml_hes", "mpx_asml_fgj"};
+      static const char* gname[2] = {"mpx_asml_hes_global", "mpx_asml_fgj_global"};
+      int li[5] = {0, 0, 0, 0, 0};
+      hipFunction_t fl = nullptr, fg = nullptr;
+      if (hipModuleGetGlobal(&sym, &bytes, c->module, iname[ps]) == hipSuccess && bytes == sizeof li && hipMemcpyDtoH(li, sym, sizeof li) == hipSuccess &&
+          li[0] >= 1 && li[2] == (int)(ps == 0 ? D->nnz_hess : D->nnz_jac) && hipModuleGetFunction(&fl, c->module, kname2[ps]) == hipSuccess &&
+          (li[3] == 0 || hipModuleGetFunction(&fg, c->module, gname[ps]) == hipSuccess))
+        a->lanes[ps].fn = fl, a->lanes[ps].fn_global = fg, a->lanes[ps].groups = li[0], a->lanes[ps].n_global = li[3], a->lanes[ps].n_sid = li[4];
     }
     (void)hipGetLastError();
   }
@@ -674,25 +683,36 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
   return MPX_OK;
 }
 
-// Lane-per-evaluation-point Hessian kernel (mpx_assembly_lanes.h): whole blocks of 64 evaluation points, one wavefront per
-// (group of point tasks, block); the groups of a block sit on one XCD.  Bit-identical to the other two paths, so the host picks by
-// batch size; MPX_NO_LANES=1 / MPX_LANES_MIN_BATCH=n (read per call) switch.
-static bool use_lanes(const mpx_asm_state* a, int64_t batch) {
-  if (!a->fn_lanes || getenv("MPX_NO_LANES")) return false;
+// Lane-per-evaluation-point kernels (mpx_assembly_lanes.h): one wavefront per (group of point tasks, block of 64 evaluation points);
+// the groups of a block sit on one XCD; a second small kernel for the pass's global rows, if it has any (raw values through a scratch
+// array).  Bit-identical to the other two paths, so the host picks by batch size; MPX_NO_LANES=1 / MPX_LANES_MIN_BATCH=n (read per
+// call) switch.
+static bool use_lanes(const mpx_asm_state* a, int ps, int64_t batch) {
+  if (!a->lanes[ps].fn || getenv("MPX_NO_LANES")) return false;
   const char* mb = getenv("MPX_LANES_MIN_BATCH");
   return batch >= std::max<int64_t>(mb ? atoll(mb) : 512, 64);
 }
 
-static int launch_lanes(mpx_ctx* c, int64_t batch, const double* z, const double* lam, const double* sigma, double* hess_val) {
-  const int64_t n_blocks = (batch + 63) / 64;  // (the last block of a ragged batch starts at batch - 64)
+static int launch_lanes(mpx_ctx* c, int ps, int64_t batch, const double* z, const double* lam, const double* sigma, double* const* out) {
   mpx_asm_state* a = c->assembled;
+  const mpx_asm_state::Lanes& L = a->lanes[ps];
+  const int64_t n_blocks = (batch + 63) / 64;  // (the last block of a ragged batch starts at batch - 64)
+  int rc;
+  if (L.n_sid > 0 && (rc = reserve(c, a->lane_scratch, (size_t)(n_blocks * L.n_sid * 64)))) return rc;
   MpxLaneArgs A{};
-  A.z = z, A.z_stride = c->n_z, A.lam = lam, A.lam_stride = c->n_g, A.sigma = sigma, A.out = hess_val, A.out_stride = c->nnz_h;
+  A.z = z, A.lam = lam, A.sigma = sigma;
+  for (int k = 0; k < 4; ++k) A.out[k] = out[k];
+  A.scratch = L.n_sid > 0 ? a->lane_scratch.p : nullptr;
   A.B = (int32_t)batch, A.n_blocks = (int32_t)n_blocks;
-  const unsigned grid = (unsigned)(8 * (int64_t)a->lanes_groups * ((n_blocks + 7) / 8));
+  {
+    const char* ord = getenv("MPX_LANES_ORDER");  // (read per call: A/B)
+    A.order = ord ? atoi(ord) : (ps == 1 ? 1 : 0);
+  }
+  const unsigned grid = (unsigned)(8 * (int64_t)L.groups * ((n_blocks + 7) / 8));
   size_t sz = sizeof(A);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIPCHK(c, hipModuleLaunchKernel(a->fn_lanes, grid, 1, 1, 64, 1, 1, 0, c->stream, nullptr, cfg));
+  HIPCHK(c, hipModuleLaunchKernel(L.fn, grid, 1, 1, 64, 1, 1, 0, c->stream, nullptr, cfg));
+  if (L.n_global > 0) HIPCHK(c, hipModuleLaunchKernel(L.fn_global, (unsigned)n_blocks, (unsigned)L.n_global, 1, 64, 1, 1, 0, c->stream, nullptr, cfg));
   return MPX_OK;
 }
 
@@ -712,11 +732,12 @@ static int64_t points_per_pass(int64_t batch, int64_t doubles_per_point) {
   return ((batch + n_pass - 1) / n_pass + 3) / 4 * 4;
 }
 
-extern "C" int mpx_get_assembled_plan(const mpx_ctx* c, int32_t* fused_lanes, int32_t* hess_lane_groups) {
+extern "C" int mpx_get_assembled_plan(const mpx_ctx* c, int32_t* fused_lanes, int32_t* hess_lane_groups, int32_t* first_order_lane_groups) {
   if (!c || c->kind != 1) return MPX_ERR_INVALID;
   const mpx_asm_state* a = c->has_device ? c->assembled : nullptr;  // (a context without a device has no kernels)
   if (fused_lanes) *fused_lanes = a ? a->fuse_nt : 0;
-  if (hess_lane_groups) *hess_lane_groups = a && a->fn_lanes ? a->lanes_groups : 0;
+  if (hess_lane_groups) *hess_lane_groups = a && a->lanes[0].fn ? a->lanes[0].groups : 0;
+  if (first_order_lane_groups) *first_order_lane_groups = a && a->lanes[1].fn ? a->lanes[1].groups : 0;
   return MPX_OK;
 }
 
@@ -727,7 +748,14 @@ int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, co
   mpx_asm_state* a = c->assembled;
   if (mask & (MPX_BOUNDARY_ONLY | MPX_JAC_VARIABLE_ONLY)) return fail(c, MPX_ERR_UNSUPPORTED, "mask bit not available on assembled contexts");
   int rc;
-  if ((mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC)) && use_fused(a, (mask & (MPX_GRAD | MPX_JAC)) ? MPX_MODE_FGJ : MPX_MODE_FG, batch)) {
+  if ((mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC)) == (MPX_F | MPX_G | MPX_GRAD | MPX_JAC) && use_lanes(a, 1, batch)) {
+    hipEvent_t pe = nullptr;  // (the whole first-order pass with one lane per evaluation point; partial masks keep the fused kernels)
+    if ((rc = prof_begin(c, &pe))) return rc;
+    double* outp[4] = {f, g, grad_f, jac_val};
+    if ((rc = launch_lanes(c, 1, batch, z, nullptr, nullptr, outp))) return rc;
+    if ((rc = prof_end(c, pe))) return rc;
+    if (c->profile) ++c->prof_launches;
+  } else if ((mask & (MPX_F | MPX_G | MPX_GRAD | MPX_JAC)) && use_fused(a, (mask & (MPX_GRAD | MPX_JAC)) ? MPX_MODE_FGJ : MPX_MODE_FG, batch)) {
     const int mode = (mask & (MPX_GRAD | MPX_JAC)) ? MPX_MODE_FGJ : MPX_MODE_FG;
     hipEvent_t pe = nullptr;
     if ((rc = prof_begin(c, &pe))) return rc;
@@ -759,8 +787,9 @@ int mpx_asm_eval_device(mpx_ctx* c, int mask, int64_t batch, const double* z, co
     hipEvent_t pe = nullptr;  // (mpx_profile: one bracket per evaluation, counted as one launch)
     if ((rc = prof_begin(c, &pe))) return rc;
     int64_t done = 0;
-    if (use_lanes(a, batch)) {
-      if ((rc = launch_lanes(c, batch, z, lam_g, sigma, hess_val))) return rc;
+    if (use_lanes(a, 0, batch)) {
+      double* outp[4] = {hess_val, nullptr, nullptr, nullptr};
+      if ((rc = launch_lanes(c, 0, batch, z, lam_g, sigma, outp))) return rc;
       done = batch;
     }
     if (done < batch && use_fused(a, MPX_MODE_HESS, batch - done)) {

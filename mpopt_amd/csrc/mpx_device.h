@@ -431,17 +431,17 @@ struct MpxFusedArgs {
   int32_t n_ldict, n_mdict;
 };
 
-// Arguments of the lane-per-evaluation-point Hessian kernel of assembled contexts (mpx_assembly_lanes.h, generated by
-// mpopt_amd/assembly_lanes.py): every table of the pass is in the instruction stream of the code object, the call carries the arrays.
+// Arguments of the lane-per-evaluation-point kernels of assembled contexts (mpx_assembly_lanes.h, generated by
+// mpopt_amd/assembly_lanes.py): every table of a pass is in the instruction stream / constant data of the code object, the call
+// carries the arrays.  z, lam_g and the outputs are dense (row strides n_z, n_g, array lengths: compile-time constants there).
 struct MpxLaneArgs {
   const double* z;
-  int64_t z_stride;
   const double* lam;
-  int64_t lam_stride;
   const double* sigma;
-  double* out;  // hess_val
-  int64_t out_stride;
+  double* out[4];   // hess_l pass: {hess_val}; first-order pass: {f, g, grad_f, jac_val}
+  double* scratch;  // [block][slot][64]: raw values the global rows read (written by the group kernel, read by the *_global kernel)
   int32_t B, n_blocks;  // evaluation points; 64-point blocks
+  int32_t order, pad_;  // workgroup -> (group, block): 0 the groups of a block next to each other, 1 the blocks of a group next to each other
 };
 
 #if defined(__HIPCC__)

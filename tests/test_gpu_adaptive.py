@@ -335,6 +335,7 @@ LANE_CASES = {
     "van_der_pol_mixed": (problems.van_der_pol, 9, [2, 4, 3] * 3, "CGL"),
     "hyper_sensitive_4x3": (problems.hyper_sensitive, 4, 3, "LGL"),    # small enough for the symbolic CPU oracle
     "van_der_pol_3_mixed": (problems.van_der_pol, 3, [2, 4, 3], "CGL"),
+    "van_der_pol_10x6": (problems.van_der_pol, 10, 6, "LGR"),          # 264 raw values a group, rows in three chunks of the tile
 }
 
 
@@ -399,4 +400,79 @@ def test_contexts_without_groups_keep_the_fused_kernel():
     mpo = mp.mpopt_adaptive(problems.kitchen_sink(mp, M.math), 6, 4, "LGR")
     o = mpo.create_nlp()[0]["oracle"]
     assert o.lanes_plan is None and o.batched_plan()[1] == 0 and o.batched_plan()[0] > 0
+    o.close()
+
+
+@pytest.mark.parametrize("builder,S,P,scheme", [(problems.moon_lander, 20, 5, "LGR"), (problems.hyper_sensitive, 12, 4, "LGL")])
+def test_lane_per_point_first_order_pass_is_bit_identical(builder, S, P, scheme, monkeypatch):
+    """MPX_LANES_FGJ=1 (opt-in; measured slower than the fused kernel, which already runs at the write-stream ceiling): f, g, grad_f and
+    jac_g of a batch with one lane per evaluation point, the entries of jac_g group-major, and the pass's GLOBAL rows -- f, d f / d t0,
+    d f / d tf: sums over every point task -- through the scratch array and the second kernel (mpx_asml_fgj_global: partial sums and
+    the pairwise tree of the two-pass kernel's wavefront sum).  Every output equals the two-pass and the fused kernels bit for bit;
+    a call that does not ask for all four outputs keeps the fused kernels."""
+    import torch
+    from mpopt_amd._lib import MPX_F, MPX_G, MPX_GRAD, MPX_JAC
+
+    monkeypatch.setenv("MPX_LANES_FGJ", "1")
+    mpo = mp.mpopt_adaptive(builder(mp, M.math), S, P, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    pl = o.lanes_plan_fgj
+    assert pl is not None and o.batched_plan()[2] == len(pl.groups) > 0 and len(pl.global_rows) >= 1 and len(pl.sid) > 0
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("MPX_LANES_MIN_BATCH", "64")
+    for B in (64, 65, 640 + 13):
+        rng = np.random.default_rng(B)
+        Z = torch.tensor(mpo.initialize_solution()[None, :] * (1 + 0.05 * rng.uniform(-1, 1, (B, o.n_z))) + 0.02 * rng.uniform(-1, 1, (B, o.n_z)), device=dev)
+
+        def run(mask=MPX_F | MPX_G | MPX_GRAD | MPX_JAC):
+            mk = lambda *s_: torch.full(s_, float("nan"), dtype=torch.float64, device=dev)
+            bufs = (mk(B), mk(B, o.n_g), mk(B, o.n_z), mk(B, o.nnz_jac))
+            o.eval_device(mask, B, Z, None, 0, None, None, *bufs, None)
+            o.sync()
+            return bufs
+
+        got = run()
+        part = run(MPX_G | MPX_JAC)  # (not all four: the fused kernels)
+        monkeypatch.setenv("MPX_NO_LANES", "1")
+        fused = run()
+        monkeypatch.setenv("MPX_NO_FUSE", "1")
+        two = run()
+        monkeypatch.delenv("MPX_NO_FUSE")
+        monkeypatch.delenv("MPX_NO_LANES")
+        for k, nm in enumerate(("f", "g", "grad_f", "jac_g")):
+            assert not bool(torch.isnan(got[k]).any()), (nm, B)
+            assert torch.equal(got[k], two[k]) and torch.equal(fused[k], two[k]), (nm, B, float((got[k] - two[k]).abs().max()))
+        assert torch.equal(part[1], two[1]) and torch.equal(part[3], two[3]) and bool(torch.isnan(part[0]).all())
+    o.close()
+
+
+def test_lane_kernel_with_global_rows_of_a_time_dependent_hessian(monkeypatch):
+    """MPX_LANES_GLOBAL=1 (opt-in; slower than the fused kernel there): with time-dependent dynamics the entries of hess_l for pairs of
+    widths sum over every later point task -- global rows, summed by mpx_asml_hes_global from the scratch array.  Same bits."""
+    import torch
+    from mpopt_amd._lib import MPX_HESS
+
+    monkeypatch.setenv("MPX_LANES_GLOBAL", "1")
+    monkeypatch.setenv("MPX_LANES_MAX_RAW", "640")
+    mpo = mp.mpopt_adaptive(problems.time_dependent(mp, M.math), 10, 3, "LGR")
+    o = mpo.create_nlp()[0]["oracle"]
+    pl = o.lanes_plan
+    assert pl is not None and len(pl.global_rows) > 0 and o.batched_plan()[1] == len(pl.groups)
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("MPX_LANES_MIN_BATCH", "64")
+    B = 64 + 29
+    rng = np.random.default_rng(5)
+    Z = torch.tensor(mpo.initialize_solution()[None, :] * (1 + 0.05 * rng.uniform(-1, 1, (B, o.n_z))) + 0.02 * rng.uniform(-1, 1, (B, o.n_z)), device=dev)
+    lam, sig = torch.tensor(rng.standard_normal((B, o.n_g)), device=dev), torch.tensor(rng.uniform(0.5, 1.5, B), device=dev)
+
+    def run():
+        hv = torch.full((B, o.nnz_hess), float("nan"), dtype=torch.float64, device=dev)
+        o.eval_device(MPX_HESS, B, Z, None, 0, lam, sig, None, None, None, None, hv)
+        o.sync()
+        return hv
+
+    got = run()
+    monkeypatch.setenv("MPX_NO_LANES", "1")
+    two = run()
+    assert not bool(torch.isnan(got).any()) and torch.equal(got, two)
     o.close()

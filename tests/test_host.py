@@ -353,59 +353,70 @@ def test_mixed_degree_row_span_plan(monkeypatch):
 
 @pytest.mark.parametrize("builder,S,P,scheme,expect", [
     (problems.moon_lander, 20, 5, "LGR", True), (problems.hyper_sensitive, 12, 4, "LGL", True), (problems.generic_two_phase, 6, 4, "LGR", True),
-    (problems.kitchen_sink, 6, 4, "LGR", False), (problems.moon_lander, 3, 2, "LGR", False)])
-def test_lane_plan_of_assembled_hessians(builder, S, P, scheme, expect):
+    (problems.kitchen_sink, 6, 4, "LGR", False), (problems.moon_lander, 3, 2, "LGR", False), (problems.time_dependent, 10, 3, "LGR", False)])
+def test_lane_plan_of_assembled_hessians(builder, S, P, scheme, expect, monkeypatch):
     """mpopt_amd/assembly_lanes.py: the point tasks of an mpopt_adaptive transcription fall into groups (a collocation segment each)
-    unless every row couples everything (time-dependent dynamics) or the problem is tiny.  Structure of a plan: every entry of
-    hess_l in exactly one group, group by group in the pattern's order; every raw value a row reads belongs to a task of ITS group
-    (own or halo); the group's columns of z / lam_g cover what its tasks read for those entries; the generated source has one
-    LaneGrp per group and the pattern is still the same SET of (row, col) pairs as without the plan."""
-    import os
-
+    unless every row couples everything (time-dependent dynamics: global rows, dropped for hess_l) or the problem is tiny.
+    Structure of a plan: every entry of hess_l in exactly one group, group by group in the pattern's order; every raw value a row
+    reads belongs to a task of ITS group (own or halo); the group's columns of z / lam_g cover what its tasks read for those
+    entries; the generated source has one LaneGrpHES per group and the pattern is still the same SET of (row, col) pairs as without
+    the plan.  MPX_LANES_FGJ=1 (opt-in: the first-order pass the same way, with its global rows f, d f / d t0, d f / d tf through the
+    scratch array): the same checks on the rows of g / grad_f / jac_g, every row in one group or global."""
     from mpopt_amd import assembly_lanes
 
     assert assembly_lanes._pieces([(10, 5, 0), (40, 138, 5)]) == [(10, 2, 0), (14, 0, 4), (40, 6, 5), (104, 6, 69), (168, 3, 133), (176, 1, 141)]  # <= 64 columns a piece
+    monkeypatch.setenv("MPX_LANES_FGJ", "1")
     mpo = mp.mpopt_adaptive(builder(mp, M.math), S, P, scheme)
     o = mpo.create_nlp()[0]["oracle"]
     pl = o.lanes_plan
     assert (pl is not None) == expect
-    os.environ["MPX_NO_LANES_CODE"] = "1"
-    try:
-        o2 = mp.mpopt_adaptive(builder(mp, M.math), S, P, scheme).create_nlp()[0]["oracle"]
-    finally:
-        del os.environ["MPX_NO_LANES_CODE"]
-    assert o2.lanes_plan is None and "mpx_asml" not in o2.source
+    monkeypatch.setenv("MPX_NO_LANES_CODE", "1")
+    o2 = mp.mpopt_adaptive(builder(mp, M.math), S, P, scheme).create_nlp()[0]["oracle"]
+    monkeypatch.delenv("MPX_NO_LANES_CODE")
+    assert o2.lanes_plan is None and o2.lanes_plan_fgj is None and "mpx_asml" not in o2.source
     key = lambda r, c: sorted(zip(np.asarray(r).tolist(), np.asarray(c).tolist()))
     assert key(*o.hess_pattern()) == key(*o2.hess_pattern()) and key(*o.jac_pattern()) == key(*o2.jac_pattern())
-    if pl is None:
+    if pl is None and o.lanes_plan_fgj is None:
         assert "mpx_asml" not in o.source
         return
-    ptr, src, _ = o.hess
-    slot_task = {}
-    for k, s in enumerate(o.sets):
-        for q in range(s.fn.n_hess):
-            for p in range(s.n):
-                slot_task[o.rawh_off[k] + q * s.n + p] = (k, p, q)
-    first = 0
-    for gi, g in enumerate(pl.groups):
-        assert g["rows"] == list(range(first, first + len(g["rows"]))) and len(g["rows"]) > 0
-        first += len(g["rows"])
-        tasks = set(g["tasks"])
-        for r in g["rows"]:
-            for e in range(ptr[r], ptr[r + 1]):
-                k, p, q = slot_task[int(src[e])]
-                assert (k, p) in tasks
-                lv, mv = g["use"][(k, p)]
-                dl, dm = assembly_lanes._hess_deps(o.sets[k].fn)[q]
-                assert dl <= lv and dm <= mv
-        zc = set(g["zcols"])
-        for (k, p), (lv, _) in g["use"].items():
-            s = o.sets[k]
-            for v in lv:
-                lo, hi = s.L.indptr[p * s.fn.n_loc + v], s.L.indptr[p * s.fn.n_loc + v + 1]
-                assert {int(c) for c, d in zip(s.L.indices[lo:hi], s.L.data[lo:hi]) if d != 0} <= zc
-        assert f"struct LaneGrp<{gi}>" in o.source
-    assert first == o.nnz_hess and f"#define MPX_LANE_GROUPS {len(pl.groups)}" in o.source and "MPX_INSTANTIATE_LANES_HESS" in o.source
-    # the same transcription evaluated through both orders of the pattern gives the same Hessian matrix (CPU contexts cannot
-    # evaluate; the -m gpu tests do) -- here: the CCS permutations of both contexts address the same matrix positions
-    assert sorted(zip(*o.hess_pattern())) == sorted(zip(*o2.hess_pattern()))
+    for plan in (pl, o.lanes_plan_fgj):
+        if plan is None:
+            continue
+        Pq = assembly_lanes.Pass(o, plan.kind)
+        ptr, src = Pq.ptr, Pq.src
+        KIND = plan.kind.upper()
+        seen = set(plan.global_rows)
+        assert len(seen) == len(plan.global_rows) and (plan.kind == "fgj" or not seen)
+        arr_rows = {a: [] for a in range(len(Pq.arrays))}
+        for gi, g in enumerate(plan.groups):
+            tasks = set(g["tasks"])
+            for r in g["rows"]:
+                assert r not in seen
+                seen.add(r)
+                arr_rows[Pq.array_of(r)[0]].append(r)
+                for x in src[ptr[r]:ptr[r + 1]]:
+                    if x >= 0:
+                        kp = Pq.tasks[Pq.task_of[x]]
+                        assert kp in tasks
+                        lv, mv = g["use"][kp]
+                        dl, dm = Pq.deps(o.sets[kp[0]].fn)[int(Pq.val_of[x])]
+                        assert dl <= lv and dm <= mv
+                    elif x <= -2:
+                        assert -2 - int(x) in set(g["zcols"])
+            zc = set(g["zcols"])
+            for (k, p), (lv, _) in g["use"].items():
+                s_ = o.sets[k]
+                for v in lv:
+                    lo, hi = s_.L.indptr[p * s_.fn.n_loc + v], s_.L.indptr[p * s_.fn.n_loc + v + 1]
+                    assert {int(c) for c, d in zip(s_.L.indices[lo:hi], s_.L.data[lo:hi]) if d != 0} <= zc
+            for kp, lst in g["scratch"].items():  # scratch slots are written by the group that owns the task, once
+                assert kp in g["own"]
+            assert f"struct LaneGrp{KIND}<{gi}>" in o.source
+        assert seen == set(range(Pq.n_rows))  # every row: one group, or global
+        # the reordered array (hess_l / jac_g): group by group, the global rows last
+        last = len(Pq.arrays) - 1
+        rows_last = arr_rows[last] + [r for r in plan.global_rows if Pq.array_of(r)[0] == last]
+        assert rows_last == list(range(Pq.arrays[last][1], Pq.arrays[last][1] + Pq.arrays[last][2]))
+        written = [sd for g in plan.groups for lst in g["scratch"].values() for _, sd in lst]
+        assert sorted(written) == list(range(len(plan.sid)))
+        assert f"#define MPX_LANE_{KIND}_GROUPS {len(plan.groups)}" in o.source and f"MPX_INSTANTIATE_LANES({plan.kind}, {KIND}," in o.source

@@ -13,12 +13,22 @@ name = sys.argv[1] if len(sys.argv) > 1 else "moon_lander"
 S, P = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (20, 5)
 mpo = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
 o = mpo.create_nlp()[0]["oracle"]
-pl = o.lanes_plan
-print(f"{name} {S}x{P}: n_z {o.n_z} n_g {o.n_g} nnz_hess {o.nnz_hess}; lanes plan: " + ("none" if pl is None else f"{len(pl.groups)} groups, {pl.n_tasks} tasks + {pl.halo_tasks} halo, tile rows {pl.ne_max}"))
+FGJ = os.environ.get("PASS", "hes") == "fgj"  # PASS=fgj: the first-order pass (f, g, grad_f, jac_g together) instead of hess_l
+pl = o.lanes_plan_fgj if FGJ else o.lanes_plan
+print(f"{name} {S}x{P}: n_z {o.n_z} n_g {o.n_g} nnz_jac {o.nnz_jac} nnz_hess {o.nnz_hess}; lanes plan ({'fgj' if FGJ else 'hes'}): " + ("none" if pl is None else f"{len(pl.groups)} groups, {pl.n_tasks} tasks + {pl.halo_tasks} halo, tile rows {pl.tile_rows}, {len(pl.global_rows)} global rows / {len(pl.sid)} scratch slots") + f"; code object: {o.batched_plan()}")
 dev = torch.device("cuda", 0)
 VARIANTS = [("lanes", {}, o), ("fused", {"MPX_NO_LANES": "1"}, o), ("two-pass", {"MPX_NO_LANES": "1", "MPX_NO_FUSE": "1"}, o)]
+for od in [x for x in os.environ.get("ORDERS", "").split() if x]:  # ORDERS="0 1": the lanes kernel with MPX_LANES_ORDER=...
+    VARIANTS.append((f"lanes order {od}", {"MPX_LANES_ORDER": od}, o))
 keep = []
 for fl in [x for x in os.environ.get("FLAGS", "").split(";") if x]:
+    if fl.startswith("CHUNK="):  # (a generation-time switch, not a compiler flag: MPX_LANES_CHUNK)
+        os.environ["MPX_LANES_CHUNK"] = fl[6:]
+        m2 = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
+        keep.append(m2)
+        VARIANTS.append(("lanes " + fl, {}, m2.create_nlp()[0]["oracle"]))
+        del os.environ["MPX_LANES_CHUNK"]
+        continue
     os.environ["MPX_HIPCC_FLAGS"] = fl
     m2 = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
     keep.append(m2)
@@ -29,18 +39,24 @@ for B in [int(b) for b in os.environ.get("B", "512 1024 4096 4133 16384").split(
     Z = torch.tensor(mpo.initialize_solution()[None, :] * (1 + 0.02 * rng.uniform(-1, 1, (B, o.n_z))), device=dev)
     lam = torch.tensor(rng.standard_normal((B, o.n_g)), device=dev)
     sig = torch.tensor(rng.uniform(0.5, 1.5, B), device=dev)
-    hv = torch.empty(B, o.nnz_hess, dtype=torch.float64, device=dev)
-    alg = 8 * (o.n_z + o.n_g + 1 + o.nnz_hess)
+    hv = torch.empty(B, (1 + o.n_g + o.n_z + o.nnz_jac) if FGJ else o.nnz_hess, dtype=torch.float64, device=dev)
+    alg = 8 * (2 * o.n_z + o.n_g + o.nnz_jac + 1) if FGJ else 8 * (o.n_z + o.n_g + 1 + o.nnz_hess)
+    if FGJ:  # (one allocation, four arrays: f | g | grad_f | jac_g)
+        flat = hv.view(-1)
+        of, og, oq, oj = flat[:B], flat[B:B + B * o.n_g].view(B, o.n_g), flat[B + B * o.n_g:B + B * (o.n_g + o.n_z)].view(B, o.n_z), flat[B + B * (o.n_g + o.n_z):].view(B, o.nnz_jac)
+        call = lambda oc: oc.eval_device(15, B, Z, None, 0, None, None, of, og, oq, oj, None)
+    else:
+        call = lambda oc: oc.eval_device(16, B, Z, None, 0, lam, sig, None, None, None, None, hv)
     res, outs = {v[0]: [] for v in VARIANTS}, {}
     for rnd in range(5):
         for v, env, oc in VARIANTS:
-            for k in ("MPX_NO_LANES", "MPX_NO_FUSE"):
+            for k in ("MPX_NO_LANES", "MPX_NO_FUSE", "MPX_LANES_ORDER"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             hv.fill_(float("nan"))
-            for _ in range(3): oc.eval_device(16, B, Z, None, 0, lam, sig, None, None, None, None, hv)
+            for _ in range(3): call(oc)
             oc.sync(); oc.timer_start()
-            for _ in range(20): oc.eval_device(16, B, Z, None, 0, lam, sig, None, None, None, None, hv)
+            for _ in range(20): call(oc)
             res[v].append(oc.timer_stop() / 20 * 1e3)
             if rnd == 0: outs[v] = hv.clone()
     for v, _, _ in VARIANTS:
