@@ -295,6 +295,15 @@ def soak_case(seed):
     return builder, S, po, ["LGR", "LGL", "CGL"][seed % 3]
 
 
+def lane_soak_case(seed):
+    """(builder, n_segments, poly_orders, scheme) of a random small mixed-degree mpopt_adaptive grid with time-independent dynamics
+    (the problems whose point tasks fall into groups: mpopt_amd/assembly_lanes.py)."""
+    rng = np.random.default_rng(seed)
+    builder = [van_der_pol, dae_vdp, two_phase_schwartz, hyper_sensitive, moon_lander, generic_two_phase][seed % 6]
+    S = int(rng.integers(4, 26))
+    return builder, S, [int(x) for x in rng.integers(1, 7, size=S)], ["LGR", "LGL", "CGL"][seed % 3]
+
+
 def sample_point(name, n_z, n_p, n_g, z0, lbx, ubx):
     """Deterministic evaluation point: Z0 + seeded perturbation clipped
     to the bounds, non-uniform positive widths summing to one per phase, N(0,1) multipliers."""
