@@ -587,7 +587,7 @@ def main():
                          "frac_vs_measured_peak": achieved / HBM_MEASURED_GBS if not (shard and world > 1) else None,
                          "measured_peak": HBM_MEASURED_GBS,
                          "kernel": ("whole loop: mpx_node_hess_0_3 (with the mid-point residuals, MPX_MID_RESID) + mpx_boundary_hess + mpx_equal_area_kernel (wall time of the step)" if loop5
-                                    else ("mpx_asml_hes (lane per evaluation point, the tables of the pass as generated code)" if hess_mode and o.batched_plan()[1] and not os.environ.get("MPX_NO_LANES") and B >= 512
+                                    else ("mpx_asml_hes (lane per evaluation point, the tables of the pass as generated code)" if hess_mode and o.batched_plan()[1] and not os.environ.get("MPX_NO_LANES") and B >= 64
                                           else "mpx_pts_* + mpx_gather_kernel (MPX_NO_FUSE)" if os.environ.get("MPX_NO_FUSE") else f"mpx_asm_{'hes' if hess_mode else 'fgj'} (fused point + gather pass)") if adaptive
                                     else "mpx_node_hessn_* (node-ordered tiles of the mixed-degree grid)" if hess_mode and isinstance(P, (list, tuple)) and len(set(P)) > 1
                                     else f"mpx_light_{'fgq' if mask & MPX_GRAD else 'fg'}_0_{o.light_plan()[0]} (matrix cores)" if partial_sel and not mask & MPX_JAC and o.light_plan()[0] and not os.environ.get("MPX_NO_LIGHT")

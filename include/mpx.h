@@ -422,7 +422,7 @@ int mpx_create_assembled(const mpx_assembly* desc, mpx_ctx** out);
 /* Which batched kernels the code object of an assembled context carries (0: none; single evaluations and small batches always
  * run the two-pass kernels): fused_lanes = lanes per workgroup of the fused persistent kernels (batches of >= 256 points);
  * hess_lane_groups / first_order_lane_groups = groups of point tasks of the lane-per-evaluation-point kernels (mpx_asml_hes: hess_l;
- * mpx_asml_fgj: f + g + grad_f + jac_g requested together; batches of >= 512 points; one wavefront per group and 64 evaluation
+ * mpx_asml_fgj: f + g + grad_f + jac_g requested together, an opt-in of the generator; batches of >= 64 / 512 points; one wavefront per group and 64 evaluation
  * points, a second small kernel for rows that sum over all groups).  All paths give the same bits. */
 int mpx_get_assembled_plan(const mpx_ctx* ctx, int32_t* fused_lanes, int32_t* hess_lane_groups, int32_t* first_order_lane_groups);
 

@@ -685,12 +685,14 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
 
 // Lane-per-evaluation-point kernels (mpx_assembly_lanes.h): one wavefront per (group of point tasks, block of 64 evaluation points);
 // the groups of a block sit on one XCD; a second small kernel for the pass's global rows, if it has any (raw values through a scratch
-// array).  Bit-identical to the other two paths, so the host picks by batch size; MPX_NO_LANES=1 / MPX_LANES_MIN_BATCH=n (read per
-// call) switch.
+// array).  Bit-identical to the other two paths, so the host picks by batch size (hess_l: from 64 points on); MPX_NO_LANES=1 /
+// MPX_LANES_MIN_BATCH=n (read per call) switch.
 static bool use_lanes(const mpx_asm_state* a, int ps, int64_t batch) {
   if (!a->lanes[ps].fn || getenv("MPX_NO_LANES")) return false;
   const char* mb = getenv("MPX_LANES_MIN_BATCH");
-  return batch >= std::max<int64_t>(mb ? atoll(mb) : 512, 64);
+  // (hess_l: faster than the other two paths from one block of 64 points on -- 6.3 against 11.6 us at B = 64, profiles/r5_lanes/ab9;
+  // the opt-in first-order pass keeps 512)
+  return batch >= std::max<int64_t>(mb ? atoll(mb) : (ps == 0 ? 64 : 512), 64);
 }
 
 static int launch_lanes(mpx_ctx* c, int ps, int64_t batch, const double* z, const double* lam, const double* sigma, double* const* out) {
