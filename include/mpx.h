@@ -425,6 +425,11 @@ int mpx_create_assembled(const mpx_assembly* desc, mpx_ctx** out);
  * mpx_asml_fgj: f + g + grad_f + jac_g requested together, an opt-in of the generator; batches of >= 64 / 512 points; one wavefront per group and 64 evaluation
  * points, a second small kernel for rows that sum over all groups).  All paths give the same bits. */
 int mpx_get_assembled_plan(const mpx_ctx* ctx, int32_t* fused_lanes, int32_t* hess_lane_groups, int32_t* first_order_lane_groups);
+/* Attach a second code object with the lane-per-evaluation-point kernels (mpx_asml_*, generated by mpopt_amd/assembly_lanes.py for
+ * the same transcription and the same order of the patterns) to an assembled context.  They serve batches only, and their straight-line
+ * code takes as long to compile as everything else of the context together: a caller that only ever evaluates single points (IPOPT)
+ * never pays for them -- the Python layer attaches them at the first batch of >= 64 points.  The code object is copied. */
+int mpx_assembled_attach_kernels(mpx_ctx* ctx, const void* code_object, size_t code_object_size);
 
 /* ---------------------------------------------------------------------------------------------
  * CasADi-external-compatible surface (mpx_casadi.cpp): the symbols nlp (the base oracle (x, p) -> (f, g) that

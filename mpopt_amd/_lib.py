@@ -216,6 +216,7 @@ SYMBOLS = {
     "mpx_get_notes": (ctypes.c_char_p, [ctypes.c_void_p]),
     "mpx_get_light_plan": (ctypes.c_int, [ctypes.c_void_p, c_int32_p, c_int64_p, c_int64_p, c_int64_p]),
     "mpx_get_assembled_plan": (ctypes.c_int, [ctypes.c_void_p, c_int32_p, c_int32_p, c_int32_p]),
+    "mpx_assembled_attach_kernels": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "mpx_get_partials": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), c_int64_p]),
     "mpx_shard_setup": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "mpx_shard_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_int64_p, c_int64_p]),

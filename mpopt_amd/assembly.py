@@ -224,7 +224,7 @@ class AssembledNlpFunctions(NlpFunctions):
         from . import assembly_lanes
         import os
         self.lanes_plan = self.lanes_plan_fgj = None
-        lanes_src = None
+        self.lanes_source, self._lanes_attached = None, False
         if not os.environ.get("MPX_NO_LANES_CODE"):
             self.lanes_plan = assembly_lanes.plan_pass(self, "hes")
             # (the first-order pass this way is an opt-in, MPX_LANES_FGJ=1: bit-identical, but the pass is 96 % output and the fused kernel
@@ -237,8 +237,12 @@ class AssembledNlpFunctions(NlpFunctions):
                     mt = sizes["MT_" + tag]
                     parts.append(assembly_lanes.pass_source(self, mt if mt >= 2 else 24, plan))
             if parts:
-                lanes_src = "\n".join([assembly_lanes.common_source(self)] + parts)
-        self.source = self._source(funcs, sizes, self._set_consts, extra=lanes_src)
+                # a translation unit of its own, compiled and attached at the first batch (attach_lane_kernels): its straight-line code
+                # takes as long to compile as the rest of the context together, and a solve through single evaluations never runs it
+                self.lanes_source = "\n".join(["// generated by mpopt_amd.assembly_lanes -- do not edit", "#include <hip/hip_runtime.h>", "namespace mpxgen {",
+                                               "template <int FID> struct Pt;"] + [f.source(k) for k, f in enumerate(funcs)] +
+                                              ["}  // namespace mpxgen", assembly_lanes.common_source(self)] + parts) + "\n"
+        self.source = self._source(funcs, sizes, self._set_consts)
         if with_device is None:
             with_device = _lib.gpu_available()
         self.code_object = None
@@ -246,9 +250,30 @@ class AssembledNlpFunctions(NlpFunctions):
             self.code_object, self.code_object_path = _lib.compile_kernels(self.source, verbose=verbose)
         self._create(device)
 
+    def attach_lane_kernels(self, verbose=False):
+        """Compile (cached) and attach the lane-per-evaluation-point kernels of this transcription (mpx_assembled_attach_kernels).
+        Called by the evaluation methods at the first batch of >= 64 points; idempotent."""
+        if self._lanes_attached or self.lanes_source is None or self.code_object is None:
+            return
+        co, _ = _lib.compile_kernels(self.lanes_source, verbose=verbose)
+        buf = ctypes.create_string_buffer(co, len(co))
+        _lib.check(self._L.mpx_assembled_attach_kernels(self._ctx, ctypes.cast(buf, ctypes.c_void_p), len(co)), self._ctx)
+        self._lanes_attached = True
+
+    def eval_device(self, mask, batch, *args, **kwargs):
+        if batch >= 64 and not self._lanes_attached:
+            self.attach_lane_kernels()
+        return super().eval_device(mask, batch, *args, **kwargs)
+
+    def eval(self, what, z, *args, **kwargs):
+        if not self._lanes_attached and np.ndim(z) == 2 and np.shape(z)[0] >= 64:
+            self.attach_lane_kernels()
+        return super().eval(what, z, *args, **kwargs)
+
     def batched_plan(self):
         """(lanes per workgroup of the fused kernels, groups of the lane-per-point hess_l kernel, groups of the lane-per-point first-order
-        kernel) the context's code object carries (mpx_get_assembled_plan); 0: that kernel is absent."""
+        kernel) the context carries (mpx_get_assembled_plan; attaches the lane kernels if that has not happened yet); 0: absent."""
+        self.attach_lane_kernels()
         a, b, d = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
         _lib.check(self._L.mpx_get_assembled_plan(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(d)), self._ctx)
         return a.value, b.value, d.value

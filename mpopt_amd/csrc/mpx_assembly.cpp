@@ -61,6 +61,7 @@ struct mpx_asm_state {
     int groups = 0, n_global = 0, n_sid = 0;
   } lanes[2];
   DevBuf<double> lane_scratch;
+  hipModule_t lanes_module = nullptr;  // the code object attached later with the lane kernels (mpx_assembled_attach_kernels)
   int fuse_nt = 0, fuse_u[2] = {0, 0};  // lanes per workgroup; evaluation points per workgroup pass (first order, Hessian); 0: no kernel
   int fuse_wg[3] = {0, 0, 0};           // resident workgroups per launch (compute units x occupancy)
   long long* dbg = nullptr;             // MPX_FUSE_DEBUG
@@ -312,10 +313,51 @@ void mpx_asm_release(mpx_ctx* c) {
   for (auto q : a->d_loc_pack) fr(q);
   for (auto q : a->d_mu_pack) fr(q);
   fr(a->d_l_dict), fr(a->d_m_dict);
+  fr(a->lane_scratch.p);
+  if (a->lanes_module) (void)hipModuleUnload(a->lanes_module);
   fr(a->raw.p), fr(a->d_sets), fr(a->d_task_ptr[0]), fr(a->d_task_ptr[1]), fr(a->d_task_list[0]), fr(a->d_task_list[1]);
   if (a->dbg) (void)hipHostFree(a->dbg);
   delete a;
   c->assembled = nullptr;
+}
+
+// The lane-per-point kernels of a code object (generated when the point tasks fall into groups: mpopt_amd/assembly_lanes.py), either the
+// context's own or one attached later (mpx_assembled_attach_kernels): mpx_asml_<pass>_info = {groups, tile doubles, nnz of the pass's
+// pattern (a check), global rows, scratch slots}.
+static void load_lanes(mpx_asm_state* a, hipModule_t mod, int64_t nnz_hess, int64_t nnz_jac) {
+  for (int ps = 0; ps < 2; ++ps) {
+    static const char* iname[2] = {"mpx_asml_hes_info", "mpx_asml_fgj_info"};
+    static const char* kname2[2] = {"mpx_asml_hes", "mpx_asml_fgj"};
+    static const char* gname[2] = {"mpx_asml_hes_global", "mpx_asml_fgj_global"};
+    int li[5] = {0, 0, 0, 0, 0};
+    hipFunction_t fl = nullptr, fg = nullptr;
+    hipDeviceptr_t sym = nullptr;
+    size_t bytes = 0;
+    if (hipModuleGetGlobal(&sym, &bytes, mod, iname[ps]) == hipSuccess && bytes == sizeof li && hipMemcpyDtoH(li, sym, sizeof li) == hipSuccess &&
+        li[0] >= 1 && li[2] == (int)(ps == 0 ? nnz_hess : nnz_jac) && hipModuleGetFunction(&fl, mod, kname2[ps]) == hipSuccess &&
+        (li[3] == 0 || hipModuleGetFunction(&fg, mod, gname[ps]) == hipSuccess))
+      a->lanes[ps].fn = fl, a->lanes[ps].fn_global = fg, a->lanes[ps].groups = li[0], a->lanes[ps].n_global = li[3], a->lanes[ps].n_sid = li[4];
+  }
+  (void)hipGetLastError();
+}
+
+extern "C" int mpx_assembled_attach_kernels(mpx_ctx* c, const void* code_object, size_t size) {
+  if (!c || c->kind != 1 || !code_object || !size) return fail(c, MPX_ERR_INVALID, "mpx_assembled_attach_kernels: an assembled context and a code object");
+  if (!c->has_device || !c->assembled) return fail(c, MPX_ERR_UNSUPPORTED, "mpx_assembled_attach_kernels: the context has no device");
+  mpx_asm_state* a = c->assembled;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (a->lanes_module) {  // (replaces what was attached before)
+    a->lanes[0] = a->lanes[1] = mpx_asm_state::Lanes();
+    (void)hipModuleUnload(a->lanes_module);
+    a->lanes_module = nullptr;
+  }
+  if (hipModuleLoadData(&a->lanes_module, code_object) != hipSuccess) {
+    a->lanes_module = nullptr;
+    return fail(c, MPX_ERR_HIP, "mpx_assembled_attach_kernels: hipModuleLoadData failed (is the code object built for this GPU?)");
+  }
+  load_lanes(a, a->lanes_module, c->nnz_h, c->nnz_j);
+  return MPX_OK;
 }
 
 extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
@@ -565,17 +607,7 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
       }
     }
     (void)hipGetLastError();
-    for (int ps = 0; ps < 2; ++ps) {  // the lane-per-point kernels (generated when the point tasks fall into groups: mpopt_amd/assembly_lanes.py)
-      static const char* iname[2] = {"mpx_asml_hes_info", "mpx_asml_fgj_info"};
-      static const char* kname2[2] = {"mpx_asml_hes", "mpx_asml_fgj"};
-      static const char* gname[2] = {"mpx_asml_hes_global", "mpx_asml_fgj_global"};
-      int li[5] = {0, 0, 0, 0, 0};
-      hipFunction_t fl = nullptr, fg = nullptr;
-      if (hipModuleGetGlobal(&sym, &bytes, c->module, iname[ps]) == hipSuccess && bytes == sizeof li && hipMemcpyDtoH(li, sym, sizeof li) == hipSuccess &&
-          li[0] >= 1 && li[2] == (int)(ps == 0 ? D->nnz_hess : D->nnz_jac) && hipModuleGetFunction(&fl, c->module, kname2[ps]) == hipSuccess &&
-          (li[3] == 0 || hipModuleGetFunction(&fg, c->module, gname[ps]) == hipSuccess))
-        a->lanes[ps].fn = fl, a->lanes[ps].fn_global = fg, a->lanes[ps].groups = li[0], a->lanes[ps].n_global = li[3], a->lanes[ps].n_sid = li[4];
-    }
+    load_lanes(a, c->module, D->nnz_hess, D->nnz_jac);  // (code objects that carry the lane kernels themselves)
     (void)hipGetLastError();
   }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "hipEventCreate failed"));

@@ -373,11 +373,12 @@ def test_lane_plan_of_assembled_hessians(builder, S, P, scheme, expect, monkeypa
     monkeypatch.setenv("MPX_NO_LANES_CODE", "1")
     o2 = mp.mpopt_adaptive(builder(mp, M.math), S, P, scheme).create_nlp()[0]["oracle"]
     monkeypatch.delenv("MPX_NO_LANES_CODE")
-    assert o2.lanes_plan is None and o2.lanes_plan_fgj is None and "mpx_asml" not in o2.source
+    assert o2.lanes_plan is None and o2.lanes_plan_fgj is None and o2.lanes_source is None and "mpx_asml" not in o2.source
     key = lambda r, c: sorted(zip(np.asarray(r).tolist(), np.asarray(c).tolist()))
     assert key(*o.hess_pattern()) == key(*o2.hess_pattern()) and key(*o.jac_pattern()) == key(*o2.jac_pattern())
+    assert "mpx_asml" not in o.source and "LaneGrp" not in o.source  # (the lane kernels are a translation unit of their own, attached at the first batch)
     if pl is None and o.lanes_plan_fgj is None:
-        assert "mpx_asml" not in o.source
+        assert o.lanes_source is None
         return
     for plan in (pl, o.lanes_plan_fgj):
         if plan is None:
@@ -411,7 +412,7 @@ def test_lane_plan_of_assembled_hessians(builder, S, P, scheme, expect, monkeypa
                     assert {int(c) for c, d in zip(s_.L.indices[lo:hi], s_.L.data[lo:hi]) if d != 0} <= zc
             for kp, lst in g["scratch"].items():  # scratch slots are written by the group that owns the task, once
                 assert kp in g["own"]
-            assert f"struct LaneGrp{KIND}<{gi}>" in o.source
+            assert f"struct LaneGrp{KIND}<{gi}>" in o.lanes_source
         assert seen == set(range(Pq.n_rows))  # every row: one group, or global
         # the reordered array (hess_l / jac_g): group by group, the global rows last
         last = len(Pq.arrays) - 1
@@ -419,4 +420,4 @@ def test_lane_plan_of_assembled_hessians(builder, S, P, scheme, expect, monkeypa
         assert rows_last == list(range(Pq.arrays[last][1], Pq.arrays[last][1] + Pq.arrays[last][2]))
         written = [sd for g in plan.groups for lst in g["scratch"].values() for _, sd in lst]
         assert sorted(written) == list(range(len(plan.sid)))
-        assert f"#define MPX_LANE_{KIND}_GROUPS {len(plan.groups)}" in o.source and f"MPX_INSTANTIATE_LANES({plan.kind}, {KIND}," in o.source
+        assert f"#define MPX_LANE_{KIND}_GROUPS {len(plan.groups)}" in o.lanes_source and f"MPX_INSTANTIATE_LANES({plan.kind}, {KIND}," in o.lanes_source

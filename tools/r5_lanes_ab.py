@@ -27,12 +27,14 @@ for fl in [x for x in os.environ.get("FLAGS", "").split(";") if x]:
         m2 = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
         keep.append(m2)
         VARIANTS.append(("lanes " + fl, {}, m2.create_nlp()[0]["oracle"]))
+        VARIANTS[-1][2].batched_plan()
         del os.environ["MPX_LANES_CHUNK"]
         continue
     os.environ["MPX_HIPCC_FLAGS"] = fl
     m2 = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
     keep.append(m2)
     VARIANTS.append(("lanes " + fl, {}, m2.create_nlp()[0]["oracle"]))
+    VARIANTS[-1][2].batched_plan()  # (compiles and attaches the lane kernels while the flags are set)
 os.environ.pop("MPX_HIPCC_FLAGS", None)
 for B in [int(b) for b in os.environ.get("B", "512 1024 4096 4133 16384").split()]:
     rng = np.random.default_rng(B)
