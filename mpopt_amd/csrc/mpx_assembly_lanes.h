@@ -187,6 +187,12 @@ __device__ __forceinline__ void lane_global_row(const ::MpxLaneArgs& A, int blk,
 // Two wavefronts per SIMD (<= 256 registers instead of the 260 the allocator takes when left alone): a batch of 4096 evaluation points
 // is 1280 wavefronts, and with five per compute unit (LDS) they are all resident at once -- 21.6 -> 18.3 us at moon lander 20x5
 // (profiles/r5_lanes); 0: no bound.
+// (Every wavefront of a small batch starts at the same time and the phases of a group take the same time everywhere: loads, then
+// arithmetic, then stores, chip-wide.  MPX_LANE_STAGGER=n: every other wavefront starts n x 64 x 64 cycles late -- measured, see
+// profiles/r5_lanes.)
+#ifndef MPX_LANE_STAGGER
+#define MPX_LANE_STAGGER 0
+#endif
 #ifndef MPX_LANE_WAVES_PER_EU
 #define MPX_LANE_WAVES_PER_EU 2
 #endif
@@ -214,6 +220,8 @@ __device__ __forceinline__ void lane_global_row(const ::MpxLaneArgs& A, int blk,
     const int g = A.order ? idx / nb8 : idx % MPX_LANE_##KIND##_GROUPS;                                                         \
     const int blk = (A.order ? idx % nb8 : idx / MPX_LANE_##KIND##_GROUPS) * 8 + xcd;                                           \
     if (blk >= A.n_blocks) return;                                                                                              \
+    if (MPX_LANE_STAGGER > 0 && (idx & 1))                                                                                      \
+      for (int k = 0; k < MPX_LANE_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);                                                  \
     mpxk::LaneDispatch<mpxgen::LaneGrp##KIND, mpxgen::LaneST##KIND, MPX_LANE_##KIND##_GROUPS - 1>::run(A, g, blk, T);           \
   }                                                                                                                             \
   extern "C" __global__ __launch_bounds__(64) void mpx_asml_##kind##_global(const MpxLaneArgs A) {                              \
