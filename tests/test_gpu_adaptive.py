@@ -39,6 +39,15 @@ def test_adaptive_matches_reference_golden(name):
     assert_coo_close(hr, hc, r["hess_l"], G["hess_row"], G["hess_col"], G["hess_val"], TOL, "hess_l")
     r0 = o.eval(["f", "g"], G["z0"], None)
     assert rel_err(r0["f"], G["f_z0_equal"]) < TOL and rel_err(r0["g"], G["g_z0_equal"]) < TOL
+    # the same golden point as every point of a batch of 64 + 5: hess_l then comes from the lane-per-evaluation-point kernel where the
+    # transcription has groups (three of the five cases), else from the two-pass kernels -- against the reference's values either way
+    B = 69
+    rb = o.eval(["hess_l"], np.tile(z, (B, 1)), None, lam_g=np.tile(lam, (B, 1)), sigma=np.full(B, sig))
+    if name in ("adaptive_van_der_pol_mixed_CGL", "adaptive_hyper_sensitive_4x3_LGL", "adaptive_generic_two_phase_LGR"):
+        assert o.lanes_plan is not None and o.batched_plan()[1] > 0
+    for b in (0, 37, 63, 64, 68):
+        assert_coo_close(hr, hc, rb["hess_l"][b], G["hess_row"], G["hess_col"], G["hess_val"], TOL, f"hess_l (batch, point {b})")
+        assert np.array_equal(rb["hess_l"][b], r["hess_l"])
 
 
 @pytest.mark.parametrize("name", ["adaptive_moon_lander_3x2_LGR", "adaptive_van_der_pol_mixed_CGL"])
