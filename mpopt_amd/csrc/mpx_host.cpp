@@ -281,7 +281,9 @@ int build_layout(mpx_ctx* c) {
       const int cap_limit = std::min(64 * MPX_LIGHT_CHUNKS, (int)((int64_t)(53248 - 8 * (int64_t)L.ftab.size()) / (8 * MPX_LIGHT_WAVES * nin)));  // the span rows of a workgroup's wavefronts in 52 KB of LDS (+ 9 KB of tables: under the 64 KB a launch gets by default, two workgroups per compute unit)
       L.deg = dL, L.dt = deg_index(c, dL), L.first_node = segsL[0] == 0 ? 1 : 0, L.ok = true;
       for (int i = 0; i < nL && L.ok;) {
-        int cnt = std::min(16, nL - i);
+        int seg_cap = 16;  // high-degree segments of a group = columns of the matrix instructions (MPX_LIGHT_SEGS=n: fewer, A/B)
+        if (const char* e = getenv("MPX_LIGHT_SEGS")) seg_cap = std::min(16, std::max(1, atoi(e)));
+        int cnt = std::min(seg_cap, nL - i);
         for (; cnt > 0; --cnt) {  // as many segments as the span buffer and the foreign-node slots (2 turns of 64 lanes) hold
           const int64_t lo_w = i == 0 ? 0 : (int64_t)c->seg_start[segsL[i]] + 1, hi = i + cnt < nL ? (int64_t)c->seg_start[segsL[i + cnt]] + 1 : N;
           const int64_t lo_r = std::max<int64_t>(lo_w - 1, 0);

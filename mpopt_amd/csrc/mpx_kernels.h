@@ -2371,11 +2371,14 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
 
 #define MPX_INSTANTIATE_LIGHT(PH, P) MPX_INSTANTIATE_LIGHT_PF(PH, P, 0)
 // (PF: the grid's one low degree, 0 if it has none or several -- light_body)
+#ifndef MPX_LIGHT_MIN_WG
+#define MPX_LIGHT_MIN_WG 2  // workgroups per compute unit the light kernels are compiled for (A/B with MPX_LIGHT_SEGS / MPX_LIGHT_PER_CU)
+#endif
 #define MPX_INSTANTIATE_LIGHT_PF(PH, P, PF)                                                                                   \
-  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_light_fg_##PH##_##P(const MpxLightArgs A) {          \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LIGHT_MIN_WG) void mpx_light_fg_##PH##_##P(const MpxLightArgs A) {          \
     mpxk::light_body<PH, P, MPX_MODE_FG, PF>(A);                                                                              \
   }                                                                                                                           \
-  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, 2) void mpx_light_fgq_##PH##_##P(const MpxLightArgs A) {         \
+  extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LIGHT_MIN_WG) void mpx_light_fgq_##PH##_##P(const MpxLightArgs A) {         \
     mpxk::light_body<PH, P, MPX_MODE_FGJ, PF>(A);                                                                             \
   }
 

@@ -10,10 +10,16 @@ flags = sys.argv[1:] or [""]
 builder, S, P, scheme = problems.BENCH_CASES[int(os.environ.get("CASE", 0))]
 B = int(os.environ.get("B", 4096))
 ctx = []
-for fl in flags:
-    os.environ["MPX_HIPCC_FLAGS"] = fl
+percu = []
+for fl in flags:  # (tokens SEGS=n / PERCU=n inside a flag string: MPX_LIGHT_SEGS at context creation, MPX_LIGHT_PER_CU around that context's calls)
+    toks = fl.split()
+    os.environ["MPX_HIPCC_FLAGS"] = " ".join(t for t in toks if not t.startswith(("SEGS=", "PERCU=")))
+    for t in toks:
+        if t.startswith("SEGS="): os.environ["MPX_LIGHT_SEGS"] = t[5:]
+    percu.append(next((t[6:] for t in toks if t.startswith("PERCU=")), None))
     mpo = mp.mpopt(builder(mp, M.math), S, P, scheme)
     ctx.append((mpo, mpo.create_nlp()[0]["oracle"]))
+    os.environ.pop("MPX_LIGHT_SEGS", None)
 os.environ.pop("MPX_HIPCC_FLAGS")
 mpo, o = ctx[0]
 dev = torch.device("cuda", 0)
@@ -32,6 +38,8 @@ for name, mask in ((("f+g+grad_f+jac_g", 15), ("hess_l", 16)) if heavy else (("f
     res, outs = [[] for _ in ctx], []
     for rnd in range(6):
         for k, (_, ok) in enumerate(ctx):
+            os.environ.pop("MPX_LIGHT_PER_CU", None)
+            if percu[k]: os.environ["MPX_LIGHT_PER_CU"] = percu[k]
             for _ in range(3): ok.eval_device(*args)
             ok.sync(); ok.timer_start()
             for _ in range(30): ok.eval_device(*args)
