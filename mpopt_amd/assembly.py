@@ -280,7 +280,7 @@ class AssembledNlpFunctions(NlpFunctions):
 
     # -- generated source ---------------------------------------------------------------------------
     @staticmethod
-    def _source(funcs, sizes, set_consts=(), extra=None):
+    def _source(funcs, sizes, set_consts=()):
         parts = ["// generated by mpopt_amd.assembly -- do not edit", "#include <hip/hip_runtime.h>", "namespace mpxgen {",
                  "template <int FID> struct Pt;"]
         parts += [f.source(k) for k, f in enumerate(funcs)]
@@ -302,8 +302,6 @@ class AssembledNlpFunctions(NlpFunctions):
                              f"  __host__ __device__ static constexpr int mt(int r) {{ constexpr int a[] = {arr(mt)}; return a[r]; }}\n}};")
             parts += ["}  // namespace mpxgen", f"#define MPX_FUSE_SETS {len(set_consts)}"]
         parts += ['#include "mpx_assembly_fused.h"', f"MPX_INSTANTIATE_FUSED({len(funcs)})"]
-        if extra:
-            parts.append(extra)
         return "\n".join(parts) + "\n"
 
     # -- expansion of the chain rule into gather rows -------------------------------------------------
