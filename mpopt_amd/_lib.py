@@ -52,7 +52,7 @@ def hipcc():
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("mpx_host.cpp", "mpx_shard.cpp", "mpx_equal_area.cpp", "mpx_assembly.cpp", "mpx_colloc.cpp", "mpx_casadi.cpp", "mpx_device.h",
+    return [os.path.join(CSRC, f) for f in ("mpx_host.cpp", "mpx_layout.cpp", "mpx_shard.cpp", "mpx_equal_area.cpp", "mpx_assembly.cpp", "mpx_colloc.cpp", "mpx_casadi.cpp", "mpx_device.h",
                                             "mpx_internal.h", "mpx_scan.h", "mpx_assembly_kernels.h")] + [os.path.join(INCLUDE, "mpx.h")]
 
 
@@ -106,6 +106,7 @@ def _build_library_in(tmp, verbose):
     cobj = os.path.join(tmp, "mpx_casadi.o")
     aobj = os.path.join(tmp, "mpx_assembly.o")
     sobj, eobj = os.path.join(tmp, "mpx_shard.o"), os.path.join(tmp, "mpx_equal_area.o")
+    lobj = os.path.join(tmp, "mpx_layout.o")
     out = os.path.join(tmp, "libmpx.so")
     extra = os.environ.get("MPX_LIB_HIPCC_FLAGS", "").split()  # diagnostics builds (-DMPX_EA_STAMPS ...)
     cmds = [
@@ -114,12 +115,14 @@ def _build_library_in(tmp, verbose):
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
          os.path.join(CSRC, "mpx_host.cpp"), "-o", hobj] + extra,
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
+         os.path.join(CSRC, "mpx_layout.cpp"), "-o", lobj] + extra,
+        [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
          os.path.join(CSRC, "mpx_assembly.cpp"), "-o", aobj] + extra,
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
          os.path.join(CSRC, "mpx_shard.cpp"), "-o", sobj] + extra,
         [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c",
          os.path.join(CSRC, "mpx_equal_area.cpp"), "-o", eobj] + extra,
-        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, aobj, sobj, eobj, obj, cobj, "-o", out],
+        [cc, f"--offload-arch={ARCH}", "-fPIC", "-shared", hobj, lobj, aobj, sobj, eobj, obj, cobj, "-o", out],
     ]
     for cmd in cmds:
         r = subprocess.run(cmd, capture_output=True, text=True)

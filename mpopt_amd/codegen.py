@@ -318,7 +318,7 @@ class ProblemProgram:
 
     def light_low_chunks(self, d):
         """64-node chunks per span of the low-degree light kernels, exactly as light_low_body (mpx_kernels.h: CAP0 / CHL) and the
-        host's plan (mpx_host.cpp: lplan, `ok = chl >= 2`) compute them: the X / U rows of MPX_LIGHT_WAVES = 4 wavefronts share 52 KB
+        host's plan (mpx_layout.cpp: lplan, `ok = chl >= 2`) compute them: the X / U rows of MPX_LIGHT_WAVES = 4 wavefronts share 52 KB
         of LDS.  Problems with many states + controls (nx + nu > ~11 at degree 3) get fewer than two chunks: the host would not use
         the kernels, and from ~24 inputs on their span rows do not fit the LDS of a workgroup at all (static_assert in the kernel) --
         so they are not instantiated (the node kernels serve the light passes of such problems, as before round 4)."""

@@ -311,6 +311,12 @@ inline int reserve_wcum(mpx_ctx* c, size_t n) {
 }
 inline uint32_t all_phases(const mpx_ctx* c) { return c->n_phases >= 32 ? ~0u : ((1u << c->n_phases) - 1u); }
 
+// mpx_layout.cpp -- the planner of mpx_create: structure words -> phases; per-degree tables; tiles, index maps, patterns, light plans
+int parse_structure(mpx_ctx* c, const int32_t* s, int64_t len);
+int build_tables(mpx_ctx* c);
+int deg_index(const mpx_ctx* c, int d);
+int build_layout(mpx_ctx* c);
+
 }  // namespace mpxi
 
 // mpx_assembly.cpp

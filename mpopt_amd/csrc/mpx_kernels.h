@@ -114,7 +114,7 @@ typedef double mpx_d2 __attribute__((ext_vector_type(2)));
 // that one store instruction of a wavefront writes ONE contiguous run with 16 bytes per lane:
 //     slots are interleaved in pairs:  index(q, l) = (q/2)*2n + 2l + (q&1)      for q < NS - (NS&1)
 //     an unpaired last slot is plain:  index(NS-1, l) = (NS-1)*n + l
-// (the COO patterns reported by mpx_pattern_* follow the same formula, mpx_host.cpp).  Measured on
+// (the COO patterns reported by mpx_pattern_* follow the same formula, mpx_layout.cpp).  Measured on
 // MI355X (tools/store_bw.hip): 16 B/lane contiguous stores stream at 5.2-5.5 TB/s, 8 B/lane at
 // 4.4-5.0 TB/s, nontemporal stores are slower than both.
 // Addressing: uniform base (SGPRs) + ONE running 32-bit byte offset per lane.  The offsets are loop
@@ -144,7 +144,7 @@ __device__ __forceinline__ void scatter_slots(double* __restrict__ blk, int64_t 
       w.x = sv(q);
       w.y = sv(q + 1);
       *reinterpret_cast<mpx_d2*>(base + off) = w;
-    } else {  // block not 16-byte aligned (odd-sized blocks come last, mpx_host.cpp)
+    } else {  // block not 16-byte aligned (odd-sized blocks come last, mpx_layout.cpp)
       *reinterpret_cast<double*>(base + off) = sv(q);
       *reinterpret_cast<double*>(base + off + 8u) = sv(q + 1);
     }
@@ -1043,7 +1043,7 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
         const MpxLightForeign F = Fd[u];
         constexpr bool SLOW = PF > 0 && MPX_LIGHT_STATIC_LOW;
 #if MPX_LIGHT_DESC_LDS
-        // (one low degree, compile time: its two tables are the whole of sTab -- D at 0, C_mid behind it, mpx_host.cpp: lplan.ftab)
+        // (one low degree, compile time: its two tables are the whole of sTab -- D at 0, C_mid behind it, mpx_layout.cpp: lplan.ftab)
         const int di = F.dk >> 8, k = F.dk & 255, pf = SLOW ? PF : sFdeg[di], p1f = pf + 1;
         const double* __restrict__ Dr = sTab + (SLOW ? 0 : sFD[di]) + k * p1f;
         const double* __restrict__ Cr = sTab + (SLOW ? (PF + 1) * (PF + 1) : sFC[di]) + (k >= 1 ? k - 1 : 0) * p1f;

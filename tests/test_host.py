@@ -163,7 +163,7 @@ def test_wide_problems_compile_and_get_low_degree_light_kernels_only_when_they_f
     """Round-4 advisor finding: MPX_INSTANTIATE_LIGHT_LOW was emitted for every single-degree grid of degree <= 12, and
     light_low_body's span rows (4 wavefronts x (nx + nu) rows) do not fit the LDS of a workgroup from ~24 inputs on -- the code
     object of OCP(n_states=20, n_controls=6) no longer compiled, create_nlp on a GPU raised.  The generator now instantiates them
-    only where the host's plan would use them (>= 2 chunks per span, the same arithmetic as mpx_host.cpp / mpx_kernels.h), and every
+    only where the host's plan would use them (>= 2 chunks per span, the same arithmetic as mpx_layout.cpp / mpx_kernels.h), and every
     width compiles (hipcc cross-compiles gfx950 without a GPU)."""
     ocp = mp.OCP(n_states=nx, n_controls=nu)
     ocp.dynamics[0] = lambda x, u, t: [u[i % nu] - 0.1 * x[i] * x[(i + 1) % nx] for i in range(nx)]
