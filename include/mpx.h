@@ -428,7 +428,8 @@ int mpx_get_assembled_plan(const mpx_ctx* ctx, int32_t* fused_lanes, int32_t* he
 /* Attach a second code object with the lane-per-evaluation-point kernels (mpx_asml_*, generated by mpopt_amd/assembly_lanes.py for
  * the same transcription and the same order of the patterns) to an assembled context.  They serve batches only, and their straight-line
  * code takes as long to compile as everything else of the context together: a caller that only ever evaluates single points (IPOPT)
- * never pays for them -- the Python layer attaches them at the first batch of >= 64 points.  The code object is copied. */
+ * never pays for them -- the Python layer attaches them at the first batch of >= 64 points.  The image is handed to hipModuleLoadData
+ * like mpx_assembly.code_object; the Python layer keeps both buffers for the life of the context. */
 int mpx_assembled_attach_kernels(mpx_ctx* ctx, const void* code_object, size_t code_object_size);
 
 /* ---------------------------------------------------------------------------------------------

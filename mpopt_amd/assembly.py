@@ -256,8 +256,8 @@ class AssembledNlpFunctions(NlpFunctions):
         if self._lanes_attached or self.lanes_source is None or self.code_object is None:
             return
         co, _ = _lib.compile_kernels(self.lanes_source, verbose=verbose)
-        buf = ctypes.create_string_buffer(co, len(co))
-        _lib.check(self._L.mpx_assembled_attach_kernels(self._ctx, ctypes.cast(buf, ctypes.c_void_p), len(co)), self._ctx)
+        self._lanes_co_buf = ctypes.create_string_buffer(co, len(co))  # (kept like the context's own code object)
+        _lib.check(self._L.mpx_assembled_attach_kernels(self._ctx, ctypes.cast(self._lanes_co_buf, ctypes.c_void_p), len(co)), self._ctx)
         self._lanes_attached = True
 
     def eval_device(self, mask, batch, *args, **kwargs):
