@@ -145,6 +145,7 @@ def plan_pass(o, kind, min_tasks=8, max_tasks=40, max_raw=None, max_tile=300):
     ptr, src = P.ptr, P.src
     n_rows, tasks, n_t = P.n_rows, P.tasks, len(P.tasks)
     verbose = os.environ.get("MPX_LANES_VERBOSE")
+    min_tasks = int(os.environ.get("MPX_LANES_MIN_TASKS", min_tasks))  # (own tasks of a group: min_tasks .. 2 min_tasks; A/B)
     if max_raw is None:
         max_raw = int(os.environ.get("MPX_LANES_MAX_RAW", 400))  # (Van der Pol 10x6, 264 raw values per group: 30.5 against 180 us fused)
     if n_rows == 0 or P.raw_n == 0 or n_t < 2 * min_tasks:

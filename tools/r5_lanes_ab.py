@@ -22,13 +22,15 @@ for od in [x for x in os.environ.get("ORDERS", "").split() if x]:  # ORDERS="0 1
     VARIANTS.append((f"lanes order {od}", {"MPX_LANES_ORDER": od}, o))
 keep = []
 for fl in [x for x in os.environ.get("FLAGS", "").split(";") if x]:
-    if fl.startswith("CHUNK="):  # (a generation-time switch, not a compiler flag: MPX_LANES_CHUNK)
-        os.environ["MPX_LANES_CHUNK"] = fl[6:]
+    if fl.startswith(("CHUNK=", "MIN_TASKS=")):  # (generation-time switches, not compiler flags: MPX_LANES_CHUNK, MPX_LANES_MIN_TASKS)
+        key = "MPX_LANES_" + fl.split("=")[0]
+        os.environ[key] = fl.split("=")[1]
         m2 = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
         keep.append(m2)
         VARIANTS.append(("lanes " + fl, {}, m2.create_nlp()[0]["oracle"]))
         VARIANTS[-1][2].batched_plan()
-        del os.environ["MPX_LANES_CHUNK"]
+        print(fl, "->", len(VARIANTS[-1][2].lanes_plan.groups), "groups,", VARIANTS[-1][2].lanes_plan.halo_tasks, "halo tasks")
+        del os.environ[key]
         continue
     os.environ["MPX_HIPCC_FLAGS"] = fl
     m2 = mp.mpopt_adaptive(getattr(problems, name)(mp, M.math), S, P, "LGR")
