@@ -260,14 +260,22 @@ class AssembledNlpFunctions(NlpFunctions):
         _lib.check(self._L.mpx_assembled_attach_kernels(self._ctx, ctypes.cast(self._lanes_co_buf, ctypes.c_void_p), len(co)), self._ctx)
         self._lanes_attached = True
 
+    def _wants_lanes(self, mask, batch):
+        """A batch of a pass that has lane kernels (hess_l; the first-order pass only as the MPX_LANES_FGJ opt-in)?"""
+        return (batch >= 64 and not self._lanes_attached and self.lanes_source is not None and
+                ((mask & _lib.MPX_HESS and self.lanes_plan is not None) or (mask & 15) == 15 and self.lanes_plan_fgj is not None))
+
     def eval_device(self, mask, batch, *args, **kwargs):
-        if batch >= 64 and not self._lanes_attached:
+        if self._wants_lanes(int(mask), int(batch)):
             self.attach_lane_kernels()
         return super().eval_device(mask, batch, *args, **kwargs)
 
     def eval(self, what, z, *args, **kwargs):
-        if not self._lanes_attached and np.ndim(z) == 2 and np.shape(z)[0] >= 64:
-            self.attach_lane_kernels()
+        if np.ndim(z) == 2:
+            names = set(what)
+            mask = (_lib.MPX_HESS if "hess_l" in names else 0) | (15 if {"f", "g", "grad_f", "jac_g"} <= names else 0)
+            if self._wants_lanes(mask, np.shape(z)[0]):
+                self.attach_lane_kernels()
         return super().eval(what, z, *args, **kwargs)
 
     def batched_plan(self):
