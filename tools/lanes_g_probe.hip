@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+#ifndef NO_CONTRACTION
+#define NO_CONTRACTION 0  // 1: one term per row instead of 31 -- the data movement and the node functions alone
+#endif
 constexpr int LDW = 65, P = 30, P1 = 31, PF = 3;
 #define SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -95,7 +98,7 @@ extern "C" __global__ __launch_bounds__(64) void probe(const Args A) {
     for (int k = 1; k <= P; ++k) {
       double acc = 0;
 #pragma unroll
-      for (int j = 0; j < P1; ++j) acc = __builtin_fma(A.D[k * P1 + j], x0[j], acc);
+      for (int j = 0; j < (NO_CONTRACTION ? 1 : P1); ++j) acc = __builtin_fma(A.D[k * P1 + j], x0[j], acc);
       r[k - 1] = acc - kap * ((1.0 - x1[k] * x1[k]) * x0[k] - x1[k] + u[k]);
     }
     store30(gb, A.gs, st + 1, lane, T, r);
@@ -103,7 +106,7 @@ extern "C" __global__ __launch_bounds__(64) void probe(const Args A) {
     for (int k = 1; k <= P; ++k) {
       double acc = 0;
 #pragma unroll
-      for (int j = 0; j < P1; ++j) acc = __builtin_fma(A.D[k * P1 + j], x1[j], acc);
+      for (int j = 0; j < (NO_CONTRACTION ? 1 : P1); ++j) acc = __builtin_fma(A.D[k * P1 + j], x1[j], acc);
       r[k - 1] = acc - kap * x0[k];
     }
     store30(gb + N, A.gs, st + 1, lane, T, r);
@@ -111,7 +114,7 @@ extern "C" __global__ __launch_bounds__(64) void probe(const Args A) {
     for (int k = 1; k <= P; ++k) {
       double acc = 0;
 #pragma unroll
-      for (int j = 0; j < P1; ++j) acc = __builtin_fma(A.C[(k - 1) * P1 + j], u[j], acc);
+      for (int j = 0; j < (NO_CONTRACTION ? 1 : P1); ++j) acc = __builtin_fma(A.C[(k - 1) * P1 + j], u[j], acc);
       r[k - 1] = acc;
     }
     store30(gb + 2 * (int64_t)N, A.gs, st, lane, T, r);
