@@ -271,6 +271,7 @@ class AssembledNlpFunctions(NlpFunctions):
         return super().eval_device(mask, batch, *args, **kwargs)
 
     def eval(self, what, z, *args, **kwargs):
+        what = list(what)  # (iterated twice)
         if np.ndim(z) == 2:
             names = set(what)
             mask = (_lib.MPX_HESS if "hess_l" in names else 0) | (15 if {"f", "g", "grad_f", "jac_g"} <= names else 0)
