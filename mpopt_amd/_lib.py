@@ -279,7 +279,10 @@ def compile_kernels(source, verbose=False):
     for dep in ("mpx_kernels.h", "mpx_assembly_kernels.h", "mpx_assembly_fused.h", "mpx_assembly_lanes.h", "mpx_device.h"):
         with open(os.path.join(CSRC, dep), "rb") as f:
             h.update(f.read())
-    h.update(os.environ.get("MPX_HIPCC_FLAGS", "").encode())
+    flags = os.environ.get("MPX_HIPCC_FLAGS", "").split()
+    if os.environ.get("MPX_TABLES_STREAM_ABOVE"):  # the host side reads the same variable at context creation (mpx_device.h)
+        flags.append(f"-DMPX_TABLES_STREAM_ABOVE={max(12, min(255, int(os.environ['MPX_TABLES_STREAM_ABOVE'])))}")
+    h.update(" ".join(flags).encode())
     key = h.hexdigest()[:24]
     os.makedirs(JIT_DIR, exist_ok=True)
     co = os.path.join(JIT_DIR, f"mpx_{key}.hsaco")
@@ -290,9 +293,7 @@ def compile_kernels(source, verbose=False):
             f.write(source)
         co_tmp = src_tmp[:-4] + ".hsaco.tmp"
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "--genco", "-I", CSRC, "-o", co_tmp, src_tmp]
-        extra = os.environ.get("MPX_HIPCC_FLAGS")
-        if extra:
-            cmd[1:1] = extra.split()
+        cmd[1:1] = flags
         r = subprocess.run(cmd, capture_output=True, text=True)
         if verbose:
             print(" ".join(cmd), "\n", r.stdout, r.stderr)

@@ -6,6 +6,13 @@
 
 #define MPX_TILE 256           // nodes (= lanes) per workgroup tile: 4 wavefronts of 64
 #define MPX_MAX_PHASES 8
+// Polynomial degrees above this do not keep the differentiation / mid-point tables in LDS: the node kernels stream them from the
+// transposed tables in global memory (mpx_kernels.h: node_body, TAB_GLB).  A build-time constant of the code object
+// (-DMPX_TABLES_STREAM_ABOVE=n; exported as `mpx_tables_stream_above`, which the host compares with its own value: the
+// environment variable MPX_TABLES_STREAM_ABOVE at context creation, else this default) -- the host lays the tables out accordingly.
+#ifndef MPX_TABLES_STREAM_ABOVE
+#define MPX_TABLES_STREAM_ABOVE 63
+#endif
 #define MPX_LIGHT_WAVES 4       // wavefronts per workgroup of the light-pass kernels (mpx_light_*): two workgroups per compute unit
 
 // kernel modes
@@ -65,8 +72,9 @@ struct MpxNodeArgs {
   const MpxTile* tiles;    // tiles of this bucket (blockIdx.x indexes it, offset by tile_first)
   const int32_t* node_i;   // bucket-local node -> node index in the phase
   const int32_t* node_sk;  // bucket-local node -> (segment << 8) | point
-  const double* Dmat;      // (P+1)x(P+1) row-major first-derivative matrix of this degree
-  const double* Cmid;      // P x (P+1) interpolation to the mid-points between consecutive nodes
+  const double* Dmat;      // (P+1)x(P+1) row-major first-derivative matrix of this degree ...
+  const double* Cmid;      // P x (P+1) interpolation to the mid-points between consecutive nodes ...
+                           // ... degrees above MPX_TABLES_STREAM_ABOVE: both TRANSPOSED ([j][k], [j][k - 1]), streamed by the lanes
   const double* tk;        // (tau_k - tau0)/(tau1 - tau0), k = 0..P
   const double* Dmid;      // P x (P+1): first derivative of the Lagrange basis at the mid-points (MPX_MID_RESID)
   const double* tkm;       // ((tau_{k-1} + tau_k)/2 - tau0)/(tau1 - tau0), k = 1..P at index k - 1

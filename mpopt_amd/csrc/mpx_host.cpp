@@ -55,6 +55,18 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
       c->time_dep = v != 0 || getenv("MPX_ALWAYS_PREFIX") != nullptr;
     (void)hipGetLastError();
   }
+  {  // the degree from which the node kernels stream their tables is a build-time constant of the code object: the host lays the
+     // tables out for it (transposed copies) and sized the LDS plans with its own value -- the two must agree
+    hipDeviceptr_t sym = nullptr;
+    size_t bytes = 0;
+    int v = -1;
+    if (hipModuleGetGlobal(&sym, &bytes, c->module, "mpx_tables_stream_above") != hipSuccess || bytes != sizeof(int) || hipMemcpyDtoH(&v, sym, sizeof(int)) != hipSuccess)
+      v = -1;
+    (void)hipGetLastError();
+    if (v != c->stream_above)
+      return fail(c, MPX_ERR_INVALID, "code object built with MPX_TABLES_STREAM_ABOVE=%d, the context expects %d (set the environment variable for both, "
+                  "mpx_device.h)", v, c->stream_above);
+  }
   static const char* modes[3] = {"fg", "fgj", "hess"};
   for (auto& B : c->buckets)
     for (int m = 0; m < 3; ++m) {
@@ -126,6 +138,15 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   for (auto& t : c->degs) {
     if ((rc = upload(c, &t.d_D, t.D))) return rc;
     if ((rc = upload(c, &t.d_Cmid, t.Cmid))) return rc;
+    if (t.deg > c->stream_above) {  // streamed degrees: DT[j][k] = D[k][j], CT[j][k - 1] = C_mid[k - 1][j] (mpx_kernels.h: node_body, TAB_GLB)
+      const size_t n1 = (size_t)t.deg + 1, nm = (size_t)t.deg;
+      std::vector<double> DT(n1 * n1), CT(n1 * nm);
+      for (size_t k = 0; k < n1; ++k)
+        for (size_t j = 0; j < n1; ++j) DT[j * n1 + k] = t.D[k * n1 + j];
+      for (size_t k = 0; k < nm; ++k)
+        for (size_t j = 0; j < n1; ++j) CT[j * nm + k] = t.Cmid[k * n1 + j];
+      if ((rc = upload(c, &t.d_DT, DT)) || (rc = upload(c, &t.d_CT, CT))) return rc;
+    }
     if ((rc = upload(c, &t.d_tk, t.tk))) return rc;
     if ((rc = upload(c, &t.d_Dmid, t.Dmid)) || (rc = upload(c, &t.d_tkm, t.tkm)) || (rc = upload(c, &t.d_w, t.w))) return rc;
   }
@@ -328,8 +349,8 @@ MpxNodeArgs node_args_static(const mpx_ctx* c, const Bucket& B, bool absorber) {
   A.tiles = c->d_tiles;
   A.node_i = B.d_node_i;
   A.node_sk = B.d_node_sk;
-  A.Dmat = t.d_D;
-  A.Cmid = t.d_Cmid;
+  A.Dmat = t.d_DT ? t.d_DT : t.d_D;  // (streamed degrees: the transposed tables)
+  A.Cmid = t.d_CT ? t.d_CT : t.d_Cmid;
   A.tk = t.d_tk;
   A.Dmid = t.d_Dmid;
   A.tkm = t.d_tkm;
@@ -655,6 +676,7 @@ extern "C" int mpx_create(const mpx_problem* prob, mpx_ctx** out) {
   c->tau1 = prob->tau1;
   c->device = prob->device;
   c->orders.assign(prob->poly_orders, prob->poly_orders + prob->n_segments);
+  if (const char* e = getenv("MPX_TABLES_STREAM_ABOVE")) c->stream_above = std::max(12, std::min(255, atoi(e)));  // (A/B and the bit-identity tests: with the matching code object)
   if (prob->n_links > 0 && prob->links) c->links.assign(prob->links, prob->links + 2 * prob->n_links);
   for (size_t l = 0; l < c->links.size(); ++l)
     if (c->links[l] < 0 || c->links[l] >= c->n_phases) {
@@ -694,7 +716,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     auto fr = [](void* p) {
       if (p) (void)hipFree(p);
     };
-    for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk), fr(t.d_Dmid), fr(t.d_tkm), fr(t.d_w);
+    for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk), fr(t.d_Dmid), fr(t.d_tkm), fr(t.d_w), fr(t.d_DT), fr(t.d_CT);
     for (auto& B : c->buckets) fr(B.d_node_i), fr(B.d_node_sk);
     fr(c->d_htiles), fr(c->d_node_seg), fr(c->d_node_tk);
     fr(c->d_tiles), fr(c->d_Wnode), fr(c->d_seg_start), fr(c->d_lin_ptr), fr(c->d_lin_idx), fr(c->d_lin_row), fr(c->d_lin_coef);

@@ -36,6 +36,7 @@ struct DegTable {
   int deg = 0;
   std::vector<double> roots, D, Cmid, w, tk, Dmid, tkm;
   double *d_D = nullptr, *d_Cmid = nullptr, *d_tk = nullptr, *d_Dmid = nullptr, *d_tkm = nullptr, *d_w = nullptr;
+  double *d_DT = nullptr, *d_CT = nullptr;  // degrees above mpx_ctx::stream_above: D and C_mid transposed, what node_body's lanes stream
 };
 
 struct Bucket {
@@ -91,6 +92,7 @@ struct mpx_ctx {
   std::vector<double> lt_coef;
   // device
   bool has_device = false;
+  int stream_above = MPX_TABLES_STREAM_ABOVE;  // degrees above it stream their tables (mpx_device.h; MPX_TABLES_STREAM_ABOVE at creation; checked against the code object)
   bool time_dep = true;  // some node function uses the node time (mpx_time_dependent of the code object; true when the symbol is absent): else no prefix sums of the widths
   hipModule_t module = nullptr;
   hipFunction_t fn_bound[3] = {nullptr, nullptr, nullptr};

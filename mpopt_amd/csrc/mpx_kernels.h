@@ -36,6 +36,16 @@
 #ifndef MPX_TABLES_IN_LDS_ABOVE
 #define MPX_TABLES_IN_LDS_ABOVE 12  // degrees above this keep the D / mid-point tables in LDS
 #endif
+// Degrees above MPX_TABLES_STREAM_ABOVE (mpx_device.h; the host checks the value a code object was built with) do not hold the
+// tables at all: 2 (P + 1)^2 doubles are 37 KB at degree 48, 130 KB at 90 (ONE workgroup per compute unit) and 1 MB at 255 -- the
+// reference documents and times 1 x 100 (docs/source/notebooks/getting_started.ipynb:721-743).  There every lane STREAMS its rows
+// from the TRANSPOSED tables in global memory (L2-resident; DT[j][k] = D[k][j]: the lanes of a segment hold consecutive k, so a
+// wavefront's load of one j is one or two contiguous runs), eight columns at a time, the next eight requested before the stores
+// of the current ones (node_body: stream_tables).
+
+#ifndef MPX_STREAM_CH
+#define MPX_STREAM_CH 4  // columns per step of the streamed-table walk (even); two steps' values are live: 8 costs 64 VGPRs and spilled
+#endif
 
 namespace mpxk {
 
@@ -239,6 +249,14 @@ __device__ __forceinline__ double* mpx_lds() {
   return blk;
 }
 
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for_n(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_n<N, I + 1>(f);
+  }
+}
+
 template <int PH, int P, int MODE>
 __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx = -1, const int item_bx = -1, const unsigned item_by = 0) {
   // res_bx >= 0: called by the resident kernel for tile res_bx of the bucket;  item_bx >= 0: called by the all-phases kernel
@@ -326,19 +344,23 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
   // halve the occupancy) the two tables are staged once per workgroup in LDS and read per use.  Rows of
   // different points are 2*(P+1) dwords apart: for odd P+1 the b64 reads of a wavefront hit distinct
   // banks, equal points broadcast.
-  constexpr bool TAB_LDS = (P > MPX_TABLES_IN_LDS_ABOVE);
-  constexpr int NREG = TAB_LDS ? 1 : P1;
+  // (the hess_l kernels use the tables for the mid-point residuals only, and those exist for register tables only: above that
+  // degree a hess_l kernel neither stages nor reads a table)
+  constexpr bool TAB_REG = (P <= MPX_TABLES_IN_LDS_ABOVE);
+  constexpr bool TAB_GLB = !TAB_REG && MODE != MPX_MODE_HESS && (P > MPX_TABLES_STREAM_ABOVE);
+  constexpr bool TAB_LDS = !TAB_REG && MODE != MPX_MODE_HESS && !TAB_GLB;
+  constexpr int NREG = TAB_REG ? P1 : 1;
   double* const sD = mpx_lds<(TAB_LDS ? P1 * P1 : 1), 2>();
   double* const sC = mpx_lds<(TAB_LDS ? P * P1 : 1), 3>();
   double Drow_[NREG], Crow_[NREG], Dmrow_[NREG];
   const int drow = k * P1, crow = (k >= 1 ? k - 1 : 0) * P1;
   // MPX_MID_RESID (hess_l pass only, degrees with the tables in registers): residual of the dynamics at the mid-point before node k
-  const bool midres = MODE == MPX_MODE_HESS && !TAB_LDS && A.io.mid_resid != nullptr;
+  const bool midres = MODE == MPX_MODE_HESS && TAB_REG && A.io.mid_resid != nullptr;
   if constexpr (TAB_LDS) {
     for (int e = l; e < P1 * P1; e += MPX_TILE) sD[e] = A.Dmat[e];
     for (int e = l; e < P * P1; e += MPX_TILE) sC[e] = A.Cmid[e];
     __syncthreads();
-  } else {
+  } else if constexpr (TAB_REG) {
     // hess_l passes, tables of at most 64 entries: ONE load per table, lane and wavefront (lane e holds entry e), the lane's rows are
     // fetched from the lanes that hold them (ds_bpermute, no memory) instead of 2-3 (P + 1) loads per lane in front of every
     // workgroup -- an ablation without the table loads gains 3-8 % on these short workgroups (profiles/r3_soak.md).  Same box,
@@ -540,7 +562,7 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
       Vec<G::NHN> hn;
       G::hess(Xs, Us, t0v, tfv, As, kap, th, Wn, io.sigma[b], lF, lC, hn, red);
       scatter_slots<G::NHN>(io.hess + (int64_t)b * io.hess_stride + T.hess_base, n, l, own, vech, [&](int q) { return hn[q]; });
-      if constexpr (!TAB_LDS) {
+      if constexpr (TAB_REG) {
       if (midres && own && k >= 1) {
         // D_mid.X - h Sx dyn(I_mid.X, I_mid.U, t_mid, a) at the mid-point between nodes i - 1 and i: the same fma chains, in the
         // same order, as mpx_resid_<ph>_<deg> runs for that target point (mpopt.py:1466-1481), from the segment's X / U in LDS
@@ -592,6 +614,142 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
       } else {
         G::fg(Xs, Us, t0v, tfv, As, kap, th, Wn, fx, cc, red[0]);
       }
+      // Streamed tables (TAB_GLB): ONE walk over the lane's rows of D and of the mid-point matrix serves the contractions
+      // (sequential fma chains over j, the bits of the other two table modes) and the constant rows of the lane's Jacobian block.
+      // Slot q of a lane lives at pair q / 2 (scatter_slots' layout); a row that starts on an odd slot opens and closes every
+      // chunk with an 8-byte half of a pair, the rest are 16-byte stores.  Addresses: uniform pointer (SGPRs) + the lane's byte
+      // offset, for the table loads and for the stores.
+      double aX[NX], aDU[G::DIFF_U ? NU : 1], aMU[G::MIDU ? NU : 1];
+      if constexpr (TAB_GLB) {
+#pragma unroll
+        for (int a = 0; a < NX; ++a) aX[a] = 0;
+#pragma unroll
+        for (int c = 0; c < (G::DIFF_U ? NU : 1); ++c) aDU[c] = 0;
+#pragma unroll
+        for (int c = 0; c < (G::MIDU ? NU : 1); ++c) aMU[c] = 0;
+        const bool want_g = own && io.g != nullptr;
+        const bool want_j = MODE == MPX_MODE_FGJ && own && io.jac != nullptr;
+        using std::integral_constant;
+        // NSR: slots of a lane of this tile, VEC2: 16-byte stores (compile time: three instantiations below)
+        auto walk = [&](auto nsr_c, auto vec_c) {
+          constexpr int NSR = decltype(nsr_c)::value;
+          constexpr bool VEC2 = decltype(vec_c)::value;
+          constexpr int LASTQ = (NSR & 1) ? NSR - 1 : -1;  // an unpaired last slot is plain (scatter_slots)
+          const bool vo = io.jac_variable_only != 0;
+          const bool mid = G::MIDU && k >= 1;  // the lane has mid-point rows (every owning lane but node 0 of the phase)
+          char* const jbase = reinterpret_cast<char*>(io.jac + (int64_t)b * io.jac_stride + T.jac_base);
+          const uint32_t nb = (uint32_t)n * 8u, l16 = (uint32_t)l * 16u, l8 = (uint32_t)l * 8u;
+          // slot q0 + j (q0 compile time, j a uniform runtime value or 0)
+          auto put1 = [&](auto q0_c, auto maybe_last_c, uint32_t j, double v) {
+            constexpr int Q0 = decltype(q0_c)::value;
+            const uint32_t q = (uint32_t)Q0 + j;
+            if (decltype(maybe_last_c)::value && LASTQ >= 0 && q == (uint32_t)LASTQ) {
+              uint32_t o = l8;
+              asm volatile("" : "+v"(o));
+              *reinterpret_cast<double*>(jbase + (size_t)q * nb + o) = v;
+            } else {
+              uint32_t o = l16;
+              asm volatile("" : "+v"(o));  // (pinned: uniform pointer in SGPRs + one 32-bit lane offset, no 64-bit address per store)
+              *reinterpret_cast<double*>(jbase + ((size_t)(q >> 1) * 2u * nb + (q & 1u) * 8u) + o) = v;
+            }
+          };
+          auto put2 = [&](auto q0_c, uint32_t j, double v0, double v1) {  // Q0 + j even, both slots exist
+            char* const pu = jbase + (size_t)(((uint32_t)decltype(q0_c)::value + j) >> 1) * 2u * nb;
+            uint32_t o = l16;
+            asm volatile("" : "+v"(o));
+            if constexpr (VEC2) {
+              mpx_d2 w;
+              w.x = v0, w.y = v1;
+              *reinterpret_cast<mpx_d2*>(pu + o) = w;
+            } else {
+              *reinterpret_cast<double*>(pu + o) = v0;
+              *reinterpret_cast<double*>(pu + 8 + o) = v1;
+            }
+          };
+          // val(0 .. CNT - 1) to the slots Q0 + j ..; rows start at compile-time slots and chunks at even j, so the parity of the
+          // first slot is a compile-time fact.  ML: the values may include the lane's last slot
+          auto emit = [&](auto q0_c, auto cnt_c, auto ml_c, uint32_t j, auto val) {
+            constexpr int Q0 = decltype(q0_c)::value, PAR = Q0 & 1, CNT = decltype(cnt_c)::value;
+            if constexpr (PAR == 1 && CNT > 0) put1(q0_c, ml_c, j, val(0));
+#pragma unroll
+            for (int c = PAR; c + 1 < CNT; c += 2) put2(q0_c, j + (uint32_t)c, val(c), val(c + 1));
+            if constexpr (CNT > PAR && ((CNT - PAR) & 1) != 0) put1(q0_c, ml_c, j + (uint32_t)(CNT - 1), val(CNT - 1));
+          };
+          constexpr int CH = MPX_STREAM_CH, NFULL = P1 / CH, REM = P1 % CH;
+          static_assert(CH % 2 == 0, "chunks start at even columns");
+          const uint32_t kd8 = 8u * (uint32_t)k, kc8 = 8u * (uint32_t)(k >= 1 ? k - 1 : 0);
+          auto fetch = [&](int j0, double (&d)[CH], double (&cm)[CH]) {
+            // (unconditional, clamped: a guarded prefetch meets the old values in phi nodes and is waited for at once)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              const int j = (j0 + c < P1) ? j0 + c : P;
+              uint32_t od = kd8, oc = kc8;
+              asm volatile("" : "+v"(od), "+v"(oc));
+              d[c] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.Dmat + j * P1) + od);  // TRANSPOSED tables: DT[j][k] = D[k][j]
+              if constexpr (G::MIDU) cm[c] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.Cmid + j * P) + oc);  // CT[j][k - 1] = C_mid[k - 1][j]
+              else cm[c] = 0.0;
+            }
+          };
+          auto work = [&](auto cnt_c, auto ml_c, int j0, const double (&d)[CH], const double (&cm)[CH]) {
+            constexpr int CNT = decltype(cnt_c)::value;
+            if (want_g) {
+#pragma unroll
+              for (int c = 0; c < CNT; ++c) {
+#pragma unroll
+                for (int a = 0; a < NX; ++a) aX[a] = fma(d[c], sXU[buf][a][base + j0 + c], aX[a]);
+                if constexpr (G::DIFF_U || G::MIDU) {
+#pragma unroll
+                  for (int cu = 0; cu < NU; ++cu) {
+                    const double u = sXU[buf][NX + cu][base + j0 + c];
+                    if constexpr (G::DIFF_U) aDU[cu] = fma(d[c], u, aDU[cu]);
+                    if constexpr (G::MIDU) aMU[cu] = fma(cm[c], u, aMU[cu]);
+                  }
+                }
+              }
+            }
+            if constexpr (MODE == MPX_MODE_FGJ) {
+              if (want_j) {
+                static_for_n<NX>([&](auto a_c) {
+                  constexpr int a = decltype(a_c)::value;
+                  if (!vo || G::DD_VARIABLE[a])
+                    emit(integral_constant<int, a * P1>{}, cnt_c, ml_c, (uint32_t)j0, [&](int c) { return (j0 + c == k) ? d[c] - dd[a] : d[c]; });
+                });
+                if (!vo) {
+                  if constexpr (G::DIFF_U)
+                    static_for_n<NU>([&](auto c_c) {
+                      emit(integral_constant<int, NX * P1 + G::NJV + decltype(c_c)::value * P1>{}, cnt_c, ml_c, (uint32_t)j0, [&](int c) { return d[c]; });
+                    });
+                  if constexpr (NS_MID > 0 && NSR > NS_MAIN) {
+                    if (mid)
+                      static_for_n<NU>([&](auto c_c) {
+                        emit(integral_constant<int, NS_MAIN + decltype(c_c)::value * P1>{}, cnt_c, ml_c, (uint32_t)j0, [&](int c) { return cm[c]; });
+                      });
+                  }
+                }
+              }
+            }
+          };
+          if constexpr (MODE == MPX_MODE_FGJ && G::NJV > 0) {
+            if (want_j) emit(integral_constant<int, NX * P1>{}, integral_constant<int, G::NJV>{}, std::true_type{}, 0u, [&](int q) { return jv[q]; });
+          }
+          double d0[CH], c0[CH], d1[CH], c1[CH];
+          fetch(0, d0, c0);
+#pragma unroll 2
+          for (int ci = 0; ci < NFULL; ++ci) {
+            fetch((ci + 1) * CH, d1, c1);  // the next chunk is requested before the stores of this one (vmcnt retires in order)
+            // (column P, and with it possibly the lane's last slot, lies in a full chunk only when P + 1 is a multiple of CH)
+            work(integral_constant<int, CH>{}, integral_constant<bool, REM == 0>{}, ci * CH, d0, c0);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) d0[c] = d1[c], c0[c] = c1[c];
+          }
+          if constexpr (REM > 0) work(integral_constant<int, REM>{}, std::true_type{}, NFULL * CH, d0, c0);
+        };
+        if (want_g || want_j) {
+          if (T.node0) walk(integral_constant<int, NS_MAIN>{}, std::false_type{});
+          else if (vec) walk(integral_constant<int, NS_MAIN + NS_MID>{}, std::true_type{});
+          else walk(integral_constant<int, NS_MAIN + NS_MID>{}, std::false_type{});
+        }
+      }
 #ifdef MPX_ABL_NO_G
       if (false) {
 #else
@@ -610,8 +768,11 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
 #pragma unroll
         for (int a = 0; a < NX; ++a) {  // defect  F = D.X - h*Sx*dyn      (mpopt.py:227-232)
           double acc = 0;
+          if constexpr (TAB_GLB) acc = aX[a];
+          else {
 #pragma unroll(TAB_LDS ? 4 : P1)
-          for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][a][base + j], acc);
+            for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][a][base + j], acc);
+          }
           gput(a, gb + (A.g_off_F + (int64_t)a * N) + i, acc - fx[a]);
         }
 #pragma unroll
@@ -620,8 +781,11 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
 #pragma unroll
           for (int c = 0; c < NU; ++c) {
             double acc = 0;
+            if constexpr (TAB_GLB) acc = aDU[c];
+            else {
 #pragma unroll(TAB_LDS ? 4 : P1)
-            for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][NX + c][base + j], acc);
+              for (int j = 0; j < P1; ++j) acc = fma(Drow(j), sXU[buf][NX + c][base + j], acc);
+            }
             gput(NX + NC + c, gb + (A.g_off_DU + (int64_t)c * N) + i, acc);
           }
         }
@@ -630,8 +794,11 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
               double acc = 0;
+              if constexpr (TAB_GLB) acc = aMU[c];
+              else {
 #pragma unroll(TAB_LDS ? 4 : P1)
-              for (int j = 0; j < P1; ++j) acc = fma(Crow(j), sXU[buf][NX + c][base + j], acc);
+                for (int j = 0; j < P1; ++j) acc = fma(Crow(j), sXU[buf][NX + c][base + j], acc);
+              }
               gput(NX + NC + (G::DIFF_U ? NU : 0) + c, gb + (A.g_off_mU + (int64_t)c * (N - 1)) + (i - 1), acc);
             }
           }
@@ -691,7 +858,9 @@ __device__ __forceinline__ void node_body(const MpxNodeArgs& A, const int res_bx
             if (q < NX * P1) return G::DD_VARIABLE[q / P1];
             return q < NX * P1 + G::NJV;
           };
-          if (io.jac_variable_only) {
+          if constexpr (TAB_GLB) {
+            // (written by the walk over the streamed tables above)
+          } else if (io.jac_variable_only) {
             if (T.node0)
               scatter_slots<NS_MAIN, 0>(jb, n, l, own, false, sv, variable);
             else
@@ -1282,13 +1451,6 @@ __device__ __forceinline__ void light_body(const MpxLightArgs& L) {
 // SMALL batches can run the same arithmetic with one chunk per wavefront (SMALL = true: a single evaluation keeps 79 wavefronts busy at config 2 instead of 10; with the long
 // spans a single nlp_f + nlp_g + nlp_grad_f pass took 33 instead of 22 us) and still give the bits of a large batch.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int N, int I = 0, class F>
-__device__ __forceinline__ void static_for_n(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for_n<N, I + 1>(f);
-  }
-}
 
 // One implementation for the per-phase kernels (PH0 = the phase, NPHK = 1) and the all-phases kernels (PH0 = 0, NPHK = MPX_NPH;
 // round 5): there an item is (span, phase, evaluation point) -- the phases of a grid share its nodes and tables and differ in the
@@ -1674,11 +1836,16 @@ __device__ __forceinline__ void resid_body(const MpxResidArgs& A) {
   // the wavefront's rows are consecutive (single-degree grids: always, except in the last wavefront)?
   const int row0 = __shfl(row, 0, 64);
   const bool contig = __all(valid && row == row0 + (int)(threadIdx.x & 63));
-  double Crow[P1], Drow[P1];
+  // the point's interpolation / derivative rows: registers for the batch loop -- up to degree 32 (2 (P + 1) doubles per lane); above,
+  // they are read inside the contraction, one j for every row at once (the same fma chains)
+  constexpr bool ROWS_REG = P <= 32;
+  double Crow[ROWS_REG ? P1 : 1], Drow[ROWS_REG ? P1 : 1];
+  if constexpr (ROWS_REG) {
 #pragma unroll
-  for (int j = 0; j < P1; ++j) {
-    Crow[j] = A.Cmat[(int64_t)j * A.n + m];
-    Drow[j] = A.Dmat[(int64_t)j * A.n + m];
+    for (int j = 0; j < P1; ++j) {
+      Crow[j] = A.Cmat[(int64_t)j * A.n + m];
+      Drow[j] = A.Dmat[(int64_t)j * A.n + m];
+    }
   }
   const int N = A.N;
   const int b0 = blockIdx.y * A.b_per_block;
@@ -1689,6 +1856,7 @@ __device__ __forceinline__ void resid_body(const MpxResidArgs& A) {
     Vec<NU> Ui, DUi;
     Vec<NA> As;
     Vec<NC> cc;
+    if constexpr (ROWS_REG) {
 #pragma unroll
     for (int a = 0; a < NX; ++a) {
       double v = 0, d = 0;
@@ -1712,6 +1880,28 @@ __device__ __forceinline__ void resid_body(const MpxResidArgs& A) {
       }
       Ui[c] = v;
       DUi[c] = d;
+    }
+    } else {
+#pragma unroll
+      for (int a = 0; a < NX; ++a) Xi[a] = 0, DXi[a] = 0;
+#pragma unroll
+      for (int c = 0; c < NU; ++c) Ui[c] = 0, DUi[c] = 0;
+#pragma unroll 4
+      for (int j = 0; j < P1; ++j) {
+        const double cj = A.Cmat[(int64_t)j * A.n + m], dj = A.Dmat[(int64_t)j * A.n + m];
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+          const double x = (zb + (int64_t)a * N)[st + j];
+          Xi[a] = fma(cj, x, Xi[a]);
+          DXi[a] = fma(dj, x, DXi[a]);
+        }
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+          const double x = (zb + (int64_t)(NX + c) * N)[st + j];
+          Ui[c] = fma(cj, x, Ui[c]);
+          DUi[c] = fma(dj, x, DUi[c]);
+        }
+      }
     }
     const double* __restrict__ zt = zb + (int64_t)(NX + NU) * N;
     const double t0v = zt[0], tfv = zt[1];
@@ -1989,10 +2179,15 @@ __device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
   constexpr int NRED = 2 + NA;
   // multiplier rows staged per segment: defect rows, control-slope rows (DIFF_U), mid-point control rows (MIDU)
   constexpr int L_DU = NX, L_MU = NX + (G::DIFF_U ? NU : 0), NL = L_MU + (G::MIDU ? NU : 0);
+  // (degrees above MPX_TABLES_STREAM_ABOVE: the tables stay in global memory -- column j = the lane's point k, so the lanes of a
+  // segment read consecutive addresses of the ROW-major tables; node_body's streamed mode reads the transposed ones)
+  constexpr bool TAB_GLB = P > MPX_TABLES_STREAM_ABOVE;
   __shared__ double sL[NL][SLOTS];
-  __shared__ double sD[P1 * P1];
-  __shared__ double sC[P * P1];
+  __shared__ double sD_[TAB_GLB ? 1 : P1 * P1];
+  __shared__ double sC_[TAB_GLB ? 1 : P * P1];
   __shared__ double sRed[MPX_TILE / 64][NRED];
+  const double* __restrict__ const sD = TAB_GLB ? A.Dmat : sD_;
+  const double* __restrict__ const sC = TAB_GLB ? A.Cmid : sC_;
   const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x, tot_ = gridDim.x * gridDim.y;  // XCD-blocked walk, as node_body
   const unsigned xcd_ = lin_ % 8, q_ = tot_ / 8, r_ = tot_ % 8;
   const unsigned item_ = xcd_ * q_ + (xcd_ < r_ ? xcd_ : r_) + lin_ / 8;
@@ -2007,8 +2202,10 @@ __device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
   const bool halo = act && k == 1 && !T.node0;  // loads the multipliers of the segment's first node (owned by the previous segment)
   const int N = A.N;
   const int b = A.b_first + (int)by_;
-  for (int e = l; e < P1 * P1; e += MPX_TILE) sD[e] = A.Dmat[e];
-  for (int e = l; e < P * P1; e += MPX_TILE) sC[e] = A.Cmid[e];
+  if constexpr (!TAB_GLB) {
+    for (int e = l; e < P1 * P1; e += MPX_TILE) sD_[e] = A.Dmat[e];
+    for (int e = l; e < P * P1; e += MPX_TILE) sC_[e] = A.Cmid[e];
+  }
   const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride + A.z_off;
   const double* __restrict__ lb = A.lam_g + (int64_t)b * A.lam_stride;
   Vec<NX> Xs, lF;
@@ -2063,11 +2260,13 @@ __device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
   const int klo = s == 0 ? 0 : 1;
   auto col_D = [&](int row, int j) {
     double acc = 0;
+#pragma unroll 4
     for (int kp = klo; kp < P1; ++kp) acc = fma(sL[row][base + kp], sD[kp * P1 + j], acc);
     return acc;
   };
   auto col_C = [&](int row, int j) {
     double acc = 0;
+#pragma unroll 4
     for (int kp = 1; kp < P1; ++kp) acc = fma(sL[row][base + kp], sC[(kp - 1) * P1 + j], acc);
     return acc;
   };
@@ -2349,7 +2548,10 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
 #ifndef MPX_MIN_WAVES_HIGH  // degrees with the tables in LDS: the register budget that gives 4 wavefronts per SIMD (<= 128 VGPRs)
 #define MPX_MIN_WAVES_HIGH 4
 #endif
-#define MPX_WAVES_FOR(P) ((P) > MPX_TABLES_IN_LDS_ABOVE ? MPX_MIN_WAVES_HIGH : MPX_MIN_WAVES)
+#ifndef MPX_MIN_WAVES_STREAM  // streamed tables: two chunks of table values are live on top (168 VGPRs; 4 spilled 35 dwords)
+#define MPX_MIN_WAVES_STREAM 3
+#endif
+#define MPX_WAVES_FOR(P) ((P) > MPX_TABLES_STREAM_ABOVE ? MPX_MIN_WAVES_STREAM : (P) > MPX_TABLES_IN_LDS_ABOVE ? MPX_MIN_WAVES_HIGH : MPX_MIN_WAVES)
 #define MPX_INSTANTIATE_NODE(PH, P)                                                                         \
   extern "C" __global__ __launch_bounds__(MPX_TILE, MPX_MIN_WAVES) void mpx_node_fg_##PH##_##P(const MpxNodeArgs A) {      \
     mpxk::node_body<PH, P, MPX_MODE_FG>(A);                                                                 \
@@ -2441,3 +2643,6 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
   extern "C" __global__ __launch_bounds__(256) void mpx_boundary_hess(const MpxBoundArgs A) {               \
     mpxk::boundary_body<MPX_MODE_HESS>(A);                                                                  \
   }
+
+// (read by libmpx when it loads the code object: mpx_host.cpp, load_device)
+extern "C" __device__ __attribute__((used)) const int mpx_tables_stream_above = MPX_TABLES_STREAM_ABOVE;

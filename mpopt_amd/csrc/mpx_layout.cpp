@@ -108,12 +108,13 @@ int build_tables(mpx_ctx* c) {
   distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
   for (int d : distinct) {
     if (d < 1 || d > 255) return fail(c, MPX_ERR_UNSUPPORTED, "polynomial degree %d outside 1..255", d);
-    {  // what the node kernel of this degree keeps in LDS (mpx_kernels.h: sD, sC above degree 12; the double-buffered X/U tile)
+    {  // what the node kernel of this degree keeps in LDS (mpx_kernels.h: sD, sC for degrees 13 .. stream_above -- higher degrees
+       // stream their tables from global memory --; the double-buffered X/U tile)
       const int64_t P1 = d + 1, segs = MPX_TILE / d;
-      const int64_t lds = 8 * ((d > 12 ? P1 * P1 + (int64_t)d * P1 : 0) + 2 * (int64_t)(c->nx + c->nu) * segs * P1) + 8 * 2 * 4 * 64;
+      const int64_t lds = 8 * ((d > 12 && d <= c->stream_above ? P1 * P1 + (int64_t)d * P1 : 0) + 2 * (int64_t)(c->nx + c->nu) * segs * P1) + 8 * 2 * 4 * 64;
       if (lds > 150 * 1024)
-        return fail(c, MPX_ERR_UNSUPPORTED, "polynomial degree %d needs %lld KB of LDS per workgroup (differentiation + mid-point tables and the "
-                    "state/control tile); the limit is 150 of the 160 KB of an MI355X compute unit", d, (long long)(lds / 1024));
+        return fail(c, MPX_ERR_UNSUPPORTED, "polynomial degree %d needs %lld KB of LDS per workgroup (%sthe state/control tile); the limit is 150 of the "
+                    "160 KB of an MI355X compute unit", d, (long long)(lds / 1024), d <= c->stream_above ? "differentiation + mid-point tables (MPX_TABLES_STREAM_ABOVE is set above this degree) and " : "");
     }
     DegTable t;
     t.deg = d;
@@ -399,7 +400,7 @@ int build_layout(mpx_ctx* c) {
       {  // static LDS of the bucket's node kernel (same arithmetic as build_tables) + the span rows: up to 150 of the 160 KB of a
          // compute unit (past the 64 KB a launch gets by default load_device raises the kernels' dynamic shared memory limit)
         const int64_t P1 = B.deg + 1, segs = MPX_TILE / B.deg;
-        const int64_t lds_static = 8 * ((B.deg > 12 ? P1 * P1 + (int64_t)B.deg * P1 : 0) + 2 * (int64_t)(nx + nu) * segs * P1) + 8 * 2 * 4 * 64;
+        const int64_t lds_static = 8 * ((B.deg > 12 && B.deg <= c->stream_above ? P1 * P1 + (int64_t)B.deg * P1 : 0) + 2 * (int64_t)(nx + nu) * segs * P1) + 8 * 2 * 4 * 64;
         if (lds_static + (int64_t)cap * nsg * 8 > 150 * 1024) {
           if (c->absorb) c->notes += "mixed-degree grid: the row spans of the largest bucket need " + std::to_string((lds_static + (int64_t)cap * nsg * 8) / 1024) +
                                      " KB of LDS per workgroup (limit 150): g / grad_f of the heavy passes go through the staging block and the unpack pass instead\n";
