@@ -86,7 +86,7 @@ def interp_matrix(nodes, taus):  # mpopt.py:3884-3905
 
 
 # ---------------------------------------------------------------------------------------------
-# The same definitions in 50-digit arithmetic.  The reference's "numerical" back-end above loses
+# The same definitions in multi-precision arithmetic.  The reference's "numerical" back-end above loses
 # digits as the degree grows (np.poly1d coefficient products: ~1e-9 at p=20, ~4e-4 at p=30, see
 # tests/test_tables.py and DESIGN.md), while its default "symbolic" back-end (CasADi AD of the
 # product form, mpopt.py:3832-3840) does not.  Above degree 10 the oracle therefore evaluates the
@@ -95,7 +95,9 @@ def interp_matrix(nodes, taus):  # mpopt.py:3884-3905
 def _mp_basis_coeffs(nodes):
     import mpmath as mpm
 
-    mpm.mp.dps = 50
+    # (monomial coefficients of degree-n basis polynomials on [-1, 1] grow like 2^n and their evaluation cancels as much again:
+    # 50 digits are exact to 1e-16 up to degree ~60 only -- at degree 100 the weights came out wrong in the 4th digit)
+    mpm.mp.dps = max(50, 30 + len(nodes))
     xs = [mpm.mpf(float(v)) for v in nodes]
     out = []
     for j in range(len(xs)):
@@ -121,8 +123,10 @@ def _mp_polyval(c, t):
     return v
 
 
-def exact_tables(nodes, taus, order, a=None, b=None):
-    """order 0/1/2: matrix l_j^(order)(taus_i); order 'w': weights over [a, b]."""
+def exact_tables_monomial(nodes, taus, order, a=None, b=None):
+    """order 0/1/2: matrix l_j^(order)(taus_i); order 'w': weights over [a, b] -- from the monomial coefficients of the basis
+    polynomials (O(n^3) multi-precision operations with n + 30 digits: minutes at degree 255).  The form the oracle used up to round
+    5; kept as the independent check of ``exact_tables`` (tests/test_oracle.py)."""
     import mpmath as mpm
 
     C = _mp_basis_coeffs(nodes)
@@ -141,6 +145,89 @@ def exact_tables(nodes, taus, order, a=None, b=None):
             d = [ck * (m - k) for k, ck in enumerate(d[:-1])] or [mpm.mpf(0)]
         for i, t in enumerate(taus):
             out[i, j] = float(_mp_polyval(d, mpm.mpf(float(t))))
+    return out
+
+
+def _mp_gauss_legendre(nq):
+    """Gauss-Legendre nodes / weights on [-1, 1] in the current mpmath precision (Newton on the three-term recurrence from
+    numpy's double-precision nodes)."""
+    import mpmath as mpm
+
+    xs, ws = [], []
+    for x0 in np.polynomial.legendre.leggauss(nq)[0]:
+        x = mpm.mpf(float(x0))
+        for _ in range(6):
+            p0, p1 = mpm.mpf(1), x
+            for k in range(2, nq + 1):
+                p0, p1 = p1, ((2 * k - 1) * x * p1 - (k - 1) * p0) / k
+            dp = nq * (x * p1 - p0) / (x * x - 1)
+            x = x - p1 / dp
+        p0, p1 = mpm.mpf(1), x
+        for k in range(2, nq + 1):
+            p0, p1 = p1, ((2 * k - 1) * x * p1 - (k - 1) * p0) / k
+        dp = nq * (x * p1 - p0) / (x * x - 1)
+        xs.append(x)
+        ws.append(2 / ((1 - x * x) * dp * dp))
+    return xs, ws
+
+
+def exact_tables(nodes, taus, order, a=None, b=None):
+    """order 0/1/2: matrix l_j^(order)(taus_i); order 'w': weights int_a^b l_j -- the DEFINITIONS evaluated in 50-digit arithmetic
+    through the barycentric form (well conditioned at every degree, O(n^2) operations per table): l_j(t) = (lam_j / (t - x_j)) /
+    sum_m lam_m / (t - x_m); l_j'(x_i) = (lam_j / lam_i) / (x_i - x_j), l_i'(x_i) = - sum_{j != i} l_j'(x_i) (the derivatives of a
+    partition of unity sum to zero); l_j^(k) at other points and l_j'' by exact re-interpolation (l_j' has degree < n); the weights
+    by a Gauss-Legendre rule that is exact for degree n - 1.  Equal to the monomial form above wherever that one has digits left
+    (tests/test_oracle.py: degrees 12 ... 100)."""
+    import mpmath as mpm
+
+    mpm.mp.dps = 50
+    xs = [mpm.mpf(float(v)) for v in nodes]
+    n = len(xs)
+    lam = []
+    for j in range(n):
+        v = mpm.mpf(1)
+        for m in range(n):
+            if m != j:
+                v *= xs[j] - xs[m]
+        lam.append(1 / v)
+
+    def basis_row(t):
+        for j in range(n):
+            if t == xs[j]:
+                return [mpm.mpf(1 if m == j else 0) for m in range(n)]
+        s = [lam[j] / (t - xs[j]) for j in range(n)]
+        tot = mpm.fsum(s)
+        return [v / tot for v in s]
+
+    if order == "w":
+        gx, gw = _mp_gauss_legendre(n // 2 + 1)
+        a, b = mpm.mpf(float(a)), mpm.mpf(float(b))
+        half, mid = (b - a) / 2, (b + a) / 2
+        acc = [mpm.mpf(0)] * n
+        for x, w in zip(gx, gw):
+            row = basis_row(mid + half * x)
+            acc = [s + w * v for s, v in zip(acc, row)]
+        return np.array([float(v * half) for v in acc])
+    if order == 0:
+        return np.array([[float(v) for v in basis_row(mpm.mpf(float(t)))] for t in taus]).reshape(len(taus), n)
+    D1 = [[mpm.mpf(0)] * n for _ in range(n)]
+    for i in range(n):
+        for j in range(n):
+            if i != j:
+                D1[i][j] = (lam[j] / lam[i]) / (xs[i] - xs[j])
+        D1[i][i] = -mpm.fsum(D1[i])
+    Dk = D1
+    if order == 2:
+        Dk = [[mpm.fsum(D1[i][m] * D1[m][j] for m in range(n)) for j in range(n)] for i in range(n)]
+    out = np.zeros((len(taus), n))
+    for i, t in enumerate(taus):
+        t = mpm.mpf(float(t))
+        hit = [k for k in range(n) if t == xs[k]]
+        if hit:
+            out[i] = [float(v) for v in Dk[hit[0]]]
+        else:
+            row = basis_row(t)
+            out[i] = [float(mpm.fsum(row[m] * Dk[m][j] for m in range(n))) for j in range(n)]
     return out
 
 

@@ -201,3 +201,33 @@ def test_adaptive_oracle_matches_reference(name):
         Hr = np.zeros_like(H)
         Hr[G["hess_row"], G["hess_col"]] = G["hess_val"]
         assert rel_err(H, Hr + np.triu(Hr, 1).T) < TOL
+
+
+@pytest.mark.parametrize("scheme,deg", [("LGR", 12), ("CGL", 31), ("LGL", 50), ("LGR", 64)])
+def test_exact_tables_barycentric_equal_monomial(scheme, deg):
+    """The oracle's multi-precision tables (barycentric definitions, O(n^2)) against the monomial-coefficient form it used up to
+    round 5 (O(n^3), n + 30 digits): the same doubles, for D, D'', interpolation, off-node derivatives and (sub-interval) weights."""
+    from oracle.mpopt_oracle import exact_tables, exact_tables_monomial, roots
+
+    x = roots(scheme, deg)
+    mids = (x[1:] + x[:-1]) / 2
+    for taus, order, ab in ((x, 1, None), (mids, 0, None), (mids[:7], 1, None), (x[:4], 2, None), (None, "w", (-1.0, 1.0)), (None, "w", (-1.0, 0.3))):
+        a = exact_tables(x, taus, order, *(ab or ()))
+        b = exact_tables_monomial(x, taus, order, *(ab or ()))
+        assert np.abs(a - b).max() <= 4e-16 * max(1.0, np.abs(b).max()), (order, ab)
+
+
+def test_exact_tables_at_degree_255_are_consistent():
+    """Degree 255 (the largest the library takes): rows of D sum to zero, D differentiates x^3 exactly, the weights integrate 1, x^2
+    exactly and equal the library's (long-double barycentric + Gauss-Legendre) to rounding; 50-digit monomial arithmetic gave
+    weights wrong in the 4th digit at degree 100 and garbage at 128."""
+    from oracle.mpopt_oracle import exact_tables, roots
+    from mpopt_amd.mpopt import Collocation
+
+    x = roots("LGR", 255)
+    D = exact_tables(x, x, 1)
+    w = exact_tables(x, None, "w", -1.0, 1.0)
+    assert np.abs(D.sum(axis=1)).max() < 1e-9 and np.abs(D @ x**3 - 3 * x**2).max() < 1e-8
+    assert abs(w.sum() - 2.0) < 1e-14 and abs(w @ x**2 - 2.0 / 3.0) < 1e-14
+    C = Collocation([255], "LGR")
+    assert np.abs(np.asarray(C.get_quadrature_weights(255)).ravel() - w).max() < 2e-15
