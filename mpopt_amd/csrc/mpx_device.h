@@ -10,8 +10,11 @@
 // transposed tables in global memory (mpx_kernels.h: node_body, TAB_GLB).  A build-time constant of the code object
 // (-DMPX_TABLES_STREAM_ABOVE=n; exported as `mpx_tables_stream_above`, which the host compares with its own value: the
 // environment variable MPX_TABLES_STREAM_ABOVE at context creation, else this default) -- the host lays the tables out accordingly.
+// 68: up to there two workgroups share a compute unit with the tables in LDS (2 * 69^2 doubles = 76 KB each) and the LDS form is
+// the faster one (tools/r6_stream_ab.py, B = 256, f+g+grad_f+jac_g in TB/s, LDS | streamed: degree 48 5.0 | 4.1, 56 5.5 | 5.5,
+// 64 5.6 | 5.3, 80 3.4 | 4.5, 92 3.0 | 4.7; g alone at 92: 468 | 131 us).
 #ifndef MPX_TABLES_STREAM_ABOVE
-#define MPX_TABLES_STREAM_ABOVE 63
+#define MPX_TABLES_STREAM_ABOVE 68
 #endif
 #define MPX_LIGHT_WAVES 4       // wavefronts per workgroup of the light-pass kernels (mpx_light_*): two workgroups per compute unit
 

@@ -281,6 +281,16 @@ FULL_EXTRA_CASES = [
 
 #: seeds of the random mixed-degree grids of tests/test_gpu_parity.py::test_random_mixed_degree_grids (round 2's tools/span_soak.py
 #: as a test); __graft_entry__.build() compiles their kernels so that the GPU box finds them in the cache
+# degrees above the LDS tables (round 6: streamed tables, mpx_kernels.h TAB_GLB; tests/test_gpu_high_degree.py)
+HIGH_DEGREE_CASES = {
+    "moon_lander_1x100_LGR": (moon_lander, 1, 100, "LGR"),     # the reference's documented grid (docs/source/notebooks/getting_started.ipynb:743)
+    "van_der_pol_2x69_CGL": (van_der_pol, 2, 69, "CGL"),       # first streamed degree
+    "dae_vdp_3_100_3_LGL": (dae_vdp, 3, [3, 100, 3], "LGL"),   # mixed: a streamed bucket between register-table buckets, parameter + path row
+    "hyper_sensitive_4x128_LGR": (hyper_sensitive, 4, 128, "LGR"),  # two segments per tile, tile boundary inside the phase
+    "kitchen_sink_95_71": (kitchen_sink, 2, [95, 71], "LGR"),  # two phases, control-slope rows (D.U), time dependence; P + 1 = 96 = 0 mod 4
+    "moon_lander_1x255_CGL": (moon_lander, 1, 255, "CGL"),     # the largest degree the library takes
+}
+
 SOAK_SEEDS = [int(x) for x in os.environ["MPX_SOAK_SEEDS"].split(",")] if os.environ.get("MPX_SOAK_SEEDS") else [3, 11, 12, 22, 29, 40]  # (env: one-off wider soaks)
 
 

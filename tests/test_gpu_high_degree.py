@@ -1,4 +1,4 @@
-"""Grids of polynomial degree 64 ... 255 (round 6): above MPX_TABLES_STREAM_ABOVE (mpx_device.h, default 63) the node kernels do
+"""Grids of polynomial degree 69 ... 255 (round 6): above MPX_TABLES_STREAM_ABOVE (mpx_device.h, default 68) the node kernels do
 not keep the differentiation / mid-point tables in LDS -- every lane streams its rows from the transposed tables in global memory
 (mpx_kernels.h: node_body, TAB_GLB).  Up to round 5 mpx_create refused every degree >= 94 (two tables of (P + 1)^2 doubles in the LDS
 of one workgroup), although the reference documents and times `mp.solve(ocp, n_segments=1, poly_orders=100, scheme="LGR")`
@@ -45,14 +45,7 @@ def random_point(o, mpo, seed, S, n_ph):
     return z, (w / w.sum(axis=1, keepdims=True)).ravel(), rng.standard_normal(o.n_g), float(rng.uniform(0.2, 2.0))
 
 
-HIGH = {
-    "moon_lander_1x100_LGR": (problems.moon_lander, 1, 100, "LGR"),     # the reference's documented grid (getting_started.ipynb:743)
-    "van_der_pol_2x64_CGL": (problems.van_der_pol, 2, 64, "CGL"),       # first streamed degree; P + 1 = 65 odd
-    "dae_vdp_3_100_3_LGL": (problems.dae_vdp, 3, [3, 100, 3], "LGL"),   # mixed: a streamed bucket between register-table buckets, parameter + path row
-    "hyper_sensitive_4x128_LGR": (problems.hyper_sensitive, 4, 128, "LGR"),  # two segments per tile, tile boundary inside the phase
-    "kitchen_sink_95_71": (problems.kitchen_sink, 2, [95, 71], "LGR"),  # two phases, control-slope rows (D.U), time dependence; P + 1 = 96 = 0 mod 4
-    "moon_lander_1x255_CGL": (problems.moon_lander, 1, 255, "CGL"),     # the largest degree the library takes
-}
+HIGH = problems.HIGH_DEGREE_CASES
 
 
 @pytest.mark.parametrize("name", list(HIGH))
@@ -94,7 +87,7 @@ BOTH = {
     "vdp_mixed_3_30_3_CGL": (problems.van_der_pol, 12, [30 if s % 3 == 1 else 3 for s in range(12)], "CGL"),
     "kitchen_sink_16_21": (problems.kitchen_sink, 2, [16, 21], "LGL"),
     "dae_vdp_2x64_LGL": (problems.dae_vdp, 2, 64, "LGL"),
-    "moon_lander_5x93_LGR": (problems.moon_lander, 5, 93, "LGR"),  # the largest degree of the LDS mode (140 KB of tables)
+    "moon_lander_5x92_LGR": (problems.moon_lander, 5, 92, "LGR"),  # the largest degree of the LDS mode at nx + nu = 3 (137 KB of tables)
     "hyper_sensitive_20x13_CGL": (problems.hyper_sensitive, 20, 13, "CGL"),  # smallest degree outside the register tables
 }
 

@@ -101,9 +101,18 @@ def test_bad_inputs_are_reported_not_fatal():
     assert L.mpx_create(None, None) < 0 and b"null" in L.mpx_last_error(None)
 
 
-def test_degrees_whose_tables_exceed_lds_are_refused_with_a_message():
+def test_every_degree_up_to_255_creates_and_the_lds_limit_applies_to_lds_tables_only(monkeypatch):
+    """Round 6: degrees above MPX_TABLES_STREAM_ABOVE (68) stream their tables, so no degree <= 255 is refused for LDS (up to round 5:
+    every degree >= 94, although the reference documents 1 x 100, getting_started.ipynb:743).  With the threshold forced above a
+    degree whose tables cannot fit, the old message still names the cause."""
     ocp = problems.moon_lander(mp, M.math)
-    M.NlpFunctions(ocp, 1, [60], "LGR", with_device=False).close()  # the largest degree the GPU tests exercise
+    for S, po in ((1, [60]), (1, [100]), (4, [128] * 4), (3, [3, 100, 3]), (1, [255])):
+        o = M.NlpFunctions(ocp, S, po, "LGR", with_device=False)
+        assert o.n_nodes == sum(po) + 1
+        o.close()
+    with pytest.raises(M.MpxError, match="outside 1..255"):
+        M.NlpFunctions(ocp, 1, [256], "LGR", with_device=False)
+    monkeypatch.setenv("MPX_TABLES_STREAM_ABOVE", "255")
     with pytest.raises(M.MpxError, match="LDS"):
         M.NlpFunctions(ocp, 1, [120], "LGR", with_device=False)
 
