@@ -450,6 +450,17 @@ int mpx_current_pin_buffers(int enable);
  * made by the cache and calls answered without a device pass.  MPX_NO_COALESCE=1 (environment, read by mpx_set_current)
  * switches the cache off. */
 int mpx_current_cache_stats(long long* fused_passes, long long* served_from_cache);
+/* The name nlp_hess_l_name_out(0) answers with.  CasADi resolves the functions of an external oracle BY NAME and compares every
+ * input / output name with its request string (':' -> '_'); the request for the Hessian of the Lagrangian differs between the
+ * versions the reference admits (setup.py:29 casadi >= 3.5.5; requirements.txt:4 casadi == 3.6.0):
+ *   3.6.x  "triu:hess:gamma:x:x" -> triu_hess_gamma_x_x   (default; mpx_current_set_casadi_abi(306))
+ *   3.5.x  "sym:hess:gamma:x:x"  -> sym_hess_gamma_x_x    (mpx_current_set_casadi_abi(305); from the 3.5.5 sources as remembered --
+ *          no CasADi of any version is available to the build)
+ * Both are the same upper-triangular compressed-column matrix.  mpx_current_set_hess_l_output_name sets any other identifier
+ * ([A-Za-z0-9_], < 64 characters) -- e.g. the one a future importer's "Inconsistent output name. Expected: ..." message names.
+ * Process-wide, like the current context; call before ca.nlpsol(...). */
+int mpx_current_set_casadi_abi(int major_minor);
+int mpx_current_set_hess_l_output_name(const char* name);
 /* Caller arrays page-locked so far by mpx_current_pin_buffers(1) and registrations that failed (remembered, not retried): a
  * solver that passes the same work-vector slices on every call stops adding to these after its first iteration. */
 int mpx_current_pin_stats(long long* registered, long long* failed);

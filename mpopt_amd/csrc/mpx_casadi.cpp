@@ -310,7 +310,24 @@ extern "C" const char* nlp_hess_l_name_in(long long i) {
   static const char* n[] = {"x", "p", "lam_f", "lam_g"};
   return i >= 0 && i < 4 ? n[i] : 0;
 }
-extern "C" const char* nlp_hess_l_name_out(long long i) { return i == 0 ? "triu_hess_gamma_x_x" : 0; }
+// ... and the request is VERSION-specific: the reference admits casadi >= 3.5.5 (setup.py:29, requirements_dev.txt:5), whose solver
+// interfaces ask for the same upper-triangular Hessian as "sym:hess:gamma:x:x" (the "triu:" attribute came with 3.6).  The name is a
+// property of the process-wide hand-off like the current context: mpx_current_set_casadi_abi(305 | 306) picks it, and
+// mpx_current_set_hess_l_output_name takes whatever string an importer's "Inconsistent output name. Expected: ..." asks for.
+static char g_hess_l_out_name[64] = "triu_hess_gamma_x_x";
+extern "C" int mpx_current_set_hess_l_output_name(const char* name) {
+  if (!name || !*name || strlen(name) >= sizeof g_hess_l_out_name) return MPX_ERR_INVALID;
+  for (const char* q = name; *q; ++q)
+    if (!((*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || (*q >= '0' && *q <= '9') || *q == '_')) return MPX_ERR_INVALID;
+  strcpy(g_hess_l_out_name, name);
+  return MPX_OK;
+}
+extern "C" int mpx_current_set_casadi_abi(int major_minor) {
+  if (major_minor >= 306) return mpx_current_set_hess_l_output_name("triu_hess_gamma_x_x");
+  if (major_minor >= 303) return mpx_current_set_hess_l_output_name("sym_hess_gamma_x_x");
+  return MPX_ERR_UNSUPPORTED;
+}
+extern "C" const char* nlp_hess_l_name_out(long long i) { return i == 0 ? g_hess_l_out_name : 0; }
 extern "C" const long long* nlp_hess_l_sparsity_in(long long i) {
   return i == 0 ? C.sp_x.data() : (i == 1 ? C.sp_p.data() : (i == 2 ? C.sp_one.data() : (i == 3 ? C.sp_g.data() : 0)));
 }

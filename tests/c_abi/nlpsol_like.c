@@ -144,13 +144,21 @@ int main(int argc, char** argv) {
    * For an external oracle External::factory looks the function up BY NAME in the library and then checks every input / output
    * name against the request string with ':' replaced by '_' ("Inconsistent input name. Expected: ..."); the expected symbol
    * names below are COMPUTED by that rule from the request strings, never written out. */
+  /* NLPSOL_LIKE_CASADI_ABI=305: the table of CasADi 3.5.x (the reference's setup.py:29 admits casadi >= 3.5.5), which differs in ONE
+   * request -- nlp_hess_l's output is "sym:hess:gamma:x:x" -- after telling the library so (mpx_current_set_casadi_abi). */
+  const char* abi_env = getenv("NLPSOL_LIKE_CASADI_ABI");
+  const int abi = abi_env ? atoi(abi_env) : 306;
+  if (abi != 306) {
+    int (*p_abi)(int) = (int (*)(int))sym("mpx_current_set_casadi_abi", "", 1);
+    if (p_abi(abi) != MPX_OK) DIE(4, "mpx_current_set_casadi_abi(%d) refused", abi);
+  }
   typedef struct { const char* name; const char* in[4]; const char* out[4]; } request_t;
-  static const request_t REQ[NFN] = {
+  const request_t REQ[NFN] = {
       {"nlp_f", {"x", "p", 0, 0}, {"f", 0, 0, 0}},
       {"nlp_g", {"x", "p", 0, 0}, {"g", 0, 0, 0}},
       {"nlp_grad_f", {"x", "p", 0, 0}, {"f", "grad:f:x", 0, 0}},
       {"nlp_jac_g", {"x", "p", 0, 0}, {"g", "jac:g:x", 0, 0}},
-      {"nlp_hess_l", {"x", "p", "lam:f", "lam:g"}, {"triu:hess:gamma:x:x", 0, 0, 0}},
+      {"nlp_hess_l", {"x", "p", "lam:f", "lam:g"}, {abi >= 306 ? "triu:hess:gamma:x:x" : "sym:hess:gamma:x:x", 0, 0, 0}},
       {"nlp", {"x", "p", 0, 0}, {"f", "g", 0, 0}},
       {"nlp_grad", {"x", "p", "lam:f", "lam:g"}, {"f", "g", "grad:gamma:x", "grad:gamma:p"}}};
   const char* NAMES[NFN];

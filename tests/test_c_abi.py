@@ -2,6 +2,7 @@
 libmpx.so and driven with a problem description dumped from Python.  Without a GPU it must create a structure-only
 context and report sizes / patterns; on the GPU it evaluates a batch through mpx_eval and the values are compared with the
 reference goldens."""
+import ctypes
 import os
 import struct
 import subprocess
@@ -147,6 +148,28 @@ def test_nlpsol_like_caller_binds_every_symbol_without_a_gpu(name, tmp_path):
     hr, hc = o.hess_pattern()
     perm, ci = o.ccs_perm("hess")
     assert (nrow, ncol) == (o.n_z, o.n_z) and np.array_equal(colind, ci) and np.array_equal(rows, hr[perm])
+
+
+def test_nlp_hess_l_output_name_follows_the_casadi_version(tmp_path):
+    """CasADi 3.5.x requests the Hessian of the Lagrangian as "sym:hess:gamma:x:x", 3.6.x as "triu:hess:gamma:x:x"; the reference admits
+    both (setup.py:29, requirements.txt:4).  The importer stand-in runs with either table: with the 3.5 table it first tells the
+    library (mpx_current_set_casadi_abi(305)) -- and the 3.5 table against a library left at its default fails with CasADi's message."""
+    exe = build_nlpsol_like(tmp_path)
+    ocp, mpo, o = build_case("moon_lander_20x3_LGR", with_device=False)
+    dump_problem(tmp_path / "problem.bin", o, code=False)
+    args = [exe, _lib.LIB_PATH, str(tmp_path / "problem.bin"), str(tmp_path / "out.bin")]
+    for abi in ("306", "305"):
+        r = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, NLPSOL_LIKE_CASADI_ABI=abi))
+        assert r.returncode == 0, r.stderr
+    L = _lib.lib()
+    try:
+        assert L.mpx_current_set_casadi_abi(305) == 0 and ctypes.cast(L.nlp_hess_l_name_out, ctypes.CFUNCTYPE(ctypes.c_char_p, ctypes.c_longlong))(0) == b"sym_hess_gamma_x_x"
+        assert L.mpx_current_set_hess_l_output_name(b"hess_gamma_x_x") == 0
+        assert ctypes.cast(L.nlp_hess_l_name_out, ctypes.CFUNCTYPE(ctypes.c_char_p, ctypes.c_longlong))(0) == b"hess_gamma_x_x"
+        assert L.mpx_current_set_hess_l_output_name(b"bad:name") != 0 and L.mpx_current_set_casadi_abi(200) != 0
+    finally:
+        assert L.mpx_current_set_casadi_abi(306) == 0
+    assert ctypes.cast(L.nlp_hess_l_name_out, ctypes.CFUNCTYPE(ctypes.c_char_p, ctypes.c_longlong))(0) == b"triu_hess_gamma_x_x"
 
 
 @pytest.mark.gpu

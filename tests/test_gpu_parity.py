@@ -99,6 +99,7 @@ def test_time_dependent_two_phase_multi_tile_against_numpy_oracle():
 
 
 FULL = {
+    "config1_moon_lander_20x3_LGR": ((problems.moon_lander, 20, 3, "LGR"), ["moon_lander"], 1.0, [1]),  # BASELINE.json configs[0]
     "config2_moon_lander_1000x5_LGR": (problems.BENCH_CASES[0], ["moon_lander"], 1.0, [1]),
     "config3_vdp_2000_mixed_CGL": (problems.BENCH_CASES[1], ["van_der_pol"], 1.0, [1]),
     "config4_schwartz_2x500x3_LGL": (problems.BENCH_CASES[2], ["schwartz_phase0", "schwartz_phase1"], 1.0, [1, 0]),
@@ -179,6 +180,19 @@ def test_full_size_against_c_oracle_and_properties(name):
         assert_by_class(Jd, Jal[b], jcl, 10 * TOL, tag + " jac_g")
         assert_by_class(np.asarray(Cd.hess_matrix(Z[b], p, sig, lam)[hr, hc]).ravel(), np.asarray(Hc[hr, hc]).ravel(), hess_classes(o, hr, hc), 10 * TOL, tag + " hess_l")
         assert_by_class(cd["grad_f"], c["grad_f"], grad_classes(o), 10 * TOL, tag + " grad_f")
+        # north_star's contract is stated against the CPU reference in BINARY64: at the five BASELINE configurations (and the C3
+        # variant) the GPU is within 1e-10 per entry of the binary64 oracle as well.  Not asserted for the time_dependent stress
+        # cases: from ~5000 segments of an explicitly time-dependent problem the reference's own sequential accumulation of the
+        # node times (mpopt.py:192) is more than 1e-10 from exact in the (t0, tf) border columns (1.7e-10 at 8000 x 3, logged
+        # above) -- libmpx follows the exact value.
+        if name.startswith("config"):
+            tag = f"{name}[{b}] (GPU vs the C oracle in binary64:)"
+            assert rel_err(r["f"][b], cd["f"]) < TOL
+            assert_by_class(r["jac_g"][b], Jd, jcl, TOL, tag + " jac_g")
+            assert_by_class(r["g"][b], cd["g"], {"defect rows (D.X - h Sx dyn)": isF, "other rows": ~isF}, TOL, tag + " g",
+                            floors={"defect rows (D.X - h Sx dyn)": term})
+            assert_by_class(r["grad_f"][b], cd["grad_f"], grad_classes(o), TOL, tag + " grad_f")
+            assert_by_class(r["hess_l"][b], np.asarray(Cd.hess_matrix(Z[b], p, sig, lam)[hr, hc]).ravel(), hess_classes(o, hr, hc), TOL, tag + " hess_l")
     # size-independent derivative properties (central differences of the GPU's own f, g)
     rng = np.random.default_rng(5)
     v = rng.standard_normal(o.n_z)
@@ -197,7 +211,7 @@ def test_full_size_against_c_oracle_and_properties(name):
     assert np.abs(H @ v - dL).max() < 2e-5 * max(1.0, np.abs(dL).max())
 
 
-@pytest.mark.parametrize("name", list(FULL))
+@pytest.mark.parametrize("name", [n for n in FULL if not n.startswith("config1_")])  # (20 x 3: 61 nodes, no span plan)
 def test_full_size_light_passes_against_c_oracle_and_node_kernels(name, monkeypatch):
     """The kernels a line search calls -- nlp_f, nlp_g, nlp_grad_f WITHOUT the Jacobian values are served by the span kernels
     (mpx_lightlow_* on single-degree grids, mpx_light_* on the matrix cores for the [3, 30, 3] grids) -- at every BASELINE size: at
