@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="evaluation points per GPU per step (default 4096; 512 for config 3 first-order and the config-5 loop, 16 for the shard workloads)")
     ap.add_argument("--segments", type=int, default=1000)
     ap.add_argument("--degree", type=int, default=5)
+    ap.add_argument("--adaptive-grid", default="20x5", help="adaptive-* workloads: SEGMENTSxDEGREE of the mpopt_adaptive transcription (default 20x5)")
     ap.add_argument("--plain-outputs", action="store_true", help="time plain torch.empty output arrays instead of NlpFunctions.alloc_outputs")
     ap.add_argument("--workload", default="config2-fgj", choices=["config2-fgj", "config5-hess", "config3-fgj", "config3-hess", "config2-hess", "adaptive-fgj", "config3-shard", "config4-shard", "config5-loop",
                                                                       "config4-fgj", "config4-hess", "config5-fgj", "adaptive-hess"],
@@ -390,8 +391,8 @@ def main():
         hess_mode = True
     adaptive = args.workload.startswith("adaptive")
     if adaptive:  # widths as decision variables, assembled context (point kernels + gather)
-        S, P = 20, 5
-        label = "moon-lander OCP, mpopt_adaptive (segment widths as variables), n_segments=20, poly_orders=5, LGR"
+        S, P = (int(v) for v in args.adaptive_grid.lower().split("x"))
+        label = f"moon-lander OCP, mpopt_adaptive (segment widths as variables), n_segments={S}, poly_orders={P}, LGR"
     ocp = builder(mp, M.math)
     mpo = (mp.mpopt_adaptive if adaptive else mp.mpopt)(ocp, S, P, scheme, device=dev_id)
     if rank == 0 or world == 1:

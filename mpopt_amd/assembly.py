@@ -230,18 +230,18 @@ class AssembledNlpFunctions(NlpFunctions):
             # (the first-order pass this way is an opt-in, MPX_LANES_FGJ=1: bit-identical, but the pass is 96 % output and the fused kernel
             # already runs at the write-stream ceiling -- 100 against 58 us at moon lander 20x5, profiles/r5_lanes)
             self.lanes_plan_fgj = assembly_lanes.plan_pass(self, "fgj") if os.environ.get("MPX_LANES_FGJ", "0") == "1" else None
-            parts = []
+            # Only the PLAN and the entry order it implies are fixed here (the public order of hess_l / jac_g depends on it: use
+            # jac_pattern / hess_pattern / ccs_perm, never an assumed order); the source text of the kernels is generated, compiled and
+            # attached at the first batch (attach_lane_kernels) -- a solve through single evaluations never pays for any of it.
+            self._lanes_todo = []
             for plan, tag in ((self.lanes_plan, "HES"), (self.lanes_plan_fgj, "FGJ")):
                 if plan is not None:
                     assembly_lanes.group_major(self, plan)
                     mt = sizes["MT_" + tag]
-                    parts.append(assembly_lanes.pass_source(self, mt if mt >= 2 else 24, plan))
-            if parts:
-                # a translation unit of its own, compiled and attached at the first batch (attach_lane_kernels): its straight-line code
-                # takes as long to compile as the rest of the context together, and a solve through single evaluations never runs it
-                self.lanes_source = "\n".join(["// generated by mpopt_amd.assembly_lanes -- do not edit", "#include <hip/hip_runtime.h>", "namespace mpxgen {",
-                                               "template <int FID> struct Pt;"] + [f.source(k) for k, f in enumerate(funcs)] +
-                                              ["}  // namespace mpxgen", assembly_lanes.common_source(self)] + parts) + "\n"
+                    self._lanes_todo.append((plan, mt if mt >= 2 else 24))
+            self._lanes_funcs = funcs
+            if self._lanes_todo:
+                self.lanes_source = True  # (generated on demand: lanes_source_text)
         self.source = self._source(funcs, sizes, self._set_consts)
         if with_device is None:
             with_device = _lib.gpu_available()
@@ -255,10 +255,37 @@ class AssembledNlpFunctions(NlpFunctions):
         Called by the evaluation methods at the first batch of >= 64 points; idempotent."""
         if self._lanes_attached or self.lanes_source is None or self.code_object is None:
             return
-        co, _ = _lib.compile_kernels(self.lanes_source, verbose=verbose)
-        self._lanes_co_buf = ctypes.create_string_buffer(co, len(co))  # (kept like the context's own code object)
-        _lib.check(self._L.mpx_assembled_attach_kernels(self._ctx, ctypes.cast(self._lanes_co_buf, ctypes.c_void_p), len(co)), self._ctx)
+        # Whatever goes wrong here -- a source too large to be worth compiling, hipcc failing, the library refusing the object -- the
+        # fused and two-pass kernels serve every call: the failure is recorded ONCE (a warning, `lanes_error`) and never retried.
         self._lanes_attached = True
+        try:
+            src = self.lanes_source_text()
+            if len(src) > self.LANES_MAX_SOURCE_BYTES:
+                raise _lib.MpxError(f"generated source of {len(src) >> 10} KB exceeds LANES_MAX_SOURCE_BYTES ({self.LANES_MAX_SOURCE_BYTES >> 10} KB)")
+            co, _ = _lib.compile_kernels(src, verbose=verbose)
+            self._lanes_co_buf = ctypes.create_string_buffer(co, len(co))  # (kept like the context's own code object)
+            _lib.check(self._L.mpx_assembled_attach_kernels(self._ctx, ctypes.cast(self._lanes_co_buf, ctypes.c_void_p), len(co)), self._ctx)
+        except _lib.MpxError as e:
+            import warnings
+
+            self.lanes_error, self.lanes_source = str(e), None
+            warnings.warn(f"mpopt_amd: lane-per-point kernels not attached ({str(e)[:300]}); the fused kernels serve the batches", RuntimeWarning)
+
+    # (one body per group SHAPE keeps real grids at 100-500 KB of source: moon lander 200 x 3 -> 125 KB, 1.5 s of hipcc; a transcription
+    # whose every group is its own shape would grow with the grid as it did up to round 5 -- 3 MB and 107 s at 80 x 5 -- and is refused)
+    LANES_MAX_SOURCE_BYTES = 2 << 20
+    lanes_error = None
+
+    def lanes_source_text(self):
+        """The translation unit of the lane-per-point kernels (generated on first use, kept)."""
+        if getattr(self, "_lanes_text", None) is None:
+            from . import assembly_lanes
+
+            parts = [assembly_lanes.pass_source(self, thr, plan) for plan, thr in self._lanes_todo]
+            self._lanes_text = "\n".join(["// generated by mpopt_amd.assembly_lanes -- do not edit", "#include <hip/hip_runtime.h>", "namespace mpxgen {",
+                                          "template <int FID> struct Pt;"] + [f.source(k) for k, f in enumerate(self._lanes_funcs)] +
+                                         ["}  // namespace mpxgen", assembly_lanes.common_source(self)] + parts) + "\n"
+        return self._lanes_text
 
     def _wants_lanes(self, mask, batch):
         """A batch of a pass that has lane kernels (hess_l; the first-order pass only as the MPX_LANES_FGJ opt-in)?"""

@@ -375,7 +375,18 @@ def pass_source(o, thr, plan):
     kind, ptr, src, coef = plan.kind, P.ptr, P.src, P.coef
     KIND = kind.upper()
     parts = [f"namespace mpxgen {{", f"template <int G> struct LaneGrp{KIND};"]
+    # One generated body per group SHAPE, not per group (round 6): equal-degree interior segments of a grid differ in nothing but where
+    # their columns of z / lam_g and their rows of the outputs start -- those numbers are the group's PARAMETERS (a constant int table
+    # of the code object, read with scalar loads: `par[i]`), everything else (coefficients, tile positions, term order) is the shape's
+    # text, and groups whose text is equal share one struct.  Up to round 5 every group was its own struct: 100 x 3 compiled for 49 s
+    # into a 459 KB code object, every wavefront of a launch on different instructions.
+    shapes, shape_of, par_off, par_all = {}, [], [], []
     for gi, g in enumerate(plan.groups):
+        par = []
+
+        def P_(v):  # a group parameter -> the expression that reads it
+            par.append(int(v))
+            return f"par[{len(par) - 1}]"
         zpos = {c: e for e, c in enumerate(g["zcols"])}
         nz = len(g["zcols"])
         lpos = {c: nz + e for e, c in enumerate(g["lcols"])}
@@ -413,7 +424,7 @@ def pass_source(o, thr, plan):
                 out.append(f"      (void)mu; Pt<{fid}>::jac(loc, cst, {vn}, {vn} + {fn.n_out});")
             out.append("    }")
             for q, sd in g["scratch"].get(kp, []):  # (values global rows read: this group owns the task)
-                out.append(f"    io.S[{sd} * 64] = {vn}[{q}];")
+                out.append(f"    io.S[{P_(sd)} * 64] = {vn}[{q}];")
             return out
 
         def value(x):
@@ -462,23 +473,33 @@ def pass_source(o, thr, plan):
                 while j + n < len(crow) and P.array_of(crow[j + n]) == (a, i0 + n):
                     n += 1
                 for start, k2, e in _pieces([(i0, n, ob + j)]):
-                    body.append(f"      io.template st<{a}, {start}, {k2}, {e}>();")
+                    body.append(f"      io.template st<{a}, {k2}, {e}>({P_(start)});")
                 j += n
             body.append("    }")
         zr, lr = _pieces(_runs(g["zcols"])), _pieces(_runs(g["lcols"]))
-        parts.append(f"template <> struct LaneGrp{KIND}<{gi}> {{")
-        parts.append(f"  static constexpr int NE = {g['ne']};")
-        for name, call in (("load", "ld"), ("fill", "put")):
-            parts.append(f"  template <class IO> __device__ static __forceinline__ void {name}(IO& io) {{")
-            parts += [f"    io.template {call}<0, {a}, {n}, {e}>();" for a, n, e in zr]
-            parts += [f"    io.template {call}<1, {a}, {n}, {nz + e}>();" for a, n, e in lr]
-            parts.append("  }")
-        parts.append("  template <class IO> __device__ static __forceinline__ void run(IO& io, const double sg) {")
-        parts.append("#pragma clang fp contract(off)")
-        parts.append("    const double* __restrict__ T = io.T + io.lane; (void)T; (void)sg;")
-        parts += [ln for ln in body if ln]
-        parts.append("  }")
-        parts.append("};")
+        text = [f"  static constexpr int NE = {g['ne']};"]
+        text.append("  template <class IO> __device__ static __forceinline__ void load(IO& io, const int* __restrict__ par) {")
+        text += [f"    io.template ld<0, {n}, {e}>({P_(a)});" for a, n, e in zr]
+        text += [f"    io.template ld<1, {n}, {nz + e}>({P_(a)});" for a, n, e in lr]
+        text.append("  }")
+        text.append("  template <class IO> __device__ static __forceinline__ void fill(IO& io) {")
+        text += [f"    io.template put<{n}, {e}>();" for a, n, e in zr]
+        text += [f"    io.template put<{n}, {nz + e}>();" for a, n, e in lr]
+        text.append("  }")
+        text.append("  template <class IO> __device__ static __forceinline__ void run(IO& io, const double sg, const int* __restrict__ par) {")
+        text.append("#pragma clang fp contract(off)")
+        text.append("    const double* __restrict__ T = io.T + io.lane; (void)T; (void)sg; (void)par;")
+        text += [ln for ln in body if ln]
+        text.append("  }")
+        text = "\n".join(text)
+        if text not in shapes:
+            shapes[text] = len(shapes)
+            parts.append(f"template <> struct LaneGrp{KIND}<{shapes[text]}> {{")
+            parts.append(text)
+            parts.append("};")
+        shape_of.append(shapes[text])
+        par_off.append(len(par_all))
+        par_all += par
     # the global rows: a constant table of the code object (row pointers, sources -- scratch slot, -1: 1.0, <= -2: column of z --,
     # coefficients, output array and index); mpx_asml_*_global sums them with lanes <-> evaluation points
     # (every row padded with terms (0.0, the constant 1.0) to a multiple of 8, the long rows of 64: mpx_assembly_lanes.h)
@@ -496,6 +517,9 @@ def pass_source(o, thr, plan):
         a, i = P.array_of(r)
         garr.append(a), gidx.append(i), glong.append(1 if nt > thr else 0)
     arr = lambda v, f=str: "{" + ", ".join(f(x) for x in (v if len(v) else [0])) + "}"
+    parts.append(f"__device__ const int lane_shape_{kind}[] = {arr(shape_of)};")
+    parts.append(f"__device__ const int lane_poff_{kind}[] = {arr(par_off)};")
+    parts.append(f"__device__ const int lane_par_{kind}[] = {arr(par_all)};")
     parts.append(f"__device__ const int lane_gptr_{kind}[] = {arr(gptr)};")
     parts.append(f"__device__ const int lane_gsrc_{kind}[] = {arr(gsrc)};")
     parts.append(f"__device__ const double lane_gcoef_{kind}[] = {arr(gcoef, _cfloat)};")
@@ -505,14 +529,28 @@ def pass_source(o, thr, plan):
     parts.append("}  // namespace mpxgen")
     strides = [o.nnz_hess_] if kind == "hes" else [1, o.n_g_, o.n_z_, o.nnz_jac_]
     parts.append(f"#define MPX_LANE_{KIND}_GROUPS {len(plan.groups)}")
+    parts.append(f"#define MPX_LANE_{KIND}_SHAPES {len(shapes)}")
+    plan.n_shapes = len(shapes)
     parts.append(f"#define MPX_LANE_{KIND}_TILE_ROWS {plan.tile_rows}")
     parts.append(f"#define MPX_LANE_{KIND}_NGLOBAL {len(plan.global_rows)}")
     parts.append(f"#define MPX_LANE_{KIND}_NSID {len(plan.sid)}")
     parts.append(f"#define MPX_LANE_{KIND}_THR {int(thr)}")
     parts.append(f"#define MPX_LANE_{KIND}_CHECK {o.nnz_hess_ if kind == 'hes' else o.nnz_jac_}")
+    parts.append(f"#define MPX_LANE_{KIND}_HASH {pattern_hash(*((o.hrow, o.hcol) if kind == 'hes' else (o.jrow, o.jcol)), o.n_z_, o.n_g_)}")
     parts.append(f"#define MPX_LANE_{KIND}_STRIDES {arr(strides)}")
     parts.append(f"MPX_INSTANTIATE_LANES({kind}, {KIND}, {0 if kind == 'hes' else 1})")
     return "\n".join(parts)
+
+
+def pattern_hash(row, col, n_z, n_g):
+    """31-bit hash of a pattern IN ITS ORDER (+ the sizes): the lane kernels bake the group-major entry order of one transcription
+    into their stores, so libmpx compares this number (mpx_assembly.cpp: lane_pattern_hash, the same arithmetic) with the pattern of
+    the context a code object is attached to -- an object generated for another order with the same nnz is refused."""
+    i = np.arange(len(row), dtype=np.uint64)
+    m = np.uint64(0xFFFFFFFF)
+    v = ((np.asarray(row, np.uint64) * np.uint64(73856093)) & m) ^ ((np.asarray(col, np.uint64) * np.uint64(19349663)) & m) ^ ((i * np.uint64(83492791)) & m)
+    h = (int(v.sum()) + 2654435761 * (int(n_z) & 0xFFFFFFFF) + 40503 * (int(n_g) & 0xFFFFFFFF)) & 0xFFFFFFFF
+    return h & 0x7FFFFFFF
 
 
 def common_source(o):

@@ -324,17 +324,27 @@ void mpx_asm_release(mpx_ctx* c) {
 // The lane-per-point kernels of a code object (generated when the point tasks fall into groups: mpopt_amd/assembly_lanes.py), either the
 // context's own or one attached later (mpx_assembled_attach_kernels): mpx_asml_<pass>_info = {groups, tile doubles, nnz of the pass's
 // pattern (a check), global rows, scratch slots}.
-static void load_lanes(mpx_asm_state* a, hipModule_t mod, int64_t nnz_hess, int64_t nnz_jac) {
+// (assembly_lanes.py: pattern_hash -- the same arithmetic)
+static int lane_pattern_hash(const std::vector<int32_t>& row, const std::vector<int32_t>& col, int64_t n_z, int64_t n_g) {
+  uint64_t s = 0;
+  for (size_t i = 0; i < row.size(); ++i)
+    s += (((uint64_t)(uint32_t)row[i] * 73856093u) & 0xFFFFFFFFu) ^ (((uint64_t)(uint32_t)col[i] * 19349663u) & 0xFFFFFFFFu) ^ (((uint64_t)i * 83492791u) & 0xFFFFFFFFu);
+  const uint64_t h = (s + 2654435761ull * ((uint64_t)n_z & 0xFFFFFFFFu) + 40503ull * ((uint64_t)n_g & 0xFFFFFFFFu)) & 0xFFFFFFFFu;
+  return (int)(h & 0x7FFFFFFFu);
+}
+
+static void load_lanes(mpx_ctx* c, mpx_asm_state* a, hipModule_t mod, int64_t nnz_hess, int64_t nnz_jac) {
+  const int want_hash[2] = {lane_pattern_hash(c->hrow, c->hcol, c->n_z, c->n_g), lane_pattern_hash(c->jrow, c->jcol, c->n_z, c->n_g)};
   for (int ps = 0; ps < 2; ++ps) {
     static const char* iname[2] = {"mpx_asml_hes_info", "mpx_asml_fgj_info"};
     static const char* kname2[2] = {"mpx_asml_hes", "mpx_asml_fgj"};
     static const char* gname[2] = {"mpx_asml_hes_global", "mpx_asml_fgj_global"};
-    int li[5] = {0, 0, 0, 0, 0};
+    int li[6] = {0, 0, 0, 0, 0, 0};
     hipFunction_t fl = nullptr, fg = nullptr;
     hipDeviceptr_t sym = nullptr;
     size_t bytes = 0;
     if (hipModuleGetGlobal(&sym, &bytes, mod, iname[ps]) == hipSuccess && bytes == sizeof li && hipMemcpyDtoH(li, sym, sizeof li) == hipSuccess &&
-        li[0] >= 1 && li[2] == (int)(ps == 0 ? nnz_hess : nnz_jac) && hipModuleGetFunction(&fl, mod, kname2[ps]) == hipSuccess &&
+        li[0] >= 1 && li[2] == (int)(ps == 0 ? nnz_hess : nnz_jac) && li[5] == want_hash[ps] && hipModuleGetFunction(&fl, mod, kname2[ps]) == hipSuccess &&
         (li[3] == 0 || hipModuleGetFunction(&fg, mod, gname[ps]) == hipSuccess))
       a->lanes[ps].fn = fl, a->lanes[ps].fn_global = fg, a->lanes[ps].groups = li[0], a->lanes[ps].n_global = li[3], a->lanes[ps].n_sid = li[4];
   }
@@ -356,7 +366,7 @@ extern "C" int mpx_assembled_attach_kernels(mpx_ctx* c, const void* code_object,
     a->lanes_module = nullptr;
     return fail(c, MPX_ERR_HIP, "mpx_assembled_attach_kernels: hipModuleLoadData failed (is the code object built for this GPU?)");
   }
-  load_lanes(a, a->lanes_module, c->nnz_h, c->nnz_j);
+  load_lanes(c, a, a->lanes_module, c->nnz_h, c->nnz_j);
   return MPX_OK;
 }
 
@@ -607,7 +617,7 @@ extern "C" int mpx_create_assembled(const mpx_assembly* D, mpx_ctx** out) {
       }
     }
     (void)hipGetLastError();
-    load_lanes(a, c->module, D->nnz_hess, D->nnz_jac);  // (code objects that carry the lane kernels themselves)
+    load_lanes(c, a, c->module, D->nnz_hess, D->nnz_jac);  // (code objects that carry the lane kernels themselves)
     (void)hipGetLastError();
   }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(c, MPX_ERR_HIP, "hipEventCreate failed"));
@@ -731,6 +741,10 @@ static int launch_lanes(mpx_ctx* c, int ps, int64_t batch, const double* z, cons
   mpx_asm_state* a = c->assembled;
   const mpx_asm_state::Lanes& L = a->lanes[ps];
   const int64_t n_blocks = (batch + 63) / 64;  // (the last block of a ragged batch starts at batch - 64)
+  // (the last block of a ragged batch repeats a few points of its neighbour: two wavefronts store the SAME values to the same
+  // addresses -- the lane kernels' outputs must stay pure overwrites, never accumulations)
+  if (batch < 64 || batch > INT32_MAX - 64 || 8 * (int64_t)L.groups * ((n_blocks + 7) / 8) > INT32_MAX)
+    return fail(c, MPX_ERR_UNSUPPORTED, "lane kernels: a batch of %lld evaluation points x %d groups does not fit one launch", (long long)batch, L.groups);
   int rc;
   if (L.n_sid > 0 && (rc = reserve(c, a->lane_scratch, (size_t)(n_blocks * L.n_sid * 64)))) return rc;
   MpxLaneArgs A{};

@@ -50,22 +50,24 @@ struct LaneIO {
   // A piece of 2^K columns starting at START of array SRC (0: z, 1: lam_g), tile rows E0 .. E0 + 2^K - 1: instruction i of its 2^K
   // moves the points i * PPI .. (i + 1) * PPI - 1, PPI = 64 >> K; lane = (point within the instruction) << K | column.  Every
   // address is  uniform base + a per-lane term that depends on K only + a compile-time constant  (the row strides are constants).
-  template <int SRC, int START, int K, int E0>
-  __device__ __forceinline__ void ld() {
+  // (`start`: a parameter of the GROUP, read from the code object's constant table -- uniform, it joins the base pointer; everything
+  // else of a piece is the group's SHAPE, compile time)
+  template <int SRC, int K, int E0>
+  __device__ __forceinline__ void ld(const int start) {
     constexpr int PPI = 64 >> K, STRIDE = SRC == 0 ? MPX_LANE_ZS : MPX_LANE_LS;
     // (byte offsets in 32 bits: uniform base in scalar registers + one VGPR offset per access, no 64-bit address arithmetic per lane)
     const unsigned lo = 8u * (unsigned)((lane >> K) * STRIDE + (lane & ((1 << K) - 1)));
-    const char* __restrict__ src = (const char*)(SRC == 0 ? zb : lb);
+    const char* __restrict__ src = (const char*)((SRC == 0 ? zb : lb) + start);
 #pragma unroll
     for (int i = 0; i < (1 << K); ++i) {
       // (one 32-bit add per access, pinned: left alone the compiler widens  base + lane offset  to 64 bits once and then adds every
       // constant to that with a carry chain, two vector instructions per access)
-      unsigned off = lo + 8u * (unsigned)(i * PPI * STRIDE + START);
+      unsigned off = lo + 8u * (unsigned)(i * PPI * STRIDE);
       asm volatile("" : "+v"(off));
       v[E0 + i] = *(const double*)(src + off);
     }
   }
-  template <int SRC, int START, int K, int E0>
+  template <int K, int E0>
   __device__ __forceinline__ void put() {
     constexpr int PPI = 64 >> K;
     const int lo = (lane & ((1 << K) - 1)) * MPX_LANE_LDW + (lane >> K);
@@ -73,18 +75,18 @@ struct LaneIO {
     for (int i = 0; i < (1 << K); ++i) T[lo + (E0 * MPX_LANE_LDW + i * PPI)] = v[E0 + i];
   }
   // rows E0 .. of the tile -> entries START .. of output array ARR
-  template <int ARR, int START, int K, int E0>
-  __device__ __forceinline__ void st() {
+  template <int ARR, int K, int E0>
+  __device__ __forceinline__ void st(const int start) {
     constexpr int PPI = 64 >> K, OS = ST::stride(ARR);
     const unsigned lo = 8u * (unsigned)((lane >> K) * OS + (lane & ((1 << K) - 1)));
     const int lt = (lane & ((1 << K) - 1)) * MPX_LANE_LDW + (lane >> K);
-    char* __restrict__ dst = (char*)ob[ARR];
+    char* __restrict__ dst = (char*)(ob[ARR] + start);
     double w[1 << K];  // (all of the piece's tile reads first: the pinned offsets below keep the order they are written in)
 #pragma unroll
     for (int i = 0; i < (1 << K); ++i) w[i] = T[lt + (E0 * MPX_LANE_LDW + i * PPI)];
 #pragma unroll
     for (int i = 0; i < (1 << K); ++i) {
-      unsigned off = lo + 8u * (unsigned)(i * PPI * OS + START);
+      unsigned off = lo + 8u * (unsigned)(i * PPI * OS);
       asm volatile("" : "+v"(off));
       *(double*)(dst + off) = w[i];
     }
@@ -94,32 +96,33 @@ struct LaneIO {
 // (Blocks are always whole: the last block of a batch that is no multiple of 64 starts at B - 64 and repeats a few evaluation points
 // of its neighbour -- the same values into the same places; B >= 64.)
 template <class GR, class ST>
-__device__ __forceinline__ void lane_group(const ::MpxLaneArgs& A, int blk, double* __restrict__ T) {
+__device__ __forceinline__ void lane_group(const ::MpxLaneArgs& A, int blk, double* __restrict__ T, const int* __restrict__ par) {
   const int lane = threadIdx.x;
   const int64_t b0 = (int64_t)blk * 64 + 64 <= A.B ? (int64_t)blk * 64 : (int64_t)A.B - 64;
   LaneIO<GR::NE, ST> io{A.z + b0 * MPX_LANE_ZS, A.lam ? A.lam + b0 * MPX_LANE_LS : nullptr, {nullptr, nullptr, nullptr, nullptr},
                         A.scratch ? A.scratch + ((int64_t)blk * ST::NSID) * 64 + lane : nullptr, T, lane, {}};
 #pragma unroll
   for (int a = 0; a < ST::NARR; ++a) io.ob[a] = A.out[a] + b0 * ST::stride(a);
-  if (!(MPX_LANE_ABL & 1)) GR::load(io);
+  if (!(MPX_LANE_ABL & 1)) GR::load(io, par);
   const double sg = A.sigma ? A.sigma[b0 + lane] : 0.0;
   GR::fill(io);
   MPX_LANE_SYNC();
-  if (!(MPX_LANE_ABL & 2)) GR::run(io, sg);
+  if (!(MPX_LANE_ABL & 2)) GR::run(io, sg, par);
 }
 
+// (G: a group SHAPE -- the groups of a shape run the same struct with their own parameter rows `par`)
 template <template <int> class GRT, class ST, int G>
 struct LaneDispatch {
-  __device__ static __forceinline__ void run(const ::MpxLaneArgs& A, int g, int blk, double* T) {
-    if (g == G)
-      lane_group<GRT<G>, ST>(A, blk, T);
+  __device__ static __forceinline__ void run(const ::MpxLaneArgs& A, int shape, int blk, double* T, const int* par) {
+    if (shape == G)
+      lane_group<GRT<G>, ST>(A, blk, T, par);
     else
-      LaneDispatch<GRT, ST, G - 1>::run(A, g, blk, T);
+      LaneDispatch<GRT, ST, G - 1>::run(A, shape, blk, T, par);
   }
 };
 template <template <int> class GRT, class ST>
 struct LaneDispatch<GRT, ST, -1> {
-  __device__ static __forceinline__ void run(const ::MpxLaneArgs&, int, int, double*) {}
+  __device__ static __forceinline__ void run(const ::MpxLaneArgs&, int, int, double*, const int*) {}
 };
 
 // One global row of one block of evaluation points: lane <-> point, the row's terms from the constant table (uniform: scalar loads),
@@ -201,7 +204,8 @@ __device__ __forceinline__ void lane_global_row(const ::MpxLaneArgs& A, int blk,
 #else
 #define MPX_LANE_OCC
 #endif
-// mpx_asml_<pass>_info: {groups, tile doubles, check (nnz of the pass's reordered pattern), global rows, scratch slots per block}
+// mpx_asml_<pass>_info: {groups, tile doubles, check (nnz of the pass's reordered pattern), global rows, scratch slots per block,
+// hash of that pattern in its order (assembly_lanes.py: pattern_hash)}
 #define MPX_INSTANTIATE_LANES(kind, KIND, PASS)                                                                                 \
   namespace mpxgen {                                                                                                            \
   struct LaneST##KIND {                                                                                                         \
@@ -211,9 +215,9 @@ __device__ __forceinline__ void lane_global_row(const ::MpxLaneArgs& A, int blk,
     __host__ __device__ static constexpr int stride(int a) { return strides_[a]; }                                             \
   };                                                                                                                            \
   }                                                                                                                             \
-  extern "C" __device__ __attribute__((used)) const int mpx_asml_##kind##_info[5] = {                                          \
+  extern "C" __device__ __attribute__((used)) const int mpx_asml_##kind##_info[6] = {                                          \
       MPX_LANE_##KIND##_GROUPS, MPX_LANE_##KIND##_TILE_ROWS * MPX_LANE_LDW, MPX_LANE_##KIND##_CHECK, MPX_LANE_##KIND##_NGLOBAL, \
-      MPX_LANE_##KIND##_NSID};                                                                                                  \
+      MPX_LANE_##KIND##_NSID, MPX_LANE_##KIND##_HASH};                                                                          \
   extern "C" __global__ __launch_bounds__(64) MPX_LANE_OCC void mpx_asml_##kind(const MpxLaneArgs A) {                         \
     __shared__ double T[MPX_LANE_##KIND##_TILE_ROWS * MPX_LANE_LDW];                                                            \
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, nb8 = (A.n_blocks + 7) >> 3;                                         \
@@ -222,7 +226,8 @@ __device__ __forceinline__ void lane_global_row(const ::MpxLaneArgs& A, int blk,
     if (blk >= A.n_blocks) return;                                                                                              \
     if (MPX_LANE_STAGGER > 0 && (idx & 1))                                                                                      \
       for (int k = 0; k < MPX_LANE_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);                                                  \
-    mpxk::LaneDispatch<mpxgen::LaneGrp##KIND, mpxgen::LaneST##KIND, MPX_LANE_##KIND##_GROUPS - 1>::run(A, g, blk, T);           \
+    mpxk::LaneDispatch<mpxgen::LaneGrp##KIND, mpxgen::LaneST##KIND, MPX_LANE_##KIND##_SHAPES - 1>::run(                        \
+        A, mpxgen::lane_shape_##kind[g], blk, T, mpxgen::lane_par_##kind + mpxgen::lane_poff_##kind[g]);                       \
   }                                                                                                                             \
   extern "C" __global__ __launch_bounds__(64) void mpx_asml_##kind##_global(const MpxLaneArgs A) {                              \
     if constexpr (MPX_LANE_##KIND##_NGLOBAL > 0)                                                                                \

@@ -368,7 +368,7 @@ def test_lane_plan_of_assembled_hessians(builder, S, P, scheme, expect, monkeypa
     unless every row couples everything (time-dependent dynamics: global rows, dropped for hess_l) or the problem is tiny.
     Structure of a plan: every entry of hess_l in exactly one group, group by group in the pattern's order; every raw value a row
     reads belongs to a task of ITS group (own or halo); the group's columns of z / lam_g cover what its tasks read for those
-    entries; the generated source has one LaneGrpHES per group and the pattern is still the same SET of (row, col) pairs as without
+    entries; the generated source has one LaneGrpHES per group SHAPE and the pattern is still the same SET of (row, col) pairs as without
     the plan.  MPX_LANES_FGJ=1 (opt-in: the first-order pass the same way, with its global rows f, d f / d t0, d f / d tf through the
     scratch array): the same checks on the rows of g / grad_f / jac_g, every row in one group or global."""
     from mpopt_amd import assembly_lanes
@@ -421,7 +421,6 @@ def test_lane_plan_of_assembled_hessians(builder, S, P, scheme, expect, monkeypa
                     assert {int(c) for c, d in zip(s_.L.indices[lo:hi], s_.L.data[lo:hi]) if d != 0} <= zc
             for kp, lst in g["scratch"].items():  # scratch slots are written by the group that owns the task, once
                 assert kp in g["own"]
-            assert f"struct LaneGrp{KIND}<{gi}>" in o.lanes_source
         assert seen == set(range(Pq.n_rows))  # every row: one group, or global
         # the reordered array (hess_l / jac_g): group by group, the global rows last
         last = len(Pq.arrays) - 1
@@ -429,4 +428,43 @@ def test_lane_plan_of_assembled_hessians(builder, S, P, scheme, expect, monkeypa
         assert rows_last == list(range(Pq.arrays[last][1], Pq.arrays[last][1] + Pq.arrays[last][2]))
         written = [sd for g in plan.groups for lst in g["scratch"].values() for _, sd in lst]
         assert sorted(written) == list(range(len(plan.sid)))
-        assert f"#define MPX_LANE_{KIND}_GROUPS {len(plan.groups)}" in o.lanes_source and f"MPX_INSTANTIATE_LANES({plan.kind}, {KIND}," in o.lanes_source
+        text = o.lanes_source_text()
+        assert f"#define MPX_LANE_{KIND}_GROUPS {len(plan.groups)}" in text and f"MPX_INSTANTIATE_LANES({plan.kind}, {KIND}," in text
+        # one struct per group SHAPE (round 6), every group an entry of the shape / parameter tables
+        assert 1 <= plan.n_shapes <= len(plan.groups) and f"#define MPX_LANE_{KIND}_SHAPES {plan.n_shapes}" in text
+        for sh in range(plan.n_shapes):
+            assert f"struct LaneGrp{KIND}<{sh}>" in text
+        assert f"struct LaneGrp{KIND}<{plan.n_shapes}>" not in text
+
+
+def test_lane_kernels_are_one_body_per_group_shape_not_per_segment():
+    """Round 6: equal-degree interior segments share ONE generated body -- what differs between them (where their
+    columns of z / lam_g and their rows of hess_l start) is a row of the code object's parameter table.  Moon lander 100 x 3 was 67
+    bodies, 32 527 lines, 48.8 s of hipcc and a 459 KB code object; now a handful of shapes whatever the number of segments, and
+    the source stops growing with the grid."""
+    sizes = {}
+    for S in (20, 100):
+        o = mp.mpopt_adaptive(problems.moon_lander(mp, M.math), S, 3, "LGR").create_nlp()[0]["oracle"]
+        assert o.lanes_plan is not None
+        text = o.lanes_source_text()
+        sizes[S] = (len(o.lanes_plan.groups), o.lanes_plan.n_shapes, len(text))
+        o.close()
+    assert sizes[100][0] >= 4 * sizes[20][0] and sizes[100][1] <= 6 and sizes[20][1] <= 6
+    assert sizes[100][2] < 1.5 * sizes[20][2] and sizes[100][2] < 300 * 1024
+
+
+def test_lane_kernel_failure_falls_back_once(monkeypatch):
+    """whatever goes wrong when the lane kernels are generated / compiled / attached must not reach the caller of eval --
+    the fused kernels serve the call, the failure is recorded once and not retried."""
+    import warnings
+
+    o = mp.mpopt_adaptive(problems.moon_lander(mp, M.math), 20, 3, "LGR").create_nlp()[0]["oracle"]
+    o.code_object = b"x"  # (pretend there is a device: attach_lane_kernels returns early without one)
+    monkeypatch.setattr(type(o), "LANES_MAX_SOURCE_BYTES", 1000)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        o.attach_lane_kernels()
+        o.attach_lane_kernels()
+    assert len(w) == 1 and "exceeds" in o.lanes_error and o.lanes_source is None and not o._wants_lanes(16, 4096)
+    o.code_object = None
+    o.close()
