@@ -239,6 +239,7 @@ def time_dependent(mp, fn):
 #: tests/golden/ holds vectors produced by the reference's own transcription code.
 GOLDEN_CASES = {
     "moon_lander_20x3_LGR": (moon_lander, 20, 3, "LGR"),            # BASELINE.json configs[0]
+    "moon_lander_10x6_LGR": (moon_lander, 10, 6, "LGR"),            # the grid of the reference's published per-call table (moon_lander.ipynb:171-210)
     "moon_lander_mixed_LGL": (moon_lander, 3, [2, 4, 3], "LGL"),
     "van_der_pol_4x3_CGL": (van_der_pol, 4, 3, "CGL"),
     "dae_vdp_mixed_CGL": (dae_vdp, 3, [3, 6, 3], "CGL"),
@@ -281,6 +282,20 @@ FULL_EXTRA_CASES = [
 
 #: seeds of the random mixed-degree grids of tests/test_gpu_parity.py::test_random_mixed_degree_grids (round 2's tools/span_soak.py
 #: as a test); __graft_entry__.build() compiles their kernels so that the GPU box finds them in the cache
+# The grids the reference PUBLISHES per-call oracle timings for (CasADi's timing table recorded in the
+# documentation notebooks, unknown CPU): name -> (builder, n_segments, degree, scheme, C-oracle problem names, scale_t, midu,
+# published (nlp_f, nlp_g, nlp_grad_f, nlp_jac_g, nlp_hess_l) in us per call, citation under /root/reference/docs/source/notebooks/)
+PUBLISHED_GRIDS = {
+    "moon_lander_10x6_LGR": (moon_lander, 10, 6, "LGR", ["moon_lander"], 1.0, [1], (4.39, 23.46, 6.24, 30.44, 8.44), "moon_lander.ipynb:171-210"),
+    "moon_lander_2x30_CGL": (moon_lander, 2, 30, "CGL", ["moon_lander"], 1.0, [1], (4.38, 59.19, 6.20, 88.47, 8.11), "moon_lander.ipynb:280-319"),
+    "moon_lander_2x30_LGL": (moon_lander, 2, 30, "LGL", ["moon_lander"], 1.0, [1], (4.22, 60.86, 6.28, 89.37, 8.16), "moon_lander.ipynb:373-412"),
+    "hyper_sensitive_5x50_LGR": (hyper_sensitive, 5, 50, "LGR", ["hyper_sensitive"], 1e-3, [0], (11.35, 113.76, 23.05, 196.68, 49.66), "hypersensitive.ipynb:165-204"),
+    "hyper_sensitive_5x50_CGL": (hyper_sensitive, 5, 50, "CGL", ["hyper_sensitive"], 1e-3, [0], (11.31, 113.88, 23.22, 201.06, 51.43), "hypersensitive.ipynb:267-306"),
+    "hyper_sensitive_5x50_LGL": (hyper_sensitive, 5, 50, "LGL", ["hyper_sensitive"], 1e-3, [0], (11.98, 124.86, 23.43, 201.54, 50.91), "hypersensitive.ipynb:360-399"),
+    "van_der_pol_1x25_LGR": (van_der_pol, 1, 25, "LGR", ["van_der_pol"], 1.0, [1], (4.39, 26.99, 5.92, 39.66, 10.50), "vanderpol.ipynb:177-216"),
+    "schwartz_1x20_LGR": (two_phase_schwartz, 1, 20, "LGR", ["schwartz_phase0", "schwartz_phase1"], 1.0, [1, 0], (3.22, 30.29, 4.03, 46.51, 13.69), "twophaseschwartz.ipynb:195-234"),
+}
+
 # degrees above the LDS tables (round 6: streamed tables, mpx_kernels.h TAB_GLB; tests/test_gpu_high_degree.py)
 HIGH_DEGREE_CASES = {
     "moon_lander_1x100_LGR": (moon_lander, 1, 100, "LGR"),     # the reference's documented grid (docs/source/notebooks/getting_started.ipynb:743)
