@@ -83,10 +83,11 @@ def main():
     print("|---|---|---|---|---|---|---|")
     for name, row in summary:
         print(f"| {name.replace('_', ' ')} | {row[0]:.1f} | {row[1]:.1f} | {row[2]:.1f} | {row[3]:.1f} | {row[4]:.1f} | {row[3] / row[0]:.2f} |")
-    print("\nThese grids are 80-500 variables: the regime where a call is launch + completion latency (~10 us on device pointers, ~18-20 us "
-          "through host pointers), not bandwidth.  On them the GPU path is SLOWER per call than one CPU core running the port and roughly on "
-          "par with CasADi's recorded times; the crossover to the GPU lies near 1 000 nodes (config 2: 92 us against 647 us per iteration for "
-          "the port, `bench.py` -> `ipopt_iter`).  Function evaluations are 4-13 % of the reference's recorded solve times (BASELINE.md 1b).")
+    print("\nThese grids are 80-500 variables: the regime where a call is launch + completion latency (~7-16 us on device pointers, ~19-30 us "
+          "through host pointers), not bandwidth.  In IPOPT's call order the GPU path needs 0.15-0.54 of the oracle time CasADi recorded per "
+          "iteration (unknown CPU) and 1.5-6 times what ONE CPU core needs with the C port of the same arithmetic; the crossover to the GPU "
+          "lies near 1 000 nodes (config 2: 92 us against 647 us per iteration for the port, `bench.py` -> `ipopt_iter`).  Function evaluations "
+          "are 4-13 % of the reference's recorded solve times (BASELINE.md 1b).")
 
 
 if __name__ == "__main__":
