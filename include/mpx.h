@@ -169,6 +169,10 @@ int mpx_get_sizes(const mpx_ctx* ctx, mpx_sizes* out);
 /* fixed COO patterns, 0-based (rows of g / indices of z) */
 int mpx_pattern_jac(const mpx_ctx* ctx, int32_t* row, int32_t* col);
 int mpx_pattern_hess(const mpx_ctx* ctx, int32_t* row, int32_t* col);
+/* is_variable[nnz_jac] (order of mpx_pattern_jac): 1 where the value depends on (z, p), 0 where it is a constant of the grid --
+ * copies of the differentiation / mid-point interpolation tables and the +-1 / slope coefficients of the linear rows (mpopt.py:227-232,
+ * 350-369, 398-411, 484-519; about three quarters of jac_g at 1000 x 5).  What MPX_JAC_VARIABLE_ONLY rewrites is a superset of the 1s. */
+int mpx_pattern_jac_variable(const mpx_ctx* ctx, uint8_t* is_variable);
 /* perm[k] = position in the library's value order of the k-th entry in compressed-column order
  * (sorted by column, then row), colind[n_cols+1]; which = MPX_JAC or MPX_HESS */
 int mpx_ccs_perm(const mpx_ctx* ctx, int which, int64_t* perm, int64_t* colind);
@@ -461,6 +465,14 @@ int mpx_current_cache_stats(long long* fused_passes, long long* served_from_cach
  * Process-wide, like the current context; call before ca.nlpsol(...). */
 int mpx_current_set_casadi_abi(int major_minor);
 int mpx_current_set_hess_l_output_name(const char* name);
+/* Opt-in for nlp_jac_g: leave the constants of a large Jacobian in the caller's array.  After a full pass into res[1], later calls
+ * with the SAME res[1] rewrite only the (z, p)-dependent entries (a single evaluation is bound by what it writes over PCIe: 0.96 MB ->
+ * 0.25 MB at 1000 x 5).  CONTRACT: nothing but nlp_jac_g writes to that array between the calls -- true of the work-vector slice
+ * CasADi's nlpsol passes.  As a safety net ~500 sampled constants are compared before every partial pass (a cleared, reused or
+ * reallocated array falls back to the full pass); a caller that alters single constants is not detected -- hence opt-in.
+ * mpx_current_jac_stats counts partial and full passes since the context was selected. */
+int mpx_current_keep_jac_constants(int enable);
+int mpx_current_jac_stats(long long* variable_only_passes, long long* full_passes);
 /* Caller arrays page-locked so far by mpx_current_pin_buffers(1) and registrations that failed (remembered, not retried): a
  * solver that passes the same work-vector slices on every call stops adding to these after its first iteration. */
 int mpx_current_pin_stats(long long* registered, long long* failed);

@@ -212,6 +212,9 @@ SYMBOLS = {
     "mpx_current_pin_buffers": (ctypes.c_int, [ctypes.c_int]),
     "mpx_current_set_casadi_abi": (ctypes.c_int, [ctypes.c_int]),
     "mpx_current_set_hess_l_output_name": (ctypes.c_int, [ctypes.c_char_p]),
+    "mpx_current_keep_jac_constants": (ctypes.c_int, [ctypes.c_int]),
+    "mpx_current_jac_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
+    "mpx_pattern_jac_variable": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8)]),
     "mpx_current_cache_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "mpx_current_pin_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "mpx_set_tile_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),

@@ -14,6 +14,7 @@
 //
 // CasADi is not installable in the build image: the metadata and the numerical results are tested
 // through ctypes (tests/test_host.py, tests/test_gpu_golden.py), the hand-off to nlpsol itself is not.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -42,7 +43,35 @@ struct Current {
   std::vector<double> cx, cp;
   double cf = 0, *sg = nullptr, *sgrad = nullptr, *sjac = nullptr;
   long long n_fused = 0, n_served = 0;  // statistics (mpx_current_cache_stats)
+  // Constants of a large Jacobian stay in the caller's array (opt-in, mpx_current_keep_jac_constants).  Three quarters of jac_g at
+  // the metric's configuration are copies of table entries, the same at every iterate, and a single evaluation is bound by what it
+  // writes over PCIe (0.96 MB).  When nlp_jac_g is handed the SAME res[1] it completed a full pass into, and the sampled constants
+  // below still hold their values, only the (z, p)-dependent entries are rewritten (MPX_JAC_VARIABLE_ONLY | MPX_CCS_ORDER).
+  // The CONTRACT is the caller's (CasADi's nlpsol writes that work-vector slice through nlp_jac_g only); the samples catch a buffer
+  // that was cleared, reused or reallocated in between, not a caller that alters single constants.
+  bool keep_const = false;
+  const double* jc_ptr = nullptr;                         // array the last FULL pass went to
+  std::vector<std::pair<int64_t, double>> jc_samples;    // (compressed-column position, value) of sampled constant entries
+  std::vector<int64_t> const_pos;                         // compressed-column positions of all constant entries
+  long long n_jac_var = 0, n_jac_full = 0;                // statistics (mpx_current_jac_stats)
 } C;
+
+bool jac_constants_intact(const double* jv) {
+  if (C.jc_samples.empty()) return false;
+  for (auto& s : C.jc_samples)
+    if (memcmp(&jv[s.first], &s.second, 8) != 0) return false;
+  return true;
+}
+void jac_take_samples(const double* jv) {
+  C.jc_samples.clear();
+  const size_t n = C.const_pos.size();
+  if (n == 0) return;
+  const size_t want = std::min<size_t>(n, 509);  // (a prime: positions spread over every column block)
+  for (size_t i = 0; i < want; ++i) {
+    const int64_t k = C.const_pos[(size_t)((double)i * (double)(n - 1) / (double)std::max<size_t>(want - 1, 1))];
+    C.jc_samples.emplace_back(k, jv[k]);
+  }
+}
 
 void release_scratch() {
   if (!C.ctx) return;
@@ -135,6 +164,19 @@ extern "C" int mpx_current_pin_stats(long long* registered, long long* failed) {
   return MPX_OK;
 }
 
+extern "C" int mpx_current_keep_jac_constants(int enable) {
+  if (!C.ctx) return MPX_ERR_INVALID;
+  C.keep_const = enable != 0;
+  C.jc_ptr = nullptr, C.jc_samples.clear();
+  return MPX_OK;
+}
+
+extern "C" int mpx_current_jac_stats(long long* variable_only_passes, long long* full_passes) {
+  if (variable_only_passes) *variable_only_passes = C.n_jac_var;
+  if (full_passes) *full_passes = C.n_jac_full;
+  return MPX_OK;
+}
+
 extern "C" int mpx_current_cache_stats(long long* fused_passes, long long* served_from_cache) {
   if (fused_passes) *fused_passes = C.n_fused;
   if (served_from_cache) *served_from_cache = C.n_served;
@@ -178,6 +220,12 @@ extern "C" int mpx_set_current(mpx_ctx* ctx) {
   n.buf_h.resize(z.nnz_hess);
   n.buf_g.resize(z.n_g);
   n.buf_grad.resize(z.n_z);
+  {  // compressed-column positions of the constant entries (mpx_current_keep_jac_constants)
+    std::vector<uint8_t> var(z.nnz_jac > 0 ? z.nnz_jac : 1);
+    if (mpx_pattern_jac_variable(ctx, var.data()) == MPX_OK)
+      for (int64_t k = 0; k < z.nnz_jac; ++k)
+        if (!var[(size_t)n.perm_j[(size_t)k]]) n.const_pos.push_back(k);
+  }
   n.coalesce = getenv("MPX_NO_COALESCE") == nullptr;
   n.jac_small = z.nnz_jac * 8 <= 65536;  // copying <= 64 KB costs ~2 us: cheaper than any second call
   C = std::move(n);
@@ -290,7 +338,18 @@ extern "C" int nlp_jac_g(const double** arg, double** res, long long*, double*, 
     if (want_g) memcpy(res[0], C.sg, (size_t)C.sz.n_g * 8);
     if (!want_j) return 0;
     if (C.pin) pin(res[1], C.sz.nnz_jac);
-    return mpx_eval(C.ctx, MPX_JAC | MPX_CCS_ORDER, 1, x, pp, 0, 0, 0, 0, 0, 0, res[1], 0) ? 1 : 0;
+    const bool vo = C.keep_const && C.jc_ptr == res[1] && jac_constants_intact(res[1]);
+    if (mpx_eval(C.ctx, MPX_JAC | MPX_CCS_ORDER | (vo ? MPX_JAC_VARIABLE_ONLY : 0), 1, x, pp, 0, 0, 0, 0, 0, 0, res[1], 0)) {
+      C.jc_ptr = nullptr;
+      return 1;
+    }
+    if (vo)
+      ++C.n_jac_var;
+    else {
+      ++C.n_jac_full;
+      if (C.keep_const) C.jc_ptr = res[1], jac_take_samples(res[1]);
+    }
+    return 0;
   }
   // (uncoalesced: what is not requested is not computed -- a NULL res[0] used to send g to a pageable spare buffer, which
   // also took the call off the zero-copy path)

@@ -723,7 +723,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->d_mg_dst), fr(c->d_hc_dst), fr(c->d_th_dst);
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
-    fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h);
+    fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h), fr(c->d_var_dst), fr(c->d_var_src);
     fr(c->d_lgroups), fr(c->d_lforeign), fr(c->d_lftab), fr(c->gl_halo.p), fr(c->gl_pnode.p), fr(c->st_ggx.p), fr(c->st_ggp.p), fr(c->gl_grad.p), fr(c->gl_jac.p);
     fr(c->d_lt_ptr), fr(c->d_lt_col), fr(c->d_lt_row), fr(c->d_lt_coef), fr(c->d_colind_j), fr(c->d_jrow);
     fr(c->d_gmap), fr(c->d_qmap), fr(c->d_abs_fpos), fr(c->d_abs_fstage), fr(c->d_abs_fn), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
@@ -1171,8 +1171,38 @@ __global__ __launch_bounds__(256) void mpx_permute_kernel(const double* __restri
   if (k < n) out[(int64_t)blockIdx.y * n + k] = in[(int64_t)blockIdx.y * n + perm[k]];
 }
 
+// out[b][dst[i]] = in[b][src[i]]: the (z, p)-dependent entries only (MPX_JAC_VARIABLE_ONLY | MPX_CCS_ORDER)
+__global__ __launch_bounds__(256) void mpx_permute_sel_kernel(const double* __restrict__ in, double* __restrict__ out, const int64_t* __restrict__ dst,
+                                                              const int64_t* __restrict__ src, int64_t n_sel, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_sel) out[(int64_t)blockIdx.y * n + dst[i]] = in[(int64_t)blockIdx.y * n + src[i]];
+}
+
+extern "C" int mpx_pattern_jac_variable(const mpx_ctx* c, uint8_t* is_variable) {
+  if (!c || !is_variable) return MPX_ERR_INVALID;
+  if (c->jac_var.size() != (size_t)c->nnz_j) {  // (assembled contexts: no classification -- everything counts as variable)
+    memset(is_variable, 1, (size_t)c->nnz_j);
+    return MPX_OK;
+  }
+  memcpy(is_variable, c->jac_var.data(), (size_t)c->nnz_j);
+  return MPX_OK;
+}
+
 static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
                        const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix);
+
+// compressed-column positions of the variable entries of jac_g and their native sources
+static int upload_var_sel(mpx_ctx* c) {
+  if (c->n_var_j >= 0) return MPX_OK;
+  std::vector<int64_t> perm((size_t)std::max<int64_t>(c->nnz_j, 1)), colind((size_t)c->n_z + 1), dst, src;
+  int rc = mpx_ccs_perm(c, MPX_JAC, perm.data(), colind.data());
+  if (rc) return rc;
+  for (int64_t k = 0; k < c->nnz_j; ++k)
+    if (c->jac_var[(size_t)perm[(size_t)k]]) dst.push_back(k), src.push_back(perm[(size_t)k]);
+  if ((rc = upload(c, &c->d_var_dst, dst)) || (rc = upload(c, &c->d_var_src, src))) return rc;
+  c->n_var_j = (int64_t)dst.size();
+  return MPX_OK;
+}
 
 static int upload_ccs_perm(mpx_ctx* c, int which, int64_t** dst) {
   if (*dst) return MPX_OK;
@@ -1187,7 +1217,14 @@ static int upload_ccs_perm(mpx_ctx* c, int which, int64_t** dst) {
 static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const double* p, int p_per_point, const double* lam_g,
                      const double* sigma, double* f, double* g, double* grad_f, double* jac_val, double* hess_val, bool skip_prefix) {
   if (!c || !(mask & MPX_CCS_ORDER)) return eval_native(c, mask, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, jac_val, hess_val, skip_prefix);
-  if (mask & (MPX_JAC_VARIABLE_ONLY | MPX_BOUNDARY_ONLY)) return fail(c, MPX_ERR_INVALID, "MPX_CCS_ORDER cannot be combined with MPX_JAC_VARIABLE_ONLY / MPX_BOUNDARY_ONLY");
+  if (mask & MPX_BOUNDARY_ONLY) return fail(c, MPX_ERR_INVALID, "MPX_CCS_ORDER cannot be combined with MPX_BOUNDARY_ONLY");
+  // MPX_JAC_VARIABLE_ONLY | MPX_CCS_ORDER (round 6; what nlp_jac_g uses when the caller's array still holds the constants of a
+  // previous call, mpx_casadi.cpp): the node kernels evaluate the WHOLE Jacobian into the device scratch as ever -- on the device
+  // that costs nothing to speak of -- and only the (z, p)-dependent entries leave in compressed-column order: a single evaluation
+  // through host pointers writes 0.25 instead of 0.96 MB over PCIe at config 2.  Contexts without the classification (assembled
+  // ones) write everything.
+  const bool var_only = (mask & MPX_JAC_VARIABLE_ONLY) && (mask & MPX_JAC) && c->kind == 0 && c->jac_var.size() == (size_t)c->nnz_j;
+  mask &= ~MPX_JAC_VARIABLE_ONLY;
   if (c->shard_world > 1) return fail(c, MPX_ERR_INVALID, "MPX_CCS_ORDER on a context in segment-sharded mode");
   if (!c->has_device) return fail(c, MPX_ERR_NO_DEVICE, "mpx_eval: context was created without a gfx950 code object; there is no CPU fallback");
   if (batch < 1 || batch > 65535) return fail(c, MPX_ERR_INVALID, "MPX_CCS_ORDER: batch must be 1..65535");
@@ -1204,7 +1241,13 @@ static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const
     th = c->ccs_h.p;
   }
   if ((rc = eval_native(c, mask & ~MPX_CCS_ORDER, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, tj, th, skip_prefix))) return rc;
-  if (tj != jac_val) hipLaunchKernelGGL(mpx_permute_kernel, dim3((unsigned)((c->nnz_j + 255) / 256), (unsigned)batch), dim3(256), 0, c->stream, tj, jac_val, c->d_perm_j, c->nnz_j);
+  if (tj != jac_val && var_only) {
+    if ((rc = upload_var_sel(c))) return rc;
+    if (c->n_var_j > 0)
+      hipLaunchKernelGGL(mpx_permute_sel_kernel, dim3((unsigned)((c->n_var_j + 255) / 256), (unsigned)batch), dim3(256), 0, c->stream, tj, jac_val, c->d_var_dst,
+                         c->d_var_src, c->n_var_j, c->nnz_j);
+  } else if (tj != jac_val)
+    hipLaunchKernelGGL(mpx_permute_kernel, dim3((unsigned)((c->nnz_j + 255) / 256), (unsigned)batch), dim3(256), 0, c->stream, tj, jac_val, c->d_perm_j, c->nnz_j);
   if (th != hess_val) hipLaunchKernelGGL(mpx_permute_kernel, dim3((unsigned)((c->nnz_h + 255) / 256), (unsigned)batch), dim3(256), 0, c->stream, th, hess_val, c->d_perm_h, c->nnz_h);
   HIPCHK(c, hipGetLastError());
   return MPX_OK;
@@ -1535,6 +1578,7 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
       return MPX_OK;
     }
   }
+  if (mask & MPX_CCS_ORDER) mask &= ~MPX_JAC_VARIABLE_ONLY;  // (staged copies move whole arrays: the full pass)
   if ((rc = reserve(c, c->st_z, B * c->n_z))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->st_z.p, z, B * c->n_z * 8, hipMemcpyHostToDevice, c->stream));
   if (mask & MPX_HESS) {

@@ -80,6 +80,7 @@ struct mpx_ctx {
   std::vector<MpxTile> tiles;  // global, phase-major, bucket-major
   std::vector<double> compW;
   std::vector<int32_t> jrow, jcol, hrow, hcol;
+  std::vector<uint8_t> jac_var;  // per entry of jac_g (native order): 1 = depends on (z, p), 0 = a constant of the grid (mpx_pattern_jac_variable)
   // linear rows
   std::vector<int64_t> lin_ptr, lin_idx, lin_row;
   std::vector<double> lin_coef;
@@ -146,6 +147,8 @@ struct mpx_ctx {
   // MPX_CCS_ORDER: scratch in native order + device copies of the permutations (built on first use)
   DevBuf<double> ccs_j, ccs_h;
   int64_t *d_perm_j = nullptr, *d_perm_h = nullptr;
+  int64_t *d_var_dst = nullptr, *d_var_src = nullptr;  // MPX_JAC_VARIABLE_ONLY | MPX_CCS_ORDER: compressed-column positions of the variable entries and where they come from
+  int64_t n_var_j = -1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double* mid_resid_out = nullptr;  // mpx_set_mid_resid_output: device array the MPX_MID_RESID passes write
   int64_t tile_begin = 0, tile_end = 0;

@@ -440,6 +440,10 @@ int build_layout(mpx_ctx* c) {
       }
   jr.assign(jpos, 0);
   jc.assign(jpos, 0);
+  // which entries depend on (z, p): the diagonal of a node's D block (D[k][k] - d(h Sx dyn_a)/dX_a; counted as variable whether or
+  // not that derivative is structurally zero), the variable entries of the node, the terminal rows -- everything else is a copy of
+  // a table entry (node_body: `variable`; MPX_JAC_VARIABLE_ONLY rewrites a superset of this set, never less)
+  c->jac_var.assign((size_t)jpos, 0);
   for (auto& B : c->buckets) {
     const PhaseStruct& P = c->ph[B.phase];
     const int d = B.deg, P1 = d + 1;
@@ -452,15 +456,16 @@ int build_layout(mpx_ctx* c) {
         const int64_t st = c->seg_start[s];
         int64_t q = 0;
         const int64_t ns = tile_slots(T, P, d);
-        auto put = [&](int64_t row, int64_t col) {
+        auto put = [&](int64_t row, int64_t col, bool var = false) {
           const int64_t at = base + slot_index(q, l, n, ns);
           jr[at] = (int32_t)row;
           jc[at] = (int32_t)col;
+          c->jac_var[(size_t)at] = var ? 1 : 0;
           ++q;
         };
         for (int a = 0; a < nx; ++a)
-          for (int j = 0; j < P1; ++j) put(P.g_off_F + (int64_t)a * N + i, zcol(*c, P, MPX_COL_X, a, st + j));
-        for (auto& e : P.jv) put((e.a == MPX_ROW_F ? P.g_off_F : P.g_off_C) + (int64_t)e.b * N + i, zcol(*c, P, e.c, e.d, i));
+          for (int j = 0; j < P1; ++j) put(P.g_off_F + (int64_t)a * N + i, zcol(*c, P, MPX_COL_X, a, st + j), j == (sk & 255));
+        for (auto& e : P.jv) put((e.a == MPX_ROW_F ? P.g_off_F : P.g_off_C) + (int64_t)e.b * N + i, zcol(*c, P, e.c, e.d, i), true);
         if (P.diff_u)
           for (int u = 0; u < nu; ++u)
             for (int j = 0; j < P1; ++j) put(P.g_off_DU + (int64_t)u * N + i, zcol(*c, P, MPX_COL_U, u, st + j));
@@ -477,6 +482,7 @@ int build_layout(mpx_ctx* c) {
     for (auto& e : P.tj) {
       jr.push_back((int32_t)(P.g_off_TC + e.row));
       jc.push_back((int32_t)zterm(*c, P, e.kind, e.comp));
+      c->jac_var.push_back(1);
       ++jpos;
     }
   }
@@ -530,6 +536,7 @@ int build_layout(mpx_ctx* c) {
     for (int64_t e = c->lin_ptr[r]; e < c->lin_ptr[r + 1]; ++e) {
       jr.push_back((int32_t)c->lin_row[r]);
       jc.push_back((int32_t)c->lin_idx[e]);
+      c->jac_var.push_back(0);
       ++jpos;
     }
   c->nnz_j = jpos;

@@ -269,6 +269,13 @@ int main(int argc, char** argv) {
     const double* LAM = P + n_p;
     const double* SIG = LAM + K * n_g;
     if (p_pin(1) != MPX_OK) return 2;
+    /* NLPSOL_LIKE_KEEP_JAC=1: the opt-in of a caller whose Jacobian array is written by nlp_jac_g only (mpx_current_keep_jac_constants)
+     * -- and, to show the safety net, ONE iterate where this caller breaks that promise and clears the array between the calls */
+    const int keep_jac = getenv("NLPSOL_LIKE_KEEP_JAC") != NULL;
+    if (keep_jac) {
+      int (*p_keep)(int) = (int (*)(int))sym("mpx_current_keep_jac_constants", "", 1);
+      if (p_keep(1) != MPX_OK) return 2;
+    }
     memcpy(w + o_p, P, 8 * (size_t)n_p);
     head[5] = K;
     fwrite(head, 8, 7, out);
@@ -294,6 +301,7 @@ int main(int argc, char** argv) {
       res[0] = NULL; res[1] = w + o_gr;
       if (F[2].eval(arg, res, iw, w + o_w, F[2].mem)) DIE(6, "nlp_grad_f");
       res[0] = NULL; res[1] = w + o_j;
+      if (keep_jac && k == 4) memset(w + o_j, 0xFF, 8 * (size_t)nnz_j); /* (the scribble) */
       if (F[3].eval(arg, res, iw, w + o_w, F[3].mem)) DIE(6, "nlp_jac_g");
       arg[2] = w + o_lf; arg[3] = w + o_lg; res[0] = w + o_h;
       if (F[4].eval(arg, res, iw, w + o_w, F[4].mem)) DIE(6, "nlp_hess_l");
@@ -341,6 +349,12 @@ int main(int argc, char** argv) {
     free(fg_g);
     p_cache(&stats[0], &stats[1]);
     fwrite(stats, 8, 6, out);
+    if (keep_jac) {
+      long long nv = -1, nf = -1;
+      int (*p_jst)(long long*, long long*) = (int (*)(long long*, long long*))sym("mpx_current_jac_stats", "", 1);
+      p_jst(&nv, &nf);
+      printf("jac_passes variable_only=%lld full=%lld\n", nv, nf);
+    }
     if (p_pin(0) != MPX_OK) return 2; /* unregisters h0 too: only now may it be freed */
     free(g2); free(h0);
     free(in);

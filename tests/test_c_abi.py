@@ -173,7 +173,7 @@ def test_nlp_hess_l_output_name_follows_the_casadi_version(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL", "moon_lander_60x5_big_jac"])
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "kitchen_sink_mixed_CGL", "moon_lander_60x5_big_jac", "moon_lander_60x5_big_jac_keep_constants"])
 def test_nlpsol_like_caller_runs_ipopt_call_sequence_on_the_gpu(name, tmp_path):
     """The solver half: ONE work arena, arg / res carved from it, checkout / release, the calls of K interior-point iterates in
     IPOPT's order (nlp_f, nlp_g at trial points -- some rejected --, then nlp_grad_f, nlp_jac_g with res[0] = NULL, nlp_hess_l), the
@@ -181,6 +181,11 @@ def test_nlpsol_like_caller_runs_ipopt_call_sequence_on_the_gpu(name, tmp_path):
     (same kernels), the goldens to 1e-10; no slice is registered after the first iterate; the same-iterate cache made ONE fused
     pass per new point for f, g, grad_f (and jac_g where it is small)."""
     exe = build_nlpsol_like(tmp_path)
+    # (..._keep_constants: the same run with mpx_current_keep_jac_constants(1) -- after the first full pass nlp_jac_g rewrites only the
+    # (z, p)-dependent entries of the caller's array; at iterate 4 the caller clears the array between the calls and the sampled
+    # constants send that call back to the full pass.  Every iterate's values still equal mpx_eval's bit for bit.)
+    keep = name.endswith("_keep_constants")
+    name = name.replace("_keep_constants", "")
     if name == "moon_lander_60x5_big_jac":  # nnz_jac * 8 > 64 KB: the Jacobian is not part of the fused first pass
         import problems
         from mpopt_amd import mp
@@ -208,8 +213,10 @@ def test_nlpsol_like_caller_runs_ipopt_call_sequence_on_the_gpu(name, tmp_path):
         for a in (Z, p, lam, sig):
             f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
     r = subprocess.run([exe, _lib.LIB_PATH, str(tmp_path / "problem.bin"), str(tmp_path / "iterates.bin"), str(tmp_path / "out.bin")],
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, env=dict(os.environ, **({"NLPSOL_LIKE_KEEP_JAC": "1"} if keep else {})))
     assert r.returncode == 0, r.stderr
+    if keep:  # 7 iterates: full passes at iterate 0 and at the scribbled iterate 4, partial passes at the other five
+        assert "jac_passes variable_only=5 full=2" in r.stdout, r.stdout
     raw = open(tmp_path / "out.bin", "rb").read()
     head = struct.unpack_from("<7q", raw, 0)
     assert head[:6] == (o.n_z, o.n_p, o.n_g, o.nnz_jac, o.nnz_hess, K)

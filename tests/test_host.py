@@ -468,3 +468,31 @@ def test_lane_kernel_failure_falls_back_once(monkeypatch):
     assert len(w) == 1 and "exceeds" in o.lanes_error and o.lanes_source is None and not o._wants_lanes(16, 4096)
     o.code_object = None
     o.close()
+
+
+@pytest.mark.parametrize("name", ["moon_lander_20x3_LGR", "dae_vdp_mixed_CGL", "schwartz_4x3_LGL", "kitchen_sink_mixed_CGL"])
+def test_jac_variable_mask_marks_only_constants_as_constant(name):
+    """mpx_pattern_jac_variable (round 6): every entry the library calls a constant of the grid has the same value at two unrelated
+    points (z, p) of the reference's golden NLP / the numpy oracle; the constants are the bulk of the Jacobian; terminal rows and the
+    variable node entries are marked variable."""
+    import ctypes
+    from oracle.mpopt_oracle import OracleNLP
+
+    builder, S, po, scheme = problems.GOLDEN_CASES[name]
+    ocp = builder(mp, M.math)
+    o = M.NlpFunctions(ocp, S, [po] * S if isinstance(po, int) else list(po), scheme, with_device=False)
+    var = np.zeros(o.nnz_jac, np.uint8)
+    assert _lib.lib().mpx_pattern_jac_variable(o._ctx, var.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))) == 0
+    O = OracleNLP(ocp, S, po, scheme)
+    rng = np.random.default_rng(2)
+    jr, jc = o.jac_pattern()
+    vals = []
+    for _ in range(2):
+        z = O.initial_guess() + rng.uniform(-0.3, 0.3, o.n_z)
+        w = rng.uniform(0.3, 1.7, (ocp.n_phases, S))
+        J = O.jac_g(z, (w / w.sum(axis=1, keepdims=True)).ravel()).tocsr()
+        vals.append(np.asarray(J[jr, jc]).ravel())
+    const = var == 0
+    assert np.array_equal(vals[0][const], vals[1][const]) and const.sum() > 0.4 * o.nnz_jac
+    assert (vals[0][~const] != vals[1][~const]).mean() > 0.5  # (the variable set is a superset: structurally zero diagonals included)
+    o.close()
