@@ -107,13 +107,13 @@ def ipopt_iter_report(builder, S, P, scheme, cnames, scale_t, midu, dev_id, seco
     del os.environ["MPX_NO_COALESCE"]
     o.make_current()
     L.mpx_current_pin_buffers(1)
-    gpu_full, n_it = sequence(seconds / 2)
-    # ... and as the CasADi binding of INTEGRATION.md section 3 sets it up: the constants of a large Jacobian stay in the caller's
-    # array (mpx_current_keep_jac_constants(1): CasADi's work-vector slice is written by nlp_jac_g only), so every nlp_jac_g after the
-    # first rewrites the (z, p)-dependent quarter of the values.  This is the figure `us_per_iter` reports; the full rewrite of every
-    # call is beside it.
+    gpu, n_it = sequence(seconds)
+    # ... and with the constants of a large Jacobian left in the caller's array (mpx_current_keep_jac_constants(1), round 6: every
+    # nlp_jac_g after the first rewrites only the (z, p)-dependent quarter of the values).  A NEGATIVE result, reported beside the
+    # default: in compressed-column order those entries are isolated 8-byte words, and 30 000 of them cost more PCIe packets than
+    # 0.96 MB of full cache lines (config 2: nlp_jac_g 36.8 -> 43.6 us; profiles/r6_jac_constants/README.md).
     L.mpx_current_keep_jac_constants(1)
-    gpu, n_it2 = sequence(seconds)
+    gpu_keep, n_it2 = sequence(seconds / 2)
     n_it += n_it2 + 20
     jvar, jfull = ctypes.c_longlong(), ctypes.c_longlong()
     L.mpx_current_jac_stats(ctypes.byref(jvar), ctypes.byref(jfull))
@@ -135,12 +135,12 @@ def ipopt_iter_report(builder, S, P, scheme, cnames, scale_t, midu, dev_id, seco
     assert abs(Jg - Jc).max() < 1e-9 * max(1.0, abs(Jc).max())
     cpu = {k: C.time_fn(k, z[None, :], p, 1.0, lam, seconds) * 1e6 for k in gpu}
     o.close()
-    return {"us_per_iter": mix(gpu), "us_per_iter_full_jac_every_call": mix(gpu_full), "us_per_iter_uncoalesced": mix(plain), "cpu_port_us_per_iter": mix(cpu),
+    return {"us_per_iter": mix(gpu), "us_per_iter_keep_jac_constants": mix(gpu_keep), "us_per_iter_uncoalesced": mix(plain), "cpu_port_us_per_iter": mix(cpu),
             "speedup_vs_cpu_port": mix(cpu) / mix(gpu),
-            "per_call_us": {k: round(v, 2) for k, v in gpu.items()}, "per_call_us_full_jac_every_call": {k: round(v, 2) for k, v in gpu_full.items()},
+            "per_call_us": {k: round(v, 2) for k, v in gpu.items()}, "per_call_us_keep_jac_constants": {k: round(v, 2) for k, v in gpu_keep.items()},
             "per_call_us_uncoalesced": {k: round(v, 2) for k, v in plain.items()},
-            "jac_constants": {"kept_in_callers_array": True, "variable_only_passes": jvar.value, "full_passes": jfull.value,
-                              "note": "mpx_current_keep_jac_constants(1), the CasADi binding of INTEGRATION.md section 3; small Jacobians (<= 64 KB) are served by the same-iterate cache instead"},
+            "jac_constants": {"variable_only_passes": jvar.value, "full_passes": jfull.value,
+                              "note": "opt-in mpx_current_keep_jac_constants(1): not faster (isolated 8-byte words over PCIe), never part of us_per_iter; small Jacobians (<= 64 KB) are served by the same-iterate cache instead"},
             "cpu_port_per_call_us": {k: round(v, 2) for k, v in cpu.items()},
             "cache": {"iterates": n_it + 20, "fused_device_passes": fused.value, "calls_served_without_a_device_pass": served.value},
             "n_z": o.n_z, "n_g": o.n_g, "nnz_jac": o.nnz_jac, "nnz_hess": o.nnz_hess}
