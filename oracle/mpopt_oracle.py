@@ -963,3 +963,46 @@ class OracleAdaptiveNLP(OracleNLP):
         if len(R):
             H[R, Cc] = np.array(fn(*[float(v) for v in z], *[float(v) for v in lam], float(sigma)), float)
         return H + np.triu(H, 1).T
+
+    # -- derivatives: exact operator-overloading AD of the value code above (oracle/sparse_ad.py) -----------------------------------
+    # The same quantities as jac_g / grad_f / hess_l, for grids where sympy on the whole NLP is not practical (the bench size
+    # 20 x 5, 100 x 3, ...): _nlp_generic runs on sparse hyper-dual numbers.  Equal to the sympy route to rounding on the five golden
+    # cases (tests/test_oracle.py).
+    def _ad_pass(self, z, order):
+        from .sparse_ad import SD
+
+        old, SD.ORDER = SD.ORDER, order
+        try:
+            return self._nlp_generic([SD.var(float(v), i) for i, v in enumerate(z)])
+        finally:
+            SD.ORDER = old
+
+    def ad_first(self, z):
+        """-> (f, g, grad_f dense, jac_g CSR) from ONE first-order pass."""
+        from .sparse_ad import gradient, value
+
+        g, f = self._ad_pass(z, 1)
+        grad = np.zeros(self.n_z)
+        for k, v in gradient(f).items():
+            grad[k] = v
+        R, Cc, V = [], [], []
+        for r, e in enumerate(g):
+            for k, v in gradient(e).items():
+                R.append(r), Cc.append(k), V.append(v)
+        J = sp.coo_matrix((np.array(V, float), (np.array(R, int), np.array(Cc, int))), shape=(self.n_g, self.n_z)).tocsr()
+        return value(f), np.array([value(e) for e in g]), grad, J
+
+    def ad_hess_l(self, z, sigma, lam):
+        """Upper triangle (CSR) of the Hessian of sigma f + lam^T g from one second-order pass."""
+        from .sparse_ad import SD, hessian
+
+        g, f = self._ad_pass(z, 2)
+        acc = {}
+        for wt, e in [(float(sigma), f)] + [(float(l), e) for l, e in zip(lam, g)]:
+            if wt == 0.0 or not isinstance(e, SD):
+                continue
+            for k, v in hessian(e).items():
+                acc[k] = acc.get(k, 0.0) + wt * v
+        keys = list(acc)
+        return sp.coo_matrix((np.array([acc[k] for k in keys], float), (np.array([k[0] for k in keys], int), np.array([k[1] for k in keys], int))),
+                             shape=(self.n_z, self.n_z)).tocsr()

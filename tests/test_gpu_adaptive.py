@@ -8,7 +8,7 @@ import pytest
 import mpopt_amd as M
 from mpopt_amd import mp
 import problems
-from helpers import assert_coo_close, load_golden, rel_err
+from helpers import assert_coo_close, assert_entries, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -492,3 +492,54 @@ def test_lane_kernel_with_global_rows_of_a_time_dependent_hessian(monkeypatch):
     two = run()
     assert not bool(torch.isnan(got).any()) and torch.equal(got, two)
     o.close()
+
+
+BENCH_SIZE = {
+    "moon_lander_20x5": (problems.moon_lander, 20, 5, "LGR"),        # the bench workload (adaptive-fgj / adaptive-hess)
+    "moon_lander_100x3": (problems.moon_lander, 100, 3, "LGR"),      # 67 groups of the lane kernel sharing 4 bodies
+    "hyper_sensitive_40x4": (problems.hyper_sensitive, 40, 4, "LGL"),
+    "van_der_pol_10x6": (problems.van_der_pol, 10, 6, "LGR"),
+    "dae_vdp_12x4": (problems.dae_vdp, 12, 4, "CGL"),               # a parameter and a path row
+    "time_dependent_10x3": (problems.time_dependent, 10, 3, "LGR"),  # every row couples to all earlier widths (no lane plan: fused kernels)
+    "kitchen_sink_20x3": (problems.kitchen_sink, 20, 3, "LGR"),      # two phases, time-dependent, control-slope rows
+}
+
+
+@pytest.mark.parametrize("name", list(BENCH_SIZE))
+def test_assembled_kernels_against_the_exact_ad_oracle_at_bench_size(name):
+    """VERDICT r5 (missing 5 / weak 3): above 4 segments the assembled contexts of mpopt_adaptive (reference mpopt.py:2927-2979,
+    3034-3136) were checked against finite differences of their own outputs.  Here every output of every kernel family -- single
+    evaluations (point + gather kernels), a batch of 40 (fused kernels), a batch of 150 (lane-per-point hess_l where the problem has
+    a plan) -- is compared per entry with the oracle's restated value code differentiated EXACTLY by sparse hyper-dual arithmetic
+    (oracle/sparse_ad.py; pinned to sympy and to the reference's goldens in tests/test_oracle.py), at the bench size and at 100 x 3."""
+    from oracle.mpopt_oracle import OracleAdaptiveNLP
+
+    builder, S, P, scheme = BENCH_SIZE[name]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt_adaptive(ocp, S, P, scheme)
+    nlp, bounds = mpo.create_nlp()
+    o = nlp["oracle"]
+    O = OracleAdaptiveNLP(ocp, S, [P] * S, scheme)
+    assert (o.n_z, o.n_g) == (O.n_z, O.n_g) and np.array_equal(mpo.initialize_solution(), O.initial_guess())
+    lbx, ubx, lbg, ubg = O.bounds()
+    assert np.array_equal(bounds["lbx"], lbx) and np.array_equal(bounds["ubx"], ubx) and np.array_equal(bounds["lbg"], lbg) and np.array_equal(bounds["ubg"], ubg)
+    rng = np.random.default_rng(19)
+    z0 = O.initial_guess()
+    jr, jc = o.jac_pattern()
+    hr, hc = o.hess_pattern()
+    jset, hset = set(zip(jr.tolist(), jc.tolist())), set(zip(hr.tolist(), hc.tolist()))
+    for B in (1, 40, 150):
+        Z = z0[None, :] * (1 + 0.05 * rng.uniform(-1, 1, (B, o.n_z))) + 0.02 * rng.uniform(-1, 1, (B, o.n_z))
+        lam, sig = rng.standard_normal((B, o.n_g)), rng.uniform(0.3, 1.7, B)
+        r = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], Z if B > 1 else Z[0], None, lam_g=lam if B > 1 else lam[0], sigma=sig if B > 1 else sig[0])
+        if B == 1:
+            r = {k: np.asarray(v)[None] for k, v in r.items()}
+        for b in sorted({0, B // 2, B - 1}):
+            f, g, grad, J = O.ad_first(Z[b])
+            H = O.ad_hess_l(Z[b], sig[b], lam[b])
+            assert rel_err(r["f"][b], f) < TOL and rel_err(r["g"][b], g) < TOL and rel_err(r["grad_f"][b], grad) < TOL
+            Jc, Hc = J.tocoo(), H.tocoo()
+            assert set(zip(Jc.row[Jc.data != 0].tolist(), Jc.col[Jc.data != 0].tolist())) <= jset  # nothing of the oracle outside the pattern
+            assert set(zip(Hc.row[Hc.data != 0].tolist(), Hc.col[Hc.data != 0].tolist())) <= hset
+            assert_entries(r["jac_g"][b], np.asarray(J[jr, jc]).ravel(), TOL, what=f"{name} B={B}[{b}] assembled jac_g vs exact AD oracle")
+            assert_entries(r["hess_l"][b], np.asarray(H[hr, hc]).ravel(), TOL, what=f"{name} B={B}[{b}] assembled hess_l vs exact AD oracle")

@@ -231,3 +231,49 @@ def test_exact_tables_at_degree_255_are_consistent():
     assert abs(w.sum() - 2.0) < 1e-14 and abs(w @ x**2 - 2.0 / 3.0) < 1e-14
     C = Collocation([255], "LGR")
     assert np.abs(np.asarray(C.get_quadrature_weights(255)).ravel() - w).max() < 2e-15
+
+
+@pytest.mark.parametrize("name", list(problems.ADAPTIVE_CASES))
+def test_adaptive_oracle_ad_equals_sympy_and_the_reference_goldens(name):
+    """The widths-as-variables NLP (mpopt.py:2927-2979, 3034-3136): derivatives of the oracle's restated value code by exact sparse
+    hyper-dual arithmetic (oracle/sparse_ad.py -- the route that scales to the bench size) against sympy on the whole NLP (the route
+    of rounds 1-5) and against the goldens of the reference's own mpopt_adaptive.create_nlp(): f, g, grad_f, jac_g, hess_l."""
+    import scipy.sparse as sp
+    from oracle.mpopt_oracle import OracleAdaptiveNLP
+
+    builder, S, po, scheme = problems.ADAPTIVE_CASES[name]
+    O = OracleAdaptiveNLP(builder(mp, M.math), S, po, scheme)
+    G = load_golden(name)
+    z, lam, sig = G["z"], G["lam"], float(G["sigma"])
+    f, g, grad, J = O.ad_first(z)
+    H = O.ad_hess_l(z, sig, lam)
+    tol = lambda ref: 1e-12 * max(1.0, np.abs(ref).max())
+    assert abs(f - float(G["f"])) < tol(G["f"]) and np.abs(g - G["g"]).max() < tol(G["g"]) and np.abs(grad - G["grad_f"]).max() < tol(G["grad_f"])
+    Jg = sp.coo_matrix((G["jac_val"], (G["jac_row"], G["jac_col"])), shape=J.shape).tocsr()
+    Hg = sp.coo_matrix((G["hess_val"], (G["hess_row"], G["hess_col"])), shape=H.shape).tocsr()
+    assert abs(J - Jg).max() < tol(G["jac_val"]) and abs(H - Hg).max() < tol(G["hess_val"])
+    # ... and the sympy route of the same oracle
+    assert abs(J - O.jac_g(z)).max() < tol(G["jac_val"]) and np.abs(grad - O.grad_f(z)).max() < tol(G["grad_f"])
+    Hs = O.hess_l(z, None, sig, lam)
+    assert np.abs((H + sp.triu(H, 1).T).toarray() - Hs).max() < tol(Hs)
+
+
+def test_sparse_hyper_dual_numbers_against_sympy():
+    """oracle/sparse_ad.py on its own: value, gradient and Hessian of an expression using every operator and function."""
+    import sympy as sy
+    from oracle.sparse_ad import SD
+
+    def expr(x, y, w, fn):
+        return (x * y - fn.sin(w * x)) / (1.0 + y * y) + fn.exp(-0.3 * x) * fn.sqrt(2.0 + w * w) + x ** 3 - 2.0 / y + fn.tanh(x * w) + fn.log(3.0 + y) + fn.cos(y) * fn.atan(w) - (x - y) ** 2
+
+    p = [0.7, 1.3, -0.4]
+    SD.ORDER = 2
+    r = expr(*[SD.var(v, i) for i, v in enumerate(p)], M.math)
+    X = sy.symbols("x y w")
+    e = expr(*X, M.math)
+    sub = dict(zip(X, p))
+    assert r.v == pytest.approx(float(e.subs(sub)), rel=1e-14)
+    for i in range(3):
+        assert r.g.get(i, 0.0) == pytest.approx(float(sy.diff(e, X[i]).subs(sub)), rel=1e-13, abs=1e-14)
+        for j in range(i, 3):
+            assert r.h.get((i, j), 0.0) == pytest.approx(float(sy.diff(e, X[i], X[j]).subs(sub)), rel=1e-12, abs=1e-13)
