@@ -172,6 +172,9 @@ class AssembledNlpFunctions(NlpFunctions):
                 funcs.append(s.fn)
         self.functions = funcs
         self._expand(Gz, g0)
+        import os
+        if os.environ.get("MPX_ASM_CLASS_MAJOR", "1") != "0":
+            self._class_major_jac()
         sizes = dict(RAW_N=self.raw_n, RAWH_N=self.rawh_n, NZ=self.n_z_, NG=self.n_g_, NNZJ=self.nnz_jac_, NNZH=self.nnz_hess_)
         # ELL tables of the local variables and of the multipliers of every set (what _create hands to libmpx), and the number of
         # distinct coefficients (bit patterns, padding included) in each family: the dictionaries of the packed tables of the fused
@@ -195,7 +198,7 @@ class AssembledNlpFunctions(NlpFunctions):
         sizes["NDICT_MU"] = _ndistinct([e[1][2] for e in self._ell]) if self.n_g_ + 1 < 65536 else 0
         for tag, (ptr, _, _) in (("FGJ", self.fgj), ("HES", self.hess)):  # shape of the multi-term and long rows of each pass
             nt = np.diff(ptr)
-            multi, longr = nt[(nt >= 2) & (nt <= 24)], nt[nt > 24]  # 24 = MPX_GATHER_LONG
+            multi, longr = nt[(nt >= 2) & (nt <= 24)], nt[nt > 24]  # 24 = MPX_GATHER_LONG (mt below: _ell_width)
             # ELL width of the multi-term rows kept in registers: the smallest width <= 12 that leaves at most 16 wider rows to
             # the one-wavefront-per-row path
             mt = 0
@@ -341,6 +344,36 @@ class AssembledNlpFunctions(NlpFunctions):
         return "\n".join(parts) + "\n"
 
     # -- expansion of the chain rule into gather rows -------------------------------------------------
+    @staticmethod
+    def _ell_width(nt):
+        """ELL width of the multi-term rows of a pass (the smallest width <= 12 that leaves at most 16 wider rows to the
+        one-wavefront-per-row path; 0: no multi-term rows) -- the threshold between 'multi' and 'long' rows is this, or 24 without it."""
+        multi = nt[(nt >= 2) & (nt <= 24)]
+        return next((w for w in range(2, 13) if (multi > w).sum() <= 16), 12) if len(multi) else 0
+
+    def _class_major_jac(self):
+        """Order the entries of jac_g by ROW CLASS (round 6): first the rows with at most one term -- constants of the linear part and
+        single products, 85-95 % of a Jacobian --, then the rows with 2 .. MT terms, then the long rows.  The order of a pattern is the
+        context's to choose (jac_pattern / ccs_perm report it).  Why: the fused kernel keeps a lane's single-term rows in registers and
+        stores them 8 bytes per lane; with the classes interleaved a lane could not own two ADJACENT single-term rows, so pairing rows
+        for 16-byte stores (MPX_FUSE_PAIR_ROWS) met a multi-term row in every few pairs and lost (60.2 against 56.8 us, round 4).  With
+        the classes contiguous every pair of the first region is complete."""
+        ptr, src, coef = self.fgj
+        first = 1 + self.n_g_ + self.n_z_
+        nt = np.diff(ptr)
+        mt = self._ell_width(nt)
+        thr = mt if mt >= 2 else 24
+        ntj = nt[first:]
+        cls = np.where(ntj <= 1, 0, np.where(ntj <= thr, 1, 2))
+        order = np.argsort(cls, kind="stable")  # (inside a class the column-major order of the pattern stays)
+        if np.array_equal(order, np.arange(len(order))):
+            return
+        full = np.concatenate([np.arange(first), first + order])
+        new_ptr = np.concatenate([[0], np.cumsum(nt[full])]).astype(ptr.dtype)
+        take = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in full]) if len(src) else np.zeros(0, np.int64)
+        self.fgj = (new_ptr, np.ascontiguousarray(src[take]), np.ascontiguousarray(coef[take]))
+        self.jrow, self.jcol = np.ascontiguousarray(self.jrow[order]), np.ascontiguousarray(self.jcol[order])
+
     def _expand(self, Gz, g0):
         n_z, n_g = self.n_z_, self.n_g_
         off = offh = 0
