@@ -173,7 +173,7 @@ class AssembledNlpFunctions(NlpFunctions):
         self.functions = funcs
         self._expand(Gz, g0)
         import os
-        if os.environ.get("MPX_ASM_CLASS_MAJOR", "1") != "0":
+        if os.environ.get("MPX_ASM_CLASS_MAJOR", "0") == "1":  # (A/B of round 6, a negative result: profiles/r6_asm_pair/README.md)
             self._class_major_jac()
         sizes = dict(RAW_N=self.raw_n, RAWH_N=self.rawh_n, NZ=self.n_z_, NG=self.n_g_, NNZJ=self.nnz_jac_, NNZH=self.nnz_hess_)
         # ELL tables of the local variables and of the multipliers of every set (what _create hands to libmpx), and the number of
@@ -357,7 +357,9 @@ class AssembledNlpFunctions(NlpFunctions):
         context's to choose (jac_pattern / ccs_perm report it).  Why: the fused kernel keeps a lane's single-term rows in registers and
         stores them 8 bytes per lane; with the classes interleaved a lane could not own two ADJACENT single-term rows, so pairing rows
         for 16-byte stores (MPX_FUSE_PAIR_ROWS) met a multi-term row in every few pairs and lost (60.2 against 56.8 us, round 4).  With
-        the classes contiguous every pair of the first region is complete."""
+        the classes contiguous every pair of the first region is complete.  MEASURED (round 6, tools/r6_asm_pair_ab.sh, moon lander 20x5,
+        B = 4096): no gain either -- 57.0-59.5 us as it was, 58.3-60.4 with this order, 60.5-62.5 with this order and paired rows:
+        the pass is not bound by the width of its stores.  Off by default (MPX_ASM_CLASS_MAJOR=1)."""
         ptr, src, coef = self.fgj
         first = 1 + self.n_g_ + self.n_z_
         nt = np.diff(ptr)
