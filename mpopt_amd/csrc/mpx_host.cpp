@@ -646,7 +646,13 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
     }
   // (MPX_BOUNDARY_ANYORDER=1, read per call, MPX_BOUNDARY_ONLY calls only: an experiment of round 5 -- the boundary pass of the config-5
   // loop launched without a barrier against the equal-area kernel in front of it, profiles/r5_loop/)
+  // Compiled out of production builds: without the barrier the pass reads f and the sums while the kernel in front of it
+  // may still be writing them -- only for the measurement it was written for (MPX_LIB_HIPCC_FLAGS=-DMPX_EXPERIMENTS).
+#ifdef MPX_EXPERIMENTS
   const bool any_order = !nodes && getenv("MPX_BOUNDARY_ANYORDER") != nullptr;
+#else
+  const bool any_order = false;
+#endif
   return launch(c, c->fn_bound[mode], dim3((unsigned)io.B, 1, 1), dim3(256, 1, 1), &G, sizeof G, 0, any_order);
 }
 

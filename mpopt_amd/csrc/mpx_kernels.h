@@ -2548,8 +2548,8 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
 #ifndef MPX_MIN_WAVES_HIGH  // degrees with the tables in LDS: the register budget that gives 4 wavefronts per SIMD (<= 128 VGPRs)
 #define MPX_MIN_WAVES_HIGH 4
 #endif
-#ifndef MPX_MIN_WAVES_STREAM  // streamed tables: two chunks of table values are live on top (168 VGPRs; 4 spilled 35 dwords)
-#define MPX_MIN_WAVES_STREAM 3
+#ifndef MPX_MIN_WAVES_STREAM  // streamed tables: two chunks of table values are live on top; 4 spilled 35 dwords, 3 (168 VGPRs) measured 8-19 % slower than 2 at degrees 72-80 (tools/r6_stream_ab.py)
+#define MPX_MIN_WAVES_STREAM 2
 #endif
 #define MPX_WAVES_FOR(P) ((P) > MPX_TABLES_STREAM_ABOVE ? MPX_MIN_WAVES_STREAM : (P) > MPX_TABLES_IN_LDS_ABOVE ? MPX_MIN_WAVES_HIGH : MPX_MIN_WAVES)
 #define MPX_INSTANTIATE_NODE(PH, P)                                                                         \

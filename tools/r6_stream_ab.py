@@ -38,10 +38,10 @@ def timeit(fn, o, reps=30):
 
 
 print(f"B = {B}; us per pass: LDS tables | streamed tables")
-for P in (13, 20, 30, 40, 48, 56, 64, 80, 92):
+for P in [int(x) for x in os.environ.get("PLIST", "13,20,30,40,48,56,64,80,92").split(",")]:
     S = max(1, 5000 // P)
     res = {}
-    for thr in (255, 12):
+    for thr in ((255, 12) if P <= 92 else (12, 12)):
         mpo, o = make(P, S, thr)
         rng = np.random.default_rng(1)
         z0 = mpo.initialize_solution()
@@ -59,5 +59,5 @@ for P in (13, 20, 30, 40, 48, 56, 64, 80, 92):
         res[thr] = (t_fgj, t_g, t_gl, by / t_fgj / 1e6)
         o.close()
         del Z, jv
-    a, b = res[255], res[12]
+    a, b = res.get(255, res[12]), res[12]
     print(f"P={P:3d} S={S:4d}  fgj {a[0]:8.1f} | {b[0]:8.1f} us ({a[3]:.2f} | {b[3]:.2f} TB/s)   g {a[1]:7.1f} | {b[1]:7.1f}   nlp_grad {a[2]:7.1f} | {b[2]:7.1f}", flush=True)
