@@ -383,7 +383,7 @@ def main():
     S, P, B, K, W = args.segments, args.degree, args.batch if batch_given else 4096, args.steps, args.warmup
     hess_mode = args.workload.endswith("hess")
     shard = args.workload.endswith("-shard")
-    scheme, builder, label = "LGR", problems.moon_lander, f"moon-lander OCP, n_segments={S}, poly_orders={P}, LGR (BASELINE configs[1])"
+    scheme, builder, label = "LGR", problems.moon_lander, f"moon-lander OCP, n_segments={S}, poly_orders={P}, LGR" + (" (BASELINE configs[1])" if (S, P) == (1000, 5) else " (NOT a BASELINE configuration: --segments / --degree)")
     loop5 = args.workload == "config5-loop"
     if args.workload in ("config5-hess", "config5-loop"):
         builder, S, P, scheme = problems.BENCH_CASES[3]
