@@ -17,6 +17,7 @@ from oracle.c_oracle import COracle
 dev = torch.device("cuda:0")
 CFG = [
     ("anchor moon lander 10x6 LGR", problems.moon_lander, 10, 6, "LGR", ["moon_lander"], 1.0, [1]),
+    ("moon lander 1x100 LGR (the reference's documented high-degree grid, getting_started.ipynb:721-743; streamed tables)", problems.moon_lander, 1, 100, "LGR", ["moon_lander"], 1.0, [1]),
     ("C1 moon lander 20x3 LGR", problems.moon_lander, 20, 3, "LGR", ["moon_lander"], 1.0, [1]),
     ("C2 moon lander 1000x5 LGR", *problems.BENCH_CASES[0], ["moon_lander"], 1.0, [1]),
     ("C3 Van der Pol 2000x[3,30,3] CGL", *problems.BENCH_CASES[1], ["van_der_pol"], 1.0, [1]),
