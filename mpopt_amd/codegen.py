@@ -270,7 +270,6 @@ class ProblemProgram:
         """``degrees``: distinct polynomial degrees on the grid; ``midu_rows[ph]``: whether the
         mid-point control rows are emitted for that phase (mpopt.py:346, 363-365)."""
         self.ocp = ocp
-        self.poly_orders = [int(d) for d in degrees]  # (one entry per segment when the caller passes the grid: _small_source counts the tiles)
         self.degrees = sorted(set(int(d) for d in degrees))
         self.phases = [PhaseProgram(ocp, ph) for ph in range(ocp.n_phases)]
         self.flags = [dict(diff_u=bool(ocp.diff_u[ph]), midu=bool(midu_rows[ph]),
@@ -315,42 +314,7 @@ class ProblemProgram:
         parts.append('extern "C" __device__ __attribute__((used)) const int mpx_time_dependent = '
                      f"{1 if any(p.time_dependent for p in self.phases) else 0};")
         parts += self._resident_source()
-        parts += self._small_source()
         return "\n".join(parts) + "\n"
-
-    SMALL_MAX_TILES = 8  # = MPX_SMALL_MAX_TILES (mpx_device.h)
-
-    def _small_source(self):
-        """mpx_small_<mode>: a single evaluation of a SMALL single-degree grid in one launch (mpx_kernels.h: small_body) -- the node
-        tiles of every phase one after the other in ONE workgroup, the boundary pass, the compressed-column permutation and the
-        completion flag.  Generated when the grid has at most SMALL_MAX_TILES tiles (host: the same count) and the static LDS of the
-        inlined node kernels fits a default launch."""
-        if len(self.degrees) != 1:
-            return []
-        d = self.degrees[0]
-        S = len(self.poly_orders)
-        tiles = len(self.phases) * (1 + -(-S // max(256 // d, 1)))
-        if tiles > self.SMALL_MAX_TILES:
-            return []
-        p1 = d + 1
-        nin = self.phases[0].nx + self.phases[0].nu
-        lds = 2 * nin * (256 // d) * p1 * 8 + 4096 + (8 * (p1 * p1 + d * p1) if 12 < d <= self.stream_above() else 0)
-        if lds > 60 * 1024:
-            return []
-        out = []
-        for mode, tag in (("MPX_MODE_FG", "fg"), ("MPX_MODE_FGJ", "fgj"), ("MPX_MODE_HESS", "hess")):
-            out.append(f'extern "C" __global__ __launch_bounds__(MPX_TILE) void mpx_small_{tag}(const MpxSmallArgs S) {{')
-            out.append(f"  mpxk::small_body<{mode}>(S, [&](int p, int t) {{")
-            for ph in range(len(self.phases)):
-                out.append(f"    {'if' if ph == 0 else 'else if'} (p == {ph}) mpxk::node_body<{ph}, {d}, {mode}>(S.a[{ph}], t);")
-            out += ["  });", "}"]
-        return out
-
-    @staticmethod
-    def stream_above():
-        import os
-
-        return max(12, min(255, int(os.environ["MPX_TABLES_STREAM_ABOVE"]))) if os.environ.get("MPX_TABLES_STREAM_ABOVE") else 68
 
     def light_low_chunks(self, d):
         """64-node chunks per span of the low-degree light kernels, exactly as light_low_body (mpx_kernels.h: CAP0 / CHL) and the

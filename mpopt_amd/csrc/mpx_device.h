@@ -286,25 +286,6 @@ struct MpxResidArgs {
   int32_t n, n_pts, N, seg_off, B, b_per_block;
 };
 
-// Single evaluations of SMALL problems in ONE launch (round 6; mpx_small_<mode>, generated for single-degree grids of at most
-// MPX_SMALL_MAX_TILES tiles: the reference's own examples and every grid it publishes timings for).  A single evaluation is nothing but
-// launch and completion latency -- node kernel, boundary kernel, compressed-column permutation, completion flag: four dependent
-// launches for 61 nodes -- so ONE workgroup runs the tiles one after the other (the same node_body: the same bits), the boundary pass,
-// the permutation of this pass's values into the caller's array and raises the completion flag.  The array sized by the code
-// object's phase count comes last (the host passes the first n_ph entries, as for MpxNodeMultiArgs).
-#define MPX_SMALL_MAX_TILES 8
-struct MpxSmallArgs {
-  MpxBoundArgs bound;
-  const int64_t* perm;       // compressed-column output of this pass: ccs_out[k] = ccs_in[perm[k]], k < ccs_n (NULL: none)
-  const double* ccs_in;
-  double* ccs_out;
-  int64_t ccs_n;
-  unsigned long long* flag;  // completion flag in page-locked host memory (NULL: none) and the value to store
-  unsigned long long seq;
-  int32_t n_ph, pad_;
-  MpxNodeArgs a[MPX_NPH_ARGS];
-};
-
 #define MPX_ACCUM_BIT (1LL << 62)
 
 // ---- resident kernel (single evaluations, the regime an NLP solver drives) ------------------------------------------------

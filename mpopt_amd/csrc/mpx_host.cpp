@@ -81,13 +81,6 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     hipError_t e = hipModuleGetFunction(&c->fn_bound[m], c->module, name);
     if (e != hipSuccess) return fail(c, MPX_ERR_INVALID, "code object lacks kernel %s", name);
   }
-  if (c->degs.size() == 1 && (int64_t)c->tiles.size() <= MPX_SMALL_MAX_TILES && (int)c->buckets.size() == c->n_phases) {  // (optional kernels)
-    char name[64];
-    for (int m = 0; m < 3; ++m) {
-      snprintf(name, sizeof name, "mpx_small_%s", modes[m]);
-      if (hipModuleGetFunction(&c->fn_small[m], c->module, name) != hipSuccess) c->fn_small[m] = nullptr, (void)hipGetLastError();
-    }
-  }
   if (c->n_phases > 1 && c->degs.size() == 1) {  // all phases in one launch (optional kernels)
     static const char* lm[2] = {"fg", "fgq"};
     char name[96];
@@ -429,7 +422,7 @@ MpxBoundArgs bound_args_static(const mpx_ctx* c) {
   return G;
 }
 
-int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool owner = false, bool last = true) {
+int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool owner = false) {
   MpxIO io = io0;
   // (the array that identifies the pass for the geometry measurement: its largest output)
   const void* geom_key = mode == MPX_MODE_HESS ? (const void*)io.hess : io.jac ? (const void*)io.jac : io.g ? (const void*)io.g : io.grad ? (const void*)io.grad : (const void*)io.f;
@@ -467,35 +460,6 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
     if (rc) return rc;
     io.gtmp = c->gtmp.p;
     io.gtmp_stride = c->gtmp_n;
-  }
-  // ---- a single evaluation of a small problem: the whole pass in ONE launch (mpx_small_<mode>; mpx_kernels.h: small_body) ------------
-  // One workgroup runs the tiles in order (the same node_body, tile by tile: the same bits), the boundary pass, the compressed-column
-  // permutation of this pass's values when eval_core asked for one, and -- in the last pass of a zero-copy mpx_eval -- raises the
-  // completion flag: 1 launch where there were 2-4 dependent ones (node kernel, boundary kernel, permutation, flag).  MPX_NO_SMALL=1
-  // (read per call): the separate launches (A/B, the bit-identity test).
-  if (c->fn_small[mode] && io.B == 1 && nodes && !shard && !owner && !light && !packed && c->run_boundary && c->tile_begin == 0 &&
-      c->tile_end == (int64_t)c->tiles.size() && !c->profile && !geom.begin && !getenv("MPX_NO_SMALL")) {
-    MpxSmallArgs SA{};
-    SA.bound = bound_args_static(c);
-    SA.bound.io = io;
-    SA.bound.part_group = 1;
-    SA.n_ph = c->n_phases;
-    for (auto& B : c->buckets) {
-      MpxNodeArgs& A = SA.a[B.phase];
-      A = node_args_static(c, B, false);
-      A.io = io;
-      A.tile_first = B.tile_first, A.tile_count = B.tile_count;
-    }
-    const bool hess = mode == MPX_MODE_HESS;
-    double* ccs_out = hess ? c->post.ccs_out_h : (io.jac ? c->post.ccs_out_j : nullptr);
-    if (ccs_out) {
-      SA.perm = hess ? c->d_perm_h : c->d_perm_j, SA.ccs_in = hess ? io.hess : io.jac, SA.ccs_out = ccs_out, SA.ccs_n = hess ? c->nnz_h : c->nnz_j;
-      (hess ? c->post.perm_done_h : c->post.perm_done_j) = true;
-    }
-    // (the flag only when nothing of this call is left to launch behind this kernel)
-    if (last && c->post.flag && (!c->post.ccs_out_j || c->post.perm_done_j) && (!c->post.ccs_out_h || c->post.perm_done_h))
-      SA.flag = c->post.flag, SA.seq = c->post.seq, c->post.flag_raised = true;
-    return launch(c, c->fn_small[mode], dim3(1, 1, 1), dim3(MPX_TILE, 1, 1), &SA, offsetof(MpxSmallArgs, a) + (size_t)c->n_phases * sizeof(MpxNodeArgs));
   }
   const int gy = (io.B + io.b_per_block - 1) / io.b_per_block;
   hipEvent_t pe1 = nullptr;
@@ -1282,15 +1246,7 @@ static int eval_core(mpx_ctx* c, int mask, int64_t batch, const double* z, const
     if ((rc = upload_ccs_perm(c, MPX_HESS, &c->d_perm_h)) || (rc = reserve(c, c->ccs_h, (size_t)(batch * c->nnz_h)))) return rc;
     th = c->ccs_h.p;
   }
-  // (a single evaluation of a small problem permutes inside its one kernel: run_mode, mpx_small_<mode>)
-  c->post.ccs_out_j = (tj != jac_val && !var_only) ? jac_val : nullptr, c->post.ccs_out_h = th != hess_val ? hess_val : nullptr;
-  c->post.perm_done_j = c->post.perm_done_h = false;
-  rc = eval_native(c, mask & ~MPX_CCS_ORDER, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, tj, th, skip_prefix);
-  const bool done_j = c->post.perm_done_j, done_h = c->post.perm_done_h;
-  c->post.ccs_out_j = c->post.ccs_out_h = nullptr, c->post.perm_done_j = c->post.perm_done_h = false;
-  if (rc) return rc;
-  if (done_j) tj = jac_val;
-  if (done_h) th = hess_val;
+  if ((rc = eval_native(c, mask & ~MPX_CCS_ORDER, batch, z, p, p_per_point, lam_g, sigma, f, g, grad_f, tj, th, skip_prefix))) return rc;
   if (tj != jac_val && var_only) {
     if ((rc = upload_var_sel(c))) return rc;
     if (c->n_var_j > 0)
@@ -1369,9 +1325,9 @@ static int eval_native(mpx_ctx* c, int mask, int64_t batch, const double* z, con
   const bool nodes = !(mask & MPX_BOUNDARY_ONLY), owner = (mask & MPX_OWNER_RESIDENT) != 0;
   if (!nodes && !c->run_boundary && c->shard_world <= 1) return fail(c, MPX_ERR_INVALID, "MPX_BOUNDARY_ONLY with the boundary pass disabled");
   if (mask & (MPX_GRAD | MPX_JAC)) {
-    if ((rc = run_mode(c, MPX_MODE_FGJ, io, nodes, owner, !(mask & MPX_HESS)))) return rc;
+    if ((rc = run_mode(c, MPX_MODE_FGJ, io, nodes, owner))) return rc;
   } else if (mask & (MPX_F | MPX_G)) {
-    if ((rc = run_mode(c, MPX_MODE_FG, io, nodes, owner, !(mask & MPX_HESS)))) return rc;
+    if ((rc = run_mode(c, MPX_MODE_FG, io, nodes, owner))) return rc;
   }
   if (mask & MPX_HESS) {
     if ((rc = run_mode(c, MPX_MODE_HESS, io, nodes, owner))) return rc;
@@ -1388,12 +1344,9 @@ __global__ void mpx_signal_kernel(unsigned long long* flag, unsigned long long s
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-static int wait_flag(mpx_ctx* c, bool already_raised = false) {
-  ++c->flag_seq;
-  if (!already_raised) {  // (else the evaluation's own last kernel stores the number: mpx_small_<mode>)
-    hipLaunchKernelGGL(mpx_signal_kernel, dim3(1), dim3(64), 0, c->stream, c->h_flag_dev, c->flag_seq);
-    HIPCHK(c, hipGetLastError());
-  }
+static int wait_flag(mpx_ctx* c) {
+  hipLaunchKernelGGL(mpx_signal_kernel, dim3(1), dim3(64), 0, c->stream, c->h_flag_dev, ++c->flag_seq);
+  HIPCHK(c, hipGetLastError());
   const auto t0 = std::chrono::steady_clock::now();
   for (uint64_t spins = 1; __atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != c->flag_seq; ++spins) {
     if ((spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
@@ -1606,23 +1559,18 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
         if (mask & MPX_F) memcpy(f, c->h_scratch, B * 8);
         return MPX_OK;
       }
-      static const bool no_flag = getenv("MPX_NO_FLAG_WAIT") != nullptr;
-      // (the last kernel of a small problem's evaluation raises the completion flag itself: run_mode, mpx_small_<mode>)
-      c->post.flag = no_flag ? nullptr : c->h_flag_dev, c->post.seq = c->flag_seq + 1, c->post.flag_raised = false;
       rc = eval_core(c, mask, batch, (const double*)zd, c->st_p.p, p_per_point, (const double*)ld, c->h_scratch_dev + B, c->h_scratch_dev, (double*)gd,
                      (double*)qd, (double*)jd, (double*)hd, same_p);
-      const bool raised = c->post.flag_raised;
-      c->post.flag = nullptr, c->post.flag_raised = false;
       if (rc) {
         c->wcum_valid = false;
-        if (raised) ++c->flag_seq;
         return rc;
       }
       c->wcum_valid = true;
       const double t2 = lat_dbg ? now() : 0;
+      static const bool no_flag = getenv("MPX_NO_FLAG_WAIT") != nullptr;
       if (no_flag)
         HIPCHK(c, hipStreamSynchronize(c->stream));
-      else if ((rc = wait_flag(c, raised)))
+      else if ((rc = wait_flag(c)))
         return rc;
       if (lat_dbg) {
         const double t3 = now();

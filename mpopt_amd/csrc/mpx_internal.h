@@ -97,15 +97,6 @@ struct mpx_ctx {
   bool time_dep = true;  // some node function uses the node time (mpx_time_dependent of the code object; true when the symbol is absent): else no prefix sums of the widths
   hipModule_t module = nullptr;
   hipFunction_t fn_bound[3] = {nullptr, nullptr, nullptr};
-  // single evaluations of small problems in one launch (mpx_small_<mode>, MpxSmallArgs; nullptr: the code object has none)
-  hipFunction_t fn_small[3] = {nullptr, nullptr, nullptr};
-  struct Post {  // what the LAST kernel of a single evaluation may do on behalf of its callers (eval_core: permutation; mpx_eval: flag)
-    double *ccs_out_j = nullptr, *ccs_out_h = nullptr;  // set by eval_core: the caller's arrays for the compressed-column values
-    bool perm_done_j = false, perm_done_h = false;      // set by run_mode when the small kernel wrote them
-    unsigned long long* flag = nullptr;                 // set by mpx_eval (zero-copy path): raise this flag ...
-    unsigned long long seq = 0;                         // ... to this value
-    bool flag_raised = false;                           // set by run_mode when the last small kernel raises it
-  } post;
   // all phases of a single-degree grid in one launch (n_phases > 1; mpx_node_<mode>_all_<deg>, mpx_lightlow[s]_<fg|fgq>_all_<deg>);
   // nullptr: the code object has none (one degree per phase only, or generated before round 5) -- one launch per phase then
   hipFunction_t fn_node_all[3] = {nullptr, nullptr, nullptr};

@@ -2171,30 +2171,6 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A, const int r
 // grad_gamma_p[s] = sum_{i in s} (gk_i / (tau1 - tau0) + gth_i * tk_i) + sum_{i in later segments} gth_i: the node pass leaves the two
 // per-node terms in `pnode`, the finishing pass forms the per-segment sums and the suffix sums in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------------
-// One workgroup evaluates a whole small problem at one point (MpxSmallArgs): tiles in order -> boundary pass -> permutation -> flag.
-// What one phase of the pass wrote to global memory (tile partials, staged values, native-order Jacobian / Hessian values) is read by
-// OTHER lanes of the same workgroup in the next: a device-scope fence and a barrier between the phases.
-template <int MODE, class NodeFn>
-__device__ __forceinline__ void small_body(const MpxSmallArgs& S, NodeFn node) {
-  for (int p = 0; p < S.n_ph; ++p) {
-    const int nt = S.a[p < MPX_NPH ? p : 0].tile_count;
-    for (int t = 0; t < nt; ++t) node(p, t);
-  }
-  __threadfence();
-  __syncthreads();
-  boundary_body<MODE>(S.bound, 0);
-  if (S.perm) {
-    __threadfence();
-    __syncthreads();
-    for (int64_t k = threadIdx.x; k < S.ccs_n; k += MPX_TILE) S.ccs_out[k] = S.ccs_in[S.perm[k]];
-  }
-  if (S.flag) {
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(S.flag, S.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 template <int PH, int P>
 __device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
   using G = mpxgen::Phase<PH>;

@@ -496,11 +496,3 @@ def test_jac_variable_mask_marks_only_constants_as_constant(name):
     assert np.array_equal(vals[0][const], vals[1][const]) and const.sum() > 0.4 * o.nnz_jac
     assert (vals[0][~const] != vals[1][~const]).mean() > 0.5  # (the variable set is a superset: structurally zero diagonals included)
     o.close()
-
-
-def test_small_kernels_exist_only_for_small_single_degree_grids():
-    """The generator emits mpx_small_* for grids of at most 8 tiles and one degree; larger or mixed grids keep the separate launches."""
-    ocp = problems.moon_lander(mp, M.math)
-    assert "mpx_small_fgj" in M.NlpFunctions(ocp, 20, [3] * 20, "LGR", with_device=False).source
-    assert "mpx_small_fgj" not in M.NlpFunctions(ocp, 1000, [5] * 1000, "LGR", with_device=False).source
-    assert "mpx_small_fgj" not in M.NlpFunctions(ocp, 3, [3, 6, 3], "LGR", with_device=False).source
