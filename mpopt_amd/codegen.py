@@ -304,6 +304,8 @@ class ProblemProgram:
                     parts.append(f"MPX_INSTANTIATE_LIGHT_PF({ph}, {d}, {low[0] if len(low) == 1 and low[0] <= 12 else 0})")
                 if d <= 12 and len(self.degrees) == 1 and self.light_low_chunks(d) >= 2:  # ... and of single-degree grids of low degree (light_low_body)
                     parts.append(f"MPX_INSTANTIATE_LIGHT_LOW({ph}, {d})")
+                if d >= 32 and len(self.degrees) == 1:  # ... and of single-degree grids of HIGH degree: evaluation points as a matrix dimension (light_high_body)
+                    parts.append(f"MPX_INSTANTIATE_LIGHT_HIGH({ph}, {d})")
         if nph > 1 and len(self.degrees) == 1:  # all phases of a single-degree grid in ONE launch (mpx_kernels.h: node_all, light_low_all)
             d = self.degrees[0]
             parts.append(f"MPX_INSTANTIATE_NODE_ALL({d})")

@@ -113,9 +113,14 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
     snprintf(name, sizeof name, "mpx_node_gradl_%d_%d", B.phase, B.deg);
     if (hipModuleGetFunction(&B.fn_gradl, c->module, name) != hipSuccess) B.fn_gradl = nullptr, (void)hipGetLastError();
     static const char* lm[2] = {"fg", "fgq"};
-    for (int m = 0; m < 2 && ((B.deg > 12 && B.deg <= 31) || c->lplan.low); ++m) {  // light passes (mpx_kernels.h: light_body / light_low_body)
-      snprintf(name, sizeof name, "mpx_light%s_%s_%d_%d", c->lplan.low ? "low" : "", lm[m], B.phase, B.deg);
+    for (int m = 0; m < 2 && ((B.deg > 12 && B.deg <= 31) || c->lplan.low || c->lplan.high); ++m) {  // light passes (mpx_kernels.h: light_body / light_low_body / light_high_body)
+      snprintf(name, sizeof name, "mpx_light%s_%s_%d_%d", c->lplan.low ? "low" : (c->lplan.high ? "high" : ""), lm[m], B.phase, B.deg);
       if (hipModuleGetFunction(&B.fn_light[m], c->module, name) != hipSuccess) B.fn_light[m] = nullptr, (void)hipGetLastError();
+      if (c->lplan.high && B.fn_light[m]) {  // the input tile of a workgroup: dynamic LDS, past the 64 KB a launch gets by default from degree ~160
+        const int dyn = (int)((int64_t)(c->nx + c->nu) * c->lplan.span_cap * 17 * 8);
+        if (dyn > 60 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(B.fn_light[m]), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess)
+          B.fn_light[m] = nullptr, (void)hipGetLastError();
+      }
       snprintf(name, sizeof name, "mpx_lightlows_%s_%d_%d", lm[m], B.phase, B.deg);  // one chunk per wavefront: small batches
       if (!c->lplan.low || hipModuleGetFunction(&B.fn_light_small[m], c->module, name) != hipSuccess) B.fn_light_small[m] = nullptr, (void)hipGetLastError();
     }
@@ -138,7 +143,7 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   for (auto& t : c->degs) {
     if ((rc = upload(c, &t.d_D, t.D))) return rc;
     if ((rc = upload(c, &t.d_Cmid, t.Cmid))) return rc;
-    if (t.deg > c->stream_above) {  // streamed degrees: DT[j][k] = D[k][j], CT[j][k - 1] = C_mid[k - 1][j] (mpx_kernels.h: node_body, TAB_GLB)
+    if (t.deg > c->stream_above || (c->lplan.ok && c->lplan.high)) {  // streamed degrees and the high-degree light kernels: DT[j][k] = D[k][j], CT[j][k - 1] = C_mid[k - 1][j] (mpx_kernels.h: node_body TAB_GLB, light_high_body)
       const size_t n1 = (size_t)t.deg + 1, nm = (size_t)t.deg;
       std::vector<double> DT(n1 * n1), CT(n1 * nm);
       for (size_t k = 0; k < n1; ++k)
@@ -349,8 +354,8 @@ MpxNodeArgs node_args_static(const mpx_ctx* c, const Bucket& B, bool absorber) {
   A.tiles = c->d_tiles;
   A.node_i = B.d_node_i;
   A.node_sk = B.d_node_sk;
-  A.Dmat = t.d_DT ? t.d_DT : t.d_D;  // (streamed degrees: the transposed tables)
-  A.Cmid = t.d_CT ? t.d_CT : t.d_Cmid;
+  A.Dmat = t.deg > c->stream_above ? t.d_DT : t.d_D;  // (streamed degrees: the transposed tables)
+  A.Cmid = t.deg > c->stream_above ? t.d_CT : t.d_Cmid;
   A.tk = t.d_tk;
   A.Dmid = t.d_Dmid;
   A.tkm = t.d_tkm;
@@ -450,7 +455,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
                c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_LIGHT");
   for (auto& B : c->buckets)
     if (light && B.deg == c->lplan.deg && (!B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0] || (c->lplan.low && !B.fn_light_small[mode == MPX_MODE_FGJ ? 1 : 0]))) light = false;
-  if (light && c->lplan.low) io.n_tiles_total = c->n_phases * c->lplan.n_low_chunks;  // (partial-sum slots of a light pass: [phase][64-node chunk])
+  if (light && (c->lplan.low || c->lplan.high)) io.n_tiles_total = c->n_phases * c->lplan.n_low_chunks;  // (partial-sum slots of a light pass: [phase][64-node chunk] / [phase][segment])
   // low-degree plan: fewer long spans than a wavefront per SIMD of the device -> one 64-node chunk per wavefront (same sums)
   const bool light_small = light && c->lplan.low && (int64_t)c->lplan.n_low_groups * io.B < 1024 && !getenv("MPX_LIGHT_LONG_SPANS");
   const bool packed = want_g && io.B <= 65535 && !light &&
@@ -493,14 +498,26 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
       A.z_off = P.z_off, A.g_off_F = P.g_off_F, A.g_off_C = P.g_off_C, A.g_off_DU = P.g_off_DU, A.g_off_mU = P.g_off_mU;
       A.N = (int32_t)c->N, A.seg_off = B.phase * c->S;
       L.groups = c->d_lgroups, L.foreign = c->d_lforeign, L.wdeg = t.d_w;
-      for (size_t k = 0; k < c->degs.size() && !c->lplan.low; ++k) L.fD_off[k] = c->lplan.fD_off[k], L.fC_off[k] = c->lplan.fC_off[k], L.fdeg[k] = c->degs[k].deg;
+      for (size_t k = 0; k < c->degs.size() && !c->lplan.low && !c->lplan.high; ++k) L.fD_off[k] = c->lplan.fD_off[k], L.fC_off[k] = c->lplan.fC_off[k], L.fdeg[k] = c->degs[k].deg;
       L.ftab = c->d_lftab, L.ftab_n = (int32_t)c->lplan.ftab.size();
       L.n_groups = c->lplan.low ? c->lplan.n_low_groups : (int32_t)c->lplan.groups.size(), L.first_node = c->lplan.first_node, L.span_cap = c->lplan.span_cap, L.slot_first = P.tile_first;
       // low-degree plan: fewer long spans than half the wavefront slots of the device -> one 64-node chunk per wavefront (same sums:
       // the partial-sum slots are per chunk for both span lengths)
       const bool small = light_small;
-      if (c->lplan.low) L.slot_first = B.phase * c->lplan.n_low_chunks;
+      if (c->lplan.low || c->lplan.high) L.slot_first = B.phase * c->lplan.n_low_chunks;
       if (small) L.n_groups = c->lplan.n_low_chunks;
+      if (c->lplan.high) {  // light_high_body: workgroup = (segment, 16 evaluation points); the TRANSPOSED tables as matrix operands
+        A.Dmat = t.d_DT, A.Cmid = t.d_CT;
+        const unsigned lds = (unsigned)((int64_t)(c->nx + c->nu) * c->lplan.span_cap * 17 * 8);
+        const int64_t nblk = (io.B + 15) / 16;
+        for (int64_t y0 = 0; y0 < nblk; y0 += 65535) {
+          A.io.b_first = (int32_t)(16 * y0);
+          int rc = launch(c, B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0], dim3((unsigned)c->S, (unsigned)std::min<int64_t>(65535, nblk - y0), 1), dim3(256, 1, 1), &L, sizeof L, lds);
+          if (rc) return rc;
+          if (c->profile) ++c->prof_launches;
+        }
+        continue;
+      }
       static long long* ldbg = nullptr;
       if (!ldbg && getenv("MPX_LIGHT_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
       L.dbg = ldbg;
@@ -641,7 +658,8 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   G.part_group = light_small ? c->lplan.own / 64 : 1;
   if (light)  // the slots the light kernels wrote: one per group in front of the phase's tile slots, or [phase][64-node chunk]
     for (int p = 0; p < c->n_phases; ++p) {
-      if (c->lplan.low) G.ph[p].tile_first = p * c->lplan.n_low_chunks, G.ph[p].tile_count = light_small ? c->lplan.n_low_chunks : c->lplan.n_low_groups;
+      if (c->lplan.high) G.ph[p].tile_first = p * c->lplan.n_low_chunks, G.ph[p].tile_count = c->lplan.n_low_chunks;
+      else if (c->lplan.low) G.ph[p].tile_first = p * c->lplan.n_low_chunks, G.ph[p].tile_count = light_small ? c->lplan.n_low_chunks : c->lplan.n_low_groups;
       else G.ph[p].tile_count = (int32_t)c->lplan.groups.size();
     }
   // (MPX_BOUNDARY_ANYORDER=1, read per call, MPX_BOUNDARY_ONLY calls only: an experiment of round 5 -- the boundary pass of the config-5
@@ -859,7 +877,7 @@ extern "C" int mpx_get_light_plan(const mpx_ctx* c, int32_t* degree, int64_t* n_
   if (!c) return MPX_ERR_INVALID;
   const bool ok = c->kind == 0 && c->lplan.ok;
   if (degree) *degree = ok ? c->lplan.deg : 0;
-  if (n_groups) *n_groups = ok ? (c->lplan.low ? (int64_t)c->lplan.n_low_groups : (int64_t)c->lplan.groups.size()) : 0;
+  if (n_groups) *n_groups = ok ? (c->lplan.low || c->lplan.high ? (int64_t)c->lplan.n_low_groups : (int64_t)c->lplan.groups.size()) : 0;
   if (max_span_nodes) *max_span_nodes = ok ? c->lplan.span_cap : 0;
   if (n_low_degree_nodes) *n_low_degree_nodes = ok ? (int64_t)c->lplan.foreign.size() : 0;
   return MPX_OK;

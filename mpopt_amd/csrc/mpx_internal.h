@@ -117,6 +117,7 @@ struct mpx_ctx {
   // degrees <= 12.  Groups of up to 16 high-degree segments + the low-degree segments between them (the same for every phase)
   struct LightPlan {
     bool ok = false, low = false;           // low: single-degree grid of degree <= 12 (light_low_body: spans of `own` nodes)
+    bool high = false;                      // high: single-degree grid of degree >= 32 (light_high_body: workgroup = segment x 16 evaluation points; n_low_chunks = S slots per phase, span_cap = padded K)
     int deg = 0, dt = -1, first_node = 0, span_cap = 0, own = 0, n_low_groups = 0, n_low_chunks = 0;
     std::vector<MpxLightGroup> groups;
     std::vector<MpxLightForeign> foreign;
@@ -260,7 +261,7 @@ inline int fail(mpx_ctx* c, int code, const char* fmt, ...) {
 // Doubles-per-point of the partial-sum buffer, in slots: the tiles, or -- light passes of single-degree low-degree grids -- one slot per
 // 64-node chunk of every phase (mpx_kernels.h: light_low_body), whichever is more
 inline int64_t partial_slots(const mpx_ctx* c) {
-  const int64_t low = c->lplan.ok && c->lplan.low ? (int64_t)c->n_phases * c->lplan.n_low_chunks : 0;
+  const int64_t low = c->lplan.ok && (c->lplan.low || c->lplan.high) ? (int64_t)c->n_phases * c->lplan.n_low_chunks : 0;
   return std::max<int64_t>((int64_t)c->tiles.size(), low);
 }
 

@@ -1705,6 +1705,199 @@ __device__ __forceinline__ void light_low_all(const MpxLightMultiArgs& M) {
 // MODE_HESS branch of node_body (G::hess, slot layout of scatter_slots, fixed-order tile sums), without anything that depends
 // on the degree; segment and reference position of a node come from two per-node tables instead of the bucket's node list.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------------
+// Light passes of SINGLE-DEGREE grids of HIGH degree (32 <= P <= 255; round 6): mpx_lighthigh_{fg,fgq}_<ph>_<deg>.
+// node_body serves these degrees one evaluation point per walk over the tables: 2 (P + 1)^2 table values from L2 per tile and point
+// for (nx + nu) (P + 1) outputs -- nlp_g of moon lander 50 x 100 at B = 512: 319 us, 0.05 of the HBM roofline (profiles/r6_final).
+// Here the contraction of a segment IS a matrix product with the EVALUATION POINTS as one dimension:
+//     G^T[b][i] = sum_k X^T[b][k] * D^T[k][i]        b: 16 evaluation points, i: the segment's points, k: the segment's points
+// on v_mfma_f64_16x16x4_f64 -- A operand = the segment's X / U values of 16 evaluation points (an LDS tile [input][k][point],
+// padded to 17), B operand = a 4 x 16 block of the TRANSPOSED differentiation / mid-point table straight from L2 (the lanes of a
+// 16-lane row read 16 consecutive entries), accumulated over k in order: the sequential fused chain of node_body, bit for bit
+// (tools/mfma_f64_probe.hip; products commute).  A workgroup = (segment, block of 16 evaluation points); its four wavefronts share
+// the input tile and take the 16-node column tiles in turn.  In the C/D layout a lane holds ONE node for four evaluation points
+// (row = point q + 4 r, column = node n), so the node functions run in place and every row of g / grad_f leaves from registers
+// as 128-byte runs (16 consecutive nodes of one point per 16-lane row) -- no output staging.  Each table entry is read once per 16
+// points instead of once per point.  g and the node entries of grad_f have node_body's bits; f and the (t0, tf, a) sums are
+// added in another fixed order (lane: its nodes in order; 16-lane row by DPP; wavefronts in order; one partial-sum slot per
+// segment, the boundary pass adds the segments in order).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PH, int P, int MODE>
+__device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
+  using G = mpxgen::Phase<PH>;
+  const MpxNodeArgs& A = L.node;
+  const MpxIO& io = A.io;
+  constexpr int NX = G::NX, NU = G::NU, NA = G::NA, NC = G::NC, NIN = NX + NU;
+  constexpr int P1 = P + 1, NTN = (P1 + 15) / 16, KS = (P1 + 3) / 4, KP = 4 * KS, LDB = 17;
+  constexpr int NRED = (MODE == MPX_MODE_FG) ? 1 : G::NRED;
+  extern __shared__ double sT[];  // [NIN][KP][LDB]: X / U of the segment's points k for 16 evaluation points (rows k > P: zero)
+  __shared__ double sRed[4][16][NRED];
+  __shared__ double sTk[NTN * 16], sWt[NTN * 16];
+  const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63, n = l & 15, q = l >> 4;
+  const int s = blockIdx.x, N = A.N, st = s * P;
+  const int b0 = io.b_first + 16 * (int)blockIdx.y;
+  const int nb = io.B - b0 < 16 ? io.B - b0 : 16;
+  // (1) the tile: thread (point b = t % 16, k-pair kc = t / 16) moves two consecutive k of one evaluation point per step
+  {
+    const int b = t & 15, kc = t >> 4;
+    const double* __restrict__ zb = io.z + (int64_t)(b0 + (b < nb ? b : nb - 1)) * io.z_stride + A.z_off + st;
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+    for (int a = 0; a < NIN; ++a) {
+      constexpr int STEPS = (KP + 31) / 32;
+      d2u v[STEPS];
+#pragma unroll
+      for (int u = 0; u < STEPS; ++u) {
+        const int k = 32 * u + 2 * kc;
+        const double* __restrict__ src = zb + (int64_t)a * N + k;
+        if (k + 1 <= P) v[u] = *(const d2u*)src;
+        else v[u] = d2u{k <= P ? src[0] : 0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < STEPS; ++u) {
+        const int k = 32 * u + 2 * kc;
+        if (k < KP) sT[(a * KP + k) * LDB + b] = v[u].x, sT[(a * KP + k + 1) * LDB + b] = v[u].y;
+      }
+    }
+  }
+  if (t < NTN * 16) sTk[t] = A.tk[t <= P ? t : P], sWt[t] = L.wdeg[t <= P ? t : P];
+  // the lane's four evaluation points (rows q + 4 r of the products): scalars of the point
+  double t0v[4], tfv[4], ws[4], wc[4];
+  Vec<NA> As[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = q + 4 * r, bb = b0 + (b < nb ? b : nb - 1);
+    const double* __restrict__ zt = io.z + (int64_t)bb * io.z_stride + A.z_off + (int64_t)NIN * N;
+    t0v[r] = zt[0], tfv[r] = zt[1];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) As[r][c] = zt[2 + c];
+    const int64_t woff = (int64_t)bb * io.w_stride + A.seg_off + s;
+    ws[r] = io.w[woff], wc[r] = io.wcum[woff];
+  }
+  __syncthreads();
+  const bool want_g = io.g != nullptr, want_q = MODE == MPX_MODE_FGJ && io.grad != nullptr;
+  double racc[4][NRED];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) racc[r][k] = 0.0;
+  const double* __restrict__ DT = A.Dmat;  // transposed: DT[k * P1 + i] = D[i][k]
+  const double* __restrict__ CT = A.Cmid;  //             CT[k * P + (i - 1)] = C_mid[i - 1][k]
+  for (int nt = wave; nt < NTN; nt += 4) {
+    const int i = 16 * nt + n;  // the lane's node of the segment (column n of the products)
+    const bool inode = i <= P;
+    mpx_d4 aX[NX], aDU[NU > 0 ? NU : 1], aCU[NU > 0 ? NU : 1];
+#pragma unroll
+    for (int a = 0; a < NX; ++a) aX[a] = mpx_d4{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < (NU > 0 ? NU : 1); ++c) aDU[c] = mpx_d4{0, 0, 0, 0}, aCU[c] = mpx_d4{0, 0, 0, 0};
+    if (want_g) {
+#pragma unroll 4
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kk = 4 * ks + q;
+        const bool in = inode && kk <= P;
+        const double bD = in ? DT[(in ? kk : 0) * P1 + (in ? i : 0)] : 0.0;
+        double bC = 0.0;
+        if constexpr (G::MIDU) bC = (in && i >= 1) ? CT[(in ? kk : 0) * P + ((in && i >= 1) ? i - 1 : 0)] : 0.0;
+#pragma unroll
+        for (int a = 0; a < NX; ++a) aX[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(sT[(a * KP + kk) * LDB + n], bD, aX[a], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+          const double uop = sT[((NX + c) * KP + kk) * LDB + n];
+          if constexpr (G::DIFF_U) aDU[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(uop, bD, aDU[c], 0, 0, 0);
+          if constexpr (G::MIDU) aCU[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(uop, bC, aCU[c], 0, 0, 0);
+        }
+      }
+    }
+    // (2) node functions in place: node i of evaluation points q, q + 4, q + 8, q + 12
+    const bool vnode = inode && (i >= 1 || s == 0);  // (point 0 of a segment belongs to the previous one -- except node 0 of the phase)
+    const int ic = inode ? i : P;
+    const int64_t node = (int64_t)st + ic;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = q + 4 * r;
+      const bool valid = vnode && b < nb;
+      Vec<NX> Xs, fx;
+      Vec<NU> Us;
+      Vec<NC> cc;
+#pragma unroll
+      for (int a = 0; a < NX; ++a) Xs[a] = sT[(a * KP + ic) * LDB + b];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) Us[c] = sT[((NX + c) * KP + ic) * LDB + b];
+      const double kap = ws[r] * A.inv_dtau, th = wc[r] + ws[r] * sTk[ic];
+      Vec<NRED> gr;
+      Vec<NIN> gn;
+      if constexpr (MODE == MPX_MODE_FG) {
+        G::fg(Xs, Us, t0v[r], tfv[r], As[r], kap, th, sWt[ic], fx, cc, gr[0]);
+      } else {
+        Vec<NX> dd;
+        Vec<G::NJV> jv;
+        G::fgj(Xs, Us, t0v[r], tfv[r], As[r], kap, th, sWt[ic], fx, cc, dd, jv, gn, gr);
+      }
+      if (valid) {
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) racc[r][k] += gr[k];
+        if (want_g) {
+          double* __restrict__ gb = io.g + (int64_t)(b0 + b) * io.g_stride;
+#pragma unroll
+          for (int a = 0; a < NX; ++a) gb[A.g_off_F + (int64_t)a * N + node] = aX[a][r] - fx[a];
+#pragma unroll
+          for (int j = 0; j < NC; ++j) gb[A.g_off_C + (int64_t)j * N + node] = cc[j];
+          if constexpr (G::DIFF_U) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) gb[A.g_off_DU + (int64_t)c * N + node] = aDU[c][r];
+          }
+          if constexpr (G::MIDU) {
+            if (i >= 1) {
+#pragma unroll
+              for (int c = 0; c < NU; ++c) gb[A.g_off_mU + (int64_t)c * (N - 1) + (node - 1)] = aCU[c][r];
+            }
+          }
+        }
+        if constexpr (MODE == MPX_MODE_FGJ) {
+          if (want_q) {
+            double* __restrict__ qb = io.grad + (int64_t)(b0 + b) * io.grad_stride + A.z_off;
+#pragma unroll
+            for (int a = 0; a < NIN; ++a) qb[(int64_t)a * N + node] = gn[a];
+          }
+        }
+      }
+    }
+  }
+  // (3) the points' sums over this segment: 16-lane rows by DPP (row_shr 1, 2, 4, 8: lane 15 of a row holds its total), wavefronts in order
+  auto row_total = [](double x) {
+    auto dpp0 = [](double v, auto ctrl) {
+      constexpr int C = decltype(ctrl)::value;
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), C, 0xf, 0xf, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), C, 0xf, 0xf, false);
+      return __hiloint2double(hi, lo);
+    };
+    using std::integral_constant;
+    x += dpp0(x, integral_constant<int, 0x111>{});
+    x += dpp0(x, integral_constant<int, 0x112>{});
+    x += dpp0(x, integral_constant<int, 0x114>{});
+    x += dpp0(x, integral_constant<int, 0x118>{});
+    return x;
+  };
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) {
+      const double v = row_total(racc[r][k]);
+      if (n == 15) sRed[wave][q + 4 * r][k] = v;
+    }
+  __syncthreads();
+  if (t < 16 * NRED) {
+    const int b = t / NRED, k = t - b * NRED;
+    if (b < nb) {
+      double v = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += sRed[w][b][k];
+      io.partial[((int64_t)(b0 + b) * io.n_tiles_total + L.slot_first + s) * io.nred + k] = v;
+    }
+  }
+}
+
 template <int PH>
 __device__ __forceinline__ void hess_by_node_body(const MpxHessNodeArgs& A) {
   using G = mpxgen::Phase<PH>;
@@ -2582,6 +2775,14 @@ __device__ __forceinline__ void resident_loop(const MpxResidentArgs& R, Dispatch
   }                                                                                                                           \
   extern "C" __global__ __launch_bounds__(64 * MPX_LIGHT_WAVES, MPX_LIGHT_MIN_WG) void mpx_light_fgq_##PH##_##P(const MpxLightArgs A) {         \
     mpxk::light_body<PH, P, MPX_MODE_FGJ, PF>(A);                                                                             \
+  }
+
+#define MPX_INSTANTIATE_LIGHT_HIGH(PH, P)                                                                                     \
+  extern "C" __global__ __launch_bounds__(256) void mpx_lighthigh_fg_##PH##_##P(const MpxLightArgs A) {                        \
+    mpxk::light_high_body<PH, P, MPX_MODE_FG>(A);                                                                             \
+  }                                                                                                                           \
+  extern "C" __global__ __launch_bounds__(256) void mpx_lighthigh_fgq_##PH##_##P(const MpxLightArgs A) {                       \
+    mpxk::light_high_body<PH, P, MPX_MODE_FGJ>(A);                                                                            \
   }
 
 // (two workgroups per compute unit: three measured 8 - 13 % slower at config 2, one 45 % -- profiles/r4_lightlow/README.md)

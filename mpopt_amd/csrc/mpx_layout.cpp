@@ -315,6 +315,14 @@ int build_layout(mpx_ctx* c) {
       L.n_low_chunks = (int)((N + 63) / 64);  // partial-sum slots of a phase in a light pass: one per 64-node chunk
       L.ok = chl >= 2;  // (rows of more than ~24 inputs leave one chunk per span: the node kernels do as well)
     }
+    // single-degree grids of HIGH degree (mpx_lighthigh_*, light_high_body; round 6): a workgroup = (segment, 16 evaluation points), the
+    // input tile [nx + nu][4 ceil((P + 1) / 4)][17] doubles in LDS, one partial-sum slot per segment
+    if (!L.ok && c->degs.size() == 1 && c->degs[0].deg >= 32 && !getenv("MPX_NO_LIGHT_HIGH")) {
+      const int P = c->degs[0].deg, kp = 4 * ((P + 1 + 3) / 4);
+      L = mpx_ctx::LightPlan();
+      L.high = true, L.deg = P, L.dt = 0, L.span_cap = kp, L.n_low_chunks = S, L.n_low_groups = S;
+      L.ok = (int64_t)(nx + nu) * kp * 17 * 8 + 8192 <= 150 * 1024;
+    }
   }
 
   // ---- packed g / grad_f staging (see MpxIO::gtmp): used by mixed-degree phases and by segment-sharded evaluations ----

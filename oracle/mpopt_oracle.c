@@ -46,7 +46,7 @@
 #endif
 
 #define MAXV 16 /* nx + nu + 1 + na */
-#define MAXP 64 /* max degree + 1 */
+#define MAXP 256 /* max degree + 1 (round 6: the library takes degrees up to 255; above degree 10 the tables come from orc_set_table, the monomial form below is only exact there) */
 
 typedef struct {
   const char* name;

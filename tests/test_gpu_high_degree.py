@@ -71,9 +71,10 @@ def test_high_degree_against_numpy_oracle(name):
     Ho = sp.csr_matrix(np.triu(O.hess_l(z, p, sig, lam)))
     d = sp.coo_matrix((r["hess_l"], (hr, hc)), shape=(o.n_z, o.n_z)).tocsr() - Ho
     assert (abs(d).max() if d.nnz else 0.0) < TOL * max(1.0, abs(Ho).max())
-    # a light pass (the node kernels in f / g mode serve these degrees), the separate calls and a batch give the same bits
+    # a light pass (single-degree grids: mpx_lighthigh_* on the matrix cores, another fixed order of the sums in f; mixed grids: the
+    # node kernels in f / g mode), the separate calls and a batch give the same bits of g
     lg = o.eval(["f", "g"], z, p)
-    assert np.array_equal(lg["g"], r["g"]) and lg["f"] == r["f"]
+    assert np.array_equal(lg["g"], r["g"]) and abs(lg["f"] - r["f"]) <= 1e-13 * max(1.0, abs(r["f"]))
     rb = o.eval(["f", "g", "grad_f", "jac_g"], np.stack([z, z + 1e-3, z]), p)
     assert np.array_equal(rb["jac_g"][0], r["jac_g"]) and np.array_equal(rb["jac_g"][2], r["jac_g"]) and np.array_equal(rb["g"][2], r["g"])
     # nlp_grad: grad_gamma_x / grad_gamma_p (the D / C_mid transposes straight from global memory at these degrees)
@@ -183,3 +184,58 @@ def test_jac_variable_only_at_streamed_degrees(name):
     o.eval_device(8 | MPX_JAC_VARIABLE_ONLY, B, Z2, p, 0, None, None, None, None, None, jn, None)
     o.sync()
     assert torch.isnan(jn).any() and not torch.isnan(jn).all()
+
+
+LIGHT_HIGH = {
+    "moon_lander_6x40_LGR": (problems.moon_lander, 6, 40, "LGR"),        # node kernels of this degree keep their tables in LDS
+    "moon_lander_3x100_LGR": (problems.moon_lander, 3, 100, "LGR"),      # ... stream them
+    "kitchen_sink_3x36_LGL": (problems.kitchen_sink, 3, 36, "LGL"),      # two phases, control-slope rows (D.U), path rows, parameters, time dependence
+    "dae_vdp_2x69_CGL": (problems.dae_vdp, 2, 69, "CGL"),                # path row + parameter
+    "hyper_sensitive_1x255_LGR": (problems.hyper_sensitive, 1, 255, "LGR"),  # 16 column tiles, 64 K steps; no mid-point rows
+    "schwartz_2x33_LGR": (problems.two_phase_schwartz, 2, 33, "LGR"),    # P + 1 = 34: two nodes in the third column tile
+}
+
+
+@pytest.mark.parametrize("name", list(LIGHT_HIGH))
+def test_high_degree_light_passes_on_the_matrix_cores(name, monkeypatch):
+    """Round 6: nlp_f / nlp_g / nlp_grad_f WITHOUT the Jacobian values on single-degree grids of degree >= 32 (mpx_lighthigh_*,
+    light_high_body): the contraction of a segment as a matrix product with 16 evaluation points as one dimension, v_mfma_f64_16x16x4_f64,
+    the transposed tables as operands straight from L2.  Against the node kernels (MPX_NO_LIGHT=1): g and the node entries of grad_f bit
+    for bit (the same sequential fused chains), f and the (t0, tf, a) sums -- another fixed order -- to rounding; for batches that are
+    no multiple of 16, per-point widths; and against the numpy oracle.  Defects: mpopt.py:227-232; objective: mpopt.py:455."""
+    from helpers import border_columns
+
+    builder, S, P, scheme = LIGHT_HIGH[name]
+    ocp = builder(mp, M.math)
+    mpo = mp.mpopt(ocp, S, P, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    assert o.light_plan()[:2] == (P, S), "no high-degree light plan: the masks below would run the node kernels"
+    z, p, lam, sig = random_point(o, mpo, 23, S, ocp.n_phases)
+    rng = np.random.default_rng(7)
+    node = np.ones(o.n_z, bool)
+    node[border_columns(o)] = False
+    masks = (["f"], ["g"], ["f", "grad_f"], ["f", "g", "grad_f"])
+    for B in (1, 5, 16, 37):
+        Z = z[None, :] * (1 + 0.01 * rng.uniform(-1, 1, (B, o.n_z))) + 0.01 * rng.uniform(-1, 1, (B, o.n_z))
+        Z[0] = z
+        w = rng.uniform(0.3, 1.7, (B, ocp.n_phases, S))
+        Pw = (w / w.sum(axis=2, keepdims=True)).reshape(B, -1)
+        for pp in (p, Pw):
+            light = [o.eval(m, Z if B > 1 else Z[0], pp if B > 1 else (pp if pp.ndim == 1 else pp[0])) for m in masks]
+            monkeypatch.setenv("MPX_NO_LIGHT", "1")
+            heavy = [o.eval(m, Z if B > 1 else Z[0], pp if B > 1 else (pp if pp.ndim == 1 else pp[0])) for m in masks]
+            monkeypatch.delenv("MPX_NO_LIGHT")
+            for m, a, h in zip(masks, light, heavy):
+                a, h = ({k: np.atleast_2d(v) if k != "f" else np.atleast_1d(v) for k, v in d.items()} for d in (a, h))
+                if "g" in m:
+                    assert np.array_equal(a["g"], h["g"]), (name, B, m)
+                if "grad_f" in m:
+                    assert np.array_equal(a["grad_f"][:, node], h["grad_f"][:, node]), (name, B, m)
+                    sc = max(1.0, np.abs(h["grad_f"][:, ~node]).max())
+                    assert np.abs(a["grad_f"][:, ~node] - h["grad_f"][:, ~node]).max() <= 1e-12 * sc, (name, B, m)
+                if "f" in m:
+                    assert np.abs(a["f"] - h["f"]).max() <= 1e-13 * max(1.0, np.abs(h["f"]).max()), (name, B, m)
+                    assert np.array_equal(a["f"], np.atleast_1d(light[0]["f"])), (name, B, m)  # every light pass sums f in the same order
+    O = OracleNLP(ocp, S, P, scheme)
+    r = o.eval(["f", "g", "grad_f"], z, p)
+    assert rel_err(r["f"], O.f(z, p)) < TOL and rel_err(r["g"], O.g(z, p)) < TOL and rel_err(r["grad_f"], O.grad_f(z, p)) < TOL
