@@ -1783,32 +1783,56 @@ __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
     for (int k = 0; k < NRED; ++k) racc[r][k] = 0.0;
   const double* __restrict__ DT = A.Dmat;  // transposed: DT[k * P1 + i] = D[i][k]
   const double* __restrict__ CT = A.Cmid;  //             CT[k * P + (i - 1)] = C_mid[i - 1][k]
-  for (int nt = wave; nt < NTN; nt += 4) {
-    const int i = 16 * nt + n;  // the lane's node of the segment (column n of the products)
-    const bool inode = i <= P;
-    mpx_d4 aX[NX], aDU[NU > 0 ? NU : 1], aCU[NU > 0 ? NU : 1];
+  // The wavefront's column tiles nt = wave, wave + 4, ... (NTW of them): K outermost, so that one LDS read of the A operands serves all
+  // of them and the table loads of 4 K-steps x NTW tiles are in flight together (with the tiles outermost every K-step of every tile
+  // was its own round trip to L2: 91 us for nlp_g at 50 x 100, B = 512; now the chain is KS / 4 round trips per wavefront).
+  constexpr int NTW = (NTN + 3) / 4;
+  mpx_d4 aX[NTW][NX], aDU[NTW][NU > 0 ? NU : 1], aCU[NTW][NU > 0 ? NU : 1];
 #pragma unroll
-    for (int a = 0; a < NX; ++a) aX[a] = mpx_d4{0, 0, 0, 0};
+  for (int tw = 0; tw < NTW; ++tw) {
 #pragma unroll
-    for (int c = 0; c < (NU > 0 ? NU : 1); ++c) aDU[c] = mpx_d4{0, 0, 0, 0}, aCU[c] = mpx_d4{0, 0, 0, 0};
-    if (want_g) {
+    for (int a = 0; a < NX; ++a) aX[tw][a] = mpx_d4{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < (NU > 0 ? NU : 1); ++c) aDU[tw][c] = mpx_d4{0, 0, 0, 0}, aCU[tw][c] = mpx_d4{0, 0, 0, 0};
+  }
+  if (want_g) {
 #pragma unroll 4
-      for (int ks = 0; ks < KS; ++ks) {
-        const int kk = 4 * ks + q;
-        const bool in = inode && kk <= P;
-        const double bD = in ? DT[(in ? kk : 0) * P1 + (in ? i : 0)] : 0.0;
-        double bC = 0.0;
-        if constexpr (G::MIDU) bC = (in && i >= 1) ? CT[(in ? kk : 0) * P + ((in && i >= 1) ? i - 1 : 0)] : 0.0;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kk = 4 * ks + q;
+      double bD[NTW], bC[NTW];
 #pragma unroll
-        for (int a = 0; a < NX; ++a) aX[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(sT[(a * KP + kk) * LDB + n], bD, aX[a], 0, 0, 0);
+      for (int tw = 0; tw < NTW; ++tw) {
+        const int i = 16 * (wave + 4 * tw) + n;
+        const bool in = i <= P && kk <= P;
+        bD[tw] = in ? DT[(in ? kk : 0) * P1 + (in ? i : 0)] : 0.0;
+        bC[tw] = 0.0;
+        if constexpr (G::MIDU) bC[tw] = (in && i >= 1) ? CT[(in ? kk : 0) * P + ((in && i >= 1) ? i - 1 : 0)] : 0.0;
+      }
+      double xa[NX], ua[NU > 0 ? NU : 1];
 #pragma unroll
-        for (int c = 0; c < NU; ++c) {
-          const double uop = sT[((NX + c) * KP + kk) * LDB + n];
-          if constexpr (G::DIFF_U) aDU[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(uop, bD, aDU[c], 0, 0, 0);
-          if constexpr (G::MIDU) aCU[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(uop, bC, aCU[c], 0, 0, 0);
+      for (int a = 0; a < NX; ++a) xa[a] = sT[(a * KP + kk) * LDB + n];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) ua[c] = sT[((NX + c) * KP + kk) * LDB + n];
+#pragma unroll
+      for (int tw = 0; tw < NTW; ++tw) {
+        if (wave + 4 * tw < NTN) {  // (uniform)
+#pragma unroll
+          for (int a = 0; a < NX; ++a) aX[tw][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[a], bD[tw], aX[tw][a], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < NU; ++c) {
+            if constexpr (G::DIFF_U) aDU[tw][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[c], bD[tw], aDU[tw][c], 0, 0, 0);
+            if constexpr (G::MIDU) aCU[tw][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[c], bC[tw], aCU[tw][c], 0, 0, 0);
+          }
         }
       }
     }
+  }
+#pragma unroll
+  for (int tw = 0; tw < NTW; ++tw) {
+    const int nt = wave + 4 * tw;
+    if (nt >= NTN) continue;
+    const int i = 16 * nt + n;  // the lane's node of the segment (column n of the products)
+    const bool inode = i <= P;
     // (2) node functions in place: node i of evaluation points q, q + 4, q + 8, q + 12
     const bool vnode = inode && (i >= 1 || s == 0);  // (point 0 of a segment belongs to the previous one -- except node 0 of the phase)
     const int ic = inode ? i : P;
@@ -1840,17 +1864,17 @@ __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
         if (want_g) {
           double* __restrict__ gb = io.g + (int64_t)(b0 + b) * io.g_stride;
 #pragma unroll
-          for (int a = 0; a < NX; ++a) gb[A.g_off_F + (int64_t)a * N + node] = aX[a][r] - fx[a];
+          for (int a = 0; a < NX; ++a) gb[A.g_off_F + (int64_t)a * N + node] = aX[tw][a][r] - fx[a];
 #pragma unroll
           for (int j = 0; j < NC; ++j) gb[A.g_off_C + (int64_t)j * N + node] = cc[j];
           if constexpr (G::DIFF_U) {
 #pragma unroll
-            for (int c = 0; c < NU; ++c) gb[A.g_off_DU + (int64_t)c * N + node] = aDU[c][r];
+            for (int c = 0; c < NU; ++c) gb[A.g_off_DU + (int64_t)c * N + node] = aDU[tw][c][r];
           }
           if constexpr (G::MIDU) {
             if (i >= 1) {
 #pragma unroll
-              for (int c = 0; c < NU; ++c) gb[A.g_off_mU + (int64_t)c * (N - 1) + (node - 1)] = aCU[c][r];
+              for (int c = 0; c < NU; ++c) gb[A.g_off_mU + (int64_t)c * (N - 1) + (node - 1)] = aCU[tw][c][r];
             }
           }
         }
