@@ -1722,6 +1722,9 @@ __device__ __forceinline__ void light_low_all(const MpxLightMultiArgs& M) {
 // added in another fixed order (lane: its nodes in order; 16-lane row by DPP; wavefronts in order; one partial-sum slot per
 // segment, the boundary pass adds the segments in order).
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef MPX_LH_UNROLL
+#define MPX_LH_UNROLL 4  // K-steps whose table loads are requested together
+#endif
 template <int PH, int P, int MODE>
 __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
   using G = mpxgen::Phase<PH>;
@@ -1796,7 +1799,7 @@ __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
     for (int c = 0; c < (NU > 0 ? NU : 1); ++c) aDU[tw][c] = mpx_d4{0, 0, 0, 0}, aCU[tw][c] = mpx_d4{0, 0, 0, 0};
   }
   if (want_g) {
-#pragma unroll 4
+#pragma unroll MPX_LH_UNROLL
     for (int ks = 0; ks < KS; ++ks) {
       const int kk = 4 * ks + q;
       double bD[NTW], bC[NTW];
@@ -1815,7 +1818,11 @@ __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
       for (int c = 0; c < NU; ++c) ua[c] = sT[((NX + c) * KP + kk) * LDB + n];
 #pragma unroll
       for (int tw = 0; tw < NTW; ++tw) {
+#ifdef MPX_ABL_LH_NO_MFMA  // ablation (wrong results): no matrix instructions
+        if (false) {
+#else
         if (wave + 4 * tw < NTN) {  // (uniform)
+#endif
 #pragma unroll
           for (int a = 0; a < NX; ++a) aX[tw][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[a], bD[tw], aX[tw][a], 0, 0, 0);
 #pragma unroll
@@ -1861,7 +1868,11 @@ __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
       if (valid) {
 #pragma unroll
         for (int k = 0; k < NRED; ++k) racc[r][k] += gr[k];
+#ifdef MPX_ABL_LH_NO_STORE  // ablation: the rows of g are not stored (unless a value is an impossible one: the arithmetic stays)
+        if (want_g && aX[tw][0][r] == 1.2345e300) {
+#else
         if (want_g) {
+#endif
           double* __restrict__ gb = io.g + (int64_t)(b0 + b) * io.g_stride;
 #pragma unroll
           for (int a = 0; a < NX; ++a) gb[A.g_off_F + (int64_t)a * N + node] = aX[tw][a][r] - fx[a];
