@@ -9,11 +9,12 @@ LABEL = {"headline": "headline: config 2 f+g+grad_f+jac_g", "c2_hess": "config 2
          "c4_fgj": "config 4 f+g+grad_f+jac_g (all phases in one launch)", "c4_hess": "config 4 hess_l", "c5_fgj": "config 5 f+g+grad_f+jac_g", "c5_hess": "config 5 hess_l",
          "adaptive_fgj": "mpopt_adaptive 20x5 f+g+grad_f+jac_g", "adaptive_hess": "mpopt_adaptive 20x5 hess_l",
          "deg100_fgj": "moon lander 50 x degree 100, f+g+grad_f+jac_g (B=512; streamed tables)", "deg255_fgj": "moon lander 20 x degree 255, f+g+grad_f+jac_g (B=512; streamed tables)",
-         "deg100_light_g": "moon lander 50 x degree 100, nlp_g alone (B=512; node kernel in f / g mode)"}
+         "deg100_light_g": "moon lander 50 x degree 100, nlp_g alone (B=512; matrix cores, evaluation points as a matrix dimension -- bound by the FP64 matrix pipes, not HBM)",
+         "deg255_light_g": "moon lander 20 x degree 255, nlp_g alone (B=512; the same)", "deg100_light_f_grad_f": "moon lander 50 x degree 100, nlp_f + nlp_grad_f alone (B=512)"}
 for c in "2345":
     for sel, nm in (("f", "nlp_f"), ("g", "nlp_g"), ("f_grad_f", "nlp_f + nlp_grad_f")):
         LABEL[f"c{c}_light_{sel}"] = f"config {c} {nm} alone" + (" (B=512)" if c == "3" else "")
-for d in ["headline", "c2_hess", "c5_fgj", "c5_hess", "c4_fgj", "c4_hess", "c3_fgj", "c3_hess", "adaptive_fgj", "adaptive_hess", "deg100_fgj", "deg255_fgj", "deg100_light_g"] + [f"c{c}_light_{s}" for c in "2345" for s in ("f", "g", "f_grad_f")]:
+for d in ["headline", "c2_hess", "c5_fgj", "c5_hess", "c4_fgj", "c4_hess", "c3_fgj", "c3_hess", "adaptive_fgj", "adaptive_hess", "deg100_fgj", "deg255_fgj", "deg100_light_g", "deg255_light_g", "deg100_light_f_grad_f"] + [f"c{c}_light_{s}" for c in "2345" for s in ("f", "g", "f_grad_f")]:
     if not os.path.exists(R + d + "/traffic.json"):
         continue
     t = json.load(open(R + d + "/traffic.json")); b = json.load(open(R + d + "/bench_line.json")); r = b["roofline"]
