@@ -1750,16 +1750,17 @@ __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
       constexpr int STEPS = (KP + 31) / 32;
       d2u v[STEPS];
 #pragma unroll
+      // (UNCONDITIONAL loads at clamped addresses, the padding selected afterwards: a guarded load is its own basic block, and the
+      // compiler waits for a block's loads before the next block's -- the tile arrived one round trip per step instead of one in all)
       for (int u = 0; u < STEPS; ++u) {
-        const int k = 32 * u + 2 * kc;
-        const double* __restrict__ src = zb + (int64_t)a * N + k;
-        if (k + 1 <= P) v[u] = *(const d2u*)src;
-        else v[u] = d2u{k <= P ? src[0] : 0.0, 0.0};
+        const int k = 32 * u + 2 * kc, kl = k < P ? k : P - 1;  // (k is even; the pair kl, kl + 1 lies inside the segment)
+        v[u] = *(const d2u*)(zb + (int64_t)a * N + kl);
       }
 #pragma unroll
       for (int u = 0; u < STEPS; ++u) {
         const int k = 32 * u + 2 * kc;
-        if (k < KP) sT[(a * KP + k) * LDB + b] = v[u].x, sT[(a * KP + k + 1) * LDB + b] = v[u].y;
+        const double x0 = k < P ? v[u].x : (k == P ? v[u].y : 0.0), x1 = k + 1 <= P ? v[u].y : 0.0;
+        if (k < KP) sT[(a * KP + k) * LDB + b] = x0, sT[(a * KP + k + 1) * LDB + b] = x1;
       }
     }
   }
@@ -1805,11 +1806,12 @@ __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
       double bD[NTW], bC[NTW];
 #pragma unroll
       for (int tw = 0; tw < NTW; ++tw) {
-        const int i = 16 * (wave + 4 * tw) + n;
-        const bool in = i <= P && kk <= P;
-        bD[tw] = in ? DT[(in ? kk : 0) * P1 + (in ? i : 0)] : 0.0;
+        // (unconditional, clamped: rows k > P of the A tile are zero, so what multiplies them is irrelevant; columns i > P -- and the
+        // mid-point column of point 0 -- are never stored)
+        const int i = 16 * (wave + 4 * tw) + n, il = i <= P ? i : P, kl = kk <= P ? kk : P;
+        bD[tw] = DT[kl * P1 + il];
         bC[tw] = 0.0;
-        if constexpr (G::MIDU) bC[tw] = (in && i >= 1) ? CT[(in ? kk : 0) * P + ((in && i >= 1) ? i - 1 : 0)] : 0.0;
+        if constexpr (G::MIDU) bC[tw] = CT[kl * P + (il >= 1 ? il - 1 : 0)];
       }
       double xa[NX], ua[NU > 0 ? NU : 1];
 #pragma unroll
