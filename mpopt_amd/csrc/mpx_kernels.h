@@ -1799,13 +1799,17 @@ __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
 #pragma unroll
     for (int c = 0; c < (NU > 0 ? NU : 1); ++c) aDU[tw][c] = mpx_d4{0, 0, 0, 0}, aCU[tw][c] = mpx_d4{0, 0, 0, 0};
   }
-  if (want_g) {
+  // (the number of the wavefront's tiles as a compile-time fact of the loop -- only the last one depends on the wavefront: a uniform
+  // branch INSIDE the K loop put the accumulators through phi nodes, and the compiler moved them between the accumulation and the
+  // vector registers every K-step, waiting for the matrix pipe to drain each time)
+  auto kloop = [&](auto nta_c) {
+    constexpr int NTA = decltype(nta_c)::value;
 #pragma unroll MPX_LH_UNROLL
     for (int ks = 0; ks < KS; ++ks) {
       const int kk = 4 * ks + q;
-      double bD[NTW], bC[NTW];
+      double bD[NTA > 0 ? NTA : 1], bC[NTA > 0 ? NTA : 1];
 #pragma unroll
-      for (int tw = 0; tw < NTW; ++tw) {
+      for (int tw = 0; tw < NTA; ++tw) {
         // (unconditional, clamped: rows k > P of the A tile are zero, so what multiplies them is irrelevant; columns i > P -- and the
         // mid-point column of point 0 -- are never stored)
         const int i = 16 * (wave + 4 * tw) + n, il = i <= P ? i : P, kl = kk <= P ? kk : P;
@@ -1818,23 +1822,23 @@ __device__ __forceinline__ void light_high_body(const MpxLightArgs& L) {
       for (int a = 0; a < NX; ++a) xa[a] = sT[(a * KP + kk) * LDB + n];
 #pragma unroll
       for (int c = 0; c < NU; ++c) ua[c] = sT[((NX + c) * KP + kk) * LDB + n];
+#ifndef MPX_ABL_LH_NO_MFMA  // ablation (wrong results): no matrix instructions
 #pragma unroll
-      for (int tw = 0; tw < NTW; ++tw) {
-#ifdef MPX_ABL_LH_NO_MFMA  // ablation (wrong results): no matrix instructions
-        if (false) {
-#else
-        if (wave + 4 * tw < NTN) {  // (uniform)
-#endif
+      for (int tw = 0; tw < NTA; ++tw) {
 #pragma unroll
-          for (int a = 0; a < NX; ++a) aX[tw][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[a], bD[tw], aX[tw][a], 0, 0, 0);
+        for (int a = 0; a < NX; ++a) aX[tw][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[a], bD[tw], aX[tw][a], 0, 0, 0);
 #pragma unroll
-          for (int c = 0; c < NU; ++c) {
-            if constexpr (G::DIFF_U) aDU[tw][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[c], bD[tw], aDU[tw][c], 0, 0, 0);
-            if constexpr (G::MIDU) aCU[tw][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[c], bC[tw], aCU[tw][c], 0, 0, 0);
-          }
+        for (int c = 0; c < NU; ++c) {
+          if constexpr (G::DIFF_U) aDU[tw][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[c], bD[tw], aDU[tw][c], 0, 0, 0);
+          if constexpr (G::MIDU) aCU[tw][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[c], bC[tw], aCU[tw][c], 0, 0, 0);
         }
       }
+#endif
     }
+  };
+  if (want_g) {
+    if (wave + 4 * (NTW - 1) < NTN) kloop(std::integral_constant<int, NTW>{});
+    else kloop(std::integral_constant<int, NTW - 1>{});
   }
 #pragma unroll
   for (int tw = 0; tw < NTW; ++tw) {
