@@ -271,6 +271,11 @@ const char* mpx_get_notes(const mpx_ctx* ctx);
  * the grid has none, else the high degree (n_groups = groups of <= 16 high-degree segments, n_low_degree_nodes = nodes evaluated by
  * lanes) or the single low degree (n_groups = spans per phase, max_span_nodes = LDS row length, n_low_degree_nodes = 0); structure
  * only: works without a device.  MPX_NO_LIGHT=1 (environment, read per call) switches the light kernels off. */
+/* Round 6: single-degree grids of degree 32 ... 255 have a third family, mpx_lighthigh_*: a workgroup = (segment, 16 evaluation points),
+ * the contraction a matrix product with the evaluation points as one dimension (the transposed tables as operands from L2); the
+ * query then reports degree = the grid's degree, n_groups = segments per phase, max_span_nodes = the padded K length.  Polynomial
+ * degrees: every degree 1 ... 255 is accepted (round 6; degrees above MPX_TABLES_STREAM_ABOVE = 68 stream their tables instead of
+ * keeping them in LDS -- up to round 5 mpx_create refused degrees >= 94). */
 int mpx_get_light_plan(const mpx_ctx* ctx, int32_t* degree, int64_t* n_groups, int64_t* max_span_nodes, int64_t* n_low_degree_nodes);
 
 /* Device buffer holding the per-tile partial sums of the last mpx_eval_device call
