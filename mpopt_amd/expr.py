@@ -615,7 +615,8 @@ _Math.atan2 = staticmethod(_Math._binary("atan2", np.arctan2, "atan2"))
 _Math.fmax = staticmethod(_Math._binary("fmax", np.maximum, "Max"))
 _Math.fmin = staticmethod(_Math._binary("fmin", np.minimum, "Min"))
 _Math.norm_2 = staticmethod(lambda xs: _Math.sqrt(_Math.sumsqr(xs)))
-_Math.arcsin, _Math.arccos, _Math.arctan, _Math.arctan2 = _Math.asin, _Math.acos, _Math.atan, _Math.atan2
+# (numpy spellings; `_Math.asin` read through the class is the bare function: wrap again, or an instance would bind it as a method)
+_Math.arcsin, _Math.arccos, _Math.arctan, _Math.arctan2 = (staticmethod(f) for f in (_Math.asin, _Math.acos, _Math.atan, _Math.atan2))
 _Math.power = staticmethod(lambda a, b: a ** b)
 
 

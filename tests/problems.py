@@ -432,3 +432,147 @@ def staged_ascent(mp, fn):
     ocp.scale_x = np.array([1.0, 1.0, 1.0, 2.0, 2.0, 2.0, 1.5])
     ocp.validate()
     return ocp
+
+
+# ---- random OCPs (round 6): the user callables themselves drawn at random -----------------------------------------------------------
+# Every other problem here is hand-written; the product's tracer, symbolic differentiation and code generator (mpopt_amd/expr.py,
+# codegen.py) take the place of CasADi's SX graph + AD behind `ca.nlpsol` (mpopt.py:757), and the numpy / sympy oracle differentiates the
+# same callables by another route (sympy).  A seed draws: phases, states, controls, parameters, every optional row block, the scalings,
+# the callables as random expression trees over (x, u, t, a) / (xf, tf, x0, t0, a), and a grid.
+RANDOM_OCP_SEEDS = [int(x) for x in os.environ["MPX_RANDOM_OCP_SEEDS"].split(",")] if os.environ.get("MPX_RANDOM_OCP_SEEDS") else list(range(1, 13))
+
+
+def _random_tree(rng, leaves, depth):
+    """A random expression tree (nested tuples) over `leaves`; every operation is smooth and bounded-ish on bounded arguments."""
+    if depth == 0 or rng.random() < 0.15:
+        if rng.random() < 0.2:
+            return ("const", float(np.round(rng.uniform(-2, 2), 3)))
+        return ("leaf", leaves[int(rng.integers(len(leaves)))])
+    op = ["add", "sub", "mul", "mul", "div1", "sin", "cos", "exp", "sqrt1", "tanh", "log2", "pow2", "pow3", "atan", "powf", "scale"][int(rng.integers(16))]
+    if op in ("add", "sub", "mul", "div1"):
+        return (op, _random_tree(rng, leaves, depth - 1), _random_tree(rng, leaves, depth - 1))
+    if op == "scale":
+        return (op, float(np.round(rng.uniform(-1.5, 1.5), 3)), _random_tree(rng, leaves, depth - 1))
+    return (op, _random_tree(rng, leaves, depth - 1))
+
+
+def _eval_tree(tr, env, fn):
+    op = tr[0]
+    if op == "const":
+        return tr[1]
+    if op == "leaf":
+        return env[tr[1]]
+    if op == "scale":
+        return tr[1] * _eval_tree(tr[2], env, fn)
+    a = _eval_tree(tr[1], env, fn)
+    if op in ("add", "sub", "mul", "div1"):
+        b = _eval_tree(tr[2], env, fn)
+        return a + b if op == "add" else a - b if op == "sub" else a * b if op == "mul" else a / (1.5 + b * b)
+    if op == "sin":
+        return fn.sin(a)
+    if op == "cos":
+        return fn.cos(a)
+    if op == "exp":
+        return fn.exp(0.2 * a)
+    if op == "sqrt1":
+        return fn.sqrt(1.0 + a * a)
+    if op == "tanh":
+        return fn.tanh(a)
+    if op == "log2":
+        return fn.log(2.0 + a * a)
+    if op == "pow2":
+        return a * a
+    if op == "pow3":
+        return a ** 3
+    if op == "atan":
+        return fn.arctan(a)
+    if op == "powf":
+        return (1.5 + a * a) ** 0.7
+    raise ValueError(op)
+
+
+def random_ocp_case(seed):
+    """(builder, n_segments, poly_orders, scheme) of the random OCP of `seed`."""
+    g = np.random.default_rng(1000 + seed)
+    nph, nx, nu, na = int(g.integers(1, 3)), int(g.integers(1, 5)), int(g.integers(1, 3)), int(g.integers(0, 3))
+    timed = bool(g.random() < 0.6)
+    node_leaves = [("x", i) for i in range(nx)] + [("u", i) for i in range(nu)] + [("a", i) for i in range(na)] + ([("t", 0)] * 2 if timed else [])
+    term_leaves = [("xf", i) for i in range(nx)] + [("x0", i) for i in range(nx)] + [("tf", 0), ("t0", 0)] + [("a", i) for i in range(na)]
+    spec = []
+    for ph in range(nph):
+        spec.append(dict(
+            dyn=[_random_tree(g, node_leaves, int(g.integers(1, 4))) for _ in range(nx)],
+            path=[_random_tree(g, node_leaves, int(g.integers(1, 3))) for _ in range(int(g.integers(0, 3)))],
+            run=_random_tree(g, node_leaves, int(g.integers(1, 4))),
+            tcost=_random_tree(g, term_leaves, int(g.integers(0, 3))),
+            tcon=[_random_tree(g, term_leaves, int(g.integers(1, 3))) for _ in range(int(g.integers(0, 3)))],
+        ))
+    sx, su, sa, st = g.choice([0.5, 1.0, 2.0, 1.25], nx), g.choice([0.25, 1.0, 4.0], nu), g.choice([0.5, 1.0, 2.0], max(na, 1))[:na], float(g.choice([0.1, 1.0, 2.0]))
+    guess = dict(x00=g.uniform(-1, 1, (nph, nx)), xf0=g.uniform(-1, 1, (nph, nx)), u00=g.uniform(-1, 1, (nph, nu)), uf0=g.uniform(-1, 1, (nph, nu)),
+                 a0=g.uniform(-1, 1, (nph, max(na, 1)))[:, :na], t=np.cumsum(g.uniform(0.5, 2.0, nph + 1)))
+    flags = dict(diff_u=g.integers(0, 2, nph), du_cont=g.integers(0, 2, nph), midu=g.integers(0, 2, nph), ubu_inf=g.random(nph) < 0.3)
+    S = int(g.integers(1, 7))
+    degs = g.choice([2, 3, 4, 5, 7, 9, 13, 16, 21], size=int(g.integers(1, 4)), replace=False)
+    po = [int(x) for x in g.choice(degs, size=S)]
+    scheme = ["LGR", "LGL", "CGL"][int(g.integers(3))]
+
+    def builder(mp, fn):
+        ocp = mp.OCP(n_states=nx, n_controls=nu, n_phases=nph, n_params=na)
+
+        def node_env(x, u, t, a):
+            env = {("x", i): x[i] for i in range(nx)}
+            env.update({("u", i): u[i] for i in range(nu)})
+            env.update({("a", i): a[i] for i in range(na)})
+            env[("t", 0)] = t
+            return env
+
+        def term_env(xf, tf, x0, t0, a):
+            env = {("xf", i): xf[i] for i in range(nx)}
+            env.update({("x0", i): x0[i] for i in range(nx)})
+            env.update({("a", i): a[i] for i in range(na)})
+            env[("tf", 0)], env[("t0", 0)] = tf, t0
+            return env
+
+        def node_fn(trees, scalar=False):
+            if na:
+                f = lambda x, u, t, a: [_eval_tree(tr, node_env(x, u, t, a), fn) for tr in trees]
+                return (lambda x, u, t, a: f(x, u, t, a)[0]) if scalar else f
+            f = lambda x, u, t: [_eval_tree(tr, node_env(x, u, t, None), fn) for tr in trees]
+            return (lambda x, u, t: f(x, u, t)[0]) if scalar else f
+
+        def term_fn(trees, scalar=False):
+            if na:
+                f = lambda xf, tf, x0, t0, a: [_eval_tree(tr, term_env(xf, tf, x0, t0, a), fn) for tr in trees]
+                return (lambda xf, tf, x0, t0, a: f(xf, tf, x0, t0, a)[0]) if scalar else f
+            f = lambda xf, tf, x0, t0: [_eval_tree(tr, term_env(xf, tf, x0, t0, None), fn) for tr in trees]
+            return (lambda xf, tf, x0, t0: f(xf, tf, x0, t0)[0]) if scalar else f
+
+        for ph in range(nph):
+            sp_ = spec[ph]
+            ocp.dynamics[ph] = node_fn(sp_["dyn"])
+            if sp_["path"]:
+                ocp.path_constraints[ph] = node_fn(sp_["path"])
+            ocp.running_costs[ph] = node_fn([sp_["run"]], scalar=True)
+            ocp.terminal_costs[ph] = term_fn([sp_["tcost"]], scalar=True)
+            if sp_["tcon"]:
+                ocp.terminal_constraints[ph] = term_fn(sp_["tcon"])
+            ocp.x00[ph], ocp.xf0[ph] = guess["x00"][ph].tolist(), guess["xf0"][ph].tolist()
+            ocp.u00[ph], ocp.uf0[ph] = guess["u00"][ph].tolist(), guess["uf0"][ph].tolist()
+            if na:
+                ocp.a0[ph] = guess["a0"][ph].tolist()
+                ocp.lba[ph], ocp.uba[ph] = [-2.0] * na, [2.0] * na
+            ocp.t00[ph], ocp.tf0[ph] = float(guess["t"][ph]), float(guess["t"][ph + 1])
+            ocp.lbx[ph], ocp.ubx[ph] = [-3.0] * nx, [3.0] * nx
+            ocp.lbu[ph] = [-2.0] * nu
+            ocp.ubu[ph] = [np.inf if flags["ubu_inf"][ph] else 2.0] * nu
+            ocp.lbtf[ph], ocp.ubtf[ph] = float(guess["t"][ph + 1]) - 0.4, float(guess["t"][ph + 1]) + 0.4
+            if ph:
+                ocp.lbt0[ph], ocp.ubt0[ph] = float(guess["t"][ph]) - 0.4, float(guess["t"][ph]) + 0.4
+            ocp.diff_u[ph], ocp.du_continuity[ph], ocp.midu[ph] = int(flags["diff_u"][ph]), int(flags["du_cont"][ph]), int(flags["midu"][ph])
+        ocp.scale_x, ocp.scale_u, ocp.scale_t = np.array(sx, float), np.array(su, float), st
+        if na:
+            ocp.scale_a = np.array(sa, float)
+        ocp.validate()
+        return ocp
+
+    return builder, S, po, scheme

@@ -496,3 +496,49 @@ def test_jac_variable_mask_marks_only_constants_as_constant(name):
     assert np.array_equal(vals[0][const], vals[1][const]) and const.sum() > 0.4 * o.nnz_jac
     assert (vals[0][~const] != vals[1][~const]).mean() > 0.5  # (the variable set is a superset: structurally zero diagonals included)
     o.close()
+
+
+def test_math_namespace_numpy_spellings_on_the_instance():
+    """`M.math.arctan(x)` ... : the numpy spellings are static on the namespace INSTANCE as well (found by the random OCPs: the aliases
+    had been assigned from the class attribute, i.e. as plain functions, and an instance bound them as methods)."""
+    import sympy as sp
+
+    m, tr = M.math, Tracer()
+    x = tr.var("x")
+    X = sp.Symbol("x")
+    for name, spf, v in (("arcsin", sp.asin, 0.3), ("arccos", sp.acos, 0.3), ("arctan", sp.atan, 0.3), ("asin", sp.asin, 0.3), ("atan", sp.atan, 0.3)):
+        f = getattr(m, name)
+        assert f(v) == pytest.approx(float(spf(v)), rel=1e-15)
+        assert tr.evaluate([f(x)], {"x": v})[0] == pytest.approx(float(spf(v)), rel=1e-15)
+        assert tr.evaluate([tr.diff(f(x), x)], {"x": v})[0] == pytest.approx(float(sp.diff(spf(X), X).subs(X, v)), rel=1e-14)
+        assert f(X) == spf(X)
+    assert m.arctan2(1.0, 2.0) == m.atan2(1.0, 2.0) == pytest.approx(np.arctan2(1.0, 2.0))
+    assert tr.evaluate([m.arctan2(x, 2.0)], {"x": 1.0})[0] == pytest.approx(np.arctan2(1.0, 2.0))
+
+
+@pytest.mark.parametrize("seed", problems.RANDOM_OCP_SEEDS)
+def test_random_ocps_host_side(seed):
+    """tests/problems.py random_ocp_case without a device: sizes, bounds, initial guess equal to the oracle's, and the structural
+    patterns (the tracer's structural derivatives) hold every non-zero of the oracle's dense jac_g / hess_l (sympy's derivatives)."""
+    from oracle.mpopt_oracle import OracleNLP
+
+    builder, S, po, scheme = problems.random_ocp_case(seed)
+    ocp = builder(mp, M.math)
+    o = M.NlpFunctions(ocp, S, po, scheme, with_device=False)
+    O = OracleNLP(ocp, S, po, scheme)
+    assert (o.n_z, o.n_g) == (O.n_z, O.n_g)
+    rng = np.random.default_rng(seed)
+    z = O.initial_guess() + 0.1 * rng.uniform(-1, 1, O.n_z)
+    w = rng.uniform(0.3, 1.7, (ocp.n_phases, S))
+    p = (w / w.sum(axis=1, keepdims=True)).ravel()
+    jr, jc = o.jac_pattern()
+    hr, hc = o.hess_pattern()
+    assert len(set(zip(jr.tolist(), jc.tolist()))) == len(jr) and len(set(zip(hr.tolist(), hc.tolist()))) == len(hr) and np.all(hr <= hc)
+    mask = np.zeros((o.n_g, o.n_z), bool)
+    mask[jr, jc] = True
+    Jd = O.jac_g(z, p)
+    assert not np.any((np.asarray(Jd.todense() if hasattr(Jd, 'todense') else Jd) != 0) & ~mask)
+    mask = np.zeros((o.n_z, o.n_z), bool)
+    mask[hr, hc] = True
+    assert not np.any((np.triu(O.hess_l(z, p, 0.7, rng.standard_normal(O.n_g))) != 0) & ~mask)
+    o.close()
