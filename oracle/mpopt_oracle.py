@@ -298,6 +298,22 @@ class Grid:
 # ---------------------------------------------------------------------------------------------
 # Transcription (mpopt.py:105-639)
 # ---------------------------------------------------------------------------------------------
+def _almost_everywhere(e):
+    """Derivatives of the piecewise functions (Abs, sign, Max, Min) as AD takes them -- away from the kinks: sympy's delta terms
+    (DiracDelta, unevaluated d sign / d Heaviside) are zero almost everywhere, and CasADi's AD never forms them (d|x| = sign x,
+    d sign = 0, d fmax = the active argument's).  Nested lists of expressions in, the same shape out."""
+    import sympy as sy
+
+    if isinstance(e, (list, tuple)):
+        return [_almost_everywhere(v) for v in e]
+    e = sy.sympify(e)
+    if not e.has(sy.DiracDelta, sy.Derivative, sy.Subs):
+        return e
+    e = e.replace(lambda x: isinstance(x, sy.Subs) and isinstance(x.expr, sy.Derivative) and x.expr.expr.func in (sy.sign, sy.Heaviside), lambda x: sy.S.Zero)
+    e = e.replace(lambda x: isinstance(x, sy.Derivative) and x.expr.func in (sy.sign, sy.Heaviside), lambda x: sy.S.Zero)
+    return e.replace(lambda x: isinstance(x, sy.DiracDelta), lambda x: sy.S.Zero)
+
+
 class OracleNLP:
     """f, g and derivatives of the NLP that ``mpopt.create_nlp`` builds, evaluated on the CPU."""
 
@@ -561,7 +577,7 @@ class OracleNLP:
             M = sy.sympify(o.get_terminal_costs(ph)(xf, tf, x0, t0, a_))
             TC = [sy.sympify(e) for e in o.get_terminal_constraints(ph)(xf, tf, x0, t0, a_)] if self.has_tc[ph] else []
             tvars = list(XF) + [tfv] + list(XI) + [t0v] + list(A)
-            L = lambda exprs, ar: sy.lambdify(ar, exprs, "numpy")
+            L = lambda exprs, ar: sy.lambdify(ar, _almost_everywhere(exprs), "numpy")
             d = dict(nc=len(c), ntc=len(TC), v=v, tvars=tvars,
                      vals=L(fx + c + [q], args),
                      jac=L([[sy.diff(e, s) for s in v] for e in fx + c + [q]], args),

@@ -177,9 +177,39 @@ class SD:
         t = math.tanh(self.v)
         return self._unary(t, 1.0 - t * t, -2.0 * t * (1.0 - t * t))
 
-    _UFUNCS = {"sqrt": "sqrt", "exp": "exp", "log": "log", "sin": "sin", "cos": "cos", "tan": "tan", "arcsin": "arcsin", "arccos": "arccos",
+    # piecewise functions, as AD takes them away from the kinks (ties: the first argument, as mpopt_amd/expr.py and CasADi's fmax / fmin at a
+    # generic point): d|x| = sign x, d sign = 0, d max = the active argument's
+    def absolute(self):
+        return self._unary(abs(self.v), math.copysign(1.0, self.v) if self.v != 0.0 else 0.0, 0.0)
+
+    def sign(self):
+        return SD(math.copysign(1.0, self.v) if self.v != 0.0 else 0.0)
+
+    def maximum(self, o):
+        return self if self.v >= value(o) else o
+
+    def minimum(self, o):
+        return self if self.v <= value(o) else o
+
+    def _rmaximum(self, o):  # max(o, self), o a plain number
+        return o if float(o) >= self.v else self
+
+    def _rminimum(self, o):
+        return o if float(o) <= self.v else self
+
+    def arctan2(self, x):
+        """atan2(self, x), x != 0: the derivatives of atan(self / x), the value on the right branch."""
+        r = (self / x).arctan()
+        return SD(math.atan2(self.v, value(x)), r.g, r.h)
+
+    def _rarctan2(self, y):
+        r = (float(y) / self).arctan()
+        return SD(math.atan2(float(y), self.v), r.g, r.h)
+
+    _UFUNCS = {"absolute": "absolute", "fabs": "absolute", "sign": "sign", "sqrt": "sqrt", "exp": "exp", "log": "log", "sin": "sin", "cos": "cos", "tan": "tan", "arcsin": "arcsin", "arccos": "arccos",
                "arctan": "arctan", "sinh": "sinh", "cosh": "cosh", "tanh": "tanh", "negative": "__neg__", "reciprocal": "reciprocal"}
-    _BINARY = {"add": "__add__", "subtract": "__sub__", "multiply": "__mul__", "true_divide": "__truediv__", "divide": "__truediv__", "power": "__pow__"}
+    _BINARY = {"add": "__add__", "subtract": "__sub__", "multiply": "__mul__", "true_divide": "__truediv__", "divide": "__truediv__", "power": "__pow__",
+               "maximum": "maximum", "fmax": "maximum", "minimum": "minimum", "fmin": "minimum", "arctan2": "arctan2"}
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         if method != "__call__" or kwargs:
@@ -192,7 +222,7 @@ class SD:
             if isinstance(a, SD):
                 return getattr(a, SD._BINARY[name])(b)
             r = {"add": "__radd__", "subtract": "__rsub__", "multiply": "__rmul__", "true_divide": "__rtruediv__", "divide": "__rtruediv__",
-                 "power": "__rpow__"}[name]
+                 "power": "__rpow__", "maximum": "_rmaximum", "fmax": "_rmaximum", "minimum": "_rminimum", "fmin": "_rminimum", "arctan2": "_rarctan2"}[name]
             return getattr(b, r)(a)
         return NotImplemented
 

@@ -440,20 +440,30 @@ def staged_ascent(mp, fn):
 # same callables by another route (sympy).  A seed draws: phases, states, controls, parameters, every optional row block, the scalings,
 # the callables as random expression trees over (x, u, t, a) / (xf, tf, x0, t0, a), and a grid.
 RANDOM_OCP_SEEDS = [int(x) for x in os.environ["MPX_RANDOM_OCP_SEEDS"].split(",")] if os.environ.get("MPX_RANDOM_OCP_SEEDS") else list(range(1, 13))
+RANDOM_OCP_WIDE_SEEDS = [int(x) for x in os.environ["MPX_RANDOM_OCP_WIDE_SEEDS"].split(",")] if os.environ.get("MPX_RANDOM_OCP_WIDE_SEEDS") else list(range(1, 9))
+#: (seed, wide) of the random OCPs of the suite; wide = callables drawn from the whole math namespace (tan, asin, acos, sinh, cosh, atan2, fabs, fmax, fmin, sign, x ** y)
+RANDOM_OCPS = [(s, False) for s in RANDOM_OCP_SEEDS] + [(s, True) for s in RANDOM_OCP_WIDE_SEEDS]
 
 
-def _random_tree(rng, leaves, depth):
+_TREE_OPS = ["add", "sub", "mul", "mul", "div1", "sin", "cos", "exp", "sqrt1", "tanh", "log2", "pow2", "pow3", "atan", "powf", "scale"]
+# the rest of the math namespace (mpopt_amd/expr.py: _Math), arguments mapped into each function's domain; the piecewise ones
+# (fabs, fmax, fmin, sign) are differentiable at the random evaluation points with probability one
+_TREE_OPS_WIDE = _TREE_OPS + ["tan", "asin", "acos", "sinh", "cosh", "atan2", "fabs", "fmax", "fmin", "sign", "powg", "rdiv", "neg"]
+_TREE_BINARY = ("add", "sub", "mul", "div1", "atan2", "fmax", "fmin", "powg")
+
+
+def _random_tree(rng, leaves, depth, ops=_TREE_OPS):
     """A random expression tree (nested tuples) over `leaves`; every operation is smooth and bounded-ish on bounded arguments."""
     if depth == 0 or rng.random() < 0.15:
         if rng.random() < 0.2:
             return ("const", float(np.round(rng.uniform(-2, 2), 3)))
         return ("leaf", leaves[int(rng.integers(len(leaves)))])
-    op = ["add", "sub", "mul", "mul", "div1", "sin", "cos", "exp", "sqrt1", "tanh", "log2", "pow2", "pow3", "atan", "powf", "scale"][int(rng.integers(16))]
-    if op in ("add", "sub", "mul", "div1"):
-        return (op, _random_tree(rng, leaves, depth - 1), _random_tree(rng, leaves, depth - 1))
+    op = ops[int(rng.integers(len(ops)))]
+    if op in _TREE_BINARY:
+        return (op, _random_tree(rng, leaves, depth - 1, ops), _random_tree(rng, leaves, depth - 1, ops))
     if op == "scale":
-        return (op, float(np.round(rng.uniform(-1.5, 1.5), 3)), _random_tree(rng, leaves, depth - 1))
-    return (op, _random_tree(rng, leaves, depth - 1))
+        return (op, float(np.round(rng.uniform(-1.5, 1.5), 3)), _random_tree(rng, leaves, depth - 1, ops))
+    return (op, _random_tree(rng, leaves, depth - 1, ops))
 
 
 def _eval_tree(tr, env, fn):
@@ -465,9 +475,35 @@ def _eval_tree(tr, env, fn):
     if op == "scale":
         return tr[1] * _eval_tree(tr[2], env, fn)
     a = _eval_tree(tr[1], env, fn)
-    if op in ("add", "sub", "mul", "div1"):
+    if op in _TREE_BINARY:
         b = _eval_tree(tr[2], env, fn)
+        if op == "atan2":
+            return fn.atan2(a, 1.5 + b * b)
+        if op == "fmax":
+            return fn.fmax(a, b)
+        if op == "fmin":
+            return fn.fmin(a, 0.5 * b + 0.1)
+        if op == "powg":
+            return fn.power(1.5 + a * a, 0.3 * b)
         return a + b if op == "add" else a - b if op == "sub" else a * b if op == "mul" else a / (1.5 + b * b)
+    if op == "tan":
+        return fn.tan(0.4 * fn.tanh(a))
+    if op == "asin":
+        return fn.asin(0.9 * fn.tanh(a))
+    if op == "acos":
+        return fn.acos(0.9 * fn.sin(a))
+    if op == "sinh":
+        return fn.sinh(0.3 * a)
+    if op == "cosh":
+        return fn.cosh(0.3 * a)
+    if op == "fabs":
+        return fn.fabs(a - 0.05)
+    if op == "sign":
+        return fn.sign(a - 0.05) * a
+    if op == "rdiv":
+        return 1.0 / (2.0 + a * a)
+    if op == "neg":
+        return -a
     if op == "sin":
         return fn.sin(a)
     if op == "cos":
@@ -491,9 +527,10 @@ def _eval_tree(tr, env, fn):
     raise ValueError(op)
 
 
-def random_ocp_case(seed):
-    """(builder, n_segments, poly_orders, scheme) of the random OCP of `seed`."""
-    g = np.random.default_rng(1000 + seed)
+def random_ocp_case(seed, wide=False):
+    """(builder, n_segments, poly_orders, scheme) of the random OCP of `seed`; wide: the callables draw from the whole math namespace."""
+    g = np.random.default_rng((5000 if wide else 1000) + seed)
+    ops = _TREE_OPS_WIDE if wide else _TREE_OPS
     nph, nx, nu, na = int(g.integers(1, 3)), int(g.integers(1, 5)), int(g.integers(1, 3)), int(g.integers(0, 3))
     timed = bool(g.random() < 0.6)
     node_leaves = [("x", i) for i in range(nx)] + [("u", i) for i in range(nu)] + [("a", i) for i in range(na)] + ([("t", 0)] * 2 if timed else [])
@@ -501,11 +538,11 @@ def random_ocp_case(seed):
     spec = []
     for ph in range(nph):
         spec.append(dict(
-            dyn=[_random_tree(g, node_leaves, int(g.integers(1, 4))) for _ in range(nx)],
-            path=[_random_tree(g, node_leaves, int(g.integers(1, 3))) for _ in range(int(g.integers(0, 3)))],
-            run=_random_tree(g, node_leaves, int(g.integers(1, 4))),
-            tcost=_random_tree(g, term_leaves, int(g.integers(0, 3))),
-            tcon=[_random_tree(g, term_leaves, int(g.integers(1, 3))) for _ in range(int(g.integers(0, 3)))],
+            dyn=[_random_tree(g, node_leaves, int(g.integers(1, 4)), ops) for _ in range(nx)],
+            path=[_random_tree(g, node_leaves, int(g.integers(1, 3)), ops) for _ in range(int(g.integers(0, 3)))],
+            run=_random_tree(g, node_leaves, int(g.integers(1, 4)), ops),
+            tcost=_random_tree(g, term_leaves, int(g.integers(0, 3)), ops),
+            tcon=[_random_tree(g, term_leaves, int(g.integers(1, 3)), ops) for _ in range(int(g.integers(0, 3)))],
         ))
     sx, su, sa, st = g.choice([0.5, 1.0, 2.0, 1.25], nx), g.choice([0.25, 1.0, 4.0], nu), g.choice([0.5, 1.0, 2.0], max(na, 1))[:na], float(g.choice([0.1, 1.0, 2.0]))
     guess = dict(x00=g.uniform(-1, 1, (nph, nx)), xf0=g.uniform(-1, 1, (nph, nx)), u00=g.uniform(-1, 1, (nph, nu)), uf0=g.uniform(-1, 1, (nph, nu)),

@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-@pytest.mark.parametrize("seed", problems.RANDOM_OCP_SEEDS)
-def test_random_ocp_against_numpy_oracle(seed):
-    builder, S, po, scheme = problems.random_ocp_case(seed)
+@pytest.mark.parametrize("seed,wide", problems.RANDOM_OCPS, ids=[("wide" if w else "smooth") + str(s) for s, w in problems.RANDOM_OCPS])
+def test_random_ocp_against_numpy_oracle(seed, wide):
+    builder, S, po, scheme = problems.random_ocp_case(seed, wide)
     ocp = builder(mp, M.math)
     mpo = mp.mpopt(ocp, S, po, scheme)
     nlp, bounds = mpo.create_nlp()
@@ -72,14 +72,14 @@ def test_random_ocp_against_numpy_oracle(seed):
     o.close()
 
 
-@pytest.mark.parametrize("seed", problems.RANDOM_OCP_SEEDS)
-def test_random_ocp_with_widths_as_variables_against_the_exact_ad_oracle(seed):
+@pytest.mark.parametrize("seed,wide", problems.RANDOM_OCPS, ids=[("wide" if w else "smooth") + str(s) for s, w in problems.RANDOM_OCPS])
+def test_random_ocp_with_widths_as_variables_against_the_exact_ad_oracle(seed, wide):
     """The same random OCPs through mpopt_adaptive (segment widths as decision variables, reference mpopt.py:2927-2979, 3034-3136):
     the assembled contexts (mpopt_amd/assembly.py: per-point derivatives + chain rule through the widths) against the oracle's restated
     value code differentiated exactly by sparse hyper-dual arithmetic (oracle/sparse_ad.py) -- single evaluations and a batch."""
     from oracle.mpopt_oracle import OracleAdaptiveNLP
 
-    builder, S, po, scheme = problems.random_ocp_case(seed)
+    builder, S, po, scheme = problems.random_ocp_case(seed, wide)
     ocp = builder(mp, M.math)
     mpo = mp.mpopt_adaptive(ocp, S, po, scheme)
     nlp, bounds = mpo.create_nlp()

@@ -516,13 +516,13 @@ def test_math_namespace_numpy_spellings_on_the_instance():
     assert tr.evaluate([m.arctan2(x, 2.0)], {"x": 1.0})[0] == pytest.approx(np.arctan2(1.0, 2.0))
 
 
-@pytest.mark.parametrize("seed", problems.RANDOM_OCP_SEEDS)
-def test_random_ocps_host_side(seed):
+@pytest.mark.parametrize("seed,wide", problems.RANDOM_OCPS, ids=[("wide" if w else "smooth") + str(s) for s, w in problems.RANDOM_OCPS])
+def test_random_ocps_host_side(seed, wide):
     """tests/problems.py random_ocp_case without a device: sizes, bounds, initial guess equal to the oracle's, and the structural
     patterns (the tracer's structural derivatives) hold every non-zero of the oracle's dense jac_g / hess_l (sympy's derivatives)."""
     from oracle.mpopt_oracle import OracleNLP
 
-    builder, S, po, scheme = problems.random_ocp_case(seed)
+    builder, S, po, scheme = problems.random_ocp_case(seed, wide)
     ocp = builder(mp, M.math)
     o = M.NlpFunctions(ocp, S, po, scheme, with_device=False)
     O = OracleNLP(ocp, S, po, scheme)

@@ -277,3 +277,36 @@ def test_sparse_hyper_dual_numbers_against_sympy():
         assert r.g.get(i, 0.0) == pytest.approx(float(sy.diff(e, X[i]).subs(sub)), rel=1e-13, abs=1e-14)
         for j in range(i, 3):
             assert r.h.get((i, j), 0.0) == pytest.approx(float(sy.diff(e, X[i], X[j]).subs(sub)), rel=1e-12, abs=1e-13)
+
+
+def test_sparse_hyper_dual_numbers_piecewise_and_remaining_functions():
+    """The rest of the math namespace on hyper-dual numbers (tan, asin, acos, sinh, cosh, atan2, x ** y, |x|, sign, max, min): against sympy
+    for the smooth ones, against the active branch for the piecewise ones (the derivative AD takes away from the kinks)."""
+    import sympy as sy
+    from oracle.sparse_ad import SD
+
+    m = M.math
+
+    def smooth(x, y, fn):
+        return fn.tan(0.4 * x) * fn.asin(0.5 * y) + fn.acos(0.3 * x * y) + fn.sinh(x) * fn.cosh(0.5 * y) + fn.atan2(x, 1.5 + y * y) + fn.power(1.5 + x * x, 0.3 * y) + fn.atan2(2.0, y) + fn.atan2(-x, -1.0 - y * y)
+
+    p = [0.7, -1.3]
+    SD.ORDER = 2
+    r = smooth(*[SD.var(v, i) for i, v in enumerate(p)], m)
+    X = sy.symbols("x y", real=True)
+    e = smooth(*X, m)
+    sub = dict(zip(X, p))
+    assert r.v == pytest.approx(float(e.subs(sub)), rel=1e-14)
+    for i in range(2):
+        assert r.g[i] == pytest.approx(float(sy.diff(e, X[i]).subs(sub)), rel=1e-13)
+        for j in range(i, 2):
+            assert r.h[(i, j)] == pytest.approx(float(sy.diff(e, X[i], X[j]).subs(sub)), rel=1e-12)
+    # piecewise: equal to the active branch, value and derivatives
+    for xv, yv in ((0.7, -1.3), (-0.2, 0.9), (1.1, 1.4)):
+        x, y = SD.var(xv, 0), SD.var(yv, 1)
+        pw = m.fabs(x * y) + m.fmax(x * x, y) * m.fmin(x, 0.3 * y) + m.sign(x - 0.1) * y * y + m.fmax(0.25, x) + m.fmin(y, 0.5)
+        sgn = 1.0 if xv * yv > 0 else -1.0
+        br = sgn * (x * y) + (x * x if xv * xv >= yv else y) * (x if xv <= 0.3 * yv else 0.3 * y) + (1.0 if xv > 0.1 else -1.0) * y * y + (0.25 if 0.25 >= xv else x) + (y if yv <= 0.5 else 0.5)
+        assert pw.v == pytest.approx(br.v, rel=1e-15)
+        assert pw.g.keys() == br.g.keys() and all(pw.g[k] == pytest.approx(br.g[k], rel=1e-15) for k in br.g)
+        assert all(pw.h.get(k, 0.0) == pytest.approx(br.h.get(k, 0.0), rel=1e-15, abs=1e-300) for k in set(pw.h) | set(br.h))
