@@ -652,21 +652,21 @@ def main():
                 if os.path.exists(p_):
                     return p_, json.load(open(p_))
             return None, None
-        # (newest round first; every secondary workload has a PMC pass since round 5: tools/r5_evidence.sh -> profiles/r5_final/)
+        # (newest round first; every secondary workload has a PMC pass since round 5: tools/r6_evidence.sh -> profiles/r6_final/)
         cfgn = args.workload[6] if args.workload.startswith("config") else ""
-        tsrc = {"config2-fgj": (("r5_final/headline", "r4_final/headline", "r3_final/headline", "r2_headline"), 4096),
-                "config3-fgj": (("r5_final/c3_fgj", "r4_final/c3_fgj", "r3_final/c3_fgj", "r2_c3_spans"), 512),
-                "config3-hess": (("r5_final/c3_hess", "r4_final/c3_hess", "r3_final/c3_hess"), 2048),
-                "config5-hess": (("r5_final/c5_hess", "r2_config5_hess"), 4096), "config2-hess": (("r5_final/c2_hess", "r2_config2_hess"), 4096),
-                "config4-fgj": (("r5_final/c4_fgj",), 4096), "config4-hess": (("r5_final/c4_hess",), 4096), "config5-fgj": (("r5_final/c5_fgj",), 4096),
-                "adaptive-fgj": (("r5_final/adaptive_fgj", "r4_final/adaptive", "r3_final/adaptive", "r3_adaptive2"), 4096),
-                "adaptive-hess": (("r5_lanes/adaptive_hess",) if not os.environ.get("MPX_NO_LANES") else ("r5_final/adaptive_hess",), 4096),
-                "config5-loop": (("r5_final/config5_loop", "r4_final/config5_loop", "r3_final/config5_loop"), 512)}.get(args.workload)
+        tsrc = {"config2-fgj": (("r6_final/headline", "r5_final/headline", "r4_final/headline", "r3_final/headline", "r2_headline"), 4096),
+                "config3-fgj": (("r6_final/c3_fgj", "r5_final/c3_fgj", "r4_final/c3_fgj", "r3_final/c3_fgj", "r2_c3_spans"), 512),
+                "config3-hess": (("r6_final/c3_hess", "r5_final/c3_hess", "r4_final/c3_hess", "r3_final/c3_hess"), 2048),
+                "config5-hess": (("r6_final/c5_hess", "r5_final/c5_hess", "r2_config5_hess"), 4096), "config2-hess": (("r6_final/c2_hess", "r5_final/c2_hess", "r2_config2_hess"), 4096),
+                "config4-fgj": (("r6_final/c4_fgj", "r5_final/c4_fgj",), 4096), "config4-hess": (("r6_final/c4_hess", "r5_final/c4_hess",), 4096), "config5-fgj": (("r6_final/c5_fgj", "r5_final/c5_fgj",), 4096),
+                "adaptive-fgj": (("r6_final/adaptive_fgj", "r5_final/adaptive_fgj", "r4_final/adaptive", "r3_final/adaptive", "r3_adaptive2"), 4096),
+                "adaptive-hess": (("r6_lanes/adaptive_hess_20x5", "r5_lanes/adaptive_hess") if not os.environ.get("MPX_NO_LANES") else ("r5_final/adaptive_hess",), 4096),
+                "config5-loop": (("r6_final/config5_loop", "r5_final/config5_loop", "r4_final/config5_loop", "r3_final/config5_loop"), 512)}.get(args.workload)
         if partial_sel:  # the light passes (no Jacobian values): one PMC pass per configuration and selection
             seln = "_".join(w for w in ("f", "g", "grad_f") if w in sel)
             tsrc = None
             if not mask & MPX_JAC and cfgn in "2345" and cfgn:
-                tsrc = ((f"r5_final/c{cfgn}_light_{seln}",) + ((f"r4_c3_fg/after_{seln}",) if cfgn == "3" else ()) + ((f"r4_final/c2_light_{seln}",) if cfgn == "2" else ()),
+                tsrc = ((f"r6_final/c{cfgn}_light_{seln}", f"r5_final/c{cfgn}_light_{seln}") + ((f"r4_c3_fg/after_{seln}",) if cfgn == "3" else ()) + ((f"r4_final/c2_light_{seln}",) if cfgn == "2" else ()),
                         512 if cfgn == "3" else 4096)
         if tsrc and B == tsrc[1]:
             tfp, tr = _first(*tsrc[0])
