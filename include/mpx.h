@@ -188,6 +188,15 @@ int mpx_get_comp_weights(const mpx_ctx* ctx, double* compW);
  * repeated every 512 passes. */
 int mpx_geometry_reset(mpx_ctx* ctx);
 
+/* The A/B and test switches of the EVALUATION path (environment variables MPX_NO_LIGHT, MPX_BPB, MPX_NO_LANES, ...: DESIGN.md
+ * section 4's table) are read ONCE per process, at the first evaluation -- no getenv() on the call path.  on = 1: read them at every
+ * call again (the test suite and the A/B tools switch them inside one process; the same as MPX_ENV_DYNAMIC=1 in the environment when
+ * the library is first used); on = 0: take a new snapshot now and keep it.  Call with no evaluation in flight.  Switches read at context
+ * creation are not affected. */
+int mpx_env_dynamic(int on);
+/* What the evaluation path sees for one of those switches (NULL: unset, or not a switch of the evaluation path). */
+const char* mpx_env_knob(const char* name);
+
 /* Use `stream` (a hipStream_t) for all subsequent work of this context; NULL = default stream. */
 int mpx_set_stream(mpx_ctx* ctx, void* stream);
 
@@ -270,7 +279,7 @@ const char* mpx_get_notes(const mpx_ctx* ctx);
  * result never depends on the batch size it was computed in (MPX_LIGHT_LONG_SPANS=1: long spans always).  This query reports the plan: degree = 0 when
  * the grid has none, else the high degree (n_groups = groups of <= 16 high-degree segments, n_low_degree_nodes = nodes evaluated by
  * lanes) or the single low degree (n_groups = spans per phase, max_span_nodes = LDS row length, n_low_degree_nodes = 0); structure
- * only: works without a device.  MPX_NO_LIGHT=1 (environment, read per call) switches the light kernels off. */
+ * only: works without a device.  MPX_NO_LIGHT=1 (environment; see mpx_env_dynamic) switches the light kernels off. */
 /* Round 6: single-degree grids of degree 32 ... 255 have a third family, mpx_lighthigh_*: a workgroup = (segment, 16 evaluation points),
  * the contraction a matrix product with the evaluation points as one dimension (the transposed tables as operands from L2); the
  * query then reports degree = the grid's degree, n_groups = segments per phase, max_span_nodes = the padded K length.  Polynomial

@@ -198,6 +198,8 @@ SYMBOLS = {
     "mpx_ccs_perm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int64_p, c_int64_p]),
     "mpx_get_comp_weights": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "mpx_geometry_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpx_env_dynamic": (ctypes.c_int, [ctypes.c_int]),
+    "mpx_env_knob": (ctypes.c_char_p, [ctypes.c_char_p]),
     "mpx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mpx_set_mid_resid_output": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mpx_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7),

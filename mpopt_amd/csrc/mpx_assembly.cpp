@@ -682,8 +682,8 @@ static int launch_gather(mpx_ctx* c, const DevGather& g, int64_t batch, const do
 // two-pass kernels, whose many small workgroups finish a lone point sooner.  Results are bit-identical either way.
 // MPX_NO_FUSE=1 / MPX_FUSE_MIN_BATCH=n (read per call) switch.
 static bool use_fused(const mpx_asm_state* a, int mode, int64_t batch) {
-  if (!a->fuse_nt || a->fuse_u[mode == MPX_MODE_HESS ? 1 : 0] <= 0 || getenv("MPX_NO_FUSE")) return false;
-  const char* mb = getenv("MPX_FUSE_MIN_BATCH");
+  if (!a->fuse_nt || a->fuse_u[mode == MPX_MODE_HESS ? 1 : 0] <= 0 || mpx_knob(MPX_K_NO_FUSE)) return false;
+  const char* mb = mpx_knob(MPX_K_FUSE_MIN_BATCH);
   return batch >= (mb ? atoll(mb) : 256);
 }
 
@@ -718,7 +718,7 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
     fprintf(stderr, "fused mode %d grid %u: z %.2f | points %.2f | wait %.2f | rows1 %.2f | multi %.2f | mid %.2f | long %.2f | wait %.2f  (chunk %.2f us)\n", mode, grid,
             (d[1] - d[0]) / 100.0, (d[2] - d[1]) / 100.0, (d[3] - d[2]) / 100.0, (d[4] - d[3]) / 100.0, (d[5] - d[4]) / 100.0, (d[6] - d[5]) / 100.0, (d[7] - d[6]) / 100.0,
             (d[8] - d[7]) / 100.0, (d[8] - d[0]) / 100.0);
-    if (getenv("MPX_FUSE_PT_STAMPS"))
+    if (mpx_knob(MPX_K_FUSE_PT_STAMPS))
       fprintf(stderr, "  point task of wave 0: start +%.2f | gather %.2f | function %.2f | raw stores %.2f\n", (d[16] - d[1]) / 100.0, (d[17] - d[16]) / 100.0,
               (d[18] - d[17]) / 100.0, (d[19] - d[18]) / 100.0);
   }
@@ -730,8 +730,8 @@ static int launch_fused(mpx_ctx* c, int mode, int64_t batch, const double* z, co
 // array).  Bit-identical to the other two paths, so the host picks by batch size (hess_l: from 64 points on); MPX_NO_LANES=1 /
 // MPX_LANES_MIN_BATCH=n (read per call) switch.
 static bool use_lanes(const mpx_asm_state* a, int ps, int64_t batch) {
-  if (!a->lanes[ps].fn || getenv("MPX_NO_LANES")) return false;
-  const char* mb = getenv("MPX_LANES_MIN_BATCH");
+  if (!a->lanes[ps].fn || mpx_knob(MPX_K_NO_LANES)) return false;
+  const char* mb = mpx_knob(MPX_K_LANES_MIN_BATCH);
   // (hess_l: faster than the other two paths from one block of 64 points on -- 6.3 against 11.6 us at B = 64, profiles/r5_lanes/ab9;
   // the opt-in first-order pass keeps 512)
   return batch >= std::max<int64_t>(mb ? atoll(mb) : (ps == 0 ? 64 : 512), 64);
@@ -753,7 +753,7 @@ static int launch_lanes(mpx_ctx* c, int ps, int64_t batch, const double* z, cons
   A.scratch = L.n_sid > 0 ? a->lane_scratch.p : nullptr;
   A.B = (int32_t)batch, A.n_blocks = (int32_t)n_blocks;
   {
-    const char* ord = getenv("MPX_LANES_ORDER");  // (read per call: A/B)
+    const char* ord = mpx_knob(MPX_K_LANES_ORDER);  // (A/B)
     A.order = ord ? atoi(ord) : (ps == 1 ? 1 : 0);
   }
   const unsigned grid = (unsigned)(8 * (int64_t)L.groups * ((n_blocks + 7) / 8));
@@ -771,7 +771,7 @@ static int launch_lanes(mpx_ctx* c, int ps, int64_t batch, const double* z, cons
 // 256 MB are therefore cut into equal passes of at most 256 MB that reuse ONE raw buffer (smaller passes lose more to the
 // shorter launches than the cache gives back); every evaluation point is independent, results unchanged.
 static int64_t points_per_pass(int64_t batch, int64_t doubles_per_point) {
-  const char* env = getenv("MPX_ASM_PASS_MB");  // (read per call: tests switch it inside one process)
+  const char* env = mpx_knob(MPX_K_ASM_PASS_MB);
   const int64_t budget = env ? atoll(env) * 1000000 : 256000000;  // 0: one pass
   if (budget <= 0) return batch;
   const int64_t fit = std::max<int64_t>(budget / (8 * std::max<int64_t>(doubles_per_point, 1)), 256);

@@ -361,12 +361,12 @@ extern "C" int mpx_equal_area_widths_device(mpx_ctx* c, int phase, int64_t batch
   const int64_t pos_off = (staged + (pad ? staged / chunk : 0) + 2) & ~(int64_t)1;
   const size_t lds_fast = (size_t)(pos_off + std::max<int64_t>(c->S + 1, MPX_EA_WR * MPX_EA_THREADS / 2)) * 8;  // (boundaries, or the marks they alias)
   const bool fast = n_pts <= (int64_t)MPX_EA_PF * MPX_EA_THREADS && c->S <= MPX_EA_WR * MPX_EA_THREADS &&
-                    lds_fast <= 150 * 1024 && !getenv("MPX_EA_GENERIC");
+                    lds_fast <= 150 * 1024 && !mpx_knob(MPX_K_EA_GENERIC);
   int rc;
   if (!fast && !in_lds && (rc = reserve(c, c->ea_scratch, (size_t)(batch * n_pts)))) return rc;
   const size_t lds = fast ? lds_fast : in_lds ? lds_all : lds_pos;
   long long*& dbg = c->ea_dbg;  // per context: freed in mpx_destroy
-  if (!dbg && getenv("MPX_EA_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&dbg, 128, hipHostMallocMapped));
+  if (!dbg && mpx_knob(MPX_K_EA_DEBUG)) HIPCHK(c, hipHostMalloc((void**)&dbg, 128, hipHostMallocMapped));
   if (lds > 48 * 1024 && lds > c->ea_lds_allowed) {  // the attribute is per device: remembered per context, not per process
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_fast_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(mpx_equal_area_fast_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -12,6 +12,8 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <mutex>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstddef>
@@ -37,6 +39,48 @@ std::string& create_error() {
   return e;
 }
 }  // namespace mpxi
+
+// ---- knobs of the evaluation path (mpx_internal.h) -------------------------------------------------------------------------------------
+namespace {
+const char* const kKnobNames[MPX_K_COUNT] = {
+    "MPX_BPB", "MPX_NO_LIGHT", "MPX_LIGHT_LONG_SPANS", "MPX_NO_PACKED_G", "MPX_NO_PHASE_MERGE", "MPX_LIGHT_DEBUG", "MPX_LIGHT_PER_CU",
+    "MPX_RESIDENT", "MPX_NO_RESIDENT", "MPX_GRADL_GENERIC", "MPX_NO_FUSE", "MPX_FUSE_MIN_BATCH", "MPX_FUSE_PT_STAMPS", "MPX_NO_LANES",
+    "MPX_LANES_MIN_BATCH", "MPX_LANES_ORDER", "MPX_ASM_PASS_MB", "MPX_EA_GENERIC", "MPX_EA_DEBUG"};
+std::atomic<int> g_env_dynamic{0};
+std::string g_knob_val[MPX_K_COUNT];
+bool g_knob_set[MPX_K_COUNT];
+std::once_flag g_knob_once;
+void knob_snapshot() {
+  for (int k = 0; k < MPX_K_COUNT; ++k) {
+    const char* v = getenv(kKnobNames[k]);
+    g_knob_set[k] = v != nullptr;
+    g_knob_val[k] = v ? v : "";
+  }
+}
+}  // namespace
+
+const char* mpx_knob(MpxKnob k) {
+  if (g_env_dynamic.load(std::memory_order_relaxed)) return getenv(kKnobNames[k]);
+  std::call_once(g_knob_once, [] {
+    if (getenv("MPX_ENV_DYNAMIC")) g_env_dynamic.store(1);
+    else knob_snapshot();
+  });
+  if (g_env_dynamic.load(std::memory_order_relaxed)) return getenv(kKnobNames[k]);
+  return g_knob_set[k] ? g_knob_val[k].c_str() : nullptr;
+}
+
+extern "C" const char* mpx_env_knob(const char* name) {
+  for (int k = 0; name && k < MPX_K_COUNT; ++k)
+    if (!strcmp(name, kKnobNames[k])) return mpx_knob((MpxKnob)k);
+  return nullptr;
+}
+
+extern "C" int mpx_env_dynamic(int on) {
+  std::call_once(g_knob_once, [] {});
+  if (!on) knob_snapshot();  // (single-threaded moment by contract: no evaluation in flight)
+  g_env_dynamic.store(on ? 1 : 0);
+  return MPX_OK;
+}
 #define g_create_error (mpxi::create_error())
 
 namespace {
@@ -261,6 +305,7 @@ __global__ __launch_bounds__(256) void mpx_unpack_kernel(const double* __restric
     if (k < nb) out[(int64_t)k * stride] = v[k];
 }
 
+
 // Evaluation points per workgroup.
 //  * Round 1 picked 4-8 for large batches (best case of the software-pipelined loop).  Round 2 measured both over physical
 //    placements of the output buffers on five boxes (tools/placement_ab.py, profiles/r2_headline): with 5 points per workgroup the
@@ -280,7 +325,7 @@ struct GeomPick {
 
 GeomPick pick_geometry(mpx_ctx* c, int64_t B, int mode, const void* key, int sig = 0) {
   const bool light = !(sig & 8);
-  const char* env = getenv("MPX_BPB");  // tuning / test override (read per call: tools switch it inside one process)
+  const char* env = mpx_knob(MPX_K_BPB);  // tuning / test override
   if (env && atoi(env) > 0 && mode != MPX_MODE_HESS) return {atoi(env), nullptr, nullptr};
   // (the hess_l node kernels take one evaluation point per workgroup as a compile-time fact, mpx_kernels.h: MPX_HESS_ONE_POINT --
   // a host-side override could only leave points unevaluated, so there is none; a code object built with -DMPX_HESS_ONE_POINT=0
@@ -452,14 +497,14 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   // one slot per group / span or [phase][64-node chunk] --, which a later MPX_BOUNDARY_ONLY call and mpx_get_partials, both laid
   // out per tile, would misread; mpx_set_tile_range(0, n_tiles, run_boundary = 0) therefore keeps the node kernels)
   bool light = c->lplan.ok && mode != MPX_MODE_HESS && !io.jac && !shard && nodes && c->run_boundary && c->tile_begin == 0 &&
-               c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_LIGHT");
+               c->tile_end == (int64_t)c->tiles.size() && !mpx_knob(MPX_K_NO_LIGHT);
   for (auto& B : c->buckets)
     if (light && B.deg == c->lplan.deg && (!B.fn_light[mode == MPX_MODE_FGJ ? 1 : 0] || (c->lplan.low && !B.fn_light_small[mode == MPX_MODE_FGJ ? 1 : 0]))) light = false;
   if (light && (c->lplan.low || c->lplan.high)) io.n_tiles_total = c->n_phases * c->lplan.n_low_chunks;  // (partial-sum slots of a light pass: [phase][64-node chunk] / [phase][segment])
   // low-degree plan: fewer long spans than a wavefront per SIMD of the device -> one 64-node chunk per wavefront (same sums)
-  const bool light_small = light && c->lplan.low && (int64_t)c->lplan.n_low_groups * io.B < 1024 && !getenv("MPX_LIGHT_LONG_SPANS");
+  const bool light_small = light && c->lplan.low && (int64_t)c->lplan.n_low_groups * io.B < 1024 && !mpx_knob(MPX_K_LIGHT_LONG_SPANS);
   const bool packed = want_g && io.B <= 65535 && !light &&
-                      ((shard && !owner) || (c->g_packed && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_PACKED_G")));
+                      ((shard && !owner) || (c->g_packed && nodes && c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !mpx_knob(MPX_K_NO_PACKED_G)));
   if (packed) {
     int rc = reserve(c, c->gtmp, (size_t)(io.B * c->gtmp_n));
     if (rc) return rc;
@@ -484,7 +529,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
     // one launch for all phases where the code object has the kernels (single-degree grid, n_phases > 1); MPX_NO_PHASE_MERGE=1: A/B
     const int lmode = mode == MPX_MODE_FGJ ? 1 : 0;
     const bool merged_light = c->lplan.low && c->n_phases > 1 && (light_small ? c->fn_lightlows_all : c->fn_lightlow_all)[lmode] != nullptr &&
-                              (int)c->buckets.size() == c->n_phases && !getenv("MPX_NO_PHASE_MERGE");
+                              (int)c->buckets.size() == c->n_phases && !mpx_knob(MPX_K_NO_PHASE_MERGE);
     MpxLightMultiArgs LM{};
     for (auto& B : c->buckets) {
       if (B.deg != c->lplan.deg) continue;
@@ -519,10 +564,10 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
         continue;
       }
       static long long* ldbg = nullptr;
-      if (!ldbg && getenv("MPX_LIGHT_DEBUG")) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
+      if (!ldbg && mpx_knob(MPX_K_LIGHT_DEBUG)) HIPCHK(c, hipHostMalloc((void**)&ldbg, 128, hipHostMallocMapped));
       L.dbg = ldbg;
       int per_cu = 2;  // resident workgroups per compute unit (the kernels' launch bounds)
-      if (const char* e = getenv("MPX_LIGHT_PER_CU")) per_cu = std::max(1, atoi(e));
+      if (const char* e = mpx_knob(MPX_K_LIGHT_PER_CU)) per_cu = std::max(1, atoi(e));
       if (merged_light) {  // collect the phases; the launch follows the last one
         if (B.phase == 0) LM.base = L;
         LM.ph[B.phase] = MpxLightPhase{A.z_off, A.g_off_F, A.g_off_C, A.g_off_DU, A.g_off_mU, A.seg_off, L.slot_first};
@@ -582,7 +627,7 @@ int run_mode(mpx_ctx* c, int mode, const MpxIO& io0, bool nodes = true, bool own
   // phases' ranges one after the other.  MPX_NO_PHASE_MERGE=1 (read per call): one launch per phase, the same bits (tested).
   bool merged_nodes = false;
   if (!by_node && !light && nodes && c->fn_node_all[mode] && c->n_phases > 1 && (int)c->buckets.size() == c->n_phases && !absorb &&
-      !getenv("MPX_NO_PHASE_MERGE")) {
+      !mpx_knob(MPX_K_NO_PHASE_MERGE)) {
     MpxNodeMultiArgs M{};
     int64_t total = 0;
     for (auto& B : c->buckets) {
@@ -1563,12 +1608,12 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
       // single evaluations through the resident kernel (no launch, no stream synchronisation) -- OPT-IN (MPX_RESIDENT=1): measured on
       // MI355X it is not faster than the launched kernels (moon lander 20x3: 43.5 against 44.1 us per IPOPT iteration, 1000x5: 127
       // against 101 us; profiles/r4_resident): what the device saves in launches it spends polling and fencing over PCIe
-      const bool res_on = getenv("MPX_RESIDENT") != nullptr;  // (read per call: tests switch it inside one process)
+      const bool res_on = mpx_knob(MPX_K_RESIDENT) != nullptr;
       const bool resident = res_on && c->res.ok && B == 1 && c->kind == 0 && !(mask & ~(MPX_F | MPX_G | MPX_GRAD | MPX_JAC | MPX_HESS | MPX_CCS_ORDER)) &&
-                            c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !getenv("MPX_NO_RESIDENT") &&
+                            c->tile_begin == 0 && c->tile_end == (int64_t)c->tiles.size() && !mpx_knob(MPX_K_NO_RESIDENT) &&
                             // (passes the span kernels take -- no Jacobian / Hessian values, light plan -- stay with them: their f is
                             // summed per 64-node chunk, the resident kernel's per tile)
-                            !(c->lplan.ok && !(mask & (MPX_JAC | MPX_HESS)) && !getenv("MPX_NO_LIGHT"));
+                            !(c->lplan.ok && !(mask & (MPX_JAC | MPX_HESS)) && !mpx_knob(MPX_K_NO_LIGHT));
       if (resident) {
         rc = res_eval(c, mask, (const double*)zd, c->st_p.p, (const double*)ld, c->h_scratch_dev + B, c->h_scratch_dev, (double*)gd, (double*)qd, (double*)jd,
                       (double*)hd, same_p);
@@ -1681,7 +1726,7 @@ extern "C" int mpx_eval_grad_gamma_device(mpx_ctx* c, int64_t batch, const doubl
   HIPCHK(c, hipSetDevice(c->device));
   c->wcum_valid = false;
   if (!grad_gamma_x && (!grad_gamma_p || c->n_p == 0)) return MPX_OK;
-  const bool generic = getenv("MPX_GRADL_GENERIC") != nullptr;  // (read per call: tests switch it inside one process)
+  const bool generic = mpx_knob(MPX_K_GRADL_GENERIC) != nullptr;
   if (c->kind == 1) return grad_gamma_x ? grad_gamma_generic(c, batch, z, p, p_per_point, lam_g, sigma, grad_gamma_x) : MPX_OK;  // (n_p == 0 there)
   if (generic && grad_gamma_x) {
     int rc = grad_gamma_generic(c, batch, z, p, p_per_point, lam_g, sigma, grad_gamma_x);

@@ -11,6 +11,18 @@
 #include "mpx.h"
 #include "mpx_device.h"
 
+// ---- A/B and test knobs of the EVALUATION path (environment variables) ---------------------------------------------------------------
+// Read once per process, at the first evaluation -- not with getenv() on every call (~10 look-ups of ~50 ns on the
+// single-evaluation latency path, and getenv is not safe against a concurrent setenv) -- unless the process asks for the old behaviour:
+// MPX_ENV_DYNAMIC=1 in the environment when the library is first used, or mpx_env_dynamic(1) (the test suite and the A/B tools switch
+// knobs inside one process).  Knobs read at context CREATION (mpx_layout.cpp, load_device, ...) are plain getenv() calls.
+enum MpxKnob {
+  MPX_K_BPB, MPX_K_NO_LIGHT, MPX_K_LIGHT_LONG_SPANS, MPX_K_NO_PACKED_G, MPX_K_NO_PHASE_MERGE, MPX_K_LIGHT_DEBUG, MPX_K_LIGHT_PER_CU,
+  MPX_K_RESIDENT, MPX_K_NO_RESIDENT, MPX_K_GRADL_GENERIC, MPX_K_NO_FUSE, MPX_K_FUSE_MIN_BATCH, MPX_K_FUSE_PT_STAMPS, MPX_K_NO_LANES,
+  MPX_K_LANES_MIN_BATCH, MPX_K_LANES_ORDER, MPX_K_ASM_PASS_MB, MPX_K_EA_GENERIC, MPX_K_EA_DEBUG, MPX_K_COUNT
+};
+const char* mpx_knob(MpxKnob k);  // the variable's value, nullptr if unset
+
 namespace mpxi {
 
 std::string& create_error();  // thread-local message of a failed mpx_create*

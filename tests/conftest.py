@@ -8,6 +8,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# The tests switch the library's A/B knobs (MPX_NO_LIGHT, MPX_BPB, ...) inside one process: have libmpx read them at every call, as it
+# did up to round 5, instead of once per process (include/mpx.h: mpx_env_dynamic).  Inherited by the subprocesses the tests start.
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

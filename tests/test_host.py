@@ -542,3 +542,40 @@ def test_random_ocps_host_side(seed, wide):
     mask[hr, hc] = True
     assert not np.any((np.triu(O.hess_l(z, p, 0.7, rng.standard_normal(O.n_g))) != 0) & ~mask)
     o.close()
+
+
+def test_evaluation_path_switches_are_read_once_per_process():
+    """include/mpx.h mpx_env_dynamic / mpx_env_knob: without MPX_ENV_DYNAMIC the knobs of the evaluation path are a snapshot
+    taken at first use -- a later setenv is not seen until mpx_env_dynamic(1), and mpx_env_dynamic(0) takes a new snapshot."""
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+from mpopt_amd import _lib
+L = _lib.lib()
+assert L.mpx_env_knob(b"MPX_NO_LIGHT") is None and L.mpx_env_knob(b"MPX_BPB") == b"3" and L.mpx_env_knob(b"PATH") is None
+os.environ["MPX_NO_LIGHT"] = "1"; os.environ["MPX_BPB"] = "5"
+assert L.mpx_env_knob(b"MPX_NO_LIGHT") is None and L.mpx_env_knob(b"MPX_BPB") == b"3"      # the snapshot
+assert L.mpx_env_dynamic(1) == 0
+assert L.mpx_env_knob(b"MPX_NO_LIGHT") == b"1" and L.mpx_env_knob(b"MPX_BPB") == b"5"      # per call
+del os.environ["MPX_BPB"]
+assert L.mpx_env_knob(b"MPX_BPB") is None
+assert L.mpx_env_dynamic(0) == 0                                                             # a new snapshot
+del os.environ["MPX_NO_LIGHT"]
+assert L.mpx_env_knob(b"MPX_NO_LIGHT") == b"1" and L.mpx_env_knob(b"MPX_BPB") is None
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("MPX_ENV_DYNAMIC", "MPX_NO_LIGHT")}
+    env["MPX_BPB"] = "3"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+    # ... and with MPX_ENV_DYNAMIC in the environment (this test process: tests/conftest.py) every call reads the environment
+    L = _lib.lib()
+    os.environ["MPX_LANES_ORDER"] = "probe"
+    try:
+        assert L.mpx_env_knob(b"MPX_LANES_ORDER") == b"probe"
+    finally:
+        del os.environ["MPX_LANES_ORDER"]
+    assert L.mpx_env_knob(b"MPX_LANES_ORDER") is None

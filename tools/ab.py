@@ -1,6 +1,7 @@
 """Scratch: interleaved A/B of kernel build variants in ONE process (guide rule 24).
 usage: VARIANTS="-DMPX_NO_VEC|" python tools/ab.py     (each variant = extra hipcc flags)"""
 import os, sys, time
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """Same-process A/B of the packed g / grad_f staging on a mixed-degree grid (BASELINE configs[2]): MPX_NO_PACKED_G toggled per round."""
 import os
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 import sys
 
 import numpy as np

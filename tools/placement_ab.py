@@ -2,6 +2,7 @@
 Config 2, B=4096.  Repeatedly re-allocates the outputs (torch.empty after empty_cache(): same virtual addresses, new physical
 pages), classifies the allocation with the default build and then times the variants on the SAME buffers."""
 import os, sys
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch

@@ -1,6 +1,7 @@
 """One evaluation point per workgroup as a COMPILE-TIME fact (-DMPX_ABL_BPB1: no software-pipeline state) against the run-time batch loop
 at MPX_BPB=1 and at the library's choice: config given by CASE, masks all-four / hess_l / f+g."""
 import os
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 import sys
 
 import numpy as np

@@ -3,6 +3,7 @@ process -- bitwise comparison of every output and HIP-event timing of both, per 
 usage: python tools/r3_fused_ab.py [case ...]     (MPX_FUSE_WG=n, MPX_HIPCC_FLAGS="-DMPX_FUSE_NT=.. -DMPX_FUSE_MAX_U=.." to explore)"""
 import json
 import os
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 import sys
 
 import numpy as np

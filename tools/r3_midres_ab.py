@@ -1,6 +1,7 @@
 """hess_l pass of the config-5 loop (hypersensitive 4000x3 LGR, B = 512, widths per point): plain, and with the mid-point residuals
 (MPX_MID_RESID), over kernel build variants in ONE process.  usage: VARIANTS="|-DMPX_ABL_MID_NOSTORE|-DMPX_ABL_MID_NOCOMPUTE" python tools/r3_midres_ab.py"""
 import os
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 import sys
 
 import numpy as np

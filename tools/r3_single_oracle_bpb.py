@@ -1,5 +1,6 @@
 """Single oracles at large batches (config 2, B = 4096): evaluation points per workgroup (MPX_BPB) against the library's choice."""
 import os
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 import sys
 
 import numpy as np

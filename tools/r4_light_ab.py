@@ -1,6 +1,7 @@
 """In-process A/B of kernel build flags on the light passes (f, g, f+grad_f alone) of a BASELINE configuration: one context per flag
 set, the SAME arrays, interleaved rounds.   CASE=0..3 B=4096 python tools/r4_light_ab.py "" "-DMPX_LIGHT_XCD_BLOCKED=0" ..."""
 import os, sys
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch
 import mpopt_amd as M

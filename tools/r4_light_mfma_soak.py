@@ -2,6 +2,7 @@
 random runs, span kernels against the node kernels (MPX_NO_LIGHT=1): g and the node entries of grad_f bit for bit, f / border entries
 to rounding; a batch against its single evaluations bit for bit.  python tools/r4_light_mfma_soak.py [seed] [n]"""
 import os, sys
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
 import mpopt_amd as M

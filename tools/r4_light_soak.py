@@ -3,6 +3,7 @@
 node entries of grad_f bit for bit, f to rounding; short spans against long spans bit for bit; a batch against its single evaluations.
 python tools/r4_light_soak.py [seed] [n_random]"""
 import os, sys
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
 import mpopt_amd as M

@@ -1,6 +1,7 @@
 """Low-degree light kernels (mpx_lightlow_*) against the node kernels (MPX_NO_LIGHT=1): bit equality of g / node grad_f, and the
 pass times of both at B=4096 (BASELINE configs 1, 2, 4, 5).  Usage: python tools/r4_lightlow_check.py [time]"""
 import os, sys, time
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch
 import mpopt_amd as M

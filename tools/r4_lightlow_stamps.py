@@ -1,6 +1,7 @@
 """Phase stamps of one wavefront's third item in the low-degree light kernels (build the kernels with MPX_HIPCC_FLAGS=-DMPX_LIGHT_STAMPS,
 run with MPX_LIGHT_DEBUG=1 set by this script).  Usage: MPX_HIPCC_FLAGS=-DMPX_LIGHT_STAMPS python tools/r4_lightlow_stamps.py [case]"""
 import os, sys
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch
 import mpopt_amd as M

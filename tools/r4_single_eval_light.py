@@ -1,6 +1,7 @@
 """Single evaluations through host pointers (the regime IPOPT drives): latency of the light passes with the span kernels (default)
 and with the node kernels (MPX_NO_LIGHT=1), configs 2 and 3.  python tools/r4_single_eval_light.py"""
 import os, sys, time
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
 import mpopt_amd as M

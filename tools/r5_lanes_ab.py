@@ -4,6 +4,7 @@ lane-per-evaluation-point kernel (mpx_asml_hes, round 5), the fused kernel (mpx_
 python tools/r5_lanes_ab.py [problem=moon_lander S=20 P=5] ; B="512 1024 4096 4133 16384"; FLAGS="-DX=1;-DY=2": more contexts whose code
 objects are built with these MPX_HIPCC_FLAGS (lanes kernel only), e.g. the ablations -DMPX_LANE_ABL=1|2|4."""
 import os, sys
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch
 import mpopt_amd as M

@@ -6,6 +6,7 @@
     writes the widths), the next node pass waits for both.
 Checks that every variant gives the same hess_val and widths bit for bit.   B=512 python tools/r5_loop_anyorder.py"""
 import os, sys
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch
 import mpopt_amd as M

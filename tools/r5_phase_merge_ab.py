@@ -2,6 +2,7 @@
 (two-phase Schwartz, 500 x 3 per phase): the SAME context and arrays, interleaved rounds, every oracle.
     B=4096 python tools/r5_phase_merge_ab.py"""
 import os, sys
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch
 import mpopt_amd as M

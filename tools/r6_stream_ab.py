@@ -2,6 +2,7 @@
 whole-pass time of f+g+grad_f+jac_g, of g alone and of nlp_grad for one degree per line.  Picks the default threshold.
     python tools/r6_stream_ab.py [B]"""
 import os
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,7 @@
 """One-off soak of the row-span scheme: random mixed-degree grids, row spans against the unpack pass (bitwise) for several masks
 and batch sizes.  usage: python tools/span_soak.py <first seed> <count>"""
 import os
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")  # this tool switches libmpx's knobs inside one process (include/mpx.h: mpx_env_dynamic)
 import sys
 
 import numpy as np
