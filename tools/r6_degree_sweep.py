@@ -1,0 +1,86 @@
+"""Every degree 32 ... 255 once (round 6): a two-segment moon lander / Van der Pol grid per degree, scheme cycling, a ragged batch of 19 -- the
+light passes through the matrix-core kernels (mpx_lighthigh_*) against the same calls through the node kernels (MPX_NO_LIGHT=1: g and the node
+entries of grad_f bit for bit, f and the (t0, tf) sums to rounding), and f, g, grad_f, jac_g against the numpy oracle (tables in 50-digit
+arithmetic) at 1e-10.  The suite's high-degree cases pick 12 degrees; this runs all 224 (tile tails of every residue of P + 1 mod 16 and mod 4).
+    python tools/r6_degree_sweep.py compile LO HI      (no GPU: fills the in-tree kernel cache)
+    python tools/r6_degree_sweep.py run LO HI          (GPU)"""
+import os
+import sys
+
+os.environ.setdefault("MPX_ENV_DYNAMIC", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+import scipy.sparse as sp
+
+import mpopt_amd as M
+from mpopt_amd import mp, _lib
+import problems
+
+
+def case(P):
+    builder = [problems.moon_lander, problems.van_der_pol, problems.dae_vdp][P % 3]
+    return builder, 2, P, ["LGR", "LGL", "CGL"][(P // 3) % 3]
+
+
+def main():
+    what, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    worst = 0.0
+    for P in range(lo, hi):
+        builder, S, po, scheme = case(P)
+        ocp = builder(mp, M.math)
+        if what == "compile":
+            o = M.NlpFunctions(ocp, S, [po] * S, scheme, with_device=False)
+            _lib.compile_kernels(o.source)
+            o.close()
+            print(P, "compiled", flush=True)
+            continue
+        from oracle.mpopt_oracle import OracleNLP
+
+        mpo = mp.mpopt(ocp, S, po, scheme)
+        o = mpo.create_nlp()[0]["oracle"]
+        assert o.light_plan()[1] > 0, P
+        rng = np.random.default_rng(P)
+        z0 = mpo.initialize_solution()
+        B = 19
+        Z = z0[None, :] + 0.05 * np.abs(z0)[None, :] * rng.uniform(-1, 1, (B, o.n_z)) + 0.05 * rng.uniform(-1, 1, (B, o.n_z))
+        w = rng.uniform(0.3, 1.7, (1, S))
+        p = (w / w.sum(axis=1, keepdims=True)).ravel()
+        res = {}
+        for no_light in (False, True):
+            if no_light:
+                os.environ["MPX_NO_LIGHT"] = "1"
+            try:
+                res[no_light] = [o.eval(["f", "g"], Z, p), o.eval(["f", "grad_f"], Z, p), o.eval(["f", "g", "grad_f"], Z[3], p), o.eval(["g"], Z[:16], p)]
+            finally:
+                os.environ.pop("MPX_NO_LIGHT", None)
+        nn = o.n_z - 2 - ocp.na  # node entries of grad_f
+        for a, b in zip(res[False], res[True]):
+            if "g" in a:
+                assert np.array_equal(a["g"], b["g"]), (P, "g")
+            if "grad_f" in a:
+                assert np.array_equal(np.asarray(a["grad_f"])[..., :nn], np.asarray(b["grad_f"])[..., :nn]), (P, "grad_f nodes")
+                assert np.allclose(a["grad_f"], b["grad_f"], rtol=1e-12, atol=1e-13), (P, "grad_f sums")
+            if "f" in a:
+                assert np.allclose(a["f"], b["f"], rtol=1e-13, atol=1e-13), (P, "f")
+        O = OracleNLP(ocp, S, po, scheme)
+        full = o.eval(["f", "g", "grad_f", "jac_g"], Z[:2], p)
+        jr, jc = o.jac_pattern()
+        for b in range(2):
+            fo, go, qo = O.f(Z[b], p), O.g(Z[b], p), O.grad_f(Z[b], p)
+            e = max(abs(full["f"][b] - fo) / max(1, abs(fo)), np.abs(full["g"][b] - go).max() / max(1, np.abs(go).max()),
+                    np.abs(full["grad_f"][b] - qo).max() / max(1, np.abs(qo).max()),
+                    abs(res[False][0]["f"][b] - fo) / max(1, abs(fo)), np.abs(res[False][0]["g"][b] - go).max() / max(1, np.abs(go).max()))
+            Jo = sp.csr_matrix(O.jac_g(Z[b], p))
+            d = sp.coo_matrix((full["jac_g"][b], (jr, jc)), shape=(o.n_g, o.n_z)).tocsr() - Jo
+            e = max(e, (abs(d).max() if d.nnz else 0.0) / max(1.0, abs(Jo).max()))
+            assert e < 1e-10, (P, e)
+            worst = max(worst, e)
+        o.close()
+        print(P, scheme, builder.__name__, "ok", f"{e:.1e}", flush=True)
+    if what == "run":
+        print(f"degrees {lo}..{hi - 1}: all bit-identical to the node kernels; worst relative error against the numpy oracle {worst:.2e}")
+
+
+if __name__ == "__main__":
+    main()
