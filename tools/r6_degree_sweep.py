@@ -1,7 +1,8 @@
 """Every degree 32 ... 255 once (round 6): a two-segment moon lander / Van der Pol grid per degree, scheme cycling, a ragged batch of 19 -- the
 light passes through the matrix-core kernels (mpx_lighthigh_*) against the same calls through the node kernels (MPX_NO_LIGHT=1: g and the node
 entries of grad_f bit for bit, f and the (t0, tf) sums to rounding), and f, g, grad_f, jac_g against the numpy oracle (tables in 50-digit
-arithmetic) at 1e-10.  The suite's high-degree cases pick 12 degrees; this runs all 224 (tile tails of every residue of P + 1 mod 16 and mod 4).
+arithmetic) at 1e-10.  The suite's high-degree cases pick 12 degrees; this runs all 224 (tile tails of every residue of P + 1 mod 16 and mod 4).  Degrees 1 ... 31: a
+single-degree grid of 40 segments and a mixed one in the pattern of BASELINE configs[2] per degree (mpx_lightlow_* / mpx_light_*).
     python tools/r6_degree_sweep.py compile LO HI      (no GPU: fills the in-tree kernel cache)
     python tools/r6_degree_sweep.py run LO HI          (GPU)"""
 import os
@@ -18,19 +19,26 @@ from mpopt_amd import mp, _lib
 import problems
 
 
-def case(P):
+def cases(P):
+    """Grids of degree P: (builder, S, orders, scheme, light plan expected)."""
     builder = [problems.moon_lander, problems.van_der_pol, problems.dae_vdp][P % 3]
-    return builder, 2, P, ["LGR", "LGL", "CGL"][(P // 3) % 3]
+    scheme = ["LGR", "LGL", "CGL"][(P // 3) % 3]
+    if P >= 32:
+        return [(builder, 2, [P, P], scheme, True)]
+    # degrees 1 ... 31: a single-degree grid (register tables / mpx_lightlow_* up to 12, LDS tables / mpx_light_* on the matrix cores above) and
+    # a mixed one in the pattern of BASELINE configs[2] (the degree between low-degree neighbours; for P <= 12 next to a degree-13 bucket)
+    single = (builder, 40, [P] * 40, scheme, P >= 13 or P >= 2)
+    mixed = (builder, 9, [3, P, 3, 3, P, 2, 3, P, 3] if P >= 13 else [P, 13, P, P, 13, P, 13, P, P], scheme, True)
+    return [single, mixed]
 
 
 def main():
     what, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     worst = 0.0
-    for P in range(lo, hi):
-        builder, S, po, scheme = case(P)
+    for P, (builder, S, po, scheme, want_light) in [(P, c) for P in range(lo, hi) for c in cases(P)]:
         ocp = builder(mp, M.math)
         if what == "compile":
-            o = M.NlpFunctions(ocp, S, [po] * S, scheme, with_device=False)
+            o = M.NlpFunctions(ocp, S, po, scheme, with_device=False)
             _lib.compile_kernels(o.source)
             o.close()
             print(P, "compiled", flush=True)
@@ -39,12 +47,13 @@ def main():
 
         mpo = mp.mpopt(ocp, S, po, scheme)
         o = mpo.create_nlp()[0]["oracle"]
-        assert o.light_plan()[1] > 0, P
+        has_light = o.light_plan()[1] > 0
+        assert has_light or not want_light or P < 13, (P, S, "no light plan")
         rng = np.random.default_rng(P)
         z0 = mpo.initialize_solution()
         B = 19
         Z = z0[None, :] + 0.05 * np.abs(z0)[None, :] * rng.uniform(-1, 1, (B, o.n_z)) + 0.05 * rng.uniform(-1, 1, (B, o.n_z))
-        w = rng.uniform(0.3, 1.7, (1, S))
+        w = rng.uniform(0.3, 1.7, (ocp.n_phases, S))
         p = (w / w.sum(axis=1, keepdims=True)).ravel()
         res = {}
         for no_light in (False, True):
@@ -77,9 +86,9 @@ def main():
             assert e < 1e-10, (P, e)
             worst = max(worst, e)
         o.close()
-        print(P, scheme, builder.__name__, "ok", f"{e:.1e}", flush=True)
+        print(P, S, scheme, builder.__name__, "light" if has_light else "no light plan", "ok", f"{e:.1e}", flush=True)
     if what == "run":
-        print(f"degrees {lo}..{hi - 1}: all bit-identical to the node kernels; worst relative error against the numpy oracle {worst:.2e}")
+        print(f"degrees {lo}..{hi - 1}: light passes bit-identical to the node kernels; worst relative error against the numpy oracle {worst:.2e}")
 
 
 if __name__ == "__main__":
