@@ -1,6 +1,6 @@
 """Every degree 32 ... 255 once (round 6): a two-segment moon lander / Van der Pol grid per degree, scheme cycling, a ragged batch of 19 -- the
 light passes through the matrix-core kernels (mpx_lighthigh_*) against the same calls through the node kernels (MPX_NO_LIGHT=1: g and the node
-entries of grad_f bit for bit, f and the (t0, tf) sums to rounding), and f, g, grad_f, jac_g against the numpy oracle (tables in 50-digit
+entries of grad_f bit for bit, f and the (t0, tf) sums to rounding), and f, g, grad_f, jac_g, hess_l and nlp_grad's two outputs against the numpy oracle (tables in 50-digit
 arithmetic) at 1e-10.  The suite's high-degree cases pick 12 degrees; this runs all 224 (tile tails of every residue of P + 1 mod 16 and mod 4).  Degrees 1 ... 31: a
 single-degree grid of 40 segments and a mixed one in the pattern of BASELINE configs[2] per degree (mpx_lightlow_* / mpx_light_*).
     python tools/r6_degree_sweep.py compile LO HI      (no GPU: fills the in-tree kernel cache)
@@ -73,8 +73,10 @@ def main():
             if "f" in a:
                 assert np.allclose(a["f"], b["f"], rtol=1e-13, atol=1e-13), (P, "f")
         O = OracleNLP(ocp, S, po, scheme)
-        full = o.eval(["f", "g", "grad_f", "jac_g"], Z[:2], p)
+        lam, sig = rng.standard_normal((2, o.n_g)), rng.uniform(0.3, 1.7, 2)
+        full = o.eval(["f", "g", "grad_f", "jac_g", "hess_l"], Z[:2], p, lam_g=lam, sigma=sig)
         jr, jc = o.jac_pattern()
+        hr, hc = o.hess_pattern()
         for b in range(2):
             fo, go, qo = O.f(Z[b], p), O.g(Z[b], p), O.grad_f(Z[b], p)
             e = max(abs(full["f"][b] - fo) / max(1, abs(fo)), np.abs(full["g"][b] - go).max() / max(1, np.abs(go).max()),
@@ -83,6 +85,12 @@ def main():
             Jo = sp.csr_matrix(O.jac_g(Z[b], p))
             d = sp.coo_matrix((full["jac_g"][b], (jr, jc)), shape=(o.n_g, o.n_z)).tocsr() - Jo
             e = max(e, (abs(d).max() if d.nnz else 0.0) / max(1.0, abs(Jo).max()))
+            Ho = sp.csr_matrix(np.triu(O.hess_l(Z[b], p, sig[b], lam[b])))
+            d = sp.coo_matrix((full["hess_l"][b], (hr, hc)), shape=(o.n_z, o.n_z)).tocsr() - Ho
+            e = max(e, (abs(d).max() if d.nnz else 0.0) / max(1.0, abs(Ho).max()))
+            q = o.eval_grad_gamma(Z[b], p, lam[b], sig[b])
+            gx, gp = O.grad_gamma(Z[b], p, sig[b], lam[b])
+            e = max(e, np.abs(q["grad_gamma_x"] - gx).max() / max(1, np.abs(gx).max()), np.abs(q["grad_gamma_p"] - gp).max() / max(1, np.abs(gp).max()))
             assert e < 1e-10, (P, e)
             worst = max(worst, e)
         o.close()
