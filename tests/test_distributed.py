@@ -233,7 +233,7 @@ def test_partition_tiles_properties():
     assert [shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
 
 
-@pytest.mark.parametrize("case", ["vdp_mixed", "schwartz", "kitchen_sink"])
+@pytest.mark.parametrize("case", ["vdp_mixed", "schwartz", "kitchen_sink", "dae_vdp_3_100_3", "kitchen_sink_128"])
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_owner_resident_ownership_tables(case, world):
     """mpx_shard_owned (structure only, no GPU): over all ranks every node row of g, every node entry of grad_f and every tile
@@ -250,7 +250,10 @@ def test_owner_resident_ownership_tables(case, world):
 
     builder, S, po, scheme = {"vdp_mixed": (problems.van_der_pol, 48, [30 if s % 3 == 1 else 3 for s in range(48)], "CGL"),
                               "schwartz": (problems.two_phase_schwartz, 200, [3] * 200, "LGL"),
-                              "kitchen_sink": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR")}[case]
+                              "kitchen_sink": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR"),
+                              # round 6: degrees above the LDS tables (tiles of one or two segments; a streamed bucket between low-degree ones)
+                              "dae_vdp_3_100_3": (problems.dae_vdp, 12, [3, 100, 3] * 4, "LGL"),
+                              "kitchen_sink_128": (problems.kitchen_sink, 10, [128] * 10, "LGR")}[case]
     ocp = builder(mp, M.math)
     o = M.NlpFunctions(ocp, S, po, scheme, with_device=False)
     o.shard_setup(world, 0)
@@ -278,12 +281,12 @@ def test_owner_resident_ownership_tables(case, world):
     assert np.array_equal(count["grad_f"] == 1, is_node)
     # g: the unowned rows are few (terminal, continuity, events) and the owned ones are whole node blocks
     n_unowned = int((count["g"] == 0).sum())
-    assert n_unowned <= nph * (8 + nu * S) + 8 * nph and (n_unowned > 0 or case == "vdp_mixed")  # Van der Pol: no terminal / linking rows
+    assert n_unowned <= nph * (8 + nu * S) + 8 * nph and (n_unowned > 0 or case in ("vdp_mixed", "dae_vdp_3_100_3"))  # Van der Pol: no terminal / linking rows
     jr, jc = o.jac_pattern()
     assert set(np.unique(jr[count["jac_g"] == 0])) <= set(np.nonzero(count["g"] == 0)[0])  # unowned Jacobian values sit on unowned rows
     hr, hc = o.hess_pattern()
     un = count["hess_l"] == 0
-    if case != "vdp_mixed":  # (time-independent dynamics without terminal functions have no corner / terminal entries)
+    if case not in ("vdp_mixed", "dae_vdp_3_100_3"):  # (time-independent dynamics without terminal functions have no corner / terminal entries)
         loc = (hc[un] % nzp) % N  # node index of a node column
         assert un.sum() > 0 and ((~is_node[hc[un]]) | (loc == 0) | (loc == N - 1)).all()  # a global variable or a phase end
     o.shard_setup(1, 0)

@@ -44,6 +44,8 @@ def _worker(rank, world, port, case, q):
         "kitchen_sink": (problems.kitchen_sink, 40, [2, 5, 3, 4] * 10, "LGR"),                           # parameters, DU rows, 2 phases
         "hyper_sensitive": (problems.hyper_sensitive, 700, 3, "LGR"),                                    # config 5, reduced
         "kitchen_sink_400": (problems.kitchen_sink, 400, [2, 5, 3, 4] * 100, "LGR"),                     # several tiles per bucket: corner sums cross ranks
+        "dae_vdp_3_100_3": (problems.dae_vdp, 12, [3, 100, 3] * 4, "LGL"),                               # round 6: a streamed-table bucket (degree 100) between register-table buckets
+        "hyper_sensitive_9x128": (problems.hyper_sensitive, 9, 128, "LGR"),                              # round 6: streamed tables, two segments per tile, 5 tiles over 3 ranks
         "config3_full": problems.BENCH_CASES[1],   # BASELINE configs[2] at full size: Van der Pol 2000 x [3,30,3], CGL
         "config4_full": problems.BENCH_CASES[2],   # BASELINE configs[3] at full size: two-phase Schwartz, 500 x 3 per phase, LGL
     }[case]
@@ -138,7 +140,7 @@ def _worker(rank, world, port, case, q):
     q.put((rank, "ok"))
 
 
-@pytest.mark.parametrize("case,world", [("vdp_mixed", 2), ("schwartz", 3), ("kitchen_sink", 2), ("hyper_sensitive", 2), ("kitchen_sink_400", 3),
+@pytest.mark.parametrize("case,world", [("vdp_mixed", 2), ("schwartz", 3), ("kitchen_sink", 2), ("hyper_sensitive", 2), ("kitchen_sink_400", 3), ("dae_vdp_3_100_3", 2), ("hyper_sensitive_9x128", 3),
                                         ("config3_full", 2), ("config4_full", 2)])
 def test_segment_sharded_evaluator_under_torch_distributed(case, world):
     import torch.multiprocessing as tmp
