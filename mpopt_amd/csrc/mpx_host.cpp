@@ -171,7 +171,13 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   }
   if (hipModuleGetFunction(&c->fn_gradl_fin, c->module, "mpx_gradl_finish") != hipSuccess) c->fn_gradl_fin = nullptr, (void)hipGetLastError();
   int rc;
-  if (c->lplan.ok && ((rc = upload(c, &c->d_lgroups, c->lplan.groups)) || (rc = upload(c, &c->d_lforeign, c->lplan.foreign)) || (rc = upload(c, &c->d_lftab, c->lplan.ftab)))) return rc;
+  // (light_body reads the descriptor foreign[f_first + 0] of a group also when the group has NO low-degree node -- every lane fetches one
+  // before it knows the count -- and takes a segment index from it for the width loads: a zero descriptor closes the list, so that a
+  // group without low-degree nodes at the end of the list, or a single-degree grid with an empty list, reads segment 0 and not whatever
+  // the allocation held: a memory access fault on one placement in some thousand, found by the round-6 soak of random grids)
+  std::vector<MpxLightForeign> lforeign = c->lplan.foreign;
+  lforeign.push_back(MpxLightForeign{});
+  if (c->lplan.ok && ((rc = upload(c, &c->d_lgroups, c->lplan.groups)) || (rc = upload(c, &c->d_lforeign, lforeign)) || (rc = upload(c, &c->d_lftab, c->lplan.ftab)))) return rc;
   if ((rc = upload(c, &c->d_lt_ptr, c->lt_ptr)) || (rc = upload(c, &c->d_lt_col, c->lt_col)) || (rc = upload(c, &c->d_lt_row, c->lt_row)) ||
       (rc = upload(c, &c->d_lt_coef, c->lt_coef)))
     return rc;

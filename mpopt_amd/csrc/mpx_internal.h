@@ -282,6 +282,7 @@ inline int upload(mpx_ctx* c, T** dst, const std::vector<T>& v) {
   size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
   HIPCHK(c, hipMalloc((void**)dst, bytes));
   if (!v.empty()) HIPCHK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  else HIPCHK(c, hipMemset(*dst, 0, bytes));  // (an empty list is one zeroed element on the device, never uninitialised memory)
   return MPX_OK;
 }
 

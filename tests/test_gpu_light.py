@@ -156,3 +156,43 @@ def test_short_and_long_spans_give_the_same_bits(name, monkeypatch):
                 assert np.array_equal(np.asarray(one[k]), np.asarray(big[k][b_])), (name, mask, k, b_)
                 assert np.array_equal(np.asarray(one[k]), np.asarray(forced[k])), (name, mask, k, b_, "forced long spans")
     o.close()
+
+
+def test_light_pass_of_a_single_degree_grid_on_poisoned_device_memory():
+    """Round 6 (found by a soak of random grids, one placement in some thousand): a group of light_body without low-degree nodes -- every
+    group of a single-degree grid of degree 13 ... 31 -- fetched the descriptor `foreign[f_first]` all the same and took a segment index
+    from it for its width loads; the list was empty and its one-element allocation uninitialised, so the index was whatever the memory
+    held: a memory access fault when it was large.  The list now ends with a zero descriptor and empty uploads are zeroed.  Here the
+    device allocator's small blocks are filled with 0x7f bytes and freed before the context is created."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes, hip.hipMemset.argtypes, hip.hipFree.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t], [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t], [ctypes.c_void_p]
+    blocks = []
+    for size in (8, 16, 24, 32, 48, 64, 128, 256, 512, 1024, 4096) * 24:
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), size) == 0
+        assert hip.hipMemset(ptr, 0x7F, size) == 0
+        blocks.append(ptr)
+    assert hip.hipDeviceSynchronize() == 0
+    for ptr in blocks:
+        assert hip.hipFree(ptr) == 0
+    ocp = problems.van_der_pol(mp, M.math)
+    S, P = 98, 20
+    mpo = mp.mpopt(ocp, S, P, "CGL")
+    o = mpo.create_nlp()[0]["oracle"]
+    assert o.light_plan()[1] > 0
+    rng = np.random.default_rng(50)
+    z = mpo.initialize_solution() + 0.05 * rng.standard_normal(o.n_z)
+    w = rng.uniform(0.4, 1.6, S)
+    p = w / w.sum()
+    for B in (1, 5):
+        Z = np.stack([z] * B)
+        light = o.eval(["f", "g"], Z if B > 1 else z, p)
+        full = o.eval(["f", "g", "grad_f", "jac_g"], Z if B > 1 else z, p)
+        assert np.array_equal(np.asarray(light["g"]), np.asarray(full["g"]))
+    from oracle.mpopt_oracle import OracleNLP
+
+    go = OracleNLP(ocp, S, P, "CGL").g(z, p)
+    assert np.abs(np.asarray(light["g"])[0] - go).max() < 1e-10 * max(1.0, np.abs(go).max())
+    o.close()
