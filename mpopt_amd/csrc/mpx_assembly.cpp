@@ -205,6 +205,7 @@ template <class T>
 int upload_n(mpx_ctx* c, T** dst, const T* src, size_t n) {
   HIPCHK(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
   if (n) HIPCHK(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  else HIPCHK(c, hipMemset(*dst, 0, sizeof(T)));  // (an empty list: one zeroed element, never uninitialised memory)
   return MPX_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -277,6 +278,14 @@ inline int64_t partial_slots(const mpx_ctx* c) {
   return std::max<int64_t>((int64_t)c->tiles.size(), low);
 }
 
+// MPX_POISON_ALLOC=1 (debugging aid, round 6): every scratch buffer the library allocates on the device starts out as 0x7f bytes
+// (doubles of 1.4e306, indices of 2.1e9) instead of whatever the block held: a kernel that reads scratch memory nobody wrote shows up
+// as a wrong result or a fault in the test suite, not once in some thousand placements.
+inline bool poison_alloc() {
+  static const bool on = getenv("MPX_POISON_ALLOC") != nullptr;
+  return on;
+}
+
 template <class T>
 inline int upload(mpx_ctx* c, T** dst, const std::vector<T>& v) {
   size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
@@ -293,6 +302,7 @@ inline int reserve(mpx_ctx* c, DevBuf<T>& b, size_t n) {
   b.p = nullptr;
   b.cap = 0;
   HIPCHK(c, hipMalloc((void**)&b.p, n * sizeof(T)));
+  if (poison_alloc()) HIPCHK(c, hipMemset(b.p, 0x7f, n * sizeof(T)));
   b.cap = n;
   return MPX_OK;
 }
