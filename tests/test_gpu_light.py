@@ -158,6 +158,7 @@ def test_short_and_long_spans_give_the_same_bits(name, monkeypatch):
     o.close()
 
 
+@pytest.mark.gpu
 def test_light_pass_of_a_single_degree_grid_on_poisoned_device_memory():
     """Round 6 (found by a soak of random grids, one placement in some thousand): a group of light_body without low-degree nodes -- every
     group of a single-degree grid of degree 13 ... 31 -- fetched the descriptor `foreign[f_first]` all the same and took a segment index
