@@ -200,7 +200,7 @@ def test_nlpsol_like_caller_runs_ipopt_call_sequence_on_the_gpu(name, tmp_path):
         ocp, mpo, o = build_case(name, with_device=True)
         z0, p = G["z"], G["p"]
     dump_problem(tmp_path / "problem.bin", o)
-    K = 7
+    K = 7 if keep else int(os.environ.get("MPX_NLPSOL_K", 7))  # (MPX_NLPSOL_K=n: one-off stress of the call sequence, round 6: 3000 iterates)
     rng = np.random.default_rng(4)
     Z = z0[None, :] * (1 + 0.01 * rng.uniform(-1, 1, (K, o.n_z))) + 0.01 * rng.uniform(-1, 1, (K, o.n_z))
     Z[0] = z0
