@@ -203,7 +203,7 @@ namespace {
 
 template <class T>
 int upload_n(mpx_ctx* c, T** dst, const T* src, size_t n) {
-  HIPCHK(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+  HIPCHK(c, dev_malloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
   if (n) HIPCHK(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
   else HIPCHK(c, hipMemset(*dst, 0, sizeof(T)));  // (an empty list: one zeroed element, never uninitialised memory)
   return MPX_OK;
@@ -304,7 +304,7 @@ void mpx_asm_release(mpx_ctx* c) {
   mpx_asm_state* a = c->assembled;
   if (!a) return;
   auto fr = [](void* p) {
-    if (p) (void)hipFree(p);
+    if (p) (void)dev_free(p);
   };
   for (auto& s : a->sets) fr(s.loc_toff), fr(s.loc_idx), fr(s.mu_toff), fr(s.mu_idx), fr(s.loc_coef), fr(s.cst), fr(s.mu_coef);
   for (DevGather* g : {&a->fgj, &a->hess}) fr(g->ptr), fr(g->src), fr(g->coef), fr(g->long_rows);

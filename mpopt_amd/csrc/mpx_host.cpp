@@ -786,10 +786,10 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
       if (c->res.stream) (void)hipStreamSynchronize(c->res.stream), (void)hipStreamDestroy(c->res.stream);
       (void)hipHostFree(c->res.box);
       for (void* q : {(void*)c->res.d_buckets, (void*)c->res.d_tile_bucket, (void*)c->res.d_bound, (void*)c->res.d_slots, (void*)c->res.d_seq, (void*)c->res.d_sync})
-        if (q) (void)hipFree(q);
+        if (q) (void)dev_free(q);
     }
     auto fr = [](void* p) {
-      if (p) (void)hipFree(p);
+      if (p) (void)dev_free(p);
     };
     for (auto& t : c->degs) fr(t.d_D), fr(t.d_Cmid), fr(t.d_tk), fr(t.d_Dmid), fr(t.d_tkm), fr(t.d_w), fr(t.d_DT), fr(t.d_CT);
     for (auto& B : c->buckets) fr(B.d_node_i), fr(B.d_node_sk);
@@ -1066,14 +1066,14 @@ extern "C" int mpx_resid_plan_destroy(mpx_resid_plan* P) {
   if (P->ctx && P->ctx->has_device) {
     (void)hipSetDevice(P->ctx->device);
     for (auto& B : P->buckets) {
-      if (B.d_id) (void)hipFree(B.d_id);
-      if (B.d_seg) (void)hipFree(B.d_seg);
-      if (B.d_tn) (void)hipFree(B.d_tn);
-      if (B.d_C) (void)hipFree(B.d_C);
-      if (B.d_D) (void)hipFree(B.d_D);
+      if (B.d_id) (void)dev_free(B.d_id);
+      if (B.d_seg) (void)dev_free(B.d_seg);
+      if (B.d_tn) (void)dev_free(B.d_tn);
+      if (B.d_C) (void)dev_free(B.d_C);
+      if (B.d_D) (void)dev_free(B.d_D);
     }
     for (auto& b : P->st)
-      if (b.p) (void)hipFree(b.p);
+      if (b.p) (void)dev_free(b.p);
   }
   delete P;
   return MPX_OK;

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <map>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -286,10 +289,52 @@ inline bool poison_alloc() {
   return on;
 }
 
+// MPX_GUARD_ALLOC=1 | head (debugging aid, round 6): every device buffer of the library is the LAST bytes (head: the first bytes) of its own
+// allocation of a multiple of 2 MB, so that a kernel running past the end (before the start) of one of the library's tables or scratch buffers
+// leaves the allocation -- a memory access fault -- instead of reading its neighbour.  (The tail pointer keeps 16-byte alignment: an overrun of
+// less than 16 bytes can stay inside.)  tools/r6_tail_guard.py does the same for the caller's arrays.
+struct GuardAlloc {
+  std::mutex mu;
+  std::map<void*, void*> base_of;  // pointer handed out -> allocation
+  int mode = 0;                    // 0 off, 1 tail, 2 head
+  GuardAlloc() {
+    const char* e = getenv("MPX_GUARD_ALLOC");
+    mode = !e ? 0 : (!strcmp(e, "head") ? 2 : 1);
+  }
+};
+inline GuardAlloc& guard_alloc() {
+  static GuardAlloc g;
+  return g;
+}
+inline hipError_t dev_malloc(void** p, size_t bytes) {
+  GuardAlloc& g = guard_alloc();
+  if (!g.mode) return hipMalloc(p, bytes);
+  const size_t gran = size_t(2) << 20, nb = (std::max<size_t>(bytes, 1) + 15) & ~size_t(15), size = (nb + gran - 1) / gran * gran;
+  void* base = nullptr;
+  hipError_t e = hipMalloc(&base, size);
+  if (e != hipSuccess) return e;
+  *p = g.mode == 2 ? base : static_cast<char*>(base) + (size - nb);
+  std::lock_guard<std::mutex> lk(g.mu);
+  g.base_of[*p] = base;
+  return hipSuccess;
+}
+inline hipError_t dev_free(void* p) {
+  GuardAlloc& g = guard_alloc();
+  if (g.mode) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    auto it = g.base_of.find(p);
+    if (it != g.base_of.end()) {
+      p = it->second;
+      g.base_of.erase(it);
+    }
+  }
+  return hipFree(p);
+}
+
 template <class T>
 inline int upload(mpx_ctx* c, T** dst, const std::vector<T>& v) {
   size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
-  HIPCHK(c, hipMalloc((void**)dst, bytes));
+  HIPCHK(c, dev_malloc((void**)dst, bytes));
   if (!v.empty()) HIPCHK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   else HIPCHK(c, hipMemset(*dst, 0, bytes));  // (an empty list is one zeroed element on the device, never uninitialised memory)
   return MPX_OK;
@@ -298,10 +343,10 @@ inline int upload(mpx_ctx* c, T** dst, const std::vector<T>& v) {
 template <class T>
 inline int reserve(mpx_ctx* c, DevBuf<T>& b, size_t n) {
   if (n <= b.cap) return MPX_OK;
-  if (b.p) HIPCHK(c, hipFree(b.p));
+  if (b.p) HIPCHK(c, dev_free(b.p));
   b.p = nullptr;
   b.cap = 0;
-  HIPCHK(c, hipMalloc((void**)&b.p, n * sizeof(T)));
+  HIPCHK(c, dev_malloc((void**)&b.p, n * sizeof(T)));
   if (poison_alloc()) HIPCHK(c, hipMemset(b.p, 0x7f, n * sizeof(T)));
   b.cap = n;
   return MPX_OK;

@@ -109,7 +109,7 @@ extern "C" int mpx_shard_setup(mpx_ctx* c, int world, int rank) {
     c->shard_ent[ps].clear();
     c->shard_ent_first[ps].assign(1, 0);
     c->shard_len[ps] = 0;
-    if (c->d_shard_ent[ps]) (void)hipFree(c->d_shard_ent[ps]);
+    if (c->d_shard_ent[ps]) (void)dev_free(c->d_shard_ent[ps]);
     c->d_shard_ent[ps] = nullptr;
   }
   if (world == 1) {
