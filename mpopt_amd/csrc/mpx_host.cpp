@@ -966,7 +966,7 @@ extern "C" int mpx_host_alloc(mpx_ctx* c, size_t bytes, void** ptr) {
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = bytes ? bytes : 8;
   HIPCHK(c, hipHostMalloc(ptr, n, hipHostMallocMapped));
-  if (poison_alloc()) memset(*ptr, 0x7f, n);
+  if (poison_alloc()) memset(*ptr, poison_byte(), n);
   void* dev = nullptr;
   if (hipHostGetDevicePointer(&dev, *ptr, 0) == hipSuccess && dev) c->pins.push_back({static_cast<char*>(*ptr), n, static_cast<char*>(dev), true});
   return MPX_OK;
@@ -1598,7 +1598,7 @@ extern "C" int mpx_eval(mpx_ctx* c, int mask, int64_t batch, const double* z, co
         c->h_scratch = nullptr, c->h_scratch_cap = 0;
         const size_t cap = std::max<size_t>(2 * B, 64);
         HIPCHK(c, hipHostMalloc((void**)&c->h_scratch, cap * 8, hipHostMallocMapped));
-        if (poison_alloc()) memset(c->h_scratch, 0x7f, cap * 8);
+        if (poison_alloc()) memset(c->h_scratch, poison_byte(), cap * 8);
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_scratch_dev, c->h_scratch, 0));
         c->h_scratch_cap = cap;
       }

@@ -288,6 +288,13 @@ inline bool poison_alloc() {
   static const bool on = getenv("MPX_POISON_ALLOC") != nullptr;
   return on;
 }
+inline int poison_byte() {  // MPX_POISON_ALLOC=1: 0x7f; MPX_POISON_ALLOC=ff (any two hex digits): that byte (0xff: NaN doubles, indices of -1)
+  static const int b = [] {
+    const char* e = getenv("MPX_POISON_ALLOC");
+    return e && strlen(e) == 2 ? (int)strtol(e, nullptr, 16) & 0xff : 0x7f;
+  }();
+  return b;
+}
 
 // MPX_GUARD_ALLOC=1 | head (debugging aid, round 6): every device buffer of the library is the LAST bytes (head: the first bytes) of its own
 // allocation of a multiple of 2 MB, so that a kernel running past the end (before the start) of one of the library's tables or scratch buffers
@@ -347,7 +354,7 @@ inline int reserve(mpx_ctx* c, DevBuf<T>& b, size_t n) {
   b.p = nullptr;
   b.cap = 0;
   HIPCHK(c, dev_malloc((void**)&b.p, n * sizeof(T)));
-  if (poison_alloc()) HIPCHK(c, hipMemset(b.p, 0x7f, n * sizeof(T)));
+  if (poison_alloc()) HIPCHK(c, hipMemset(b.p, poison_byte(), n * sizeof(T)));
   b.cap = n;
   return MPX_OK;
 }
