@@ -226,8 +226,11 @@ struct MpxGradlArgs {
   const double* sigma;
   double* gx;           int64_t gx_stride;  // grad_gamma_x [B][n_z]; NULL: only what grad_gamma_p needs is computed
   double* halo;         // [B][n_phases * S][nx + nu]: what the rows of segment s >= 1 contribute to the columns of ITS FIRST node --
-                        //   the last node of segment s - 1, owned by another lane (often another workgroup); added by the finishing pass
-  double* pnode;        // [B][n_phases * N][2]: per node (d gamma_i / d w_s of its own segment, d gamma_i / d th)
+                        //   the last node of segment s - 1 -- where that node's lane is NOT the previous lane of the same workgroup (the
+                        //   first segment of a tile; a neighbour of another degree): added by the finishing pass.  Everywhere else the
+                        //   owner of the node adds it itself (round 6: 999 of 1000 segments at configs[1])
+  double* pseg;         // [B][n_phases * S][2]: per SEGMENT the sums over its nodes of (d gamma_i / d w_s of the node's own segment,
+                        //   d gamma_i / d th), added from the last node down (round 6: per node before, summed by the finishing pass)
   double* partial;      // [B][n_tiles_total][nred]: tile sums of d gamma_i / d (t0, tf, A)
   int32_t n_tiles_total, nred;
   int32_t B, b_first;
@@ -240,7 +243,8 @@ struct MpxGradlArgs {
   const double* Wnode;
   double inv_dtau;
   int64_t z_off, g_off_F, g_off_C, g_off_DU, g_off_mU;
-  int32_t N, seg_off, tile_first, phase, S, pad_;
+  int32_t N, seg_off, tile_first, phase, S;
+  int32_t bpb;          // evaluation points a workgroup takes, one after the other (B = one past the last point of this launch)
 };
 struct MpxGradlFinArgs {
   const double* z;      int64_t z_stride;
@@ -249,9 +253,11 @@ struct MpxGradlFinArgs {
   double* gx;           int64_t gx_stride;
   double* gp;           int64_t gp_stride;  // grad_gamma_p [B][n_phases * S]; NULL: not requested
   const double* halo;
-  const double* pnode;
+  const double* pseg;
   const double* partial;
   int32_t n_tiles_total, nred;
+  const int32_t* halo_seg;                  // the segments whose `halo` entry the node pass wrote, phase by phase
+  int32_t halo_off[MPX_MAX_PHASES + 1];     // phase p: halo_seg[halo_off[p] .. halo_off[p + 1])
   MpxPhaseInfo ph[MPX_MAX_PHASES];
   const int32_t* seg_start;  // [S + 1]
   int32_t S, n_lt;

@@ -45,7 +45,7 @@ namespace {
 const char* const kKnobNames[MPX_K_COUNT] = {
     "MPX_BPB", "MPX_NO_LIGHT", "MPX_LIGHT_LONG_SPANS", "MPX_NO_PACKED_G", "MPX_NO_PHASE_MERGE", "MPX_LIGHT_DEBUG", "MPX_LIGHT_PER_CU",
     "MPX_RESIDENT", "MPX_NO_RESIDENT", "MPX_GRADL_GENERIC", "MPX_NO_FUSE", "MPX_FUSE_MIN_BATCH", "MPX_FUSE_PT_STAMPS", "MPX_NO_LANES",
-    "MPX_LANES_MIN_BATCH", "MPX_LANES_ORDER", "MPX_ASM_PASS_MB", "MPX_EA_GENERIC", "MPX_EA_DEBUG"};
+    "MPX_LANES_MIN_BATCH", "MPX_LANES_ORDER", "MPX_ASM_PASS_MB", "MPX_EA_GENERIC", "MPX_EA_DEBUG", "MPX_GRADL_BPB"};
 std::atomic<int> g_env_dynamic{0};
 std::string g_knob_val[MPX_K_COUNT];
 bool g_knob_set[MPX_K_COUNT];
@@ -212,6 +212,30 @@ int load_device(mpx_ctx* c, const mpx_problem* prob) {
   if ((rc = upload(c, &c->d_tiles, c->tiles))) return rc;
   if ((rc = upload(c, &c->d_Wnode, c->compW))) return rc;
   if ((rc = upload(c, &c->d_seg_start, c->seg_start))) return rc;
+  {  // nlp_grad: the segments whose column-0 sums travel through `halo` (mpx_kernels.h: gradl_body halo_out) -- the first lane of the segment is
+     // the first lane of its tile, or the lane before it belongs to another segment than s - 1 (mixed-degree grids)
+    c->gl_halo_seg.clear();
+    c->gl_halo_off.assign((size_t)c->n_phases + 1, 0);
+    for (int p_ = 0; p_ < c->n_phases; ++p_) {
+      std::vector<int32_t> segs;
+      for (auto& B : c->buckets) {
+        if (B.phase != p_) continue;
+        for (int t = B.tile_first; t < B.tile_first + B.tile_count; ++t) {
+          const MpxTile& T = c->tiles[(size_t)t];
+          if (T.node0) continue;
+          for (int j = 0; j < T.n; ++j) {
+            const int sk = B.node_sk[(size_t)(T.m0 + j)], s_ = sk >> 8;
+            if ((sk & 255) != 1 || s_ < 1) continue;
+            if (!(j >= 1 && (B.node_sk[(size_t)(T.m0 + j - 1)] >> 8) == s_ - 1)) segs.push_back(s_);
+          }
+        }
+      }
+      std::sort(segs.begin(), segs.end());
+      c->gl_halo_seg.insert(c->gl_halo_seg.end(), segs.begin(), segs.end());
+      c->gl_halo_off[(size_t)p_ + 1] = (int32_t)c->gl_halo_seg.size();
+    }
+    if ((rc = upload(c, &c->d_gl_halo_seg, c->gl_halo_seg))) return rc;
+  }
   if ((rc = upload(c, &c->d_lin_ptr, c->lin_ptr))) return rc;
   if ((rc = upload(c, &c->d_lin_idx, c->lin_idx))) return rc;
   if ((rc = upload(c, &c->d_lin_row, c->lin_row))) return rc;
@@ -799,7 +823,7 @@ extern "C" int mpx_destroy(mpx_ctx* c) {
     fr(c->partial.p), fr(c->wcum.p), fr(c->st_z.p), fr(c->st_p.p), fr(c->st_lam.p), fr(c->st_sig.p), fr(c->st_f.p);
     fr(c->st_g.p), fr(c->st_grad.p), fr(c->st_jac.p), fr(c->st_hess.p);
     fr(c->ccs_j.p), fr(c->ccs_h.p), fr(c->d_perm_j), fr(c->d_perm_h), fr(c->d_var_dst), fr(c->d_var_src);
-    fr(c->d_lgroups), fr(c->d_lforeign), fr(c->d_lftab), fr(c->gl_halo.p), fr(c->gl_pnode.p), fr(c->st_ggx.p), fr(c->st_ggp.p), fr(c->gl_grad.p), fr(c->gl_jac.p);
+    fr(c->d_lgroups), fr(c->d_lforeign), fr(c->d_lftab), fr(c->d_gl_halo_seg), fr(c->gl_halo.p), fr(c->gl_pnode.p), fr(c->st_ggx.p), fr(c->st_ggp.p), fr(c->gl_grad.p), fr(c->gl_jac.p);
     fr(c->d_lt_ptr), fr(c->d_lt_col), fr(c->d_lt_row), fr(c->d_lt_coef), fr(c->d_colind_j), fr(c->d_jrow);
     fr(c->d_gmap), fr(c->d_qmap), fr(c->d_abs_fpos), fr(c->d_abs_fstage), fr(c->d_abs_fn), fr(c->gtmp.p), fr(c->d_shard_ent[0]), fr(c->d_shard_ent[1]), fr(c->ea_scratch.p);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
@@ -1748,7 +1772,7 @@ extern "C" int mpx_eval_grad_gamma_device(mpx_ctx* c, int64_t batch, const doubl
   const int64_t n_w = p_per_point ? batch : 1, nt = (int64_t)c->tiles.size();
   int rc;
   if ((rc = reserve_wcum(c, (size_t)(n_w * c->n_p))) || (rc = reserve(c, c->partial, (size_t)(batch * nt * c->nred))) ||
-      (rc = reserve(c, c->gl_pnode, (size_t)(batch * c->n_phases * c->N * 2))) ||
+      (rc = reserve(c, c->gl_pnode, (size_t)(batch * c->n_phases * c->S * 2))) ||
       (rc = reserve(c, c->gl_halo, (size_t)(batch * c->n_phases * c->S * (c->nx + c->nu)))))
     return rc;
   if ((rc = launch_prefix(c, p, n_w, p_per_point))) return rc;
@@ -1760,23 +1784,32 @@ extern "C" int mpx_eval_grad_gamma_device(mpx_ctx* c, int64_t batch, const doubl
     A.w = p, A.wcum = c->wcum.p, A.w_stride = p_per_point ? c->n_p : 0;
     A.lam_g = lam_g, A.lam_stride = c->n_g, A.sigma = sigma;
     A.gx = grad_gamma_x, A.gx_stride = c->n_z;
-    A.halo = c->gl_halo.p, A.pnode = c->gl_pnode.p, A.partial = c->partial.p;
+    A.halo = c->gl_halo.p, A.pseg = c->gl_pnode.p, A.partial = c->partial.p;
     A.n_tiles_total = (int32_t)nt, A.nred = c->nred, A.B = (int32_t)batch;
     A.tiles = c->d_tiles, A.node_i = B.d_node_i, A.node_sk = B.d_node_sk;
     A.Dmat = t.d_D, A.Cmid = t.d_Cmid, A.tk = t.d_tk, A.Wnode = c->d_Wnode;
     A.inv_dtau = 1.0 / (c->tau1 - c->tau0);
     A.z_off = P.z_off, A.g_off_F = P.g_off_F, A.g_off_C = P.g_off_C, A.g_off_DU = P.g_off_DU, A.g_off_mU = P.g_off_mU;
     A.N = (int32_t)c->N, A.seg_off = B.phase * c->S, A.tile_first = B.tile_first, A.phase = B.phase, A.S = c->S;
-    for (int64_t bf = 0; bf < batch; bf += 65535) {
+    // evaluation points per workgroup: 1 for small batches (every point its own workgroups: latency), 4 from a few thousand workgroups on
+    // (MPX_GRADL_BPB=n: A/B; measured at configs[1], B = 4096: profiles/r6_nlp_grad)
+    const char* bpb_knob = mpx_knob(MPX_K_GRADL_BPB);
+    const int bpb = bpb_knob ? std::max(1, atoi(bpb_knob)) : (batch * B.tile_count >= 8192 ? 4 : 1);
+    A.bpb = bpb;
+    for (int64_t bf = 0; bf < batch; bf += (int64_t)65535 * bpb) {
       A.b_first = (int32_t)bf;
-      if ((rc = launch(c, B.fn_gradl, dim3((unsigned)B.tile_count, (unsigned)std::min<int64_t>(65535, batch - bf), 1), dim3(MPX_TILE, 1, 1), &A, sizeof A))) return rc;
+      A.B = (int32_t)std::min<int64_t>(batch, bf + (int64_t)65535 * bpb);
+      const int64_t rows = (A.B - bf + bpb - 1) / bpb;
+      if ((rc = launch(c, B.fn_gradl, dim3((unsigned)B.tile_count, (unsigned)rows, 1), dim3(MPX_TILE, 1, 1), &A, sizeof A))) return rc;
     }
   }
   MpxGradlFinArgs F{};
   F.z = z, F.z_stride = c->n_z, F.lam_g = lam_g, F.lam_stride = c->n_g, F.sigma = sigma;
   F.gx = grad_gamma_x, F.gx_stride = c->n_z;
   F.gp = c->n_p ? grad_gamma_p : nullptr, F.gp_stride = c->n_p;
-  F.halo = c->gl_halo.p, F.pnode = c->gl_pnode.p, F.partial = c->partial.p;
+  F.halo = c->gl_halo.p, F.pseg = c->gl_pnode.p, F.partial = c->partial.p;
+  F.halo_seg = c->d_gl_halo_seg;
+  for (int p_ = 0; p_ <= c->n_phases; ++p_) F.halo_off[p_] = c->gl_halo_off[(size_t)p_];
   F.n_tiles_total = (int32_t)nt, F.nred = c->nred;
   for (int p_ = 0; p_ < c->n_phases; ++p_) {
     const PhaseStruct& P = c->ph[p_];
@@ -1791,7 +1824,7 @@ extern "C" int mpx_eval_grad_gamma_device(mpx_ctx* c, int64_t batch, const doubl
     Fs.z += bf * c->n_z, Fs.lam_g += bf * c->n_g, Fs.sigma += bf;
     if (Fs.gx) Fs.gx += bf * c->n_z;
     if (Fs.gp) Fs.gp += bf * c->n_p;
-    Fs.halo += bf * c->n_phases * c->S * (c->nx + c->nu), Fs.pnode += bf * c->n_phases * c->N * 2, Fs.partial += bf * nt * c->nred;
+    Fs.halo += bf * c->n_phases * c->S * (c->nx + c->nu), Fs.pseg += bf * c->n_phases * c->S * 2, Fs.partial += bf * nt * c->nred;
     if ((rc = launch(c, c->fn_gradl_fin, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), &Fs, sizeof Fs))) return rc;
   }
   return MPX_OK;

@@ -23,7 +23,7 @@
 enum MpxKnob {
   MPX_K_BPB, MPX_K_NO_LIGHT, MPX_K_LIGHT_LONG_SPANS, MPX_K_NO_PACKED_G, MPX_K_NO_PHASE_MERGE, MPX_K_LIGHT_DEBUG, MPX_K_LIGHT_PER_CU,
   MPX_K_RESIDENT, MPX_K_NO_RESIDENT, MPX_K_GRADL_GENERIC, MPX_K_NO_FUSE, MPX_K_FUSE_MIN_BATCH, MPX_K_FUSE_PT_STAMPS, MPX_K_NO_LANES,
-  MPX_K_LANES_MIN_BATCH, MPX_K_LANES_ORDER, MPX_K_ASM_PASS_MB, MPX_K_EA_GENERIC, MPX_K_EA_DEBUG, MPX_K_COUNT
+  MPX_K_LANES_MIN_BATCH, MPX_K_LANES_ORDER, MPX_K_ASM_PASS_MB, MPX_K_EA_GENERIC, MPX_K_EA_DEBUG, MPX_K_GRADL_BPB, MPX_K_COUNT
 };
 const char* mpx_knob(MpxKnob k);  // the variable's value, nullptr if unset
 
@@ -128,7 +128,9 @@ struct mpx_ctx {
   // nlp_grad (mpx_eval_grad_gamma*): finishing kernel, staging of the node pass (MpxGradlArgs::halo / pnode), host-path outputs,
   // and the generic J^T lam route (assembled contexts; MPX_GRADL_GENERIC=1): scratch grad_f / jac_val + compressed-column tables
   hipFunction_t fn_gradl_fin = nullptr;
-  DevBuf<double> gl_halo, gl_pnode, st_ggx, st_ggp, gl_grad, gl_jac;
+  DevBuf<double> gl_halo, gl_pnode, st_ggx, st_ggp, gl_grad, gl_jac;  // (gl_pnode: the per-segment sums of nlp_grad, MpxGradlArgs::pseg)
+  std::vector<int32_t> gl_halo_seg, gl_halo_off;  // nlp_grad: segments whose column-0 sums go through `halo`, per phase (MpxGradlFinArgs)
+  int32_t* d_gl_halo_seg = nullptr;
   // light passes on the matrix cores (mpx_light_*, mpx_kernels.h: light_body): grids with ONE high degree (12 < P <= 31) and otherwise
   // degrees <= 12.  Groups of up to 16 high-degree segments + the low-degree segments between them (the same for every phase)
   struct LightPlan {

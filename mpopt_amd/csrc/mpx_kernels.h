@@ -2403,7 +2403,14 @@ __device__ __forceinline__ void boundary_body(const MpxBoundArgs& A, const int r
 //     first point of a segment is the last node of the previous one (mpopt.py:189-195), i.e. another lane's entry: its sum goes to
 //     the `halo` staging array and the finishing pass adds it (one addition, fixed order).
 // grad_gamma_p[s] = sum_{i in s} (gk_i / (tau1 - tau0) + gth_i * tk_i) + sum_{i in later segments} gth_i: the node pass leaves the two
-// per-node terms in `pnode`, the finishing pass forms the per-segment sums and the suffix sums in a fixed order.
+// per-SEGMENT sums in `pseg` (added from the segment's last node down; segment 0's by the mini-tile of node 0, which holds the whole
+// segment), the finishing pass forms the suffix sums in a fixed order.
+// Round 6: measured as a batched pass for the first time (tools/r6_nlp_grad_bench.py), configs[1] took 1166 us for 1.5 GB -- longer than the
+// whole f + g + grad_f + jac_g pass -- and two thirds of it in the finishing kernel: it read-modify-wrote one `halo` entry per segment into
+// grad_gamma_x (3 000 scattered 8-byte updates per evaluation point) and walked the per-node `pnode` pairs three times with a stride of one
+// lane's chunk.  Now the lane that owns a segment's last node adds the next segment's column-0 sum itself whenever that segment's lanes
+// follow in the same workgroup (same additions in the same order: bit-identical), and the per-segment sums are formed where the node
+// terms are -- in the workgroup's LDS.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int PH, int P>
 __device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
@@ -2420,6 +2427,7 @@ __device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
   __shared__ double sD_[TAB_GLB ? 1 : P1 * P1];
   __shared__ double sC_[TAB_GLB ? 1 : P * P1];
   __shared__ double sRed[MPX_TILE / 64][NRED];
+  __shared__ double sPn[2][MPX_TILE];  // the lanes' (d gamma_i / d w_s, d gamma_i / d th): summed per segment below
   const double* __restrict__ const sD = TAB_GLB ? A.Dmat : sD_;
   const double* __restrict__ const sC = TAB_GLB ? A.Cmid : sC_;
   const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x, tot_ = gridDim.x * gridDim.y;  // XCD-blocked walk, as node_body
@@ -2434,12 +2442,22 @@ __device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
   const int s = sk >> 8, k = sk & 255;
   const int base = ((k == 0) ? 0 : (l - T.node0) / P) * P1;
   const bool halo = act && k == 1 && !T.node0;  // loads the multipliers of the segment's first node (owned by the previous segment)
+  // the lane's node is also point 0 of the NEXT segment: if that segment's lanes follow in this workgroup (regular tiles hold whole
+  // segments in node order; in a mixed-degree grid the next lane may belong to a segment further on), this lane adds the next segment's
+  // column-0 sums to its outputs itself; otherwise the next segment's first lane leaves them in `halo` for the finishing pass
+  const bool fuse_next = act && !T.node0 && k == P && l + 1 < T.n && (A.node_sk[m + 1] >> 8) == s + 1;
+  const bool halo_out = halo && s >= 1 && !(l >= 1 && (A.node_sk[m - (l >= 1 ? 1 : 0)] >> 8) == s - 1);
   const int N = A.N;
-  const int b = A.b_first + (int)by_;
   if constexpr (!TAB_GLB) {
     for (int e = l; e < P1 * P1; e += MPX_TILE) sD_[e] = A.Dmat[e];
     for (int e = l; e < P * P1; e += MPX_TILE) sC_[e] = A.Cmid[e];
   }
+  // A.bpb evaluation points per workgroup, one after the other (round 6: one point per workgroup left 86 000 workgroups of a few
+  // microseconds each at configs[1], every one of them loading the tables and its tile descriptor again).  The LDS arrays are reused without
+  // an extra barrier: sL is read only before the second barrier of a point, sPn / sRed are written only after the first barrier of the next.
+  for (int bi = 0; bi < A.bpb; ++bi) {
+  const int b = A.b_first + (int)by_ * A.bpb + bi;
+  if (b >= A.B) break;  // (uniform)
   const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride + A.z_off;
   const double* __restrict__ lb = A.lam_g + (int64_t)b * A.lam_stride;
   Vec<NX> Xs, lF;
@@ -2504,18 +2522,42 @@ __device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
     for (int kp = 1; kp < P1; ++kp) acc = fma(sL[row][base + kp], sC[(kp - 1) * P1 + j], acc);
     return acc;
   };
+  // column 0 of the NEXT segment's block (its rows 1 ... P: the next segment is never segment 0): the same chains as that segment's
+  // first lane runs for `halo`
+  auto next_D = [&](int row) {
+    double acc = 0;
+#pragma unroll 4
+    for (int kp = 1; kp < P1; ++kp) acc = fma(sL[row][base + P1 + kp], sD[kp * P1], acc);
+    return acc;
+  };
+  auto next_C = [&](int row) {
+    double acc = 0;
+#pragma unroll 4
+    for (int kp = 1; kp < P1; ++kp) acc = fma(sL[row][base + P1 + kp], sC[(kp - 1) * P1], acc);
+    return acc;
+  };
   if (own && A.gx) {
     double* __restrict__ gb = A.gx + (int64_t)b * A.gx_stride + A.z_off;
 #pragma unroll
-    for (int a = 0; a < NX; ++a) gb[(int64_t)a * N + i] = gx[a] + col_D(a, k);
+    for (int a = 0; a < NX; ++a) {
+      double v = gx[a] + col_D(a, k);
+      if (fuse_next) v += next_D(a);  // (what the finishing pass added from `halo`: one addition, after the node's own sum)
+      gb[(int64_t)a * N + i] = v;
+    }
 #pragma unroll
     for (int c = 0; c < NU; ++c) {
       double v = gx[NX + c];
       if constexpr (G::DIFF_U) v += col_D(L_DU + c, k);
       if constexpr (G::MIDU) v += col_C(L_MU + c, k);
+      if (fuse_next) {
+        double h = 0;
+        if constexpr (G::DIFF_U) h += next_D(L_DU + c);
+        if constexpr (G::MIDU) h += next_C(L_MU + c);
+        v += h;
+      }
       gb[(int64_t)(NX + c) * N + i] = v;
     }
-    if (halo && s >= 1) {
+    if (halo_out) {
       double* __restrict__ hb = A.halo + ((int64_t)b * A.S * MPX_NPH + A.seg_off + s) * (NX + NU);
 #pragma unroll
       for (int a = 0; a < NX; ++a) hb[a] = col_D(a, 0);
@@ -2528,23 +2570,32 @@ __device__ __forceinline__ void gradl_body(const MpxGradlArgs& A) {
       }
     }
   }
-  if (own) {
-    double* __restrict__ pn = A.pnode + (((int64_t)b * MPX_NPH + A.phase) * N + i) * 2;
-    pn[0] = fma(gth, tkk, gk * A.inv_dtau);
-    pn[1] = gth;
-  }
+  sPn[0][l] = fma(gth, tkk, gk * A.inv_dtau);
+  sPn[1][l] = gth;
 #pragma unroll
   for (int r = 0; r < NRED; ++r) {
     const double v = wave_sum(own ? gr[r] : 0.0);
     if (lane == 0) sRed[wave][r] = v;
   }
   __syncthreads();
+  // the segment's sums, from its last node down (then node 0 for segment 0: the order the finishing pass used to add the per-node values
+  // in).  Segment 0 is summed by the mini-tile of node 0 -- lanes 0 ... P hold node 0 and the whole segment there --, every other
+  // segment by the regular tile that owns its nodes.
+  if (act && k == P && (T.node0 || s != 0)) {
+    double v0 = 0, v1 = 0;
+#pragma unroll 4
+    for (int kk = 0; kk < P; ++kk) v0 += sPn[0][l - kk], v1 += sPn[1][l - kk];
+    if (T.node0) v0 += sPn[0][0], v1 += sPn[1][0];
+    double* __restrict__ ps = A.pseg + (((int64_t)b * MPX_NPH + A.phase) * A.S + s) * 2;
+    ps[0] = v0, ps[1] = v1;
+  }
   if (l < NRED) {
     double v = 0;
 #pragma unroll
     for (int w = 0; w < MPX_TILE / 64; ++w) v += sRed[w][l];
     A.partial[((int64_t)b * A.n_tiles_total + T.tile_id) * A.nred + l] = v;
   }
+  }  // (evaluation points of the workgroup)
 }
 
 template <int PH>
@@ -2594,34 +2645,57 @@ __device__ __forceinline__ void gradl_finish_phase(const MpxGradlFinArgs& A, int
       gt[1] = red[1] + tg[NX];
       for (int c = 0; c < NA; ++c) gt[2 + c] = red[2 + c] + tg[2 * NX + 2 + c];
     }
-    // first node of segment s >= 1 = last node of segment s - 1: add what the rows of segment s contribute to its columns
+    // first node of segment s >= 1 = last node of segment s - 1: add what the rows of segment s contribute to its columns -- for the
+    // segments whose predecessor's lanes were not in the same workgroup of the node pass (the others were added there)
     const double* __restrict__ hb = A.halo + ((int64_t)b * S * MPX_NPH + (int64_t)PH * S) * (NX + NU);
-    for (int e = l; e < (S - 1) * (NX + NU); e += 256) {
-      const int s = 1 + e / (NX + NU), r = e % (NX + NU);
+    const int h0 = A.halo_off[PH], nh = A.halo_off[PH + 1] - h0;
+    for (int e = l; e < nh * (NX + NU); e += 256) {
+      const int s = A.halo_seg[h0 + e / (NX + NU)], r = e % (NX + NU);
       gb[(int64_t)r * N + A.seg_start[s]] += hb[(int64_t)s * (NX + NU) + r];
     }
   }
   if (A.gp) {
     // grad_gamma_p[s] = (sum of pnode[i][0] over the nodes segment s owns) + (sum of pnode[i][1] over the nodes of all LATER segments):
     // a lane owns a contiguous chunk of segments, chunk totals meet in LDS, every sum runs from the last segment down
-    const double* __restrict__ pn = A.pnode + ((int64_t)b * MPX_NPH + PH) * (int64_t)N * 2;
+    const double* __restrict__ pn = A.pseg + ((int64_t)b * MPX_NPH + PH) * (int64_t)S * 2;
     double* __restrict__ gp = A.gp + (int64_t)b * A.gp_stride + (int64_t)PH * S;
     const int chunk = (S + 255) / 256, s0 = l * chunk < S ? l * chunk : S, s1 = s0 + chunk < S ? s0 + chunk : S;
-    auto seg_sum = [&](int s, int which) {
-      double v = 0;
-      for (int i = A.seg_start[s + 1]; i > A.seg_start[s]; --i) v += pn[(int64_t)i * 2 + which];
-      if (s == 0) v += pn[which];  // node 0 belongs to segment 0
-      return v;
-    };
+    auto seg_sum = [&](int s, int which) { return pn[(int64_t)s * 2 + which]; };  // (formed by the node pass, from the segment's last node down)
+    // (up to 16 segments per lane -- S <= 4096, every BASELINE grid --: the lane's pairs are read ONCE, 16 bytes at a time, and kept in
+    // registers; read value by value in both loops, configs[4] (S = 4000) spent 885 us here on lines fetched eight times over)
+    constexpr int CH = 16;
+    typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
+    const d2a* __restrict__ pn2 = reinterpret_cast<const d2a*>(pn);
+    d2a v[CH];
+    const bool cached = chunk <= CH;
+    if (cached) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] = s0 + j < s1 ? pn2[s0 + j] : d2a{0.0, 0.0};
+    }
     double tot = 0;
-    for (int s = s1 - 1; s >= s0; --s) tot += seg_sum(s, 1);
+    if (cached) {
+#pragma unroll
+      for (int j = CH - 1; j >= 0; --j)
+        if (s0 + j < s1) tot += v[j].y;
+    } else {
+      for (int s = s1 - 1; s >= s0; --s) tot += seg_sum(s, 1);
+    }
     sScan[l] = tot;
     __syncthreads();
     double off = 0;
     for (int q = 255; q > l; --q) off += sScan[q];
-    for (int s = s1 - 1; s >= s0; --s) {
-      gp[s] = seg_sum(s, 0) + off;
-      off += seg_sum(s, 1);
+    if (cached) {
+#pragma unroll
+      for (int j = CH - 1; j >= 0; --j)
+        if (s0 + j < s1) {
+          gp[s0 + j] = v[j].x + off;
+          off += v[j].y;
+        }
+    } else {
+      for (int s = s1 - 1; s >= s0; --s) {
+        gp[s] = seg_sum(s, 0) + off;
+        off += seg_sum(s, 1);
+      }
     }
   }
   __syncthreads();
