@@ -2082,61 +2082,120 @@ __device__ __forceinline__ void resid_body(const MpxResidArgs& A) {
     }
   }
   const int N = A.N;
+  // Degrees from 8 on (round 6): the node values of the workgroup's segments are staged in LDS once per evaluation point.  Every lane of a
+  // segment contracts the SAME P + 1 values per input: read from global memory by each lane itself that is (NX + NU) (P + 1) load instructions
+  // per lane and point -- 93 at degree 30 --, and the pass was bound by them (configs[2]: 0.13 of the HBM peak, profiles/r6_resid).  The span
+  // [first node of the lowest segment, last node of the highest] of the workgroup's points is a fact of the plan; spans that do not fit (plans
+  // with few points per segment) keep the direct loads.  Same values, same fma chains: bit-identical.
+  constexpr int NIN = NX + NU;
+  constexpr bool STAGE = P >= 8;
+  constexpr int ZCAP = STAGE ? (4096 / NIN < 512 ? (4096 / NIN < 64 ? 64 : 4096 / NIN) : 512) : 1;  // (a workgroup of the mid-point grid spans 256 + P nodes)
+  __shared__ double sZ[STAGE ? NIN : 1][ZCAP];
+  __shared__ int sSeg[2];
+  int n0 = 0, span = 0;
+  bool staged = false;
+  if constexpr (STAGE) {
+    if (threadIdx.x == 0) sSeg[0] = 0x7fffffff, sSeg[1] = -1;
+    __syncthreads();
+    if (valid) atomicMin(&sSeg[0], s), atomicMax(&sSeg[1], s);
+    __syncthreads();
+    n0 = A.seg_start[sSeg[0]];
+    span = A.seg_start[sSeg[1] + 1] - n0 + 1;
+    staged = span <= ZCAP;
+  }
+  const int so = st - n0;  // point 0 of the lane's segment in the staged span
+  constexpr int ZQ = (ZCAP + MPX_TILE - 1) / MPX_TILE;
+  double pf[STAGE ? NIN : 1][ZQ];
+  auto fetch = [&](int bb) {
+    const double* __restrict__ zq = A.z + (int64_t)bb * A.z_stride + A.z_off + n0;
+#pragma unroll
+    for (int a = 0; a < (STAGE ? NIN : 0); ++a)
+#pragma unroll
+      for (int q = 0; q < ZQ; ++q) {
+        const int e = (int)threadIdx.x + q * MPX_TILE;
+        pf[a][q] = (zq + (int64_t)a * N)[e < span ? e : span - 1];
+      }
+  };
   const int b0 = blockIdx.y * A.b_per_block;
   const int b1 = (b0 + A.b_per_block < A.B) ? b0 + A.b_per_block : A.B;
   for (int b = b0; b < b1; ++b) {
     const double* __restrict__ zb = A.z + (int64_t)b * A.z_stride + A.z_off;
+    if constexpr (STAGE) {
+      if (staged) {  // (uniform)
+        // the NEXT point's values are requested before this point's contraction starts and written to LDS after it (unconditional, clamped
+        // loads: a guarded prefetch meets its old value in a phi node and is waited for at once; the last point fetches itself again)
+        if (b == b0) fetch(b0);
+        __syncthreads();  // the previous point's contractions are done with the buffer
+#pragma unroll
+        for (int a = 0; a < NIN; ++a)
+#pragma unroll
+          for (int q = 0; q < ZQ; ++q)
+            if ((int)threadIdx.x + q * MPX_TILE < span) sZ[a][threadIdx.x + q * MPX_TILE] = pf[a][q];
+        __syncthreads();
+        fetch(b + 1 < b1 ? b + 1 : b);
+      }
+    }
     Vec<NX> Xi, DXi, fx, res;
     Vec<NU> Ui, DUi;
     Vec<NA> As;
     Vec<NC> cc;
-    if constexpr (ROWS_REG) {
+    // (the staged and the direct form as two instantiations under one uniform branch: with a select per value the compiler kept both
+    // address streams alive through the unrolled chains -- 512 registers and scratch at degree 30)
+    auto contract = [&](auto from_lds) {
+      constexpr bool LDS = decltype(from_lds)::value;
+      auto zval = [&](int a, int j) {
+        if constexpr (LDS) return sZ[STAGE ? a : 0][so + j];
+        else return (zb + (int64_t)a * N)[st + j];
+      };
+      // (degrees 8 ... 32, spans that do not fit the buffer -- rare: plans with a few points per segment --: the rows are read inside a
+      // partially unrolled loop, as above degree 32; fully unrolled with 64-bit addresses per value, that form set the kernel's register count)
+      if constexpr (ROWS_REG && (LDS || !STAGE)) {
+        // (j outermost: 2 (NX + NU) independent chains advance together and a step needs NX + NU values, where the input-by-input order
+        // ran two chains at a time behind P + 1 loads each -- the same chains, term by term)
 #pragma unroll
-    for (int a = 0; a < NX; ++a) {
-      double v = 0, d = 0;
+        for (int a = 0; a < NX; ++a) Xi[a] = 0, DXi[a] = 0;
 #pragma unroll
-      for (int j = 0; j < P1; ++j) {
-        const double x = (zb + (int64_t)a * N)[st + j];
-        v = fma(Crow[j], x, v);
-        d = fma(Drow[j], x, d);
-      }
-      Xi[a] = v;
-      DXi[a] = d;
-    }
+        for (int c = 0; c < NU; ++c) Ui[c] = 0, DUi[c] = 0;
 #pragma unroll
-    for (int c = 0; c < NU; ++c) {
-      double v = 0, d = 0;
+        for (int j = 0; j < P1; ++j) {
 #pragma unroll
-      for (int j = 0; j < P1; ++j) {
-        const double x = (zb + (int64_t)(NX + c) * N)[st + j];
-        v = fma(Crow[j], x, v);
-        d = fma(Drow[j], x, d);
-      }
-      Ui[c] = v;
-      DUi[c] = d;
-    }
-    } else {
+          for (int a = 0; a < NX; ++a) {
+            const double x = zval(a, j);
+            Xi[a] = fma(Crow[j], x, Xi[a]);
+            DXi[a] = fma(Drow[j], x, DXi[a]);
+          }
 #pragma unroll
-      for (int a = 0; a < NX; ++a) Xi[a] = 0, DXi[a] = 0;
+          for (int c = 0; c < NU; ++c) {
+            const double x = zval(NX + c, j);
+            Ui[c] = fma(Crow[j], x, Ui[c]);
+            DUi[c] = fma(Drow[j], x, DUi[c]);
+          }
+        }
+      } else {
 #pragma unroll
-      for (int c = 0; c < NU; ++c) Ui[c] = 0, DUi[c] = 0;
+        for (int a = 0; a < NX; ++a) Xi[a] = 0, DXi[a] = 0;
+#pragma unroll
+        for (int c = 0; c < NU; ++c) Ui[c] = 0, DUi[c] = 0;
 #pragma unroll 4
-      for (int j = 0; j < P1; ++j) {
-        const double cj = A.Cmat[(int64_t)j * A.n + m], dj = A.Dmat[(int64_t)j * A.n + m];
+        for (int j = 0; j < P1; ++j) {
+          const double cj = A.Cmat[(int64_t)j * A.n + m], dj = A.Dmat[(int64_t)j * A.n + m];
 #pragma unroll
-        for (int a = 0; a < NX; ++a) {
-          const double x = (zb + (int64_t)a * N)[st + j];
-          Xi[a] = fma(cj, x, Xi[a]);
-          DXi[a] = fma(dj, x, DXi[a]);
-        }
+          for (int a = 0; a < NX; ++a) {
+            const double x = zval(a, j);
+            Xi[a] = fma(cj, x, Xi[a]);
+            DXi[a] = fma(dj, x, DXi[a]);
+          }
 #pragma unroll
-        for (int c = 0; c < NU; ++c) {
-          const double x = (zb + (int64_t)(NX + c) * N)[st + j];
-          Ui[c] = fma(cj, x, Ui[c]);
-          DUi[c] = fma(dj, x, DUi[c]);
+          for (int c = 0; c < NU; ++c) {
+            const double x = zval(NX + c, j);
+            Ui[c] = fma(cj, x, Ui[c]);
+            DUi[c] = fma(dj, x, DUi[c]);
+          }
         }
       }
-    }
+    };
+    if (STAGE && staged) contract(std::true_type{});
+    else contract(std::false_type{});
     const double* __restrict__ zt = zb + (int64_t)(NX + NU) * N;
     const double t0v = zt[0], tfv = zt[1];
 #pragma unroll

@@ -147,3 +147,42 @@ def test_gpu_residuals_full_size_batch():
         ro = O.residuals(Z[b], p, 0, mids)
         for k in FIELDS:
             assert rel_err(np.asarray(r2[k][b]).ravel(), ro[k].ravel()) < TOL, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("builder,S,po,scheme", [(problems.van_der_pol, 60, 13, "LGR"), (problems.kitchen_sink, 24, [8, 21, 30, 9] * 6, "LGL"),
+                                                 (problems.dae_vdp, 40, [3, 30, 3, 3, 30] * 8, "CGL")])
+def test_gpu_residuals_with_the_segments_staged_in_lds_and_without(builder, S, po, scheme):
+    """Round 6: from degree 8 on mpx_resid_<ph>_<deg> stages the node values of a workgroup's segments in LDS once per evaluation point (the next
+    point's values requested before the current contraction) -- when the span of the workgroup's points fits the buffer.  Plans with many points
+    per segment (staged), with one point per segment over many segments (span too long: the direct loads) and with empty segments in between,
+    single evaluations and a batch of 37 (16 points per workgroup in a row): against the numpy oracle, batch against single bit for bit."""
+    ocp = builder(mp, M.math)
+    orders = [po] * S if isinstance(po, int) else po
+    mpo = mp.mpopt(ocp, S, orders, scheme)
+    o = mpo.create_nlp()[0]["oracle"]
+    O = OracleNLP(ocp, S, orders, scheme)
+    rng = np.random.default_rng(12)
+    z0 = mpo.initialize_solution()
+    Z = z0[None, :] + 0.05 * np.abs(z0)[None, :] * rng.uniform(-1, 1, (37, o.n_z)) + 0.05 * rng.uniform(-1, 1, (37, o.n_z))
+    w = rng.uniform(0.5, 1.5, (ocp.n_phases, S))
+    p = (w / w.sum(axis=1, keepdims=True)).ravel()
+    plans = {"many points per segment": [np.sort(rng.uniform(-1, 1, 17 + s % 5)) for s in range(S)],
+             "one point per segment": [rng.uniform(-1, 1, 1) for s in range(S)],
+             "every third segment": [np.sort(rng.uniform(-1, 1, 9)) if s % 3 == 0 else np.zeros(0) for s in range(S)]}
+    for ph in range(ocp.n_phases):
+        for label, taus in plans.items():
+            plan = o.residual_plan(ph, taus)
+            rb = plan.eval(Z, p)
+            for b in (0, 36):
+                r1 = plan.eval(Z[b], p)
+                ref = O.residuals(Z[b], p, ph, taus)
+                for key in ("ti", "xi", "ui", "dxi", "dui", "dyn", "resid"):
+                    if key not in r1:
+                        continue
+                    assert np.array_equal(r1[key], rb[key][b]), (label, key, b)
+                    want = np.asarray(ref[key], dtype=float).reshape(plan.n_pts, -1)
+                    got = np.asarray(r1[key]).reshape(plan.n_pts, -1)
+                    assert np.abs(got - want).max() < 1e-10 * max(1.0, np.abs(want).max()), (label, key, b)
+            plan.close()
+    o.close()
