@@ -1,6 +1,6 @@
 """Every degree 32 ... 255 once (round 6): a two-segment moon lander / Van der Pol grid per degree, scheme cycling, a ragged batch of 19 -- the
 light passes through the matrix-core kernels (mpx_lighthigh_*) against the same calls through the node kernels (MPX_NO_LIGHT=1: g and the node
-entries of grad_f bit for bit, f and the (t0, tf) sums to rounding), and f, g, grad_f, jac_g, hess_l and nlp_grad's two outputs against the numpy oracle (tables in 50-digit
+entries of grad_f bit for bit, f and the (t0, tf) sums to rounding), and f, g, grad_f, jac_g, hess_l, nlp_grad's two outputs and the off-node residuals of three plans against the numpy oracle (tables in 50-digit
 arithmetic) at 1e-10.  The suite's high-degree cases pick 12 degrees; this runs all 224 (tile tails of every residue of P + 1 mod 16 and mod 4).  Degrees 1 ... 31: a
 single-degree grid of 40 segments and a mixed one in the pattern of BASELINE configs[2] per degree (mpx_lightlow_* / mpx_light_*).
     python tools/r6_degree_sweep.py compile LO HI      (no GPU: fills the in-tree kernel cache)
@@ -93,6 +93,23 @@ def main():
             e = max(e, np.abs(q["grad_gamma_x"] - gx).max() / max(1, np.abs(gx).max()), np.abs(q["grad_gamma_p"] - gp).max() / max(1, np.abs(gp).max()))
             assert e < 1e-10, (P, e)
             worst = max(worst, e)
+        # off-node residuals (mpx_resid_*: staged in LDS from degree 8 on where the span fits): a dense plan, a one-point-per-segment plan and a
+        # plan with empty segments, single evaluation and the batch's point 18, against the numpy oracle
+        for taus in ([np.sort(rng.uniform(-1, 1, 11 + sgi % 4)) for sgi in range(S)], [rng.uniform(-1, 1, 1) for _ in range(S)],
+                     [np.sort(rng.uniform(-1, 1, 7)) if sgi % 2 == 0 else np.zeros(0) for sgi in range(S)]):
+            plan = o.residual_plan(0, taus)
+            rb = plan.eval(Z, p)
+            for bb in (0, 18):
+                r1 = plan.eval(Z[bb], p)
+                ref = O.residuals(Z[bb], p, 0, taus)
+                for key in ("xi", "ui", "dxi", "dyn", "resid"):
+                    assert np.array_equal(r1[key], rb[key][bb]), (P, key)
+                    want = np.asarray(ref[key], dtype=float).reshape(plan.n_pts, -1)
+                    er = np.abs(np.asarray(r1[key]).reshape(plan.n_pts, -1) - want).max() / max(1.0, np.abs(want).max())
+                    assert er < 1e-10, (P, key, er)
+                    e = max(e, er)
+            plan.close()
+        worst = max(worst, e)
         o.close()
         print(P, S, scheme, builder.__name__, "light" if has_light else "no light plan", "ok", f"{e:.1e}", flush=True)
     if what == "run":
